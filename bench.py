@@ -1,0 +1,256 @@
+#!/usr/bin/env python3
+"""bench.py -- phase-2 candidate-verification throughput on MI355X (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): RSM-ED phase 2, synthetic data-{n} with n = 1e8 (seeded restatement of
+K/DataGenerator.java), query length m = 8192 drawn from the series, 1e6 candidate start offsets per GPU in
+phase-1-shaped intervals (sorted, disjoint, geometric lengths, mean 64).  A "step" is one full phase-2 pass over
+the candidate list: intervals in host memory -> sorted answers in host memory (the reference's T_2 window,
+K/QueryEngine.java:339-365), the series already resident in HBM (staged once, like the reference's data file).
+The headline runs with early abandoning OFF, i.e. every candidate is evaluated over all m points: that is the
+only mode whose work is data-independent (with abandoning on, random candidates die after ~12 points and the
+number measures launch overhead; it is reported separately as value_early_abandon).
+
+Multi-GPU: weak scaling -- every rank verifies its own contiguous shard of 1e6 candidates of a world*1e6 list
+(series replicated), then ONE all-gather (RCCL) of the surviving (offset, distance) pairs.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "kv-match_amd"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+import kvmatch  # noqa: E402
+from kvmatch import datagen, distributed  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
+FP64_VALU_PEAK_TFLOPS = 78.6  # vendor vector fp64 peak, FMA = 2 flop
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n", type=int, default=100_000_000)
+    ap.add_argument("--m", type=int, default=8192)
+    ap.add_argument("--candidates", type=int, default=1_000_000, help="candidate offsets per GPU")
+    ap.add_argument("--epsilon", type=float, default=10.0)
+    ap.add_argument("--extras", type=int, default=1, help="also measure cNSM-ED / cNSM-DTW (N=1 only)")
+    ap.add_argument("--cpu-baseline", type=int, default=1)
+    ap.add_argument("--ed-kernel", type=int, default=0)
+    return ap.parse_args()
+
+
+def timed_steps(fn, steps, warmup, world):
+    for _ in range(warmup):
+        fn()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    n, m = a.n, a.m
+
+    # ---- inputs: every rank builds the same series (replicated), deterministic from the seed ------------
+    t0 = time.perf_counter()
+    series = datagen.gen_series(n)
+    qoff = n // 3 + 17
+    planted = [n // 7, n // 2 + 1000, n - 3 * m]
+    q = datagen.plant_copies(series, qoff, m, planted, [1.0, 1.0, 1.0], [0.0, 0.02, -0.03], 0.01)
+    left, right = datagen.gen_intervals(n, m, a.candidates * world, 64.0, must_cover=[qoff] + planted, seed=1)
+    my_l, my_r = distributed.split_intervals(left, right, world, rank)
+    my_cands = int((my_r.astype(np.int64) - my_l + 1).sum())
+    ctx = kvmatch.Phase2Context(local_rank)
+    ctx.load_series(series)
+    ctx.set_option(kvmatch.OPT_TIMING, 1)
+    ctx.set_option(kvmatch.OPT_ED_KERNEL, a.ed_kernel)
+    setup_s = time.perf_counter() - t0
+
+    eng = kvmatch.QueryEngine(ctx)
+    lib, h = ctx._lib, ctx._h
+    kernel_ns = []
+    last = {}
+
+    def step():
+        ans = eng.verify((my_l, my_r), 1, q, a.epsilon)
+        kernel_ns.append(int(lib.kvm_last_kernel_ns(h)))
+        if world > 1:
+            offs, dists = distributed.gather_answers(ans.offsets, ans.distances, device=f"cuda:{local_rank}")
+        else:
+            offs, dists = ans.offsets, ans.distances
+        last["offs"], last["dists"], last["ans"] = offs, dists, ans
+
+    # ---- headline: early abandon off ---------------------------------------------------------------------
+    ctx.set_option(kvmatch.OPT_EARLY_ABANDON, 0)
+    step()  # first call allocates scratch
+    kernel_ns.clear()
+    dt = timed_steps(step, a.steps, a.warmup, world)
+    k_ns = kernel_ns[-a.steps:]
+    total_cands = my_cands
+    if world > 1:
+        t = torch.tensor([my_cands], dtype=torch.int64, device="cuda")
+        dist.all_reduce(t)
+        total_cands = int(t.item())
+    value = total_cands * a.steps / dt
+    head_offs, head_dists = last["offs"].copy(), last["dists"].copy()
+    windows = last["ans"].stats[kvmatch.STAT_WINDOWS]
+    avg_kernel_s = float(np.mean(k_ns)) * 1e-9
+    algo_bytes = windows * 8.0 * m  # 8*m algorithmic bytes per candidate
+    achieved = algo_bytes / avg_kernel_s / 1e9 if avg_kernel_s > 0 else 0.0
+
+    # ---- same workload with the reference's early abandoning on (reported, not the headline) -------------
+    ctx.set_option(kvmatch.OPT_EARLY_ABANDON, 1)
+    dt_ab = timed_steps(step, max(3, a.steps // 2), 1, world)
+    value_ab = total_cands * max(3, a.steps // 2) / dt_ab
+    ab_match = bool(np.array_equal(head_offs, last["offs"]))
+
+    out = {
+        "metric": "candidate subsequences verified/sec (RSM-ED, n=1e8, m=8192)",
+        "value": value,
+        "unit": "candidates/s",
+        "n_gpus": world,
+        "steps": a.steps,
+        "warmup": a.warmup,
+        "ms_per_step": dt / a.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic (seeded restatement of K/DataGenerator.java; query + 3 noisy copies planted)",
+        "config": {"workload": "RSM-ED phase 2 (BASELINE configs[1])", "n": n, "m": m,
+                   "candidates_per_gpu": my_cands, "intervals_per_gpu": int(len(my_l)), "epsilon": a.epsilon,
+                   "early_abandon": False, "parallelism": f"candidate shards x{world}, series replicated",
+                   "answers": int(len(head_offs)), "ed_kernel": a.ed_kernel},
+        "value_early_abandon": value_ab,
+        "early_abandon_same_answers": ab_match,
+        "setup_s": setup_s,
+    }
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "ed_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                       "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                       "kernel": "kvm_ed kernel (RSM-ED)", "kernel_ms": avg_kernel_s * 1e3,
+                       "algorithmic_bytes_per_launch": algo_bytes,
+                       "fp64_valu_tflops": windows * m * 3.0 / avg_kernel_s / 1e12 if avg_kernel_s > 0 else 0.0,
+                       "fp64_valu_peak_tflops": FP64_VALU_PEAK_TFLOPS}
+
+    # ---- CPU baseline: the oracle (a C port of the reference loops), rank 0, N=1 only --------------------
+    if rank == 0 and world == 1 and a.cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import oracle  # test infrastructure: used here only as the timed CPU baseline / checker
+        t1 = time.perf_counter()
+        o_off, o_dist, o_st = oracle.rsm_ed(series, q, my_l, my_r, 0, a.epsilon, no_abandon=True)
+        cpu_s = time.perf_counter() - t1
+        t1 = time.perf_counter()
+        oracle.rsm_ed(series, q, my_l, my_r, 0, a.epsilon, no_abandon=False)
+        cpu_ab_s = time.perf_counter() - t1
+        out["cpu_baseline"] = {
+            "value": o_st["windows"] / cpu_s, "unit": "candidates/s", "cores": 1, "kind": "port",
+            "sample": f"all {o_st['windows']} candidates of the N=1 workload, early abandon off (same work as "
+                      f"`value`), single thread; C restatement of K/QueryEngine.java:338-363 (no JDK on the box, "
+                      f"avoids Java boxing so it flatters the CPU side)",
+            "value_early_abandon": o_st["windows"] / cpu_ab_s,
+            "seconds": cpu_s,
+        }
+        same = sorted(o_off.tolist()) == sorted(head_offs.tolist())
+        od = dict(zip(o_off.tolist(), o_dist.tolist()))
+        close = same and all(abs(d - od[o]) <= max(1e-6 * max(d, od[o]), 1e-9)
+                             for o, d in zip(head_offs.tolist(), head_dists.tolist()))
+        out["parity_vs_oracle"] = bool(same and close)
+
+    # ---- extras (N=1): the other variants on the same staged series ---------------------------------------
+    if rank == 0 and world == 1 and a.extras:
+        ex = {}
+        try:
+            ctx.set_option(kvmatch.OPT_EARLY_ABANDON, 0)
+            neng = kvmatch.NormQueryEngine(ctx)
+            f = lambda: neng.verify((my_l, my_r), 1, q, a.epsilon, 2.0, 1e9)  # noqa: E731 (filter passes all)
+            f()
+            t1 = time.perf_counter()
+            for _ in range(5):
+                r_ = f()
+            ex["cnsm_ed_no_abandon_candidates_per_s"] = my_cands * 5 / (time.perf_counter() - t1)
+            ex["cnsm_ed_pass_filter"] = r_.stats[kvmatch.STAT_PASS_FILTER]
+            ctx.set_option(kvmatch.OPT_EARLY_ABANDON, 1)
+            # cNSM-DTW, BASELINE configs[3]: m=4096, rho=5%
+            m2 = 4096
+            q2 = series[qoff - 1: qoff - 1 + m2].copy()
+            l2, r2 = datagen.gen_intervals(n, m2, a.candidates, 64.0, must_cover=[qoff], seed=2)
+            deng = kvmatch.NormQueryEngineDtw(ctx)
+            g = lambda: deng.verify((l2, r2), 1, q2, 10.0, 0.05, 2.0, 10.0)  # noqa: E731
+            g()
+            t1 = time.perf_counter()
+            reps = 3
+            for _ in range(reps):
+                r_ = g()
+            ex["cnsm_dtw_m4096_candidates_per_s"] = r_.cnt_candidate * reps / (time.perf_counter() - t1)
+            ex["cnsm_dtw_stats"] = {"windows": r_.stats[0], "pass_filter": r_.stats[1], "pass_kim": r_.stats[2],
+                                    "pass_keogh": r_.stats[3], "dp": r_.stats[4], "answers": len(r_)}
+            # DP kernel alone: cascade off on a small slice => every filter-passing window runs the full DP
+            ctx.set_option(kvmatch.OPT_LB_CASCADE, 0)
+            ctx.set_option(kvmatch.OPT_EARLY_ABANDON, 0)
+            l3, r3 = l2[:64], r2[:64]
+            g3 = lambda: deng.verify((l3, r3), 1, q2, 10.0, 0.05, 1e9, 1e9)  # noqa: E731
+            g3()
+            t1 = time.perf_counter()
+            r_ = g3()
+            dtp = time.perf_counter() - t1
+            rho = 204
+            cells = m2 * (2 * rho + 1) - rho * (rho + 1)
+            ex["dtw_dp_full_candidates_per_s"] = r_.stats[0] / dtp
+            ex["dtw_dp_cells_per_s"] = r_.stats[0] * cells / dtp
+            ex["dtw_dp_kernel_ms"] = lib.kvm_last_kernel_ns(h) * 1e-6
+            ctx.set_option(kvmatch.OPT_LB_CASCADE, 1)
+            ctx.set_option(kvmatch.OPT_EARLY_ABANDON, 1)
+        except Exception as e:  # extras must never take the headline down
+            ex["error"] = repr(e)
+        out["extras"] = ex
+
+    ctx.close()
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,175 @@
+/*
+ * kvmatch.h -- C ABI of the MI355X-native phase-2 ("post-processing") candidate verifier for
+ * KV-match.  This is the drop-in boundary: the four inline phase-2 blocks of the reference's
+ * query engines are replaced by one call each.  A JNI shim (kv-match_amd/jni/) or any other FFI
+ * binds exactly these symbols; INTEGRATION.md shows the reference-side binding.
+ *
+ * Reference paths are relative to src/main/java/cn/edu/fudan/dsm/kvmatch/ (abbreviated K/).
+ *
+ * Conventions shared with the reference:
+ *   - series offsets are 1-based int32 (K/operator/file/TimeSeriesFileOperator.java:54-57);
+ *   - all values are IEEE-754 binary64;
+ *   - `left[i], right[i]` are the `validPositions` intervals handed over by phase 1, sorted,
+ *     disjoint and non-adjacent (result of sortAndMergeIntervals, K/QueryEngine.java:664-693);
+ *     only getLeft()/getRight() are read by phase 2;
+ *   - `shift` = (lastSegment - 1) * WuList[0]  (K/QueryEngine.java:346; WuList[0] = 25);
+ *   - candidate window start offsets of interval i are
+ *         max(1, left[i]-shift) .. min(right[i]-shift, n-m+1)      (K/QueryEngine.java:346-354);
+ *   - cntCandidate = sum(right[i]-left[i]+1), counted before clipping (K/QueryEngine.java:344);
+ *   - answers are (offset, sqrt(distance^2)) sorted by distance, ties in ascending offset
+ *     (stable sort of an offset-ascending list, K/QueryEngine.java:373).
+ *
+ * Threading: one kvm_ctx per engine instance; calls on one ctx must be serialised by the caller
+ * (the reference engines are not re-entrant either).  A ctx owns one HIP stream on one device.
+ * Multi-GPU = one process (or at least one ctx) per GPU; see kv-match_amd/kvmatch/distributed.py.
+ *
+ * Every function returns KVM_OK (0) or a negative status; kvm_last_error() gives the message.
+ * The library never falls back to a CPU path: without a usable HIP device kvm_open fails.
+ */
+#ifndef KVMATCH_H
+#define KVMATCH_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KVM_OK 0
+#define KVM_ERR_INVALID_HANDLE (-1)
+/* maps to java.lang.IllegalArgumentException (K/operator/file/TimeSeriesFileOperator.java:55-57;
+ * parameter validation of K/NormQueryEngineDtw.java:112-162) */
+#define KVM_ERR_ILLEGAL_ARGUMENT (-2)
+/* maps to java.io.IOException (propagates out of query(), K/QueryEngine.java:155) */
+#define KVM_ERR_IO (-3)
+#define KVM_ERR_DEVICE (-5)        /* HIP runtime failure (also -> IOException in the shim) */
+#define KVM_ERR_NO_SERIES (-6)     /* verify called before a series was loaded */
+#define KVM_ERR_UNSUPPORTED (-7)   /* parameter outside what the kernels are built for */
+
+typedef struct kvm_ctx kvm_ctx;
+typedef struct kvm_result kvm_result;
+
+/* ---- lifecycle ------------------------------------------------------------------------------ */
+
+/* Replaces nothing in the reference (there is no device layer); the analogue is the engine
+ * constructor QueryEngine(int n, String storageType) (K/QueryEngine.java:70).  `device` is the HIP
+ * device ordinal as seen by this process. */
+int kvm_open(int device, kvm_ctx **ctx);
+int kvm_close(kvm_ctx *ctx);
+const char *kvm_last_error(const kvm_ctx *ctx); /* ctx may be NULL: returns the last open() error */
+const char *kvm_version(void);
+
+/* ---- series staging: TimeSeriesOperator (K/operator/TimeSeriesOperator.java:29-54) ------------- */
+
+/* Stage a native-endian fp64 host array of n values into HBM (once) and build the
+ * block-restarted prefix sums of x and x^2 used for per-window mean/std.  Replaces the
+ * per-interval readTimeSeries(begin, len) of K/QueryEngine.java:352 (cf. the "whole series in
+ * memory" precedent K/operator/memory/TimeSeriesMemoryOperator.java:41-66). */
+int kvm_load_series_f64(kvm_ctx *ctx, const double *host_values, int64_t n);
+
+/* Same, from the reference's on-disk/wire encoding: n big-endian fp64 values
+ * (K/common/entity/TimeSeriesNode.java:38-52, K/DataGenerator.java:111).  The byte swap runs on the GPU. */
+int kvm_load_series_be64(kvm_ctx *ctx, const void *be_bytes, int64_t n);
+
+/* Same, reading files/data-{N} (K/operator/file/TimeSeriesFileOperator.java:50-52). */
+int kvm_load_series_file(kvm_ctx *ctx, const char *path, int64_t n);
+
+/* Borrow an fp64 array already resident in this device's memory (e.g. a torch tensor's
+ * data_ptr()).  The caller keeps it alive until kvm_close or the next load. */
+int kvm_attach_series_device(kvm_ctx *ctx, const double *device_values, int64_t n);
+
+int64_t kvm_series_length(const kvm_ctx *ctx);
+
+/* TimeSeriesOperator.readTimeSeries(left, length) served from HBM
+ * (K/operator/TimeSeriesOperator.java:38; same range check and error as
+ * K/operator/file/TimeSeriesFileOperator.java:55-57).  `out` receives `length` host doubles. */
+int kvm_read_time_series(kvm_ctx *ctx, int32_t left, int32_t length, double *out);
+
+/* ---- phase 2: the four verification entry points ------------------------------------------------ */
+
+/* RSM-ED.  Replaces K/QueryEngine.java:338-363 (+ sort :373). */
+int kvm_verify_rsm_ed(kvm_ctx *ctx, const double *query, int32_t m, const int32_t *left, const int32_t *right,
+                      int32_t k, int32_t shift, double epsilon, kvm_result **result);
+
+/* cNSM-ED.  Replaces K/NormQueryEngine.java:432-528; meanQ/stdQ are recomputed from `query` exactly
+ * as K/NormQueryEngine.java:192-198 does. */
+int kvm_verify_cnsm_ed(kvm_ctx *ctx, const double *query, int32_t m, const int32_t *left, const int32_t *right,
+                       int32_t k, int32_t shift, double epsilon, double alpha, double beta, kvm_result **result);
+
+/* RSM-DTW.  Replaces K/QueryEngineDtw.java:349-452.  `rho` is the resolved Sakoe-Chiba half-width
+ * (see kvm_resolve_rho). */
+int kvm_verify_rsm_dtw(kvm_ctx *ctx, const double *query, int32_t m, const int32_t *left, const int32_t *right,
+                       int32_t k, int32_t shift, double epsilon, int32_t rho, kvm_result **result);
+
+/* cNSM-DTW.  Replaces K/NormQueryEngineDtw.java:457-603. */
+int kvm_verify_cnsm_dtw(kvm_ctx *ctx, const double *query, int32_t m, const int32_t *left, const int32_t *right,
+                        int32_t k, int32_t shift, double epsilon, int32_t rho, double alpha, double beta,
+                        kvm_result **result);
+
+/* `r <= 1 -> floor(r*m) else floor(r)`  (K/QueryEngineDtw.java:135-140). */
+int32_t kvm_resolve_rho(double r, int32_t m);
+
+/* ---- results: List<Pair<Integer, Double>> answers + statistics[2..4] ---------------------------- */
+
+int64_t kvm_result_count(const kvm_result *r);        /* answers.size()   -> statistics[4] (K/QueryEngine.java:370) */
+int64_t kvm_result_candidates(const kvm_result *r);   /* cntCandidate     -> statistics[3] (K/QueryEngine.java:369) */
+double kvm_result_elapsed_ms(const kvm_result *r);    /* T_2 wall ms      -> statistics[2] (K/QueryEngine.java:368) */
+const int32_t *kvm_result_offsets(const kvm_result *r);   /* Pair.getFirst(), sorted by distance */
+const double *kvm_result_distances(const kvm_result *r);  /* Pair.getSecond() */
+/* Work counters (no reference counterpart; for measurement): see KVM_STAT_* */
+int64_t kvm_result_stat(const kvm_result *r, int32_t which);
+void kvm_result_free(kvm_result *r);
+
+#define KVM_STAT_WINDOWS 0       /* candidate windows actually evaluated (after clipping) */
+#define KVM_STAT_PASS_FILTER 1   /* passed the (alpha, beta) filter (cNSM) */
+#define KVM_STAT_PASS_LB_KIM 2   /* passed LB_Kim (DTW) */
+#define KVM_STAT_PASS_LB_KEOGH 3 /* passed LB_Keogh, query envelope (DTW) */
+#define KVM_STAT_PASS_LB_KEOGH2 4 /* passed LB_Keogh, data envelope = DP launched (DTW) */
+#define KVM_STAT_KERNEL_NS 5     /* device time of the dominant kernel(s), ns (HIP events) */
+#define KVM_STAT_RECHECKED 6     /* knife-edge candidates re-evaluated in reference order */
+#define KVM_STAT_COUNT 7
+
+/* ---- knobs (measurement only; defaults reproduce the reference's behaviour) ---------------------- */
+
+#define KVM_OPT_EARLY_ABANDON 1  /* 1 (default): stop a distance once it exceeds eps^2, as the
+                                    reference does; 0: evaluate every candidate over all m points */
+#define KVM_OPT_LB_CASCADE 2     /* 1 (default): LB_Kim/LB_Keogh cascade before the DTW DP; 0: DP on
+                                    every filter-passing candidate */
+#define KVM_OPT_ED_KERNEL 3      /* 0 auto (default), 1 wave-per-candidate, 2 LDS-tiled */
+#define KVM_OPT_TIMING 4         /* 1: record HIP-event kernel times into KVM_STAT_KERNEL_NS */
+int kvm_set_option(kvm_ctx *ctx, int32_t option, int64_t value);
+int64_t kvm_get_option(const kvm_ctx *ctx, int32_t option);
+/* Device time (ns, HIP events on the launch stream) of the verification kernels of the most recent
+ * kvm_verify_* / kvm_verify_device call on this ctx; 0 unless KVM_OPT_TIMING is set. */
+int64_t kvm_last_kernel_ns(const kvm_ctx *ctx);
+
+/* ---- device-resident variant (multi-GPU host plumbing: no host copies, caller's stream) ----------- */
+
+/* Same computation as kvm_verify_*, but survivors stay in device memory so that the host layer can
+ * hand them to one RCCL all-gather.  `variant`: 0 rsm_ed, 1 cnsm_ed, 2 rsm_dtw,
+ * 3 cnsm_dtw.  d_out_off / d_out_dist are device buffers of `cap` entries, d_out_count a device
+ * int64.  Unsorted.  `stream` is a hipStream_t (NULL = the ctx stream). */
+int kvm_verify_device(kvm_ctx *ctx, int32_t variant, const double *query, int32_t m, const int32_t *left,
+                      const int32_t *right, int32_t k, int32_t shift, double epsilon, int32_t rho, double alpha,
+                      double beta, int32_t *d_out_off, double *d_out_dist, int64_t cap, int64_t *d_out_count,
+                      int64_t *cnt_candidate, void *stream);
+
+/* ---- synthetic inputs: seeded restatement of K/DataGenerator.java:80-119 ------------------------ */
+
+/* Fills out[0..n) with the reference generator's distribution (random-walk / Gaussian / mixed-sine
+ * segments), deterministically from `seed`.  Host-side; used by tests and bench.py. */
+int kvm_gen_series(uint64_t seed, int64_t n, double *out);
+
+/* Seeded phase-1-shaped interval list (sorted, disjoint, non-adjacent, geometric lengths, total
+ * about `target_candidates`), always covering `must_cover[0..n_must)`.  Returns the number of
+ * intervals written (<= cap) or a negative status. */
+int64_t kvm_gen_intervals(uint64_t seed, int64_t n, int32_t m, int64_t target_candidates, double mean_len,
+                          const int32_t *must_cover, int32_t n_must, int32_t *left, int32_t *right, int64_t cap);
+
+/* Write / read files/data-{N} in the reference's format (flat big-endian fp64). */
+int kvm_write_series_file(const char *path, const double *values, int64_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KVMATCH_H */

@@ -1,0 +1,597 @@
+// kvm_api.hip -- the C ABI of include/kvmatch.h: context, series staging, the four phase-2 entry
+// points and result objects.  Host orchestration only; every distance is computed by the HIP kernels in
+// kvm_ed*.hip / kvm_dtw*.hip.  There is deliberately no CPU fallback: every entry point fails with
+// KVM_ERR_DEVICE when HIP is unusable.
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <deque>
+#include <numeric>
+
+#include "kvm_internal.h"
+
+#define KVM_MAX_SCAN_DATA_LENGTH 40000  // K/NormQueryEngine.java:60, K/NormQueryEngineDtw.java:61
+#define KVM_TILE_MAX 64                 // candidates per tile (== ED_TILE_MAX in kvm_ed.hip)
+
+static thread_local std::string g_open_err;
+
+static int fail(kvm_ctx *ctx, int code, const std::string &msg) {
+    if (ctx) ctx->err = msg; else g_open_err = msg;
+    return code;
+}
+
+#define HIPCHK(ctx, call)                                                                            \
+    do {                                                                                             \
+        hipError_t e_ = (call);                                                                      \
+        if (e_ != hipSuccess)                                                                        \
+            return fail(ctx, KVM_ERR_DEVICE, std::string(#call) + ": " + hipGetErrorString(e_));     \
+    } while (0)
+
+static int ensure(kvm_ctx *ctx, kvm_dev_buf &b, size_t bytes) {
+    if (bytes <= b.cap) return KVM_OK;
+    if (b.p) HIPCHK(ctx, hipFree(b.p));
+    b.p = nullptr;
+    b.cap = 0;
+    size_t want = bytes + bytes / 4 + 4096;
+    HIPCHK(ctx, hipMalloc(&b.p, want));
+    b.cap = want;
+    return KVM_OK;
+}
+
+static int ensure_pinned(kvm_ctx *ctx, size_t bytes) {
+    if (bytes <= ctx->h_pinned_cap) return KVM_OK;
+    if (ctx->h_pinned) HIPCHK(ctx, hipHostFree(ctx->h_pinned));
+    ctx->h_pinned = nullptr;
+    ctx->h_pinned_cap = 0;
+    size_t want = bytes + bytes / 4 + 4096;
+    HIPCHK(ctx, hipHostMalloc(&ctx->h_pinned, want, hipHostMallocDefault));
+    ctx->h_pinned_cap = want;
+    return KVM_OK;
+}
+
+extern "C" const char *kvm_version(void) { return "kvmatch-hip 0.1 (gfx950)"; }
+
+extern "C" const char *kvm_last_error(const kvm_ctx *ctx) { return ctx ? ctx->err.c_str() : g_open_err.c_str(); }
+
+extern "C" int kvm_open(int device, kvm_ctx **out) {
+    if (!out) return fail(nullptr, KVM_ERR_ILLEGAL_ARGUMENT, "kvm_open: null out pointer");
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(nullptr, KVM_ERR_DEVICE,
+                    std::string("kvm_open: no usable HIP device (") + hipGetErrorString(e) +
+                        "); this library has no CPU fallback");
+    if (device < 0 || device >= ndev)
+        return fail(nullptr, KVM_ERR_ILLEGAL_ARGUMENT, "kvm_open: device ordinal out of range");
+    kvm_ctx *ctx = new kvm_ctx();
+    ctx->device = device;
+    if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreate(&ctx->stream)) != hipSuccess ||
+        (e = hipEventCreate(&ctx->ev0)) != hipSuccess || (e = hipEventCreate(&ctx->ev1)) != hipSuccess) {
+        std::string msg = std::string("kvm_open: ") + hipGetErrorString(e);
+        delete ctx;
+        return fail(nullptr, KVM_ERR_DEVICE, msg);
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
+        ctx->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        if (std::strstr(prop.gcnArchName, "gfx950") == nullptr) {
+            std::string msg = std::string("kvm_open: built for gfx950 only, device is ") + prop.gcnArchName;
+            hipStreamDestroy(ctx->stream);
+            delete ctx;
+            return fail(nullptr, KVM_ERR_DEVICE, msg);
+        }
+    }
+    *out = ctx;
+    return KVM_OK;
+}
+
+static void free_series(kvm_ctx *ctx) {
+    if (ctx->own_series && ctx->d_series) hipFree(ctx->d_series);
+    ctx->d_series = nullptr;
+    ctx->own_series = false;
+    if (ctx->d_prefix) hipFree(ctx->d_prefix);
+    ctx->d_prefix = nullptr;
+    if (ctx->d_env_u) hipFree(ctx->d_env_u);
+    if (ctx->d_env_l) hipFree(ctx->d_env_l);
+    ctx->d_env_u = ctx->d_env_l = nullptr;
+    ctx->env_rho = -1;
+    ctx->n = 0;
+}
+
+extern "C" int kvm_close(kvm_ctx *ctx) {
+    if (!ctx) return KVM_ERR_INVALID_HANDLE;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    free_series(ctx);
+    kvm_dev_buf *bufs[] = {&ctx->b_query, &ctx->b_tiles, &ctx->b_out_off, &ctx->b_out_dist, &ctx->b_counters,
+                           &ctx->b_cands, &ctx->b_cands2, &ctx->b_aux,   &ctx->b_aux2,    &ctx->b_scratch};
+    for (kvm_dev_buf *b : bufs)
+        if (b->p) hipFree(b->p);
+    if (ctx->h_pinned) hipHostFree(ctx->h_pinned);
+    hipEventDestroy(ctx->ev0);
+    hipEventDestroy(ctx->ev1);
+    hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return KVM_OK;
+}
+
+extern "C" int kvm_set_option(kvm_ctx *ctx, int32_t option, int64_t value) {
+    if (!ctx) return KVM_ERR_INVALID_HANDLE;
+    switch (option) {
+        case KVM_OPT_EARLY_ABANDON: ctx->opt_early_abandon = value ? 1 : 0; return KVM_OK;
+        case KVM_OPT_LB_CASCADE: ctx->opt_lb_cascade = value ? 1 : 0; return KVM_OK;
+        case KVM_OPT_ED_KERNEL:
+            if (value < 0 || value > 2) return fail(ctx, KVM_ERR_ILLEGAL_ARGUMENT, "KVM_OPT_ED_KERNEL in {0,1,2}");
+            ctx->opt_ed_kernel = value;
+            return KVM_OK;
+        case KVM_OPT_TIMING: ctx->opt_timing = value ? 1 : 0; return KVM_OK;
+    }
+    return fail(ctx, KVM_ERR_ILLEGAL_ARGUMENT, "unknown option");
+}
+
+extern "C" int64_t kvm_last_kernel_ns(const kvm_ctx *ctx) { return ctx ? ctx->last_kernel_ns : 0; }
+
+extern "C" int64_t kvm_get_option(const kvm_ctx *ctx, int32_t option) {
+    if (!ctx) return KVM_ERR_INVALID_HANDLE;
+    switch (option) {
+        case KVM_OPT_EARLY_ABANDON: return ctx->opt_early_abandon;
+        case KVM_OPT_LB_CASCADE: return ctx->opt_lb_cascade;
+        case KVM_OPT_ED_KERNEL: return ctx->opt_ed_kernel;
+        case KVM_OPT_TIMING: return ctx->opt_timing;
+    }
+    return KVM_ERR_ILLEGAL_ARGUMENT;
+}
+
+// ---- series staging -----------------------------------------------------------------------------------
+
+static int finish_load(kvm_ctx *ctx) {
+    // prefix sums for per-window mean/std (replaces the running ex/ex2 of K/NormQueryEngine.java:497-509)
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_prefix, (size_t)ctx->n * sizeof(double2)));
+    HIPCHK(ctx, kvm_launch_prefix(ctx->d_series, ctx->d_prefix, ctx->n, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return KVM_OK;
+}
+
+static int alloc_series(kvm_ctx *ctx, int64_t n) {
+    if (n < 1 || n > 2147483647LL)  // offsets are Java ints (K/operator/file/TimeSeriesFileOperator.java:32)
+        return fail(ctx, KVM_ERR_ILLEGAL_ARGUMENT, "series length must be in [1, 2^31-1]");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    free_series(ctx);
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_series, (size_t)n * sizeof(double)));
+    ctx->own_series = true;
+    ctx->n = n;
+    return KVM_OK;
+}
+
+extern "C" int kvm_load_series_f64(kvm_ctx *ctx, const double *host_values, int64_t n) {
+    if (!ctx) return KVM_ERR_INVALID_HANDLE;
+    if (!host_values) return fail(ctx, KVM_ERR_ILLEGAL_ARGUMENT, "null series");
+    int rc = alloc_series(ctx, n);
+    if (rc) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_series, host_values, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+    return finish_load(ctx);
+}
+
+extern "C" int kvm_load_series_be64(kvm_ctx *ctx, const void *be_bytes, int64_t n) {
+    if (!ctx) return KVM_ERR_INVALID_HANDLE;
+    if (!be_bytes) return fail(ctx, KVM_ERR_ILLEGAL_ARGUMENT, "null series");
+    int rc = alloc_series(ctx, n);
+    if (rc) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_series, be_bytes, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, kvm_launch_bswap64((uint64_t *)ctx->d_series, n, ctx->stream));
+    return finish_load(ctx);
+}
+
+extern "C" int kvm_load_series_file(kvm_ctx *ctx, const char *path, int64_t n) {
+    if (!ctx) return KVM_ERR_INVALID_HANDLE;
+    if (!path) return fail(ctx, KVM_ERR_ILLEGAL_ARGUMENT, "null path");
+    int fd = open(path, O_RDONLY);
+    if (fd < 0) return fail(ctx, KVM_ERR_IO, std::string("cannot open ") + path);
+    struct stat st;
+    if (fstat(fd, &st) != 0 || (int64_t)st.st_size < n * 8) {
+        close(fd);
+        return fail(ctx, KVM_ERR_IO, std::string(path) + ": shorter than n*8 bytes");
+    }
+    void *map = mmap(nullptr, (size_t)n * 8, PROT_READ, MAP_PRIVATE, fd, 0);
+    close(fd);
+    if (map == MAP_FAILED) return fail(ctx, KVM_ERR_IO, std::string("mmap failed for ") + path);
+    int rc = kvm_load_series_be64(ctx, map, n);
+    munmap(map, (size_t)n * 8);
+    return rc;
+}
+
+extern "C" int kvm_attach_series_device(kvm_ctx *ctx, const double *device_values, int64_t n) {
+    if (!ctx) return KVM_ERR_INVALID_HANDLE;
+    if (!device_values || n < 1 || n > 2147483647LL) return fail(ctx, KVM_ERR_ILLEGAL_ARGUMENT, "bad device series");
+    if (((uintptr_t)device_values & 31) != 0)
+        return fail(ctx, KVM_ERR_ILLEGAL_ARGUMENT, "device series must be 32-byte aligned");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    free_series(ctx);
+    ctx->d_series = const_cast<double *>(device_values);
+    ctx->own_series = false;
+    ctx->n = n;
+    return finish_load(ctx);
+}
+
+extern "C" int64_t kvm_series_length(const kvm_ctx *ctx) { return ctx ? ctx->n : KVM_ERR_INVALID_HANDLE; }
+
+extern "C" int kvm_read_time_series(kvm_ctx *ctx, int32_t left, int32_t length, double *out) {
+    if (!ctx) return KVM_ERR_INVALID_HANDLE;
+    if (!ctx->d_series) return fail(ctx, KVM_ERR_NO_SERIES, "no series loaded");
+    // K/operator/file/TimeSeriesFileOperator.java:55-57
+    if (left < 1 || (int64_t)left + length - 1 > ctx->n || length < 1 || !out) {
+        char msg[96];
+        snprintf(msg, sizeof msg, "left: %d, length: %d", left, length);
+        return fail(ctx, KVM_ERR_ILLEGAL_ARGUMENT, msg);
+    }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipMemcpyAsync(out, ctx->d_series + (left - 1), (size_t)length * 8, hipMemcpyDeviceToHost,
+                               ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return KVM_OK;
+}
+
+extern "C" int32_t kvm_resolve_rho(double r, int32_t m) {
+    if (r <= 1) return (int32_t)std::floor(r * m);  // K/QueryEngineDtw.java:135-140
+    return (int32_t)std::floor(r);
+}
+
+// ---- plan: intervals -> runs -> tiles -------------------------------------------------------------------
+
+struct plan {
+    std::vector<kvm_tile> tiles;
+    int64_t cnt_candidate = 0;  // sum(right-left+1) before clipping, K/QueryEngine.java:344
+    int64_t windows = 0;        // windows actually evaluated
+};
+
+// Window start offsets of interval [left,right]: max(1,left-shift) .. min(right-shift, n-m+1)
+// (K/QueryEngine.java:346-354: begin/end clipping, loop `i + length - 1 < data.size()`).
+static int build_plan(kvm_ctx *ctx, bool cnsm, int32_t m, const int32_t *left, const int32_t *right, int32_t k,
+                      int32_t shift, plan &pl) {
+    const int64_t n = ctx->n;
+    if (!cnsm) {
+        // RSM engines fetch per interval: readTimeSeries(begin, end-begin+1) throws when the clipped range is
+        // empty (K/QueryEngine.java:346-352; K/operator/file/TimeSeriesFileOperator.java:55-57).
+        for (int32_t p = 0; p < k; p++) {
+            int64_t begin = (int64_t)left[p] - shift, end = (int64_t)right[p] - shift + m - 1;
+            if (begin < 1) begin = 1;
+            if (end > n) end = n;
+            if (end - begin + 1 < 1) {
+                char msg[96];
+                snprintf(msg, sizeof msg, "left: %lld, length: %lld", (long long)begin, (long long)(end - begin + 1));
+                return fail(ctx, KVM_ERR_ILLEGAL_ARGUMENT, msg);
+            }
+        }
+    } else {
+        // cNSM engines fetch greedy-merged chunks of <= MAX_SCAN_DATA_LENGTH points
+        // (K/NormQueryEngine.java:454-482); only the chunk read can throw.
+        int32_t idx = 0;
+        while (idx < k) {
+            int32_t beginIdx = idx, endIdx = idx;
+            int64_t begin = (int64_t)left[idx] - shift, end = (int64_t)right[idx] - shift + m - 1;
+            if (begin < 1) begin = 1;
+            int64_t length = end - begin + 1;
+            idx++;
+            while (idx < k) {
+                begin = (int64_t)left[idx] - shift;
+                int64_t newLength = length + begin - end - 1;
+                end = (int64_t)right[idx] - shift + m - 1;
+                if (end > n) end = n;
+                newLength += end - begin + 1;
+                if (newLength > KVM_MAX_SCAN_DATA_LENGTH) break;
+                endIdx = idx;
+                length = newLength;
+                idx++;
+            }
+            begin = (int64_t)left[beginIdx] - shift;
+            end = (int64_t)right[endIdx] - shift + m - 1;
+            if (begin < 1) begin = 1;
+            if (end > n) end = n;
+            if (end - begin + 1 < 1 || begin > n) {
+                char msg[96];
+                snprintf(msg, sizeof msg, "left: %lld, length: %lld", (long long)begin, (long long)(end - begin + 1));
+                return fail(ctx, KVM_ERR_ILLEGAL_ARGUMENT, msg);
+            }
+        }
+    }
+    pl.tiles.clear();
+    pl.tiles.reserve((size_t)k + 16);
+    for (int32_t p = 0; p < k; p++) {
+        pl.cnt_candidate += (int64_t)right[p] - left[p] + 1;
+        int64_t lo = (int64_t)left[p] - shift, hi = (int64_t)right[p] - shift;
+        if (lo < 1) lo = 1;
+        if (hi > n - m + 1) hi = n - m + 1;
+        for (int64_t s = lo; s <= hi; s += KVM_TILE_MAX) {
+            kvm_tile t;
+            t.start = (int32_t)s;
+            t.count = (int32_t)std::min<int64_t>(KVM_TILE_MAX, hi - s + 1);
+            pl.tiles.push_back(t);
+            pl.windows += t.count;
+        }
+    }
+    return KVM_OK;
+}
+
+// Upper/lower envelope of the query: u[i] = max q[max(0,i-r)..min(m-1,i+r)], l[i] = min (same values as
+// DtwUtils.lowerUpperLemire, K/utils/DtwUtils.java:50-91, which is a pure selection).  Monotonic deques.
+static void query_envelope(const std::vector<double> &q, int r, std::vector<double> &u, std::vector<double> &l) {
+    const int m = (int)q.size();
+    u.assign(m, 0.0);
+    l.assign(m, 0.0);
+    std::deque<int> mx, mn;
+    int next = 0;
+    for (int i = 0; i < m; i++) {
+        int hi = std::min(m - 1, i + r), lo = std::max(0, i - r);
+        for (; next <= hi; next++) {
+            while (!mx.empty() && q[mx.back()] <= q[next]) mx.pop_back();
+            mx.push_back(next);
+            while (!mn.empty() && q[mn.back()] >= q[next]) mn.pop_back();
+            mn.push_back(next);
+        }
+        while (mx.front() < lo) mx.pop_front();
+        while (mn.front() < lo) mn.pop_front();
+        u[i] = q[mx.front()];
+        l[i] = q[mn.front()];
+    }
+}
+
+// ---- the shared verification driver ---------------------------------------------------------------------
+
+struct verify_out {
+    int32_t *d_off;
+    double *d_dist;
+    int64_t cap;
+};
+
+enum { V_RSM_ED = 0, V_CNSM_ED = 1, V_RSM_DTW = 2, V_CNSM_DTW = 3 };
+
+static int ensure_envelope(kvm_ctx *ctx, int32_t rho) {
+    if (ctx->env_rho == rho && ctx->d_env_u) return KVM_OK;
+    if (!ctx->d_env_u) {
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_env_u, (size_t)ctx->n * 8));
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_env_l, (size_t)ctx->n * 8));
+    }
+    HIPCHK(ctx, kvm_launch_envelope(ctx->d_series, ctx->n, rho, ctx->d_env_u, ctx->d_env_l, ctx->stream));
+    ctx->env_rho = rho;
+    return KVM_OK;
+}
+
+// Runs the kernels of one variant; survivors land (unsorted) in out.d_off/out.d_dist, counters stay on the
+// device in ctx->b_counters.  `stream` is the stream to launch on.
+static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m, const int32_t *left,
+                       const int32_t *right, int32_t k, int32_t shift, double epsilon, int32_t rho, double alpha,
+                       double beta, plan &pl, verify_out out, hipStream_t stream, int64_t *kernel_ns) {
+    if (!ctx->d_series) return fail(ctx, KVM_ERR_NO_SERIES, "no series loaded");
+    if (!query || m < 1 || k < 0 || (k > 0 && (!left || !right)))
+        return fail(ctx, KVM_ERR_ILLEGAL_ARGUMENT, "bad query/interval arguments");
+    if (m > ctx->n) return fail(ctx, KVM_ERR_ILLEGAL_ARGUMENT, "query longer than the series");
+    if (!(epsilon >= 0)) return fail(ctx, KVM_ERR_ILLEGAL_ARGUMENT, "epsilon must be >= 0");
+    const bool cnsm = variant == V_CNSM_ED || variant == V_CNSM_DTW;
+    const bool dtw = variant == V_RSM_DTW || variant == V_CNSM_DTW;
+    if (cnsm && !(alpha > 0)) return fail(ctx, KVM_ERR_ILLEGAL_ARGUMENT, "alpha must be > 0");
+    if (dtw && rho < 0) return fail(ctx, KVM_ERR_ILLEGAL_ARGUMENT, "rho must be >= 0");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int rc = build_plan(ctx, cnsm, m, left, right, k, shift, pl);
+    if (rc) return rc;
+
+    // ---- query-side constants (host, sequential, exactly the reference's arithmetic) ----
+    std::vector<double> q(query, query + m), qu, ql;
+    kvm_query_dev qd;
+    std::memset(&qd, 0, sizeof qd);
+    qd.m = m;
+    qd.rho = rho;
+    qd.eps2 = epsilon * epsilon;
+    qd.normalised = cnsm ? 1 : 0;
+    qd.early_abandon = (int32_t)ctx->opt_early_abandon;
+    qd.alpha = alpha;
+    qd.beta = beta;
+    if (cnsm) {
+        // K/NormQueryEngine.java:192-198 (phase 0) and :438-441 (z-normalisation)
+        double ex = 0, ex2 = 0;
+        for (int i = 0; i < m; i++) {
+            ex += query[i];
+            ex2 += query[i] * query[i];
+        }
+        qd.meanQ = ex / m;
+        qd.stdQ = std::sqrt(ex2 / m - qd.meanQ * qd.meanQ);
+        for (int i = 0; i < m; i++) q[i] = (query[i] - qd.meanQ) / qd.stdQ;
+    }
+    if (dtw) query_envelope(q, rho, qu, ql);
+
+    // ---- uploads (one pinned staging area: query | envelopes | tiles) ----
+    const size_t qbytes = (size_t)m * 8 * (dtw ? 3 : 1);
+    const size_t tbytes = pl.tiles.size() * sizeof(kvm_tile);
+    rc = ensure_pinned(ctx, qbytes + tbytes + 64);
+    if (rc) return rc;
+    if ((rc = ensure(ctx, ctx->b_query, qbytes + 64))) return rc;
+    if ((rc = ensure(ctx, ctx->b_tiles, tbytes + 64))) return rc;
+    if ((rc = ensure(ctx, ctx->b_counters, KVM_CNT_TOTAL * sizeof(unsigned long long)))) return rc;
+    char *hp = (char *)ctx->h_pinned;
+    std::memcpy(hp, q.data(), (size_t)m * 8);
+    if (dtw) {
+        std::memcpy(hp + (size_t)m * 8, qu.data(), (size_t)m * 8);
+        std::memcpy(hp + (size_t)m * 16, ql.data(), (size_t)m * 8);
+    }
+    if (tbytes) std::memcpy(hp + qbytes, pl.tiles.data(), tbytes);
+    HIPCHK(ctx, hipMemcpyAsync(ctx->b_query.p, hp, qbytes, hipMemcpyHostToDevice, stream));
+    if (tbytes) HIPCHK(ctx, hipMemcpyAsync(ctx->b_tiles.p, hp + qbytes, tbytes, hipMemcpyHostToDevice, stream));
+    HIPCHK(ctx, hipMemsetAsync(ctx->b_counters.p, 0, KVM_CNT_TOTAL * sizeof(unsigned long long), stream));
+    qd.q = (const double *)ctx->b_query.p;
+    qd.qu = dtw ? qd.q + m : nullptr;
+    qd.ql = dtw ? qd.q + 2 * (size_t)m : nullptr;
+    unsigned long long *counters = (unsigned long long *)ctx->b_counters.p;
+    const kvm_tile *d_tiles = (const kvm_tile *)ctx->b_tiles.p;
+    const int64_t n_tiles = (int64_t)pl.tiles.size();
+
+    if (kernel_ns) *kernel_ns = 0;
+    ctx->last_kernel_ns = 0;
+    if (n_tiles == 0) return KVM_OK;
+
+    if (ctx->opt_timing) HIPCHK(ctx, hipEventRecord(ctx->ev0, stream));
+    if (!dtw) {
+        int which = (int)ctx->opt_ed_kernel;
+        if (which == 0) which = 1;  // auto -> wave kernel until the tiled kernel is selected by the planner
+        if (which == 2)
+            HIPCHK(ctx, kvm_launch_ed_tiled(ctx->d_series, ctx->d_prefix, ctx->n, qd, d_tiles, n_tiles, out.d_off,
+                                            out.d_dist, out.cap, counters, stream));
+        else
+            HIPCHK(ctx, kvm_launch_ed_wave(ctx->d_series, ctx->d_prefix, ctx->n, qd, d_tiles, n_tiles, out.d_off,
+                                           out.d_dist, out.cap, counters, stream));
+    } else {
+        const int use_lb = (int)ctx->opt_lb_cascade;
+        if ((rc = ensure(ctx, ctx->b_cands, (size_t)pl.windows * sizeof(kvm_cand) + 64))) return rc;
+        kvm_cand *c1 = (kvm_cand *)ctx->b_cands.p;
+        HIPCHK(ctx, kvm_launch_dtw_filter(ctx->d_series, ctx->d_prefix, ctx->n, qd, d_tiles, n_tiles, use_lb, c1,
+                                          counters, stream));
+        const kvm_cand *dp_in = c1;
+        const unsigned long long *dp_n = counters + KVM_CNT_CANDS1;
+        if (use_lb) {
+            if ((rc = ensure(ctx, ctx->b_cands2, (size_t)pl.windows * sizeof(kvm_cand) + 64))) return rc;
+            if ((rc = ensure_envelope(ctx, rho))) return rc;
+            kvm_cand *c2 = (kvm_cand *)ctx->b_cands2.p;
+            HIPCHK(ctx, kvm_launch_dtw_keogh(ctx->d_series, ctx->d_env_u, ctx->d_env_l, ctx->n, qd, c1,
+                                             counters + KVM_CNT_CANDS1, pl.windows, c2, counters, stream));
+            dp_in = c2;
+            dp_n = counters + KVM_CNT_CANDS2;
+        }
+        HIPCHK(ctx, kvm_launch_dtw_dp(ctx->d_series, ctx->n, qd, dp_in, dp_n, pl.windows, out.d_off, out.d_dist,
+                                      out.cap, counters, ctx->num_cu, stream));
+    }
+    if (ctx->opt_timing) {
+        HIPCHK(ctx, hipEventRecord(ctx->ev1, stream));
+        HIPCHK(ctx, hipEventSynchronize(ctx->ev1));
+        float ms = 0;
+        HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+        ctx->last_kernel_ns = (int64_t)((double)ms * 1e6);
+        if (kernel_ns) *kernel_ns = ctx->last_kernel_ns;
+    }
+    return KVM_OK;
+}
+
+static int verify_host(kvm_ctx *ctx, int variant, const double *query, int32_t m, const int32_t *left,
+                       const int32_t *right, int32_t k, int32_t shift, double epsilon, int32_t rho, double alpha,
+                       double beta, kvm_result **result) {
+    if (!ctx) return KVM_ERR_INVALID_HANDLE;
+    if (!result) return fail(ctx, KVM_ERR_ILLEGAL_ARGUMENT, "null result pointer");
+    *result = nullptr;
+    auto t0 = std::chrono::steady_clock::now();
+    plan pl;
+    // capacity: every evaluated window may be an answer
+    int64_t worst = 0;
+    for (int32_t p = 0; p < k && left && right; p++) worst += std::max<int64_t>(0, (int64_t)right[p] - left[p] + 1);
+    int rc;
+    if ((rc = ensure(ctx, ctx->b_out_off, (size_t)worst * 4 + 64))) return rc;
+    if ((rc = ensure(ctx, ctx->b_out_dist, (size_t)worst * 8 + 64))) return rc;
+    verify_out out{(int32_t *)ctx->b_out_off.p, (double *)ctx->b_out_dist.p, worst};
+    int64_t kernel_ns = 0;
+    rc = run_variant(ctx, variant, query, m, left, right, k, shift, epsilon, rho, alpha, beta, pl, out, ctx->stream,
+                     &kernel_ns);
+    if (rc) return rc;
+    unsigned long long hc[KVM_CNT_TOTAL] = {0};
+    if (!pl.tiles.empty()) {
+        HIPCHK(ctx, hipMemcpyAsync(hc, ctx->b_counters.p, sizeof hc, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    const int64_t cnt = (int64_t)hc[KVM_CNT_ANSWERS];
+    if (cnt > worst) return fail(ctx, KVM_ERR_DEVICE, "answer buffer overflow (internal error)");
+    kvm_result *r = new kvm_result();
+    std::vector<int32_t> off((size_t)cnt);
+    std::vector<double> dist((size_t)cnt);
+    if (cnt) {
+        HIPCHK(ctx, hipMemcpyAsync(off.data(), out.d_off, (size_t)cnt * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(dist.data(), out.d_dist, (size_t)cnt * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    // answers.sort(Comparator.comparing(Pair::getSecond)) -- stable on an offset-ascending list
+    // (K/QueryEngine.java:373) == sort by (distance, offset).
+    std::vector<int64_t> perm((size_t)cnt);
+    std::iota(perm.begin(), perm.end(), 0);
+    std::sort(perm.begin(), perm.end(), [&](int64_t a, int64_t b) {
+        if (dist[a] != dist[b]) return dist[a] < dist[b];
+        return off[a] < off[b];
+    });
+    r->off.resize((size_t)cnt);
+    r->dist.resize((size_t)cnt);
+    for (int64_t i = 0; i < cnt; i++) {
+        r->off[i] = off[perm[i]];
+        r->dist[i] = dist[perm[i]];
+    }
+    r->candidates = pl.cnt_candidate;
+    r->stats[KVM_STAT_WINDOWS] = pl.windows;
+    const bool cnsm = variant == V_CNSM_ED || variant == V_CNSM_DTW;
+    const bool dtw = variant == V_RSM_DTW || variant == V_CNSM_DTW;
+    r->stats[KVM_STAT_PASS_FILTER] = cnsm ? (int64_t)hc[KVM_CNT_PASS_FILTER] : pl.windows;
+    if (dtw) {
+        r->stats[KVM_STAT_PASS_LB_KIM] = (int64_t)hc[KVM_CNT_PASS_KIM];
+        r->stats[KVM_STAT_PASS_LB_KEOGH] = ctx->opt_lb_cascade ? (int64_t)hc[KVM_CNT_PASS_KEOGH] : (int64_t)hc[KVM_CNT_PASS_KIM];
+        r->stats[KVM_STAT_PASS_LB_KEOGH2] =
+            ctx->opt_lb_cascade ? (int64_t)hc[KVM_CNT_PASS_KEOGH2] : (int64_t)hc[KVM_CNT_PASS_KIM];
+    }
+    r->stats[KVM_STAT_KERNEL_NS] = kernel_ns;
+    auto t1 = std::chrono::steady_clock::now();
+    r->elapsed_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+    *result = r;
+    return KVM_OK;
+}
+
+extern "C" int kvm_verify_rsm_ed(kvm_ctx *ctx, const double *query, int32_t m, const int32_t *left,
+                                 const int32_t *right, int32_t k, int32_t shift, double epsilon,
+                                 kvm_result **result) {
+    return verify_host(ctx, V_RSM_ED, query, m, left, right, k, shift, epsilon, 0, 1.0, 0.0, result);
+}
+extern "C" int kvm_verify_cnsm_ed(kvm_ctx *ctx, const double *query, int32_t m, const int32_t *left,
+                                  const int32_t *right, int32_t k, int32_t shift, double epsilon, double alpha,
+                                  double beta, kvm_result **result) {
+    return verify_host(ctx, V_CNSM_ED, query, m, left, right, k, shift, epsilon, 0, alpha, beta, result);
+}
+extern "C" int kvm_verify_rsm_dtw(kvm_ctx *ctx, const double *query, int32_t m, const int32_t *left,
+                                  const int32_t *right, int32_t k, int32_t shift, double epsilon, int32_t rho,
+                                  kvm_result **result) {
+    return verify_host(ctx, V_RSM_DTW, query, m, left, right, k, shift, epsilon, rho, 1.0, 0.0, result);
+}
+extern "C" int kvm_verify_cnsm_dtw(kvm_ctx *ctx, const double *query, int32_t m, const int32_t *left,
+                                   const int32_t *right, int32_t k, int32_t shift, double epsilon, int32_t rho,
+                                   double alpha, double beta, kvm_result **result) {
+    return verify_host(ctx, V_CNSM_DTW, query, m, left, right, k, shift, epsilon, rho, alpha, beta, result);
+}
+
+extern "C" int kvm_verify_device(kvm_ctx *ctx, int32_t variant, const double *query, int32_t m, const int32_t *left,
+                                 const int32_t *right, int32_t k, int32_t shift, double epsilon, int32_t rho,
+                                 double alpha, double beta, int32_t *d_out_off, double *d_out_dist, int64_t cap,
+                                 int64_t *d_out_count, int64_t *cnt_candidate, void *stream) {
+    if (!ctx) return KVM_ERR_INVALID_HANDLE;
+    if (variant < 0 || variant > 3 || !d_out_off || !d_out_dist || !d_out_count || cap < 0)
+        return fail(ctx, KVM_ERR_ILLEGAL_ARGUMENT, "bad kvm_verify_device arguments");
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    plan pl;
+    verify_out out{d_out_off, d_out_dist, cap};
+    int rc = run_variant(ctx, variant, query, m, left, right, k, shift, epsilon, rho, alpha, beta, pl, out, s, nullptr);
+    if (rc) return rc;
+    if (cnt_candidate) *cnt_candidate = pl.cnt_candidate;
+    if (pl.tiles.empty()) {
+        HIPCHK(ctx, hipMemsetAsync(d_out_count, 0, sizeof(int64_t), s));
+    } else {
+        HIPCHK(ctx, hipMemcpyAsync(d_out_count, (unsigned long long *)ctx->b_counters.p + KVM_CNT_ANSWERS,
+                                   sizeof(int64_t), hipMemcpyDeviceToDevice, s));
+    }
+    return KVM_OK;
+}
+
+// ---- results ----------------------------------------------------------------------------------------------
+extern "C" int64_t kvm_result_count(const kvm_result *r) { return r ? (int64_t)r->off.size() : 0; }
+extern "C" int64_t kvm_result_candidates(const kvm_result *r) { return r ? r->candidates : 0; }
+extern "C" double kvm_result_elapsed_ms(const kvm_result *r) { return r ? r->elapsed_ms : 0.0; }
+extern "C" const int32_t *kvm_result_offsets(const kvm_result *r) { return r ? r->off.data() : nullptr; }
+extern "C" const double *kvm_result_distances(const kvm_result *r) { return r ? r->dist.data() : nullptr; }
+extern "C" int64_t kvm_result_stat(const kvm_result *r, int32_t which) {
+    return (r && which >= 0 && which < KVM_STAT_COUNT) ? r->stats[which] : 0;
+}
+extern "C" void kvm_result_free(kvm_result *r) { delete r; }

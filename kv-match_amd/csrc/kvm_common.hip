@@ -1,0 +1,191 @@
+// kvm_common.hip -- staging kernels: big-endian decode, block-restarted prefix sums, sliding envelope.
+// gfx950 (CDNA4) only.  All three are single-pass HBM-bound streaming kernels.
+#include "kvm_internal.h"
+
+// ---------------------------------------------------------------------------------------------------
+// Big-endian fp64 -> native.  Replaces Bytes.toDouble per value (K/common/entity/TimeSeriesNode.java:46-52).
+// 16 B per lane, grid-stride; in place.
+__global__ __launch_bounds__(256) void kvm_bswap64_kernel(uint64_t *__restrict__ d, int64_t n) {
+    int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 2;
+    int64_t stride = (int64_t)gridDim.x * blockDim.x * 2;
+    for (; i + 1 < n; i += stride) {
+        ulonglong2 v = *reinterpret_cast<ulonglong2 *>(d + i);
+        v.x = __builtin_bswap64(v.x);
+        v.y = __builtin_bswap64(v.y);
+        *reinterpret_cast<ulonglong2 *>(d + i) = v;
+    }
+    if (i < n) d[i] = __builtin_bswap64(d[i]);  // odd tail (at most one thread hits this)
+}
+
+hipError_t kvm_launch_bswap64(uint64_t *d, int64_t n, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    int64_t pairs = (n + 1) / 2;
+    int64_t blocks = (pairs + 255) / 256;
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    hipLaunchKernelGGL(kvm_bswap64_kernel, dim3((unsigned)blocks), dim3(256), 0, s, d, n);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Block-restarted inclusive prefix sums of x and x*x (see KVM_PS_BLOCK in kvm_internal.h).
+// One workgroup scans one block of 16384 points as 16 sub-tiles of 1024 (4 consecutive points per
+// thread: 32 B loads, 64 B stores per lane).  Blocks are independent, so this is a one-pass kernel:
+// 8 B read + 16 B written per point.
+__global__ __launch_bounds__(256) void kvm_prefix_kernel(const double *__restrict__ x, double2 *__restrict__ P,
+                                                         int64_t n) {
+    __shared__ double wtot1[4], wtot2[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t base = (int64_t)blockIdx.x << KVM_PS_BLOCK_LOG2;
+    double carry1 = 0.0, carry2 = 0.0;
+    for (int sub = 0; sub < KVM_PS_BLOCK / 1024; sub++) {
+        const int64_t i0 = base + sub * 1024 + tid * 4;
+        if (base + sub * 1024 >= n) break;  // uniform across the workgroup
+        double v[4];
+        if (i0 + 3 < n) {
+            const double4 t = *reinterpret_cast<const double4 *>(x + i0);
+            v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; c++) v[c] = (i0 + c < n) ? x[i0 + c] : 0.0;
+        }
+        double a1[4], a2[4];
+        a1[0] = v[0];
+        a2[0] = v[0] * v[0];
+#pragma unroll
+        for (int c = 1; c < 4; c++) {
+            a1[c] = a1[c - 1] + v[c];
+            a2[c] = a2[c - 1] + v[c] * v[c];
+        }
+        // wave-inclusive scan of the per-thread totals
+        double s1 = a1[3], s2 = a2[3];
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            double t1 = __shfl_up(s1, o, 64), t2 = __shfl_up(s2, o, 64);
+            if (lane >= o) {
+                s1 += t1;
+                s2 += t2;
+            }
+        }
+        if (lane == 63) {
+            wtot1[wave] = s1;
+            wtot2[wave] = s2;
+        }
+        __syncthreads();
+        double off1 = carry1, off2 = carry2;
+        for (int w = 0; w < wave; w++) {
+            off1 += wtot1[w];
+            off2 += wtot2[w];
+        }
+        // exclusive prefix of this thread = inclusive - own total
+        off1 += s1 - a1[3];
+        off2 += s2 - a2[3];
+        if (i0 + 3 < n) {
+#pragma unroll
+            for (int c = 0; c < 4; c++) P[i0 + c] = make_double2(off1 + a1[c], off2 + a2[c]);
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; c++)
+                if (i0 + c < n) P[i0 + c] = make_double2(off1 + a1[c], off2 + a2[c]);
+        }
+        carry1 += (wtot1[0] + wtot1[1]) + (wtot1[2] + wtot1[3]);
+        carry2 += (wtot2[0] + wtot2[1]) + (wtot2[2] + wtot2[3]);
+        __syncthreads();
+    }
+}
+
+hipError_t kvm_launch_prefix(const double *x, double2 *prefix, int64_t n, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    int64_t blocks = (n + KVM_PS_BLOCK - 1) >> KVM_PS_BLOCK_LOG2;
+    hipLaunchKernelGGL(kvm_prefix_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, prefix, n);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Sliding envelope over the whole series: u[i] = max x[max(0,i-r) .. min(n-1,i+r)], l[i] = min ... .
+// Same values as DtwUtils.lowerUpperLemire (K/utils/DtwUtils.java:93-134) applied to the WHOLE series
+// (pure selections, no arithmetic).  The reference applies it per fetched chunk, so its envelope is
+// clipped at chunk ends; the global envelope is equal inside and looser at those ends -- still a valid
+// bound, affects pruning only.
+//
+// Each workgroup produces ENV_TS outputs from an LDS tile of ENV_TS + 2r points using the two-window
+// (sparse-table) trick: with p = floor(log2(w)), w = 2r+1, max over a w-window = max(M_p[a], M_p[a+w-2^p])
+// where M_p[i] = max x[i .. i+2^p).  M_p is built by p ping-pong doubling passes in LDS.
+#define ENV_TS 2048
+extern __shared__ double kvm_env_lds[];
+
+__global__ __launch_bounds__(256) void kvm_envelope_kernel(const double *__restrict__ x, int64_t n, int32_t r,
+                                                           double *__restrict__ u, double *__restrict__ l) {
+    const int tid = threadIdx.x;
+    const int len = ENV_TS + 2 * r;  // tile incl. halo
+    double *A = kvm_env_lds;         // ping
+    double *B = kvm_env_lds + len;   // pong
+    const int64_t t0 = (int64_t)blockIdx.x * ENV_TS;  // first output index
+    const int64_t g0 = t0 - r;                        // global index of tile[0]
+    const int w = 2 * r + 1;
+    int p = 0;
+    while ((2 << p) <= w) p++;  // 2^p <= w < 2^(p+1)
+
+    for (int pass = 0; pass < 2; pass++) {  // pass 0: max, pass 1: min
+        const double pad = pass == 0 ? -__builtin_huge_val() : __builtin_huge_val();
+        for (int i = tid; i < len; i += 256) {
+            int64_t g = g0 + i;
+            A[i] = (g >= 0 && g < n) ? x[g] : pad;
+        }
+        __syncthreads();
+        double *src = A, *dst = B;
+        for (int t = 0; t < p; t++) {
+            const int h = 1 << t;
+            for (int i = tid; i < len; i += 256) {
+                double a = src[i];
+                double b = (i + h < len) ? src[i + h] : pad;
+                dst[i] = pass == 0 ? fmax(a, b) : fmin(a, b);
+            }
+            __syncthreads();
+            double *tmp = src;
+            src = dst;
+            dst = tmp;
+        }
+        const int span = 1 << p;
+        for (int i = tid; i < ENV_TS; i += 256) {
+            int64_t g = t0 + i;
+            if (g < n) {
+                // window = tile indices [i, i+w)
+                double a = src[i], b = src[i + w - span];
+                if (pass == 0)
+                    u[g] = fmax(a, b);
+                else
+                    l[g] = fmin(a, b);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// Fallback for very wide bands (LDS tile would not fit): direct O(w) scan per point.
+__global__ __launch_bounds__(256) void kvm_envelope_naive_kernel(const double *__restrict__ x, int64_t n, int32_t r,
+                                                                 double *__restrict__ u, double *__restrict__ l) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int64_t lo = i - r < 0 ? 0 : i - r, hi = i + r > n - 1 ? n - 1 : i + r;
+    double mx = x[lo], mn = x[lo];
+    for (int64_t g = lo + 1; g <= hi; g++) {
+        double v = x[g];
+        mx = fmax(mx, v);
+        mn = fmin(mn, v);
+    }
+    u[i] = mx;
+    l[i] = mn;
+}
+
+hipError_t kvm_launch_envelope(const double *x, int64_t n, int32_t rho, double *u, double *l, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    size_t lds = (size_t)(ENV_TS + 2 * (int64_t)rho) * 2 * sizeof(double);
+    if (lds <= 64 * 1024) {
+        int64_t blocks = (n + ENV_TS - 1) / ENV_TS;
+        hipLaunchKernelGGL(kvm_envelope_kernel, dim3((unsigned)blocks), dim3(256), lds, s, x, n, rho, u, l);
+    } else {
+        int64_t blocks = (n + 255) / 256;
+        hipLaunchKernelGGL(kvm_envelope_naive_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, n, rho, u, l);
+    }
+    return hipGetLastError();
+}

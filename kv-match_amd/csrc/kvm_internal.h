@@ -1,0 +1,188 @@
+// kvm_internal.h -- shared declarations of libkvmatch_hip (gfx950 only; no CPU fallback anywhere).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/kvmatch.h"
+
+#define KVM_WAVE 64
+
+// Block-restarted prefix sums: P[i] = sum of x (and x*x) from the start of i's block up to i inclusive.
+// A window of m <= KVM_PS_BLOCK points touches at most two blocks, so window sums are differences of
+// O(block)-sized partial sums (error comparable to the reference's own per-interval running sums,
+// K/NormQueryEngine.java:487-509), not of n-sized global prefixes.  See DESIGN.md "mu/sigma".
+#define KVM_PS_BLOCK_LOG2 14
+#define KVM_PS_BLOCK (1 << KVM_PS_BLOCK_LOG2)
+
+// One candidate run = a clipped interval of consecutive window start offsets (1-based).
+struct kvm_run {
+    int32_t start;  // first window start offset (1-based)
+    int32_t count;  // number of consecutive offsets
+};
+
+// Tile = up to `count` consecutive candidates taken from one run.
+struct kvm_tile {
+    int32_t start;
+    int32_t count;
+};
+
+// Survivor record flowing between the cascade kernels.
+struct kvm_cand {
+    int32_t start;  // window start offset (1-based)
+    int32_t pad;
+    double mean;
+    double std;
+};
+
+struct kvm_dev_buf {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+struct kvm_ctx {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int64_t n = 0;
+    double *d_series = nullptr;
+    bool own_series = false;
+    double2 *d_prefix = nullptr;  // n entries {sum x, sum x^2}, block-restarted
+    // cached data envelope for LB_Keogh2 (per rho)
+    double *d_env_u = nullptr, *d_env_l = nullptr;
+    int32_t env_rho = -1;
+    // grow-only scratch
+    kvm_dev_buf b_query, b_tiles, b_out_off, b_out_dist, b_counters, b_cands, b_cands2, b_aux, b_aux2, b_scratch;
+    void *h_pinned = nullptr;
+    size_t h_pinned_cap = 0;
+    int64_t opt_early_abandon = 1, opt_lb_cascade = 1, opt_ed_kernel = 0, opt_timing = 0;
+    int num_cu = 256;
+    int64_t last_kernel_ns = 0;
+    std::string err;
+};
+
+struct kvm_result {
+    std::vector<int32_t> off;
+    std::vector<double> dist;
+    int64_t candidates = 0;
+    double elapsed_ms = 0;
+    int64_t stats[KVM_STAT_COUNT] = {0};
+};
+
+// ---- kernel launchers (each file implements its own) -----------------------------------------------
+// common
+hipError_t kvm_launch_bswap64(uint64_t *d, int64_t n, hipStream_t s);
+hipError_t kvm_launch_prefix(const double *x, double2 *prefix, int64_t n, hipStream_t s);
+hipError_t kvm_launch_envelope(const double *x, int64_t n, int32_t rho, double *u, double *l, hipStream_t s);
+
+// Query-side constants shared by kernels.
+struct kvm_query_dev {
+    const double *q;   // raw query (RSM) or z-normalised query (cNSM), device, m entries
+    const double *qu;  // upper envelope of q (DTW), device
+    const double *ql;  // lower envelope of q (DTW), device
+    int32_t m;
+    int32_t rho;
+    double eps2;    // epsilon * epsilon
+    double meanQ, stdQ, alpha, beta;
+    int32_t normalised;  // 0 RSM, 1 cNSM
+    int32_t early_abandon;
+};
+
+// ED: wave-per-candidate kernel over tiles.  counters[0] = #answers, counters[1] = #windows,
+// counters[2] = #passed filter.
+hipError_t kvm_launch_ed_wave(const double *series, const double2 *prefix, int64_t n, const kvm_query_dev &qd,
+                              const kvm_tile *tiles, int64_t n_tiles, int32_t *out_off, double *out_dist,
+                              int64_t cap, unsigned long long *counters, hipStream_t s);
+// ED: LDS-tiled kernel for dense runs.
+hipError_t kvm_launch_ed_tiled(const double *series, const double2 *prefix, int64_t n, const kvm_query_dev &qd,
+                               const kvm_tile *tiles, int64_t n_tiles, int32_t *out_off, double *out_dist,
+                               int64_t cap, unsigned long long *counters, hipStream_t s);
+
+// DTW cascade.
+hipError_t kvm_launch_dtw_filter(const double *series, const double2 *prefix, int64_t n, const kvm_query_dev &qd,
+                                 const kvm_tile *tiles, int64_t n_tiles, int32_t use_lb, kvm_cand *out,
+                                 unsigned long long *counters, hipStream_t s);
+hipError_t kvm_launch_dtw_keogh(const double *series, const double *env_u, const double *env_l, int64_t n,
+                                const kvm_query_dev &qd, const kvm_cand *in, const unsigned long long *d_n_in,
+                                int64_t max_in, kvm_cand *out, unsigned long long *counters, hipStream_t s);
+hipError_t kvm_launch_dtw_dp(const double *series, int64_t n, const kvm_query_dev &qd, const kvm_cand *in,
+                             const unsigned long long *d_n_in, int64_t max_in, int32_t *out_off, double *out_dist,
+                             int64_t cap, unsigned long long *counters, int num_cu, hipStream_t s);
+
+// counters layout (unsigned long long[16])
+#define KVM_CNT_ANSWERS 0
+#define KVM_CNT_WINDOWS 1
+#define KVM_CNT_PASS_FILTER 2
+#define KVM_CNT_PASS_KIM 3
+#define KVM_CNT_PASS_KEOGH 4
+#define KVM_CNT_PASS_KEOGH2 5
+#define KVM_CNT_QUEUE 6   // work-queue head of the DP kernel
+#define KVM_CNT_CANDS1 7  // #records in cands (after filter/Kim)
+#define KVM_CNT_CANDS2 8  // #records in cands2 (after Keogh)
+#define KVM_CNT_TOTAL 16
+
+// ---- device helpers ---------------------------------------------------------------------------------
+#ifdef __HIPCC__
+// Sum of x and x^2 over 0-based [s, s+m) from the block-restarted prefix array.
+__device__ __forceinline__ double2 kvm_window_sums(const double2 *__restrict__ P, int64_t s, int32_t m) {
+    int64_t e = s + m - 1;
+    int64_t bs = s >> KVM_PS_BLOCK_LOG2, be = e >> KVM_PS_BLOCK_LOG2;
+    double2 pe = P[e];
+    double s1, s2;
+    if (bs == be) {
+        if ((s & (KVM_PS_BLOCK - 1)) == 0) {
+            s1 = pe.x;
+            s2 = pe.y;
+        } else {
+            double2 ps = P[s - 1];
+            s1 = pe.x - ps.x;
+            s2 = pe.y - ps.y;
+        }
+    } else {
+        // tail of the first block
+        double2 pl = P[((bs + 1) << KVM_PS_BLOCK_LOG2) - 1];
+        if ((s & (KVM_PS_BLOCK - 1)) == 0) {
+            s1 = pl.x;
+            s2 = pl.y;
+        } else {
+            double2 ps = P[s - 1];
+            s1 = pl.x - ps.x;
+            s2 = pl.y - ps.y;
+        }
+        for (int64_t b = bs + 1; b < be; b++) {  // whole middle blocks (only when m > KVM_PS_BLOCK)
+            double2 pm = P[((b + 1) << KVM_PS_BLOCK_LOG2) - 1];
+            s1 += pm.x;
+            s2 += pm.y;
+        }
+        s1 += pe.x;
+        s2 += pe.y;
+    }
+    return make_double2(s1, s2);
+}
+
+// mean / std exactly in the reference's form (K/NormQueryEngine.java:507-508): mean = ex/m;
+// std = sqrt(ex2/m - mean*mean).  Compiled with -ffp-contract=off so no FMA sneaks in.
+__device__ __forceinline__ void kvm_mean_std(double2 sums, int32_t m, double &mean, double &std) {
+    mean = sums.x / m;
+    std = sqrt(sums.y / m - mean * mean);
+}
+
+// (alpha, beta) filter, K/NormQueryEngine.java:511.
+__device__ __forceinline__ bool kvm_cnsm_filter(double mean, double std, double meanQ, double stdQ, double alpha,
+                                                double beta) {
+    return fabs(mean - meanQ) <= beta && (std / stdQ) <= alpha && (std / stdQ) >= 1.0 / alpha;
+}
+
+__device__ __forceinline__ double kvm_wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double kvm_wave_min(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o, 64));
+    return v;
+}
+#endif

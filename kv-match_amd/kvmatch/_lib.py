@@ -1,0 +1,113 @@
+"""ctypes binding of libkvmatch_hip.so (the C ABI declared in include/kvmatch.h).
+
+There is no fallback of any kind: if the shared library is missing, or no gfx950 device is usable,
+loading / kvm_open raises.  Nothing in this package imports the CPU oracle under oracle/.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libkvmatch_hip.so")
+
+KVM_OK = 0
+KVM_ERR_INVALID_HANDLE = -1
+KVM_ERR_ILLEGAL_ARGUMENT = -2
+KVM_ERR_IO = -3
+KVM_ERR_DEVICE = -5
+KVM_ERR_NO_SERIES = -6
+KVM_ERR_UNSUPPORTED = -7
+
+STAT_WINDOWS, STAT_PASS_FILTER, STAT_PASS_LB_KIM, STAT_PASS_LB_KEOGH, STAT_PASS_LB_KEOGH2, STAT_KERNEL_NS, \
+    STAT_RECHECKED = range(7)
+OPT_EARLY_ABANDON, OPT_LB_CASCADE, OPT_ED_KERNEL, OPT_TIMING = 1, 2, 3, 4
+
+# every symbol include/kvmatch.h declares (checked by tests/test_abi.py)
+SYMBOLS = [
+    "kvm_open", "kvm_close", "kvm_last_error", "kvm_version",
+    "kvm_load_series_f64", "kvm_load_series_be64", "kvm_load_series_file", "kvm_attach_series_device",
+    "kvm_series_length", "kvm_read_time_series",
+    "kvm_verify_rsm_ed", "kvm_verify_cnsm_ed", "kvm_verify_rsm_dtw", "kvm_verify_cnsm_dtw", "kvm_resolve_rho",
+    "kvm_result_count", "kvm_result_candidates", "kvm_result_elapsed_ms", "kvm_result_offsets",
+    "kvm_result_distances", "kvm_result_stat", "kvm_result_free",
+    "kvm_set_option", "kvm_get_option", "kvm_last_kernel_ns", "kvm_verify_device",
+    "kvm_gen_series", "kvm_gen_intervals", "kvm_write_series_file",
+]
+
+
+class KvMatchDeviceError(RuntimeError):
+    """HIP/runtime failure (the JNI shim maps this to java.io.IOException)."""
+
+
+class KvMatchIOError(IOError):
+    """I/O failure -> java.io.IOException (K/QueryEngine.java:155 `throws IOException`)."""
+
+
+class KvMatchIllegalArgument(ValueError):
+    """-> java.lang.IllegalArgumentException (K/operator/file/TimeSeriesFileOperator.java:55-57)."""
+
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once).  Raises OSError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise OSError(f"{LIB_PATH} not found: build it with `make -C kv-match_amd/csrc` "
+                      "(or __graft_entry__.build()); there is no CPU fallback")
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, i64, f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_double
+    pd, pi = C.POINTER(C.c_double), C.POINTER(C.c_int32)
+    sig = {
+        "kvm_open": (C.c_int, [C.c_int, C.POINTER(vp)]),
+        "kvm_close": (C.c_int, [vp]),
+        "kvm_last_error": (C.c_char_p, [vp]),
+        "kvm_version": (C.c_char_p, []),
+        "kvm_load_series_f64": (C.c_int, [vp, vp, i64]),
+        "kvm_load_series_be64": (C.c_int, [vp, vp, i64]),
+        "kvm_load_series_file": (C.c_int, [vp, C.c_char_p, i64]),
+        "kvm_attach_series_device": (C.c_int, [vp, vp, i64]),
+        "kvm_series_length": (i64, [vp]),
+        "kvm_read_time_series": (C.c_int, [vp, i32, i32, vp]),
+        "kvm_verify_rsm_ed": (C.c_int, [vp, vp, i32, vp, vp, i32, i32, f64, C.POINTER(vp)]),
+        "kvm_verify_cnsm_ed": (C.c_int, [vp, vp, i32, vp, vp, i32, i32, f64, f64, f64, C.POINTER(vp)]),
+        "kvm_verify_rsm_dtw": (C.c_int, [vp, vp, i32, vp, vp, i32, i32, f64, i32, C.POINTER(vp)]),
+        "kvm_verify_cnsm_dtw": (C.c_int, [vp, vp, i32, vp, vp, i32, i32, f64, i32, f64, f64, C.POINTER(vp)]),
+        "kvm_resolve_rho": (i32, [f64, i32]),
+        "kvm_result_count": (i64, [vp]),
+        "kvm_result_candidates": (i64, [vp]),
+        "kvm_result_elapsed_ms": (f64, [vp]),
+        "kvm_result_offsets": (pi, [vp]),
+        "kvm_result_distances": (pd, [vp]),
+        "kvm_result_stat": (i64, [vp, i32]),
+        "kvm_result_free": (None, [vp]),
+        "kvm_set_option": (C.c_int, [vp, i32, i64]),
+        "kvm_get_option": (i64, [vp, i32]),
+        "kvm_last_kernel_ns": (i64, [vp]),
+        "kvm_verify_device": (C.c_int, [vp, i32, vp, i32, vp, vp, i32, i32, f64, i32, f64, f64, vp, vp, i64, vp,
+                                        C.POINTER(i64), vp]),
+        "kvm_gen_series": (C.c_int, [C.c_uint64, i64, vp]),
+        "kvm_gen_intervals": (i64, [C.c_uint64, i64, i32, i64, f64, vp, i32, vp, vp, i64]),
+        "kvm_write_series_file": (C.c_int, [C.c_char_p, vp, i64]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, ctx=None):
+    """Translate a status code into the exception the reference would have thrown."""
+    if rc == KVM_OK:
+        return
+    msg = load().kvm_last_error(ctx)
+    msg = msg.decode() if msg else f"status {rc}"
+    if rc == KVM_ERR_ILLEGAL_ARGUMENT:
+        raise KvMatchIllegalArgument(msg)
+    if rc == KVM_ERR_IO:
+        raise KvMatchIOError(msg)
+    raise KvMatchDeviceError(f"[{rc}] {msg}")

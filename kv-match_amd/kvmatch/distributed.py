@@ -1,0 +1,94 @@
+"""Multi-GPU host layer: one process per GPU (torch.distributed; backend "nccl" is RCCL on ROCm).
+
+The candidate set shards embarrassingly: the series is replicated on every GPU, the interval list is
+cut into `world` contiguous shards of about equal candidate count (cutting inside an interval where needed), each
+rank verifies its shard, and ONE all-gather moves the surviving (offset, distance) pairs: first the per-rank
+counts (world x int64), then one padded all-gather of a packed [max_count, 2] fp64 buffer (offset stored exactly
+as fp64; int32 fits).  The payload is tiny (16 B per answer), so the collective is latency-bound; xGMI bandwidth
+is irrelevant to it.  Every rank ends with the full answer list, sorted by (distance, offset) exactly as the
+single-GPU path sorts (K/QueryEngine.java:373).
+"""
+import numpy as np
+
+
+def split_intervals(left, right, world, rank):
+    """Contiguous shard `rank` of `world` of the candidate list, balanced by candidate count.
+
+    Returns (left, right) int32 arrays.  Intervals are cut where a shard boundary falls inside them; the pieces of a
+    cut interval are adjacent (not merged) which is fine for phase 2: every candidate offset appears in exactly
+    one shard.  cntCandidate summed over shards equals the unsharded cntCandidate."""
+    left = np.asarray(left, dtype=np.int64)
+    right = np.asarray(right, dtype=np.int64)
+    counts = np.maximum(right - left + 1, 0)
+    total = int(counts.sum())
+    lo = (total * rank) // world        # first global candidate index of this shard
+    hi = (total * (rank + 1)) // world  # one past the last
+    if hi <= lo:
+        return np.empty(0, dtype=np.int32), np.empty(0, dtype=np.int32)
+    cum = np.concatenate(([0], np.cumsum(counts)))
+    first = int(np.searchsorted(cum, lo, side="right") - 1)
+    last = int(np.searchsorted(cum, hi, side="left") - 1)
+    l = left[first:last + 1].copy()
+    r = right[first:last + 1].copy()
+    l[0] = left[first] + (lo - cum[first])
+    r[-1] = left[last] + (hi - cum[last]) - 1
+    keep = r >= l
+    return l[keep].astype(np.int32), r[keep].astype(np.int32)
+
+
+def sort_answers(offsets, distances):
+    """(distance, offset) order == the reference's stable sort by distance of an offset-ascending list."""
+    order = np.lexsort((offsets, distances))
+    return offsets[order], distances[order]
+
+
+def gather_answers(offsets, distances, group=None, device=None):
+    """All-gather variable-length (offset, distance) lists; returns the merged, sorted arrays on every rank.
+
+    `offsets`/`distances` may be numpy arrays (CPU / gloo) or torch tensors on `device` (RCCL)."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    if isinstance(offsets, np.ndarray):
+        dev = torch.device(device) if device is not None else torch.device("cpu")
+        packed = torch.empty((len(offsets), 2), dtype=torch.float64)
+        packed[:, 0] = torch.from_numpy(np.asarray(offsets, dtype=np.float64))
+        packed[:, 1] = torch.from_numpy(np.asarray(distances, dtype=np.float64))
+        packed = packed.to(dev)
+    else:
+        dev = offsets.device
+        packed = torch.stack((offsets.to(torch.float64), distances.to(torch.float64)), dim=1)
+    n_local = torch.tensor([packed.shape[0]], dtype=torch.int64, device=dev)
+    counts = torch.empty(world, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(counts, n_local, group=group)
+    counts_h = counts.cpu().numpy()
+    mx = int(counts_h.max()) if world else 0
+    if mx == 0:
+        return np.empty(0, dtype=np.int32), np.empty(0, dtype=np.float64)
+    pad = torch.zeros((mx, 2), dtype=torch.float64, device=dev)
+    pad[: packed.shape[0]] = packed
+    allbuf = torch.empty((world * mx, 2), dtype=torch.float64, device=dev)
+    dist.all_gather_into_tensor(allbuf, pad, group=group)
+    allh = allbuf.cpu().numpy().reshape(world, mx, 2)
+    offs = np.concatenate([allh[r, : counts_h[r], 0] for r in range(world)]).astype(np.int32)
+    dists = np.concatenate([allh[r, : counts_h[r], 1] for r in range(world)])
+    return sort_answers(offs, dists)
+
+
+def sharded_verify(engine, valid_positions, last_segment, query_data, *params, group=None):
+    """Verify this rank's shard with `engine.verify(...)` (HIP path) and all-gather the answers.
+
+    Returns (offsets, distances, cnt_candidate) where cnt_candidate is the global count."""
+    import torch
+    import torch.distributed as dist
+
+    left, right = valid_positions
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    l, r = split_intervals(left, right, world, rank)
+    ans = engine.verify((l, r), last_segment, query_data, *params)
+    dev = f"cuda:{engine.ctx.device}" if dist.get_backend(group) == "nccl" else "cpu"
+    offs, dists = gather_answers(ans.offsets, ans.distances, group=group, device=dev)
+    cnt = torch.tensor([ans.cnt_candidate], dtype=torch.int64, device=dev)
+    dist.all_reduce(cnt, group=group)
+    return offs, dists, int(cnt.item())

@@ -1,0 +1,229 @@
+"""Host-side mirror of the reference's four query engines, restricted to the phase-2 seam.
+
+The reference inlines phase 2 ("post-processing") at the tail of each engine's
+``query(List<StatisticInfo>, List<Double>, ...)`` (K/QueryEngine.java:338-379,
+K/QueryEngineDtw.java:349-468, K/NormQueryEngine.java:432-544, K/NormQueryEngineDtw.java:457-619).  The classes
+here keep the reference's names and argument meaning and expose that block as ``verify(...)``: inputs are what
+phase 1 hands over (``validPositions`` as (left, right) pairs, ``lastSegment``), outputs are the sorted
+``answers`` list and ``cntCandidate``; ``statistics`` slots 2..4 (T_2, #candidates, #answers) are appended the
+way K/QueryEngine.java:368-370 does.  Phases 0/1 (index probing) are out of scope and stay in the Java host.
+
+All arithmetic happens in libkvmatch_hip.so through the C ABI; this file only marshals.
+"""
+import ctypes as C
+import numpy as np
+
+from . import _lib
+
+WU0 = 25  # WuList[0], K/QueryEngine.java:44
+
+
+class StatisticInfo:
+    """K/statistic/StatisticInfo.java:43-69 (last / sum / n / min / max accumulator)."""
+
+    def __init__(self):
+        self.last, self.sum, self.n = -1.0, 0.0, 0
+        self.maximum, self.minimum = 4.9e-324, 1.7976931348623157e308  # Double.MIN_VALUE / MAX_VALUE
+
+    def append(self, value):
+        value = float(value)
+        self.last = value
+        self.sum += value
+        self.n += 1
+        self.maximum = max(self.maximum, value)
+        self.minimum = min(self.minimum, value)
+
+    def get_average(self):
+        return self.sum / self.n
+
+
+class Answers:
+    """``List<Pair<Integer, Double>>`` sorted by distance (K/QueryEngine.java:341,373)."""
+
+    def __init__(self, offsets, distances, cnt_candidate, elapsed_ms, stats):
+        self.offsets = offsets
+        self.distances = distances
+        self.cnt_candidate = cnt_candidate
+        self.elapsed_ms = elapsed_ms
+        self.stats = stats
+
+    def __len__(self):
+        return len(self.offsets)
+
+    def pairs(self):
+        return list(zip(self.offsets.tolist(), self.distances.tolist()))
+
+
+def _as_intervals(valid_positions):
+    """Accept [(left, right), ...], an (k,2) array, or a (left[], right[]) tuple of arrays."""
+    if isinstance(valid_positions, tuple) and len(valid_positions) == 2 and np.ndim(valid_positions[0]) == 1:
+        left, right = valid_positions
+    else:
+        arr = np.asarray(valid_positions, dtype=np.int64).reshape(-1, 2)
+        left, right = arr[:, 0], arr[:, 1]
+    left = np.ascontiguousarray(left, dtype=np.int32)
+    right = np.ascontiguousarray(right, dtype=np.int32)
+    if left.shape != right.shape:
+        raise _lib.KvMatchIllegalArgument("left/right length mismatch")
+    return left, right
+
+
+class Phase2Context:
+    """One HIP device + one staged series; the analogue of the engine constructor
+    ``QueryEngine(int n, String storageType)`` (K/QueryEngine.java:70) which opens the TimeSeriesOperator."""
+
+    def __init__(self, device=0):
+        self._lib = _lib.load()
+        h = C.c_void_p()
+        _lib.check(self._lib.kvm_open(int(device), C.byref(h)))
+        self._h = h
+        self.device = device
+        self._keep = None
+
+    # -- TimeSeriesOperator side ---------------------------------------------------------------------
+    def load_series(self, values):
+        v = np.ascontiguousarray(values, dtype=np.float64)
+        _lib.check(self._lib.kvm_load_series_f64(self._h, v.ctypes.data, v.size), self._h)
+
+    def load_series_be64(self, raw_bytes, n):
+        buf = np.frombuffer(raw_bytes, dtype=np.uint8)
+        if buf.size < n * 8:
+            raise _lib.KvMatchIllegalArgument("byte buffer shorter than n*8")
+        _lib.check(self._lib.kvm_load_series_be64(self._h, buf.ctypes.data, int(n)), self._h)
+
+    def load_series_file(self, path, n):
+        _lib.check(self._lib.kvm_load_series_file(self._h, str(path).encode(), int(n)), self._h)
+
+    def attach_device_series(self, data_ptr, n, keepalive=None):
+        self._keep = keepalive
+        _lib.check(self._lib.kvm_attach_series_device(self._h, C.c_void_p(int(data_ptr)), int(n)), self._h)
+
+    @property
+    def n(self):
+        return int(self._lib.kvm_series_length(self._h))
+
+    def read_time_series(self, left, length):
+        """TimeSeriesOperator.readTimeSeries(left, length), 1-based (K/operator/TimeSeriesOperator.java:38)."""
+        out = np.empty(max(int(length), 0), dtype=np.float64)
+        _lib.check(self._lib.kvm_read_time_series(self._h, int(left), int(length), out.ctypes.data), self._h)
+        return out
+
+    def set_option(self, option, value):
+        _lib.check(self._lib.kvm_set_option(self._h, int(option), int(value)), self._h)
+
+    def get_option(self, option):
+        return int(self._lib.kvm_get_option(self._h, int(option)))
+
+    def close(self):
+        if self._h is not None and self._h.value:
+            self._lib.kvm_close(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- result unpacking ---------------------------------------------------------------------------
+    def _collect(self, res):
+        lib = self._lib
+        try:
+            cnt = lib.kvm_result_count(res)
+            if cnt:
+                off = np.ctypeslib.as_array(lib.kvm_result_offsets(res), shape=(cnt,)).copy()
+                dist = np.ctypeslib.as_array(lib.kvm_result_distances(res), shape=(cnt,)).copy()
+            else:
+                off = np.empty(0, dtype=np.int32)
+                dist = np.empty(0, dtype=np.float64)
+            stats = [int(lib.kvm_result_stat(res, i)) for i in range(7)]
+            return Answers(off, dist, int(lib.kvm_result_candidates(res)), float(lib.kvm_result_elapsed_ms(res)),
+                           stats)
+        finally:
+            lib.kvm_result_free(res)
+
+
+class _EngineBase:
+    def __init__(self, ctx):
+        self.ctx = ctx
+
+    @staticmethod
+    def _shift(last_segment):
+        return (int(last_segment) - 1) * WU0  # (lastSegment - 1) * WuList[0], K/QueryEngine.java:346
+
+    @staticmethod
+    def _finish(statistics, ans):
+        # K/QueryEngine.java:368-370: phase-2 time, #candidates, #answers
+        if statistics is not None:
+            statistics[2].append(ans.elapsed_ms)
+            statistics[3].append(ans.cnt_candidate)
+            statistics[4].append(len(ans))
+        return ans
+
+    @staticmethod
+    def _query(query_data):
+        return np.ascontiguousarray(query_data, dtype=np.float64)
+
+
+class QueryEngine(_EngineBase):
+    """RSM-ED (K/QueryEngine.java).  ``verify`` replaces lines 338-363 + the sort of :373."""
+
+    def verify(self, valid_positions, last_segment, query_data, epsilon, statistics=None):
+        q = self._query(query_data)
+        left, right = _as_intervals(valid_positions)
+        res = C.c_void_p()
+        c = self.ctx
+        _lib.check(c._lib.kvm_verify_rsm_ed(c._h, q.ctypes.data, q.size, left.ctypes.data, right.ctypes.data,
+                                            left.size, self._shift(last_segment), float(epsilon), C.byref(res)), c._h)
+        return self._finish(statistics, c._collect(res))
+
+
+class NormQueryEngine(_EngineBase):
+    """cNSM-ED (K/NormQueryEngine.java).  ``verify`` replaces lines 432-528."""
+
+    def verify(self, valid_positions, last_segment, query_data, epsilon, alpha, beta, statistics=None):
+        q = self._query(query_data)
+        left, right = _as_intervals(valid_positions)
+        res = C.c_void_p()
+        c = self.ctx
+        _lib.check(c._lib.kvm_verify_cnsm_ed(c._h, q.ctypes.data, q.size, left.ctypes.data, right.ctypes.data,
+                                             left.size, self._shift(last_segment), float(epsilon), float(alpha),
+                                             float(beta), C.byref(res)), c._h)
+        return self._finish(statistics, c._collect(res))
+
+
+class QueryEngineDtw(_EngineBase):
+    """RSM-DTW (K/QueryEngineDtw.java).  ``verify`` replaces lines 349-452.  ``rho`` follows the reference's
+    prompt rule: values <= 1 are a fraction of the query length (K/QueryEngineDtw.java:135-140)."""
+
+    def verify(self, valid_positions, last_segment, query_data, epsilon, rho, statistics=None):
+        q = self._query(query_data)
+        left, right = _as_intervals(valid_positions)
+        res = C.c_void_p()
+        c = self.ctx
+        r = c._lib.kvm_resolve_rho(float(rho), q.size)
+        _lib.check(c._lib.kvm_verify_rsm_dtw(c._h, q.ctypes.data, q.size, left.ctypes.data, right.ctypes.data,
+                                             left.size, self._shift(last_segment), float(epsilon), r,
+                                             C.byref(res)), c._h)
+        return self._finish(statistics, c._collect(res))
+
+
+class NormQueryEngineDtw(_EngineBase):
+    """cNSM-DTW (K/NormQueryEngineDtw.java).  ``verify`` replaces lines 457-603."""
+
+    def verify(self, valid_positions, last_segment, query_data, epsilon, rho, alpha, beta, statistics=None):
+        q = self._query(query_data)
+        left, right = _as_intervals(valid_positions)
+        res = C.c_void_p()
+        c = self.ctx
+        r = c._lib.kvm_resolve_rho(float(rho), q.size)
+        _lib.check(c._lib.kvm_verify_cnsm_dtw(c._h, q.ctypes.data, q.size, left.ctypes.data, right.ctypes.data,
+                                              left.size, self._shift(last_segment), float(epsilon), r, float(alpha),
+                                              float(beta), C.byref(res)), c._h)
+        return self._finish(statistics, c._collect(res))

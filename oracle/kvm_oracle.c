@@ -1,0 +1,971 @@
+/*
+ * kvm_oracle.c -- CPU restatement of KV-match's phase-2 ("post-processing") candidate
+ * verification, in plain C.
+ *
+ * THIS FILE IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may load it.  The product path (kv-match_amd/) never links,
+ * imports or calls anything in oracle/.
+ *
+ * PARITY UNPINNED: the reference (DSM-fudan/KV-match, pure Java 8) ships no tests, no golden
+ * vectors and no fixtures for this path, and it cannot be compiled or run in this image (no
+ * JDK/JVM/Maven; every file on the path imports un-vendored hbase/slf4j artefacts).  This
+ * restatement therefore follows the Java source line by line (same loop order, same running
+ * sums, same early-abandon predicates, IEEE-754 binary64 without contraction) and is
+ * cross-checked by independent brute-force implementations in tests/ (full-matrix banded DTW,
+ * naive sliding min/max, direct z-normalised ED, self-match == 0), but no output of the Java
+ * code itself was available to pin it.
+ *
+ * Reference paths below are relative to /root/reference/src/main/java/cn/edu/fudan/dsm/kvmatch/
+ * (abbreviated K/).  Build: gcc -O2 -ffp-contract=off -fno-fast-math (Java never fuses a*b+c;
+ * Math.sqrt is correctly rounded == sqrt()).
+ *
+ * Conventions (reference): offsets are 1-based ints; values are fp64; `shift` is
+ * (lastSegment - 1) * WuList[0] with WuList[0] = 25 (K/QueryEngine.java:346).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define KVO_OK 0
+#define KVO_ERR_ILLEGAL_ARGUMENT (-2) /* IllegalArgumentException, K/operator/file/TimeSeriesFileOperator.java:55-57 */
+#define KVO_ERR_IO (-3)               /* IOException */
+#define KVO_ERR_CAPACITY (-4)         /* caller's answer buffer too small (no reference counterpart) */
+
+#define KVO_MAX_SCAN_DATA_LENGTH 40000 /* K/NormQueryEngine.java:60, K/NormQueryEngineDtw.java:61 */
+#define KVO_ROW_LENGTH 1000            /* K/common/entity/TimeSeriesNode.java:30 */
+
+static const double KVO_INF = 1e20; /* K/utils/DtwUtils.java:24 */
+
+/* ------------------------------------------------------------------------------------------ */
+/* Answers: List<Pair<Integer, Double>> (K/QueryEngine.java:341)                                */
+
+typedef struct {
+    int32_t *off;
+    double *dist;
+    int64_t cap;
+    int64_t cnt;
+    int overflow;
+} kvo_answers;
+
+static void answers_add(kvo_answers *a, int32_t off, double dist) {
+    if (a->cnt < a->cap) {
+        a->off[a->cnt] = off;
+        a->dist[a->cnt] = dist;
+    } else {
+        a->overflow = 1;
+    }
+    a->cnt++;
+}
+
+/* Double.compare semantics (used by Comparator.comparing(Pair::getSecond), K/QueryEngine.java:373). */
+static int double_compare(double a, double b) {
+    if (a < b) return -1;
+    if (a > b) return 1;
+    int64_t x, y;
+    memcpy(&x, &a, 8);
+    memcpy(&y, &b, 8);
+    /* equal, or at least one NaN: Java orders by raw bits with NaN canonicalised above +inf */
+    if (a != a) x = 0x7ff8000000000000LL;
+    if (b != b) y = 0x7ff8000000000000LL;
+    return (x == y) ? 0 : (x < y ? -1 : 1);
+}
+
+/* Stable merge sort of (off, dist) by dist -- List.sort is a stable TimSort; with a consistent
+ * comparator every stable sort yields the same permutation (K/QueryEngine.java:373). */
+static void stable_sort_answers(int32_t *off, double *dist, int64_t n) {
+    if (n < 2) return;
+    int32_t *toff = (int32_t *)malloc((size_t)n * sizeof(int32_t));
+    double *tdist = (double *)malloc((size_t)n * sizeof(double));
+    for (int64_t w = 1; w < n; w *= 2) {
+        for (int64_t lo = 0; lo < n; lo += 2 * w) {
+            int64_t mid = lo + w < n ? lo + w : n;
+            int64_t hi = lo + 2 * w < n ? lo + 2 * w : n;
+            int64_t i = lo, j = mid, o = lo;
+            while (i < mid && j < hi) {
+                if (double_compare(dist[j], dist[i]) < 0) {
+                    toff[o] = off[j];
+                    tdist[o++] = dist[j++];
+                } else {
+                    toff[o] = off[i];
+                    tdist[o++] = dist[i++];
+                }
+            }
+            while (i < mid) {
+                toff[o] = off[i];
+                tdist[o++] = dist[i++];
+            }
+            while (j < hi) {
+                toff[o] = off[j];
+                tdist[o++] = dist[j++];
+            }
+        }
+        memcpy(off, toff, (size_t)n * sizeof(int32_t));
+        memcpy(dist, tdist, (size_t)n * sizeof(double));
+    }
+    free(toff);
+    free(tdist);
+}
+
+void kvo_sort_answers(int32_t *off, double *dist, int64_t n) { stable_sort_answers(off, dist, n); }
+
+/* ------------------------------------------------------------------------------------------ */
+/* Data access: TimeSeriesOperator.readTimeSeries(left, length)                                 */
+/* (K/operator/TimeSeriesOperator.java:38; file backend K/operator/file/TimeSeriesFileOperator.java:54-96). */
+/* The series is held in memory, decoded once; `series[p-1]` is the value at 1-based offset p.   */
+
+static int read_time_series(const double *series, int n, int left, int length, const double **out) {
+    if (left < 1 || (int64_t)left + length - 1 > n || length < 1) return KVO_ERR_ILLEGAL_ARGUMENT;
+    *out = series + (left - 1);
+    return KVO_OK;
+}
+
+/* Big-endian IEEE-754 decode: Bytes.toDouble (hbase-common 1.1.5), call site
+ * K/common/entity/TimeSeriesNode.java:46-52. */
+void kvo_decode_be64(const uint8_t *bytes, int64_t count, double *out) {
+    for (int64_t i = 0; i < count; i++) {
+        uint64_t v = 0;
+        for (int b = 0; b < 8; b++) v = (v << 8) | bytes[i * 8 + b];
+        memcpy(&out[i], &v, 8);
+    }
+}
+
+/* Encode (Bytes.toBytes(double), K/common/entity/TimeSeriesNode.java:38-44; DataOutputStream.writeDouble
+ * K/DataGenerator.java:111). */
+void kvo_encode_be64(const double *in, int64_t count, uint8_t *bytes) {
+    for (int64_t i = 0; i < count; i++) {
+        uint64_t v;
+        memcpy(&v, &in[i], 8);
+        for (int b = 7; b >= 0; b--) {
+            bytes[i * 8 + b] = (uint8_t)(v & 0xff);
+            v >>= 8;
+        }
+    }
+}
+
+/* readTimeSeries straight from files/data-{N}, following the node-granular addressing of
+ * K/operator/file/TimeSeriesFileOperator.java:54-96 (whole ROW_LENGTH-value nodes are read and
+ * decoded, then trimmed).  A short final node is tolerated (n not a multiple of 1000). */
+int kvo_read_time_series_file(const char *path, int n, int left, int length, double *out) {
+    if (left < 1 || (int64_t)left + length - 1 > n || length < 1) return KVO_ERR_ILLEGAL_ARGUMENT;
+    int nodeBytes = KVO_ROW_LENGTH * 8;
+    int begin = (left - 1) / KVO_ROW_LENGTH * KVO_ROW_LENGTH + 1;
+    int end = (left + length - 2) / KVO_ROW_LENGTH * KVO_ROW_LENGTH + 1;
+    int64_t pos = (int64_t)((left - 1) / KVO_ROW_LENGTH) * (int64_t)nodeBytes;
+    int64_t lengthOfBytes = (int64_t)(end - begin + KVO_ROW_LENGTH) * 8;
+    FILE *f = fopen(path, "rb");
+    if (!f) return KVO_ERR_IO;
+    uint8_t *bytes = (uint8_t *)calloc((size_t)lengthOfBytes, 1);
+    if (fseek(f, (long)pos, SEEK_SET) != 0) {
+        fclose(f);
+        free(bytes);
+        return KVO_ERR_IO;
+    }
+    size_t got = fread(bytes, 1, (size_t)lengthOfBytes, f);
+    fclose(f);
+    (void)got;
+    int64_t cnt = 0;
+    for (int64_t i = 0; i < lengthOfBytes; i += nodeBytes) {
+        double node[KVO_ROW_LENGTH];
+        kvo_decode_be64(bytes + i, KVO_ROW_LENGTH, node);
+        if (i == 0) {
+            int offset = (left - 1) % KVO_ROW_LENGTH;
+            int hi = offset + length < KVO_ROW_LENGTH ? offset + length : KVO_ROW_LENGTH;
+            for (int j = offset; j < hi; j++) out[cnt++] = node[j];
+        } else if (i == lengthOfBytes - nodeBytes) {
+            int offset = (left + length - 2) % KVO_ROW_LENGTH;
+            for (int j = 0; j <= offset; j++) out[cnt++] = node[j];
+        } else {
+            for (int j = 0; j < KVO_ROW_LENGTH; j++) out[cnt++] = node[j];
+        }
+    }
+    free(bytes);
+    return cnt == length ? KVO_OK : KVO_ERR_IO;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* CircularArray (K/common/CircularArray.java:21-110): int deque used by the envelope.           */
+
+typedef struct {
+    int *dq;
+    int size, capacity, f, r;
+} circ;
+
+static void circ_init(circ *c, int capacity) {
+    c->capacity = capacity;
+    c->size = 0;
+    c->dq = (int *)malloc((size_t)capacity * sizeof(int));
+    c->f = 0;
+    c->r = capacity - 1;
+}
+static void circ_free(circ *c) { free(c->dq); }
+static void circ_push_back(circ *c, int v) {
+    c->dq[c->r] = v;
+    c->r--;
+    if (c->r < 0) c->r = c->capacity - 1;
+    c->size++;
+}
+static void circ_pop_front(circ *c) {
+    c->f--;
+    if (c->f < 0) c->f = c->capacity - 1;
+    c->size--;
+}
+static void circ_pop_back(circ *c) {
+    c->r = (c->r + 1) % c->capacity;
+    c->size--;
+}
+static int circ_front(const circ *c) {
+    int aux = c->f - 1;
+    if (aux < 0) aux = c->capacity - 1;
+    return c->dq[aux];
+}
+static int circ_back(const circ *c) {
+    int aux = (c->r + 1) % c->capacity;
+    return c->dq[aux];
+}
+static int circ_is_empty(const circ *c) { return c->size == 0; }
+
+/* ------------------------------------------------------------------------------------------ */
+/* DtwUtils (K/utils/DtwUtils.java)                                                              */
+
+static double dmin(double a, double b) { return (a < b) ? a : b; }     /* :34-36 */
+static double ddist(double v1, double v2) { return (v1 - v2) * (v1 - v2); } /* :38-40 */
+static int imax(int a, int b) { return (a > b) ? a : b; }               /* :26-28 */
+static int imin(int a, int b) { return (a < b) ? a : b; }               /* :30-32 */
+
+/* lowerUpperLemire, array and List<Double> overloads are the same algorithm
+ * (K/utils/DtwUtils.java:50-91 and :93-134). */
+void kvo_lower_upper_lemire(const double *t, int len, int r, double *l, double *u) {
+    circ du, dl;
+    circ_init(&du, 2 * r + 2);
+    circ_init(&dl, 2 * r + 2);
+
+    circ_push_back(&du, 0);
+    circ_push_back(&dl, 0);
+
+    for (int i = 1; i < len; i++) {
+        if (i > r) {
+            u[i - r - 1] = t[circ_front(&du)];
+            l[i - r - 1] = t[circ_front(&dl)];
+        }
+        if (t[i] > t[i - 1]) {
+            circ_pop_back(&du);
+            while (!circ_is_empty(&du) && t[i] > t[circ_back(&du)]) {
+                circ_pop_back(&du);
+            }
+        } else {
+            circ_pop_back(&dl);
+            while (!circ_is_empty(&dl) && t[i] < t[circ_back(&dl)]) {
+                circ_pop_back(&dl);
+            }
+        }
+        circ_push_back(&du, i);
+        circ_push_back(&dl, i);
+        if (i == 2 * r + 1 + circ_front(&du)) {
+            circ_pop_front(&du);
+        } else if (i == 2 * r + 1 + circ_front(&dl)) {
+            circ_pop_front(&dl);
+        }
+    }
+    for (int i = len; i < len + r + 1; i++) {
+        /* Java would throw ArrayIndexOutOfBounds for i-r-1 < 0 (len <= r); callers never do that
+         * with len >= 25 > ... well, they can when rho >= len; guard to stay memory-safe. */
+        if (i - r - 1 >= 0) {
+            u[i - r - 1] = t[circ_front(&du)];
+            l[i - r - 1] = t[circ_front(&dl)];
+        }
+        if (i - circ_front(&du) >= 2 * r + 1) {
+            circ_pop_front(&du);
+        }
+        if (i - circ_front(&dl) >= 2 * r + 1) {
+            circ_pop_front(&dl);
+        }
+    }
+    circ_free(&du);
+    circ_free(&dl);
+}
+
+/* lbKimHierarchy (K/utils/DtwUtils.java:149-189) */
+double kvo_lb_kim_hierarchy(const double *t, const double *q, int j, int len, double mean, double std,
+                            double bsf) {
+    double d, lb;
+    double x0 = (t[j] - mean) / std;
+    double y0 = (t[(len - 1 + j)] - mean) / std;
+    lb = ddist(x0, q[0]) + ddist(y0, q[len - 1]);
+    if (lb >= bsf) return lb;
+
+    double x1 = (t[(j + 1)] - mean) / std;
+    d = dmin(ddist(x1, q[0]), ddist(x0, q[1]));
+    d = dmin(d, ddist(x1, q[1]));
+    lb += d;
+    if (lb >= bsf) return lb;
+
+    double y1 = (t[(len - 2 + j)] - mean) / std;
+    d = dmin(ddist(y1, q[len - 1]), ddist(y0, q[len - 2]));
+    d = dmin(d, ddist(y1, q[len - 2]));
+    lb += d;
+    if (lb >= bsf) return lb;
+
+    double x2 = (t[(j + 2)] - mean) / std;
+    d = dmin(ddist(x0, q[2]), ddist(x1, q[2]));
+    d = dmin(d, ddist(x2, q[2]));
+    d = dmin(d, ddist(x2, q[1]));
+    d = dmin(d, ddist(x2, q[0]));
+    lb += d;
+    if (lb >= bsf) return lb;
+
+    double y2 = (t[(len - 3 + j)] - mean) / std;
+    d = dmin(ddist(y0, q[len - 3]), ddist(y1, q[len - 3]));
+    d = dmin(d, ddist(y2, q[len - 3]));
+    d = dmin(d, ddist(y2, q[len - 2]));
+    d = dmin(d, ddist(y2, q[len - 1]));
+    lb += d;
+
+    return lb;
+}
+
+/* lbKeoghCumulative (K/utils/DtwUtils.java:206-222) */
+double kvo_lb_keogh_cumulative(const int *order, const double *t, const double *uo, const double *lo,
+                               double *cb, int j, int len, double mean, double std, double best_so_far) {
+    double lb = 0;
+    double x, d;
+
+    for (int i = 0; i < len && lb < best_so_far; i++) {
+        x = (t[(order[i] + j)] - mean) / std;
+        d = 0;
+        if (x > uo[i]) {
+            d = ddist(x, uo[i]);
+        } else if (x < lo[i]) {
+            d = ddist(x, lo[i]);
+        }
+        lb += d;
+        cb[order[i]] = d;
+    }
+    return lb;
+}
+
+/* lbKeoghDataCumulative (K/utils/DtwUtils.java:238-257) */
+double kvo_lb_keogh_data_cumulative(const int *order, const double *qo, double *cb, int I, const double *l,
+                                    const double *u, int len, double mean, double std, double best_so_far) {
+    double lb = 0;
+    double uu, ll, d;
+
+    for (int i = 0; i < len && lb < best_so_far; i++) {
+        uu = (u[order[i] + I] - mean) / std;
+        ll = (l[order[i] + I] - mean) / std;
+        d = 0;
+        if (qo[i] > uu) {
+            d = ddist(qo[i], uu);
+        } else {
+            if (qo[i] < ll) {
+                d = ddist(qo[i], ll);
+            }
+        }
+        lb += d;
+        cb[order[i]] = d;
+    }
+    return lb;
+}
+
+/* dtw (K/utils/DtwUtils.java:269-337).  `cells`, when non-NULL, accumulates the number of DP
+ * cells evaluated (instrumentation only; used by the bench's work accounting). */
+double kvo_dtw(const double *A, const double *B, const double *cb, int m, int r, double bsf, int64_t *cells) {
+    double *cost, *cost_prev, *cost_tmp;
+    int i, j, k;
+    double x, y, z, min_cost;
+
+    cost = (double *)malloc((size_t)(2 * r + 1) * sizeof(double));
+    for (k = 0; k < 2 * r + 1; k++) cost[k] = KVO_INF;
+    cost_prev = (double *)malloc((size_t)(2 * r + 1) * sizeof(double));
+    for (k = 0; k < 2 * r + 1; k++) cost_prev[k] = KVO_INF;
+
+    k = 0;
+    for (i = 0; i < m; i++) {
+        k = imax(0, r - i);
+        min_cost = KVO_INF;
+
+        for (j = imax(0, i - r); j <= imin(m - 1, i + r); j++, k++) {
+            if (cells) (*cells)++;
+            if ((i == 0) && (j == 0)) {
+                cost[k] = ddist(A[0], B[0]);
+                min_cost = cost[k];
+                continue;
+            }
+
+            if ((j - 1 < 0) || (k - 1 < 0)) {
+                y = KVO_INF;
+            } else {
+                y = cost[k - 1];
+            }
+            if ((i - 1 < 0) || (k + 1 > 2 * r)) {
+                x = KVO_INF;
+            } else {
+                x = cost_prev[k + 1];
+            }
+            if ((i - 1 < 0) || (j - 1 < 0)) {
+                z = KVO_INF;
+            } else {
+                z = cost_prev[k];
+            }
+
+            cost[k] = dmin(dmin(x, y), z) + ddist(A[i], B[j]);
+
+            if (cost[k] < min_cost) {
+                min_cost = cost[k];
+            }
+        }
+
+        if (i + r < m - 1 && min_cost + cb[i + r + 1] >= bsf) {
+            double ret = min_cost + cb[i + r + 1];
+            free(cost);
+            free(cost_prev);
+            return ret;
+        }
+
+        cost_tmp = cost;
+        cost = cost_prev;
+        cost_prev = cost_tmp;
+    }
+    k--;
+
+    double final_dtw = cost_prev[k];
+    free(cost);
+    free(cost_prev);
+    return final_dtw;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* Statistics out: [0]=cntCandidate (statistics[3], K/QueryEngine.java:369), [1]=#answers,       */
+/* then instrumentation (no reference counterpart): [2]=#windows evaluated, [3]=#passed (alpha,   */
+/* beta) filter, [4]=#passed lbKim, [5]=#passed lbKeogh, [6]=#passed lbKeogh2 (= #dtw calls),     */
+/* [7]=#DP cells evaluated, [8]=#ED terms evaluated.                                              */
+#define KVO_NSTAT 9
+
+/* ------------------------------------------------------------------------------------------ */
+/* RSM-ED phase 2 (K/QueryEngine.java:338-363, sort :373).                                       */
+/* no_abandon != 0 disables the `distance <= epsilon*epsilon` loop guard (measurement only: the  */
+/* answers are identical because answers always complete the loop).                              */
+int64_t kvo_query_rsm_ed(const double *series, int n, const double *queryData, int length, const int32_t *left,
+                         const int32_t *right, int k, int shift, double epsilon, int no_abandon, int32_t *out_off,
+                         double *out_dist, int64_t cap, int64_t *stats) {
+    kvo_answers answers = {out_off, out_dist, cap, 0, 0};
+    int64_t cntCandidate = 0, windows = 0, terms = 0;
+    for (int p = 0; p < k; p++) {
+        cntCandidate += right[p] - left[p] + 1;
+
+        int begin = left[p] - shift;
+        int end = right[p] - shift + length - 1;
+        if (begin < 1) begin = 1;
+        if (end > n) end = n;
+        const double *data;
+        int dataSize = end - begin + 1;
+        int rc = read_time_series(series, n, begin, dataSize, &data);
+        if (rc != KVO_OK) return rc;
+
+        for (int i = 0; i + length - 1 < dataSize; i++) {
+            double distance = 0;
+            windows++;
+            int j;
+            for (j = 0; j < length && (no_abandon || distance <= epsilon * epsilon); j++) {
+                distance += (data[i + j] - queryData[j]) * (data[i + j] - queryData[j]);
+            }
+            terms += j;
+            if (distance <= epsilon * epsilon) {
+                answers_add(&answers, begin + i, sqrt(distance));
+            }
+        }
+    }
+    if (answers.overflow) return KVO_ERR_CAPACITY;
+    stable_sort_answers(out_off, out_dist, answers.cnt);
+    if (stats) {
+        memset(stats, 0, KVO_NSTAT * sizeof(int64_t));
+        stats[0] = cntCandidate;
+        stats[1] = answers.cnt;
+        stats[2] = windows;
+        stats[8] = terms;
+    }
+    return answers.cnt;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* Index (K/common/Index.java:18-28) + the two query reorderings.                                */
+
+typedef struct {
+    double value;
+    int index;
+} kvo_index;
+
+/* Stable merge sort with a caller-supplied three-way comparator. */
+typedef int (*index_cmp)(const kvo_index *, const kvo_index *);
+static void stable_sort_index(kvo_index *a, int n, index_cmp cmp) {
+    if (n < 2) return;
+    kvo_index *tmp = (kvo_index *)malloc((size_t)n * sizeof(kvo_index));
+    for (int w = 1; w < n; w *= 2) {
+        for (int lo = 0; lo < n; lo += 2 * w) {
+            int mid = lo + w < n ? lo + w : n;
+            int hi = lo + 2 * w < n ? lo + 2 * w : n;
+            int i = lo, j = mid, o = lo;
+            while (i < mid && j < hi) {
+                if (cmp(&a[j], &a[i]) < 0)
+                    tmp[o++] = a[j++];
+                else
+                    tmp[o++] = a[i++];
+            }
+            while (i < mid) tmp[o++] = a[i++];
+            while (j < hi) tmp[o++] = a[j++];
+        }
+        memcpy(a, tmp, (size_t)n * sizeof(kvo_index));
+    }
+    free(tmp);
+}
+
+/* (o1, o2) -> Double.compare(Math.abs(o2.value), Math.abs(o1.value))  (K/NormQueryEngine.java:449) */
+static int cmp_abs_desc(const kvo_index *o1, const kvo_index *o2) {
+    return double_compare(fabs(o2->value), fabs(o1->value));
+}
+
+/* (o1, o2) -> (int) (Math.abs(o2.value) - Math.abs(o1.value))  (K/NormQueryEngineDtw.java:475-478).
+ * The truncation makes this comparator inconsistent; Java's TimSort result under it is
+ * implementation-defined (and may throw).  DIVERGENCE: a stable merge sort is used here.  The
+ * permutation only changes the summation order inside lbKeogh*, i.e. last-ulp effects on lower
+ * bounds, never the DTW distance of an answer. */
+static int cmp_abs_desc_trunc(const kvo_index *o1, const kvo_index *o2) {
+    return (int)(fabs(o2->value) - fabs(o1->value));
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* cNSM-ED phase 2 (K/NormQueryEngine.java:192-198 statistics, :432-528 phase 2).               */
+int64_t kvo_query_cnsm_ed(const double *series, int n, const double *queryData, int queryLength,
+                          const int32_t *left, const int32_t *right, int k, int shift, double epsilon, double alpha,
+                          double beta, int no_abandon, int32_t *out_off, double *out_dist, int64_t cap,
+                          int64_t *stats) {
+    kvo_answers answers = {out_off, out_dist, cap, 0, 0};
+    int64_t cntCandidate = 0, windows = 0, passed = 0, terms = 0;
+
+    /* Phase 0 (K/NormQueryEngine.java:192-198) */
+    double ex = 0, ex2 = 0;
+    for (int i = 0; i < queryLength; i++) {
+        double value = queryData[i];
+        ex += value;
+        ex2 += value * value;
+    }
+    double meanQ = ex / queryLength;
+    double stdQ = sqrt(ex2 / queryLength - meanQ * meanQ);
+
+    /* z-normalise + reorder (:438-452) */
+    double *zQ = (double *)malloc((size_t)queryLength * sizeof(double));
+    for (int i = 0; i < queryLength; i++) zQ[i] = (queryData[i] - meanQ) / stdQ;
+    int *order = (int *)malloc((size_t)queryLength * sizeof(int));
+    kvo_index *Q_tmp = (kvo_index *)malloc((size_t)queryLength * sizeof(kvo_index));
+    for (int i = 0; i < queryLength; i++) {
+        Q_tmp[i].value = zQ[i];
+        Q_tmp[i].index = i;
+    }
+    stable_sort_index(Q_tmp, queryLength, cmp_abs_desc);
+    for (int i = 0; i < queryLength; i++) {
+        zQ[i] = Q_tmp[i].value;
+        order[i] = Q_tmp[i].index;
+    }
+    double *T = (double *)malloc((size_t)2 * queryLength * sizeof(double));
+    int rc = KVO_OK;
+
+    int idx = 0;
+    while (idx < k) {
+        int beginIdx = idx, endIdx = idx;
+
+        int begin = left[idx] - shift;
+        int end = right[idx] - shift + queryLength - 1;
+        if (begin < 1) begin = 1;
+        int length = end - begin + 1;
+        idx++;
+
+        while (idx < k) {
+            begin = left[idx] - shift;
+            int newLength = length + begin - end - 1;
+            end = right[idx] - shift + queryLength - 1;
+            if (end > n) end = n;
+            newLength += end - begin + 1;
+            if (newLength > KVO_MAX_SCAN_DATA_LENGTH) break;
+            endIdx = idx;
+            length = newLength;
+            idx++;
+        }
+
+        begin = left[beginIdx] - shift;
+        end = right[endIdx] - shift + queryLength - 1;
+        if (begin < 1) begin = 1;
+        if (end > n) end = n;
+        const double *data;
+        int dataSize = end - begin + 1;
+        rc = read_time_series(series, n, begin, dataSize, &data);
+        if (rc != KVO_OK) break;
+
+        for (int idx1 = beginIdx; idx1 <= endIdx; idx1++) {
+            cntCandidate += right[idx1] - left[idx1] + 1;
+
+            ex = ex2 = 0;
+            memset(T, 0, (size_t)2 * queryLength * sizeof(double));
+
+            int begin1 = left[idx1] - shift - begin;
+            int end1 = right[idx1] - shift + queryLength - 1 - begin;
+
+            if (begin1 < 0) begin1 = 0;
+            if (end1 > dataSize - 1) end1 = dataSize - 1;
+            for (int i = begin1; i <= end1; i++) {
+                double d = data[i];
+                ex += d;
+                ex2 += d * d;
+                T[i % queryLength] = d;
+                T[(i % queryLength) + queryLength] = d;
+
+                if (i - begin1 >= queryLength - 1) {
+                    int j = (i + 1) % queryLength;
+                    windows++;
+
+                    double mean = ex / queryLength;
+                    double std = sqrt(ex2 / queryLength - mean * mean);
+
+                    if (fabs(mean - meanQ) <= beta && (std / stdQ) <= alpha && (std / stdQ) >= 1.0 / alpha) {
+                        passed++;
+                        double dist = 0;
+                        int kk;
+                        for (kk = 0; kk < queryLength && (no_abandon || dist <= epsilon * epsilon); kk++) {
+                            double x = (T[(order[kk] + j)] - mean) / std;
+                            dist += (x - zQ[kk]) * (x - zQ[kk]);
+                        }
+                        terms += kk;
+                        if (dist <= epsilon * epsilon) {
+                            answers_add(&answers, begin + i - queryLength + 1, sqrt(dist));
+                        }
+                    }
+
+                    ex -= T[j];
+                    ex2 -= T[j] * T[j];
+                }
+            }
+        }
+    }
+    free(zQ);
+    free(order);
+    free(Q_tmp);
+    free(T);
+    if (rc != KVO_OK) return rc;
+    if (answers.overflow) return KVO_ERR_CAPACITY;
+    stable_sort_answers(out_off, out_dist, answers.cnt);
+    if (stats) {
+        memset(stats, 0, KVO_NSTAT * sizeof(int64_t));
+        stats[0] = cntCandidate;
+        stats[1] = answers.cnt;
+        stats[2] = windows;
+        stats[3] = passed;
+        stats[8] = terms;
+    }
+    return answers.cnt;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* RSM-DTW phase 2 (K/QueryEngineDtw.java:349-452).  rho is the already-resolved band half-width */
+/* (K/QueryEngineDtw.java:135-140 resolves r<=1 -> floor(r*m), else floor(r); see kvo_resolve_rho). */
+int64_t kvo_query_rsm_dtw(const double *series, int n, const double *queryData, int length, const int32_t *left,
+                          const int32_t *right, int k, int shift, double epsilon, int rho, int32_t *out_off,
+                          double *out_dist, int64_t cap, int64_t *stats) {
+    kvo_answers answers = {out_off, out_dist, cap, 0, 0};
+    int64_t cntCandidate = 0, windows = 0, pKim = 0, pK1 = 0, pK2 = 0, cells = 0;
+
+    double *Q = (double *)malloc((size_t)length * sizeof(double));
+    for (int i = 0; i < length; i++) Q[i] = queryData[i];
+    double *u = (double *)malloc((size_t)length * sizeof(double));
+    double *l = (double *)malloc((size_t)length * sizeof(double));
+    kvo_lower_upper_lemire(Q, length, rho, l, u);
+    /* the reorder sort is commented out in the reference (:369-372): order = identity */
+    int *order = (int *)malloc((size_t)length * sizeof(int));
+    double *qo = (double *)malloc((size_t)length * sizeof(double));
+    double *uo = (double *)malloc((size_t)length * sizeof(double));
+    double *lo = (double *)malloc((size_t)length * sizeof(double));
+    for (int i = 0; i < length; i++) {
+        int o = i;
+        order[i] = o;
+        qo[i] = Q[o];
+        uo[i] = u[o];
+        lo[i] = l[o];
+    }
+    double *T = (double *)malloc((size_t)2 * length * sizeof(double));
+    double *cb1 = (double *)malloc((size_t)length * sizeof(double));
+    double *cb2 = (double *)malloc((size_t)length * sizeof(double));
+    double *cT = (double *)malloc((size_t)length * sizeof(double));
+    double *cb = (double *)malloc((size_t)length * sizeof(double));
+    int rc = KVO_OK;
+
+    for (int p = 0; p < k; p++) {
+        cntCandidate += right[p] - left[p] + 1;
+
+        int begin = left[p] - shift;
+        int end = right[p] - shift + length - 1;
+        if (begin < 1) begin = 1;
+        if (end > n) end = n;
+        const double *data;
+        int dataSize = end - begin + 1;
+        rc = read_time_series(series, n, begin, dataSize, &data);
+        if (rc != KVO_OK) break;
+        memset(T, 0, (size_t)2 * length * sizeof(double));
+
+        double *uBuff = (double *)malloc((size_t)dataSize * sizeof(double));
+        double *lBuff = (double *)malloc((size_t)dataSize * sizeof(double));
+        kvo_lower_upper_lemire(data, dataSize, rho, lBuff, uBuff);
+
+        for (int i = 0; i < dataSize; i++) {
+            double d = data[i];
+            T[i % length] = d;
+            T[(i % length) + length] = d;
+
+            if (i >= length - 1) {
+                int j = (i + 1) % length;
+                windows++;
+
+                double lbKim = kvo_lb_kim_hierarchy(T, Q, j, length, 0, 1, epsilon * epsilon);
+                if (lbKim <= epsilon * epsilon) {
+                    pKim++;
+                    memset(cb1, 0, (size_t)length * sizeof(double)); /* new double[length] */
+                    double lbK = kvo_lb_keogh_cumulative(order, T, uo, lo, cb1, j, length, 0, 1, epsilon * epsilon);
+                    if (lbK <= epsilon * epsilon) {
+                        pK1++;
+                        memset(cb2, 0, (size_t)length * sizeof(double));
+                        double lbK2 = kvo_lb_keogh_data_cumulative(order, qo, cb2, i - length + 1, lBuff, uBuff,
+                                                                   length, 0, 1, epsilon * epsilon);
+                        if (lbK2 <= epsilon * epsilon) {
+                            pK2++;
+                            memcpy(cT, T + j, (size_t)length * sizeof(double));
+                            if (lbK > lbK2) {
+                                cb[length - 1] = cb1[length - 1];
+                                for (int kk = length - 2; kk >= 0; kk--) cb[kk] = cb[kk + 1] + cb1[kk];
+                            } else {
+                                cb[length - 1] = cb2[length - 1];
+                                for (int kk = length - 2; kk >= 0; kk--) cb[kk] = cb[kk + 1] + cb2[kk];
+                            }
+                            double dist = kvo_dtw(cT, Q, cb, length, rho, epsilon * epsilon, &cells);
+                            if (dist <= epsilon * epsilon) {
+                                answers_add(&answers, begin + i - length + 1, sqrt(dist));
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        free(uBuff);
+        free(lBuff);
+    }
+    free(Q); free(u); free(l); free(order); free(qo); free(uo); free(lo);
+    free(T); free(cb1); free(cb2); free(cT); free(cb);
+    if (rc != KVO_OK) return rc;
+    if (answers.overflow) return KVO_ERR_CAPACITY;
+    stable_sort_answers(out_off, out_dist, answers.cnt);
+    if (stats) {
+        memset(stats, 0, KVO_NSTAT * sizeof(int64_t));
+        stats[0] = cntCandidate;
+        stats[1] = answers.cnt;
+        stats[2] = windows;
+        stats[3] = windows;
+        stats[4] = pKim;
+        stats[5] = pK1;
+        stats[6] = pK2;
+        stats[7] = cells;
+    }
+    return answers.cnt;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* cNSM-DTW phase 2 (K/NormQueryEngineDtw.java:205-211 statistics, :457-603 phase 2).           */
+int64_t kvo_query_cnsm_dtw(const double *series, int n, const double *queryData, int queryLength,
+                           const int32_t *left, const int32_t *right, int k, int shift, double epsilon, int rho,
+                           double alpha, double beta, int32_t *out_off, double *out_dist, int64_t cap,
+                           int64_t *stats) {
+    kvo_answers answers = {out_off, out_dist, cap, 0, 0};
+    int64_t cntCandidate = 0, windows = 0, passed = 0, pKim = 0, pK1 = 0, pK2 = 0, cells = 0;
+
+    double ex = 0, ex2 = 0;
+    for (int i = 0; i < queryLength; i++) {
+        double value = queryData[i];
+        ex += value;
+        ex2 += value * value;
+    }
+    double meanQ = ex / queryLength;
+    double stdQ = sqrt(ex2 / queryLength - meanQ * meanQ);
+
+    double *zQ = (double *)malloc((size_t)queryLength * sizeof(double));
+    for (int i = 0; i < queryLength; i++) zQ[i] = (queryData[i] - meanQ) / stdQ;
+    double *u = (double *)malloc((size_t)queryLength * sizeof(double));
+    double *l = (double *)malloc((size_t)queryLength * sizeof(double));
+    kvo_lower_upper_lemire(zQ, queryLength, rho, l, u);
+    kvo_index *tmpQ = (kvo_index *)malloc((size_t)queryLength * sizeof(kvo_index));
+    for (int i = 0; i < queryLength; i++) {
+        tmpQ[i].value = zQ[i];
+        tmpQ[i].index = i;
+    }
+    stable_sort_index(tmpQ, queryLength, cmp_abs_desc_trunc);
+    int *order = (int *)malloc((size_t)queryLength * sizeof(int));
+    double *qo = (double *)malloc((size_t)queryLength * sizeof(double));
+    double *uo = (double *)malloc((size_t)queryLength * sizeof(double));
+    double *lo = (double *)malloc((size_t)queryLength * sizeof(double));
+    for (int i = 0; i < queryLength; i++) {
+        int o = tmpQ[i].index;
+        order[i] = o;
+        qo[i] = zQ[o];
+        uo[i] = u[o];
+        lo[i] = l[o];
+    }
+    double *T = (double *)malloc((size_t)2 * queryLength * sizeof(double));
+    double *cb1 = (double *)malloc((size_t)queryLength * sizeof(double));
+    double *cb2 = (double *)malloc((size_t)queryLength * sizeof(double));
+    double *zT = (double *)malloc((size_t)queryLength * sizeof(double));
+    double *cb = (double *)malloc((size_t)queryLength * sizeof(double));
+    int rc = KVO_OK;
+
+    int idx = 0;
+    while (idx < k) {
+        int beginIdx = idx, endIdx = idx;
+
+        int begin = left[idx] - shift;
+        int end = right[idx] - shift + queryLength - 1;
+        if (begin < 1) begin = 1;
+        int length = end - begin + 1;
+        idx++;
+
+        while (idx < k) {
+            begin = left[idx] - shift;
+            int newLength = length + begin - end - 1;
+            end = right[idx] - shift + queryLength - 1;
+            if (end > n) end = n;
+            newLength += end - begin + 1;
+            if (newLength > KVO_MAX_SCAN_DATA_LENGTH) break;
+            endIdx = idx;
+            length = newLength;
+            idx++;
+        }
+
+        begin = left[beginIdx] - shift;
+        end = right[endIdx] - shift + queryLength - 1;
+        if (begin < 1) begin = 1;
+        if (end > n) end = n;
+        const double *data;
+        int dataSize = end - begin + 1;
+        rc = read_time_series(series, n, begin, dataSize, &data);
+        if (rc != KVO_OK) break;
+
+        double *uBuff = (double *)malloc((size_t)dataSize * sizeof(double));
+        double *lBuff = (double *)malloc((size_t)dataSize * sizeof(double));
+        kvo_lower_upper_lemire(data, dataSize, rho, lBuff, uBuff);
+
+        for (int idx1 = beginIdx; idx1 <= endIdx; idx1++) {
+            cntCandidate += right[idx1] - left[idx1] + 1;
+
+            ex = ex2 = 0;
+            memset(T, 0, (size_t)2 * queryLength * sizeof(double));
+
+            int begin1 = left[idx1] - shift - begin;
+            int end1 = right[idx1] - shift + queryLength - 1 - begin;
+
+            if (begin1 < 0) begin1 = 0;
+            if (end1 > dataSize - 1) end1 = dataSize - 1;
+            for (int i = begin1; i <= end1; i++) {
+                double d = data[i];
+                ex += d;
+                ex2 += d * d;
+                T[i % queryLength] = d;
+                T[(i % queryLength) + queryLength] = d;
+
+                if (i - begin1 >= queryLength - 1) {
+                    int j = (i + 1) % queryLength;
+                    windows++;
+
+                    double mean = ex / queryLength;
+                    double std = sqrt(ex2 / queryLength - mean * mean);
+
+                    if (fabs(mean - meanQ) <= beta && (std / stdQ) <= alpha && (std / stdQ) >= 1.0 / alpha) {
+                        passed++;
+                        double lbKim = kvo_lb_kim_hierarchy(T, zQ, j, queryLength, mean, std, epsilon * epsilon);
+                        if (lbKim <= epsilon * epsilon) {
+                            pKim++;
+                            memset(cb1, 0, (size_t)queryLength * sizeof(double));
+                            double lbK = kvo_lb_keogh_cumulative(order, T, uo, lo, cb1, j, queryLength, mean, std,
+                                                                 epsilon * epsilon);
+                            if (lbK <= epsilon * epsilon) {
+                                pK1++;
+                                for (int kk = 0; kk < queryLength; kk++) {
+                                    zT[kk] = (T[(kk + j)] - mean) / std;
+                                }
+                                memset(cb2, 0, (size_t)queryLength * sizeof(double));
+                                double lbK2 = kvo_lb_keogh_data_cumulative(order, qo, cb2, i - queryLength + 1, lBuff,
+                                                                           uBuff, queryLength, mean, std,
+                                                                           epsilon * epsilon);
+                                if (lbK2 <= epsilon * epsilon) {
+                                    pK2++;
+                                    if (lbK > lbK2) {
+                                        cb[queryLength - 1] = cb1[queryLength - 1];
+                                        for (int kk = queryLength - 2; kk >= 0; kk--) cb[kk] = cb[kk + 1] + cb1[kk];
+                                    } else {
+                                        cb[queryLength - 1] = cb2[queryLength - 1];
+                                        for (int kk = queryLength - 2; kk >= 0; kk--) cb[kk] = cb[kk + 1] + cb2[kk];
+                                    }
+                                    double dist = kvo_dtw(zT, zQ, cb, queryLength, rho, epsilon * epsilon, &cells);
+                                    if (dist <= epsilon * epsilon) {
+                                        answers_add(&answers, begin + i - queryLength + 1, sqrt(dist));
+                                    }
+                                }
+                            }
+                        }
+                    }
+
+                    ex -= T[j];
+                    ex2 -= T[j] * T[j];
+                }
+            }
+        }
+        free(uBuff);
+        free(lBuff);
+    }
+    free(zQ); free(u); free(l); free(tmpQ); free(order); free(qo); free(uo); free(lo);
+    free(T); free(cb1); free(cb2); free(zT); free(cb);
+    if (rc != KVO_OK) return rc;
+    if (answers.overflow) return KVO_ERR_CAPACITY;
+    stable_sort_answers(out_off, out_dist, answers.cnt);
+    if (stats) {
+        memset(stats, 0, KVO_NSTAT * sizeof(int64_t));
+        stats[0] = cntCandidate;
+        stats[1] = answers.cnt;
+        stats[2] = windows;
+        stats[3] = passed;
+        stats[4] = pKim;
+        stats[5] = pK1;
+        stats[6] = pK2;
+        stats[7] = cells;
+    }
+    return answers.cnt;
+}
+
+/* rho resolution used by every DTW entry point: `r <= 1 -> floor(r*m) else floor(r)`
+ * (K/QueryEngineDtw.java:135-140; K/NormQueryEngineDtw.java has the same prompt logic). */
+int kvo_resolve_rho(double r, int m) {
+    if (r <= 1) return (int)floor(r * m);
+    return (int)floor(r);
+}
+
+/* Query statistics as the cNSM engines compute them (K/NormQueryEngine.java:192-198). */
+void kvo_query_stats(const double *queryData, int m, double *meanQ, double *stdQ) {
+    double ex = 0, ex2 = 0;
+    for (int i = 0; i < m; i++) {
+        ex += queryData[i];
+        ex2 += queryData[i] * queryData[i];
+    }
+    *meanQ = ex / m;
+    *stdQ = sqrt(ex2 / m - (*meanQ) * (*meanQ));
+}
+
+/* Full (unpruned, no early abandon) banded DTW through kvo_dtw: cb = 0, bsf = +inf-ish so the
+ * abandon test never fires.  Used by tests to get the exact DP value of any candidate. */
+double kvo_dtw_full(const double *A, const double *B, int m, int r) {
+    double *cb = (double *)calloc((size_t)m, sizeof(double));
+    double v = kvo_dtw(A, B, cb, m, r, 1e300, NULL);
+    free(cb);
+    return v;
+}

@@ -1,0 +1,207 @@
+"""ctypes wrapper around oracle/libkvm_oracle.so (the C restatement of the reference's phase 2).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+Nothing under kv-match_amd/ may import this module.  PARITY UNPINNED (see kvm_oracle.c header)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libkvm_oracle.so")
+NSTAT = 9
+STAT_NAMES = ["cnt_candidate", "answers", "windows", "pass_filter", "pass_kim", "pass_keogh", "pass_keogh2",
+              "dp_cells", "ed_terms"]
+_lib = None
+
+
+def build(force=False):
+    if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < os.path.getmtime(
+            os.path.join(_HERE, "kvm_oracle.c")):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "libkvm_oracle.so"])
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        build()
+    lib = C.CDLL(os.environ.get("KVM_ORACLE_LIB", LIB_PATH))
+    vp, i32, i64, f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_double
+    common = [vp, i32, vp, i32, vp, vp, i32, i32, f64]  # series, n, q, m, left, right, k, shift, eps
+    tail = [vp, vp, i64, vp]  # out_off, out_dist, cap, stats
+    lib.kvo_query_rsm_ed.restype = i64
+    lib.kvo_query_rsm_ed.argtypes = common + [i32] + tail
+    lib.kvo_query_cnsm_ed.restype = i64
+    lib.kvo_query_cnsm_ed.argtypes = common + [f64, f64, i32] + tail
+    lib.kvo_query_rsm_dtw.restype = i64
+    lib.kvo_query_rsm_dtw.argtypes = common + [i32] + tail
+    lib.kvo_query_cnsm_dtw.restype = i64
+    lib.kvo_query_cnsm_dtw.argtypes = common + [i32, f64, f64] + tail
+    lib.kvo_lower_upper_lemire.restype = None
+    lib.kvo_lower_upper_lemire.argtypes = [vp, i32, i32, vp, vp]
+    lib.kvo_dtw.restype = f64
+    lib.kvo_dtw.argtypes = [vp, vp, vp, i32, i32, f64, vp]
+    lib.kvo_dtw_full.restype = f64
+    lib.kvo_dtw_full.argtypes = [vp, vp, i32, i32]
+    lib.kvo_lb_kim_hierarchy.restype = f64
+    lib.kvo_lb_kim_hierarchy.argtypes = [vp, vp, i32, i32, f64, f64, f64]
+    lib.kvo_lb_keogh_cumulative.restype = f64
+    lib.kvo_lb_keogh_cumulative.argtypes = [vp, vp, vp, vp, vp, i32, i32, f64, f64, f64]
+    lib.kvo_lb_keogh_data_cumulative.restype = f64
+    lib.kvo_lb_keogh_data_cumulative.argtypes = [vp, vp, vp, i32, vp, vp, i32, f64, f64, f64]
+    lib.kvo_decode_be64.restype = None
+    lib.kvo_decode_be64.argtypes = [vp, i64, vp]
+    lib.kvo_encode_be64.restype = None
+    lib.kvo_encode_be64.argtypes = [vp, i64, vp]
+    lib.kvo_read_time_series_file.restype = C.c_int
+    lib.kvo_read_time_series_file.argtypes = [C.c_char_p, i32, i32, i32, vp]
+    lib.kvo_resolve_rho.restype = C.c_int
+    lib.kvo_resolve_rho.argtypes = [f64, i32]
+    lib.kvo_query_stats.restype = None
+    lib.kvo_query_stats.argtypes = [vp, i32, vp, vp]
+    lib.kvo_sort_answers.restype = None
+    lib.kvo_sort_answers.argtypes = [vp, vp, i64]
+    _lib = lib
+    return lib
+
+
+class OracleError(Exception):
+    def __init__(self, code):
+        super().__init__({-2: "IllegalArgumentException", -3: "IOException", -4: "capacity"}.get(code, str(code)))
+        self.code = code
+
+
+def _prep(series, query, left, right):
+    s = np.ascontiguousarray(series, dtype=np.float64)
+    q = np.ascontiguousarray(query, dtype=np.float64)
+    l = np.ascontiguousarray(left, dtype=np.int32)
+    r = np.ascontiguousarray(right, dtype=np.int32)
+    cap = int(np.maximum(r.astype(np.int64) - l + 1, 0).sum()) + 1
+    off = np.empty(cap, dtype=np.int32)
+    dist = np.empty(cap, dtype=np.float64)
+    stats = np.zeros(NSTAT, dtype=np.int64)
+    return s, q, l, r, cap, off, dist, stats
+
+
+def _done(cnt, off, dist, stats):
+    if cnt < 0:
+        raise OracleError(int(cnt))
+    return off[:cnt].copy(), dist[:cnt].copy(), dict(zip(STAT_NAMES, stats.tolist()))
+
+
+def rsm_ed(series, query, left, right, shift, eps, no_abandon=False):
+    s, q, l, r, cap, off, dist, st = _prep(series, query, left, right)
+    cnt = load().kvo_query_rsm_ed(s.ctypes.data, s.size, q.ctypes.data, q.size, l.ctypes.data, r.ctypes.data, l.size,
+                                  int(shift), float(eps), int(no_abandon), off.ctypes.data, dist.ctypes.data, cap,
+                                  st.ctypes.data)
+    return _done(cnt, off, dist, st)
+
+
+def cnsm_ed(series, query, left, right, shift, eps, alpha, beta, no_abandon=False):
+    s, q, l, r, cap, off, dist, st = _prep(series, query, left, right)
+    cnt = load().kvo_query_cnsm_ed(s.ctypes.data, s.size, q.ctypes.data, q.size, l.ctypes.data, r.ctypes.data, l.size,
+                                   int(shift), float(eps), float(alpha), float(beta), int(no_abandon),
+                                   off.ctypes.data, dist.ctypes.data, cap, st.ctypes.data)
+    return _done(cnt, off, dist, st)
+
+
+def rsm_dtw(series, query, left, right, shift, eps, rho):
+    s, q, l, r, cap, off, dist, st = _prep(series, query, left, right)
+    cnt = load().kvo_query_rsm_dtw(s.ctypes.data, s.size, q.ctypes.data, q.size, l.ctypes.data, r.ctypes.data, l.size,
+                                   int(shift), float(eps), int(rho), off.ctypes.data, dist.ctypes.data, cap,
+                                   st.ctypes.data)
+    return _done(cnt, off, dist, st)
+
+
+def cnsm_dtw(series, query, left, right, shift, eps, rho, alpha, beta):
+    s, q, l, r, cap, off, dist, st = _prep(series, query, left, right)
+    cnt = load().kvo_query_cnsm_dtw(s.ctypes.data, s.size, q.ctypes.data, q.size, l.ctypes.data, r.ctypes.data,
+                                    l.size, int(shift), float(eps), int(rho), float(alpha), float(beta),
+                                    off.ctypes.data, dist.ctypes.data, cap, st.ctypes.data)
+    return _done(cnt, off, dist, st)
+
+
+def lower_upper_lemire(t, r):
+    t = np.ascontiguousarray(t, dtype=np.float64)
+    l = np.empty_like(t)
+    u = np.empty_like(t)
+    load().kvo_lower_upper_lemire(t.ctypes.data, t.size, int(r), l.ctypes.data, u.ctypes.data)
+    return l, u
+
+
+def dtw(A, B, cb, r, bsf):
+    A = np.ascontiguousarray(A, dtype=np.float64)
+    B = np.ascontiguousarray(B, dtype=np.float64)
+    cb = np.ascontiguousarray(cb, dtype=np.float64)
+    return load().kvo_dtw(A.ctypes.data, B.ctypes.data, cb.ctypes.data, A.size, int(r), float(bsf), None)
+
+
+def dtw_full(A, B, r):
+    A = np.ascontiguousarray(A, dtype=np.float64)
+    B = np.ascontiguousarray(B, dtype=np.float64)
+    return load().kvo_dtw_full(A.ctypes.data, B.ctypes.data, A.size, int(r))
+
+
+def lb_kim_hierarchy(t, q, j, length, mean, std, bsf):
+    t = np.ascontiguousarray(t, dtype=np.float64)
+    q = np.ascontiguousarray(q, dtype=np.float64)
+    return load().kvo_lb_kim_hierarchy(t.ctypes.data, q.ctypes.data, int(j), int(length), float(mean), float(std),
+                                       float(bsf))
+
+
+def lb_keogh_cumulative(order, t, uo, lo, j, length, mean, std, bsf):
+    order = np.ascontiguousarray(order, dtype=np.int32)
+    t = np.ascontiguousarray(t, dtype=np.float64)
+    uo = np.ascontiguousarray(uo, dtype=np.float64)
+    lo = np.ascontiguousarray(lo, dtype=np.float64)
+    cb = np.zeros(length, dtype=np.float64)
+    lb = load().kvo_lb_keogh_cumulative(order.ctypes.data, t.ctypes.data, uo.ctypes.data, lo.ctypes.data,
+                                        cb.ctypes.data, int(j), int(length), float(mean), float(std), float(bsf))
+    return lb, cb
+
+
+def lb_keogh_data_cumulative(order, qo, I, l, u, length, mean, std, bsf):
+    order = np.ascontiguousarray(order, dtype=np.int32)
+    qo = np.ascontiguousarray(qo, dtype=np.float64)
+    l = np.ascontiguousarray(l, dtype=np.float64)
+    u = np.ascontiguousarray(u, dtype=np.float64)
+    cb = np.zeros(length, dtype=np.float64)
+    lb = load().kvo_lb_keogh_data_cumulative(order.ctypes.data, qo.ctypes.data, cb.ctypes.data, int(I), l.ctypes.data,
+                                             u.ctypes.data, int(length), float(mean), float(std), float(bsf))
+    return lb, cb
+
+
+def decode_be64(raw, count):
+    buf = np.frombuffer(raw, dtype=np.uint8)
+    out = np.empty(count, dtype=np.float64)
+    load().kvo_decode_be64(buf.ctypes.data, int(count), out.ctypes.data)
+    return out
+
+
+def encode_be64(values):
+    v = np.ascontiguousarray(values, dtype=np.float64)
+    out = np.empty(v.size * 8, dtype=np.uint8)
+    load().kvo_encode_be64(v.ctypes.data, v.size, out.ctypes.data)
+    return out.tobytes()
+
+
+def read_time_series_file(path, n, left, length):
+    out = np.empty(max(int(length), 0), dtype=np.float64)
+    rc = load().kvo_read_time_series_file(str(path).encode(), int(n), int(left), int(length), out.ctypes.data)
+    if rc != 0:
+        raise OracleError(rc)
+    return out
+
+
+def resolve_rho(r, m):
+    return load().kvo_resolve_rho(float(r), int(m))
+
+
+def query_stats(q):
+    q = np.ascontiguousarray(q, dtype=np.float64)
+    a, b = C.c_double(), C.c_double()
+    load().kvo_query_stats(q.ctypes.data, q.size, C.byref(a), C.byref(b))
+    return a.value, b.value

@@ -1,0 +1,62 @@
+"""CPU tests: the C-ABI library loads without a GPU and exports every symbol include/kvmatch.h declares;
+no compute entry point is called here."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "kvmatch.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(kvm_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_expected_surface():
+    syms = header_symbols()
+    for s in ("kvm_open", "kvm_verify_rsm_ed", "kvm_verify_cnsm_ed", "kvm_verify_rsm_dtw", "kvm_verify_cnsm_dtw",
+              "kvm_load_series_be64", "kvm_read_time_series", "kvm_result_offsets", "kvm_verify_device"):
+        assert s in syms
+
+
+def test_library_exports_every_declared_symbol(built):
+    from kvmatch import _lib
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    missing = [s for s in header_symbols() if not hasattr(lib, s)]
+    assert not missing, missing
+    assert sorted(_lib.SYMBOLS) == header_symbols()
+    _lib.load()
+    assert _lib.load().kvm_version().startswith(b"kvmatch-hip")
+
+
+def test_resolve_rho_is_host_side(built):
+    from kvmatch import _lib
+    lib = _lib.load()
+    assert lib.kvm_resolve_rho(0.05, 4096) == 204   # K/QueryEngineDtw.java:135-140
+    assert lib.kvm_resolve_rho(1.0, 100) == 100
+    assert lib.kvm_resolve_rho(12.7, 100) == 12
+
+
+def test_product_never_imports_oracle():
+    """The product path must not route through the oracle (or any CPU fallback)."""
+    bad = []
+    for base, _, files in os.walk(os.path.join(ROOT, "kv-match_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h", ".hpp", "Makefile")):
+                txt = open(os.path.join(base, f), errors="ignore").read()
+                if re.search(r"^\s*(import|from)\s+oracle\b", txt, flags=re.M) or "kvm_oracle" in txt \
+                        or "libkvm_oracle" in txt:
+                    bad.append(os.path.join(base, f))
+    assert not bad, bad
+
+
+def test_open_fails_loudly_without_gpu(built):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import kvmatch
+    with pytest.raises(kvmatch.KvMatchDeviceError):
+        kvmatch.Phase2Context(0)

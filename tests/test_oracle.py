@@ -1,0 +1,203 @@
+"""CPU tests (-m "not gpu"): the C oracle against independent brute-force implementations and against the
+invariants the reference itself relies on (self-match == 0, full-scan semantics)."""
+import numpy as np
+import pytest
+
+import bruteforce as bf
+import oracle
+
+
+@pytest.fixture(scope="module")
+def data(series_small):
+    return series_small[:60_000].copy()
+
+
+def test_lemire_equals_clipped_sliding_minmax(built):
+    rng = np.random.default_rng(1)
+    for trial in range(200):
+        n = int(rng.integers(2, 200))
+        r = int(rng.integers(0, max(1, n - 1)))
+        if trial % 3 == 0:
+            t = rng.integers(0, 4, n).astype(np.float64)  # heavy ties
+        else:
+            t = rng.standard_normal(n)
+        l, u = oracle.lower_upper_lemire(t, r)
+        l2, u2 = bf.envelope_naive(t, r)
+        assert np.array_equal(l, l2) and np.array_equal(u, u2), (n, r)
+
+
+def test_dtw_matches_full_matrix(built):
+    rng = np.random.default_rng(2)
+    for _ in range(60):
+        m = int(rng.integers(2, 60))
+        r = int(rng.integers(0, m + 3))
+        A, B = rng.standard_normal(m), rng.standard_normal(m)
+        got = oracle.dtw_full(A, B, r)
+        want = bf.banded_dtw_full(A, B, r)
+        assert got == want, (m, r, got, want)  # same cell operations -> bit-identical
+
+
+def test_dtw_early_abandon_only_when_above_bsf(built):
+    rng = np.random.default_rng(3)
+    for _ in range(100):
+        m = int(rng.integers(8, 50))
+        r = int(rng.integers(1, m // 2 + 1))
+        A, B = rng.standard_normal(m), rng.standard_normal(m)
+        full = oracle.dtw_full(A, B, r)
+        bsf = full * rng.uniform(0.3, 1.5)
+        v = oracle.dtw(A, B, np.zeros(m), r, bsf)
+        if full < bsf:
+            assert v == full
+        else:
+            assert v >= bsf
+
+
+def test_lower_bounds_are_lower_bounds(built):
+    rng = np.random.default_rng(4)
+    for _ in range(60):
+        m = int(rng.integers(8, 64))
+        r = int(rng.integers(1, m // 2 + 1))
+        t = rng.standard_normal(m) * 2 + 1
+        q = rng.standard_normal(m)
+        mean, std = bf.znorm_stats(t)
+        zt = (t - mean) / std
+        full = oracle.dtw_full(zt, q, r)
+        kim = oracle.lb_kim_hierarchy(t, q, 0, m, mean, std, 1e300)
+        ql, qu = oracle.lower_upper_lemire(q, r)
+        order = np.arange(m, dtype=np.int32)
+        k1, cb1 = oracle.lb_keogh_cumulative(order, t, qu, ql, 0, m, mean, std, 1e300)
+        tl, tu = oracle.lower_upper_lemire(t, r)
+        k2, cb2 = oracle.lb_keogh_data_cumulative(order, q, 0, tl, tu, m, mean, std, 1e300)
+        eps = 1e-9 * max(1.0, full)
+        assert kim <= full + eps and k1 <= full + eps and k2 <= full + eps
+        assert abs(cb1.sum() - k1) < 1e-9 and abs(cb2.sum() - k2) < 1e-9
+
+
+def _all_offsets(n, m):
+    return np.array([1], dtype=np.int32), np.array([n - m + 1], dtype=np.int32)
+
+
+@pytest.mark.parametrize("m,eps", [(64, 3.0), (200, 12.0)])
+def test_rsm_ed_full_scan_semantics(data, m, eps):
+    s = data[:6000]
+    q = s[1234:1234 + m].copy()
+    L, R = _all_offsets(len(s), m)
+    off, dist, st = oracle.rsm_ed(s, q, L, R, 0, eps)
+    want = bf.answers_rsm_ed(s, q, L, R, 0, eps)
+    assert sorted(off.tolist()) == sorted(o for o, _ in want)
+    d = dict(want)
+    assert all(abs(d[o] - x) <= 1e-9 * max(1, x) for o, x in zip(off.tolist(), dist.tolist()))
+    assert off[0] == 1235 and dist[0] == 0.0  # self-match (README.md:73)
+    assert np.all(np.diff(dist) >= 0)
+    assert st["cnt_candidate"] == len(s) - m + 1 == st["windows"]
+    off2, dist2, st2 = oracle.rsm_ed(s, q, L, R, 0, eps, no_abandon=True)
+    assert np.array_equal(off, off2) and np.array_equal(dist, dist2)
+    assert st2["ed_terms"] == st2["windows"] * m >= st["ed_terms"]
+
+
+@pytest.mark.parametrize("alpha,beta", [(1.1, 1.0), (2.0, 10.0)])
+def test_cnsm_ed_full_scan_semantics(data, alpha, beta):
+    s = data[:6000]
+    m = 128
+    q = s[3000:3000 + m].copy()
+    L, R = _all_offsets(len(s), m)
+    off, dist, st = oracle.cnsm_ed(s, q, L, R, 0, 4.0, alpha, beta)
+    want = bf.answers_cnsm_ed(s, q, L, R, 0, 4.0, alpha, beta)
+    assert sorted(off.tolist()) == sorted(o for o, _ in want)
+    d = dict(want)
+    assert all(abs(d[o] - x) <= 1e-6 * max(1, x) for o, x in zip(off.tolist(), dist.tolist()))
+    assert off[0] == 3001 and dist[0] < 1e-6
+
+
+def test_dtw_engines_equal_bruteforce_answer_set(data):
+    """answer set == {filter-passing windows with full banded DTW <= eps^2} (SURVEY 8a semantic fact (i))."""
+    s = data[10_000:13_000]
+    m, rho, eps = 48, 4, 2.5
+    q = s[700:700 + m].copy()
+    L, R = _all_offsets(len(s), m)
+    off, dist, st = oracle.rsm_dtw(s, q, L, R, 0, eps, rho)
+    want = {}
+    for st_ in range(1, len(s) - m + 2):
+        v = oracle.dtw_full(s[st_ - 1: st_ - 1 + m], q, rho)
+        if v <= eps * eps:
+            want[st_] = np.sqrt(v)
+    assert sorted(off.tolist()) == sorted(want)
+    assert all(want[o] == x for o, x in zip(off.tolist(), dist.tolist()))  # RSM: bit-identical DP
+    assert 701 in off.tolist()
+    # cNSM
+    alpha, beta = 1.5, 3.0
+    off, dist, st = oracle.cnsm_dtw(s, q, L, R, 0, eps, rho, alpha, beta)
+    mq, sq = bf.znorm_stats(q)
+    zq = (q - mq) / sq
+    want = {}
+    for st_ in range(1, len(s) - m + 2):
+        w = s[st_ - 1: st_ - 1 + m]
+        mean, std = bf.znorm_stats(w)
+        if abs(mean - mq) <= beta and std / sq <= alpha and std / sq >= 1 / alpha:
+            v = oracle.dtw_full((w - mean) / std, zq, rho)
+            if v <= eps * eps:
+                want[st_] = np.sqrt(v)
+    assert sorted(off.tolist()) == sorted(want)
+    assert all(abs(want[o] - x) <= 1e-6 * max(1.0, x) for o, x in zip(off.tolist(), dist.tolist()))
+    assert st["pass_filter"] >= st["pass_kim"] >= st["pass_keogh"] >= st["pass_keogh2"] >= len(off)
+
+
+def test_interval_clipping_and_shift(data):
+    """begin/end clipping and the (lastSegment-1)*25 shift of K/QueryEngine.java:346-349."""
+    s = data[:3000]
+    m = 100
+    q = s[0:m].copy()
+    left = np.array([10, 2900], dtype=np.int32)   # after shift=50: [-40.. ] clipped to 1; tail clipped to n-m+1
+    right = np.array([60, 3000], dtype=np.int32)
+    off, dist, st = oracle.rsm_ed(s, q, left, right, 50, 1e9)
+    assert st["cnt_candidate"] == (60 - 10 + 1) + (3000 - 2900 + 1)
+    starts = bf.window_starts(left, right, 50, len(s), m)
+    assert sorted(off.tolist()) == starts.tolist()
+    assert starts[0] == 1 and starts[-1] == len(s) - m + 1
+    # an interval entirely beyond the series -> IllegalArgumentException from readTimeSeries
+    with pytest.raises(oracle.OracleError) as e:
+        oracle.rsm_ed(s, q, np.array([4000], dtype=np.int32), np.array([4010], dtype=np.int32), 0, 1.0)
+    assert e.value.code == -2
+
+
+def test_empty_interval_list(data):
+    s = data[:1000]
+    q = s[:50].copy()
+    e = np.empty(0, dtype=np.int32)
+    for fn, extra in ((oracle.rsm_ed, ()), (oracle.cnsm_ed, (1.5, 1.0)), (oracle.rsm_dtw, (3,)),
+                      (oracle.cnsm_dtw, (3, 1.5, 1.0))):
+        off, dist, st = fn(s, q, e, e, 0, 1.0, *extra)
+        assert len(off) == 0 and st["cnt_candidate"] == 0
+
+
+def test_be64_codec_and_file_reader(tmp_path, data):
+    from kvmatch import datagen
+    s = data[:3456]
+    raw = oracle.encode_be64(s)
+    assert np.array_equal(oracle.decode_be64(raw, len(s)), s)
+    assert raw[:8] == np.array([s[0]], dtype=">f8").tobytes()
+    p = tmp_path / "data-3456"
+    datagen.write_series_file(p, s)
+    assert p.read_bytes() == raw
+    for left, length in ((1, 10), (995, 20), (1000, 1), (1001, 1000), (2000, 1456), (3456, 1)):
+        got = oracle.read_time_series_file(p, len(s), left, length)
+        assert np.array_equal(got, s[left - 1:left - 1 + length]), (left, length)
+    with pytest.raises(oracle.OracleError):
+        oracle.read_time_series_file(p, len(s), 0, 5)
+    with pytest.raises(oracle.OracleError):
+        oracle.read_time_series_file(p, len(s), 3450, 10)
+
+
+def test_resolve_rho(built):
+    assert oracle.resolve_rho(0.05, 4096) == 204
+    assert oracle.resolve_rho(1.0, 100) == 100
+    assert oracle.resolve_rho(7.9, 100) == 7
+
+
+def test_generator_distribution(built):
+    from kvmatch import datagen
+    a = datagen.gen_series(300_000, seed=5)
+    b = datagen.gen_series(300_000, seed=5)
+    c = datagen.gen_series(300_000, seed=6)
+    assert np.array_equal(a, b) and not np.array_equal(a, c)
+    assert np.isfinite(a).all() and a.std() > 0.5 and np.abs(a).max() < 5000

@@ -1,0 +1,217 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI, against the CPU oracle on the same seeded
+inputs.  Bar: identical answer offsets and #answers, cntCandidate identical, distances within 1e-6 relative
+(absolute floor 1e-9); RSM-DTW distances bit-identical (same cell operations on the same inputs)."""
+import numpy as np
+import pytest
+
+import oracle
+from conftest import rel_close
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def world(built):
+    import kvmatch
+    from kvmatch import datagen
+    n = 300_000
+    series = datagen.gen_series(n, seed=777)
+    ctx = kvmatch.Phase2Context(0)
+    ctx.load_series(series)
+    yield kvmatch, datagen, series, ctx
+    ctx.close()
+
+
+def compare(got, want, exact=False, tag=""):
+    o_off, o_dist, o_st = want
+    assert got.cnt_candidate == o_st["cnt_candidate"], tag
+    assert len(got) == len(o_off), (tag, len(got), len(o_off))
+    assert sorted(got.offsets.tolist()) == sorted(o_off.tolist()), tag
+    od = dict(zip(o_off.tolist(), o_dist.tolist()))
+    ref = np.array([od[o] for o in got.offsets.tolist()])
+    if exact:
+        assert np.array_equal(ref, got.distances), tag
+        assert np.array_equal(got.offsets, o_off), tag  # identical order too
+    else:
+        assert rel_close(got.distances, ref), tag
+    assert np.all(np.diff(got.distances) >= 0), tag  # sorted by distance (K/QueryEngine.java:373)
+    assert got.stats[0] == o_st["windows"], tag
+
+
+def planted(world, m, qoff=123_456, seed=11):
+    kvmatch, datagen, series, ctx = world
+    s = series.copy()
+    q = datagen.plant_copies(s, qoff, m, [40_000, 200_000, 250_000], [1.0, 1.2, 0.8], [0.0, 0.5, -1.0], 0.02,
+                             seed=seed)
+    ctx.load_series(s)
+    L, R = datagen.gen_intervals(len(s), m, 30_000, 48.0, must_cover=[qoff, 40_000, 200_000, 250_000], seed=seed)
+    return s, q, L, R
+
+
+@pytest.mark.parametrize("m,eps", [(64, 2.0), (1000, 6.0), (1024, 10.0), (4097, 12.0)])
+def test_rsm_ed(world, m, eps):
+    kvmatch = world[0]
+    s, q, L, R = planted(world, m)
+    got = kvmatch.QueryEngine(world[3]).verify((L, R), 1, q, eps)
+    compare(got, oracle.rsm_ed(s, q, L, R, 0, eps), tag=f"rsm_ed m={m}")
+    assert got.offsets[0] == 123_456 and got.distances[0] == 0.0  # self-match, README.md:73
+    assert len(got) >= 2
+
+
+@pytest.mark.parametrize("m,eps,alpha,beta", [(128, 3.0, 1.5, 2.0), (1024, 8.0, 1.1, 1.0), (2500, 10.0, 2.0, 10.0)])
+def test_cnsm_ed(world, m, eps, alpha, beta):
+    kvmatch = world[0]
+    s, q, L, R = planted(world, m)
+    got = kvmatch.NormQueryEngine(world[3]).verify((L, R), 1, q, eps, alpha, beta)
+    want = oracle.cnsm_ed(s, q, L, R, 0, eps, alpha, beta)
+    compare(got, want, tag=f"cnsm_ed m={m}")
+    assert got.stats[1] == want[2]["pass_filter"]
+    assert 123_456 in got.offsets.tolist() and len(got) >= 2
+
+
+@pytest.mark.parametrize("m,eps,rho", [(64, 2.0, 3), (256, 4.0, 0.05), (512, 6.0, 25), (300, 5.0, 0), (129, 3.0, 200)])
+def test_rsm_dtw(world, m, eps, rho):
+    kvmatch = world[0]
+    s, q, L, R = planted(world, m)
+    got = kvmatch.QueryEngineDtw(world[3]).verify((L, R), 1, q, eps, rho)
+    want = oracle.rsm_dtw(s, q, L, R, 0, eps, oracle.resolve_rho(rho, m))
+    compare(got, want, exact=True, tag=f"rsm_dtw m={m} rho={rho}")
+    assert 123_456 in got.offsets.tolist()
+
+
+@pytest.mark.parametrize("m,eps,rho,alpha,beta", [(128, 3.0, 6, 1.5, 2.0), (512, 6.0, 0.05, 1.3, 1.5),
+                                                  (1024, 8.0, 51, 2.0, 10.0)])
+def test_cnsm_dtw(world, m, eps, rho, alpha, beta):
+    kvmatch = world[0]
+    s, q, L, R = planted(world, m)
+    got = kvmatch.NormQueryEngineDtw(world[3]).verify((L, R), 1, q, eps, rho, alpha, beta)
+    want = oracle.cnsm_dtw(s, q, L, R, 0, eps, oracle.resolve_rho(rho, m), alpha, beta)
+    compare(got, want, tag=f"cnsm_dtw m={m}")
+    assert got.stats[1] == want[2]["pass_filter"]
+    assert 123_456 in got.offsets.tolist() and len(got) >= 2
+
+
+def test_all_offsets_equals_full_scan(world):
+    """candidates = every offset: engine semantics == CsvTester / UCR full-scan semantics."""
+    kvmatch, datagen, series, ctx = world
+    s = series[:50_000].copy()
+    m = 200
+    q = datagen.plant_copies(s, 7_777, m, [30_000], [1.0], [0.0], 0.05)
+    ctx.load_series(s)
+    L = np.array([1], dtype=np.int32)
+    R = np.array([len(s) - m + 1], dtype=np.int32)
+    compare(kvmatch.QueryEngine(ctx).verify((L, R), 1, q, 4.0), oracle.rsm_ed(s, q, L, R, 0, 4.0), tag="full rsm_ed")
+    compare(kvmatch.NormQueryEngine(ctx).verify((L, R), 1, q, 3.0, 1.5, 2.0),
+            oracle.cnsm_ed(s, q, L, R, 0, 3.0, 1.5, 2.0), tag="full cnsm_ed")
+    compare(kvmatch.QueryEngineDtw(ctx).verify((L, R), 1, q, 4.0, 10), oracle.rsm_dtw(s, q, L, R, 0, 4.0, 10),
+            exact=True, tag="full rsm_dtw")
+    compare(kvmatch.NormQueryEngineDtw(ctx).verify((L, R), 1, q, 3.0, 10, 1.5, 2.0),
+            oracle.cnsm_dtw(s, q, L, R, 0, 3.0, 10, 1.5, 2.0), tag="full cnsm_dtw")
+
+
+def test_shift_clipping_empty_and_errors(world):
+    kvmatch, datagen, series, ctx = world
+    s = series[:20_000].copy()
+    ctx.load_series(s)
+    m = 100
+    q = s[:m].copy()
+    left = np.array([10, 5000, 19_950], dtype=np.int32)
+    right = np.array([60, 5100, 20_040], dtype=np.int32)
+    for last_segment in (1, 3):
+        shift = (last_segment - 1) * 25
+        compare(kvmatch.QueryEngine(ctx).verify((left, right), last_segment, q, 1e9),
+                oracle.rsm_ed(s, q, left, right, shift, 1e9), tag=f"clip ls={last_segment}")
+        compare(kvmatch.NormQueryEngine(ctx).verify((left, right), last_segment, q, 1e9, 100.0, 1e9),
+                oracle.cnsm_ed(s, q, left, right, shift, 1e9, 100.0, 1e9), tag=f"clip cnsm ls={last_segment}")
+    e = np.empty(0, dtype=np.int32)
+    for eng, args in ((kvmatch.QueryEngine, (1.0,)), (kvmatch.NormQueryEngine, (1.0, 1.5, 1.0)),
+                      (kvmatch.QueryEngineDtw, (1.0, 3)), (kvmatch.NormQueryEngineDtw, (1.0, 3, 1.5, 1.0))):
+        a = eng(ctx).verify((e, e), 1, q, *args)
+        assert len(a) == 0 and a.cnt_candidate == 0
+    # interval wholly beyond the series: IllegalArgumentException, as readTimeSeries throws
+    with pytest.raises(kvmatch.KvMatchIllegalArgument):
+        kvmatch.QueryEngine(ctx).verify(([30_000], [30_010]), 1, q, 1.0)
+    with pytest.raises(oracle.OracleError):
+        oracle.rsm_ed(s, q, [30_000], [30_010], 0, 1.0)
+    # readTimeSeries range errors (K/operator/file/TimeSeriesFileOperator.java:55-57)
+    assert np.array_equal(ctx.read_time_series(101, 50), s[100:150])
+    for left_, len_ in ((0, 5), (19_999, 3), (5, 0)):
+        with pytest.raises(kvmatch.KvMatchIllegalArgument):
+            ctx.read_time_series(left_, len_)
+
+
+def test_knobs_do_not_change_answers(world):
+    kvmatch = world[0]
+    ctx = world[3]
+    s, q, L, R = planted(world, 256)
+    base_ed = kvmatch.QueryEngine(ctx).verify((L, R), 1, q, 5.0)
+    base_dtw = kvmatch.NormQueryEngineDtw(ctx).verify((L, R), 1, q, 4.0, 12, 1.5, 2.0)
+    try:
+        ctx.set_option(kvmatch.OPT_EARLY_ABANDON, 0)
+        ctx.set_option(kvmatch.OPT_LB_CASCADE, 0)
+        a = kvmatch.QueryEngine(ctx).verify((L, R), 1, q, 5.0)
+        b = kvmatch.NormQueryEngineDtw(ctx).verify((L, R), 1, q, 4.0, 12, 1.5, 2.0)
+    finally:
+        ctx.set_option(kvmatch.OPT_EARLY_ABANDON, 1)
+        ctx.set_option(kvmatch.OPT_LB_CASCADE, 1)
+    assert np.array_equal(a.offsets, base_ed.offsets) and rel_close(a.distances, base_ed.distances)
+    assert np.array_equal(b.offsets, base_dtw.offsets) and np.array_equal(b.distances, base_dtw.distances)
+    for k in (1, 2):
+        ctx.set_option(kvmatch.OPT_ED_KERNEL, k)
+        try:
+            a = kvmatch.QueryEngine(ctx).verify((L, R), 1, q, 5.0)
+            c = kvmatch.NormQueryEngine(ctx).verify((L, R), 1, q, 4.0, 1.5, 2.0)
+        finally:
+            ctx.set_option(kvmatch.OPT_ED_KERNEL, 0)
+        assert np.array_equal(a.offsets, base_ed.offsets) and rel_close(a.distances, base_ed.distances)
+        compare(c, oracle.cnsm_ed(s, q, L, R, 0, 4.0, 1.5, 2.0), tag=f"ed kernel {k}")
+
+
+def test_series_loaders_agree(world, tmp_path):
+    """big-endian bytes / files/data-{N} / native array all stage the same series (a18)."""
+    kvmatch, datagen, series, ctx = world
+    s = series[:12_345].copy()
+    p = tmp_path / "data-12345"
+    datagen.write_series_file(p, s)
+    raw = p.read_bytes()
+    assert raw == oracle.encode_be64(s)
+    for loader in (lambda: ctx.load_series(s), lambda: ctx.load_series_be64(raw, len(s)),
+                   lambda: ctx.load_series_file(p, len(s))):
+        loader()
+        assert ctx.n == len(s)
+        assert np.array_equal(ctx.read_time_series(1, len(s)), s)
+    with pytest.raises(kvmatch.KvMatchIOError):
+        ctx.load_series_file(tmp_path / "nope", 10)
+
+
+def test_attach_torch_device_series(world):
+    import torch
+    kvmatch, datagen, series, ctx = world
+    s = series[:40_000].copy()
+    t = torch.from_numpy(s).to("cuda:0")
+    ctx2 = kvmatch.Phase2Context(0)
+    try:
+        ctx2.attach_device_series(t.data_ptr(), t.numel(), keepalive=t)
+        m = 128
+        q = s[999:999 + m].copy()
+        L, R = datagen.gen_intervals(len(s), m, 5000, 16.0, must_cover=[1000], seed=2)
+        compare(kvmatch.NormQueryEngine(ctx2).verify((L, R), 1, q, 3.0, 1.5, 2.0),
+                oracle.cnsm_ed(s, q, L, R, 0, 3.0, 1.5, 2.0), tag="attached")
+    finally:
+        ctx2.close()
+
+
+def test_prefix_sums_accuracy_far_from_origin(world):
+    """mu/sigma from block-restarted prefix sums stay accurate deep into a long random-walk stretch
+    (SURVEY 7 'hard parts'): cNSM answers late in the series still match the oracle."""
+    kvmatch, datagen, series, ctx = world
+    rng = np.random.default_rng(5)
+    s = np.cumsum(rng.uniform(-1, 1, 400_000)) + 3000.0  # |x| ~ 3000: sum x^2 ~ 1e7 per point
+    m = 1024
+    qoff = 390_000
+    q = datagen.plant_copies(s, qoff, m, [16_000, 100_000], [1.0, 1.1], [0.0, 3.0], 0.01)
+    ctx.load_series(s)
+    L, R = datagen.gen_intervals(len(s), m, 20_000, 32.0, must_cover=[qoff, 16_000, 100_000, 16_384 - 512], seed=9)
+    got = kvmatch.NormQueryEngine(ctx).verify((L, R), 1, q, 2.0, 1.5, 5.0)
+    compare(got, oracle.cnsm_ed(s, q, L, R, 0, 2.0, 1.5, 5.0), tag="far prefix")
+    assert len(got) >= 3
