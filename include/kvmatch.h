@@ -74,8 +74,9 @@ int kvm_load_series_be64(kvm_ctx *ctx, const void *be_bytes, int64_t n);
 /* Same, reading files/data-{N} (K/operator/file/TimeSeriesFileOperator.java:50-52). */
 int kvm_load_series_file(kvm_ctx *ctx, const char *path, int64_t n);
 
-/* Borrow an fp64 array already resident in this device's memory (e.g. a torch tensor's
- * data_ptr()).  The caller keeps it alive until kvm_close or the next load. */
+/* Stage from an fp64 array already resident in this device's memory (e.g. a torch tensor's
+ * data_ptr()): one device-to-device copy into the ctx's padded buffer; the caller's array is not
+ * referenced after the call returns. */
 int kvm_attach_series_device(kvm_ctx *ctx, const double *device_values, int64_t n);
 
 int64_t kvm_series_length(const kvm_ctx *ctx);

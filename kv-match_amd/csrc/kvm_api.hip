@@ -18,7 +18,8 @@
 #include "kvm_internal.h"
 
 #define KVM_MAX_SCAN_DATA_LENGTH 40000  // K/NormQueryEngine.java:60, K/NormQueryEngineDtw.java:61
-#define KVM_TILE_MAX 64                 // candidates per tile (== ED_TILE_MAX in kvm_ed.hip)
+#define KVM_TILE_MAX 64                 // candidates per tile: wave ED kernel, DTW filter (one lane each)
+#define KVM_TILE_TILED 32               // candidates per tile of the LDS-tiled ED kernel (== ED_ROW_CAND)
 
 static thread_local std::string g_open_err;
 
@@ -165,7 +166,9 @@ static int alloc_series(kvm_ctx *ctx, int64_t n) {
         return fail(ctx, KVM_ERR_ILLEGAL_ARGUMENT, "series length must be in [1, 2^31-1]");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     free_series(ctx);
-    HIPCHK(ctx, hipMalloc((void **)&ctx->d_series, (size_t)n * sizeof(double)));
+    // KVM_SERIES_PAD zero points past n let the tile kernels stage whole rows without bounds checks
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_series, (size_t)(n + KVM_SERIES_PAD) * sizeof(double)));
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_series + n, 0, (size_t)KVM_SERIES_PAD * sizeof(double), ctx->stream));
     ctx->own_series = true;
     ctx->n = n;
     return KVM_OK;
@@ -211,13 +214,11 @@ extern "C" int kvm_load_series_file(kvm_ctx *ctx, const char *path, int64_t n) {
 extern "C" int kvm_attach_series_device(kvm_ctx *ctx, const double *device_values, int64_t n) {
     if (!ctx) return KVM_ERR_INVALID_HANDLE;
     if (!device_values || n < 1 || n > 2147483647LL) return fail(ctx, KVM_ERR_ILLEGAL_ARGUMENT, "bad device series");
-    if (((uintptr_t)device_values & 31) != 0)
-        return fail(ctx, KVM_ERR_ILLEGAL_ARGUMENT, "device series must be 32-byte aligned");
-    HIPCHK(ctx, hipSetDevice(ctx->device));
-    free_series(ctx);
-    ctx->d_series = const_cast<double *>(device_values);
-    ctx->own_series = false;
-    ctx->n = n;
+    // device-to-device copy into the ctx's own padded buffer (see alloc_series); the caller's array is not
+    // referenced after this call returns
+    int rc = alloc_series(ctx, n);
+    if (rc) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_series, device_values, (size_t)n * 8, hipMemcpyDeviceToDevice, ctx->stream));
     return finish_load(ctx);
 }
 
@@ -255,7 +256,7 @@ struct plan {
 // Window start offsets of interval [left,right]: max(1,left-shift) .. min(right-shift, n-m+1)
 // (K/QueryEngine.java:346-354: begin/end clipping, loop `i + length - 1 < data.size()`).
 static int build_plan(kvm_ctx *ctx, bool cnsm, int32_t m, const int32_t *left, const int32_t *right, int32_t k,
-                      int32_t shift, plan &pl) {
+                      int32_t shift, int32_t tile_max, plan &pl) {
     const int64_t n = ctx->n;
     if (!cnsm) {
         // RSM engines fetch per interval: readTimeSeries(begin, end-begin+1) throws when the clipped range is
@@ -309,10 +310,10 @@ static int build_plan(kvm_ctx *ctx, bool cnsm, int32_t m, const int32_t *left, c
         int64_t lo = (int64_t)left[p] - shift, hi = (int64_t)right[p] - shift;
         if (lo < 1) lo = 1;
         if (hi > n - m + 1) hi = n - m + 1;
-        for (int64_t s = lo; s <= hi; s += KVM_TILE_MAX) {
+        for (int64_t s = lo; s <= hi; s += tile_max) {
             kvm_tile t;
             t.start = (int32_t)s;
-            t.count = (int32_t)std::min<int64_t>(KVM_TILE_MAX, hi - s + 1);
+            t.count = (int32_t)std::min<int64_t>(tile_max, hi - s + 1);
             pl.tiles.push_back(t);
             pl.windows += t.count;
         }
@@ -379,7 +380,10 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
     if (cnsm && !(alpha > 0)) return fail(ctx, KVM_ERR_ILLEGAL_ARGUMENT, "alpha must be > 0");
     if (dtw && rho < 0) return fail(ctx, KVM_ERR_ILLEGAL_ARGUMENT, "rho must be >= 0");
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    int rc = build_plan(ctx, cnsm, m, left, right, k, shift, pl);
+    // ED kernel choice: 1 = wave-per-candidate, 2 (and auto) = LDS-tiled
+    const int ed_kernel = ctx->opt_ed_kernel == 1 ? 1 : 2;
+    int rc = build_plan(ctx, cnsm, m, left, right, k, shift, (!dtw && ed_kernel == 2) ? KVM_TILE_TILED : KVM_TILE_MAX,
+                        pl);
     if (rc) return rc;
 
     // ---- query-side constants (host, sequential, exactly the reference's arithmetic) ----
@@ -411,7 +415,8 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
     const size_t tbytes = pl.tiles.size() * sizeof(kvm_tile);
     rc = ensure_pinned(ctx, qbytes + tbytes + 64);
     if (rc) return rc;
-    if ((rc = ensure(ctx, ctx->b_query, qbytes + 64))) return rc;
+    // KVM_SERIES_PAD spare doubles: the tiled ED kernel stages whole query chunks without bounds checks
+    if ((rc = ensure(ctx, ctx->b_query, qbytes + KVM_SERIES_PAD * sizeof(double)))) return rc;
     if ((rc = ensure(ctx, ctx->b_tiles, tbytes + 64))) return rc;
     if ((rc = ensure(ctx, ctx->b_counters, KVM_CNT_TOTAL * sizeof(unsigned long long)))) return rc;
     char *hp = (char *)ctx->h_pinned;
@@ -437,9 +442,7 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
 
     if (ctx->opt_timing) HIPCHK(ctx, hipEventRecord(ctx->ev0, stream));
     if (!dtw) {
-        int which = (int)ctx->opt_ed_kernel;
-        if (which == 0) which = 1;  // auto -> wave kernel until the tiled kernel is selected by the planner
-        if (which == 2)
+        if (ed_kernel == 2)
             HIPCHK(ctx, kvm_launch_ed_tiled(ctx->d_series, ctx->d_prefix, ctx->n, qd, d_tiles, n_tiles, out.d_off,
                                             out.d_dist, out.cap, counters, stream));
         else

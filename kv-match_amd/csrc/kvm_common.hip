@@ -27,7 +27,8 @@ hipError_t kvm_launch_bswap64(uint64_t *d, int64_t n, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Block-restarted inclusive prefix sums of x and x*x (see KVM_PS_BLOCK in kvm_internal.h).
+// Block-restarted inclusive prefix sums of (x - c_b) and (x - c_b)^2, c_b = first point of the block
+// (see KVM_PS_BLOCK in kvm_internal.h).
 // One workgroup scans one block of 16384 points as 16 sub-tiles of 1024 (4 consecutive points per
 // thread: 32 B loads, 64 B stores per lane).  Blocks are independent, so this is a one-pass kernel:
 // 8 B read + 16 B written per point.
@@ -37,16 +38,17 @@ __global__ __launch_bounds__(256) void kvm_prefix_kernel(const double *__restric
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t base = (int64_t)blockIdx.x << KVM_PS_BLOCK_LOG2;
     double carry1 = 0.0, carry2 = 0.0;
+    const double shift = x[base];  // c_b
     for (int sub = 0; sub < KVM_PS_BLOCK / 1024; sub++) {
         const int64_t i0 = base + sub * 1024 + tid * 4;
         if (base + sub * 1024 >= n) break;  // uniform across the workgroup
         double v[4];
         if (i0 + 3 < n) {
             const double4 t = *reinterpret_cast<const double4 *>(x + i0);
-            v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+            v[0] = t.x - shift; v[1] = t.y - shift; v[2] = t.z - shift; v[3] = t.w - shift;
         } else {
 #pragma unroll
-            for (int c = 0; c < 4; c++) v[c] = (i0 + c < n) ? x[i0 + c] : 0.0;
+            for (int c = 0; c < 4; c++) v[c] = (i0 + c < n) ? x[i0 + c] - shift : 0.0;
         }
         double a1[4], a2[4];
         a1[0] = v[0];

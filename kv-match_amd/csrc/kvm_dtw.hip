@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256) void kvm_dtw_filter_kernel(const double *__res
     double mean = 0.0, std = 1.0;
     if (alive) {
         if (NORM) {
-            kvm_mean_std(kvm_window_sums(prefix, (int64_t)start - 1, m), m, mean, std);
+            kvm_window_mean_std(prefix, series, (int64_t)start - 1, m, mean, std);
             pass_filter = kvm_cnsm_filter(mean, std, qd.meanQ, qd.stdQ, qd.alpha, qd.beta);
         } else {
             pass_filter = true;

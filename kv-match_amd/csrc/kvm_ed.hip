@@ -33,7 +33,7 @@ __global__ __launch_bounds__(256) void kvm_ed_wave_kernel(const double *__restri
         double mean = 0.0, inv = 1.0;
         if (NORM) {
             double std;
-            kvm_mean_std(kvm_window_sums(prefix, (int64_t)start - 1, m), m, mean, std);
+            kvm_window_mean_std(prefix, series, (int64_t)start - 1, m, mean, std);
             if (!kvm_cnsm_filter(mean, std, qd.meanQ, qd.stdQ, qd.alpha, qd.beta)) continue;  // wave-uniform
             passed++;
             inv = 1.0 / std;

@@ -10,12 +10,17 @@
 
 #define KVM_WAVE 64
 
-// Block-restarted prefix sums: P[i] = sum of x (and x*x) from the start of i's block up to i inclusive.
-// A window of m <= KVM_PS_BLOCK points touches at most two blocks, so window sums are differences of
-// O(block)-sized partial sums (error comparable to the reference's own per-interval running sums,
-// K/NormQueryEngine.java:487-509), not of n-sized global prefixes.  See DESIGN.md "mu/sigma".
+// Block-restarted, mean-shifted prefix sums.  For block b (KVM_PS_BLOCK points) with shift c_b = x[first point
+// of b]:  P[i] = { sum (x - c_b), sum (x - c_b)^2 } from the start of i's block up to i inclusive.
+// A window's sums are differences of O(block)-sized partial sums of SHIFTED values, so neither the n-sized
+// magnitude of a global prefix nor the E[x^2] - mean^2 cancellation of large-offset data (random walks reach
+// |x| ~ 1e3) enters: var = S2/m - (S1/m)^2 is formed around c_b ~ window level.  Mathematically identical to the
+// reference's mean = ex/m, std = sqrt(ex2/m - mean*mean) (K/NormQueryEngine.java:507-508), but more accurate
+// than the reference's own running sums.  See DESIGN.md "mu/sigma".
 #define KVM_PS_BLOCK_LOG2 14
 #define KVM_PS_BLOCK (1 << KVM_PS_BLOCK_LOG2)
+// The staged series is padded with this many zero points so that tile staging may read past n unguarded.
+#define KVM_SERIES_PAD 1024
 
 // One candidate run = a clipped interval of consecutive window start offsets (1-based).
 struct kvm_run {
@@ -125,48 +130,47 @@ hipError_t kvm_launch_dtw_dp(const double *series, int64_t n, const kvm_query_de
 
 // ---- device helpers ---------------------------------------------------------------------------------
 #ifdef __HIPCC__
-// Sum of x and x^2 over 0-based [s, s+m) from the block-restarted prefix array.
-__device__ __forceinline__ double2 kvm_window_sums(const double2 *__restrict__ P, int64_t s, int32_t m) {
-    int64_t e = s + m - 1;
-    int64_t bs = s >> KVM_PS_BLOCK_LOG2, be = e >> KVM_PS_BLOCK_LOG2;
-    double2 pe = P[e];
+// mean / std of the window 0-based [s, s+m) from the shifted block prefix sums.
+__device__ __forceinline__ void kvm_window_mean_std(const double2 *__restrict__ P, const double *__restrict__ x,
+                                                    int64_t s, int32_t m, double &mean, double &std) {
+    const int64_t e = s + m - 1;
+    const int64_t bs = s >> KVM_PS_BLOCK_LOG2, be = e >> KVM_PS_BLOCK_LOG2;
+    const double c = x[bs << KVM_PS_BLOCK_LOG2];  // shift of the first block; everything is re-based to it
     double s1, s2;
+    const bool at_start = (s & (KVM_PS_BLOCK - 1)) == 0;
     if (bs == be) {
-        if ((s & (KVM_PS_BLOCK - 1)) == 0) {
+        const double2 pe = P[e];
+        if (at_start) {
             s1 = pe.x;
             s2 = pe.y;
         } else {
-            double2 ps = P[s - 1];
+            const double2 ps = P[s - 1];
             s1 = pe.x - ps.x;
             s2 = pe.y - ps.y;
         }
     } else {
-        // tail of the first block
-        double2 pl = P[((bs + 1) << KVM_PS_BLOCK_LOG2) - 1];
-        if ((s & (KVM_PS_BLOCK - 1)) == 0) {
+        const double2 pl = P[((bs + 1) << KVM_PS_BLOCK_LOG2) - 1];  // tail of the first block
+        if (at_start) {
             s1 = pl.x;
             s2 = pl.y;
         } else {
-            double2 ps = P[s - 1];
+            const double2 ps = P[s - 1];
             s1 = pl.x - ps.x;
             s2 = pl.y - ps.y;
         }
-        for (int64_t b = bs + 1; b < be; b++) {  // whole middle blocks (only when m > KVM_PS_BLOCK)
-            double2 pm = P[((b + 1) << KVM_PS_BLOCK_LOG2) - 1];
-            s1 += pm.x;
-            s2 += pm.y;
+        for (int64_t b = bs + 1; b <= be; b++) {  // following blocks (exactly one unless m > KVM_PS_BLOCK)
+            const int64_t first = b << KVM_PS_BLOCK_LOG2;
+            const int64_t lastp = b < be ? first + KVM_PS_BLOCK - 1 : e;
+            const double2 t = P[lastp];
+            const double dc = x[first] - c;  // re-base from c_b to c: sum(x-c) = T1 + k*dc, sum(x-c)^2 = T2 + 2dc*T1 + k*dc^2
+            const double k = (double)(lastp - first + 1);
+            s1 += t.x + k * dc;
+            s2 += t.y + (2.0 * dc) * t.x + k * (dc * dc);
         }
-        s1 += pe.x;
-        s2 += pe.y;
     }
-    return make_double2(s1, s2);
-}
-
-// mean / std exactly in the reference's form (K/NormQueryEngine.java:507-508): mean = ex/m;
-// std = sqrt(ex2/m - mean*mean).  Compiled with -ffp-contract=off so no FMA sneaks in.
-__device__ __forceinline__ void kvm_mean_std(double2 sums, int32_t m, double &mean, double &std) {
-    mean = sums.x / m;
-    std = sqrt(sums.y / m - mean * mean);
+    const double ms = s1 / m;  // mean - c
+    mean = c + ms;
+    std = sqrt(s2 / m - ms * ms);
 }
 
 // (alpha, beta) filter, K/NormQueryEngine.java:511.

@@ -57,6 +57,13 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise OSError(f"{LIB_PATH} not found: build it with `make -C kv-match_amd/csrc` "
                       "(or __graft_entry__.build()); there is no CPU fallback")
+    # When torch is used in the same process (bench.py, distributed host) its bundled HIP runtime must be the one
+    # that initialises the GPU: load it first so that libkvmatch_hip.so binds to the already-loaded
+    # libamdhip64 (two different HIP runtimes in one process leave the second without devices).
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
     lib = C.CDLL(LIB_PATH)
     vp, i32, i64, f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_double
     pd, pi = C.POINTER(C.c_double), C.POINTER(C.c_int32)
