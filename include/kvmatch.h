@@ -138,6 +138,7 @@ void kvm_result_free(kvm_result *r);
                                     every filter-passing candidate */
 #define KVM_OPT_ED_KERNEL 3      /* 0 auto (default), 1 wave-per-candidate, 2 LDS-tiled */
 #define KVM_OPT_TIMING 4         /* 1: record HIP-event kernel times into KVM_STAT_KERNEL_NS */
+#define KVM_OPT_DP_KERNEL 5      /* 0 auto (default: register-resident band when rho <= 1023), 1 generic LDS form */
 int kvm_set_option(kvm_ctx *ctx, int32_t option, int64_t value);
 int64_t kvm_get_option(const kvm_ctx *ctx, int32_t option);
 /* Device time (ns, HIP events on the launch stream) of the verification kernels of the most recent

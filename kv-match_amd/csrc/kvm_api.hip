@@ -134,6 +134,7 @@ extern "C" int kvm_set_option(kvm_ctx *ctx, int32_t option, int64_t value) {
             ctx->opt_ed_kernel = value;
             return KVM_OK;
         case KVM_OPT_TIMING: ctx->opt_timing = value ? 1 : 0; return KVM_OK;
+        case KVM_OPT_DP_KERNEL: ctx->opt_dp_kernel = value == 1 ? 1 : 0; return KVM_OK;
     }
     return fail(ctx, KVM_ERR_ILLEGAL_ARGUMENT, "unknown option");
 }
@@ -147,6 +148,7 @@ extern "C" int64_t kvm_get_option(const kvm_ctx *ctx, int32_t option) {
         case KVM_OPT_LB_CASCADE: return ctx->opt_lb_cascade;
         case KVM_OPT_ED_KERNEL: return ctx->opt_ed_kernel;
         case KVM_OPT_TIMING: return ctx->opt_timing;
+        case KVM_OPT_DP_KERNEL: return ctx->opt_dp_kernel;
     }
     return KVM_ERR_ILLEGAL_ARGUMENT;
 }
@@ -466,7 +468,7 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
             dp_n = counters + KVM_CNT_CANDS2;
         }
         HIPCHK(ctx, kvm_launch_dtw_dp(ctx->d_series, ctx->n, qd, dp_in, dp_n, pl.windows, out.d_off, out.d_dist,
-                                      out.cap, counters, ctx->num_cu, stream));
+                                      out.cap, counters, ctx->num_cu, ctx->opt_dp_kernel == 1 ? 1 : 0, stream));
     }
     if (ctx->opt_timing) {
         HIPCHK(ctx, hipEventRecord(ctx->ev1, stream));

@@ -298,11 +298,231 @@ __global__ __launch_bounds__(64) void kvm_dtw_dp_lds_kernel(const double *__rest
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// Stage 3 (register form): the same red/black anti-diagonal sweep with the whole band in VGPRs.
+//
+// Lane p owns V consecutive even-k cells E[pV..pV+V) and V odd-k cells O[pV..pV+V) (V = pow2 >= (r+1)/64).
+// One macro-step I performs the E-update of diagonal d = 2I - r and the O-update of diagonal d + 1:
+//     E[e]: row i = I - e, column j = I - r + e          O[o]: row i = I - o, column j = I - r + 1 + o
+// so both updates of cell index c use the same data value a[c] = A[I - pV - c]; the query values are
+// b[c] = B[I - r + pV + c] (E) and b[c+1] (O).  From one macro-step to the next both windows slide by one, so a
+// lane needs ONE new A and ONE new B value per macro-step (ds_read_b64 from two wave-private LDS rings that are
+// refilled 64 values at a time); the windows live in registers and rotate by static renaming (the macro-step
+// loop is unrolled V times).  The only cross-lane traffic is one halo value per update: O[pV-1] from lane p-1
+// (DPP wave_shr:1) and E[(p+1)V] from lane p+1 (DPP wave_shl:1).
+//
+// No per-cell masks:
+//   * cells outside the matrix (i or j outside [0,m)) see poisoned operands (A = +1e10, B = -1e10 outside the
+//     window), so their value is >= ~1e20, which is how the reference treats them (INF = 1e20, K/utils/
+//     DtwUtils.java:24,297-311) -- an in-matrix cell always has a finite predecessor, so min() never selects them
+//     and the in-matrix values are bit-identical to the reference's;
+//   * cell (0,0) has no predecessor in the reference (cost = dist, :292-296): its own slot is seeded with 0.0 so
+//     that min(INF, INF, 0.0) + dist == dist exactly;
+//   * the band edge k = -1 is lane 0's left halo (DPP fill value INF); the band edge k = 2r+1 is the single cell
+//     O[r], which is reset to INF after every O-update (one v_cndmask pair).  Cells beyond it are never read
+//     by an in-band cell.
+#define DTW_POS_BIG 1e10
+#define DTW_NEG_BIG (-1e10)
+
+__device__ __forceinline__ double dp_min(double a, double b) {
+    // one v_min_f64; fmin() would add a canonicalising v_max_f64 per operand in IEEE mode
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ double dp_from_left(double v, double fill) {   // lane i <- lane i-1; lane 0 <- fill
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(__double2loint(fill), lo, 0x138 /*wave_shr:1*/, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(__double2hiint(fill), hi, 0x138, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double dp_from_right(double v, double fill) {  // lane i <- lane i+1; lane 63 <- fill
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(__double2loint(fill), lo, 0x130 /*wave_shl:1*/, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(__double2hiint(fill), hi, 0x130, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+template <int V>
+struct dp_ring {
+    static constexpr int SIZE = V <= 4 ? 512 : 1024;  // >= 64*V + 64 live values (V <= 8)
+    static constexpr int MASK = SIZE - 1;
+};
+
+template <int V, bool ABANDON>
+__global__ __launch_bounds__(256) void kvm_dtw_dp_reg_kernel(const double *__restrict__ series, kvm_query_dev qd,
+                                                             const kvm_cand *__restrict__ in,
+                                                             const unsigned long long *__restrict__ d_n_in,
+                                                             int32_t *__restrict__ out_off,
+                                                             double *__restrict__ out_dist, int64_t cap,
+                                                             unsigned long long *__restrict__ counters) {
+    constexpr int RING = dp_ring<V>::SIZE, MASK = dp_ring<V>::MASK;
+    constexpr int WAVE_LDS = 2 * RING + 64 * V;  // ring A, ring B, result scratch
+    __shared__ double lds_all[4 * WAVE_LDS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double *ringA = lds_all + wave * WAVE_LDS, *ringB = ringA + RING, *scratch = ringB + RING;
+    const int m = qd.m, r = qd.rho;
+    const double eps2 = qd.eps2;
+    const double *__restrict__ Bq = qd.q;
+    const unsigned long long n_in = *d_n_in;
+    const int I0 = r >> 1, Ilast = m - 1 + I0;
+    const int pV = lane * V;
+    const int Lr = r / V, cstar = r % V;      // position of the band-edge cell O[r]
+    const bool edge_lane = lane == Lr;
+    const int kfin = (r & 1) ? ((r - 1) >> 1) : (r >> 1);  // index of cell (m-1, m-1) (k = r) in O (r odd) / E (r even)
+
+    for (;;) {
+        unsigned long long idx = 0;
+        if (lane == 0) idx = atomicAdd(&counters[KVM_CNT_QUEUE], 1ULL);
+        idx = __shfl(idx, 0, 64);
+        if (idx >= n_in) break;
+        const kvm_cand cand = in[idx];
+        const double *__restrict__ x = series + (cand.start - 1);
+        const double mean = cand.mean, sd = cand.std;
+
+        // zT[k] = (T[k+j] - mean) / std (K/NormQueryEngineDtw.java:564-567); RSM: (x - 0) / 1 == x exactly
+        auto fillA = [&](int lo, int cnt) {
+            for (int t = lane; t < cnt; t += 64) {
+                const int i = lo + t;
+                ringA[i & MASK] = (i >= 0 && i < m) ? (x[i] - mean) / sd : DTW_POS_BIG;
+            }
+        };
+        auto fillB = [&](int lo, int cnt) {
+            for (int t = lane; t < cnt; t += 64) {
+                const int j = lo + t;
+                ringB[j & MASK] = (j >= 0 && j < m) ? Bq[j] : DTW_NEG_BIG;
+            }
+        };
+        fillA(I0 - 64 * V, 64 * V + 64);
+        fillB(I0 - r, 64 * V + 64);
+
+        double E[V], O[V], a[V], b[V];
+#pragma unroll
+        for (int c = 0; c < V; c++) {
+            E[c] = DTW_INF;
+            O[c] = DTW_INF;
+            a[c] = c >= 1 ? ringA[(I0 - pV - c) & MASK] : 0.0;
+            b[c] = ringB[(I0 - r + pV + c) & MASK];
+        }
+        // seed of cell (0,0): k = r
+        if ((r & 1) == 0) {
+#pragma unroll
+            for (int c = 0; c < V; c++)
+                if (pV + c == (r >> 1)) E[c] = 0.0;
+        } else {
+#pragma unroll
+            for (int c = 0; c < V; c++)
+                if (pV + c == ((r - 1) >> 1)) O[c] = 0.0;
+        }
+        int offA = (I0 - pV) & MASK, offB = (I0 - r + pV + V) & MASK;  // ring slots read by the next macro-step
+        bool dead = false, done = false;
+        double result = DTW_INF;
+
+        for (int Ic = I0; Ic <= Ilast && !done; Ic += 64) {
+            for (int blk = 0; blk < 64 / V && !done; blk++) {
+#pragma unroll
+                for (int s = 0; s < V; s++) {
+                    const int I = Ic + blk * V + s;
+                    const double a_new = ringA[offA], b_new = ringB[offB];
+                    offA = (offA + 1) & MASK;
+                    offB = (offB + 1) & MASK;
+                    // ---- E-update (diagonal 2I - r) ----
+                    const double halo_l = dp_from_left(O[V - 1], DTW_INF);
+#pragma unroll
+                    for (int c = V - 1; c >= 0; c--) {
+                        if (c == 0) a[(V - s) % V] = a_new;  // slot of cell 0 at step s
+                        const double av = a[((c - s) % V + V) % V], bv = b[(c + s) % V];
+                        const double dd = (av - bv) * (av - bv);
+                        const double yy = c > 0 ? O[c - 1] : halo_l;
+                        E[c] = dp_min(dp_min(O[c], yy), E[c]) + dd;
+                    }
+                    if ((r & 1) == 0 && I == Ilast) {  // r even: cell (m-1, m-1) is E[r/2] of this update
+#pragma unroll
+                        for (int c = 0; c < V; c++) scratch[pV + c] = E[c];
+                        result = scratch[kfin];
+                        done = true;
+                    }
+                    // ---- O-update (diagonal 2I - r + 1) ----
+                    const double halo_r = dp_from_right(E[0], DTW_INF);
+                    b[s % V] = b_new;  // slot (V + s) % V: query value of O cell V-1, E cell V-1 of the next step
+#pragma unroll
+                    for (int c = 0; c < V; c++) {
+                        const double av = a[((c - s) % V + V) % V], bv = b[(c + 1 + s) % V];
+                        const double dd = (av - bv) * (av - bv);
+                        const double xx = c < V - 1 ? E[c + 1] : halo_r;
+                        O[c] = dp_min(dp_min(xx, E[c]), O[c]) + dd;
+                    }
+                    if ((r & 1) == 1 && I == Ilast) {
+#pragma unroll
+                        for (int c = 0; c < V; c++) scratch[pV + c] = O[c];
+                        result = scratch[kfin];
+                        done = true;
+                    }
+                    // band edge k = 2r+1: O[r] must read as INF
+#pragma unroll
+                    for (int c = 0; c < V; c++)
+                        if (c == cstar) O[c] = edge_lane ? DTW_INF : O[c];
+                }
+            }
+            if (done) break;
+            // refill: the 64 values the next chunk adds at the top of each window
+            fillA(Ic + 64, 64);
+            fillB(Ic - r + 64 * V + 64, 64);
+            if (ABANDON) {
+                double mn = DTW_INF;
+#pragma unroll
+                for (int c = 0; c < V; c++) mn = dp_min(mn, dp_min(E[c], O[c]));
+                mn = kvm_wave_min(mn);
+                if (mn > eps2) {  // every path crosses the last two diagonals: DTW >= mn > eps^2
+                    dead = true;
+                    break;
+                }
+            }
+        }
+        if (!dead && lane == 0 && result <= eps2) {
+            unsigned long long o = atomicAdd(&counters[KVM_CNT_ANSWERS], 1ULL);
+            if ((int64_t)o < cap) {
+                out_off[o] = cand.start;
+                out_dist[o] = sqrt(result);
+            }
+        }
+    }
+}
+
+template <int V>
+static hipError_t launch_dp_reg(const double *series, const kvm_query_dev &qd, const kvm_cand *in,
+                                const unsigned long long *d_n_in, int64_t max_in, int32_t *out_off, double *out_dist,
+                                int64_t cap, unsigned long long *counters, int num_cu, hipStream_t s) {
+    const size_t lds = (size_t)4 * (2 * dp_ring<V>::SIZE + 64 * V) * sizeof(double);
+    int per_cu = (int)((160 * 1024) / lds);
+    if (per_cu > 2) per_cu = 2;  // 8 waves per CU = 2 per SIMD is enough: the kernel is VALU-bound
+    if (per_cu < 1) per_cu = 1;
+    int64_t blocks = (int64_t)num_cu * per_cu;
+    if (blocks > (max_in + 3) / 4) blocks = (max_in + 3) / 4;
+    if (qd.early_abandon)
+        hipLaunchKernelGGL((kvm_dtw_dp_reg_kernel<V, true>), dim3((unsigned)blocks), dim3(256), 0, s, series, qd, in,
+                           d_n_in, out_off, out_dist, cap, counters);
+    else
+        hipLaunchKernelGGL((kvm_dtw_dp_reg_kernel<V, false>), dim3((unsigned)blocks), dim3(256), 0, s, series, qd, in,
+                           d_n_in, out_off, out_dist, cap, counters);
+    return hipGetLastError();
+}
+
 hipError_t kvm_launch_dtw_dp(const double *series, int64_t n, const kvm_query_dev &qd, const kvm_cand *in,
                              const unsigned long long *d_n_in, int64_t max_in, int32_t *out_off, double *out_dist,
-                             int64_t cap, unsigned long long *counters, int num_cu, hipStream_t s) {
+                             int64_t cap, unsigned long long *counters, int num_cu, int force_lds, hipStream_t s) {
     (void)n;
     if (max_in <= 0) return hipSuccess;
+    // register form: band of r+1 even-k cells over 64 lanes, V = pow2 cells per lane, V <= 8 (r <= 511)
+    const int need = (qd.rho + 1 + 63) / 64;
+    if (!force_lds && need <= 8 && qd.m >= 2) {
+        if (need <= 1) return launch_dp_reg<1>(series, qd, in, d_n_in, max_in, out_off, out_dist, cap, counters, num_cu, s);
+        if (need <= 2) return launch_dp_reg<2>(series, qd, in, d_n_in, max_in, out_off, out_dist, cap, counters, num_cu, s);
+        if (need <= 4) return launch_dp_reg<4>(series, qd, in, d_n_in, max_in, out_off, out_dist, cap, counters, num_cu, s);
+        return launch_dp_reg<8>(series, qd, in, d_n_in, max_in, out_off, out_dist, cap, counters, num_cu, s);
+    }
+    // generic LDS form (any r)
     size_t lds = ((size_t)2 * (qd.rho + 1) + qd.m) * sizeof(double);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     int per_cu = (int)((160 * 1024) / lds);

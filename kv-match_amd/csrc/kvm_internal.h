@@ -62,7 +62,7 @@ struct kvm_ctx {
     kvm_dev_buf b_query, b_tiles, b_out_off, b_out_dist, b_counters, b_cands, b_cands2, b_aux, b_aux2, b_scratch;
     void *h_pinned = nullptr;
     size_t h_pinned_cap = 0;
-    int64_t opt_early_abandon = 1, opt_lb_cascade = 1, opt_ed_kernel = 0, opt_timing = 0;
+    int64_t opt_early_abandon = 1, opt_lb_cascade = 1, opt_ed_kernel = 0, opt_timing = 0, opt_dp_kernel = 0;
     int num_cu = 256;
     int64_t last_kernel_ns = 0;
     std::string err;
@@ -114,7 +114,7 @@ hipError_t kvm_launch_dtw_keogh(const double *series, const double *env_u, const
                                 int64_t max_in, kvm_cand *out, unsigned long long *counters, hipStream_t s);
 hipError_t kvm_launch_dtw_dp(const double *series, int64_t n, const kvm_query_dev &qd, const kvm_cand *in,
                              const unsigned long long *d_n_in, int64_t max_in, int32_t *out_off, double *out_dist,
-                             int64_t cap, unsigned long long *counters, int num_cu, hipStream_t s);
+                             int64_t cap, unsigned long long *counters, int num_cu, int force_lds, hipStream_t s);
 
 // counters layout (unsigned long long[16])
 #define KVM_CNT_ANSWERS 0

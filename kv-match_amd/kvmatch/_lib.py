@@ -19,7 +19,7 @@ KVM_ERR_UNSUPPORTED = -7
 
 STAT_WINDOWS, STAT_PASS_FILTER, STAT_PASS_LB_KIM, STAT_PASS_LB_KEOGH, STAT_PASS_LB_KEOGH2, STAT_KERNEL_NS, \
     STAT_RECHECKED = range(7)
-OPT_EARLY_ABANDON, OPT_LB_CASCADE, OPT_ED_KERNEL, OPT_TIMING = 1, 2, 3, 4
+OPT_EARLY_ABANDON, OPT_LB_CASCADE, OPT_ED_KERNEL, OPT_TIMING, OPT_DP_KERNEL = 1, 2, 3, 4, 5
 
 # every symbol include/kvmatch.h declares (checked by tests/test_abi.py)
 SYMBOLS = [

@@ -69,7 +69,10 @@ def test_cnsm_ed(world, m, eps, alpha, beta):
     assert 123_456 in got.offsets.tolist() and len(got) >= 2
 
 
-@pytest.mark.parametrize("m,eps,rho", [(64, 2.0, 3), (256, 4.0, 0.05), (512, 6.0, 25), (300, 5.0, 0), (129, 3.0, 200)])
+# rho picks the DP kernel form: register band with V = 1 (rho <= 63), 2, 4, 8 (<= 511) cells per lane, LDS form above
+@pytest.mark.parametrize("m,eps,rho", [(64, 2.0, 3), (256, 4.0, 0.05), (512, 6.0, 25), (300, 5.0, 0), (129, 3.0, 200),
+                                       (257, 4.0, 127), (1000, 8.0, 100), (1031, 8.0, 77), (1500, 10.0, 300),
+                                       (1200, 9.0, 511), (1200, 9.0, 600), (100, 3.0, 63), (100, 3.0, 64)])
 def test_rsm_dtw(world, m, eps, rho):
     kvmatch = world[0]
     s, q, L, R = planted(world, m)
@@ -156,6 +159,12 @@ def test_knobs_do_not_change_answers(world):
         ctx.set_option(kvmatch.OPT_LB_CASCADE, 1)
     assert np.array_equal(a.offsets, base_ed.offsets) and rel_close(a.distances, base_ed.distances)
     assert np.array_equal(b.offsets, base_dtw.offsets) and np.array_equal(b.distances, base_dtw.distances)
+    ctx.set_option(kvmatch.OPT_DP_KERNEL, 1)  # generic LDS form of the DP
+    try:
+        b2 = kvmatch.NormQueryEngineDtw(ctx).verify((L, R), 1, q, 4.0, 12, 1.5, 2.0)
+    finally:
+        ctx.set_option(kvmatch.OPT_DP_KERNEL, 0)
+    assert np.array_equal(b2.offsets, base_dtw.offsets) and np.array_equal(b2.distances, base_dtw.distances)
     for k in (1, 2):
         ctx.set_option(kvmatch.OPT_ED_KERNEL, k)
         try:
