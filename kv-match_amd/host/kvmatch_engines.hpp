@@ -1,0 +1,155 @@
+// kvmatch_engines.hpp -- C++ host-side mirror of the reference's four query engines, restricted to the phase-2
+// seam (header-only RAII wrappers over the C ABI of include/kvmatch.h).  Class names, argument order and error
+// behaviour follow the reference: K/QueryEngine.java, K/QueryEngineDtw.java, K/NormQueryEngine.java,
+// K/NormQueryEngineDtw.java (K/ = src/main/java/cn/edu/fudan/dsm/kvmatch/).  Phases 0/1 stay in the Java host.
+#pragma once
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/kvmatch.h"
+
+namespace kvmatch {
+
+// java.lang.IllegalArgumentException (K/operator/file/TimeSeriesFileOperator.java:55-57)
+struct IllegalArgumentException : std::invalid_argument { using std::invalid_argument::invalid_argument; };
+// java.io.IOException (what query() declares, K/QueryEngine.java:155); device failures map here too
+struct IOException : std::runtime_error { using std::runtime_error::runtime_error; };
+
+struct Interval { int32_t left, right; };              // K/common/Interval.java:23-35 (epsilon is not read by phase 2)
+using Answer = std::pair<int32_t, double>;             // Pair<Integer, Double>, K/QueryEngine.java:341
+constexpr int WU0 = 25;                                // WuList[0], K/QueryEngine.java:44
+
+struct Answers {
+    std::vector<Answer> answers;   // sorted by distance (K/QueryEngine.java:373)
+    int64_t cntCandidate = 0;      // statistics[3]
+    double t2_ms = 0;              // statistics[2]
+};
+
+class Phase2Context {
+public:
+    explicit Phase2Context(int device = 0) { check(kvm_open(device, &ctx_), nullptr); }
+    ~Phase2Context() { if (ctx_) kvm_close(ctx_); }
+    Phase2Context(const Phase2Context &) = delete;
+    Phase2Context &operator=(const Phase2Context &) = delete;
+
+    void loadSeries(const std::vector<double> &v) { check(kvm_load_series_f64(ctx_, v.data(), (int64_t)v.size()), ctx_); }
+    void loadSeriesFile(const std::string &path, int64_t n) { check(kvm_load_series_file(ctx_, path.c_str(), n), ctx_); }
+    // TimeSeriesOperator.readTimeSeries(left, length), K/operator/TimeSeriesOperator.java:38
+    std::vector<double> readTimeSeries(int32_t left, int32_t length) {
+        std::vector<double> out(length > 0 ? (size_t)length : 0);
+        check(kvm_read_time_series(ctx_, left, length, out.data()), ctx_);
+        return out;
+    }
+    kvm_ctx *handle() const { return ctx_; }
+
+    static void check(int rc, const kvm_ctx *ctx) {
+        if (rc == KVM_OK) return;
+        std::string msg = kvm_last_error(ctx);
+        if (rc == KVM_ERR_ILLEGAL_ARGUMENT) throw IllegalArgumentException(msg);
+        throw IOException("[" + std::to_string(rc) + "] " + msg);
+    }
+
+private:
+    kvm_ctx *ctx_ = nullptr;
+};
+
+namespace detail {
+inline void flatten(const std::vector<Interval> &v, std::vector<int32_t> &l, std::vector<int32_t> &r) {
+    l.resize(v.size());
+    r.resize(v.size());
+    for (size_t i = 0; i < v.size(); i++) { l[i] = v[i].left; r[i] = v[i].right; }
+}
+inline Answers collect(kvm_result *res) {
+    Answers a;
+    const int64_t cnt = kvm_result_count(res);
+    const int32_t *off = kvm_result_offsets(res);
+    const double *dist = kvm_result_distances(res);
+    a.answers.reserve((size_t)cnt);
+    for (int64_t i = 0; i < cnt; i++) a.answers.emplace_back(off[i], dist[i]);
+    a.cntCandidate = kvm_result_candidates(res);
+    a.t2_ms = kvm_result_elapsed_ms(res);
+    kvm_result_free(res);
+    return a;
+}
+}  // namespace detail
+
+// RSM-ED: verify() replaces K/QueryEngine.java:338-363 (+ sort :373)
+class QueryEngine {
+public:
+    explicit QueryEngine(Phase2Context &c) : c_(c) {}
+    Answers verify(const std::vector<Interval> &validPositions, int lastSegment, const std::vector<double> &queryData,
+                   double epsilon) {
+        std::vector<int32_t> l, r;
+        detail::flatten(validPositions, l, r);
+        kvm_result *res = nullptr;
+        Phase2Context::check(kvm_verify_rsm_ed(c_.handle(), queryData.data(), (int32_t)queryData.size(), l.data(),
+                                               r.data(), (int32_t)l.size(), (lastSegment - 1) * WU0, epsilon, &res),
+                             c_.handle());
+        return detail::collect(res);
+    }
+private:
+    Phase2Context &c_;
+};
+
+// RSM-DTW: verify() replaces K/QueryEngineDtw.java:349-452; rho <= 1 is a fraction of the query length (:135-140)
+class QueryEngineDtw {
+public:
+    explicit QueryEngineDtw(Phase2Context &c) : c_(c) {}
+    Answers verify(const std::vector<Interval> &validPositions, int lastSegment, const std::vector<double> &queryData,
+                   double epsilon, double rho) {
+        std::vector<int32_t> l, r;
+        detail::flatten(validPositions, l, r);
+        kvm_result *res = nullptr;
+        const int32_t m = (int32_t)queryData.size();
+        Phase2Context::check(kvm_verify_rsm_dtw(c_.handle(), queryData.data(), m, l.data(), r.data(), (int32_t)l.size(),
+                                                (lastSegment - 1) * WU0, epsilon, kvm_resolve_rho(rho, m), &res),
+                             c_.handle());
+        return detail::collect(res);
+    }
+private:
+    Phase2Context &c_;
+};
+
+// cNSM-ED: verify() replaces K/NormQueryEngine.java:432-528
+class NormQueryEngine {
+public:
+    explicit NormQueryEngine(Phase2Context &c) : c_(c) {}
+    Answers verify(const std::vector<Interval> &validPositions, int lastSegment, const std::vector<double> &queryData,
+                   double epsilon, double alpha, double beta) {
+        std::vector<int32_t> l, r;
+        detail::flatten(validPositions, l, r);
+        kvm_result *res = nullptr;
+        Phase2Context::check(kvm_verify_cnsm_ed(c_.handle(), queryData.data(), (int32_t)queryData.size(), l.data(),
+                                                r.data(), (int32_t)l.size(), (lastSegment - 1) * WU0, epsilon, alpha,
+                                                beta, &res),
+                             c_.handle());
+        return detail::collect(res);
+    }
+private:
+    Phase2Context &c_;
+};
+
+// cNSM-DTW: verify() replaces K/NormQueryEngineDtw.java:457-603
+class NormQueryEngineDtw {
+public:
+    explicit NormQueryEngineDtw(Phase2Context &c) : c_(c) {}
+    Answers verify(const std::vector<Interval> &validPositions, int lastSegment, const std::vector<double> &queryData,
+                   double epsilon, double rho, double alpha, double beta) {
+        std::vector<int32_t> l, r;
+        detail::flatten(validPositions, l, r);
+        kvm_result *res = nullptr;
+        const int32_t m = (int32_t)queryData.size();
+        Phase2Context::check(kvm_verify_cnsm_dtw(c_.handle(), queryData.data(), m, l.data(), r.data(),
+                                                 (int32_t)l.size(), (lastSegment - 1) * WU0, epsilon,
+                                                 kvm_resolve_rho(rho, m), alpha, beta, &res),
+                             c_.handle());
+        return detail::collect(res);
+    }
+private:
+    Phase2Context &c_;
+};
+
+}  // namespace kvmatch

@@ -1,0 +1,102 @@
+/*
+ * kvmatch_jni.c -- JNI shim over include/kvmatch.h for cn.edu.fudan.dsm.kvmatch.gpu.Phase2Gpu.
+ * Not part of the default build: this image has no JDK.  Compiles only where <jni.h> is available.
+ */
+#if defined(__has_include)
+#if __has_include(<jni.h>)
+#define KVM_HAVE_JNI 1
+#endif
+#endif
+
+#ifdef KVM_HAVE_JNI
+#include <jni.h>
+#include "../../include/kvmatch.h"
+
+static void throw_for(JNIEnv *env, kvm_ctx *ctx, int rc) {
+    const char *msg = kvm_last_error(ctx);
+    /* range/parameter errors -> IllegalArgumentException (K/operator/file/TimeSeriesFileOperator.java:55-57);
+     * everything else -> IOException (what query() declares, K/QueryEngine.java:155) */
+    jclass cls = (*env)->FindClass(env, rc == KVM_ERR_ILLEGAL_ARGUMENT ? "java/lang/IllegalArgumentException"
+                                                                     : "java/io/IOException");
+    (*env)->ThrowNew(env, cls, msg ? msg : "kvmatch error");
+}
+
+JNIEXPORT jlong JNICALL Java_cn_edu_fudan_dsm_kvmatch_gpu_Phase2Gpu_open(JNIEnv *env, jclass c, jint device) {
+    (void)c;
+    kvm_ctx *ctx = 0;
+    int rc = kvm_open(device, &ctx);
+    if (rc) { throw_for(env, 0, rc); return 0; }
+    return (jlong)(intptr_t)ctx;
+}
+
+JNIEXPORT void JNICALL Java_cn_edu_fudan_dsm_kvmatch_gpu_Phase2Gpu_loadSeriesFile(JNIEnv *env, jclass c, jlong h,
+                                                                               jstring path, jlong n) {
+    (void)c;
+    kvm_ctx *ctx = (kvm_ctx *)(intptr_t)h;
+    const char *p = (*env)->GetStringUTFChars(env, path, 0);
+    int rc = kvm_load_series_file(ctx, p, n);
+    (*env)->ReleaseStringUTFChars(env, path, p);
+    if (rc) throw_for(env, ctx, rc);
+}
+
+JNIEXPORT void JNICALL Java_cn_edu_fudan_dsm_kvmatch_gpu_Phase2Gpu_close(JNIEnv *env, jclass c, jlong h) {
+    (void)env; (void)c;
+    kvm_close((kvm_ctx *)(intptr_t)h);
+}
+
+static jobject make_result(JNIEnv *env, kvm_ctx *ctx, int rc, kvm_result *res) {
+    if (rc) { throw_for(env, ctx, rc); return 0; }
+    jclass cls = (*env)->FindClass(env, "cn/edu/fudan/dsm/kvmatch/gpu/Phase2Gpu$Result");
+    jobject o = (*env)->AllocObject(env, cls);
+    jsize cnt = (jsize)kvm_result_count(res);
+    jintArray off = (*env)->NewIntArray(env, cnt);
+    jdoubleArray dist = (*env)->NewDoubleArray(env, cnt);
+    if (cnt) {
+        (*env)->SetIntArrayRegion(env, off, 0, cnt, (const jint *)kvm_result_offsets(res));
+        (*env)->SetDoubleArrayRegion(env, dist, 0, cnt, kvm_result_distances(res));
+    }
+    (*env)->SetObjectField(env, o, (*env)->GetFieldID(env, cls, "offsets", "[I"), off);
+    (*env)->SetObjectField(env, o, (*env)->GetFieldID(env, cls, "distances", "[D"), dist);
+    (*env)->SetLongField(env, o, (*env)->GetFieldID(env, cls, "cntCandidate", "J"), kvm_result_candidates(res));
+    kvm_result_free(res);
+    return o;
+}
+
+#define PIN(arr) (*env)->GetPrimitiveArrayCritical(env, arr, 0)
+#define UNPIN(arr, p) (*env)->ReleasePrimitiveArrayCritical(env, arr, p, JNI_ABORT)
+
+#define KVM_JNI_BODY(CALL)                                                                         \
+    kvm_ctx *ctx = (kvm_ctx *)(intptr_t)h;                                                         \
+    jsize m = (*env)->GetArrayLength(env, q), k = (*env)->GetArrayLength(env, left);               \
+    double *pq = PIN(q);                                                                           \
+    jint *pl = PIN(left), *pr = PIN(right);                                                        \
+    kvm_result *res = 0;                                                                           \
+    int rc = CALL;                                                                                 \
+    UNPIN(right, pr); UNPIN(left, pl); UNPIN(q, pq);                                               \
+    return make_result(env, ctx, rc, res);
+
+JNIEXPORT jobject JNICALL Java_cn_edu_fudan_dsm_kvmatch_gpu_Phase2Gpu_rsmEd(JNIEnv *env, jobject self, jlong h,
+        jdoubleArray q, jintArray left, jintArray right, jint shift, jdouble eps) {
+    (void)self;
+    KVM_JNI_BODY(kvm_verify_rsm_ed(ctx, pq, m, (const int32_t *)pl, (const int32_t *)pr, k, shift, eps, &res))
+}
+JNIEXPORT jobject JNICALL Java_cn_edu_fudan_dsm_kvmatch_gpu_Phase2Gpu_cnsmEd(JNIEnv *env, jobject self, jlong h,
+        jdoubleArray q, jintArray left, jintArray right, jint shift, jdouble eps, jdouble alpha, jdouble beta) {
+    (void)self;
+    KVM_JNI_BODY(kvm_verify_cnsm_ed(ctx, pq, m, (const int32_t *)pl, (const int32_t *)pr, k, shift, eps, alpha, beta, &res))
+}
+JNIEXPORT jobject JNICALL Java_cn_edu_fudan_dsm_kvmatch_gpu_Phase2Gpu_rsmDtw(JNIEnv *env, jobject self, jlong h,
+        jdoubleArray q, jintArray left, jintArray right, jint shift, jdouble eps, jint rho) {
+    (void)self;
+    KVM_JNI_BODY(kvm_verify_rsm_dtw(ctx, pq, m, (const int32_t *)pl, (const int32_t *)pr, k, shift, eps, rho, &res))
+}
+JNIEXPORT jobject JNICALL Java_cn_edu_fudan_dsm_kvmatch_gpu_Phase2Gpu_cnsmDtw(JNIEnv *env, jobject self, jlong h,
+        jdoubleArray q, jintArray left, jintArray right, jint shift, jdouble eps, jint rho, jdouble alpha,
+        jdouble beta) {
+    (void)self;
+    KVM_JNI_BODY(kvm_verify_cnsm_dtw(ctx, pq, m, (const int32_t *)pl, (const int32_t *)pr, k, shift, eps, rho, alpha, beta, &res))
+}
+#else
+/* no <jni.h> in this toolchain: nothing to build */
+typedef int kvm_jni_not_built;
+#endif
