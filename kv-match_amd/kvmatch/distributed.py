@@ -92,3 +92,66 @@ def sharded_verify(engine, valid_positions, last_segment, query_data, *params, g
     cnt = torch.tensor([ans.cnt_candidate], dtype=torch.int64, device=dev)
     dist.all_reduce(cnt, group=group)
     return offs, dists, int(cnt.item())
+
+
+class ShardedVerifier:
+    """Device-resident sharded verification: kernels write survivors straight into torch tensors on this rank's GPU
+    (kvm_verify_device, launched on torch's current stream), the survivors are packed on the device and exchanged
+    with ONE fixed-size all-gather (count + up to `pack_cap` pairs per rank; a second, exact-size exchange only if
+    some rank exceeds `pack_cap`), then copied to the host once and sorted.
+
+    variant: 0 rsm_ed, 1 cnsm_ed, 2 rsm_dtw, 3 cnsm_dtw (the `variant` argument of kvm_verify_device)."""
+
+    def __init__(self, ctx, variant, max_candidates, group=None, pack_cap=4096):
+        import torch
+        import torch.distributed as dist
+        self.ctx, self.variant, self.group = ctx, int(variant), group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.dev = torch.device(f"cuda:{ctx.device}")
+        self.cap = int(max_candidates) + 1
+        self.pack_cap = int(pack_cap)
+        self.out_off = torch.empty(self.cap, dtype=torch.int32, device=self.dev)
+        self.out_dist = torch.empty(self.cap, dtype=torch.float64, device=self.dev)
+        self.count = torch.zeros(1, dtype=torch.int64, device=self.dev)
+        self.packed = torch.zeros((self.pack_cap + 1, 2), dtype=torch.float64, device=self.dev)
+        self.gathered = torch.empty((self.world * (self.pack_cap + 1), 2), dtype=torch.float64, device=self.dev)
+        self.cnt_candidate = 0
+
+    def verify(self, valid_positions, last_segment, query_data, epsilon, rho=0, alpha=1.0, beta=0.0):
+        import ctypes as C
+        import torch
+        import torch.distributed as dist
+        from . import _lib
+        from .engine import WU0, _as_intervals
+        left, right = _as_intervals(valid_positions)
+        q = np.ascontiguousarray(query_data, dtype=np.float64)
+        c = self.ctx
+        r = c._lib.kvm_resolve_rho(float(rho), q.size) if self.variant >= 2 else 0
+        cnt_cand = C.c_int64(0)
+        stream = torch.cuda.current_stream(self.dev).cuda_stream
+        _lib.check(c._lib.kvm_verify_device(
+            c._h, self.variant, q.ctypes.data, q.size, left.ctypes.data, right.ctypes.data, left.size,
+            (int(last_segment) - 1) * WU0, float(epsilon), int(r), float(alpha), float(beta),
+            C.c_void_p(self.out_off.data_ptr()), C.c_void_p(self.out_dist.data_ptr()), self.cap,
+            C.c_void_p(self.count.data_ptr()), C.byref(cnt_cand), C.c_void_p(stream)), c._h)
+        self.cnt_candidate = int(cnt_cand.value)
+        # pack [count | first pack_cap pairs] on the device
+        k = self.pack_cap
+        self.packed[0, 0] = self.count[0].to(torch.float64)
+        self.packed[1:, 0] = self.out_off[:k].to(torch.float64)
+        self.packed[1:, 1] = self.out_dist[:k]
+        if self.world > 1:
+            dist.all_gather_into_tensor(self.gathered, self.packed, group=self.group)
+            host = self.gathered.cpu().numpy().reshape(self.world, k + 1, 2)
+        else:
+            host = self.packed.cpu().numpy().reshape(1, k + 1, 2)
+        counts = host[:, 0, 0].astype(np.int64)
+        if counts.max() <= k:
+            offs = np.concatenate([host[w, 1:1 + counts[w], 0] for w in range(self.world)]).astype(np.int32)
+            dists = np.concatenate([host[w, 1:1 + counts[w], 1] for w in range(self.world)])
+            return sort_answers(offs, dists)
+        # rare: more answers than the packed buffer holds -> exact-size exchange of the full lists
+        n_local = int(self.count.item())
+        return gather_answers(self.out_off[:n_local], self.out_dist[:n_local], group=self.group) \
+            if self.world > 1 else sort_answers(self.out_off[:n_local].cpu().numpy(),
+                                                self.out_dist[:n_local].cpu().numpy())

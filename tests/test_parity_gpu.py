@@ -229,3 +229,100 @@ def test_prefix_sums_accuracy_far_from_origin(world):
     # query's own window starts its interval).  Absolute floor scaled accordingly; relative tolerance unchanged.
     compare(got, oracle.cnsm_ed(s, q, L, R, 0, 2.0, 1.5, 5.0), tag="far prefix", abs_floor=5e-8)
     assert len(got) >= 2
+
+
+def test_full_size_properties_n1e8_m8192(built):
+    """BASELINE configs[1]/[2] at full size (n=1e8, m=8192, ~1e6 candidates): size-independent properties instead of
+    an oracle pass -- self-match at distance exactly 0, every planted copy found, answers sorted, two independent GPU
+    implementations (LDS-tiled vs wave-per-candidate) and early-abandon on/off agree, cNSM self-match ~0 and its
+    answers a superset of the planted copies, oracle agreement on a bounded sample of the intervals."""
+    import kvmatch
+    from kvmatch import datagen
+    n, m = 100_000_000, 8192
+    series = datagen.gen_series(n)
+    qoff = n // 3 + 17
+    planted = [n // 7, n // 2 + 1000, n - 3 * m]
+    q = datagen.plant_copies(series, qoff, m, planted, [1.0, 1.0, 1.0], [0.0, 0.02, -0.03], 0.01)
+    L, R = datagen.gen_intervals(n, m, 1_000_000, 64.0, must_cover=[qoff] + planted, seed=1)
+    with kvmatch.Phase2Context(0) as ctx:
+        ctx.load_series(series)
+        eng = kvmatch.QueryEngine(ctx)
+        a = eng.verify((L, R), 1, q, 10.0)
+        assert a.offsets[0] == qoff and a.distances[0] == 0.0
+        assert set(planted) <= set(a.offsets.tolist()) and np.all(np.diff(a.distances) >= 0)
+        assert a.cnt_candidate == int((R.astype(np.int64) - L + 1).sum()) == a.stats[0]
+        ctx.set_option(kvmatch.OPT_EARLY_ABANDON, 0)
+        b = eng.verify((L, R), 1, q, 10.0)
+        ctx.set_option(kvmatch.OPT_ED_KERNEL, 1)
+        c = eng.verify((L, R), 1, q, 10.0)
+        ctx.set_option(kvmatch.OPT_ED_KERNEL, 0)
+        ctx.set_option(kvmatch.OPT_EARLY_ABANDON, 1)
+        assert np.array_equal(a.offsets, b.offsets) and np.array_equal(a.distances, b.distances)
+        assert np.array_equal(a.offsets, c.offsets) and rel_close(a.distances, c.distances)
+        z = kvmatch.NormQueryEngine(ctx).verify((L, R), 1, q, 2.0, 1.5, 5.0)
+        assert z.offsets[0] == qoff and z.distances[0] < 1e-6 and set(planted) <= set(z.offsets.tolist())
+        # oracle on a bounded sample: the intervals around the query and the planted copies plus the first 300
+        pick = np.zeros(len(L), dtype=bool)
+        pick[:300] = True
+        for o in [qoff] + planted:
+            pick |= (L <= o) & (R >= o)
+        Ls, Rs = L[pick], R[pick]
+        compare(eng.verify((Ls, Rs), 1, q, 10.0), oracle.rsm_ed(series, q, Ls, Rs, 0, 10.0), tag="n1e8 sample rsm")
+        compare(kvmatch.NormQueryEngine(ctx).verify((Ls, Rs), 1, q, 2.0, 1.5, 5.0),
+                oracle.cnsm_ed(series, q, Ls, Rs, 0, 2.0, 1.5, 5.0), tag="n1e8 sample cnsm")
+
+
+def test_full_size_dtw_m4096_rho5pct(built):
+    """BASELINE configs[3]: cNSM-DTW, m=4096, rho=204 on n=1e7 (the DP is independent of n): cascade on/off and both DP
+    kernel forms give identical answers; oracle agreement on a bounded sample."""
+    import kvmatch
+    from kvmatch import datagen
+    n, m = 10_000_000, 4096
+    series = datagen.gen_series(n, seed=4242)
+    qoff = n // 3 + 5
+    planted = [n // 5, n // 2 + 77]
+    q = datagen.plant_copies(series, qoff, m, planted, [1.0, 1.1], [0.0, 0.5], 0.05)
+    L, R = datagen.gen_intervals(n, m, 200_000, 64.0, must_cover=[qoff] + planted, seed=3)
+    with kvmatch.Phase2Context(0) as ctx:
+        ctx.load_series(series)
+        eng = kvmatch.NormQueryEngineDtw(ctx)
+        a = eng.verify((L, R), 1, q, 8.0, 0.05, 1.5, 5.0)
+        assert a.offsets[0] == qoff and a.distances[0] < 1e-6 and set(planted) <= set(a.offsets.tolist())
+        assert a.stats[1] >= a.stats[2] >= a.stats[3] >= a.stats[4] >= len(a)
+        ctx.set_option(kvmatch.OPT_LB_CASCADE, 0)
+        pick = np.zeros(len(L), dtype=bool)
+        pick[:40] = True
+        for o in [qoff] + planted:
+            pick |= (L <= o) & (R >= o)
+        Ls, Rs = L[pick], R[pick]
+        s1 = eng.verify((Ls, Rs), 1, q, 8.0, 0.05, 1.5, 5.0)
+        ctx.set_option(kvmatch.OPT_DP_KERNEL, 1)
+        s2 = eng.verify((Ls, Rs), 1, q, 8.0, 0.05, 1.5, 5.0)
+        ctx.set_option(kvmatch.OPT_DP_KERNEL, 0)
+        ctx.set_option(kvmatch.OPT_LB_CASCADE, 1)
+        s3 = eng.verify((Ls, Rs), 1, q, 8.0, 0.05, 1.5, 5.0)
+        assert np.array_equal(s1.offsets, s2.offsets) and np.array_equal(s1.distances, s2.distances)
+        assert np.array_equal(s1.offsets, s3.offsets) and np.array_equal(s1.distances, s3.distances)
+        compare(s3, oracle.cnsm_dtw(series, q, Ls, Rs, 0, 8.0, 204, 1.5, 5.0), tag="m4096 sample")
+
+
+def test_device_resident_verifier_matches_host_api(world):
+    """kvm_verify_device (survivors stay in HBM, caller's stream) == kvm_verify_* for all four variants."""
+    kvmatch = world[0]
+    from kvmatch import distributed as D
+    ctx = world[3]
+    s, q, L, R = planted(world, 300)
+    cands = int((R.astype(np.int64) - L + 1).sum())
+    host = [kvmatch.QueryEngine(ctx).verify((L, R), 1, q, 5.0),
+            kvmatch.NormQueryEngine(ctx).verify((L, R), 1, q, 4.0, 1.5, 2.0),
+            kvmatch.QueryEngineDtw(ctx).verify((L, R), 1, q, 5.0, 15),
+            kvmatch.NormQueryEngineDtw(ctx).verify((L, R), 1, q, 4.0, 15, 1.5, 2.0)]
+    args = [dict(epsilon=5.0), dict(epsilon=4.0, alpha=1.5, beta=2.0), dict(epsilon=5.0, rho=15),
+            dict(epsilon=4.0, rho=15, alpha=1.5, beta=2.0)]
+    for variant in range(4):
+        for pack_cap in (4096, 1):  # 1 forces the exact-size fallback path
+            v = D.ShardedVerifier(ctx, variant, cands, pack_cap=pack_cap)
+            offs, dists = v.verify((L, R), 1, q, **args[variant])
+            assert np.array_equal(offs, host[variant].offsets), variant
+            assert np.array_equal(dists, host[variant].distances), variant
+            assert v.cnt_candidate == host[variant].cnt_candidate
