@@ -458,16 +458,22 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
                                           counters, stream));
         const kvm_cand *dp_in = c1;
         const unsigned long long *dp_n = counters + KVM_CNT_CANDS1;
+        const double *dp_suffix = nullptr;
+        // segment length of the coarse LB_Keogh suffix: a multiple of 64 so that segments align with the lane-strided loops
+        const int32_t seg_len = (((m + KVM_DTW_NSEG - 1) / KVM_DTW_NSEG) + 63) / 64 * 64;
         if (use_lb) {
             if ((rc = ensure(ctx, ctx->b_cands2, (size_t)pl.windows * sizeof(kvm_cand) + 64))) return rc;
             if ((rc = ensure_envelope(ctx, rho))) return rc;
+            if ((rc = ensure(ctx, ctx->b_aux, (size_t)pl.windows * KVM_DTW_NSEG * sizeof(double) + 64))) return rc;
             kvm_cand *c2 = (kvm_cand *)ctx->b_cands2.p;
             HIPCHK(ctx, kvm_launch_dtw_keogh(ctx->d_series, ctx->d_env_u, ctx->d_env_l, ctx->n, qd, c1,
-                                             counters + KVM_CNT_CANDS1, pl.windows, c2, counters, stream));
+                                             counters + KVM_CNT_CANDS1, pl.windows, c2, (double *)ctx->b_aux.p, seg_len,
+                                             counters, stream));
             dp_in = c2;
             dp_n = counters + KVM_CNT_CANDS2;
+            dp_suffix = (const double *)ctx->b_aux.p;
         }
-        HIPCHK(ctx, kvm_launch_dtw_dp(ctx->d_series, ctx->n, qd, dp_in, dp_n, pl.windows, out.d_off, out.d_dist,
+        HIPCHK(ctx, kvm_launch_dtw_dp(ctx->d_series, ctx->n, qd, dp_in, dp_suffix, seg_len, dp_n, pl.windows, out.d_off, out.d_dist,
                                       out.cap, counters, ctx->num_cu, ctx->opt_dp_kernel == 1 ? 1 : 0, stream));
     }
     if (ctx->opt_timing) {

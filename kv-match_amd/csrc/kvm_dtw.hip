@@ -120,13 +120,21 @@ hipError_t kvm_launch_dtw_filter(const double *series, const double2 *prefix, in
 // LB_Keogh on the data envelope (K/utils/DtwUtils.java:238-257), both summed over all m positions in
 // lane-strided order (the reference's order[] permutation and early exit only change the summation
 // order / skip work).  A candidate survives iff both bounds are <= eps^2.
+//
+// The per-position contributions of the larger bound feed the DP's early abandon in the reference as a suffix
+// sum cb[] (K/NormQueryEngineDtw.java:576-587, used at K/utils/DtwUtils.java:324-326).  Here the positions are
+// grouped into KVM_DTW_NSEG segments of seg_len points; the kernel emits the COARSE suffix sums
+//     suffix[s] = sum of cb[pos] over pos >= s * seg_len
+// (16 doubles per survivor instead of m), which is all the DP kernel needs because it tests for abandonment
+// every 64 macro-steps anyway.  A coarse suffix is a subset sum of non-negative terms, i.e. still a lower bound.
 __global__ __launch_bounds__(256) void kvm_dtw_keogh_kernel(const double *__restrict__ series,
                                                             const double *__restrict__ env_u,
                                                             const double *__restrict__ env_l, kvm_query_dev qd,
                                                             const kvm_cand *__restrict__ in,
                                                             const unsigned long long *__restrict__ d_n_in,
-                                                            kvm_cand *__restrict__ out,
-                                                            unsigned long long *__restrict__ counters) {
+                                                            kvm_cand *__restrict__ out, double *__restrict__ out_suffix,
+                                                            int32_t seg_len, unsigned long long *__restrict__ counters) {
+    __shared__ double segs[4][2][KVM_DTW_NSEG];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned long long n_in = *d_n_in;
     const int m = qd.m;
@@ -137,40 +145,60 @@ __global__ __launch_bounds__(256) void kvm_dtw_keogh_kernel(const double *__rest
         const double *__restrict__ x = series + (c.start - 1);
         const double inv = 1.0 / c.std;
         double lb1 = 0.0;
+        for (int s = 0; s < KVM_DTW_NSEG; s++) {
+            const int j1 = min(m, (s + 1) * seg_len);
+            double p = 0.0;
 #pragma unroll 4
-        for (int j = lane; j < m; j += 64) {
-            const double v = (x[j] - c.mean) * inv;
-            const double hi = qd.qu[j], lo = qd.ql[j];
-            double d = 0.0;
-            if (v > hi) d = dsq(v, hi);
-            else if (v < lo) d = dsq(v, lo);
-            lb1 += d;
+            for (int j = s * seg_len + lane; j < j1; j += 64) {
+                const double v = (x[j] - c.mean) * inv;
+                const double hi = qd.qu[j], lo = qd.ql[j];
+                double d = 0.0;
+                if (v > hi) d = dsq(v, hi);
+                else if (v < lo) d = dsq(v, lo);
+                p += d;
+            }
+            p = kvm_wave_sum(p);
+            if (lane == 0) segs[wave][0][s] = p;
+            lb1 += p;
         }
-        lb1 = kvm_wave_sum(lb1);
         if (!(lb1 <= eps2)) continue;
         bool pass2 = true;
+        double lb2 = 0.0;
         if (env_u) {
             const double *__restrict__ uu = env_u + (c.start - 1);
             const double *__restrict__ ll = env_l + (c.start - 1);
-            double lb2 = 0.0;
+            for (int s = 0; s < KVM_DTW_NSEG; s++) {
+                const int j1 = min(m, (s + 1) * seg_len);
+                double p = 0.0;
 #pragma unroll 4
-            for (int j = lane; j < m; j += 64) {
-                const double hi = (uu[j] - c.mean) * inv, lo = (ll[j] - c.mean) * inv;
-                const double qv = qd.q[j];
-                double d = 0.0;
-                if (qv > hi) d = dsq(qv, hi);
-                else if (qv < lo) d = dsq(qv, lo);
-                lb2 += d;
+                for (int j = s * seg_len + lane; j < j1; j += 64) {
+                    const double hi = (uu[j] - c.mean) * inv, lo = (ll[j] - c.mean) * inv;
+                    const double qv = qd.q[j];
+                    double d = 0.0;
+                    if (qv > hi) d = dsq(qv, hi);
+                    else if (qv < lo) d = dsq(qv, lo);
+                    p += d;
+                }
+                p = kvm_wave_sum(p);
+                if (lane == 0) segs[wave][1][s] = p;
+                lb2 += p;
             }
-            lb2 = kvm_wave_sum(lb2);
             pass2 = lb2 <= eps2;
         }
+        unsigned long long o = 0;
         if (lane == 0) {
             atomicAdd(&counters[KVM_CNT_PASS_KEOGH], 1ULL);
             if (pass2) {
                 atomicAdd(&counters[KVM_CNT_PASS_KEOGH2], 1ULL);
-                unsigned long long o = atomicAdd(&counters[KVM_CNT_CANDS2], 1ULL);
+                o = atomicAdd(&counters[KVM_CNT_CANDS2], 1ULL);
                 out[o] = c;
+                // larger bound wins, as K/NormQueryEngineDtw.java:577-587; suffix over segments
+                const int which = (env_u && !(lb1 > lb2)) ? 1 : 0;
+                double run = 0.0;
+                for (int s = KVM_DTW_NSEG - 1; s >= 0; s--) {
+                    run += segs[wave][which][s];
+                    out_suffix[o * KVM_DTW_NSEG + s] = run;
+                }
             }
         }
     }
@@ -178,13 +206,14 @@ __global__ __launch_bounds__(256) void kvm_dtw_keogh_kernel(const double *__rest
 
 hipError_t kvm_launch_dtw_keogh(const double *series, const double *env_u, const double *env_l, int64_t n,
                                 const kvm_query_dev &qd, const kvm_cand *in, const unsigned long long *d_n_in,
-                                int64_t max_in, kvm_cand *out, unsigned long long *counters, hipStream_t s) {
+                                int64_t max_in, kvm_cand *out, double *out_suffix, int32_t seg_len,
+                                unsigned long long *counters, hipStream_t s) {
     (void)n;
     if (max_in <= 0) return hipSuccess;
     int64_t blocks = (max_in + 3) / 4;
     if (blocks > 256 * 8) blocks = 256 * 8;
     hipLaunchKernelGGL(kvm_dtw_keogh_kernel, dim3((unsigned)blocks), dim3(256), 0, s, series, env_u, env_l, qd, in,
-                       d_n_in, out, counters);
+                       d_n_in, out, out_suffix, seg_len, counters);
     return hipGetLastError();
 }
 
@@ -209,6 +238,7 @@ extern __shared__ double kvm_dp_lds[];
 template <bool ABANDON>
 __global__ __launch_bounds__(64) void kvm_dtw_dp_lds_kernel(const double *__restrict__ series, kvm_query_dev qd,
                                                             const kvm_cand *__restrict__ in,
+                                                            const double *__restrict__ suffix, int32_t seg_len,
                                                             const unsigned long long *__restrict__ d_n_in,
                                                             int32_t *__restrict__ out_off,
                                                             double *__restrict__ out_dist, int64_t cap,
@@ -277,7 +307,14 @@ __global__ __launch_bounds__(64) void kvm_dtw_dp_lds_kernel(const double *__rest
                     if (e <= r - 1) mn = fmin(mn, O[e]);
                 }
                 mn = kvm_wave_min(mn);
-                if (mn > eps2) {
+                // rows and columns > (d + r) / 2 are untouched by every cell of the last two diagonals: their
+                // LB_Keogh contributions (coarse suffix) still have to be paid (K/utils/DtwUtils.java:324-326)
+                double rest = 0.0;
+                if (suffix) {
+                    const int sidx = ((d + r) / 2 + 1 + seg_len - 1) / seg_len;
+                    rest = sidx < KVM_DTW_NSEG ? suffix[idx * KVM_DTW_NSEG + sidx] : 0.0;
+                }
+                if (mn + rest > eps2) {
                     dead = true;
                     break;
                 }
@@ -353,6 +390,7 @@ struct dp_ring {
 template <int V, bool ABANDON>
 __global__ __launch_bounds__(256) void kvm_dtw_dp_reg_kernel(const double *__restrict__ series, kvm_query_dev qd,
                                                              const kvm_cand *__restrict__ in,
+                                                             const double *__restrict__ suffix, int32_t seg_len,
                                                              const unsigned long long *__restrict__ d_n_in,
                                                              int32_t *__restrict__ out_off,
                                                              double *__restrict__ out_dist, int64_t cap,
@@ -474,7 +512,15 @@ __global__ __launch_bounds__(256) void kvm_dtw_dp_reg_kernel(const double *__res
 #pragma unroll
                 for (int c = 0; c < V; c++) mn = dp_min(mn, dp_min(E[c], O[c]));
                 mn = kvm_wave_min(mn);
-                if (mn > eps2) {  // every path crosses the last two diagonals: DTW >= mn > eps^2
+                // Every path crosses one of the last two diagonals (DTW >= mn); all their cells have row and column
+                // <= Ic+63, so the LB_Keogh contributions of the positions beyond are still to be paid
+                // (K/utils/DtwUtils.java:324-326 with the coarse suffix of stage 2).
+                double rest = 0.0;
+                if (suffix) {
+                    const int sidx = (Ic + 64 + seg_len - 1) / seg_len;
+                    rest = sidx < KVM_DTW_NSEG ? suffix[idx * KVM_DTW_NSEG + sidx] : 0.0;
+                }
+                if (mn + rest > eps2) {
                     dead = true;
                     break;
                 }
@@ -492,7 +538,7 @@ __global__ __launch_bounds__(256) void kvm_dtw_dp_reg_kernel(const double *__res
 
 template <int V>
 static hipError_t launch_dp_reg(const double *series, const kvm_query_dev &qd, const kvm_cand *in,
-                                const unsigned long long *d_n_in, int64_t max_in, int32_t *out_off, double *out_dist,
+                                const double *suffix, int32_t seg_len, const unsigned long long *d_n_in, int64_t max_in, int32_t *out_off, double *out_dist,
                                 int64_t cap, unsigned long long *counters, int num_cu, hipStream_t s) {
     const size_t lds = (size_t)4 * (2 * dp_ring<V>::SIZE + 64 * V) * sizeof(double);
     int per_cu = (int)((160 * 1024) / lds);
@@ -502,25 +548,25 @@ static hipError_t launch_dp_reg(const double *series, const kvm_query_dev &qd, c
     if (blocks > (max_in + 3) / 4) blocks = (max_in + 3) / 4;
     if (qd.early_abandon)
         hipLaunchKernelGGL((kvm_dtw_dp_reg_kernel<V, true>), dim3((unsigned)blocks), dim3(256), 0, s, series, qd, in,
-                           d_n_in, out_off, out_dist, cap, counters);
+                           suffix, seg_len, d_n_in, out_off, out_dist, cap, counters);
     else
         hipLaunchKernelGGL((kvm_dtw_dp_reg_kernel<V, false>), dim3((unsigned)blocks), dim3(256), 0, s, series, qd, in,
-                           d_n_in, out_off, out_dist, cap, counters);
+                           suffix, seg_len, d_n_in, out_off, out_dist, cap, counters);
     return hipGetLastError();
 }
 
 hipError_t kvm_launch_dtw_dp(const double *series, int64_t n, const kvm_query_dev &qd, const kvm_cand *in,
-                             const unsigned long long *d_n_in, int64_t max_in, int32_t *out_off, double *out_dist,
+                             const double *suffix, int32_t seg_len, const unsigned long long *d_n_in, int64_t max_in, int32_t *out_off, double *out_dist,
                              int64_t cap, unsigned long long *counters, int num_cu, int force_lds, hipStream_t s) {
     (void)n;
     if (max_in <= 0) return hipSuccess;
     // register form: band of r+1 even-k cells over 64 lanes, V = pow2 cells per lane, V <= 8 (r <= 511)
     const int need = (qd.rho + 1 + 63) / 64;
     if (!force_lds && need <= 8 && qd.m >= 2) {
-        if (need <= 1) return launch_dp_reg<1>(series, qd, in, d_n_in, max_in, out_off, out_dist, cap, counters, num_cu, s);
-        if (need <= 2) return launch_dp_reg<2>(series, qd, in, d_n_in, max_in, out_off, out_dist, cap, counters, num_cu, s);
-        if (need <= 4) return launch_dp_reg<4>(series, qd, in, d_n_in, max_in, out_off, out_dist, cap, counters, num_cu, s);
-        return launch_dp_reg<8>(series, qd, in, d_n_in, max_in, out_off, out_dist, cap, counters, num_cu, s);
+        if (need <= 1) return launch_dp_reg<1>(series, qd, in, suffix, seg_len, d_n_in, max_in, out_off, out_dist, cap, counters, num_cu, s);
+        if (need <= 2) return launch_dp_reg<2>(series, qd, in, suffix, seg_len, d_n_in, max_in, out_off, out_dist, cap, counters, num_cu, s);
+        if (need <= 4) return launch_dp_reg<4>(series, qd, in, suffix, seg_len, d_n_in, max_in, out_off, out_dist, cap, counters, num_cu, s);
+        return launch_dp_reg<8>(series, qd, in, suffix, seg_len, d_n_in, max_in, out_off, out_dist, cap, counters, num_cu, s);
     }
     // generic LDS form (any r)
     size_t lds = ((size_t)2 * (qd.rho + 1) + qd.m) * sizeof(double);
@@ -538,9 +584,9 @@ hipError_t kvm_launch_dtw_dp(const double *series, int64_t n, const kvm_query_de
     }
     if (qd.early_abandon)
         hipLaunchKernelGGL((kvm_dtw_dp_lds_kernel<true>), dim3((unsigned)blocks), dim3(64), lds, s, series, qd, in,
-                           d_n_in, out_off, out_dist, cap, counters);
+                           suffix, seg_len, d_n_in, out_off, out_dist, cap, counters);
     else
         hipLaunchKernelGGL((kvm_dtw_dp_lds_kernel<false>), dim3((unsigned)blocks), dim3(64), lds, s, series, qd, in,
-                           d_n_in, out_off, out_dist, cap, counters);
+                           suffix, seg_len, d_n_in, out_off, out_dist, cap, counters);
     return hipGetLastError();
 }

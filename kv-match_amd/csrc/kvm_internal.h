@@ -109,11 +109,13 @@ hipError_t kvm_launch_ed_tiled(const double *series, const double2 *prefix, int6
 hipError_t kvm_launch_dtw_filter(const double *series, const double2 *prefix, int64_t n, const kvm_query_dev &qd,
                                  const kvm_tile *tiles, int64_t n_tiles, int32_t use_lb, kvm_cand *out,
                                  unsigned long long *counters, hipStream_t s);
+#define KVM_DTW_NSEG 16  // coarse LB_Keogh suffix: segments per candidate (see kvm_dtw_keogh_kernel)
 hipError_t kvm_launch_dtw_keogh(const double *series, const double *env_u, const double *env_l, int64_t n,
                                 const kvm_query_dev &qd, const kvm_cand *in, const unsigned long long *d_n_in,
-                                int64_t max_in, kvm_cand *out, unsigned long long *counters, hipStream_t s);
+                                int64_t max_in, kvm_cand *out, double *out_suffix, int32_t seg_len,
+                                unsigned long long *counters, hipStream_t s);
 hipError_t kvm_launch_dtw_dp(const double *series, int64_t n, const kvm_query_dev &qd, const kvm_cand *in,
-                             const unsigned long long *d_n_in, int64_t max_in, int32_t *out_off, double *out_dist,
+                             const double *suffix, int32_t seg_len, const unsigned long long *d_n_in, int64_t max_in, int32_t *out_off, double *out_dist,
                              int64_t cap, unsigned long long *counters, int num_cu, int force_lds, hipStream_t s);
 
 // counters layout (unsigned long long[16])
