@@ -316,6 +316,8 @@ static int build_plan(kvm_ctx *ctx, bool cnsm, int32_t m, const int32_t *left, c
             kvm_tile t;
             t.start = (int32_t)s;
             t.count = (int32_t)std::min<int64_t>(tile_max, hi - s + 1);
+            t.run_start = (int32_t)lo;  // the reference restarts ex/ex2 here (K/NormQueryEngine.java:487-491)
+            t.pad = 0;
             pl.tiles.push_back(t);
             pl.windows += t.count;
         }
@@ -411,18 +413,37 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
         for (int i = 0; i < m; i++) q[i] = (query[i] - qd.meanQ) / qd.stdQ;
     }
     if (dtw) query_envelope(q, rho, qu, ql);
+    // cNSM-ED exact pass: the reference sums over the |zQ|-descending permutation (stable sort with
+    // Double.compare(|o2|, |o1|), K/NormQueryEngine.java:443-452)
+    std::vector<int32_t> order;
+    std::vector<double> zqs;
+    if (cnsm && !dtw) {
+        order.resize(m);
+        std::iota(order.begin(), order.end(), 0);
+        std::stable_sort(order.begin(), order.end(),
+                         [&](int32_t a, int32_t b) { return std::fabs(q[a]) > std::fabs(q[b]); });
+        zqs.resize(m);
+        for (int i = 0; i < m; i++) zqs[i] = q[order[i]];
+    }
 
     // ---- uploads (one pinned staging area: query | envelopes | tiles) ----
-    const size_t qbytes = (size_t)m * 8 * (dtw ? 3 : 1);
+    // query block: q | (qu | ql for DTW) | (zQ sorted | order for the cNSM-ED exact pass), padded
+    const size_t qmain = (size_t)m * 8 * (dtw ? 3 : 1) + KVM_SERIES_PAD * sizeof(double);
+    const size_t qbytes = qmain + ((cnsm && !dtw) ? (size_t)m * 12 : 0);
     const size_t tbytes = pl.tiles.size() * sizeof(kvm_tile);
     rc = ensure_pinned(ctx, qbytes + tbytes + 64);
     if (rc) return rc;
-    // KVM_SERIES_PAD spare doubles: the tiled ED kernel stages whole query chunks without bounds checks
-    if ((rc = ensure(ctx, ctx->b_query, qbytes + KVM_SERIES_PAD * sizeof(double)))) return rc;
+    // (KVM_SERIES_PAD spare doubles after q: the tiled ED kernel stages whole query chunks without bounds checks)
+    if ((rc = ensure(ctx, ctx->b_query, qbytes + 64))) return rc;
     if ((rc = ensure(ctx, ctx->b_tiles, tbytes + 64))) return rc;
     if ((rc = ensure(ctx, ctx->b_counters, KVM_CNT_TOTAL * sizeof(unsigned long long)))) return rc;
     char *hp = (char *)ctx->h_pinned;
+    std::memset(hp, 0, qmain);
     std::memcpy(hp, q.data(), (size_t)m * 8);
+    if (cnsm && !dtw) {
+        std::memcpy(hp + qmain, zqs.data(), (size_t)m * 8);
+        std::memcpy(hp + qmain + (size_t)m * 8, order.data(), (size_t)m * 4);
+    }
     if (dtw) {
         std::memcpy(hp + (size_t)m * 8, qu.data(), (size_t)m * 8);
         std::memcpy(hp + (size_t)m * 16, ql.data(), (size_t)m * 8);
@@ -444,12 +465,20 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
 
     if (ctx->opt_timing) HIPCHK(ctx, hipEventRecord(ctx->ev0, stream));
     if (!dtw) {
+        // pruning pass (fast kernels, guard band) -> survivors -> exact pass in the reference's operation order
+        if ((rc = ensure(ctx, ctx->b_cands, (size_t)pl.windows * sizeof(kvm_surv) + 64))) return rc;
+        kvm_surv *surv = (kvm_surv *)ctx->b_cands.p;
         if (ed_kernel == 2)
-            HIPCHK(ctx, kvm_launch_ed_tiled(ctx->d_series, ctx->d_prefix, ctx->n, qd, d_tiles, n_tiles, out.d_off,
-                                            out.d_dist, out.cap, counters, stream));
+            HIPCHK(ctx, kvm_launch_ed_tiled(ctx->d_series, ctx->d_prefix, ctx->n, qd, d_tiles, n_tiles, surv,
+                                            pl.windows, counters, stream));
         else
-            HIPCHK(ctx, kvm_launch_ed_wave(ctx->d_series, ctx->d_prefix, ctx->n, qd, d_tiles, n_tiles, out.d_off,
-                                           out.d_dist, out.cap, counters, stream));
+            HIPCHK(ctx, kvm_launch_ed_wave(ctx->d_series, ctx->d_prefix, ctx->n, qd, d_tiles, n_tiles, surv,
+                                           pl.windows, counters, stream));
+        if (ctx->opt_timing) HIPCHK(ctx, hipEventRecord(ctx->ev1, stream));
+        const double *q_exact = cnsm ? (const double *)((const char *)ctx->b_query.p + qmain) : qd.q;
+        const int32_t *d_order = cnsm ? (const int32_t *)((const char *)ctx->b_query.p + qmain + (size_t)m * 8) : nullptr;
+        HIPCHK(ctx, kvm_launch_exact_ed(ctx->d_series, qd, q_exact, d_order, surv, counters + KVM_CNT_CANDS1, pl.windows,
+                                        out.d_off, out.d_dist, out.cap, counters, ctx->num_cu, stream));
     } else {
         const int use_lb = (int)ctx->opt_lb_cascade;
         if ((rc = ensure(ctx, ctx->b_cands, (size_t)pl.windows * sizeof(kvm_cand) + 64))) return rc;
@@ -473,11 +502,17 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
             dp_n = counters + KVM_CNT_CANDS2;
             dp_suffix = (const double *)ctx->b_aux.p;
         }
+        // cNSM: replay the reference's running sums for the candidates that reach the DP (exact mean/std and
+        // exact (alpha, beta) decision), so that the DP -- bit-exact per cell -- returns the reference's distance
+        if (cnsm)
+            HIPCHK(ctx, kvm_launch_exact_stats(ctx->d_series, qd, const_cast<kvm_cand *>(dp_in), dp_n, pl.windows,
+                                               counters, ctx->num_cu, stream));
+        if (ctx->opt_timing) HIPCHK(ctx, hipEventRecord(ctx->ev0, stream));  // time the DP kernel alone
         HIPCHK(ctx, kvm_launch_dtw_dp(ctx->d_series, ctx->n, qd, dp_in, dp_suffix, seg_len, dp_n, pl.windows, out.d_off, out.d_dist,
                                       out.cap, counters, ctx->num_cu, ctx->opt_dp_kernel == 1 ? 1 : 0, stream));
     }
     if (ctx->opt_timing) {
-        HIPCHK(ctx, hipEventRecord(ctx->ev1, stream));
+        if (dtw) HIPCHK(ctx, hipEventRecord(ctx->ev1, stream));  // (ED: ev1 was recorded right after the ED kernel)
         HIPCHK(ctx, hipEventSynchronize(ctx->ev1));
         float ms = 0;
         HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
@@ -540,6 +575,7 @@ static int verify_host(kvm_ctx *ctx, int variant, const double *query, int32_t m
     const bool cnsm = variant == V_CNSM_ED || variant == V_CNSM_DTW;
     const bool dtw = variant == V_RSM_DTW || variant == V_CNSM_DTW;
     r->stats[KVM_STAT_PASS_FILTER] = cnsm ? (int64_t)hc[KVM_CNT_PASS_FILTER] : pl.windows;
+    r->stats[KVM_STAT_RECHECKED] = (int64_t)hc[KVM_CNT_RECHECKED];
     if (dtw) {
         r->stats[KVM_STAT_PASS_LB_KIM] = (int64_t)hc[KVM_CNT_PASS_KIM];
         r->stats[KVM_STAT_PASS_LB_KEOGH] = ctx->opt_lb_cascade ? (int64_t)hc[KVM_CNT_PASS_KEOGH] : (int64_t)hc[KVM_CNT_PASS_KIM];

@@ -38,16 +38,20 @@ __global__ __launch_bounds__(256) void kvm_dtw_filter_kernel(const double *__res
     bool pass_filter = false, pass_kim = false;
     const int32_t start = tile.start + lane;
     double mean = 0.0, std = 1.0;
+    double lim = qd.eps2 * (1.0 + 1e-9);  // pruning threshold of the lower bounds: eps^2 plus the guard band
     if (alive) {
         if (NORM) {
             kvm_window_mean_std(prefix, series, (int64_t)start - 1, m, mean, std);
-            pass_filter = kvm_cnsm_filter(mean, std, qd.meanQ, qd.stdQ, qd.alpha, qd.beta);
+            const double g = kvm_sigma_guard(mean, std);
+            pass_filter = kvm_cnsm_filter_guarded(mean, std, qd.meanQ, qd.stdQ, qd.alpha, qd.beta, g);
+            lim = qd.eps2 + kvm_eps2_slack(qd.eps2, m, g, 16.0);
+            if (!(std == std) || !(std > 0.0)) { std = __builtin_nan(""); lim = __builtin_huge_val(); }  // exact pass decides
         } else {
             pass_filter = true;
         }
     }
     if (pass_filter) {
-        if (use_lb && m >= 6) {
+        if (use_lb && m >= 6 && std == std) {
             const double *__restrict__ tt = series + (start - 1);
             double d, lb;
             double x0 = (tt[0] - mean) / std;
@@ -73,7 +77,7 @@ __global__ __launch_bounds__(256) void kvm_dtw_filter_kernel(const double *__res
             d = fmin(d, dsq(y2, q[m - 2]));
             d = fmin(d, dsq(y2, q[m - 1]));
             lb += d;
-            pass_kim = lb <= qd.eps2;
+            pass_kim = lb <= lim;
         } else {
             pass_kim = true;
         }
@@ -93,7 +97,7 @@ __global__ __launch_bounds__(256) void kvm_dtw_filter_kernel(const double *__res
         const unsigned long long below = bk & ((1ULL << lane) - 1ULL);
         kvm_cand c;
         c.start = start;
-        c.pad = 0;
+        c.run_start = tile.run_start;
         c.mean = mean;
         c.std = std;
         out[base + __popcll(below)] = c;
@@ -144,6 +148,19 @@ __global__ __launch_bounds__(256) void kvm_dtw_keogh_kernel(const double *__rest
         const kvm_cand c = in[idx];
         const double *__restrict__ x = series + (c.start - 1);
         const double inv = 1.0 / c.std;
+        // pruning threshold: eps^2 plus the guard band that covers the sigma uncertainty (cNSM) and summation order
+        const double lim = qd.normalised ? eps2 + kvm_eps2_slack(eps2, m, kvm_sigma_guard(c.mean, c.std), 16.0)
+                                         : eps2 * (1.0 + 1e-9);
+        if (!(c.std == c.std)) {  // degenerate sigma in the pruning arithmetic: no bound, the exact pass decides
+            if (lane == 0) {
+                atomicAdd(&counters[KVM_CNT_PASS_KEOGH], 1ULL);
+                atomicAdd(&counters[KVM_CNT_PASS_KEOGH2], 1ULL);
+                const unsigned long long o = atomicAdd(&counters[KVM_CNT_CANDS2], 1ULL);
+                out[o] = c;
+                for (int s = 0; s < KVM_DTW_NSEG; s++) out_suffix[o * KVM_DTW_NSEG + s] = 0.0;
+            }
+            continue;
+        }
         double lb1 = 0.0;
         for (int s = 0; s < KVM_DTW_NSEG; s++) {
             const int j1 = min(m, (s + 1) * seg_len);
@@ -161,7 +178,7 @@ __global__ __launch_bounds__(256) void kvm_dtw_keogh_kernel(const double *__rest
             if (lane == 0) segs[wave][0][s] = p;
             lb1 += p;
         }
-        if (!(lb1 <= eps2)) continue;
+        if (!(lb1 <= lim)) continue;
         bool pass2 = true;
         double lb2 = 0.0;
         if (env_u) {
@@ -183,7 +200,7 @@ __global__ __launch_bounds__(256) void kvm_dtw_keogh_kernel(const double *__rest
                 if (lane == 0) segs[wave][1][s] = p;
                 lb2 += p;
             }
-            pass2 = lb2 <= eps2;
+            pass2 = lb2 <= lim;
         }
         unsigned long long o = 0;
         if (lane == 0) {
@@ -258,7 +275,10 @@ __global__ __launch_bounds__(64) void kvm_dtw_dp_lds_kernel(const double *__rest
         idx = __shfl(idx, 0, 64);
         if (idx >= n_in) break;
         const kvm_cand c = in[idx];
+        if (c.start < 0) continue;  // rejected by the exact (alpha, beta) test
         const double *__restrict__ x = series + (c.start - 1);
+        const double lim_rest = qd.normalised ? eps2 + kvm_eps2_slack(eps2, m, kvm_sigma_guard(c.mean, c.std), 16.0)
+                                              : eps2 * (1.0 + 1e-9);
         // zT[k] = (T[k+j] - mean) / std   (K/NormQueryEngineDtw.java:564-567); RSM: mean 0, std 1 -> exact copy
         for (int i = lane; i < m; i += 64) A[i] = (x[i] - c.mean) / c.std;
         for (int e = lane; e <= r; e += 64) {
@@ -314,7 +334,8 @@ __global__ __launch_bounds__(64) void kvm_dtw_dp_lds_kernel(const double *__rest
                     const int sidx = ((d + r) / 2 + 1 + seg_len - 1) / seg_len;
                     rest = sidx < KVM_DTW_NSEG ? suffix[idx * KVM_DTW_NSEG + sidx] : 0.0;
                 }
-                if (mn + rest > eps2) {
+                // `rest` comes from the pruning arithmetic (approximate sigma, other summation order): guard band
+                if (mn + rest > (rest > 0.0 ? lim_rest : eps2)) {
                     dead = true;
                     break;
                 }
@@ -416,8 +437,11 @@ __global__ __launch_bounds__(256) void kvm_dtw_dp_reg_kernel(const double *__res
         idx = __shfl(idx, 0, 64);
         if (idx >= n_in) break;
         const kvm_cand cand = in[idx];
+        if (cand.start < 0) continue;  // rejected by the exact (alpha, beta) test
         const double *__restrict__ x = series + (cand.start - 1);
         const double mean = cand.mean, sd = cand.std;
+        const double lim_rest = qd.normalised ? eps2 + kvm_eps2_slack(eps2, m, kvm_sigma_guard(mean, sd), 16.0)
+                                              : eps2 * (1.0 + 1e-9);
 
         // zT[k] = (T[k+j] - mean) / std (K/NormQueryEngineDtw.java:564-567); RSM: (x - 0) / 1 == x exactly
         auto fillA = [&](int lo, int cnt) {
@@ -520,7 +544,8 @@ __global__ __launch_bounds__(256) void kvm_dtw_dp_reg_kernel(const double *__res
                     const int sidx = (Ic + 64 + seg_len - 1) / seg_len;
                     rest = sidx < KVM_DTW_NSEG ? suffix[idx * KVM_DTW_NSEG + sidx] : 0.0;
                 }
-                if (mn + rest > eps2) {
+                // `rest` comes from the pruning arithmetic (approximate sigma, other summation order): guard band
+                if (mn + rest > (rest > 0.0 ? lim_rest : eps2)) {
                     dead = true;
                     break;
                 }

@@ -17,8 +17,7 @@ template <bool NORM, bool ABANDON>
 __global__ __launch_bounds__(256) void kvm_ed_wave_kernel(const double *__restrict__ series,
                                                           const double2 *__restrict__ prefix, kvm_query_dev qd,
                                                           const kvm_tile *__restrict__ tiles,
-                                                          int32_t *__restrict__ out_off,
-                                                          double *__restrict__ out_dist, int64_t cap,
+                                                          kvm_surv *__restrict__ surv, int64_t cap,
                                                           unsigned long long *__restrict__ counters) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const kvm_tile tile = tiles[blockIdx.x];
@@ -30,13 +29,16 @@ __global__ __launch_bounds__(256) void kvm_ed_wave_kernel(const double *__restri
     for (int c = wave; c < tile.count; c += 4) {
         const int32_t start = tile.start + c;                  // 1-based window start
         const double *__restrict__ x = series + (start - 1);  // window
-        double mean = 0.0, inv = 1.0;
+        double mean = 0.0, inv = 1.0, lim = eps2 * (1.0 + 1e-9);  // pruning threshold = eps^2 + guard band
         if (NORM) {
             double std;
             kvm_window_mean_std(prefix, series, (int64_t)start - 1, m, mean, std);
-            if (!kvm_cnsm_filter(mean, std, qd.meanQ, qd.stdQ, qd.alpha, qd.beta)) continue;  // wave-uniform
+            const double g = kvm_sigma_guard(mean, std);
+            if (!kvm_cnsm_filter_guarded(mean, std, qd.meanQ, qd.stdQ, qd.alpha, qd.beta, g)) continue;  // wave-uniform
             passed++;
             inv = 1.0 / std;
+            lim = eps2 + kvm_eps2_slack(eps2, m, g, 4.0);
+            if (!(std == std) || !(std > 0.0)) { inv = 0.0; lim = __builtin_huge_val(); }  // exact pass decides
         }
         double acc = 0.0;
         bool dead = false;
@@ -51,7 +53,7 @@ __global__ __launch_bounds__(256) void kvm_ed_wave_kernel(const double *__restri
             }
             if (ABANDON && jend < m) {
                 // partial sums only grow: once the wave total exceeds eps^2 the candidate is not an answer
-                if (kvm_wave_sum(acc) > eps2) {
+                if (kvm_wave_sum(acc) > lim) {
                     dead = true;
                     break;
                 }
@@ -59,26 +61,23 @@ __global__ __launch_bounds__(256) void kvm_ed_wave_kernel(const double *__restri
         }
         if (dead) continue;
         const double total = kvm_wave_sum(acc);
-        if (total <= eps2 && lane == 0) {
-            unsigned long long idx = atomicAdd(&counters[KVM_CNT_ANSWERS], 1ULL);
-            if ((int64_t)idx < cap) {
-                out_off[idx] = start;
-                out_dist[idx] = sqrt(total);
-            }
+        if (total <= lim && lane == 0) {
+            unsigned long long idx = atomicAdd(&counters[KVM_CNT_CANDS1], 1ULL);
+            if ((int64_t)idx < cap) surv[idx] = kvm_surv{start, tile.run_start};
         }
     }
     if (NORM && lane == 0 && passed) atomicAdd(&counters[KVM_CNT_PASS_FILTER], (unsigned long long)passed);
 }
 
 hipError_t kvm_launch_ed_wave(const double *series, const double2 *prefix, int64_t n, const kvm_query_dev &qd,
-                              const kvm_tile *tiles, int64_t n_tiles, int32_t *out_off, double *out_dist,
-                              int64_t cap, unsigned long long *counters, hipStream_t s) {
+                              const kvm_tile *tiles, int64_t n_tiles, kvm_surv *surv, int64_t cap,
+                              unsigned long long *counters, hipStream_t s) {
     (void)n;
     if (n_tiles <= 0) return hipSuccess;
     dim3 grid((unsigned)n_tiles), block(256);
 #define LAUNCH(NORM, AB)                                                                                       \
-    hipLaunchKernelGGL((kvm_ed_wave_kernel<NORM, AB>), grid, block, 0, s, series, prefix, qd, tiles, out_off, \
-                       out_dist, cap, counters)
+    hipLaunchKernelGGL((kvm_ed_wave_kernel<NORM, AB>), grid, block, 0, s, series, prefix, qd, tiles, surv, cap, \
+                       counters)
     if (qd.normalised) {
         if (qd.early_abandon) LAUNCH(true, true); else LAUNCH(true, false);
     } else {

@@ -37,8 +37,7 @@ template <bool NORM, bool ABANDON>
 __global__ __launch_bounds__(256, 3) void kvm_ed_tiled_kernel(const double *__restrict__ series, int64_t n,
                                                               const double2 *__restrict__ prefix, kvm_query_dev qd,
                                                               const kvm_tile *__restrict__ tiles, int64_t n_tiles,
-                                                              int32_t *__restrict__ out_off,
-                                                              double *__restrict__ out_dist, int64_t cap,
+                                                              kvm_surv *__restrict__ surv, int64_t cap,
                                                               unsigned long long *__restrict__ counters) {
     __shared__ __attribute__((aligned(256))) double kvm_ed_lds[4 * ED_WAVE_LDS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -52,32 +51,43 @@ __global__ __launch_bounds__(256, 3) void kvm_ed_tiled_kernel(const double *__re
     // tile descriptors of the wave's four rows (wave-uniform values)
     const int64_t t0 = ((int64_t)blockIdx.x * 4 + wave) * ED_ROWS;
     if (t0 >= n_tiles) return;
-    int32_t rstart[ED_ROWS], rcount[ED_ROWS];
+    int32_t rstart[ED_ROWS], rcount[ED_ROWS], rrun[ED_ROWS];
 #pragma unroll
     for (int r = 0; r < ED_ROWS; r++) {
         if (t0 + r < n_tiles) {
             const kvm_tile t = tiles[t0 + r];
             rstart[r] = t.start;
             rcount[r] = t.count;
+            rrun[r] = t.run_start;
         } else {
             rstart[r] = 1;  // empty row: stage from the head of the series (always readable), results discarded
             rcount[r] = 0;
+            rrun[r] = 1;
         }
     }
     // static selects (a runtime-indexed register array would be demoted to scratch)
     const int32_t my_start = row == 0 ? rstart[0] : row == 1 ? rstart[1] : row == 2 ? rstart[2] : rstart[3];
     const int32_t my_count = row == 0 ? rcount[0] : row == 1 ? rcount[1] : row == 2 ? rcount[2] : rcount[3];
+    const int32_t my_run = row == 0 ? rrun[0] : row == 1 ? rrun[1] : row == 2 ? rrun[2] : rrun[3];
     const int c0 = 2 * lc;
     bool v0 = c0 < my_count, v1 = c0 + 1 < my_count;
     double mean0 = 0.0, sd0 = 1.0, mean1 = 0.0, sd1 = 1.0;
+    // pruning thresholds (in units of acc, i.e. before the division by sd^2): eps^2 plus the guard band
+    double lim0 = eps2 * (1.0 + 1e-9), lim1 = lim0;
     if (NORM) {
         if (v0) {
             kvm_window_mean_std(prefix, series, (int64_t)my_start - 1 + c0, m, mean0, sd0);
-            v0 = kvm_cnsm_filter(mean0, sd0, qd.meanQ, qd.stdQ, qd.alpha, qd.beta);
+            const double g = kvm_sigma_guard(mean0, sd0);
+            v0 = kvm_cnsm_filter_guarded(mean0, sd0, qd.meanQ, qd.stdQ, qd.alpha, qd.beta, g);
+            lim0 = (eps2 + kvm_eps2_slack(eps2, m, g, 4.0)) * (sd0 * sd0);
+            if (!(sd0 == sd0) || !(sd0 > 0.0)) { mean0 = 0.0; sd0 = 0.0; lim0 = __builtin_huge_val(); }  // exact pass decides
         }
         if (v1) {
             kvm_window_mean_std(prefix, series, (int64_t)my_start + c0, m, mean1, sd1);
-            v1 = kvm_cnsm_filter(mean1, sd1, qd.meanQ, qd.stdQ, qd.alpha, qd.beta);
+            const double g = kvm_sigma_guard(mean1, sd1);
+            v1 = kvm_cnsm_filter_guarded(mean1, sd1, qd.meanQ, qd.stdQ, qd.alpha, qd.beta, g);
+            lim1 = (eps2 + kvm_eps2_slack(eps2, m, g, 4.0)) * (sd1 * sd1);
+            if (!(sd1 == sd1) || !(sd1 > 0.0)) { mean1 = 0.0; sd1 = 0.0; lim1 = __builtin_huge_val(); }
         }
         const unsigned long long b0 = __ballot(v0), b1 = __ballot(v1);
         if (lane == 0 && (b0 | b1))
@@ -176,9 +186,8 @@ __global__ __launch_bounds__(256, 3) void kvm_ed_tiled_kernel(const double *__re
         }
         if (more) {
             if (ABANDON) {
-                const double lim0 = NORM ? eps2 * (sd0 * sd0) : eps2, lim1 = NORM ? eps2 * (sd1 * sd1) : eps2;
-                // partial sums only grow; the 1e-9 relative guard keeps rounding from ever dropping an answer
-                const bool alive = (v0 && acc0 <= lim0 * (1.0 + 1e-9)) || (v1 && acc1 <= lim1 * (1.0 + 1e-9));
+                // partial sums only grow: once both candidates of every lane exceed their pruning threshold the wave is done
+                const bool alive = (v0 && acc0 <= lim0) || (v1 && acc1 <= lim1);
                 if (!__any(alive)) return;
             }
             store_chunk();  // program order: after this chunk's LDS reads
@@ -187,35 +196,26 @@ __global__ __launch_bounds__(256, 3) void kvm_ed_tiled_kernel(const double *__re
 #undef ED_TERM
 #undef ED_GROUP
 #undef ED_FETCH
-    if (NORM) {
-        acc0 = acc0 / (sd0 * sd0);
-        acc1 = acc1 / (sd1 * sd1);
+    // survivors of the pruning pass; the exact pass (kvm_exact.hip) computes the reference's distance and decides
+    if (v0 && acc0 <= lim0) {
+        unsigned long long idx = atomicAdd(&counters[KVM_CNT_CANDS1], 1ULL);
+        if ((int64_t)idx < cap) surv[idx] = kvm_surv{my_start + c0, my_run};
     }
-    if (v0 && acc0 <= eps2) {
-        unsigned long long idx = atomicAdd(&counters[KVM_CNT_ANSWERS], 1ULL);
-        if ((int64_t)idx < cap) {
-            out_off[idx] = my_start + c0;
-            out_dist[idx] = sqrt(acc0);
-        }
-    }
-    if (v1 && acc1 <= eps2) {
-        unsigned long long idx = atomicAdd(&counters[KVM_CNT_ANSWERS], 1ULL);
-        if ((int64_t)idx < cap) {
-            out_off[idx] = my_start + c0 + 1;
-            out_dist[idx] = sqrt(acc1);
-        }
+    if (v1 && acc1 <= lim1) {
+        unsigned long long idx = atomicAdd(&counters[KVM_CNT_CANDS1], 1ULL);
+        if ((int64_t)idx < cap) surv[idx] = kvm_surv{my_start + c0 + 1, my_run};
     }
 }
 
 hipError_t kvm_launch_ed_tiled(const double *series, const double2 *prefix, int64_t n, const kvm_query_dev &qd,
-                               const kvm_tile *tiles, int64_t n_tiles, int32_t *out_off, double *out_dist,
-                               int64_t cap, unsigned long long *counters, hipStream_t s) {
+                               const kvm_tile *tiles, int64_t n_tiles, kvm_surv *surv, int64_t cap,
+                               unsigned long long *counters, hipStream_t s) {
     if (n_tiles <= 0) return hipSuccess;
     const int64_t blocks = (n_tiles + 4 * ED_ROWS - 1) / (4 * ED_ROWS);
     dim3 grid((unsigned)blocks), block(256);
 #define LAUNCH(NORM, AB)                                                                                        \
     hipLaunchKernelGGL((kvm_ed_tiled_kernel<NORM, AB>), grid, block, 0, s, series, n, prefix, qd, tiles, n_tiles, \
-                       out_off, out_dist, cap, counters)
+                       surv, cap, counters)
     if (qd.normalised) {
         if (qd.early_abandon) LAUNCH(true, true); else LAUNCH(true, false);
     } else {

@@ -30,14 +30,22 @@ struct kvm_run {
 
 // Tile = up to `count` consecutive candidates taken from one run.
 struct kvm_tile {
+    int32_t start;      // first window start offset of the tile (1-based)
+    int32_t count;      // consecutive offsets in the tile
+    int32_t run_start;  // first window start offset of the tile's whole run (where the reference's running sums restart)
+    int32_t pad;
+};
+
+// Survivor of a fast ED kernel, to be decided by the exact pass (kvm_exact.hip).
+struct kvm_surv {
     int32_t start;
-    int32_t count;
+    int32_t run_start;
 };
 
 // Survivor record flowing between the cascade kernels.
 struct kvm_cand {
-    int32_t start;  // window start offset (1-based)
-    int32_t pad;
+    int32_t start;      // window start offset (1-based); negated once the exact (alpha, beta) test rejects it
+    int32_t run_start;  // first window start offset of its run
     double mean;
     double std;
 };
@@ -95,15 +103,22 @@ struct kvm_query_dev {
     int32_t early_abandon;
 };
 
-// ED: wave-per-candidate kernel over tiles.  counters[0] = #answers, counters[1] = #windows,
-// counters[2] = #passed filter.
+// ED pruners: survivors (decision quantity within the guard band of eps^2, filter within its guard band) are appended
+// to `surv` (count in counters[KVM_CNT_CANDS1]); the exact pass decides.  Wave-per-candidate and LDS-tiled forms.
 hipError_t kvm_launch_ed_wave(const double *series, const double2 *prefix, int64_t n, const kvm_query_dev &qd,
-                              const kvm_tile *tiles, int64_t n_tiles, int32_t *out_off, double *out_dist,
-                              int64_t cap, unsigned long long *counters, hipStream_t s);
-// ED: LDS-tiled kernel for dense runs.
+                              const kvm_tile *tiles, int64_t n_tiles, kvm_surv *surv, int64_t cap,
+                              unsigned long long *counters, hipStream_t s);
 hipError_t kvm_launch_ed_tiled(const double *series, const double2 *prefix, int64_t n, const kvm_query_dev &qd,
-                               const kvm_tile *tiles, int64_t n_tiles, int32_t *out_off, double *out_dist,
-                               int64_t cap, unsigned long long *counters, hipStream_t s);
+                               const kvm_tile *tiles, int64_t n_tiles, kvm_surv *surv, int64_t cap,
+                               unsigned long long *counters, hipStream_t s);
+// Exact final pass (kvm_exact.hip)
+hipError_t kvm_launch_exact_ed(const double *series, const kvm_query_dev &qd, const double *q_exact,
+                               const int32_t *order, const kvm_surv *surv, const unsigned long long *d_n_surv,
+                               int64_t max_surv, int32_t *out_off, double *out_dist, int64_t cap,
+                               unsigned long long *counters, int num_cu, hipStream_t s);
+hipError_t kvm_launch_exact_stats(const double *series, const kvm_query_dev &qd, kvm_cand *cands,
+                                  const unsigned long long *d_n, int64_t max_n, unsigned long long *counters,
+                                  int num_cu, hipStream_t s);
 
 // DTW cascade.
 hipError_t kvm_launch_dtw_filter(const double *series, const double2 *prefix, int64_t n, const kvm_query_dev &qd,
@@ -128,6 +143,8 @@ hipError_t kvm_launch_dtw_dp(const double *series, int64_t n, const kvm_query_de
 #define KVM_CNT_QUEUE 6   // work-queue head of the DP kernel
 #define KVM_CNT_CANDS1 7  // #records in cands (after filter/Kim)
 #define KVM_CNT_CANDS2 8  // #records in cands2 (after Keogh)
+#define KVM_CNT_RECHECKED 9           // evaluations done by the exact pass
+#define KVM_CNT_PASS_FILTER_EXACT 10  // candidates passing the exact (alpha, beta) test
 #define KVM_CNT_TOTAL 16
 
 // ---- device helpers ---------------------------------------------------------------------------------
@@ -179,6 +196,27 @@ __device__ __forceinline__ void kvm_window_mean_std(const double2 *__restrict__ 
 __device__ __forceinline__ bool kvm_cnsm_filter(double mean, double std, double meanQ, double stdQ, double alpha,
                                                 double beta) {
     return fabs(mean - meanQ) <= beta && (std / stdQ) <= alpha && (std / stdQ) >= 1.0 / alpha;
+}
+
+// ---- guard bands of the pruning kernels (the exact pass decides inside them) ----
+// Relative uncertainty between this library's sigma (shifted prefix sums) and the reference's (running sums,
+// sqrt(ex2/m - mean^2)): the reference loses about E[x^2]/var ulps times the drift of ~1e4 additions.
+__device__ __forceinline__ double kvm_sigma_guard(double mean, double std) {
+    const double var = std * std;
+    const double g = 1e-9 + 1e-12 * ((mean * mean + var) / var);
+    return (g < 0.25) ? g : 0.25;  // also catches NaN / zero variance
+}
+// (alpha, beta) test widened by the guard; NaN sigma (variance rounded below zero) is left to the exact pass.
+__device__ __forceinline__ bool kvm_cnsm_filter_guarded(double mean, double std, double meanQ, double stdQ, double alpha,
+                                                        double beta, double g) {
+    if (!(std == std)) return true;
+    const double gm = 1e-9 * fmax(1.0, fmax(fabs(mean), fabs(meanQ)));
+    const double ratio = std / stdQ;
+    return fabs(mean - meanQ) <= beta + gm && ratio <= alpha * (1.0 + g) && ratio >= (1.0 / alpha) * (1.0 - g);
+}
+// Slack on eps^2 for a z-normalised distance computed with a sigma that is off by relative g: d(dist^2) ~ 2 g sqrt(m) dist.
+__device__ __forceinline__ double kvm_eps2_slack(double eps2, int32_t m, double g, double factor) {
+    return eps2 * 1e-9 + factor * g * sqrt((double)m * eps2);
 }
 
 __device__ __forceinline__ double kvm_wave_sum(double v) {

@@ -1,6 +1,7 @@
 """GPU parity tests (-m gpu): the HIP path, called through the C ABI, against the CPU oracle on the same seeded
-inputs.  Bar: identical answer offsets and #answers, cntCandidate identical, distances within 1e-6 relative
-(absolute floor 1e-9); RSM-DTW distances bit-identical (same cell operations on the same inputs)."""
+inputs.  Bar (north_star): identical answer offsets and #answers, distances within 1e-6 relative.  What is asserted
+is stronger: cntCandidate identical, answer list identical in content AND order, distances BIT-identical for all four
+variants (kvm_exact.hip replays the reference's running sums and sequential additions for every survivor)."""
 import numpy as np
 import pytest
 
@@ -22,7 +23,9 @@ def world(built):
     ctx.close()
 
 
-def compare(got, want, exact=False, tag="", abs_floor=1e-9):
+def compare(got, want, exact=True, tag="", abs_floor=1e-9):
+    """exact=True (default): offsets, their order and the fp64 distances are bit-identical to the oracle's -- the
+    final pass of the library re-evaluates every survivor in the reference's own operation order."""
     o_off, o_dist, o_st = want
     assert got.cnt_candidate == o_st["cnt_candidate"], tag
     assert len(got) == len(o_off), (tag, len(got), len(o_off))
@@ -157,7 +160,7 @@ def test_knobs_do_not_change_answers(world):
     finally:
         ctx.set_option(kvmatch.OPT_EARLY_ABANDON, 1)
         ctx.set_option(kvmatch.OPT_LB_CASCADE, 1)
-    assert np.array_equal(a.offsets, base_ed.offsets) and rel_close(a.distances, base_ed.distances)
+    assert np.array_equal(a.offsets, base_ed.offsets) and np.array_equal(a.distances, base_ed.distances)
     assert np.array_equal(b.offsets, base_dtw.offsets) and np.array_equal(b.distances, base_dtw.distances)
     ctx.set_option(kvmatch.OPT_DP_KERNEL, 1)  # generic LDS form of the DP
     try:
@@ -172,7 +175,7 @@ def test_knobs_do_not_change_answers(world):
             c = kvmatch.NormQueryEngine(ctx).verify((L, R), 1, q, 4.0, 1.5, 2.0)
         finally:
             ctx.set_option(kvmatch.OPT_ED_KERNEL, 0)
-        assert np.array_equal(a.offsets, base_ed.offsets) and rel_close(a.distances, base_ed.distances)
+        assert np.array_equal(a.offsets, base_ed.offsets) and np.array_equal(a.distances, base_ed.distances)
         compare(c, oracle.cnsm_ed(s, q, L, R, 0, 4.0, 1.5, 2.0), tag=f"ed kernel {k}")
 
 
@@ -227,7 +230,7 @@ def test_prefix_sums_accuracy_far_from_origin(world):
     # this library computes exactly as the reference does.  A z-normalised self-match therefore sits at
     # ~sqrt(m) * 1e-10 ~ 3e-9 instead of 0 unless both sides round identically (the oracle's self-match does: the
     # query's own window starts its interval).  Absolute floor scaled accordingly; relative tolerance unchanged.
-    compare(got, oracle.cnsm_ed(s, q, L, R, 0, 2.0, 1.5, 5.0), tag="far prefix", abs_floor=5e-8)
+    compare(got, oracle.cnsm_ed(s, q, L, R, 0, 2.0, 1.5, 5.0), tag="far prefix")
     assert len(got) >= 2
 
 
@@ -258,7 +261,7 @@ def test_full_size_properties_n1e8_m8192(built):
         ctx.set_option(kvmatch.OPT_ED_KERNEL, 0)
         ctx.set_option(kvmatch.OPT_EARLY_ABANDON, 1)
         assert np.array_equal(a.offsets, b.offsets) and np.array_equal(a.distances, b.distances)
-        assert np.array_equal(a.offsets, c.offsets) and rel_close(a.distances, c.distances)
+        assert np.array_equal(a.offsets, c.offsets) and np.array_equal(a.distances, c.distances)
         z = kvmatch.NormQueryEngine(ctx).verify((L, R), 1, q, 2.0, 1.5, 5.0)
         assert z.offsets[0] == qoff and z.distances[0] < 1e-6 and set(planted) <= set(z.offsets.tolist())
         # oracle on a bounded sample: the intervals around the query and the planted copies plus the first 300
