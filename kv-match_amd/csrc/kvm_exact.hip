@@ -17,18 +17,21 @@
 // completed sum decides identically.  No FMA anywhere (-ffp-contract=off).
 #include "kvm_internal.h"
 
-#define EX_CH 1024  // values per LDS chunk
+#define EX_CH 2048  // values per LDS chunk
 
-// lane 0: acc += buf[0..cnt) strictly in order
+// lane 0: acc += buf[0..cnt) strictly in order.  16 values are fetched per round so that the LDS latency is paid once
+// per 16 dependent additions.
 __device__ __forceinline__ double ex_seq_add(const double *buf, int cnt, double acc) {
     int t = 0;
-    for (; t + 4 <= cnt; t += 4) {
-        const double2 a = *reinterpret_cast<const double2 *>(buf + t);
-        const double2 b = *reinterpret_cast<const double2 *>(buf + t + 2);
-        acc += a.x;
-        acc += a.y;
-        acc += b.x;
-        acc += b.y;
+    for (; t + 16 <= cnt; t += 16) {
+        double2 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = *reinterpret_cast<const double2 *>(buf + t + 2 * u);
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            acc += v[u].x;
+            acc += v[u].y;
+        }
     }
     for (; t < cnt; t++) acc += buf[t];
     return acc;
@@ -36,30 +39,52 @@ __device__ __forceinline__ double ex_seq_add(const double *buf, int cnt, double 
 
 // Replays the reference's running sums for the window starting at 0-based index `ws` of the run whose first point is
 // 0-based index `b` (ws >= b), and returns mean/std of that window exactly as the reference would have them.
-// One wavefront (= one workgroup of 64 threads); bufA/bufB are EX_CH doubles each.
+// One wavefront (= one workgroup of 64 threads).  buf holds EX_CH steps x {d, d*d, o, o*o}: the products are formed
+// by all lanes (each an independently rounded operation), lane 0 only performs the additions, in the reference's
+// order: ex += d; ex2 += d*d; [window complete] ex -= o; ex2 -= o*o  (K/NormQueryEngine.java:497-499,523-524).
 __device__ __forceinline__ void ex_replay_stats(const double *__restrict__ x, int64_t b, int64_t ws, int m, int lane,
-                                                double *bufA, double *bufB, double &mean, double &std) {
+                                                double *buf, double &mean, double &std) {
     double ex = 0.0, ex2 = 0.0;
     const int64_t total = ws + m - b;  // points consumed up to and including the last point of the window
-    for (int64_t c0 = 0; c0 < total; c0 += EX_CH) {
-        const int cnt = (int)min((int64_t)EX_CH, total - c0);
+    constexpr int STEPS = EX_CH / 2;   // 4 doubles per step in a 2*EX_CH buffer
+    for (int64_t c0 = 0; c0 < total; c0 += STEPS) {
+        const int cnt = (int)min((int64_t)STEPS, total - c0);
         for (int t = lane; t < cnt; t += 64) {
             const int64_t g = c0 + t;  // step index; point index b + g
-            bufA[t] = x[b + g];
-            // the point leaving the window after step g (T[j] of K/NormQueryEngine.java:523): only for windows before ours
-            bufB[t] = (g >= m - 1 && g < total - 1) ? x[b + g - m + 1] : 0.0;
+            const double d = x[b + g];
+            // the point leaving the window after step g (T[j] of :523): only for the windows before ours
+            const double o = (g >= m - 1 && g < total - 1) ? x[b + g - m + 1] : 0.0;
+            *reinterpret_cast<double2 *>(buf + 4 * t) = make_double2(d, d * d);
+            *reinterpret_cast<double2 *>(buf + 4 * t + 2) = make_double2(o, o * o);
         }
         __syncthreads();
         if (lane == 0) {
-            for (int t = 0; t < cnt; t++) {
+            int t = 0;
+            // steps before the first complete window: additions only
+            const int n_add = (int)max((int64_t)0, min((int64_t)cnt, (int64_t)(m - 1) - c0));
+            for (; t + 4 <= n_add; t += 4) {
+                double2 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) v[u] = *reinterpret_cast<const double2 *>(buf + 4 * (t + u));
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    ex += v[u].x;
+                    ex2 += v[u].y;
+                }
+            }
+            for (; t < n_add; t++) {
+                ex += buf[4 * t];
+                ex2 += buf[4 * t + 1];
+            }
+            for (; t < cnt; t++) {
                 const int64_t g = c0 + t;
-                const double d = bufA[t];
-                ex += d;
-                ex2 += d * d;
-                if (g >= m - 1 && g < total - 1) {
-                    const double o = bufB[t];
-                    ex -= o;
-                    ex2 -= o * o;
+                const double2 dv = *reinterpret_cast<const double2 *>(buf + 4 * t);
+                const double2 ov = *reinterpret_cast<const double2 *>(buf + 4 * t + 2);
+                ex += dv.x;
+                ex2 += dv.y;
+                if (g < total - 1) {
+                    ex -= ov.x;
+                    ex2 -= ov.y;
                 }
             }
         }
@@ -83,8 +108,7 @@ __global__ __launch_bounds__(64) void kvm_exact_ed_kernel(const double *__restri
                                                           const unsigned long long *__restrict__ d_n_surv,
                                                           int32_t *__restrict__ out_off, double *__restrict__ out_dist,
                                                           int64_t cap, unsigned long long *__restrict__ counters) {
-    __shared__ __attribute__((aligned(16))) double bufA[EX_CH];
-    __shared__ __attribute__((aligned(16))) double bufB[EX_CH];
+    __shared__ __attribute__((aligned(16))) double bufA[2 * EX_CH];
     const int lane = threadIdx.x;
     const int m = qd.m;
     const double eps2 = qd.eps2;
@@ -95,7 +119,7 @@ __global__ __launch_bounds__(64) void kvm_exact_ed_kernel(const double *__restri
         const double *__restrict__ x = series + ws;
         double mean = 0.0, std = 1.0;
         if (NORM) {
-            ex_replay_stats(series, (int64_t)sv.run_start - 1, ws, m, lane, bufA, bufB, mean, std);
+            ex_replay_stats(series, (int64_t)sv.run_start - 1, ws, m, lane, bufA, mean, std);
             if (!kvm_cnsm_filter(mean, std, qd.meanQ, qd.stdQ, qd.alpha, qd.beta)) continue;  // wave-uniform
             if (lane == 0) atomicAdd(&counters[KVM_CNT_PASS_FILTER_EXACT], 1ULL);
         }
@@ -153,14 +177,13 @@ __global__ __launch_bounds__(64) void kvm_exact_stats_kernel(const double *__res
                                                              kvm_cand *__restrict__ cands,
                                                              const unsigned long long *__restrict__ d_n,
                                                              unsigned long long *__restrict__ counters) {
-    __shared__ double bufA[EX_CH];
-    __shared__ double bufB[EX_CH];
+    __shared__ __attribute__((aligned(16))) double bufA[2 * EX_CH];
     const int lane = threadIdx.x;
     const unsigned long long n = *d_n;
     for (unsigned long long idx = blockIdx.x; idx < n; idx += gridDim.x) {
         kvm_cand c = cands[idx];
         double mean, std;
-        ex_replay_stats(series, (int64_t)c.run_start - 1, (int64_t)c.start - 1, qd.m, lane, bufA, bufB, mean, std);
+        ex_replay_stats(series, (int64_t)c.run_start - 1, (int64_t)c.start - 1, qd.m, lane, bufA, mean, std);
         const bool pass = kvm_cnsm_filter(mean, std, qd.meanQ, qd.stdQ, qd.alpha, qd.beta);
         if (lane == 0) {
             c.mean = mean;
