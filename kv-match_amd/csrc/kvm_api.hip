@@ -247,10 +247,26 @@ extern "C" int32_t kvm_resolve_rho(double r, int32_t m) {
     return (int32_t)std::floor(r);
 }
 
+static bool kvm_trace_on() {
+    static int v = -1;
+    if (v < 0) v = getenv("KVM_TRACE") ? 1 : 0;
+    return v == 1;
+}
+#define KVM_TP(label)                                                                                         \
+    do {                                                                                                      \
+        if (kvm_trace_on()) {                                                                                 \
+            auto now_ = std::chrono::steady_clock::now();                                                     \
+            fprintf(stderr, "[kvm] %-22s %8.1f us\n", label,                                                  \
+                    std::chrono::duration<double, std::micro>(now_ - tp_).count());                           \
+            tp_ = now_;                                                                                       \
+        }                                                                                                     \
+    } while (0)
+
 // ---- plan: intervals -> runs -> tiles -------------------------------------------------------------------
 
 struct plan {
-    std::vector<kvm_tile> tiles;
+    std::vector<kvm_run> runs;  // clipped runs with the index of their first tile; expanded to tiles on the GPU
+    int64_t n_tiles = 0;
     int64_t cnt_candidate = 0;  // sum(right-left+1) before clipping, K/QueryEngine.java:344
     int64_t windows = 0;        // windows actually evaluated
 };
@@ -305,22 +321,21 @@ static int build_plan(kvm_ctx *ctx, bool cnsm, int32_t m, const int32_t *left, c
             }
         }
     }
-    pl.tiles.clear();
-    pl.tiles.reserve((size_t)k + 16);
+    pl.runs.clear();
+    pl.runs.reserve((size_t)k);
     for (int32_t p = 0; p < k; p++) {
         pl.cnt_candidate += (int64_t)right[p] - left[p] + 1;
         int64_t lo = (int64_t)left[p] - shift, hi = (int64_t)right[p] - shift;
         if (lo < 1) lo = 1;
         if (hi > n - m + 1) hi = n - m + 1;
-        for (int64_t s = lo; s <= hi; s += tile_max) {
-            kvm_tile t;
-            t.start = (int32_t)s;
-            t.count = (int32_t)std::min<int64_t>(tile_max, hi - s + 1);
-            t.run_start = (int32_t)lo;  // the reference restarts ex/ex2 here (K/NormQueryEngine.java:487-491)
-            t.pad = 0;
-            pl.tiles.push_back(t);
-            pl.windows += t.count;
-        }
+        if (hi < lo) continue;
+        kvm_run r;
+        r.start = (int32_t)lo;  // the reference restarts ex/ex2 here (K/NormQueryEngine.java:487-491)
+        r.count = (int32_t)(hi - lo + 1);
+        r.tile_base = pl.n_tiles;
+        pl.runs.push_back(r);
+        pl.n_tiles += (r.count + tile_max - 1) / tile_max;
+        pl.windows += r.count;
     }
     return KVM_OK;
 }
@@ -386,9 +401,11 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
     HIPCHK(ctx, hipSetDevice(ctx->device));
     // ED kernel choice: 1 = wave-per-candidate, 2 (and auto) = LDS-tiled
     const int ed_kernel = ctx->opt_ed_kernel == 1 ? 1 : 2;
-    int rc = build_plan(ctx, cnsm, m, left, right, k, shift, (!dtw && ed_kernel == 2) ? KVM_TILE_TILED : KVM_TILE_MAX,
-                        pl);
+    auto tp_ = std::chrono::steady_clock::now();
+    const int32_t tile_max = (!dtw && ed_kernel == 2) ? KVM_TILE_TILED : KVM_TILE_MAX;
+    int rc = build_plan(ctx, cnsm, m, left, right, k, shift, tile_max, pl);
     if (rc) return rc;
+    KVM_TP("  build_plan");
 
     // ---- query-side constants (host, sequential, exactly the reference's arithmetic) ----
     std::vector<double> q(query, query + m), qu, ql;
@@ -430,12 +447,14 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
     // query block: q | (qu | ql for DTW) | (zQ sorted | order for the cNSM-ED exact pass), padded
     const size_t qmain = (size_t)m * 8 * (dtw ? 3 : 1) + KVM_SERIES_PAD * sizeof(double);
     const size_t qbytes = qmain + ((cnsm && !dtw) ? (size_t)m * 12 : 0);
-    const size_t tbytes = pl.tiles.size() * sizeof(kvm_tile);
-    rc = ensure_pinned(ctx, qbytes + tbytes + 64);
+    const size_t rbytes = pl.runs.size() * sizeof(kvm_run);
+    const size_t tbytes = (size_t)pl.n_tiles * sizeof(kvm_tile);
+    rc = ensure_pinned(ctx, qbytes + rbytes + 64);
     if (rc) return rc;
     // (KVM_SERIES_PAD spare doubles after q: the tiled ED kernel stages whole query chunks without bounds checks)
     if ((rc = ensure(ctx, ctx->b_query, qbytes + 64))) return rc;
     if ((rc = ensure(ctx, ctx->b_tiles, tbytes + 64))) return rc;
+    if ((rc = ensure(ctx, ctx->b_aux2, rbytes + 64))) return rc;
     if ((rc = ensure(ctx, ctx->b_counters, KVM_CNT_TOTAL * sizeof(unsigned long long)))) return rc;
     char *hp = (char *)ctx->h_pinned;
     std::memset(hp, 0, qmain);
@@ -448,19 +467,26 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
         std::memcpy(hp + (size_t)m * 8, qu.data(), (size_t)m * 8);
         std::memcpy(hp + (size_t)m * 16, ql.data(), (size_t)m * 8);
     }
-    if (tbytes) std::memcpy(hp + qbytes, pl.tiles.data(), tbytes);
+    if (rbytes) std::memcpy(hp + qbytes, pl.runs.data(), rbytes);
+    KVM_TP("  query prep + staging");
     HIPCHK(ctx, hipMemcpyAsync(ctx->b_query.p, hp, qbytes, hipMemcpyHostToDevice, stream));
-    if (tbytes) HIPCHK(ctx, hipMemcpyAsync(ctx->b_tiles.p, hp + qbytes, tbytes, hipMemcpyHostToDevice, stream));
+    if (rbytes) {
+        // runs (16 B each) go up; the tile list (16 B per <= tile_max candidates) is expanded on the GPU
+        HIPCHK(ctx, hipMemcpyAsync(ctx->b_aux2.p, hp + qbytes, rbytes, hipMemcpyHostToDevice, stream));
+        HIPCHK(ctx, kvm_launch_expand_tiles((const kvm_run *)ctx->b_aux2.p, (int64_t)pl.runs.size(), tile_max,
+                                            (kvm_tile *)ctx->b_tiles.p, stream));
+    }
     HIPCHK(ctx, hipMemsetAsync(ctx->b_counters.p, 0, KVM_CNT_TOTAL * sizeof(unsigned long long), stream));
     qd.q = (const double *)ctx->b_query.p;
     qd.qu = dtw ? qd.q + m : nullptr;
     qd.ql = dtw ? qd.q + 2 * (size_t)m : nullptr;
     unsigned long long *counters = (unsigned long long *)ctx->b_counters.p;
     const kvm_tile *d_tiles = (const kvm_tile *)ctx->b_tiles.p;
-    const int64_t n_tiles = (int64_t)pl.tiles.size();
+    const int64_t n_tiles = pl.n_tiles;
 
     if (kernel_ns) *kernel_ns = 0;
     ctx->last_kernel_ns = 0;
+    KVM_TP("  H2D enqueue");
     if (n_tiles == 0) return KVM_OK;
 
     if (ctx->opt_timing) HIPCHK(ctx, hipEventRecord(ctx->ev0, stream));
@@ -529,6 +555,7 @@ static int verify_host(kvm_ctx *ctx, int variant, const double *query, int32_t m
     if (!result) return fail(ctx, KVM_ERR_ILLEGAL_ARGUMENT, "null result pointer");
     *result = nullptr;
     auto t0 = std::chrono::steady_clock::now();
+    auto tp_ = t0;
     plan pl;
     // capacity: every evaluated window may be an answer
     int64_t worst = 0;
@@ -538,24 +565,40 @@ static int verify_host(kvm_ctx *ctx, int variant, const double *query, int32_t m
     if ((rc = ensure(ctx, ctx->b_out_dist, (size_t)worst * 8 + 64))) return rc;
     verify_out out{(int32_t *)ctx->b_out_off.p, (double *)ctx->b_out_dist.p, worst};
     int64_t kernel_ns = 0;
+    KVM_TP("ensure out");
     rc = run_variant(ctx, variant, query, m, left, right, k, shift, epsilon, rho, alpha, beta, pl, out, ctx->stream,
                      &kernel_ns);
     if (rc) return rc;
+    KVM_TP("run_variant (launch)");
+    // One synchronisation in the common case: the counters and the first KVM_SPEC_ANSWERS answers are copied back
+    // together (answers are rare); a second copy only when there are more.
+    constexpr int64_t KVM_SPEC_ANSWERS = 1024;
     unsigned long long hc[KVM_CNT_TOTAL] = {0};
-    if (!pl.tiles.empty()) {
+    const int64_t spec = std::min<int64_t>(KVM_SPEC_ANSWERS, worst);
+    std::vector<int32_t> off((size_t)spec);
+    std::vector<double> dist((size_t)spec);
+    if (pl.n_tiles > 0) {
         HIPCHK(ctx, hipMemcpyAsync(hc, ctx->b_counters.p, sizeof hc, hipMemcpyDeviceToHost, ctx->stream));
+        if (spec) {
+            HIPCHK(ctx, hipMemcpyAsync(off.data(), out.d_off, (size_t)spec * 4, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(ctx, hipMemcpyAsync(dist.data(), out.d_dist, (size_t)spec * 8, hipMemcpyDeviceToHost, ctx->stream));
+        }
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     }
+    KVM_TP("sync + counters D2H");
     const int64_t cnt = (int64_t)hc[KVM_CNT_ANSWERS];
     if (cnt > worst) return fail(ctx, KVM_ERR_DEVICE, "answer buffer overflow (internal error)");
     kvm_result *r = new kvm_result();
-    std::vector<int32_t> off((size_t)cnt);
-    std::vector<double> dist((size_t)cnt);
-    if (cnt) {
-        HIPCHK(ctx, hipMemcpyAsync(off.data(), out.d_off, (size_t)cnt * 4, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(ctx, hipMemcpyAsync(dist.data(), out.d_dist, (size_t)cnt * 8, hipMemcpyDeviceToHost, ctx->stream));
+    off.resize((size_t)cnt);
+    dist.resize((size_t)cnt);
+    if (cnt > spec) {
+        HIPCHK(ctx, hipMemcpyAsync(off.data() + spec, out.d_off + spec, (size_t)(cnt - spec) * 4, hipMemcpyDeviceToHost,
+                                   ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(dist.data() + spec, out.d_dist + spec, (size_t)(cnt - spec) * 8,
+                                   hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     }
+    KVM_TP("answers D2H");
     // answers.sort(Comparator.comparing(Pair::getSecond)) -- stable on an offset-ascending list
     // (K/QueryEngine.java:373) == sort by (distance, offset).
     std::vector<int64_t> perm((size_t)cnt);
@@ -623,7 +666,7 @@ extern "C" int kvm_verify_device(kvm_ctx *ctx, int32_t variant, const double *qu
     int rc = run_variant(ctx, variant, query, m, left, right, k, shift, epsilon, rho, alpha, beta, pl, out, s, nullptr);
     if (rc) return rc;
     if (cnt_candidate) *cnt_candidate = pl.cnt_candidate;
-    if (pl.tiles.empty()) {
+    if (pl.n_tiles == 0) {
         HIPCHK(ctx, hipMemsetAsync(d_out_count, 0, sizeof(int64_t), s));
     } else {
         HIPCHK(ctx, hipMemcpyAsync(d_out_count, (unsigned long long *)ctx->b_counters.p + KVM_CNT_ANSWERS,

@@ -27,6 +27,34 @@ hipError_t kvm_launch_bswap64(uint64_t *d, int64_t n, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Runs -> tiles.  The host clips the phase-1 intervals into runs (K/QueryEngine.java:346-354) and knows each run's
+// first tile index; one wavefront per run writes its tile descriptors (16 B each, coalesced).
+__global__ __launch_bounds__(256) void kvm_expand_tiles_kernel(const kvm_run *__restrict__ runs, int64_t n_runs,
+                                                               int32_t tile_max, kvm_tile *__restrict__ tiles) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n_runs) return;
+    const kvm_run run = runs[r];
+    const int nt = (run.count + tile_max - 1) / tile_max;
+    for (int t = lane; t < nt; t += 64) {
+        kvm_tile tl;
+        tl.start = run.start + t * tile_max;
+        tl.count = min(tile_max, run.count - t * tile_max);
+        tl.run_start = run.start;
+        tl.pad = 0;
+        tiles[run.tile_base + t] = tl;
+    }
+}
+
+hipError_t kvm_launch_expand_tiles(const kvm_run *runs, int64_t n_runs, int32_t tile_max, kvm_tile *tiles,
+                                   hipStream_t s) {
+    if (n_runs <= 0) return hipSuccess;
+    hipLaunchKernelGGL(kvm_expand_tiles_kernel, dim3((unsigned)((n_runs + 3) / 4)), dim3(256), 0, s, runs, n_runs,
+                       tile_max, tiles);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Block-restarted inclusive prefix sums of (x - c_b) and (x - c_b)^2, c_b = first point of the block
 // (see KVM_PS_BLOCK in kvm_internal.h).
 // One workgroup scans one block of 16384 points as 16 sub-tiles of 1024 (4 consecutive points per

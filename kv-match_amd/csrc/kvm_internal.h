@@ -24,8 +24,9 @@
 
 // One candidate run = a clipped interval of consecutive window start offsets (1-based).
 struct kvm_run {
-    int32_t start;  // first window start offset (1-based)
-    int32_t count;  // number of consecutive offsets
+    int32_t start;      // first window start offset (1-based)
+    int32_t count;      // number of consecutive offsets
+    int64_t tile_base;  // index of the run's first tile in the tile list
 };
 
 // Tile = up to `count` consecutive candidates taken from one run.
@@ -87,6 +88,7 @@ struct kvm_result {
 // ---- kernel launchers (each file implements its own) -----------------------------------------------
 // common
 hipError_t kvm_launch_bswap64(uint64_t *d, int64_t n, hipStream_t s);
+hipError_t kvm_launch_expand_tiles(const kvm_run *runs, int64_t n_runs, int32_t tile_max, kvm_tile *tiles, hipStream_t s);
 hipError_t kvm_launch_prefix(const double *x, double2 *prefix, int64_t n, hipStream_t s);
 hipError_t kvm_launch_envelope(const double *x, int64_t n, int32_t rho, double *u, double *l, hipStream_t s);
 
