@@ -329,3 +329,132 @@ def test_device_resident_verifier_matches_host_api(world):
             assert np.array_equal(offs, host[variant].offsets), variant
             assert np.array_equal(dists, host[variant].distances), variant
             assert v.cnt_candidate == host[variant].cnt_candidate
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Knife edges: thresholds placed exactly ON a candidate's decision quantity (and one ulp to either side).  These force
+# the guard-band -> exact-pass route of the library (kvm_exact.hip); random data never gets there by itself.
+
+def _seq_sum(terms):
+    """fp64 additions strictly in order (what the reference's `distance += ...` loop does)."""
+    return float(np.add.accumulate(np.asarray(terms, dtype=np.float64))[-1])
+
+
+def _eps_for_d2(d2):
+    """smallest fp64 eps with eps*eps >= d2, and the largest with eps*eps < d2"""
+    e = np.sqrt(d2)
+    while e * e >= d2:
+        e = np.nextafter(e, 0.0)
+    below = e
+    while e * e < d2:
+        e = np.nextafter(e, np.inf)
+    return float(e), float(below)
+
+
+def test_knife_edge_rsm_ed_epsilon(world):
+    kvmatch, datagen, series, ctx = world
+    s = series[:60_000].copy()
+    m = 777
+    qoff = 20_000
+    q = datagen.plant_copies(s, qoff, m, [5_000, 41_000], [1.0, 1.0], [0.01, -0.02], 0.02, seed=3)
+    ctx.load_series(s)
+    L, R = datagen.gen_intervals(len(s), m, 8_000, 24.0, must_cover=[qoff, 5_000, 41_000], seed=8)
+    for target in (5_000, 41_000):
+        w = s[target - 1: target - 1 + m]
+        d2 = _seq_sum((w - q) * (w - q))           # the reference's distance^2 of that candidate, bit for bit
+        eps_in, eps_out = _eps_for_d2(d2)
+        assert eps_in * eps_in >= d2 > eps_out * eps_out
+        a = kvmatch.QueryEngine(ctx).verify((L, R), 1, q, eps_in)
+        b = kvmatch.QueryEngine(ctx).verify((L, R), 1, q, eps_out)
+        compare(a, oracle.rsm_ed(s, q, L, R, 0, eps_in), tag="knife in")
+        compare(b, oracle.rsm_ed(s, q, L, R, 0, eps_out), tag="knife out")
+        assert target in a.offsets.tolist() and target not in b.offsets.tolist()
+        assert a.distances[a.offsets.tolist().index(target)] == np.sqrt(d2)
+
+
+def _ref_running_stats(s, run_start, start, m):
+    """mean/std of the window `start` as the reference's running sums give them when the interval begins at
+    `run_start` (K/NormQueryEngine.java:487-509,523-524), replayed in Python."""
+    ex = ex2 = 0.0
+    b = run_start - 1
+    last = start - 1 + m - 1
+    for i in range(b, last + 1):
+        d = float(s[i])
+        ex += d
+        ex2 += d * d
+        if i - b >= m - 1 and i < last:
+            o = float(s[i - m + 1])
+            ex -= o
+            ex2 -= o * o
+    mean = ex / m
+    return mean, float(np.sqrt(ex2 / m - mean * mean))
+
+
+def test_knife_edge_cnsm_alpha_beta(world):
+    kvmatch, datagen, series, ctx = world
+    s = series[:50_000].copy()
+    m = 300
+    qoff = 12_345
+    q = datagen.plant_copies(s, qoff, m, [30_000], [1.25], [0.8], 0.01, seed=5)
+    ctx.load_series(s)
+    # one interval so that the running sums restart at a known place; the target window sits 40 into it
+    run_start, target = 29_960, 30_000
+    L = np.array([qoff, run_start], dtype=np.int32)
+    R = np.array([qoff + 3, run_start + 80], dtype=np.int32)
+    mean, std = _ref_running_stats(s, run_start, target, m)
+    meanQ, stdQ = oracle.query_stats(q)
+    beta_on = abs(mean - meanQ)
+    ratio = std / stdQ
+    assert ratio > 1.0
+    for alpha, beta in ((2.0, beta_on), (2.0, float(np.nextafter(beta_on, 0.0))),
+                        (ratio, 10.0), (float(np.nextafter(ratio, 0.0)), 10.0)):
+        got = kvmatch.NormQueryEngine(ctx).verify((L, R), 1, q, 50.0, alpha, beta)
+        want = oracle.cnsm_ed(s, q, L, R, 0, 50.0, alpha, beta)
+        compare(got, want, tag=f"knife alpha={alpha!r} beta={beta!r}")
+        inside = (abs(mean - meanQ) <= beta) and (std / stdQ <= alpha) and (std / stdQ >= 1.0 / alpha)
+        assert (target in got.offsets.tolist()) == inside
+        gd = kvmatch.NormQueryEngineDtw(ctx).verify((L, R), 1, q, 50.0, 9, alpha, beta)
+        compare(gd, oracle.cnsm_dtw(s, q, L, R, 0, 50.0, 9, alpha, beta), tag="knife dtw")
+        assert (target in gd.offsets.tolist()) == inside
+    assert got.stats[6] >= 1  # KVM_STAT_RECHECKED: the exact pass ran
+
+
+def test_knife_edge_dtw_epsilon(world):
+    kvmatch, datagen, series, ctx = world
+    s = series[:40_000].copy()
+    m, rho = 200, 11
+    qoff = 9_000
+    q = datagen.plant_copies(s, qoff, m, [25_000], [1.0], [0.0], 0.05, seed=6)
+    ctx.load_series(s)
+    L, R = datagen.gen_intervals(len(s), m, 6_000, 24.0, must_cover=[qoff, 25_000], seed=2)
+    d2 = oracle.dtw_full(s[25_000 - 1: 25_000 - 1 + m], q, rho)
+    eps_in, eps_out = _eps_for_d2(d2)
+    a = kvmatch.QueryEngineDtw(ctx).verify((L, R), 1, q, eps_in, rho)
+    b = kvmatch.QueryEngineDtw(ctx).verify((L, R), 1, q, eps_out, rho)
+    compare(a, oracle.rsm_dtw(s, q, L, R, 0, eps_in, rho), tag="dtw knife in")
+    compare(b, oracle.rsm_dtw(s, q, L, R, 0, eps_out, rho), tag="dtw knife out")
+    assert 25_000 in a.offsets.tolist() and 25_000 not in b.offsets.tolist()
+
+
+def test_degenerate_windows_constant_segments(world):
+    """sigma == 0 (constant stretch) and eps == 0: NaN / division-by-zero paths must agree with the reference."""
+    kvmatch, datagen, series, ctx = world
+    s = series[:30_000].copy()
+    s[10_000:12_000] = 3.25      # constant: variance exactly 0 -> std 0 (or NaN) -> never passes the filter
+    m = 256
+    qoff = 20_000
+    q = s[qoff - 1: qoff - 1 + m].copy()
+    ctx.load_series(s)
+    L = np.array([9_900, qoff - 5], dtype=np.int32)
+    R = np.array([11_950, qoff + 5], dtype=np.int32)
+    compare(kvmatch.NormQueryEngine(ctx).verify((L, R), 1, q, 5.0, 1.5, 100.0),
+            oracle.cnsm_ed(s, q, L, R, 0, 5.0, 1.5, 100.0), tag="const cnsm_ed")
+    compare(kvmatch.NormQueryEngineDtw(ctx).verify((L, R), 1, q, 5.0, 8, 1.5, 100.0),
+            oracle.cnsm_dtw(s, q, L, R, 0, 5.0, 8, 1.5, 100.0), tag="const cnsm_dtw")
+    a = kvmatch.QueryEngine(ctx).verify((L, R), 1, q, 0.0)       # eps = 0: exact-match search
+    compare(a, oracle.rsm_ed(s, q, L, R, 0, 0.0), tag="eps0")
+    assert a.offsets.tolist() == [qoff] and a.distances[0] == 0.0
+    qc = s[10_100 - 1: 10_100 - 1 + m].copy()                     # constant query: stdQ == 0
+    compare(kvmatch.NormQueryEngine(ctx).verify((L, R), 1, qc, 5.0, 1.5, 100.0),
+            oracle.cnsm_ed(s, qc, L, R, 0, 5.0, 1.5, 100.0), tag="const query")
+    compare(kvmatch.QueryEngine(ctx).verify((L, R), 1, qc, 1.0), oracle.rsm_ed(s, qc, L, R, 0, 1.0), tag="const rsm")
