@@ -402,13 +402,18 @@ __device__ __forceinline__ double dp_from_right(double v, double fill) {  // lan
     return __hiloint2double(hi, lo);
 }
 
+// LDS window buffers of the register-form DP.  The data/query values a lane needs advance by one index per macro-step,
+// so they are kept in LINEAR buffers (index i at position i - low): a lane's read address is base + 8*step and the
+// V steps of an unrolled block use immediate offsets.  A buffer holds the 64*V values behind the front plus
+// DP_EPOCH chunks of 64 new values; after DP_EPOCH chunks the live tail is slid back to the front.
+#define DP_EPOCH 8
 template <int V>
-struct dp_ring {
-    static constexpr int SIZE = V <= 4 ? 512 : 1024;  // >= 64*V + 64 live values (V <= 8)
-    static constexpr int MASK = SIZE - 1;
+struct dp_buf {
+    static constexpr int LIVE = 64 * V;                  // values behind the front that lanes still read
+    static constexpr int LIN = LIVE + 64 * DP_EPOCH;     // doubles per buffer (V=4: 768 = 6 KiB)
 };
 
-template <int V, bool ABANDON>
+template <int V, int CSTAR, bool ABANDON>
 __global__ __launch_bounds__(256) void kvm_dtw_dp_reg_kernel(const double *__restrict__ series, kvm_query_dev qd,
                                                              const kvm_cand *__restrict__ in,
                                                              const double *__restrict__ suffix, int32_t seg_len,
@@ -416,19 +421,18 @@ __global__ __launch_bounds__(256) void kvm_dtw_dp_reg_kernel(const double *__res
                                                              int32_t *__restrict__ out_off,
                                                              double *__restrict__ out_dist, int64_t cap,
                                                              unsigned long long *__restrict__ counters) {
-    constexpr int RING = dp_ring<V>::SIZE, MASK = dp_ring<V>::MASK;
-    constexpr int WAVE_LDS = 2 * RING + 64 * V;  // ring A, ring B, result scratch
+    constexpr int LIN = dp_buf<V>::LIN, LIVE = dp_buf<V>::LIVE;
+    constexpr int WAVE_LDS = 2 * LIN + 64 * V;  // buffer A, buffer B, result scratch
     __shared__ double lds_all[4 * WAVE_LDS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    double *ringA = lds_all + wave * WAVE_LDS, *ringB = ringA + RING, *scratch = ringB + RING;
+    double *bufA = lds_all + wave * WAVE_LDS, *bufB = bufA + LIN, *scratch = bufB + LIN;
     const int m = qd.m, r = qd.rho;
     const double eps2 = qd.eps2;
     const double *__restrict__ Bq = qd.q;
     const unsigned long long n_in = *d_n_in;
     const int I0 = r >> 1, Ilast = m - 1 + I0;
     const int pV = lane * V;
-    const int Lr = r / V, cstar = r % V;      // position of the band-edge cell O[r]
-    const bool edge_lane = lane == Lr;
+    const bool edge_lane = lane == r / V;  // the band-edge cell O[r] is cell CSTAR (= r % V) of this lane
     const int kfin = (r & 1) ? ((r - 1) >> 1) : (r >> 1);  // index of cell (m-1, m-1) (k = r) in O (r odd) / E (r even)
 
     for (;;) {
@@ -442,30 +446,31 @@ __global__ __launch_bounds__(256) void kvm_dtw_dp_reg_kernel(const double *__res
         const double mean = cand.mean, sd = cand.std;
         const double lim_rest = qd.normalised ? eps2 + kvm_eps2_slack(eps2, m, kvm_sigma_guard(mean, sd), 16.0)
                                               : eps2 * (1.0 + 1e-9);
-
+        // buffer position p holds A[lowA + p] / B[lowB + p]
+        int lowA = I0 - LIVE, lowB = I0 - r;
         // zT[k] = (T[k+j] - mean) / std (K/NormQueryEngineDtw.java:564-567); RSM: (x - 0) / 1 == x exactly
-        auto fillA = [&](int lo, int cnt) {
+        auto fillA = [&](int pos, int cnt) {
             for (int t = lane; t < cnt; t += 64) {
-                const int i = lo + t;
-                ringA[i & MASK] = (i >= 0 && i < m) ? (x[i] - mean) / sd : DTW_POS_BIG;
+                const int i = lowA + pos + t;
+                bufA[pos + t] = (i >= 0 && i < m) ? (x[i] - mean) / sd : DTW_POS_BIG;
             }
         };
-        auto fillB = [&](int lo, int cnt) {
+        auto fillB = [&](int pos, int cnt) {
             for (int t = lane; t < cnt; t += 64) {
-                const int j = lo + t;
-                ringB[j & MASK] = (j >= 0 && j < m) ? Bq[j] : DTW_NEG_BIG;
+                const int j = lowB + pos + t;
+                bufB[pos + t] = (j >= 0 && j < m) ? Bq[j] : DTW_NEG_BIG;
             }
         };
-        fillA(I0 - 64 * V, 64 * V + 64);
-        fillB(I0 - r, 64 * V + 64);
+        fillA(0, LIVE + 64);
+        fillB(0, LIVE + 64);
 
         double E[V], O[V], a[V], b[V];
 #pragma unroll
         for (int c = 0; c < V; c++) {
             E[c] = DTW_INF;
             O[c] = DTW_INF;
-            a[c] = c >= 1 ? ringA[(I0 - pV - c) & MASK] : 0.0;
-            b[c] = ringB[(I0 - r + pV + c) & MASK];
+            a[c] = c >= 1 ? bufA[I0 - pV - c - lowA] : 0.0;
+            b[c] = bufB[I0 - r + pV + c - lowB];
         }
         // seed of cell (0,0): k = r
         if ((r & 1) == 0) {
@@ -477,20 +482,24 @@ __global__ __launch_bounds__(256) void kvm_dtw_dp_reg_kernel(const double *__res
             for (int c = 0; c < V; c++)
                 if (pV + c == ((r - 1) >> 1)) O[c] = 0.0;
         }
-        int offA = (I0 - pV) & MASK, offB = (I0 - r + pV + V) & MASK;  // ring slots read by the next macro-step
+        // read pointers: macro-step I reads A[I - pV] and B[I - r + pV + V]
+        const double *pA = bufA + (I0 - pV - lowA);
+        const double *pB = bufB + (I0 - r + pV + V - lowB);
+        // halos: lane 0 (left) / lane 63 (right) never receive from a neighbour, so they keep this initial INF for ever
+        double halo_l = DTW_INF, halo_r = DTW_INF;
         bool dead = false, done = false;
         double result = DTW_INF;
+        int chunk = 0;
 
         for (int Ic = I0; Ic <= Ilast && !done; Ic += 64) {
+#pragma unroll 1
             for (int blk = 0; blk < 64 / V && !done; blk++) {
 #pragma unroll
                 for (int s = 0; s < V; s++) {
                     const int I = Ic + blk * V + s;
-                    const double a_new = ringA[offA], b_new = ringB[offB];
-                    offA = (offA + 1) & MASK;
-                    offB = (offB + 1) & MASK;
+                    const double a_new = pA[s], b_new = pB[s];
                     // ---- E-update (diagonal 2I - r) ----
-                    const double halo_l = dp_from_left(O[V - 1], DTW_INF);
+                    halo_l = dp_from_left(O[V - 1], halo_l);
 #pragma unroll
                     for (int c = V - 1; c >= 0; c--) {
                         if (c == 0) a[(V - s) % V] = a_new;  // slot of cell 0 at step s
@@ -506,7 +515,7 @@ __global__ __launch_bounds__(256) void kvm_dtw_dp_reg_kernel(const double *__res
                         done = true;
                     }
                     // ---- O-update (diagonal 2I - r + 1) ----
-                    const double halo_r = dp_from_right(E[0], DTW_INF);
+                    halo_r = dp_from_right(E[0], halo_r);
                     b[s % V] = b_new;  // slot (V + s) % V: query value of O cell V-1, E cell V-1 of the next step
 #pragma unroll
                     for (int c = 0; c < V; c++) {
@@ -522,15 +531,35 @@ __global__ __launch_bounds__(256) void kvm_dtw_dp_reg_kernel(const double *__res
                         done = true;
                     }
                     // band edge k = 2r+1: O[r] must read as INF
-#pragma unroll
-                    for (int c = 0; c < V; c++)
-                        if (c == cstar) O[c] = edge_lane ? DTW_INF : O[c];
+                    O[CSTAR] = edge_lane ? DTW_INF : O[CSTAR];
                 }
+                pA += V;
+                pB += V;
             }
             if (done) break;
-            // refill: the 64 values the next chunk adds at the top of each window
-            fillA(Ic + 64, 64);
-            fillB(Ic - r + 64 * V + 64, 64);
+            chunk++;
+            if (chunk == DP_EPOCH) {
+                // slide: the LIVE values behind the front move to the start of the buffers
+                double ta[V], tb[V];
+#pragma unroll
+                for (int c = 0; c < V; c++) {
+                    ta[c] = bufA[64 * DP_EPOCH + lane + 64 * c];
+                    tb[c] = bufB[64 * DP_EPOCH + lane + 64 * c];
+                }
+#pragma unroll
+                for (int c = 0; c < V; c++) {
+                    bufA[lane + 64 * c] = ta[c];
+                    bufB[lane + 64 * c] = tb[c];
+                }
+                lowA += 64 * DP_EPOCH;
+                lowB += 64 * DP_EPOCH;
+                pA -= 64 * DP_EPOCH;
+                pB -= 64 * DP_EPOCH;
+                chunk = 0;
+            }
+            // the 64 values the next chunk adds at the front of each window
+            fillA(LIVE + 64 * chunk, 64);
+            fillB(LIVE + 64 * chunk, 64);
             if (ABANDON) {
                 double mn = DTW_INF;
 #pragma unroll
@@ -561,23 +590,40 @@ __global__ __launch_bounds__(256) void kvm_dtw_dp_reg_kernel(const double *__res
     }
 }
 
-template <int V>
-static hipError_t launch_dp_reg(const double *series, const kvm_query_dev &qd, const kvm_cand *in,
-                                const double *suffix, int32_t seg_len, const unsigned long long *d_n_in, int64_t max_in, int32_t *out_off, double *out_dist,
-                                int64_t cap, unsigned long long *counters, int num_cu, hipStream_t s) {
-    const size_t lds = (size_t)4 * (2 * dp_ring<V>::SIZE + 64 * V) * sizeof(double);
-    int per_cu = (int)((160 * 1024) / lds);
-    if (per_cu > 2) per_cu = 2;  // 8 waves per CU = 2 per SIMD is enough: the kernel is VALU-bound
-    if (per_cu < 1) per_cu = 1;
-    int64_t blocks = (int64_t)num_cu * per_cu;
+template <int V, int CSTAR>
+static hipError_t launch_dp_reg_c(const double *series, const kvm_query_dev &qd, const kvm_cand *in,
+                                  const double *suffix, int32_t seg_len, const unsigned long long *d_n_in,
+                                  int64_t max_in, int32_t *out_off, double *out_dist, int64_t cap,
+                                  unsigned long long *counters, int num_cu, hipStream_t s) {
+    int64_t blocks = (int64_t)num_cu * 2;  // 8 waves per CU = 2 per SIMD is enough: the kernel is VALU-bound
     if (blocks > (max_in + 3) / 4) blocks = (max_in + 3) / 4;
     if (qd.early_abandon)
-        hipLaunchKernelGGL((kvm_dtw_dp_reg_kernel<V, true>), dim3((unsigned)blocks), dim3(256), 0, s, series, qd, in,
-                           suffix, seg_len, d_n_in, out_off, out_dist, cap, counters);
+        hipLaunchKernelGGL((kvm_dtw_dp_reg_kernel<V, CSTAR, true>), dim3((unsigned)blocks), dim3(256), 0, s, series, qd,
+                           in, suffix, seg_len, d_n_in, out_off, out_dist, cap, counters);
     else
-        hipLaunchKernelGGL((kvm_dtw_dp_reg_kernel<V, false>), dim3((unsigned)blocks), dim3(256), 0, s, series, qd, in,
-                           suffix, seg_len, d_n_in, out_off, out_dist, cap, counters);
+        hipLaunchKernelGGL((kvm_dtw_dp_reg_kernel<V, CSTAR, false>), dim3((unsigned)blocks), dim3(256), 0, s, series, qd,
+                           in, suffix, seg_len, d_n_in, out_off, out_dist, cap, counters);
     return hipGetLastError();
+}
+
+// dispatch on the (launch-constant) position CSTAR = rho % V of the band-edge cell
+template <int V>
+static hipError_t launch_dp_reg(const double *series, const kvm_query_dev &qd, const kvm_cand *in,
+                                const double *suffix, int32_t seg_len, const unsigned long long *d_n_in,
+                                int64_t max_in, int32_t *out_off, double *out_dist, int64_t cap,
+                                unsigned long long *counters, int num_cu, hipStream_t s) {
+#define KVM_DP_CASE(C)                                                                                          \
+    case C:                                                                                                     \
+        if constexpr (C < V)                                                                                    \
+            return launch_dp_reg_c<V, C>(series, qd, in, suffix, seg_len, d_n_in, max_in, out_off, out_dist, cap, \
+                                         counters, num_cu, s);                                                  \
+        break;
+    switch (qd.rho % V) {
+        KVM_DP_CASE(0) KVM_DP_CASE(1) KVM_DP_CASE(2) KVM_DP_CASE(3)
+        KVM_DP_CASE(4) KVM_DP_CASE(5) KVM_DP_CASE(6) KVM_DP_CASE(7)
+    }
+#undef KVM_DP_CASE
+    return hipErrorInvalidValue;
 }
 
 hipError_t kvm_launch_dtw_dp(const double *series, int64_t n, const kvm_query_dev &qd, const kvm_cand *in,
