@@ -406,7 +406,12 @@ __device__ __forceinline__ double dp_from_right(double v, double fill) {  // lan
 // so they are kept in LINEAR buffers (index i at position i - low): a lane's read address is base + 8*step and the
 // V steps of an unrolled block use immediate offsets.  A buffer holds the 64*V values behind the front plus
 // DP_EPOCH chunks of 64 new values; after DP_EPOCH chunks the live tail is slid back to the front.
-#define DP_EPOCH 8
+#ifndef DP_EPOCH
+#define DP_EPOCH 4
+#endif
+#ifndef DP_BLOCKS_PER_CU
+#define DP_BLOCKS_PER_CU 4
+#endif
 template <int V>
 struct dp_buf {
     static constexpr int LIVE = 64 * V;                  // values behind the front that lanes still read
@@ -595,7 +600,9 @@ static hipError_t launch_dp_reg_c(const double *series, const kvm_query_dev &qd,
                                   const double *suffix, int32_t seg_len, const unsigned long long *d_n_in,
                                   int64_t max_in, int32_t *out_off, double *out_dist, int64_t cap,
                                   unsigned long long *counters, int num_cu, hipStream_t s) {
-    int64_t blocks = (int64_t)num_cu * 2;  // 8 waves per CU = 2 per SIMD is enough: the kernel is VALU-bound
+    // waves per SIMD = DP_BLOCKS_PER_CU (bounded by LDS: 4 waves x (2*LIN + 64V) doubles per workgroup)
+    const int lds_limit = (int)((160 * 1024) / (4 * (2 * dp_buf<V>::LIN + 64 * V) * sizeof(double)));
+    int64_t blocks = (int64_t)num_cu * (DP_BLOCKS_PER_CU < lds_limit ? DP_BLOCKS_PER_CU : lds_limit);
     if (blocks > (max_in + 3) / 4) blocks = (max_in + 3) / 4;
     if (qd.early_abandon)
         hipLaunchKernelGGL((kvm_dtw_dp_reg_kernel<V, CSTAR, true>), dim3((unsigned)blocks), dim3(256), 0, s, series, qd,
