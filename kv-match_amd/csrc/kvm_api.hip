@@ -130,7 +130,7 @@ extern "C" int kvm_set_option(kvm_ctx *ctx, int32_t option, int64_t value) {
         case KVM_OPT_EARLY_ABANDON: ctx->opt_early_abandon = value ? 1 : 0; return KVM_OK;
         case KVM_OPT_LB_CASCADE: ctx->opt_lb_cascade = value ? 1 : 0; return KVM_OK;
         case KVM_OPT_ED_KERNEL:
-            if (value < 0 || value > 2) return fail(ctx, KVM_ERR_ILLEGAL_ARGUMENT, "KVM_OPT_ED_KERNEL in {0,1,2}");
+            if (value < 0 || value > 3) return fail(ctx, KVM_ERR_ILLEGAL_ARGUMENT, "KVM_OPT_ED_KERNEL in {0,1,2,3}");
             ctx->opt_ed_kernel = value;
             return KVM_OK;
         case KVM_OPT_TIMING: ctx->opt_timing = value ? 1 : 0; return KVM_OK;
@@ -399,10 +399,10 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
     if (cnsm && !(alpha > 0)) return fail(ctx, KVM_ERR_ILLEGAL_ARGUMENT, "alpha must be > 0");
     if (dtw && rho < 0) return fail(ctx, KVM_ERR_ILLEGAL_ARGUMENT, "rho must be >= 0");
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    // ED kernel choice: 1 = wave-per-candidate, 2 (and auto) = LDS-tiled
-    const int ed_kernel = ctx->opt_ed_kernel == 1 ? 1 : 2;
+    // ED pruning kernel: 1 = wave-per-candidate, 2 = LDS-tiled direct form, 3 (and auto) = LDS-tiled correlation form
+    const int ed_kernel = ctx->opt_ed_kernel == 0 ? 3 : (int)ctx->opt_ed_kernel;
     auto tp_ = std::chrono::steady_clock::now();
-    const int32_t tile_max = (!dtw && ed_kernel == 2) ? KVM_TILE_TILED : KVM_TILE_MAX;
+    const int32_t tile_max = (!dtw && ed_kernel >= 2) ? KVM_TILE_TILED : KVM_TILE_MAX;
     int rc = build_plan(ctx, cnsm, m, left, right, k, shift, tile_max, pl);
     if (rc) return rc;
     KVM_TP("  build_plan");
@@ -430,23 +430,30 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
         for (int i = 0; i < m; i++) q[i] = (query[i] - qd.meanQ) / qd.stdQ;
     }
     if (dtw) query_envelope(q, rho, qu, ql);
-    // cNSM-ED exact pass: the reference sums over the |zQ|-descending permutation (stable sort with
-    // Double.compare(|o2|, |o1|), K/NormQueryEngine.java:443-452)
-    std::vector<int32_t> order;
-    std::vector<double> zqs;
-    if (cnsm && !dtw) {
-        order.resize(m);
-        std::iota(order.begin(), order.end(), 0);
-        std::stable_sort(order.begin(), order.end(),
-                         [&](int32_t a, int32_t b) { return std::fabs(q[a]) > std::fabs(q[b]); });
-        zqs.resize(m);
-        for (int i = 0; i < m; i++) zqs[i] = q[order[i]];
+    // correlation-form ED pruner: centred query and its chunk-granular prefix sums
+    std::vector<double> qcen;
+    std::vector<double2> qpref;
+    const int nchunks4 = (m + ED4_JC - 1) / ED4_JC;
+    if (!dtw) {
+        double sum = 0;
+        for (int i = 0; i < m; i++) sum += q[i];
+        qd.q_mean = sum / m;
+        qcen.resize(m);
+        qpref.resize((size_t)nchunks4 + 1);
+        double p1 = 0, p2 = 0;
+        for (int i = 0; i < m; i++) {
+            if (i % ED4_JC == 0) qpref[(size_t)(i / ED4_JC)] = make_double2(p1, p2);
+            qcen[i] = q[i] - qd.q_mean;
+            p1 += qcen[i];
+            p2 += qcen[i] * qcen[i];
+        }
+        qpref[(size_t)nchunks4] = make_double2(p1, p2);
     }
-
-    // ---- uploads (one pinned staging area: query | envelopes | tiles) ----
-    // query block: q | (qu | ql for DTW) | (zQ sorted | order for the cNSM-ED exact pass), padded
+    // query block: q | (qu | ql for DTW) | pad || (qc | pad | q_pref for ED) || (zQ sorted | order: cNSM-ED exact pass)
     const size_t qmain = (size_t)m * 8 * (dtw ? 3 : 1) + KVM_SERIES_PAD * sizeof(double);
-    const size_t qbytes = qmain + ((cnsm && !dtw) ? (size_t)m * 12 : 0);
+    const size_t qdot = dtw ? 0 : ((size_t)m * 8 + KVM_SERIES_PAD * sizeof(double) + ((size_t)nchunks4 + 1) * 16);
+    const size_t qexact_off = qmain + qdot;
+    const size_t qbytes = qexact_off + ((cnsm && !dtw) ? (size_t)m * 12 : 0);
     const size_t rbytes = pl.runs.size() * sizeof(kvm_run);
     const size_t tbytes = (size_t)pl.n_tiles * sizeof(kvm_tile);
     rc = ensure_pinned(ctx, qbytes + rbytes + 64);
@@ -457,19 +464,20 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
     if ((rc = ensure(ctx, ctx->b_aux2, rbytes + 64))) return rc;
     if ((rc = ensure(ctx, ctx->b_counters, KVM_CNT_TOTAL * sizeof(unsigned long long)))) return rc;
     char *hp = (char *)ctx->h_pinned;
-    std::memset(hp, 0, qmain);
+    std::memset(hp, 0, qexact_off);
     std::memcpy(hp, q.data(), (size_t)m * 8);
-    if (cnsm && !dtw) {
-        std::memcpy(hp + qmain, zqs.data(), (size_t)m * 8);
-        std::memcpy(hp + qmain + (size_t)m * 8, order.data(), (size_t)m * 4);
+    if (!dtw) {
+        std::memcpy(hp + qmain, qcen.data(), (size_t)m * 8);
+        std::memcpy(hp + qmain + (size_t)m * 8 + KVM_SERIES_PAD * sizeof(double), qpref.data(), qpref.size() * 16);
     }
+    const size_t qfirst = (cnsm && !dtw) ? qexact_off : qbytes;  // the exact-pass block is staged later (see below)
     if (dtw) {
         std::memcpy(hp + (size_t)m * 8, qu.data(), (size_t)m * 8);
         std::memcpy(hp + (size_t)m * 16, ql.data(), (size_t)m * 8);
     }
     if (rbytes) std::memcpy(hp + qbytes, pl.runs.data(), rbytes);
     KVM_TP("  query prep + staging");
-    HIPCHK(ctx, hipMemcpyAsync(ctx->b_query.p, hp, qbytes, hipMemcpyHostToDevice, stream));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->b_query.p, hp, qfirst, hipMemcpyHostToDevice, stream));
     if (rbytes) {
         // runs (16 B each) go up; the tile list (16 B per <= tile_max candidates) is expanded on the GPU
         HIPCHK(ctx, hipMemcpyAsync(ctx->b_aux2.p, hp + qbytes, rbytes, hipMemcpyHostToDevice, stream));
@@ -478,6 +486,10 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
     }
     HIPCHK(ctx, hipMemsetAsync(ctx->b_counters.p, 0, KVM_CNT_TOTAL * sizeof(unsigned long long), stream));
     qd.q = (const double *)ctx->b_query.p;
+    qd.qc = dtw ? nullptr : (const double *)((const char *)ctx->b_query.p + qmain);
+    qd.q_pref = dtw ? nullptr
+                    : (const double2 *)((const char *)ctx->b_query.p + qmain + (size_t)m * 8 +
+                                        KVM_SERIES_PAD * sizeof(double));
     qd.qu = dtw ? qd.q + m : nullptr;
     qd.ql = dtw ? qd.q + 2 * (size_t)m : nullptr;
     unsigned long long *counters = (unsigned long long *)ctx->b_counters.p;
@@ -494,15 +506,37 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
         // pruning pass (fast kernels, guard band) -> survivors -> exact pass in the reference's operation order
         if ((rc = ensure(ctx, ctx->b_cands, (size_t)pl.windows * sizeof(kvm_surv) + 64))) return rc;
         kvm_surv *surv = (kvm_surv *)ctx->b_cands.p;
-        if (ed_kernel == 2)
+        if (ed_kernel == 3)
+            HIPCHK(ctx, kvm_launch_ed_dot(ctx->d_series, ctx->d_prefix, ctx->n, qd, d_tiles, n_tiles, surv, pl.windows,
+                                          counters, stream));
+        else if (ed_kernel == 2)
             HIPCHK(ctx, kvm_launch_ed_tiled(ctx->d_series, ctx->d_prefix, ctx->n, qd, d_tiles, n_tiles, surv,
                                             pl.windows, counters, stream));
         else
             HIPCHK(ctx, kvm_launch_ed_wave(ctx->d_series, ctx->d_prefix, ctx->n, qd, d_tiles, n_tiles, surv,
                                            pl.windows, counters, stream));
         if (ctx->opt_timing) HIPCHK(ctx, hipEventRecord(ctx->ev1, stream));
-        const double *q_exact = cnsm ? (const double *)((const char *)ctx->b_query.p + qmain) : qd.q;
-        const int32_t *d_order = cnsm ? (const int32_t *)((const char *)ctx->b_query.p + qmain + (size_t)m * 8) : nullptr;
+        if (cnsm) {
+            // cNSM-ED exact pass: the reference sums over the |zQ|-descending permutation (stable sort with
+            // Double.compare(|o2|, |o1|), K/NormQueryEngine.java:443-452).  Computed here, while the pruning kernel runs.
+            std::vector<std::pair<double, int32_t>> keyed((size_t)m);
+            for (int i = 0; i < m; i++) keyed[(size_t)i] = {std::fabs(q[i]), i};
+            std::stable_sort(keyed.begin(), keyed.end(),
+                             [](const std::pair<double, int32_t> &a, const std::pair<double, int32_t> &b) {
+                                 return a.first > b.first;
+                             });
+            double *zqs = (double *)(hp + qexact_off);
+            int32_t *order = (int32_t *)(hp + qexact_off + (size_t)m * 8);
+            for (int i = 0; i < m; i++) {
+                order[i] = keyed[(size_t)i].second;
+                zqs[i] = q[order[i]];
+            }
+            HIPCHK(ctx, hipMemcpyAsync((char *)ctx->b_query.p + qexact_off, hp + qexact_off, (size_t)m * 12,
+                                       hipMemcpyHostToDevice, stream));
+        }
+        const double *q_exact = cnsm ? (const double *)((const char *)ctx->b_query.p + qexact_off) : qd.q;
+        const int32_t *d_order =
+            cnsm ? (const int32_t *)((const char *)ctx->b_query.p + qexact_off + (size_t)m * 8) : nullptr;
         HIPCHK(ctx, kvm_launch_exact_ed(ctx->d_series, qd, q_exact, d_order, surv, counters + KVM_CNT_CANDS1, pl.windows,
                                         out.d_off, out.d_dist, out.cap, counters, ctx->num_cu, stream));
     } else {

@@ -103,6 +103,10 @@ struct kvm_query_dev {
     double meanQ, stdQ, alpha, beta;
     int32_t normalised;  // 0 RSM, 1 cNSM
     int32_t early_abandon;
+    // correlation-form pruner (kvm_ed_dot.hip): statistics of the device query q[] (raw for RSM, zQ for cNSM)
+    double q_mean;          // mean of q
+    const double *qc;       // q - q_mean, device, m entries (+ KVM_SERIES_PAD spare)
+    const double2 *q_pref;  // q_pref[t] = { sum_{j < t*ED4_JC} (q_j - q_mean), sum_{j < t*ED4_JC} (q_j - q_mean)^2 }, t = 0..nchunks
 };
 
 // ED pruners: survivors (decision quantity within the guard band of eps^2, filter within its guard band) are appended
@@ -113,6 +117,10 @@ hipError_t kvm_launch_ed_wave(const double *series, const double2 *prefix, int64
 hipError_t kvm_launch_ed_tiled(const double *series, const double2 *prefix, int64_t n, const kvm_query_dev &qd,
                                const kvm_tile *tiles, int64_t n_tiles, kvm_surv *surv, int64_t cap,
                                unsigned long long *counters, hipStream_t s);
+#define ED4_JC 160  // chunk length of the correlation-form pruner (also the granularity of kvm_query_dev::q_pref)
+hipError_t kvm_launch_ed_dot(const double *series, const double2 *prefix, int64_t n, const kvm_query_dev &qd,
+                             const kvm_tile *tiles, int64_t n_tiles, kvm_surv *surv, int64_t cap,
+                             unsigned long long *counters, hipStream_t s);
 // Exact final pass (kvm_exact.hip)
 hipError_t kvm_launch_exact_ed(const double *series, const kvm_query_dev &qd, const double *q_exact,
                                const int32_t *order, const kvm_surv *surv, const unsigned long long *d_n_surv,
@@ -151,13 +159,13 @@ hipError_t kvm_launch_dtw_dp(const double *series, int64_t n, const kvm_query_de
 
 // ---- device helpers ---------------------------------------------------------------------------------
 #ifdef __HIPCC__
-// mean / std of the window 0-based [s, s+m) from the shifted block prefix sums.
-__device__ __forceinline__ void kvm_window_mean_std(const double2 *__restrict__ P, const double *__restrict__ x,
-                                                    int64_t s, int32_t m, double &mean, double &std) {
-    const int64_t e = s + m - 1;
+// Shifted sums of the 0-based range [s, s+len): returns S1 = sum(x - c), S2 = sum(x - c)^2 and the shift c (= the
+// first point of the block that contains s), from the block-restarted shifted prefix sums.
+__device__ __forceinline__ void kvm_window_shifted_sums(const double2 *__restrict__ P, const double *__restrict__ x,
+                                                        int64_t s, int32_t len, double &s1, double &s2, double &c) {
+    const int64_t e = s + len - 1;
     const int64_t bs = s >> KVM_PS_BLOCK_LOG2, be = e >> KVM_PS_BLOCK_LOG2;
-    const double c = x[bs << KVM_PS_BLOCK_LOG2];  // shift of the first block; everything is re-based to it
-    double s1, s2;
+    c = x[bs << KVM_PS_BLOCK_LOG2];  // shift of the first block; everything is re-based to it
     const bool at_start = (s & (KVM_PS_BLOCK - 1)) == 0;
     if (bs == be) {
         const double2 pe = P[e];
@@ -179,7 +187,7 @@ __device__ __forceinline__ void kvm_window_mean_std(const double2 *__restrict__ 
             s1 = pl.x - ps.x;
             s2 = pl.y - ps.y;
         }
-        for (int64_t b = bs + 1; b <= be; b++) {  // following blocks (exactly one unless m > KVM_PS_BLOCK)
+        for (int64_t b = bs + 1; b <= be; b++) {  // following blocks (exactly one unless len > KVM_PS_BLOCK)
             const int64_t first = b << KVM_PS_BLOCK_LOG2;
             const int64_t lastp = b < be ? first + KVM_PS_BLOCK - 1 : e;
             const double2 t = P[lastp];
@@ -189,6 +197,13 @@ __device__ __forceinline__ void kvm_window_mean_std(const double2 *__restrict__ 
             s2 += t.y + (2.0 * dc) * t.x + k * (dc * dc);
         }
     }
+}
+
+// mean / std of the window 0-based [s, s+m) from the shifted block prefix sums.
+__device__ __forceinline__ void kvm_window_mean_std(const double2 *__restrict__ P, const double *__restrict__ x,
+                                                    int64_t s, int32_t m, double &mean, double &std) {
+    double s1, s2, c;
+    kvm_window_shifted_sums(P, x, s, m, s1, s2, c);
     const double ms = s1 / m;  // mean - c
     mean = c + ms;
     std = sqrt(s2 / m - ms * ms);

@@ -30,6 +30,17 @@ if mode == "ed":
     for _ in range(3):
         a = eng.verify((L, R), 1, q, 10.0)
     print("ed windows", a.stats[0], "answers", len(a))
+elif mode == "cnsm":
+    m = 8192
+    qoff = n // 3 + 17
+    planted = [n // 7, n // 2 + 1000, n - 3 * m]
+    q = datagen.plant_copies(series, qoff, m, planted, [1.0, 1.0, 1.0], [0.0, 0.02, -0.03], 0.01)
+    ctx.load_series(series)
+    L, R = datagen.gen_intervals(n, m, 1_000_000, 64.0, must_cover=[qoff] + planted, seed=1)
+    eng = kvmatch.NormQueryEngine(ctx)
+    for _ in range(3):
+        a = eng.verify((L, R), 1, q, 10.0, 2.0, 10.0)
+    print("cnsm windows", a.stats[0], "answers", len(a), "rechecked", a.stats[6])
 elif mode == "calib":
     m = 8192
     q = series[999:999 + m].copy()

@@ -168,7 +168,7 @@ def test_knobs_do_not_change_answers(world):
     finally:
         ctx.set_option(kvmatch.OPT_DP_KERNEL, 0)
     assert np.array_equal(b2.offsets, base_dtw.offsets) and np.array_equal(b2.distances, base_dtw.distances)
-    for k in (1, 2):
+    for k in (1, 2, 3):
         ctx.set_option(kvmatch.OPT_ED_KERNEL, k)
         try:
             a = kvmatch.QueryEngine(ctx).verify((L, R), 1, q, 5.0)
