@@ -458,3 +458,88 @@ def test_degenerate_windows_constant_segments(world):
     compare(kvmatch.NormQueryEngine(ctx).verify((L, R), 1, qc, 5.0, 1.5, 100.0),
             oracle.cnsm_ed(s, qc, L, R, 0, 5.0, 1.5, 100.0), tag="const query")
     compare(kvmatch.QueryEngine(ctx).verify((L, R), 1, qc, 1.0), oracle.rsm_ed(s, qc, L, R, 0, 1.0), tag="const rsm")
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Shapes at the edges of what the kernels tile for.
+
+@pytest.mark.parametrize("m", [1, 2, 5, 31, 63, 65, 159, 160, 161, 320, 20_000])
+def test_query_lengths_all_variants(world, m):
+    """m below one lane group, around the 160-point chunk, and beyond one prefix-sum block (16384)."""
+    kvmatch, datagen, series, ctx = world
+    s = series[:120_000].copy()
+    qoff = 50_000
+    q = datagen.plant_copies(s, qoff, m, [10_000, 90_000], [1.0, 1.0], [0.01, -0.01], 0.01, seed=m)
+    ctx.load_series(s)
+    L, R = datagen.gen_intervals(len(s), m, 3_000, 12.0, must_cover=[qoff, 10_000, 90_000], seed=m)
+    eps = 0.5 * np.sqrt(m) + 0.2
+    for k in (2, 3):
+        ctx.set_option(kvmatch.OPT_ED_KERNEL, k)
+        compare(kvmatch.QueryEngine(ctx).verify((L, R), 1, q, eps), oracle.rsm_ed(s, q, L, R, 0, eps), tag=f"len rsm k{k}")
+        if m >= 2:
+            compare(kvmatch.NormQueryEngine(ctx).verify((L, R), 1, q, eps, 2.0, 5.0),
+                    oracle.cnsm_ed(s, q, L, R, 0, eps, 2.0, 5.0), tag=f"len cnsm k{k}")
+    ctx.set_option(kvmatch.OPT_ED_KERNEL, 0)
+    # DTW: the reference's LB_Kim reads q[0..2] and q[m-3..m-1] and double-counts below m = 6 (and every entry point
+    # requires m >= 25 = WuList[0], K/NormQueryEngineDtw.java:112-162), so DTW parity is defined for m >= 25
+    if 25 <= m <= 320:
+        rho = max(0, m // 10)
+        compare(kvmatch.QueryEngineDtw(ctx).verify((L, R), 1, q, eps, rho), oracle.rsm_dtw(s, q, L, R, 0, eps, rho),
+                tag="len rsm_dtw")
+        if m >= 2:
+            compare(kvmatch.NormQueryEngineDtw(ctx).verify((L, R), 1, q, eps, rho, 2.0, 5.0),
+                    oracle.cnsm_dtw(s, q, L, R, 0, eps, rho, 2.0, 5.0), tag="len cnsm_dtw")
+
+
+def test_interval_shapes(world):
+    """isolated candidates, interval lengths around the 32 / 64 tile sizes, one very long interval, the last window."""
+    kvmatch, datagen, series, ctx = world
+    s = series[:150_000].copy()
+    m = 200
+    q = datagen.plant_copies(s, 70_000, m, [1, len(s) - m + 1], [1.0, 1.0], [0.0, 0.0], 0.01, seed=1)
+    ctx.load_series(s)
+    lens = [1, 1, 1, 31, 32, 33, 63, 64, 65, 127, 128, 129, 5000]
+    left, right, pos = [], [], 1
+    for ln in lens:
+        left.append(pos)
+        right.append(pos + ln - 1)
+        pos += ln + 7
+    left += [69_990, len(s) - m - 40]
+    right += [70_010, len(s) + 500]          # the last interval runs past n - m + 1 and is clipped
+    L, R = np.array(left, dtype=np.int32), np.array(right, dtype=np.int32)
+    for k in (1, 2, 3):
+        ctx.set_option(kvmatch.OPT_ED_KERNEL, k)
+        compare(kvmatch.QueryEngine(ctx).verify((L, R), 1, q, 3.0), oracle.rsm_ed(s, q, L, R, 0, 3.0), tag=f"shapes k{k}")
+        compare(kvmatch.NormQueryEngine(ctx).verify((L, R), 1, q, 3.0, 1.5, 3.0),
+                oracle.cnsm_ed(s, q, L, R, 0, 3.0, 1.5, 3.0), tag=f"shapes cnsm k{k}")
+    ctx.set_option(kvmatch.OPT_ED_KERNEL, 0)
+    a = kvmatch.QueryEngineDtw(ctx).verify((L, R), 1, q, 3.0, 10)
+    compare(a, oracle.rsm_dtw(s, q, L, R, 0, 3.0, 10), tag="shapes dtw")
+    assert {1, 70_000, len(s) - m + 1} <= set(a.offsets.tolist())
+    compare(kvmatch.NormQueryEngineDtw(ctx).verify((L, R), 1, q, 3.0, 10, 1.5, 3.0),
+            oracle.cnsm_dtw(s, q, L, R, 0, 3.0, 10, 1.5, 3.0), tag="shapes cnsm dtw")
+
+
+def test_many_answers_and_tiny_series(world):
+    """every candidate an answer (huge epsilon: exercises the > 1024-answer readback and the exact pass at scale), and a
+    series shorter than every tile / block size."""
+    kvmatch, datagen, series, ctx = world
+    s = series[:30_000].copy()
+    m = 100
+    q = s[5_000:5_000 + m].copy()
+    ctx.load_series(s)
+    L, R = datagen.gen_intervals(len(s), m, 6_000, 24.0, must_cover=[5_001], seed=12)
+    a = kvmatch.QueryEngine(ctx).verify((L, R), 1, q, 1e6)
+    compare(a, oracle.rsm_ed(s, q, L, R, 0, 1e6), tag="all answers rsm")
+    assert len(a) == a.cnt_candidate > 1024
+    b = kvmatch.NormQueryEngine(ctx).verify((L, R), 1, q, 1e6, 1e6, 1e6)
+    compare(b, oracle.cnsm_ed(s, q, L, R, 0, 1e6, 1e6, 1e6), tag="all answers cnsm")
+    c = kvmatch.NormQueryEngineDtw(ctx).verify((L[:40], R[:40]), 1, q, 1e6, 5, 1e6, 1e6)
+    compare(c, oracle.cnsm_dtw(s, q, L[:40], R[:40], 0, 1e6, 5, 1e6, 1e6), tag="all answers dtw")
+    t = series[:300].copy()
+    ctx.load_series(t)
+    qq = t[100:140].copy()
+    Ls, Rs = np.array([1], dtype=np.int32), np.array([261], dtype=np.int32)
+    compare(kvmatch.QueryEngine(ctx).verify((Ls, Rs), 1, qq, 2.0), oracle.rsm_ed(t, qq, Ls, Rs, 0, 2.0), tag="tiny rsm")
+    compare(kvmatch.NormQueryEngineDtw(ctx).verify((Ls, Rs), 1, qq, 2.0, 4, 2.0, 5.0),
+            oracle.cnsm_dtw(t, qq, Ls, Rs, 0, 2.0, 4, 2.0, 5.0), tag="tiny dtw")
