@@ -48,6 +48,9 @@ def parse():
     ap.add_argument("--extras", type=int, default=1, help="also measure cNSM-ED / cNSM-DTW (N=1 only)")
     ap.add_argument("--cpu-baseline", type=int, default=1)
     ap.add_argument("--ed-kernel", type=int, default=0)
+    ap.add_argument("--workload", default="rsm_ed", choices=["rsm_ed", "cnsm_ed", "cnsm_dtw", "mixed"],
+                    help="rsm_ed = BASELINE configs[1] (headline); cnsm_ed = configs[2]; cnsm_dtw = configs[3] "
+                         "(m=4096, rho=5%%); mixed = configs[4]-style stream alternating all four variants")
     return ap.parse_args()
 
 
@@ -100,20 +103,42 @@ def main():
     ctx.set_option(kvmatch.OPT_ED_KERNEL, a.ed_kernel)
     setup_s = time.perf_counter() - t0
 
-    eng = kvmatch.QueryEngine(ctx)
+    # per-workload query parameters (BASELINE.json configs)
+    wl = a.workload
+    if wl == "cnsm_dtw":
+        m = 4096
+        q = series[qoff - 1: qoff - 1 + m].copy()
+        left, right = datagen.gen_intervals(n, m, a.candidates * world, 64.0, must_cover=[qoff], seed=2)
+        my_l, my_r = distributed.split_intervals(left, right, world, rank)
+        my_cands = int((my_r.astype(np.int64) - my_l + 1).sum())
+    # (variant id of kvm_verify_device, engine class, positional args after epsilon, keyword args for ShardedVerifier)
+    plans = {
+        "rsm_ed": [(0, kvmatch.QueryEngine, (), {})],
+        "cnsm_ed": [(1, kvmatch.NormQueryEngine, (2.0, 10.0), dict(alpha=2.0, beta=10.0))],
+        "cnsm_dtw": [(3, kvmatch.NormQueryEngineDtw, (0.05, 2.0, 10.0), dict(rho=0.05, alpha=2.0, beta=10.0))],
+        "mixed": [(0, kvmatch.QueryEngine, (), {}),
+                  (1, kvmatch.NormQueryEngine, (2.0, 10.0), dict(alpha=2.0, beta=10.0)),
+                  (2, kvmatch.QueryEngineDtw, (0.05,), dict(rho=0.05)),
+                  (3, kvmatch.NormQueryEngineDtw, (0.05, 2.0, 10.0), dict(rho=0.05, alpha=2.0, beta=10.0))],
+    }[wl]
+    engines = [cls(ctx) for _, cls, _, _ in plans]
+    eng = engines[0]
     lib, h = ctx._lib, ctx._h
+    step_no = [0]
     kernel_ns = []
     last = {}
 
-    sharded = distributed.ShardedVerifier(ctx, 0, my_cands) if use_dist else None
+    sharded = [distributed.ShardedVerifier(ctx, v, my_cands) for v, _, _, _ in plans] if use_dist else None
 
     def step():
+        i = step_no[0] % len(plans)  # "mixed": the query stream cycles through the four variants
+        step_no[0] += 1
         if use_dist:
             # device-resident shard verification + ONE all-gather of the surviving (offset, distance) pairs (RCCL)
-            offs, dists = sharded.verify((my_l, my_r), 1, q, a.epsilon)
+            offs, dists = sharded[i].verify((my_l, my_r), 1, q, a.epsilon, **plans[i][3])
             last["windows"] = my_cands
         else:
-            ans = eng.verify((my_l, my_r), 1, q, a.epsilon)
+            ans = engines[i].verify((my_l, my_r), 1, q, a.epsilon, *plans[i][2])
             offs, dists = ans.offsets, ans.distances
             last["windows"] = ans.stats[kvmatch.STAT_WINDOWS]
         kernel_ns.append(int(lib.kvm_last_kernel_ns(h)))
@@ -121,7 +146,9 @@ def main():
 
     # ---- headline: early abandon off ---------------------------------------------------------------------
     ctx.set_option(kvmatch.OPT_EARLY_ABANDON, 0)
-    step()  # first call allocates scratch
+    for _ in plans:
+        step()  # first calls allocate scratch (and build the rho envelope for DTW)
+    step_no[0] = 0
     kernel_ns.clear()
     dt = timed_steps(step, a.steps, a.warmup, world)
     k_ns = kernel_ns[-a.steps:]
@@ -139,12 +166,19 @@ def main():
 
     # ---- same workload with the reference's early abandoning on (reported, not the headline) -------------
     ctx.set_option(kvmatch.OPT_EARLY_ABANDON, 1)
-    dt_ab = timed_steps(step, max(3, a.steps // 2), 1, world)
-    value_ab = total_cands * max(3, a.steps // 2) / dt_ab
-    ab_match = bool(np.array_equal(head_offs, last["offs"]))
+    step_no[0] = 0
+    n_ab = max(3, a.steps // 2) // len(plans) * len(plans) or len(plans)
+    dt_ab = timed_steps(step, n_ab, len(plans), world)
+    value_ab = total_cands * n_ab / dt_ab
+    step_no[0] = (a.steps - 1) % len(plans)
+    step()
+    ab_match = bool(np.array_equal(head_offs, last["offs"])) if len(plans) == 1 else None
 
     out = {
-        "metric": "candidate subsequences verified/sec (RSM-ED, n=1e8, m=8192)",
+        "metric": {"rsm_ed": "candidate subsequences verified/sec (RSM-ED, n=1e8, m=8192)",
+                   "cnsm_ed": "candidate subsequences verified/sec (cNSM-ED, n=1e8, m=8192)",
+                   "cnsm_dtw": "candidate subsequences verified/sec (cNSM-DTW, n=1e8, m=4096, rho=5%)",
+                   "mixed": "candidate subsequences verified/sec (mixed RSM/cNSM x ED/DTW query stream)"}[wl],
         "value": value,
         "unit": "candidates/s",
         "n_gpus": world,
@@ -156,7 +190,10 @@ def main():
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic (seeded restatement of K/DataGenerator.java; query + 3 noisy copies planted)",
-        "config": {"workload": "RSM-ED phase 2 (BASELINE configs[1])", "n": n, "m": m,
+        "config": {"workload": {"rsm_ed": "RSM-ED phase 2 (BASELINE configs[1])",
+                                "cnsm_ed": "cNSM-ED phase 2, alpha=2 beta=10 (BASELINE configs[2])",
+                                "cnsm_dtw": "cNSM-DTW phase 2, rho=5%, alpha=2 beta=10 (BASELINE configs[3])",
+                                "mixed": "mixed ED+DTW query stream (BASELINE configs[4] style)"}[wl], "n": n, "m": m,
                    "candidates_per_gpu": my_cands, "intervals_per_gpu": int(len(my_l)), "epsilon": a.epsilon,
                    "early_abandon": False, "parallelism": f"candidate shards x{world}, series replicated",
                    "answers": int(len(head_offs)), "ed_kernel": a.ed_kernel},
@@ -179,7 +216,7 @@ def main():
                        "fp64_valu_peak_tflops": FP64_VALU_PEAK_TFLOPS}
 
     # ---- CPU baseline: the oracle (a C port of the reference loops), rank 0, N=1 only --------------------
-    if rank == 0 and world == 1 and a.cpu_baseline:
+    if rank == 0 and world == 1 and a.cpu_baseline and wl == "rsm_ed":
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import oracle  # test infrastructure: used here only as the timed CPU baseline / checker
         t1 = time.perf_counter()
@@ -203,7 +240,7 @@ def main():
         out["parity_vs_oracle"] = bool(same and close)
 
     # ---- extras (N=1): the other variants on the same staged series ---------------------------------------
-    if rank == 0 and world == 1 and a.extras:
+    if rank == 0 and world == 1 and a.extras and wl == "rsm_ed":
         ex = {}
         try:
             ctx.set_option(kvmatch.OPT_EARLY_ABANDON, 0)
@@ -246,6 +283,13 @@ def main():
             ex["dtw_dp_kernel_ms"] = lib.kvm_last_kernel_ns(h) * 1e-6
             ctx.set_option(kvmatch.OPT_LB_CASCADE, 1)
             ctx.set_option(kvmatch.OPT_EARLY_ABANDON, 1)
+            # index-free full scan (UCR-ED semantics, K/experiments/ucr/UcrEdQueryExecutor.java): every offset a candidate
+            fl, fr = np.array([1], dtype=np.int32), np.array([n - m + 1], dtype=np.int32)
+            eng.verify((fl, fr), 1, q, a.epsilon)
+            t1 = time.perf_counter()
+            r_ = eng.verify((fl, fr), 1, q, a.epsilon)
+            ex["full_scan_rsm_ed_candidates_per_s"] = r_.cnt_candidate / (time.perf_counter() - t1)
+            ex["full_scan_answers"] = len(r_)
         except Exception as e:  # extras must never take the headline down
             ex["error"] = repr(e)
         out["extras"] = ex

@@ -86,6 +86,13 @@ int64_t kvm_series_length(const kvm_ctx *ctx);
  * K/operator/file/TimeSeriesFileOperator.java:55-57).  `out` receives `length` host doubles. */
 int kvm_read_time_series(kvm_ctx *ctx, int32_t left, int32_t length, double *out);
 
+/* Sliding window means for the index build: out[i] = mean(x[i .. i+w-1]) for every 1-based window
+ * start i+1 in [first, first+count), computed from the block prefix sums (O(1) per window).  Replaces the running-sum
+ * loop of K/IndexBuilder.java:232-247 (`ex += d; mean = ex / w; ... ex -= t[j]`, restarted every EPOCH = 100000 points
+ * "for reducing the floating point error"); values agree with it to ~1e-14 relative, not bit for bit (the index keys
+ * are these means rounded to 0.05, K/utils/MeanIntervalUtils.java:51-61).  `out` is a HOST array of `count` doubles. */
+int kvm_window_means(kvm_ctx *ctx, int32_t w, int32_t first, int64_t count, double *out);
+
 /* ---- phase 2: the four verification entry points ------------------------------------------------ */
 
 /* RSM-ED.  Replaces K/QueryEngine.java:338-363 (+ sort :373). */

@@ -242,6 +242,22 @@ extern "C" int kvm_read_time_series(kvm_ctx *ctx, int32_t left, int32_t length, 
     return KVM_OK;
 }
 
+extern "C" int kvm_window_means(kvm_ctx *ctx, int32_t w, int32_t first, int64_t count, double *out) {
+    if (!ctx) return KVM_ERR_INVALID_HANDLE;
+    if (!ctx->d_series) return fail(ctx, KVM_ERR_NO_SERIES, "no series loaded");
+    if (w < 1 || first < 1 || count < 0 || !out || (int64_t)first + count - 1 + w - 1 > ctx->n)
+        return fail(ctx, KVM_ERR_ILLEGAL_ARGUMENT, "kvm_window_means: window range outside the series");
+    if (count == 0) return KVM_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int rc = ensure(ctx, ctx->b_scratch, (size_t)count * 8);
+    if (rc) return rc;
+    HIPCHK(ctx, kvm_launch_window_means(ctx->d_series, ctx->d_prefix, w, (int64_t)first - 1, count,
+                                        (double *)ctx->b_scratch.p, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(out, ctx->b_scratch.p, (size_t)count * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return KVM_OK;
+}
+
 extern "C" int32_t kvm_resolve_rho(double r, int32_t m) {
     if (r <= 1) return (int32_t)std::floor(r * m);  // K/QueryEngineDtw.java:135-140
     return (int32_t)std::floor(r);

@@ -131,6 +131,26 @@ hipError_t kvm_launch_prefix(const double *x, double2 *prefix, int64_t n, hipStr
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Sliding window means from the shifted prefix sums (index build support): one thread per window.
+__global__ __launch_bounds__(256) void kvm_window_means_kernel(const double *__restrict__ x,
+                                                               const double2 *__restrict__ P, int32_t w, int64_t first0,
+                                                               int64_t count, double *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    double s1, s2, c;
+    kvm_window_shifted_sums(P, x, first0 + i, w, s1, s2, c);
+    out[i] = c + s1 / w;
+}
+
+hipError_t kvm_launch_window_means(const double *x, const double2 *prefix, int32_t w, int64_t first0, int64_t count,
+                                   double *out, hipStream_t s) {
+    if (count <= 0) return hipSuccess;
+    hipLaunchKernelGGL(kvm_window_means_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, x, prefix, w, first0,
+                       count, out);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Sliding envelope over the whole series: u[i] = max x[max(0,i-r) .. min(n-1,i+r)], l[i] = min ... .
 // Same values as DtwUtils.lowerUpperLemire (K/utils/DtwUtils.java:93-134) applied to the WHOLE series
 // (pure selections, no arithmetic).  The reference applies it per fetched chunk, so its envelope is

@@ -108,6 +108,15 @@ class Phase2Context:
         _lib.check(self._lib.kvm_read_time_series(self._h, int(left), int(length), out.ctypes.data), self._h)
         return out
 
+    def window_means(self, w, first=1, count=None):
+        """Sliding means of length-w windows starting at 1-based offsets first .. first+count-1 (index build support,
+        cf. K/IndexBuilder.java:232-247)."""
+        if count is None:
+            count = self.n - w + 1 - (first - 1)
+        out = np.empty(max(int(count), 0), dtype=np.float64)
+        _lib.check(self._lib.kvm_window_means(self._h, int(w), int(first), int(count), out.ctypes.data), self._h)
+        return out
+
     def set_option(self, option, value):
         _lib.check(self._lib.kvm_set_option(self._h, int(option), int(value)), self._h)
 

@@ -543,3 +543,25 @@ def test_many_answers_and_tiny_series(world):
     compare(kvmatch.QueryEngine(ctx).verify((Ls, Rs), 1, qq, 2.0), oracle.rsm_ed(t, qq, Ls, Rs, 0, 2.0), tag="tiny rsm")
     compare(kvmatch.NormQueryEngineDtw(ctx).verify((Ls, Rs), 1, qq, 2.0, 4, 2.0, 5.0),
             oracle.cnsm_dtw(t, qq, Ls, Rs, 0, 2.0, 4, 2.0, 5.0), tag="tiny dtw")
+
+
+def test_window_means_for_index_build(world):
+    """sliding means for w in WuList = {25, 50, 100, 200, 400} (K/IndexBuilder.java) from the prefix
+    sums; compared with exactly-rounded sums (math.fsum) and with the reference's running-sum loop restated in numpy."""
+    import math
+    kvmatch, datagen, series, ctx = world
+    s = series[:70_000].copy()
+    ctx.load_series(s)
+    for w in (25, 50, 100, 200, 400):
+        got = ctx.window_means(w)
+        assert got.shape == (len(s) - w + 1,)
+        cs = np.concatenate(([0.0], np.cumsum(s)))
+        approx = (cs[w:] - cs[:-w]) / w
+        assert np.allclose(got, approx, rtol=1e-9, atol=1e-9)
+        for i in (0, 1, 16_383, 16_384, 16_385, 40_000, len(s) - w):
+            exact = math.fsum(s[i:i + w]) / w
+            assert abs(got[i] - exact) <= 1e-13 * max(1.0, abs(exact)), (w, i)
+    sub = ctx.window_means(100, first=500, count=10)
+    assert np.array_equal(sub, ctx.window_means(100)[499:509])
+    with pytest.raises(kvmatch.KvMatchIllegalArgument):
+        ctx.window_means(100, first=len(s) - 50, count=10)
