@@ -15,4 +15,4 @@ for mode in ed dtw; do
   rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_LDS_ADDR_CONFLICT --output-format csv -d $OUT/${mode}_lds -- python3 profiles/prof_workloads.py $mode > $OUT/${mode}_lds.log 2>&1
   rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/${mode}_l2 -- python3 profiles/prof_workloads.py $mode > $OUT/${mode}_l2.log 2>&1
 done
-tail -2 $OUT/*_trace.log
+true
