@@ -349,6 +349,7 @@ static int build_plan(kvm_ctx *ctx, bool cnsm, int32_t m, const int32_t *left, c
         r.start = (int32_t)lo;  // the reference restarts ex/ex2 here (K/NormQueryEngine.java:487-491)
         r.count = (int32_t)(hi - lo + 1);
         r.tile_base = pl.n_tiles;
+        r.win_base = pl.windows;
         pl.runs.push_back(r);
         pl.n_tiles += (r.count + tile_max - 1) / tile_max;
         pl.windows += r.count;
@@ -512,6 +513,20 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
     const kvm_tile *d_tiles = (const kvm_tile *)ctx->b_tiles.p;
     const int64_t n_tiles = pl.n_tiles;
 
+    // scratch of the running-sum replay of the exact pass (cNSM): flags + {mean,std} per window, counts per run
+    kvm_replay_ws rws;
+    std::memset(&rws, 0, sizeof rws);
+    if (cnsm && pl.windows > 0) {
+        const size_t sbytes = (size_t)pl.windows * sizeof(double2);
+        const size_t nbytes = ((size_t)pl.windows + 15) / 16 * 16, mbytes = pl.runs.size() * sizeof(int32_t);
+        if ((rc = ensure(ctx, ctx->b_scratch, sbytes + nbytes + mbytes + 64))) return rc;
+        rws.runs = (const kvm_run *)ctx->b_aux2.p;
+        rws.n_runs = (int64_t)pl.runs.size();
+        rws.stats = (double2 *)ctx->b_scratch.p;
+        rws.need = (unsigned char *)ctx->b_scratch.p + sbytes;
+        rws.run_maxk = (int32_t *)((char *)ctx->b_scratch.p + sbytes + nbytes);
+        HIPCHK(ctx, hipMemsetAsync(rws.need, 0, nbytes + mbytes, stream));
+    }
     if (kernel_ns) *kernel_ns = 0;
     ctx->last_kernel_ns = 0;
     KVM_TP("  H2D enqueue");
@@ -554,7 +569,7 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
         const int32_t *d_order =
             cnsm ? (const int32_t *)((const char *)ctx->b_query.p + qexact_off + (size_t)m * 8) : nullptr;
         HIPCHK(ctx, kvm_launch_exact_ed(ctx->d_series, qd, q_exact, d_order, surv, counters + KVM_CNT_CANDS1, pl.windows,
-                                        out.d_off, out.d_dist, out.cap, counters, ctx->num_cu, stream));
+                                        rws, out.d_off, out.d_dist, out.cap, counters, ctx->num_cu, stream));
     } else {
         const int use_lb = (int)ctx->opt_lb_cascade;
         if ((rc = ensure(ctx, ctx->b_cands, (size_t)pl.windows * sizeof(kvm_cand) + 64))) return rc;
@@ -581,7 +596,7 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
         // cNSM: replay the reference's running sums for the candidates that reach the DP (exact mean/std and
         // exact (alpha, beta) decision), so that the DP -- bit-exact per cell -- returns the reference's distance
         if (cnsm)
-            HIPCHK(ctx, kvm_launch_exact_stats(ctx->d_series, qd, const_cast<kvm_cand *>(dp_in), dp_n, pl.windows,
+            HIPCHK(ctx, kvm_launch_exact_stats(ctx->d_series, qd, const_cast<kvm_cand *>(dp_in), dp_n, pl.windows, rws,
                                                counters, ctx->num_cu, stream));
         if (ctx->opt_timing) HIPCHK(ctx, hipEventRecord(ctx->ev0, stream));  // time the DP kernel alone
         HIPCHK(ctx, kvm_launch_dtw_dp(ctx->d_series, ctx->n, qd, dp_in, dp_suffix, seg_len, dp_n, pl.windows, out.d_off, out.d_dist,

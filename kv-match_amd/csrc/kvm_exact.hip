@@ -87,39 +87,110 @@ __device__ __forceinline__ void ex_consume_replay(const double *buf, int64_t tot
     }
 }
 
-// Replays the reference's running sums for the window starting at 0-based index `ws` of the run whose first point is
-// 0-based index `b` (ws >= b) and returns that window's mean/std exactly as the reference has them.  Workgroup of
-// EX_THREADS: waves 1-3 fill chunk c+1 into the other LDS buffer while lane 0 of wave 0 adds chunk c.
-__device__ __forceinline__ void ex_replay_stats(const double *__restrict__ x, int64_t b, int64_t ws, int m, double *bufs,
-                                                double *bcast, double &mean, double &std) {
+// ---------------------------------------------------------------------------------------------------
+// Running-sum replay, one workgroup per run.  Survivors of one run share the prefix of the reference's running sums,
+// so the run is replayed ONCE, up to the last window any survivor needs, and {mean, std} is stored for every flagged
+// window.  (Replaying per survivor would repeat the prefix for each of them.)
+__device__ __forceinline__ int64_t ex_find_run(const kvm_run *__restrict__ runs, int64_t n_runs, int32_t run_start) {
+    int64_t lo = 0, hi = n_runs - 1;  // runs are sorted by start and disjoint
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (runs[mid].start < run_start) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+template <typename REC>
+__global__ __launch_bounds__(256) void kvm_replay_mark_kernel(const REC *__restrict__ recs,
+                                                              const unsigned long long *__restrict__ d_n,
+                                                              kvm_replay_ws ws) {
+    const unsigned long long n = *d_n;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (unsigned long long)gridDim.x * blockDim.x) {
+        const REC rec = recs[i];
+        if (rec.start < 0) continue;
+        const int64_t r = ex_find_run(ws.runs, ws.n_runs, rec.run_start);
+        const int32_t k = rec.start - rec.run_start;
+        ws.need[ws.runs[r].win_base + k] = 1;
+        atomicMax(&ws.run_maxk[r], k + 1);
+    }
+}
+
+__global__ __launch_bounds__(EX_THREADS) void kvm_replay_runs_kernel(const double *__restrict__ x, int m, kvm_replay_ws ws) {
+    __shared__ __attribute__((aligned(16))) double bufs[2 * EX_BUF];
+    __shared__ unsigned char flags[2][EX_STEPS];
+    const int64_t r = blockIdx.x;
+    const int32_t maxk = ws.run_maxk[r];
+    if (maxk == 0) return;
+    const kvm_run run = ws.runs[r];
+    const int64_t b = (int64_t)run.start - 1;
+    const int64_t total = (int64_t)(maxk - 1) + m;  // steps up to the last point of the last needed window
     const int tid = threadIdx.x;
     const bool consumer = tid < 64;
     const int ptid = tid - 64, pthreads = EX_THREADS - 64;
+    const unsigned char *need = ws.need + run.win_base;
+    auto produce = [&](int64_t c0, int buf) {
+        const int cnt = (int)min((int64_t)EX_STEPS, total - c0);
+        ex_produce_replay(x, b, total, m, c0, cnt, bufs + buf * EX_BUF, ptid, pthreads);
+        for (int t = ptid; t < cnt; t += pthreads) {
+            const int64_t k = c0 + t - (m - 1);  // window completed by step c0 + t
+            flags[buf][t] = (k >= 0) ? need[k] : 0;
+        }
+    };
     double ex = 0.0, ex2 = 0.0;
-    const int64_t total = ws + m - b;  // points consumed up to and including the last point of the window
     const int nch = (int)((total + EX_STEPS - 1) / EX_STEPS);
-    if (!consumer) ex_produce_replay(x, b, total, m, 0, (int)min((int64_t)EX_STEPS, total), bufs, ptid, pthreads);
+    if (!consumer) produce(0, 0);
     __syncthreads();
     for (int c = 0; c < nch; c++) {
         const int64_t c0 = (int64_t)c * EX_STEPS;
         if (consumer) {
-            if (tid == 0) ex_consume_replay(bufs + (c & 1) * EX_BUF, total, m, c0, (int)min((int64_t)EX_STEPS, total - c0), ex, ex2);
+            if (tid == 0) {
+                const double *buf = bufs + (c & 1) * EX_BUF;
+                const unsigned char *fl = flags[c & 1];
+                const int cnt = (int)min((int64_t)EX_STEPS, total - c0);
+                int t = 0;
+                const int n_add = (int)max((int64_t)0, min((int64_t)cnt, (int64_t)(m - 1) - c0));  // no window complete yet
+                for (; t + 4 <= n_add; t += 4) {
+                    double2 v[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) v[u] = *reinterpret_cast<const double2 *>(buf + 4 * (t + u));
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        ex += v[u].x;
+                        ex2 += v[u].y;
+                    }
+                }
+                for (; t < n_add; t++) {
+                    ex += buf[4 * t];
+                    ex2 += buf[4 * t + 1];
+                }
+                for (; t < cnt; t++) {
+                    const int64_t g = c0 + t;
+                    const double2 dv = *reinterpret_cast<const double2 *>(buf + 4 * t);
+                    const double2 ov = *reinterpret_cast<const double2 *>(buf + 4 * t + 2);
+                    ex += dv.x;   // K/NormQueryEngine.java:498
+                    ex2 += dv.y;  // :499
+                    if (fl[t]) {
+                        const double mu = ex / m;                                    // :507
+                        ws.stats[run.win_base + (g - (m - 1))] = make_double2(mu, sqrt(ex2 / m - mu * mu));  // :508
+                    }
+                    if (g < total - 1) {
+                        ex -= ov.x;   // :523
+                        ex2 -= ov.y;  // :524
+                    }
+                }
+            }
         } else if (c + 1 < nch) {
-            const int64_t n0 = c0 + EX_STEPS;
-            ex_produce_replay(x, b, total, m, n0, (int)min((int64_t)EX_STEPS, total - n0), bufs + ((c + 1) & 1) * EX_BUF, ptid,
-                              pthreads);
+            produce(c0 + EX_STEPS, (c + 1) & 1);
         }
         __syncthreads();
     }
-    if (tid == 0) {
-        const double mu = ex / m;                     // K/NormQueryEngine.java:507
-        bcast[0] = mu;
-        bcast[1] = sqrt(ex2 / m - mu * mu);           // :508
-    }
-    __syncthreads();
-    mean = bcast[0];
-    std = bcast[1];
-    __syncthreads();
+}
+
+static hipError_t ex_replay(const double *series, int m, const kvm_replay_ws &ws, hipStream_t s) {
+    if (ws.n_runs <= 0) return hipSuccess;
+    hipLaunchKernelGGL(kvm_replay_runs_kernel, dim3((unsigned)ws.n_runs), dim3(EX_THREADS), 0, s, series, m, ws);
+    return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -130,7 +201,7 @@ __global__ __launch_bounds__(EX_THREADS) void kvm_exact_ed_kernel(const double *
                                                                   const int32_t *__restrict__ order,
                                                                   const kvm_surv *__restrict__ surv,
                                                                   const unsigned long long *__restrict__ d_n_surv,
-                                                                  int32_t *__restrict__ out_off,
+                                                                  kvm_replay_ws ws, int32_t *__restrict__ out_off,
                                                                   double *__restrict__ out_dist, int64_t cap,
                                                                   unsigned long long *__restrict__ counters) {
     __shared__ __attribute__((aligned(16))) double bufs[2 * EX_BUF];
@@ -143,11 +214,14 @@ __global__ __launch_bounds__(EX_THREADS) void kvm_exact_ed_kernel(const double *
     const unsigned long long n_surv = *d_n_surv;
     for (unsigned long long idx = blockIdx.x; idx < n_surv; idx += gridDim.x) {
         const kvm_surv sv = surv[idx];
-        const int64_t ws = (int64_t)sv.start - 1;
-        const double *__restrict__ x = series + ws;
+        const double *__restrict__ x = series + ((int64_t)sv.start - 1);
         double mean = 0.0, std = 1.0;
         if (NORM) {
-            ex_replay_stats(series, (int64_t)sv.run_start - 1, ws, m, bufs, bcast, mean, std);
+            // the reference's mean/std of this window (replayed per run by kvm_replay_runs_kernel)
+            const int64_t r = ex_find_run(ws.runs, ws.n_runs, sv.run_start);
+            const double2 st = ws.stats[ws.runs[r].win_base + (sv.start - sv.run_start)];
+            mean = st.x;
+            std = st.y;
             if (!kvm_cnsm_filter(mean, std, qd.meanQ, qd.stdQ, qd.alpha, qd.beta)) continue;  // workgroup-uniform
             if (tid == 0) atomicAdd(&counters[KVM_CNT_PASS_FILTER_EXACT], 1ULL);
         }
@@ -200,50 +274,55 @@ __global__ __launch_bounds__(EX_THREADS) void kvm_exact_ed_kernel(const double *
 
 hipError_t kvm_launch_exact_ed(const double *series, const kvm_query_dev &qd, const double *q_exact,
                                const int32_t *order, const kvm_surv *surv, const unsigned long long *d_n_surv,
-                               int64_t max_surv, int32_t *out_off, double *out_dist, int64_t cap,
-                               unsigned long long *counters, int num_cu, hipStream_t s) {
+                               int64_t max_surv, const kvm_replay_ws &ws, int32_t *out_off, double *out_dist,
+                               int64_t cap, unsigned long long *counters, int num_cu, hipStream_t s) {
     if (max_surv <= 0) return hipSuccess;
     int64_t blocks = std::min<int64_t>(max_surv, (int64_t)num_cu * 5);  // 32 KiB LDS per workgroup: 5 resident per CU
-    if (qd.normalised)
+    if (qd.normalised) {
+        hipLaunchKernelGGL((kvm_replay_mark_kernel<kvm_surv>), dim3((unsigned)std::min<int64_t>((max_surv + 255) / 256, 1024)),
+                           dim3(256), 0, s, surv, d_n_surv, ws);
+        hipError_t e = ex_replay(series, qd.m, ws, s);
+        if (e != hipSuccess) return e;
         hipLaunchKernelGGL((kvm_exact_ed_kernel<true>), dim3((unsigned)blocks), dim3(EX_THREADS), 0, s, series, qd,
-                           q_exact, order, surv, d_n_surv, out_off, out_dist, cap, counters);
-    else
+                           q_exact, order, surv, d_n_surv, ws, out_off, out_dist, cap, counters);
+    } else {
         hipLaunchKernelGGL((kvm_exact_ed_kernel<false>), dim3((unsigned)blocks), dim3(EX_THREADS), 0, s, series, qd,
-                           q_exact, order, surv, d_n_surv, out_off, out_dist, cap, counters);
+                           q_exact, order, surv, d_n_surv, ws, out_off, out_dist, cap, counters);
+    }
     return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Exact mean/std for the DTW candidates that reached the DP stage (cNSM-DTW): replay, exact (alpha, beta) test,
-// records updated in place; candidates failing the exact test are marked with start = -start (the DP kernel skips them).
-__global__ __launch_bounds__(EX_THREADS) void kvm_exact_stats_kernel(const double *__restrict__ series, kvm_query_dev qd,
-                                                                     kvm_cand *__restrict__ cands,
-                                                                     const unsigned long long *__restrict__ d_n,
-                                                                     unsigned long long *__restrict__ counters) {
-    __shared__ __attribute__((aligned(16))) double bufs[2 * EX_BUF];
-    __shared__ double bcast[4];
+// Exact mean/std for the DTW candidates that reached the DP stage (cNSM-DTW): mark -> replay per run -> apply.  The
+// records are updated in place with the reference's mean/std; candidates failing the exact (alpha, beta) test are
+// marked with start = -start (the DP kernel skips them).
+__global__ __launch_bounds__(256) void kvm_exact_stats_apply_kernel(kvm_query_dev qd, kvm_cand *__restrict__ cands,
+                                                                    const unsigned long long *__restrict__ d_n,
+                                                                    kvm_replay_ws ws,
+                                                                    unsigned long long *__restrict__ counters) {
     const unsigned long long n = *d_n;
-    for (unsigned long long idx = blockIdx.x; idx < n; idx += gridDim.x) {
-        kvm_cand c = cands[idx];
-        double mean, std;
-        ex_replay_stats(series, (int64_t)c.run_start - 1, (int64_t)c.start - 1, qd.m, bufs, bcast, mean, std);
-        const bool pass = kvm_cnsm_filter(mean, std, qd.meanQ, qd.stdQ, qd.alpha, qd.beta);
-        if (threadIdx.x == 0) {
-            c.mean = mean;
-            c.std = std;
-            if (!pass) c.start = -c.start;
-            cands[idx] = c;
-            atomicAdd(&counters[KVM_CNT_RECHECKED], 1ULL);
-        }
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (unsigned long long)gridDim.x * blockDim.x) {
+        kvm_cand c = cands[i];
+        const int64_t r = ex_find_run(ws.runs, ws.n_runs, c.run_start);
+        const double2 st = ws.stats[ws.runs[r].win_base + (c.start - c.run_start)];
+        c.mean = st.x;
+        c.std = st.y;
+        if (!kvm_cnsm_filter(st.x, st.y, qd.meanQ, qd.stdQ, qd.alpha, qd.beta)) c.start = -c.start;
+        cands[i] = c;
+        atomicAdd(&counters[KVM_CNT_RECHECKED], 1ULL);
     }
 }
 
 hipError_t kvm_launch_exact_stats(const double *series, const kvm_query_dev &qd, kvm_cand *cands,
-                                  const unsigned long long *d_n, int64_t max_n, unsigned long long *counters,
-                                  int num_cu, hipStream_t s) {
+                                  const unsigned long long *d_n, int64_t max_n, const kvm_replay_ws &ws,
+                                  unsigned long long *counters, int num_cu, hipStream_t s) {
+    (void)num_cu;
     if (max_n <= 0) return hipSuccess;
-    int64_t blocks = std::min<int64_t>(max_n, (int64_t)num_cu * 5);
-    hipLaunchKernelGGL(kvm_exact_stats_kernel, dim3((unsigned)blocks), dim3(EX_THREADS), 0, s, series, qd, cands, d_n,
-                       counters);
+    const unsigned g = (unsigned)std::min<int64_t>((max_n + 255) / 256, 1024);
+    hipLaunchKernelGGL((kvm_replay_mark_kernel<kvm_cand>), dim3(g), dim3(256), 0, s, cands, d_n, ws);
+    hipError_t e = ex_replay(series, qd.m, ws, s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kvm_exact_stats_apply_kernel, dim3(g), dim3(256), 0, s, qd, cands, d_n, ws, counters);
     return hipGetLastError();
 }

@@ -27,6 +27,17 @@ struct kvm_run {
     int32_t start;      // first window start offset (1-based)
     int32_t count;      // number of consecutive offsets
     int64_t tile_base;  // index of the run's first tile in the tile list
+    int64_t win_base;   // ordinal of the run's first window among all windows of the query (exclusive prefix of counts)
+};
+
+// Scratch of the running-sum replay (kvm_exact.hip): one flag and one {mean, std} slot per window of the query,
+// one "windows needed" count per run.
+struct kvm_replay_ws {
+    const kvm_run *runs;
+    int64_t n_runs;
+    unsigned char *need;   // [windows] 1 = some survivor needs the reference's mean/std of this window
+    int32_t *run_maxk;     // [n_runs]  number of leading windows of the run that must be replayed (0 = none)
+    double2 *stats;        // [windows] {mean, std} as the reference's running sums give them
 };
 
 // Tile = up to `count` consecutive candidates taken from one run.
@@ -126,11 +137,11 @@ hipError_t kvm_launch_ed_dot(const double *series, const double2 *prefix, int64_
 // Exact final pass (kvm_exact.hip)
 hipError_t kvm_launch_exact_ed(const double *series, const kvm_query_dev &qd, const double *q_exact,
                                const int32_t *order, const kvm_surv *surv, const unsigned long long *d_n_surv,
-                               int64_t max_surv, int32_t *out_off, double *out_dist, int64_t cap,
-                               unsigned long long *counters, int num_cu, hipStream_t s);
+                               int64_t max_surv, const kvm_replay_ws &ws, int32_t *out_off, double *out_dist,
+                               int64_t cap, unsigned long long *counters, int num_cu, hipStream_t s);
 hipError_t kvm_launch_exact_stats(const double *series, const kvm_query_dev &qd, kvm_cand *cands,
-                                  const unsigned long long *d_n, int64_t max_n, unsigned long long *counters,
-                                  int num_cu, hipStream_t s);
+                                  const unsigned long long *d_n, int64_t max_n, const kvm_replay_ws &ws,
+                                  unsigned long long *counters, int num_cu, hipStream_t s);
 
 // DTW cascade.
 hipError_t kvm_launch_dtw_filter(const double *series, const double2 *prefix, int64_t n, const kvm_query_dev &qd,
