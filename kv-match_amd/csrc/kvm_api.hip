@@ -419,7 +419,8 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
     // ED pruning kernel: 1 = wave-per-candidate, 2 = LDS-tiled direct form, 3 (and auto) = LDS-tiled correlation form
     const int ed_kernel = ctx->opt_ed_kernel == 0 ? 3 : (int)ctx->opt_ed_kernel;
     auto tp_ = std::chrono::steady_clock::now();
-    const int32_t tile_max = (!dtw && ed_kernel >= 2) ? KVM_TILE_TILED : KVM_TILE_MAX;
+    // 32-candidate tiles for the LDS-tiled kernels (ED pruners, fused DTW lower-bound stage), 64 otherwise
+    const int32_t tile_max = ((!dtw && ed_kernel >= 2) || (dtw && ctx->opt_lb_cascade)) ? KVM_TILE_TILED : KVM_TILE_MAX;
     int rc = build_plan(ctx, cnsm, m, left, right, k, shift, tile_max, pl);
     if (rc) return rc;
     KVM_TP("  build_plan");
@@ -574,8 +575,12 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
         const int use_lb = (int)ctx->opt_lb_cascade;
         if ((rc = ensure(ctx, ctx->b_cands, (size_t)pl.windows * sizeof(kvm_cand) + 64))) return rc;
         kvm_cand *c1 = (kvm_cand *)ctx->b_cands.p;
-        HIPCHK(ctx, kvm_launch_dtw_filter(ctx->d_series, ctx->d_prefix, ctx->n, qd, d_tiles, n_tiles, use_lb, c1,
-                                          counters, stream));
+        if (use_lb)  // fused, LDS-tiled: (alpha, beta) filter + LB_Kim + LB_Keogh(query envelope) over all candidates
+            HIPCHK(ctx, kvm_launch_dtw_lb_tiled(ctx->d_series, ctx->d_prefix, ctx->n, qd, d_tiles, n_tiles, c1, counters,
+                                                stream));
+        else
+            HIPCHK(ctx, kvm_launch_dtw_filter(ctx->d_series, ctx->d_prefix, ctx->n, qd, d_tiles, n_tiles, 0, c1,
+                                              counters, stream));
         const kvm_cand *dp_in = c1;
         const unsigned long long *dp_n = counters + KVM_CNT_CANDS1;
         const double *dp_suffix = nullptr;

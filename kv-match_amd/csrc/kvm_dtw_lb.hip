@@ -1,0 +1,240 @@
+// kvm_dtw_lb.hip -- LDS-tiled first stage of the DTW cascade for gfx950: (alpha, beta) filter, LB_Kim and LB_Keogh on the
+// query envelope for EVERY candidate window, fused in one kernel.
+//
+// Replaces, for the bulk of the candidates, K/NormQueryEngineDtw.java:550-563 / K/QueryEngineDtw.java:409-419:
+//   mean/std (prefix sums) -> |mean-meanQ| <= beta, std/stdQ in [1/alpha, alpha] -> lbKimHierarchy (K/utils/DtwUtils.java:
+//   149-189) -> lbKeoghCumulative (:206-222).
+// LB_Keogh is an O(m) sum over the window, like ED, and consecutive candidates overlap in all but one point, so it is
+// tiled exactly like the correlation-form ED kernel (kvm_ed_dot.hip): one wavefront = 8 rows x 8 lanes, a row = one tile
+// of <= 32 consecutive candidates staged once in wave-private LDS, a lane = 4 adjacent candidates; the query envelope
+// (upper/lower, wave-uniform) is staged next to the rows and read with broadcast ds_read_b128.  Per (candidate, point):
+//     v = x * inv_sigma - mean * inv_sigma;  t = max(v - U_j, L_j - v, 0);  lb += t * t         (6 VALU ops; RSM: 5)
+// against 3 LDS reads per 8 terms, i.e. VALU-bound.  A wave stops as soon as every candidate it holds has exceeded the
+// pruning threshold (lower bounds only grow).  All values here use the approximate mean/std of the prefix sums: the
+// threshold carries the guard band of kvm_internal.h and survivors are re-examined downstream (LB_Keogh on the data
+// envelope, replayed mean/std, exact DP), so this kernel can only prune candidates that no arithmetic would accept.
+#include "kvm_internal.h"
+
+#define LB4_ROWS 8
+#define LB4_JC 96
+#define LB4_ROWLEN (LB4_JC + 32)
+#define LB4_LOADS (LB4_ROWLEN / 64)
+#define LB4_RS (LB4_ROWLEN + 32)
+#define LB4_WAVE_LDS (LB4_ROWS * LB4_RS + 2 * LB4_ROWLEN)  // 8 rows + upper + lower envelope chunk
+static_assert(LB4_ROWLEN % 64 == 0 && (LB4_RS * 8) % 256 == 0 && (LB4_JC / 4) % 2 == 0, "layout");
+static_assert(4 * LB4_WAVE_LDS * 8 <= 65536 && LB4_WAVE_LDS % 2 == 0, "static LDS");
+
+typedef double lb4_d2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ double lb4_dsq(double a, double b) { return (a - b) * (a - b); }
+
+template <bool NORM>
+__global__ __launch_bounds__(256, 2) void kvm_dtw_lb_tiled_kernel(const double *__restrict__ series,
+                                                                  const double2 *__restrict__ prefix, kvm_query_dev qd,
+                                                                  const kvm_tile *__restrict__ tiles, int64_t n_tiles,
+                                                                  kvm_cand *__restrict__ out,
+                                                                  unsigned long long *__restrict__ counters) {
+    __shared__ __attribute__((aligned(256))) double2 lds_all2[4 * LB4_WAVE_LDS / 2];
+    double *lds_all = reinterpret_cast<double *>(lds_all2);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = lane >> 3, lc = lane & 7;
+    const int m = qd.m;
+    const double *__restrict__ q = qd.q;
+    double *wlds = lds_all + wave * LB4_WAVE_LDS;
+    double *ulds = wlds + LB4_ROWS * LB4_RS, *llds = ulds + LB4_ROWLEN;
+    const int nchunks = (m + LB4_JC - 1) / LB4_JC;
+
+    const int64_t t0 = ((int64_t)blockIdx.x * 4 + wave) * LB4_ROWS;
+    if (t0 >= n_tiles) return;
+    int32_t rstart[LB4_ROWS];
+#pragma unroll
+    for (int r = 0; r < LB4_ROWS; r++) rstart[r] = (t0 + r < n_tiles) ? tiles[t0 + r].start : 1;
+    kvm_tile mine;
+    mine.start = 1; mine.count = 0; mine.run_start = 1; mine.pad = 0;
+    if (t0 + row < n_tiles) mine = tiles[t0 + row];
+    const int c0 = 4 * lc;
+
+    // ---- per candidate: mean/std, (alpha, beta) filter, LB_Kim ----
+    bool v[4];
+    double mean[4], sd[4], inv[4], nmi[4], lim[4], lb[4];
+    unsigned n_filter = 0, n_kim = 0;
+#pragma unroll
+    for (int a = 0; a < 4; a++) {
+        v[a] = c0 + a < mine.count;
+        mean[a] = 0.0; sd[a] = 1.0; inv[a] = 1.0; nmi[a] = 0.0; lb[a] = 0.0;
+        lim[a] = qd.eps2 * (1.0 + 1e-9);
+        if (v[a]) {
+            const int64_t w0 = (int64_t)mine.start - 1 + c0 + a;  // 0-based window start
+            if (NORM) {
+                kvm_window_mean_std(prefix, series, w0, m, mean[a], sd[a]);
+                const double g = kvm_sigma_guard(mean[a], sd[a]);
+                v[a] = kvm_cnsm_filter_guarded(mean[a], sd[a], qd.meanQ, qd.stdQ, qd.alpha, qd.beta, g);
+                lim[a] = qd.eps2 + kvm_eps2_slack(qd.eps2, m, g, 16.0);
+                if (!(sd[a] == sd[a]) || !(sd[a] > 0.0)) {  // degenerate sigma: no bound, the exact pass decides
+                    sd[a] = __builtin_nan("");
+                    lim[a] = __builtin_huge_val();
+                    inv[a] = 0.0;
+                    nmi[a] = 0.0;
+                } else {
+                    inv[a] = 1.0 / sd[a];
+                    nmi[a] = -mean[a] * inv[a];
+                }
+            }
+            if (v[a]) {
+                n_filter++;
+                if (m >= 6 && sd[a] == sd[a]) {  // LB_Kim, K/utils/DtwUtils.java:149-189 (full bound, no early returns)
+                    const double *__restrict__ tt = series + w0;
+                    const double mu = mean[a], s = sd[a];
+                    double d, l;
+                    const double x0 = (tt[0] - mu) / s, y0 = (tt[m - 1] - mu) / s;
+                    l = lb4_dsq(x0, q[0]) + lb4_dsq(y0, q[m - 1]);
+                    const double x1 = (tt[1] - mu) / s;
+                    d = fmin(lb4_dsq(x1, q[0]), lb4_dsq(x0, q[1]));
+                    d = fmin(d, lb4_dsq(x1, q[1]));
+                    l += d;
+                    const double y1 = (tt[m - 2] - mu) / s;
+                    d = fmin(lb4_dsq(y1, q[m - 1]), lb4_dsq(y0, q[m - 2]));
+                    d = fmin(d, lb4_dsq(y1, q[m - 2]));
+                    l += d;
+                    const double x2 = (tt[2] - mu) / s;
+                    d = fmin(lb4_dsq(x0, q[2]), lb4_dsq(x1, q[2]));
+                    d = fmin(d, lb4_dsq(x2, q[2]));
+                    d = fmin(d, lb4_dsq(x2, q[1]));
+                    d = fmin(d, lb4_dsq(x2, q[0]));
+                    l += d;
+                    const double y2 = (tt[m - 3] - mu) / s;
+                    d = fmin(lb4_dsq(y0, q[m - 3]), lb4_dsq(y1, q[m - 3]));
+                    d = fmin(d, lb4_dsq(y2, q[m - 3]));
+                    d = fmin(d, lb4_dsq(y2, q[m - 2]));
+                    d = fmin(d, lb4_dsq(y2, q[m - 1]));
+                    l += d;
+                    v[a] = l <= lim[a];
+                }
+                if (v[a]) n_kim++;
+            }
+        }
+    }
+    {
+        // wave totals of the two counters (one atomic each)
+        unsigned f = n_filter, k = n_kim;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            f += __shfl_xor(f, o, 64);
+            k += __shfl_xor(k, o, 64);
+        }
+        if (lane == 0) {
+            if (NORM && f) atomicAdd(&counters[KVM_CNT_PASS_FILTER], (unsigned long long)f);
+            if (k) atomicAdd(&counters[KVM_CNT_PASS_KIM], (unsigned long long)k);
+        }
+        if (k == 0) return;  // nothing left in this wave
+    }
+
+    // ---- LB_Keogh on the query envelope, tiled ----
+    double stage[LB4_ROWS + 2][LB4_LOADS];
+    auto load_chunk = [&](int j0) {
+#pragma unroll
+        for (int r = 0; r < LB4_ROWS; r++) {
+            const double *src = series + ((int64_t)rstart[r] - 1 + j0);  // unguarded: series is padded (KVM_SERIES_PAD)
+#pragma unroll
+            for (int t = 0; t < LB4_LOADS; t++) stage[r][t] = src[t * 64 + lane];
+        }
+#pragma unroll
+        for (int t = 0; t < LB4_LOADS; t++) {
+            stage[LB4_ROWS][t] = qd.qu[j0 + t * 64 + lane];      // (query block is padded as well)
+            stage[LB4_ROWS + 1][t] = qd.ql[j0 + t * 64 + lane];
+        }
+    };
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int r = 0; r < LB4_ROWS; r++) {
+#pragma unroll
+            for (int t = 0; t < LB4_LOADS; t++) wlds[r * LB4_RS + ((r >> 1) & 1) * 2 + t * 64 + lane] = stage[r][t];
+        }
+#pragma unroll
+        for (int t = 0; t < LB4_LOADS; t++) {
+            ulds[t * 64 + lane] = stage[LB4_ROWS][t];
+            llds[t * 64 + lane] = stage[LB4_ROWS + 1][t];
+        }
+    };
+#define LB4_TERM(a, xv, hi, lo)                                                       \
+    do {                                                                              \
+        const double z_ = NORM ? __builtin_fma((xv), inv[a], nmi[a]) : (xv);          \
+        double t_ = fmax(z_ - (hi), (lo) - z_);                                       \
+        t_ = fmax(t_, 0.0);                                                           \
+        lb[a] = __builtin_fma(t_, t_, lb[a]);                                         \
+    } while (0)
+
+    load_chunk(0);
+    store_chunk();
+    const lb4_d2 *X2 = reinterpret_cast<const lb4_d2 *>(lds_all2) +
+                       (wave * (LB4_WAVE_LDS / 2) + row * (LB4_RS / 2) + ((row >> 1) & 1) + 2 * lc);
+    const lb4_d2 *U2 = reinterpret_cast<const lb4_d2 *>(lds_all2) + (wave * (LB4_WAVE_LDS / 2) + LB4_ROWS * (LB4_RS / 2));
+    const lb4_d2 *L2 = U2 + LB4_ROWLEN / 2;
+    for (int ch = 0; ch < nchunks; ch++) {
+        const int j0 = ch * LB4_JC;
+        const bool more = ch + 1 < nchunks;
+        if (more) load_chunk(j0 + LB4_JC);
+        const int jlim = min(LB4_JC, m - j0);
+        if (jlim == LB4_JC) {
+            lb4_d2 wa = X2[0], wb = X2[1];
+#pragma unroll 2
+            for (int g = 0; g < LB4_JC / 4; g++) {
+                const lb4_d2 n0 = X2[2 * g + 2], n1 = X2[2 * g + 3];
+                const lb4_d2 u0 = U2[2 * g], u1 = U2[2 * g + 1], l0 = L2[2 * g], l1 = L2[2 * g + 1];
+                LB4_TERM(0, wa.x, u0.x, l0.x); LB4_TERM(1, wa.y, u0.x, l0.x); LB4_TERM(2, wb.x, u0.x, l0.x); LB4_TERM(3, wb.y, u0.x, l0.x);
+                LB4_TERM(0, wa.y, u0.y, l0.y); LB4_TERM(1, wb.x, u0.y, l0.y); LB4_TERM(2, wb.y, u0.y, l0.y); LB4_TERM(3, n0.x, u0.y, l0.y);
+                LB4_TERM(0, wb.x, u1.x, l1.x); LB4_TERM(1, wb.y, u1.x, l1.x); LB4_TERM(2, n0.x, u1.x, l1.x); LB4_TERM(3, n0.y, u1.x, l1.x);
+                LB4_TERM(0, wb.y, u1.y, l1.y); LB4_TERM(1, n0.x, u1.y, l1.y); LB4_TERM(2, n0.y, u1.y, l1.y); LB4_TERM(3, n1.x, u1.y, l1.y);
+                wa = n0;
+                wb = n1;
+            }
+        } else {
+            const double *X = reinterpret_cast<const double *>(X2);
+            for (int jj = 0; jj < jlim; jj++) {
+                const double hi = ulds[jj], lo = llds[jj];
+                LB4_TERM(0, X[jj], hi, lo); LB4_TERM(1, X[jj + 1], hi, lo); LB4_TERM(2, X[jj + 2], hi, lo); LB4_TERM(3, X[jj + 3], hi, lo);
+            }
+        }
+        if (more) {
+            bool alive = false;
+#pragma unroll
+            for (int a = 0; a < 4; a++) alive |= v[a] && lb[a] <= lim[a];
+            if (!__any(alive)) return;  // lower bounds only grow
+            store_chunk();
+        }
+    }
+#undef LB4_TERM
+    // survivors of the filter, LB_Kim and LB_Keogh(query envelope): wave-aggregated append
+#pragma unroll
+    for (int a = 0; a < 4; a++) {
+        const bool keep = v[a] && lb[a] <= lim[a];
+        const unsigned long long bal = __ballot(keep);
+        if (bal == 0ULL) continue;
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd(&counters[KVM_CNT_CANDS1], (unsigned long long)__popcll(bal));
+        base = __shfl(base, 0, 64);
+        if (keep) {
+            kvm_cand c;
+            c.start = mine.start + c0 + a;
+            c.run_start = mine.run_start;
+            c.mean = mean[a];
+            c.std = sd[a];
+            out[base + __popcll(bal & ((1ULL << lane) - 1ULL))] = c;
+        }
+    }
+}
+
+hipError_t kvm_launch_dtw_lb_tiled(const double *series, const double2 *prefix, int64_t n, const kvm_query_dev &qd,
+                                   const kvm_tile *tiles, int64_t n_tiles, kvm_cand *out, unsigned long long *counters,
+                                   hipStream_t s) {
+    (void)n;
+    if (n_tiles <= 0) return hipSuccess;
+    const int64_t blocks = (n_tiles + 4 * LB4_ROWS - 1) / (4 * LB4_ROWS);
+    if (qd.normalised)
+        hipLaunchKernelGGL((kvm_dtw_lb_tiled_kernel<true>), dim3((unsigned)blocks), dim3(256), 0, s, series, prefix, qd, tiles,
+                           n_tiles, out, counters);
+    else
+        hipLaunchKernelGGL((kvm_dtw_lb_tiled_kernel<false>), dim3((unsigned)blocks), dim3(256), 0, s, series, prefix, qd,
+                           tiles, n_tiles, out, counters);
+    return hipGetLastError();
+}

@@ -147,6 +147,9 @@ hipError_t kvm_launch_exact_stats(const double *series, const kvm_query_dev &qd,
 hipError_t kvm_launch_dtw_filter(const double *series, const double2 *prefix, int64_t n, const kvm_query_dev &qd,
                                  const kvm_tile *tiles, int64_t n_tiles, int32_t use_lb, kvm_cand *out,
                                  unsigned long long *counters, hipStream_t s);
+hipError_t kvm_launch_dtw_lb_tiled(const double *series, const double2 *prefix, int64_t n, const kvm_query_dev &qd,
+                                   const kvm_tile *tiles, int64_t n_tiles, kvm_cand *out, unsigned long long *counters,
+                                   hipStream_t s);
 #define KVM_DTW_NSEG 16  // coarse LB_Keogh suffix: segments per candidate (see kvm_dtw_keogh_kernel)
 hipError_t kvm_launch_dtw_keogh(const double *series, const double *env_u, const double *env_l, int64_t n,
                                 const kvm_query_dev &qd, const kvm_cand *in, const unsigned long long *d_n_in,
