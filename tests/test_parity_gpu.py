@@ -565,3 +565,53 @@ def test_window_means_for_index_build(world):
     assert np.array_equal(sub, ctx.window_means(100)[499:509])
     with pytest.raises(kvmatch.KvMatchIllegalArgument):
         ctx.window_means(100, first=len(s) - 50, count=10)
+
+
+def test_randomised_sweep_all_variants(world):
+    """Seeded random sweep over series shape, query length, thresholds and interval layouts: 240 verifications, each
+    compared bit for bit with the oracle."""
+    kvmatch, datagen, series, ctx = world
+    rng = np.random.default_rng(20260101)
+    cases = 0
+    for trial in range(60):
+        n = int(rng.integers(3_000, 60_000))
+        kind = trial % 4
+        if kind == 0:
+            s = series[int(rng.integers(0, 200_000)):][:n].copy()
+        elif kind == 1:
+            s = np.cumsum(rng.uniform(-1, 1, n)) + rng.uniform(-2000, 2000)     # long random walk, large offset
+        elif kind == 2:
+            s = rng.normal(rng.uniform(-5, 5), rng.uniform(0.01, 2), n)           # noise
+            s[n // 3: n // 3 + 500] = s[n // 3]                                   # with a constant stretch
+        else:
+            s = 5 * np.sin(np.arange(n) * rng.uniform(0.001, 0.3)) + rng.normal(0, 0.1, n)
+        m = int(rng.choice([25, 32, 47, 64, 100, 128, 255, 300, 512, 1000]))
+        if m * 3 > n:
+            m = 25
+        qoff = int(rng.integers(1, n - m + 1))
+        planted = [int(p) for p in rng.integers(1, n - m + 1, 2)]
+        q = datagen.plant_copies(s, qoff, m, planted, [1.0, float(rng.uniform(0.8, 1.3))],
+                                 [0.0, float(rng.uniform(-1, 1))], float(rng.uniform(0.001, 0.1)), seed=trial)
+        ctx.load_series(s)
+        mean_len = float(rng.choice([1.0, 3.0, 16.0, 64.0, 300.0]))
+        L, R = datagen.gen_intervals(n, m, int(rng.integers(200, 4000)), mean_len, must_cover=[qoff] + planted,
+                                     seed=trial)
+        last_segment = int(rng.integers(1, 4))
+        shift = (last_segment - 1) * 25
+        L2, R2 = (L + shift).astype(np.int32), (R + shift).astype(np.int32)
+        eps = float(rng.choice([0.0, 0.05, 0.3, 1.0, 3.0])) * np.sqrt(m) * 0.2 + float(rng.uniform(0, 0.5))
+        alpha = float(rng.choice([1.0, 1.05, 1.5, 3.0, 100.0]))
+        beta = float(rng.choice([0.0, 0.1, 1.0, 10.0, 1e6]))
+        rho = int(rng.choice([0, 1, 2, m // 20, m // 10, m // 3]))
+        rho_resolved = oracle.resolve_rho(rho, m)  # the reference's prompt rule: values <= 1 are a fraction of m
+        tag = f"trial {trial} n={n} m={m} eps={eps:.3f} a={alpha} b={beta} rho={rho} ml={mean_len}"
+        compare(kvmatch.QueryEngine(ctx).verify((L2, R2), last_segment, q, eps),
+                oracle.rsm_ed(s, q, L2, R2, shift, eps), tag="rsm_ed " + tag)
+        compare(kvmatch.NormQueryEngine(ctx).verify((L2, R2), last_segment, q, eps, alpha, beta),
+                oracle.cnsm_ed(s, q, L2, R2, shift, eps, alpha, beta), tag="cnsm_ed " + tag)
+        compare(kvmatch.QueryEngineDtw(ctx).verify((L2, R2), last_segment, q, eps, rho),
+                oracle.rsm_dtw(s, q, L2, R2, shift, eps, rho_resolved), tag="rsm_dtw " + tag)
+        compare(kvmatch.NormQueryEngineDtw(ctx).verify((L2, R2), last_segment, q, eps, rho, alpha, beta),
+                oracle.cnsm_dtw(s, q, L2, R2, shift, eps, rho_resolved, alpha, beta), tag="cnsm_dtw " + tag)
+        cases += 4
+    assert cases == 240
