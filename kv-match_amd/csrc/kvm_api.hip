@@ -75,7 +75,8 @@ extern "C" int kvm_open(int device, kvm_ctx **out) {
     kvm_ctx *ctx = new kvm_ctx();
     ctx->device = device;
     if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreate(&ctx->stream)) != hipSuccess ||
-        (e = hipEventCreate(&ctx->ev0)) != hipSuccess || (e = hipEventCreate(&ctx->ev1)) != hipSuccess) {
+        (e = hipEventCreate(&ctx->ev0)) != hipSuccess || (e = hipEventCreate(&ctx->ev1)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&ctx->ev_staged, hipEventDisableTiming)) != hipSuccess) {
         std::string msg = std::string("kvm_open: ") + hipGetErrorString(e);
         delete ctx;
         return fail(nullptr, KVM_ERR_DEVICE, msg);
@@ -119,6 +120,7 @@ extern "C" int kvm_close(kvm_ctx *ctx) {
     if (ctx->h_pinned) hipHostFree(ctx->h_pinned);
     hipEventDestroy(ctx->ev0);
     hipEventDestroy(ctx->ev1);
+    hipEventDestroy(ctx->ev_staged);
     hipStreamDestroy(ctx->stream);
     delete ctx;
     return KVM_OK;
@@ -416,6 +418,12 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
     if (cnsm && !(alpha > 0)) return fail(ctx, KVM_ERR_ILLEGAL_ARGUMENT, "alpha must be > 0");
     if (dtw && rho < 0) return fail(ctx, KVM_ERR_ILLEGAL_ARGUMENT, "rho must be >= 0");
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    // Scratch buffers and the pinned staging area are reused by every call: wait until the previous call's device
+    // work has drained (kvm_verify_device returns without synchronising the caller's stream).
+    if (ctx->staged_pending) {
+        HIPCHK(ctx, hipEventSynchronize(ctx->ev_staged));
+        ctx->staged_pending = false;
+    }
     // ED pruning kernel: 1 = wave-per-candidate, 2 = LDS-tiled direct form, 3 (and auto) = LDS-tiled correlation form
     const int ed_kernel = ctx->opt_ed_kernel == 0 ? 3 : (int)ctx->opt_ed_kernel;
     auto tp_ = std::chrono::steady_clock::now();
@@ -607,6 +615,8 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
         HIPCHK(ctx, kvm_launch_dtw_dp(ctx->d_series, ctx->n, qd, dp_in, dp_suffix, seg_len, dp_n, pl.windows, out.d_off, out.d_dist,
                                       out.cap, counters, ctx->num_cu, ctx->opt_dp_kernel == 1 ? 1 : 0, stream));
     }
+    HIPCHK(ctx, hipEventRecord(ctx->ev_staged, stream));  // every copy out of h_pinned has been enqueued before this point
+    ctx->staged_pending = true;
     if (ctx->opt_timing) {
         if (dtw) HIPCHK(ctx, hipEventRecord(ctx->ev1, stream));  // (ED: ev1 was recorded right after the ED kernel)
         HIPCHK(ctx, hipEventSynchronize(ctx->ev1));

@@ -71,6 +71,8 @@ struct kvm_ctx {
     int device = -1;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev_staged = nullptr;  // recorded after the last H2D copy out of h_pinned (guards its reuse)
+    bool staged_pending = false;
     int64_t n = 0;
     double *d_series = nullptr;
     bool own_series = false;
