@@ -233,6 +233,19 @@ def main():
             "value_early_abandon": o_st["windows"] / cpu_ab_s,
             "seconds": cpu_s,
         }
+        # the same loop on all host cores: a child process (no GPU context there) forks one worker per core
+        try:
+            import subprocess
+            ncores = min(os.cpu_count() or 1, 64)
+            cp = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline.py"), str(n), str(m),
+                                 str(a.candidates), str(a.epsilon), str(ncores)], capture_output=True, text=True,
+                                timeout=300)
+            allc = json.loads(cp.stdout.strip().splitlines()[-1])
+            out["cpu_baseline"]["all_cores"] = {"cores": allc["cores"], "value": allc["no_abandon"]["candidates_per_s"],
+                                                "value_early_abandon": allc["early_abandon"]["candidates_per_s"],
+                                                "note": "same port, interval shards over forked worker processes"}
+        except Exception as e:
+            out["cpu_baseline"]["all_cores"] = {"error": repr(e)}
         same = sorted(o_off.tolist()) == sorted(head_offs.tolist())
         od = dict(zip(o_off.tolist(), o_dist.tolist()))
         close = same and all(abs(d - od[o]) <= max(1e-6 * max(d, od[o]), 1e-9)
