@@ -157,12 +157,12 @@ hipError_t kvm_launch_window_means(const double *x, const double2 *prefix, int32
 // clipped at chunk ends; the global envelope is equal inside and looser at those ends -- still a valid
 // bound, affects pruning only.
 //
-// Each workgroup produces ENV_TS outputs from an LDS tile of ENV_TS + 2r points using the two-window
+// Each workgroup produces ENV_TS (2048 or 1024) outputs from an LDS tile of ENV_TS + 2r points using the two-window
 // (sparse-table) trick: with p = floor(log2(w)), w = 2r+1, max over a w-window = max(M_p[a], M_p[a+w-2^p])
 // where M_p[i] = max x[i .. i+2^p).  M_p is built by p ping-pong doubling passes in LDS.
-#define ENV_TS 2048
 extern __shared__ double kvm_env_lds[];
 
+template <int ENV_TS>
 __global__ __launch_bounds__(256) void kvm_envelope_kernel(const double *__restrict__ x, int64_t n, int32_t r,
                                                            double *__restrict__ u, double *__restrict__ l) {
     const int tid = threadIdx.x;
@@ -229,10 +229,19 @@ __global__ __launch_bounds__(256) void kvm_envelope_naive_kernel(const double *_
 
 hipError_t kvm_launch_envelope(const double *x, int64_t n, int32_t rho, double *u, double *l, hipStream_t s) {
     if (n <= 0) return hipSuccess;
-    size_t lds = (size_t)(ENV_TS + 2 * (int64_t)rho) * 2 * sizeof(double);
-    if (lds <= 64 * 1024) {
-        int64_t blocks = (n + ENV_TS - 1) / ENV_TS;
-        hipLaunchKernelGGL(kvm_envelope_kernel, dim3((unsigned)blocks), dim3(256), lds, s, x, n, rho, u, l);
+    // output tile of 2048 points while the tile + halo fits 64 KiB of LDS (rho <= 1024); wider bands use 1024-point
+    // tiles and up to the full 160 KiB of the CU (rho <= 4608); beyond that the O(w)-per-point fallback
+    const size_t lds_big = (size_t)(2048 + 2 * (int64_t)rho) * 2 * sizeof(double);
+    const size_t lds_small = (size_t)(1024 + 2 * (int64_t)rho) * 2 * sizeof(double);
+    if (lds_big <= 64 * 1024) {
+        int64_t blocks = (n + 2047) / 2048;
+        hipLaunchKernelGGL(kvm_envelope_kernel<2048>, dim3((unsigned)blocks), dim3(256), lds_big, s, x, n, rho, u, l);
+    } else if (lds_small <= 160 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)kvm_envelope_kernel<1024>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_small);
+        if (e != hipSuccess) return e;
+        int64_t blocks = (n + 1023) / 1024;
+        hipLaunchKernelGGL(kvm_envelope_kernel<1024>, dim3((unsigned)blocks), dim3(256), lds_small, s, x, n, rho, u, l);
     } else {
         int64_t blocks = (n + 255) / 256;
         hipLaunchKernelGGL(kvm_envelope_naive_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, n, rho, u, l);

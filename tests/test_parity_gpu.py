@@ -615,3 +615,18 @@ def test_randomised_sweep_all_variants(world):
                 oracle.cnsm_dtw(s, q, L2, R2, shift, eps, rho_resolved, alpha, beta), tag="cnsm_dtw " + tag)
         cases += 4
     assert cases == 240
+
+
+@pytest.mark.parametrize("m,rho", [(3000, 1100), (9000, 2000)])
+def test_wide_bands_envelope_paths(world, m, rho):
+    """rho > 1024 (1024-point envelope tiles with > 64 KiB of LDS) and the LDS form of the DP (rho > 511)."""
+    kvmatch, datagen, series, ctx = world
+    s = series[:60_000].copy()
+    q = datagen.plant_copies(s, 20_000, m, [40_000], [1.0], [0.0], 0.02, seed=2)
+    ctx.load_series(s)
+    L, R = datagen.gen_intervals(len(s), m, 300, 8.0, must_cover=[20_000, 40_000], seed=3)
+    eps = 0.08 * np.sqrt(m)
+    compare(kvmatch.QueryEngineDtw(ctx).verify((L, R), 1, q, eps, rho), oracle.rsm_dtw(s, q, L, R, 0, eps, rho),
+            tag=f"wide band rsm {rho}")
+    compare(kvmatch.NormQueryEngineDtw(ctx).verify((L, R), 1, q, eps, rho, 1.5, 3.0),
+            oracle.cnsm_dtw(s, q, L, R, 0, eps, rho, 1.5, 3.0), tag=f"wide band cnsm {rho}")
