@@ -164,6 +164,12 @@ int kvm_verify_device(kvm_ctx *ctx, int32_t variant, const double *query, int32_
                       double beta, int32_t *d_out_off, double *d_out_dist, int64_t cap, int64_t *d_out_count,
                       int64_t *cnt_candidate, void *stream);
 
+/* Packs the device-resident answers of kvm_verify_device for a fixed-size exchange: d_packed (fp64, 2*(pack_cap+1)
+ * entries) receives {count, 0} followed by the first min(count, pack_cap) (offset, distance) pairs.  One kernel on
+ * `stream`; used by the multi-GPU host layer before its single all-gather. */
+int kvm_pack_answers_device(kvm_ctx *ctx, const int32_t *d_off, const double *d_dist, const int64_t *d_count,
+                            int64_t pack_cap, double *d_packed, void *stream);
+
 /* ---- synthetic inputs: seeded restatement of K/DataGenerator.java:80-119 ------------------------ */
 
 /* Fills out[0..n) with the reference generator's distribution (random-walk / Gaussian / mixed-sine

@@ -755,6 +755,17 @@ extern "C" int kvm_verify_device(kvm_ctx *ctx, int32_t variant, const double *qu
     return KVM_OK;
 }
 
+extern "C" int kvm_pack_answers_device(kvm_ctx *ctx, const int32_t *d_off, const double *d_dist, const int64_t *d_count,
+                                       int64_t pack_cap, double *d_packed, void *stream) {
+    if (!ctx) return KVM_ERR_INVALID_HANDLE;
+    if (!d_off || !d_dist || !d_count || !d_packed || pack_cap < 0)
+        return fail(ctx, KVM_ERR_ILLEGAL_ARGUMENT, "bad kvm_pack_answers_device arguments");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, kvm_launch_pack_answers(d_off, d_dist, d_count, pack_cap, (double2 *)d_packed,
+                                        stream ? (hipStream_t)stream : ctx->stream));
+    return KVM_OK;
+}
+
 // ---- results ----------------------------------------------------------------------------------------------
 extern "C" int64_t kvm_result_count(const kvm_result *r) { return r ? (int64_t)r->off.size() : 0; }
 extern "C" int64_t kvm_result_candidates(const kvm_result *r) { return r ? r->candidates : 0; }

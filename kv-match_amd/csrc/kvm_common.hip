@@ -27,6 +27,31 @@ hipError_t kvm_launch_bswap64(uint64_t *d, int64_t n, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// [count | first pack_cap (offset, distance) pairs] as fp64 pairs: the payload of the multi-GPU all-gather.
+__global__ __launch_bounds__(256) void kvm_pack_answers_kernel(const int32_t *__restrict__ off,
+                                                               const double *__restrict__ dist,
+                                                               const int64_t *__restrict__ count, int64_t pack_cap,
+                                                               double2 *__restrict__ packed) {
+    const int64_t cnt = *count;
+    const int64_t take = cnt < pack_cap ? cnt : pack_cap;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= pack_cap; i += (int64_t)gridDim.x * blockDim.x) {
+        if (i == 0)
+            packed[0] = make_double2((double)cnt, 0.0);
+        else if (i <= take)
+            packed[i] = make_double2((double)off[i - 1], dist[i - 1]);
+        else
+            packed[i] = make_double2(0.0, 0.0);
+    }
+}
+
+hipError_t kvm_launch_pack_answers(const int32_t *off, const double *dist, const int64_t *count, int64_t pack_cap,
+                                   double2 *packed, hipStream_t s) {
+    hipLaunchKernelGGL(kvm_pack_answers_kernel, dim3((unsigned)((pack_cap + 256) / 256)), dim3(256), 0, s, off, dist, count,
+                       pack_cap, packed);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Runs -> tiles.  The host clips the phase-1 intervals into runs (K/QueryEngine.java:346-354) and knows each run's
 // first tile index; one wavefront per run writes its tile descriptors (16 B each, coalesced).
 __global__ __launch_bounds__(256) void kvm_expand_tiles_kernel(const kvm_run *__restrict__ runs, int64_t n_runs,

@@ -103,6 +103,8 @@ struct kvm_result {
 hipError_t kvm_launch_bswap64(uint64_t *d, int64_t n, hipStream_t s);
 hipError_t kvm_launch_expand_tiles(const kvm_run *runs, int64_t n_runs, int32_t tile_max, kvm_tile *tiles, hipStream_t s);
 hipError_t kvm_launch_prefix(const double *x, double2 *prefix, int64_t n, hipStream_t s);
+hipError_t kvm_launch_pack_answers(const int32_t *off, const double *dist, const int64_t *count, int64_t pack_cap,
+                                   double2 *packed, hipStream_t s);
 hipError_t kvm_launch_window_means(const double *x, const double2 *prefix, int32_t w, int64_t first0, int64_t count,
                                    double *out, hipStream_t s);
 hipError_t kvm_launch_envelope(const double *x, int64_t n, int32_t rho, double *u, double *l, hipStream_t s);

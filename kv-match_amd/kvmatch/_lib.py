@@ -29,7 +29,7 @@ SYMBOLS = [
     "kvm_verify_rsm_ed", "kvm_verify_cnsm_ed", "kvm_verify_rsm_dtw", "kvm_verify_cnsm_dtw", "kvm_resolve_rho",
     "kvm_result_count", "kvm_result_candidates", "kvm_result_elapsed_ms", "kvm_result_offsets",
     "kvm_result_distances", "kvm_result_stat", "kvm_result_free",
-    "kvm_set_option", "kvm_get_option", "kvm_last_kernel_ns", "kvm_verify_device",
+    "kvm_set_option", "kvm_get_option", "kvm_last_kernel_ns", "kvm_verify_device", "kvm_pack_answers_device",
     "kvm_gen_series", "kvm_gen_intervals", "kvm_write_series_file",
 ]
 
@@ -96,6 +96,7 @@ def load():
         "kvm_last_kernel_ns": (i64, [vp]),
         "kvm_verify_device": (C.c_int, [vp, i32, vp, i32, vp, vp, i32, i32, f64, i32, f64, f64, vp, vp, i64, vp,
                                         C.POINTER(i64), vp]),
+        "kvm_pack_answers_device": (C.c_int, [vp, vp, vp, vp, i64, vp, vp]),
         "kvm_gen_series": (C.c_int, [C.c_uint64, i64, vp]),
         "kvm_gen_intervals": (i64, [C.c_uint64, i64, i32, i64, f64, vp, i32, vp, vp, i64]),
         "kvm_write_series_file": (C.c_int, [C.c_char_p, vp, i64]),

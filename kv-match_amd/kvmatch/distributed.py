@@ -115,6 +115,7 @@ class ShardedVerifier:
         self.count = torch.zeros(1, dtype=torch.int64, device=self.dev)
         self.packed = torch.zeros((self.pack_cap + 1, 2), dtype=torch.float64, device=self.dev)
         self.gathered = torch.empty((self.world * (self.pack_cap + 1), 2), dtype=torch.float64, device=self.dev)
+        self.host = torch.empty((self.world * (self.pack_cap + 1), 2), dtype=torch.float64).pin_memory()
         self.cnt_candidate = 0
 
     def verify(self, valid_positions, last_segment, query_data, epsilon, rho=0, alpha=1.0, beta=0.0):
@@ -135,16 +136,18 @@ class ShardedVerifier:
             C.c_void_p(self.out_off.data_ptr()), C.c_void_p(self.out_dist.data_ptr()), self.cap,
             C.c_void_p(self.count.data_ptr()), C.byref(cnt_cand), C.c_void_p(stream)), c._h)
         self.cnt_candidate = int(cnt_cand.value)
-        # pack [count | first pack_cap pairs] on the device
+        # pack [count | first pack_cap pairs] on the device (one kernel), exchange, one copy to pinned host memory
         k = self.pack_cap
-        self.packed[0, 0] = self.count[0].to(torch.float64)
-        self.packed[1:, 0] = self.out_off[:k].to(torch.float64)
-        self.packed[1:, 1] = self.out_dist[:k]
+        _lib.check(c._lib.kvm_pack_answers_device(c._h, C.c_void_p(self.out_off.data_ptr()),
+                                                  C.c_void_p(self.out_dist.data_ptr()), C.c_void_p(self.count.data_ptr()),
+                                                  k, C.c_void_p(self.packed.data_ptr()), C.c_void_p(stream)), c._h)
         if self.world > 1:
             dist.all_gather_into_tensor(self.gathered, self.packed, group=self.group)
-            host = self.gathered.cpu().numpy().reshape(self.world, k + 1, 2)
+            self.host.copy_(self.gathered, non_blocking=True)
         else:
-            host = self.packed.cpu().numpy().reshape(1, k + 1, 2)
+            self.host[: k + 1].copy_(self.packed, non_blocking=True)
+        torch.cuda.current_stream(self.dev).synchronize()
+        host = self.host.numpy().reshape(self.world, k + 1, 2)
         counts = host[:, 0, 0].astype(np.int64)
         if counts.max() <= k:
             offs = np.concatenate([host[w, 1:1 + counts[w], 0] for w in range(self.world)]).astype(np.int32)
