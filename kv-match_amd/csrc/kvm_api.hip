@@ -284,7 +284,8 @@ static bool kvm_trace_on() {
 
 struct plan {
     std::vector<kvm_run> runs;  // clipped runs with the index of their first tile; expanded to tiles on the GPU
-    int64_t n_tiles = 0;
+    int64_t n_tiles = 0;        // tiles (class A tiles in hybrid mode)
+    int64_t n_tiles_b = 0;      // hybrid mode: class B tiles
     int64_t cnt_candidate = 0;  // sum(right-left+1) before clipping, K/QueryEngine.java:344
     int64_t windows = 0;        // windows actually evaluated
 };
@@ -292,7 +293,7 @@ struct plan {
 // Window start offsets of interval [left,right]: max(1,left-shift) .. min(right-shift, n-m+1)
 // (K/QueryEngine.java:346-354: begin/end clipping, loop `i + length - 1 < data.size()`).
 static int build_plan(kvm_ctx *ctx, bool cnsm, int32_t m, const int32_t *left, const int32_t *right, int32_t k,
-                      int32_t shift, int32_t tile_max, plan &pl) {
+                      int32_t shift, int32_t tile_max, bool hybrid, plan &pl) {
     const int64_t n = ctx->n;
     if (!cnsm) {
         // RSM engines fetch per interval: readTimeSeries(begin, end-begin+1) throws when the clipped range is
@@ -351,9 +352,16 @@ static int build_plan(kvm_ctx *ctx, bool cnsm, int32_t m, const int32_t *left, c
         r.start = (int32_t)lo;  // the reference restarts ex/ex2 here (K/NormQueryEngine.java:487-491)
         r.count = (int32_t)(hi - lo + 1);
         r.tile_base = pl.n_tiles;
+        r.tile_base_b = -1;
         r.win_base = pl.windows;
+        if (hybrid) {  // correlation-form ED pruner: 64-candidate tiles + <= 32-candidate remainders (kvm_ed_dot.hip)
+            const int32_t rem = r.count % 64;
+            pl.n_tiles += r.count / 64 + (rem > 32 ? 1 : 0);
+            if (rem > 0 && rem <= 32) r.tile_base_b = pl.n_tiles_b++;
+        } else {
+            pl.n_tiles += (r.count + tile_max - 1) / tile_max;
+        }
         pl.runs.push_back(r);
-        pl.n_tiles += (r.count + tile_max - 1) / tile_max;
         pl.windows += r.count;
     }
     return KVM_OK;
@@ -429,7 +437,8 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
     auto tp_ = std::chrono::steady_clock::now();
     // 32-candidate tiles for the LDS-tiled kernels (ED pruners, fused DTW lower-bound stage), 64 otherwise
     const int32_t tile_max = ((!dtw && ed_kernel >= 2) || (dtw && ctx->opt_lb_cascade)) ? KVM_TILE_TILED : KVM_TILE_MAX;
-    int rc = build_plan(ctx, cnsm, m, left, right, k, shift, tile_max, pl);
+    const bool hybrid = !dtw && ed_kernel == 3;
+    int rc = build_plan(ctx, cnsm, m, left, right, k, shift, tile_max, hybrid, pl);
     if (rc) return rc;
     KVM_TP("  build_plan");
 
@@ -458,30 +467,33 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
     if (dtw) query_envelope(q, rho, qu, ql);
     // correlation-form ED pruner: centred query and its chunk-granular prefix sums
     std::vector<double> qcen;
-    std::vector<double2> qpref;
-    const int nchunks4 = (m + ED4_JC - 1) / ED4_JC;
+    std::vector<double2> qpref, qpref8;
+    const int nchunks4 = (m + ED4_JC - 1) / ED4_JC, nchunks8 = (m + ED8_JC - 1) / ED8_JC;
     if (!dtw) {
         double sum = 0;
         for (int i = 0; i < m; i++) sum += q[i];
         qd.q_mean = sum / m;
         qcen.resize(m);
         qpref.resize((size_t)nchunks4 + 1);
+        qpref8.resize((size_t)nchunks8 + 1);
         double p1 = 0, p2 = 0;
         for (int i = 0; i < m; i++) {
             if (i % ED4_JC == 0) qpref[(size_t)(i / ED4_JC)] = make_double2(p1, p2);
+            if (i % ED8_JC == 0) qpref8[(size_t)(i / ED8_JC)] = make_double2(p1, p2);
             qcen[i] = q[i] - qd.q_mean;
             p1 += qcen[i];
             p2 += qcen[i] * qcen[i];
         }
         qpref[(size_t)nchunks4] = make_double2(p1, p2);
+        qpref8[(size_t)nchunks8] = make_double2(p1, p2);
     }
     // query block: q | (qu | ql for DTW) | pad || (qc | pad | q_pref for ED) || (zQ sorted | order: cNSM-ED exact pass)
     const size_t qmain = (size_t)m * 8 * (dtw ? 3 : 1) + KVM_SERIES_PAD * sizeof(double);
-    const size_t qdot = dtw ? 0 : ((size_t)m * 8 + KVM_SERIES_PAD * sizeof(double) + ((size_t)nchunks4 + 1) * 16);
+    const size_t qdot = dtw ? 0 : ((size_t)m * 8 + KVM_SERIES_PAD * sizeof(double) + ((size_t)nchunks4 + nchunks8 + 2) * 16);
     const size_t qexact_off = qmain + qdot;
     const size_t qbytes = qexact_off + ((cnsm && !dtw) ? (size_t)m * 12 : 0);
     const size_t rbytes = pl.runs.size() * sizeof(kvm_run);
-    const size_t tbytes = (size_t)pl.n_tiles * sizeof(kvm_tile);
+    const size_t tbytes = (size_t)(pl.n_tiles + pl.n_tiles_b) * sizeof(kvm_tile);
     rc = ensure_pinned(ctx, qbytes + rbytes + 64);
     if (rc) return rc;
     // (KVM_SERIES_PAD spare doubles after q: the tiled ED kernel stages whole query chunks without bounds checks)
@@ -495,6 +507,8 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
     if (!dtw) {
         std::memcpy(hp + qmain, qcen.data(), (size_t)m * 8);
         std::memcpy(hp + qmain + (size_t)m * 8 + KVM_SERIES_PAD * sizeof(double), qpref.data(), qpref.size() * 16);
+        std::memcpy(hp + qmain + (size_t)m * 8 + KVM_SERIES_PAD * sizeof(double) + qpref.size() * 16, qpref8.data(),
+                    qpref8.size() * 16);
     }
     const size_t qfirst = (cnsm && !dtw) ? qexact_off : qbytes;  // the exact-pass block is staged later (see below)
     if (dtw) {
@@ -507,8 +521,13 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
     if (rbytes) {
         // runs (16 B each) go up; the tile list (16 B per <= tile_max candidates) is expanded on the GPU
         HIPCHK(ctx, hipMemcpyAsync(ctx->b_aux2.p, hp + qbytes, rbytes, hipMemcpyHostToDevice, stream));
-        HIPCHK(ctx, kvm_launch_expand_tiles((const kvm_run *)ctx->b_aux2.p, (int64_t)pl.runs.size(), tile_max,
-                                            (kvm_tile *)ctx->b_tiles.p, stream));
+        if (hybrid)
+            HIPCHK(ctx, kvm_launch_expand_tiles_hybrid((const kvm_run *)ctx->b_aux2.p, (int64_t)pl.runs.size(),
+                                                       (kvm_tile *)ctx->b_tiles.p,
+                                                       (kvm_tile *)ctx->b_tiles.p + pl.n_tiles, stream));
+        else
+            HIPCHK(ctx, kvm_launch_expand_tiles((const kvm_run *)ctx->b_aux2.p, (int64_t)pl.runs.size(), tile_max,
+                                                (kvm_tile *)ctx->b_tiles.p, stream));
     }
     HIPCHK(ctx, hipMemsetAsync(ctx->b_counters.p, 0, KVM_CNT_TOTAL * sizeof(unsigned long long), stream));
     qd.q = (const double *)ctx->b_query.p;
@@ -516,6 +535,7 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
     qd.q_pref = dtw ? nullptr
                     : (const double2 *)((const char *)ctx->b_query.p + qmain + (size_t)m * 8 +
                                         KVM_SERIES_PAD * sizeof(double));
+    qd.q_pref8 = dtw ? nullptr : qd.q_pref + (nchunks4 + 1);
     qd.qu = dtw ? qd.q + m : nullptr;
     qd.ql = dtw ? qd.q + 2 * (size_t)m : nullptr;
     unsigned long long *counters = (unsigned long long *)ctx->b_counters.p;
@@ -539,7 +559,7 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
     if (kernel_ns) *kernel_ns = 0;
     ctx->last_kernel_ns = 0;
     KVM_TP("  H2D enqueue");
-    if (n_tiles == 0) return KVM_OK;
+    if (n_tiles + pl.n_tiles_b == 0) return KVM_OK;
 
     if (ctx->opt_timing) HIPCHK(ctx, hipEventRecord(ctx->ev0, stream));
     if (!dtw) {
@@ -547,8 +567,8 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
         if ((rc = ensure(ctx, ctx->b_cands, (size_t)pl.windows * sizeof(kvm_surv) + 64))) return rc;
         kvm_surv *surv = (kvm_surv *)ctx->b_cands.p;
         if (ed_kernel == 3)
-            HIPCHK(ctx, kvm_launch_ed_dot(ctx->d_series, ctx->d_prefix, ctx->n, qd, d_tiles, n_tiles, surv, pl.windows,
-                                          counters, stream));
+            HIPCHK(ctx, kvm_launch_ed_dot(ctx->d_series, ctx->d_prefix, ctx->n, qd, d_tiles, pl.n_tiles, d_tiles + pl.n_tiles,
+                                          pl.n_tiles_b, surv, pl.windows, counters, stream));
         else if (ed_kernel == 2)
             HIPCHK(ctx, kvm_launch_ed_tiled(ctx->d_series, ctx->d_prefix, ctx->n, qd, d_tiles, n_tiles, surv,
                                             pl.windows, counters, stream));
@@ -657,7 +677,7 @@ static int verify_host(kvm_ctx *ctx, int variant, const double *query, int32_t m
     const int64_t spec = std::min<int64_t>(KVM_SPEC_ANSWERS, worst);
     std::vector<int32_t> off((size_t)spec);
     std::vector<double> dist((size_t)spec);
-    if (pl.n_tiles > 0) {
+    if (pl.n_tiles + pl.n_tiles_b > 0) {
         HIPCHK(ctx, hipMemcpyAsync(hc, ctx->b_counters.p, sizeof hc, hipMemcpyDeviceToHost, ctx->stream));
         if (spec) {
             HIPCHK(ctx, hipMemcpyAsync(off.data(), out.d_off, (size_t)spec * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -746,7 +766,7 @@ extern "C" int kvm_verify_device(kvm_ctx *ctx, int32_t variant, const double *qu
     int rc = run_variant(ctx, variant, query, m, left, right, k, shift, epsilon, rho, alpha, beta, pl, out, s, nullptr);
     if (rc) return rc;
     if (cnt_candidate) *cnt_candidate = pl.cnt_candidate;
-    if (pl.n_tiles == 0) {
+    if (pl.n_tiles + pl.n_tiles_b == 0) {
         HIPCHK(ctx, hipMemsetAsync(d_out_count, 0, sizeof(int64_t), s));
     } else {
         HIPCHK(ctx, hipMemcpyAsync(d_out_count, (unsigned long long *)ctx->b_counters.p + KVM_CNT_ANSWERS,

@@ -26,6 +26,43 @@ hipError_t kvm_launch_bswap64(uint64_t *d, int64_t n, hipStream_t s) {
     return hipGetLastError();
 }
 
+// Hybrid ED tiling (kvm_ed_dot.hip): per run floor(count/64) full 64-candidate tiles; the remainder becomes one more
+// class-A tile if it exceeds 32 candidates, else one class-B tile (<= 32 candidates).
+__global__ __launch_bounds__(256) void kvm_expand_tiles_hybrid_kernel(const kvm_run *__restrict__ runs, int64_t n_runs,
+                                                                      kvm_tile *__restrict__ tilesA,
+                                                                      kvm_tile *__restrict__ tilesB) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n_runs) return;
+    const kvm_run run = runs[r];
+    const int full = run.count / 64, rem = run.count % 64;
+    const int nA = full + (rem > 32 ? 1 : 0);
+    for (int t = lane; t < nA; t += 64) {
+        kvm_tile tl;
+        tl.start = run.start + t * 64;
+        tl.count = min(64, run.count - t * 64);
+        tl.run_start = run.start;
+        tl.pad = 0;
+        tilesA[run.tile_base + t] = tl;
+    }
+    if (lane == 0 && rem > 0 && rem <= 32) {
+        kvm_tile tl;
+        tl.start = run.start + full * 64;
+        tl.count = rem;
+        tl.run_start = run.start;
+        tl.pad = 0;
+        tilesB[run.tile_base_b] = tl;
+    }
+}
+
+hipError_t kvm_launch_expand_tiles_hybrid(const kvm_run *runs, int64_t n_runs, kvm_tile *tilesA, kvm_tile *tilesB,
+                                          hipStream_t s) {
+    if (n_runs <= 0) return hipSuccess;
+    hipLaunchKernelGGL(kvm_expand_tiles_hybrid_kernel, dim3((unsigned)((n_runs + 3) / 4)), dim3(256), 0, s, runs, n_runs,
+                       tilesA, tilesB);
+    return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------------------------------
 // [count | first pack_cap (offset, distance) pairs] as fp64 pairs: the payload of the multi-GPU all-gather.
 __global__ __launch_bounds__(256) void kvm_pack_answers_kernel(const int32_t *__restrict__ off,

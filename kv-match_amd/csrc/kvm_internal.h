@@ -26,7 +26,8 @@
 struct kvm_run {
     int32_t start;      // first window start offset (1-based)
     int32_t count;      // number of consecutive offsets
-    int64_t tile_base;  // index of the run's first tile in the tile list
+    int64_t tile_base;  // index of the run's first tile in the tile list (class A list in hybrid mode)
+    int64_t tile_base_b;  // hybrid ED tiling only: index of the run's class-B tile (its <= 32-candidate remainder), or -1
     int64_t win_base;   // ordinal of the run's first window among all windows of the query (exclusive prefix of counts)
 };
 
@@ -102,6 +103,8 @@ struct kvm_result {
 // common
 hipError_t kvm_launch_bswap64(uint64_t *d, int64_t n, hipStream_t s);
 hipError_t kvm_launch_expand_tiles(const kvm_run *runs, int64_t n_runs, int32_t tile_max, kvm_tile *tiles, hipStream_t s);
+// hybrid ED tiling: class A = 64-candidate tiles (full tiles and remainders > 32), class B = remainders <= 32
+hipError_t kvm_launch_expand_tiles_hybrid(const kvm_run *runs, int64_t n_runs, kvm_tile *tilesA, kvm_tile *tilesB, hipStream_t s);
 hipError_t kvm_launch_prefix(const double *x, double2 *prefix, int64_t n, hipStream_t s);
 hipError_t kvm_launch_pack_answers(const int32_t *off, const double *dist, const int64_t *count, int64_t pack_cap,
                                    double2 *packed, hipStream_t s);
@@ -124,6 +127,7 @@ struct kvm_query_dev {
     double q_mean;          // mean of q
     const double *qc;       // q - q_mean, device, m entries (+ KVM_SERIES_PAD spare)
     const double2 *q_pref;  // q_pref[t] = { sum_{j < t*ED4_JC} (q_j - q_mean), sum_{j < t*ED4_JC} (q_j - q_mean)^2 }, t = 0..nchunks
+    const double2 *q_pref8; // the same at ED8_JC granularity
 };
 
 // ED pruners: survivors (decision quantity within the guard band of eps^2, filter within its guard band) are appended
@@ -134,10 +138,11 @@ hipError_t kvm_launch_ed_wave(const double *series, const double2 *prefix, int64
 hipError_t kvm_launch_ed_tiled(const double *series, const double2 *prefix, int64_t n, const kvm_query_dev &qd,
                                const kvm_tile *tiles, int64_t n_tiles, kvm_surv *surv, int64_t cap,
                                unsigned long long *counters, hipStream_t s);
-#define ED4_JC 160  // chunk length of the correlation-form pruner (also the granularity of kvm_query_dev::q_pref)
+#define ED4_JC 160  // chunk lengths of the correlation-form pruner (also the granularity of kvm_query_dev::q_pref / q_pref8):
+#define ED8_JC 128  // 4 candidates per lane / 8 candidates per lane
 hipError_t kvm_launch_ed_dot(const double *series, const double2 *prefix, int64_t n, const kvm_query_dev &qd,
-                             const kvm_tile *tiles, int64_t n_tiles, kvm_surv *surv, int64_t cap,
-                             unsigned long long *counters, hipStream_t s);
+                             const kvm_tile *tilesA, int64_t nA, const kvm_tile *tilesB, int64_t nB, kvm_surv *surv,
+                             int64_t cap, unsigned long long *counters, hipStream_t s);
 // Exact final pass (kvm_exact.hip)
 hipError_t kvm_launch_exact_ed(const double *series, const kvm_query_dev &qd, const double *q_exact,
                                const int32_t *order, const kvm_surv *surv, const unsigned long long *d_n_surv,
