@@ -11,6 +11,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <numeric>
@@ -132,7 +133,7 @@ extern "C" int kvm_set_option(kvm_ctx *ctx, int32_t option, int64_t value) {
         case KVM_OPT_EARLY_ABANDON: ctx->opt_early_abandon = value ? 1 : 0; return KVM_OK;
         case KVM_OPT_LB_CASCADE: ctx->opt_lb_cascade = value ? 1 : 0; return KVM_OK;
         case KVM_OPT_ED_KERNEL:
-            if (value < 0 || value > 3) return fail(ctx, KVM_ERR_ILLEGAL_ARGUMENT, "KVM_OPT_ED_KERNEL in {0,1,2,3}");
+            if (value < 0 || value > 4) return fail(ctx, KVM_ERR_ILLEGAL_ARGUMENT, "KVM_OPT_ED_KERNEL in {0,1,2,3,4}");
             ctx->opt_ed_kernel = value;
             return KVM_OK;
         case KVM_OPT_TIMING: ctx->opt_timing = value ? 1 : 0; return KVM_OK;
@@ -432,11 +433,18 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
         HIPCHK(ctx, hipEventSynchronize(ctx->ev_staged));
         ctx->staged_pending = false;
     }
-    // ED pruning kernel: 1 = wave-per-candidate, 2 = LDS-tiled direct form, 3 (and auto) = LDS-tiled correlation form
-    const int ed_kernel = ctx->opt_ed_kernel == 0 ? 3 : (int)ctx->opt_ed_kernel;
+    // ED pruning kernel: 1 = wave-per-candidate, 2 = LDS-tiled direct form, 3 = LDS-tiled correlation form,
+    // 4 = correlation form with the lanes along the window; 0 = auto (KVM_ED_KERNEL in the environment overrides auto)
+    static const int env_ed_kernel = [] {
+        const char *e = getenv("KVM_ED_KERNEL");
+        const int v = e ? atoi(e) : 0;
+        return (v >= 1 && v <= 4) ? v : 0;
+    }();
+    const int ed_kernel = ctx->opt_ed_kernel != 0 ? (int)ctx->opt_ed_kernel : (env_ed_kernel ? env_ed_kernel : 3);
     auto tp_ = std::chrono::steady_clock::now();
     // 32-candidate tiles for the LDS-tiled kernels (ED pruners, fused DTW lower-bound stage), 64 otherwise
-    const int32_t tile_max = ((!dtw && ed_kernel >= 2) || (dtw && ctx->opt_lb_cascade)) ? KVM_TILE_TILED : KVM_TILE_MAX;
+    const int32_t tile_max = (!dtw && ed_kernel == 4) ? 16
+                             : ((!dtw && ed_kernel >= 2) || (dtw && ctx->opt_lb_cascade)) ? KVM_TILE_TILED : KVM_TILE_MAX;
     const bool hybrid = !dtw && ed_kernel == 3;
     int rc = build_plan(ctx, cnsm, m, left, right, k, shift, tile_max, hybrid, pl);
     if (rc) return rc;
@@ -468,6 +476,7 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
     // correlation-form ED pruner: centred query and its chunk-granular prefix sums
     std::vector<double> qcen;
     std::vector<double2> qpref, qpref8;
+    const int nchT = (m + JL_CHUNK - 1) / JL_CHUNK;  // lane-transposed copy for kvm_ed_jl.hip
     const int nchunks4 = (m + ED4_JC - 1) / ED4_JC, nchunks8 = (m + ED8_JC - 1) / ED8_JC;
     if (!dtw) {
         double sum = 0;
@@ -489,7 +498,8 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
     }
     // query block: q | (qu | ql for DTW) | pad || (qc | pad | q_pref for ED) || (zQ sorted | order: cNSM-ED exact pass)
     const size_t qmain = (size_t)m * 8 * (dtw ? 3 : 1) + KVM_SERIES_PAD * sizeof(double);
-    const size_t qdot = dtw ? 0 : ((size_t)m * 8 + KVM_SERIES_PAD * sizeof(double) + ((size_t)nchunks4 + nchunks8 + 2) * 16);
+    const size_t qdot0 = dtw ? 0 : ((size_t)m * 8 + KVM_SERIES_PAD * sizeof(double) + ((size_t)nchunks4 + nchunks8 + 2) * 16);
+    const size_t qdot = dtw ? 0 : qdot0 + (size_t)nchT * JL_CHUNK * 8;
     const size_t qexact_off = qmain + qdot;
     const size_t qbytes = qexact_off + ((cnsm && !dtw) ? (size_t)m * 12 : 0);
     const size_t rbytes = pl.runs.size() * sizeof(kvm_run);
@@ -509,6 +519,12 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
         std::memcpy(hp + qmain + (size_t)m * 8 + KVM_SERIES_PAD * sizeof(double), qpref.data(), qpref.size() * 16);
         std::memcpy(hp + qmain + (size_t)m * 8 + KVM_SERIES_PAD * sizeof(double) + qpref.size() * 16, qpref8.data(),
                     qpref8.size() * 16);
+        // qT[chunk][i][lane] = the pair (qc[chunk*1024 + 16*lane + 2i], qc[... + 2i + 1]); zero past m (memset above)
+        double *qT = (double *)(hp + qmain + qdot0);
+        for (int i = 0; i < m; i++) {
+            const int ch = i / JL_CHUNK, r = i % JL_CHUNK, ln = r / 16, pi = (r % 16) / 2;
+            qT[(size_t)ch * JL_CHUNK + ((size_t)pi * 64 + ln) * 2 + (r & 1)] = qcen[i];
+        }
     }
     const size_t qfirst = (cnsm && !dtw) ? qexact_off : qbytes;  // the exact-pass block is staged later (see below)
     if (dtw) {
@@ -536,6 +552,7 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
                     : (const double2 *)((const char *)ctx->b_query.p + qmain + (size_t)m * 8 +
                                         KVM_SERIES_PAD * sizeof(double));
     qd.q_pref8 = dtw ? nullptr : qd.q_pref + (nchunks4 + 1);
+    qd.qT = dtw ? nullptr : (const double *)((const char *)ctx->b_query.p + qmain + qdot0);
     qd.qu = dtw ? qd.q + m : nullptr;
     qd.ql = dtw ? qd.q + 2 * (size_t)m : nullptr;
     unsigned long long *counters = (unsigned long long *)ctx->b_counters.p;
@@ -566,7 +583,10 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
         // pruning pass (fast kernels, guard band) -> survivors -> exact pass in the reference's operation order
         if ((rc = ensure(ctx, ctx->b_cands, (size_t)pl.windows * sizeof(kvm_surv) + 64))) return rc;
         kvm_surv *surv = (kvm_surv *)ctx->b_cands.p;
-        if (ed_kernel == 3)
+        if (ed_kernel == 4)
+            HIPCHK(ctx, kvm_launch_ed_jl(ctx->d_series, ctx->d_prefix, ctx->n, qd, d_tiles, n_tiles, surv, pl.windows,
+                                         counters, ctx->num_cu, stream));
+        else if (ed_kernel == 3)
             HIPCHK(ctx, kvm_launch_ed_dot(ctx->d_series, ctx->d_prefix, ctx->n, qd, d_tiles, pl.n_tiles, d_tiles + pl.n_tiles,
                                           pl.n_tiles_b, surv, pl.windows, counters, stream));
         else if (ed_kernel == 2)

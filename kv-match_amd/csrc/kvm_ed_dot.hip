@@ -35,7 +35,7 @@ typedef double ed4_d2 __attribute__((ext_vector_type(2)));
 #define EDD_WAVE_LDS (EDD_ROWS * EDD_RS + EDD_ROWLEN)
 static_assert(ED4_JC + 8 * 4 <= EDD_ROWLEN && ED8_JC + 8 * 8 <= EDD_ROWLEN, "chunk + tile must fit the staged row");
 static_assert(4 * EDD_WAVE_LDS * 8 <= 65536 && EDD_WAVE_LDS % 2 == 0 && EDD_RS % 2 == 0 && (EDD_RS * 8) % 256 == 0, "LDS");
-static_assert(ED4_JC % 8 == 0 && ED8_JC % 8 == 0, "chunks are whole groups of 8 points");
+static_assert(ED4_JC % 16 == 0 && ED8_JC % 16 == 0, "chunks are whole groups of 16 points (4 sub-steps of the register ring)");
 
 template <int CI>
 struct edd_cfg {
@@ -194,32 +194,49 @@ __device__ __forceinline__ void edd_body(const edd_args &A, const kvm_tile *__re
         if (more) load_chunk(j0 + JC);
         const int jlim = min(JC, m - j0);
         if (jlim == JC) {
-            // window registers: W[i] = (X[c0+j+2i], X[c0+j+2i+1]), i < CI/2; two new pairs per 4 points
-            ed4_d2 W[CI / 2];
+            // Window registers: a ring of 8 pairs, R[p % 8] = (X[c0 + 2p], X[c0 + 2p + 1]).  Sub-step G (4 points) reads
+            // pairs 2G .. 2G + CI/2 + 1 and, before its arithmetic, issues the LDS reads of the two pairs and the two
+            // query pairs that sub-step G + 1 adds -- into the ring slots that died one sub-step earlier.  Four
+            // sub-steps advance the ring by exactly 8 pairs, so every register index below is a compile-time constant
+            // (no rotation moves), and every LDS read has a sub-step of FMAs (32 / 16 of them) to land.
+            constexpr int NP = CI / 2 + 2;
+            ed4_d2 R[8], QA[2], QB[2];
 #pragma unroll
-            for (int i = 0; i < CI / 2; i++) W[i] = X2[i];
-#pragma unroll 2
-            for (int g = 0; g < JC / 4; g++) {  // 4 points per iteration
-                const ed4_d2 n0 = X2[2 * g + CI / 2], n1 = X2[2 * g + CI / 2 + 1];
-                const ed4_d2 q0 = Q2[2 * g], q1 = Q2[2 * g + 1];
-                // flattened view of the CI + 4 window values involved: w[k] = X[c0 + 4g + k]
-#define EDD_WI(k) ((k) / 2 < CI / 2 ? (k) / 2 : 0) /* in-range index also in the untaken arm */
-#define EDD_W(k) ((k) < CI ? (((k) & 1) ? W[EDD_WI(k)].y : W[EDD_WI(k)].x)                               \
-                           : ((k) < CI + 2 ? (((k) & 1) ? n0.y : n0.x) : (((k) & 1) ? n1.y : n1.x)))
+            for (int j = 0; j < NP; j++) R[j] = X2[j];
+            QA[0] = Q2[0];
+            QA[1] = Q2[1];
+            for (int body = 0; body < JC / 16; body++) {
 #pragma unroll
-                for (int a = 0; a < CI; a++) acc[a] = __builtin_fma(EDD_W(a), q0.x, acc[a]);
+                for (int g = 0; g < 4; g++) {
+                    const int G = body * 4 + g;
+                    R[(2 * g + NP) % 8] = X2[2 * G + NP];  // (the last sub-step of a chunk reads past it: staged, unused)
+                    R[(2 * g + NP + 1) % 8] = X2[2 * G + NP + 1];
+                    if (g & 1) {
+                        QA[0] = Q2[2 * G + 2];
+                        QA[1] = Q2[2 * G + 3];
+                    } else {
+                        QB[0] = Q2[2 * G + 2];
+                        QB[1] = Q2[2 * G + 3];
+                    }
+                    // fence: the reads above stay above it (memory clobber), the FMAs below it (accumulator operands)
+                    if constexpr (CI == 8)
+                        asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]),
+                                     "+v"(acc[6]), "+v"(acc[7])::"memory");
+                    else
+                        asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3])::"memory");
+                    const ed4_d2 q0 = (g & 1) ? QB[0] : QA[0], q1 = (g & 1) ? QB[1] : QA[1];
+                    // w[k] = X[c0 + 4G + k], k < CI + 4
+#define EDD_W(k) (((k) & 1) ? R[(2 * g + (k) / 2) % 8].y : R[(2 * g + (k) / 2) % 8].x)
 #pragma unroll
-                for (int a = 0; a < CI; a++) acc[a] = __builtin_fma(EDD_W(a + 1), q0.y, acc[a]);
+                    for (int a = 0; a < CI; a++) acc[a] = __builtin_fma(EDD_W(a), q0.x, acc[a]);
 #pragma unroll
-                for (int a = 0; a < CI; a++) acc[a] = __builtin_fma(EDD_W(a + 2), q1.x, acc[a]);
+                    for (int a = 0; a < CI; a++) acc[a] = __builtin_fma(EDD_W(a + 1), q0.y, acc[a]);
 #pragma unroll
-                for (int a = 0; a < CI; a++) acc[a] = __builtin_fma(EDD_W(a + 3), q1.y, acc[a]);
+                    for (int a = 0; a < CI; a++) acc[a] = __builtin_fma(EDD_W(a + 2), q1.x, acc[a]);
+#pragma unroll
+                    for (int a = 0; a < CI; a++) acc[a] = __builtin_fma(EDD_W(a + 3), q1.y, acc[a]);
 #undef EDD_W
-#undef EDD_WI
-#pragma unroll
-                for (int i = 0; i + 2 < CI / 2; i++) W[i] = W[i + 2];
-                W[CI / 2 - 2] = n0;
-                W[CI / 2 - 1] = n1;
+                }
             }
         } else {
             const double *X = reinterpret_cast<const double *>(X2);

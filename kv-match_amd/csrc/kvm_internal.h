@@ -20,7 +20,7 @@
 #define KVM_PS_BLOCK_LOG2 14
 #define KVM_PS_BLOCK (1 << KVM_PS_BLOCK_LOG2)
 // The staged series is padded with this many zero points so that tile staging may read past n unguarded.
-#define KVM_SERIES_PAD 1024
+#define KVM_SERIES_PAD 2048
 
 // One candidate run = a clipped interval of consecutive window start offsets (1-based).
 struct kvm_run {
@@ -128,6 +128,7 @@ struct kvm_query_dev {
     const double *qc;       // q - q_mean, device, m entries (+ KVM_SERIES_PAD spare)
     const double2 *q_pref;  // q_pref[t] = { sum_{j < t*ED4_JC} (q_j - q_mean), sum_{j < t*ED4_JC} (q_j - q_mean)^2 }, t = 0..nchunks
     const double2 *q_pref8; // the same at ED8_JC granularity
+    const double *qT;       // qc zero-padded to whole JL_CHUNKs, lane-transposed for kvm_ed_jl.hip (see there)
 };
 
 // ED pruners: survivors (decision quantity within the guard band of eps^2, filter within its guard band) are appended
@@ -138,6 +139,10 @@ hipError_t kvm_launch_ed_wave(const double *series, const double2 *prefix, int64
 hipError_t kvm_launch_ed_tiled(const double *series, const double2 *prefix, int64_t n, const kvm_query_dev &qd,
                                const kvm_tile *tiles, int64_t n_tiles, kvm_surv *surv, int64_t cap,
                                unsigned long long *counters, hipStream_t s);
+#define JL_CHUNK 1024  // window points per chunk of the lanes-along-the-window ED pruner
+hipError_t kvm_launch_ed_jl(const double *series, const double2 *prefix, int64_t n, const kvm_query_dev &qd,
+                            const kvm_tile *tiles, int64_t n_tiles, kvm_surv *surv, int64_t cap,
+                            unsigned long long *counters, int num_cu, hipStream_t s);
 #define ED4_JC 160  // chunk lengths of the correlation-form pruner (also the granularity of kvm_query_dev::q_pref / q_pref8):
 #define ED8_JC 128  // 4 candidates per lane / 8 candidates per lane
 hipError_t kvm_launch_ed_dot(const double *series, const double2 *prefix, int64_t n, const kvm_query_dev &qd,

@@ -11,6 +11,7 @@ series = datagen.gen_series(n)
 q = series[n // 3:n // 3 + m].copy()
 ctx = kvmatch.Phase2Context(0); ctx.load_series(series); ctx.set_option(kvmatch.OPT_TIMING, 1)
 ctx.set_option(kvmatch.OPT_EARLY_ABANDON, 0)
+ctx.set_option(kvmatch.OPT_ED_KERNEL, int(os.environ.get('EDK', '0')))
 eng = kvmatch.QueryEngine(ctx)
 def run(length, count, label=""):
     stride = (n - m - length) // count
