@@ -166,16 +166,23 @@ __device__ __forceinline__ void edd_body(const edd_args &A, const kvm_tile *__re
         for (int r = 0; r < EDD_ROWS; r++) {
             const double *src = series + ((int64_t)rstart[r] - 1 + j0);  // unguarded: series is padded (KVM_SERIES_PAD)
 #pragma unroll
-            for (int t = 0; t < EDD_LOADS; t++) stage[r][t] = src[t * 64 + lane] - rshift[r];
+            for (int t = 0; t < EDD_LOADS; t++) stage[r][t] = src[t * 64 + lane];  // raw: shifted when stored
         }
 #pragma unroll
         for (int t = 0; t < EDD_LOADS; t++) stage[EDD_ROWS][t] = qc[j0 + t * 64 + lane];
     };
     auto store_chunk = [&]() {
+        // The subtraction of the row shift is the first use of the prefetched values.  Its operands pass through an
+        // empty asm placed after the chunk's arithmetic, so the compiler cannot hoist the subtractions (and with them
+        // the wait for the loads) above the FMA block that is there to cover the load latency.
+        double sh[EDD_ROWS];
+#pragma unroll
+        for (int r = 0; r < EDD_ROWS; r++) sh[r] = rshift[r];
+        asm volatile("" : "+v"(sh[0]), "+v"(sh[1]), "+v"(sh[2]), "+v"(sh[3]), "+v"(sh[4]), "+v"(sh[5]), "+v"(sh[6]), "+v"(sh[7])::"memory");
 #pragma unroll
         for (int r = 0; r < EDD_ROWS; r++) {
 #pragma unroll
-            for (int t = 0; t < EDD_LOADS; t++) wlds[r * EDD_RS + cfg::row_shift(r) + t * 64 + lane] = stage[r][t];
+            for (int t = 0; t < EDD_LOADS; t++) wlds[r * EDD_RS + cfg::row_shift(r) + t * 64 + lane] = stage[r][t] - sh[r];
         }
 #pragma unroll
         for (int t = 0; t < EDD_LOADS; t++) qlds[t * 64 + lane] = stage[EDD_ROWS][t];
