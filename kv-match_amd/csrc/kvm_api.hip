@@ -119,6 +119,7 @@ extern "C" int kvm_close(kvm_ctx *ctx) {
     for (kvm_dev_buf *b : bufs)
         if (b->p) hipFree(b->p);
     if (ctx->h_pinned) hipHostFree(ctx->h_pinned);
+    if (ctx->h_readback) hipHostFree(ctx->h_readback);
     hipEventDestroy(ctx->ev0);
     hipEventDestroy(ctx->ev1);
     hipEventDestroy(ctx->ev_staged);
@@ -284,7 +285,8 @@ static bool kvm_trace_on() {
 // ---- plan: intervals -> runs -> tiles -------------------------------------------------------------------
 
 struct plan {
-    std::vector<kvm_run> runs;  // clipped runs with the index of their first tile; expanded to tiles on the GPU
+    kvm_run *runs = nullptr;    // clipped runs with the index of their first tile (written straight into the pinned
+    int64_t n_runs = 0;         // staging buffer by build_plan); expanded to tiles on the GPU
     int64_t n_tiles = 0;        // tiles (class A tiles in hybrid mode)
     int64_t n_tiles_b = 0;      // hybrid mode: class B tiles
     int64_t cnt_candidate = 0;  // sum(right-left+1) before clipping, K/QueryEngine.java:344
@@ -341,30 +343,44 @@ static int build_plan(kvm_ctx *ctx, bool cnsm, int32_t m, const int32_t *left, c
             }
         }
     }
-    pl.runs.clear();
-    pl.runs.reserve((size_t)k);
+    pl.n_runs = 0;
+    kvm_run *out_runs = pl.runs;  // capacity k, provided by the caller
+    int64_t nr = 0;
+    // branch-free (the tile-class tests on random run lengths mispredict every other time): ~3 ns per interval
+    const int64_t hi_max = n - m + 1;
+    const uint32_t tmax = (uint32_t)tile_max;
+    int64_t cnt_candidate = 0, n_tiles = 0, n_tiles_b = 0, windows = 0;
     for (int32_t p = 0; p < k; p++) {
-        pl.cnt_candidate += (int64_t)right[p] - left[p] + 1;
-        int64_t lo = (int64_t)left[p] - shift, hi = (int64_t)right[p] - shift;
-        if (lo < 1) lo = 1;
-        if (hi > n - m + 1) hi = n - m + 1;
-        if (hi < lo) continue;
-        kvm_run r;
+        const int64_t l = left[p], r_ = right[p];
+        cnt_candidate += r_ - l + 1;
+        int64_t lo = l - shift, hi = r_ - shift;
+        lo = lo < 1 ? 1 : lo;
+        hi = hi > hi_max ? hi_max : hi;
+        const int64_t c64 = hi - lo + 1;
+        const bool ok = c64 > 0;
+        const uint32_t c = ok ? (uint32_t)c64 : 0u;
+        kvm_run &r = out_runs[nr];  // (slot nr is rewritten by the next interval if this one is empty)
         r.start = (int32_t)lo;  // the reference restarts ex/ex2 here (K/NormQueryEngine.java:487-491)
-        r.count = (int32_t)(hi - lo + 1);
-        r.tile_base = pl.n_tiles;
-        r.tile_base_b = -1;
-        r.win_base = pl.windows;
+        r.count = (int32_t)c;
+        r.tile_base = n_tiles;
+        r.win_base = windows;
         if (hybrid) {  // correlation-form ED pruner: 64-candidate tiles + <= 32-candidate remainders (kvm_ed_dot.hip)
-            const int32_t rem = r.count % 64;
-            pl.n_tiles += r.count / 64 + (rem > 32 ? 1 : 0);
-            if (rem > 0 && rem <= 32) r.tile_base_b = pl.n_tiles_b++;
+            const uint32_t rem = c & 63u, isA = rem > 32u, isB = (rem - 1u) < 32u;
+            r.tile_base_b = isB ? n_tiles_b : -1;
+            n_tiles += (c >> 6) + isA;
+            n_tiles_b += isB;
         } else {
-            pl.n_tiles += (r.count + tile_max - 1) / tile_max;
+            r.tile_base_b = -1;
+            n_tiles += (c + tmax - 1) / tmax;
         }
-        pl.runs.push_back(r);
-        pl.windows += r.count;
+        windows += c;
+        nr += ok;
     }
+    pl.cnt_candidate += cnt_candidate;
+    pl.n_tiles += n_tiles;
+    pl.n_tiles_b += n_tiles_b;
+    pl.windows += windows;
+    pl.n_runs = nr;
     return KVM_OK;
 }
 
@@ -446,7 +462,21 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
     const int32_t tile_max = (!dtw && ed_kernel == 4) ? 16
                              : ((!dtw && ed_kernel >= 2) || (dtw && ctx->opt_lb_cascade)) ? KVM_TILE_TILED : KVM_TILE_MAX;
     const bool hybrid = !dtw && ed_kernel == 3;
-    int rc = build_plan(ctx, cnsm, m, left, right, k, shift, tile_max, hybrid, pl);
+    // query block: q | (qu | ql for DTW) | pad || (qc | pad | q_pref | q_pref8 | qT for ED) || (zQ sorted | order: cNSM-ED
+    // exact pass); the runs follow it in the pinned staging buffer, where build_plan writes them directly
+    const int nchunks4 = (m + ED4_JC - 1) / ED4_JC, nchunks8 = (m + ED8_JC - 1) / ED8_JC;
+    const int nchT = (m + JL_CHUNK - 1) / JL_CHUNK;  // lane-transposed copy for kvm_ed_jl.hip
+    const size_t qmain = (size_t)m * 8 * (dtw ? 3 : 1) + KVM_SERIES_PAD * sizeof(double);
+    const size_t qdot0 = dtw ? 0 : ((size_t)m * 8 + KVM_SERIES_PAD * sizeof(double) + ((size_t)nchunks4 + nchunks8 + 2) * 16);
+    const bool use_qT = !dtw && ed_kernel == 4;
+    const size_t qdot = dtw ? 0 : qdot0 + (use_qT ? (size_t)nchT * JL_CHUNK * 8 : 0);
+    const size_t qexact_off = qmain + qdot;
+    const size_t qbytes = (qexact_off + ((cnsm && !dtw) ? (size_t)m * 12 : 0) + 15) / 16 * 16;
+    int rc = ensure_pinned(ctx, qbytes + (size_t)(k > 0 ? k : 0) * sizeof(kvm_run) + 64);
+    if (rc) return rc;
+    char *hp = (char *)ctx->h_pinned;
+    pl.runs = (kvm_run *)(hp + qbytes);
+    rc = build_plan(ctx, cnsm, m, left, right, k, shift, tile_max, hybrid, pl);
     if (rc) return rc;
     KVM_TP("  build_plan");
 
@@ -476,8 +506,6 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
     // correlation-form ED pruner: centred query and its chunk-granular prefix sums
     std::vector<double> qcen;
     std::vector<double2> qpref, qpref8;
-    const int nchT = (m + JL_CHUNK - 1) / JL_CHUNK;  // lane-transposed copy for kvm_ed_jl.hip
-    const int nchunks4 = (m + ED4_JC - 1) / ED4_JC, nchunks8 = (m + ED8_JC - 1) / ED8_JC;
     if (!dtw) {
         double sum = 0;
         for (int i = 0; i < m; i++) sum += q[i];
@@ -496,34 +524,29 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
         qpref[(size_t)nchunks4] = make_double2(p1, p2);
         qpref8[(size_t)nchunks8] = make_double2(p1, p2);
     }
-    // query block: q | (qu | ql for DTW) | pad || (qc | pad | q_pref for ED) || (zQ sorted | order: cNSM-ED exact pass)
-    const size_t qmain = (size_t)m * 8 * (dtw ? 3 : 1) + KVM_SERIES_PAD * sizeof(double);
-    const size_t qdot0 = dtw ? 0 : ((size_t)m * 8 + KVM_SERIES_PAD * sizeof(double) + ((size_t)nchunks4 + nchunks8 + 2) * 16);
-    const size_t qdot = dtw ? 0 : qdot0 + (size_t)nchT * JL_CHUNK * 8;
-    const size_t qexact_off = qmain + qdot;
-    const size_t qbytes = qexact_off + ((cnsm && !dtw) ? (size_t)m * 12 : 0);
-    const size_t rbytes = pl.runs.size() * sizeof(kvm_run);
+    const size_t rbytes = (size_t)pl.n_runs * sizeof(kvm_run);
     const size_t tbytes = (size_t)(pl.n_tiles + pl.n_tiles_b) * sizeof(kvm_tile);
-    rc = ensure_pinned(ctx, qbytes + rbytes + 64);
-    if (rc) return rc;
     // (KVM_SERIES_PAD spare doubles after q: the tiled ED kernel stages whole query chunks without bounds checks)
-    if ((rc = ensure(ctx, ctx->b_query, qbytes + 64))) return rc;
+    if ((rc = ensure(ctx, ctx->b_query, qbytes + rbytes + 64))) return rc;
     if ((rc = ensure(ctx, ctx->b_tiles, tbytes + 64))) return rc;
-    if ((rc = ensure(ctx, ctx->b_aux2, rbytes + 64))) return rc;
     if ((rc = ensure(ctx, ctx->b_counters, KVM_CNT_TOTAL * sizeof(unsigned long long)))) return rc;
-    char *hp = (char *)ctx->h_pinned;
-    std::memset(hp, 0, qexact_off);
+    // zero pads: after q (| qu | ql), after qc, and the tail of qT
+    std::memset(hp + (size_t)m * 8 * (dtw ? 3 : 1), 0, KVM_SERIES_PAD * sizeof(double));
+    if (!dtw) std::memset(hp + qmain + (size_t)m * 8, 0, KVM_SERIES_PAD * sizeof(double));
     std::memcpy(hp, q.data(), (size_t)m * 8);
     if (!dtw) {
         std::memcpy(hp + qmain, qcen.data(), (size_t)m * 8);
         std::memcpy(hp + qmain + (size_t)m * 8 + KVM_SERIES_PAD * sizeof(double), qpref.data(), qpref.size() * 16);
         std::memcpy(hp + qmain + (size_t)m * 8 + KVM_SERIES_PAD * sizeof(double) + qpref.size() * 16, qpref8.data(),
                     qpref8.size() * 16);
-        // qT[chunk][i][lane] = the pair (qc[chunk*1024 + 16*lane + 2i], qc[... + 2i + 1]); zero past m (memset above)
-        double *qT = (double *)(hp + qmain + qdot0);
-        for (int i = 0; i < m; i++) {
-            const int ch = i / JL_CHUNK, r = i % JL_CHUNK, ln = r / 16, pi = (r % 16) / 2;
-            qT[(size_t)ch * JL_CHUNK + ((size_t)pi * 64 + ln) * 2 + (r & 1)] = qcen[i];
+        if (use_qT) {
+            // qT[chunk][i][lane] = the pair (qc[chunk*1024 + 16*lane + 2i], qc[... + 2i + 1]); zero past m
+            double *qT = (double *)(hp + qmain + qdot0);
+            std::memset(qT + (size_t)(nchT - 1) * JL_CHUNK, 0, JL_CHUNK * sizeof(double));
+            for (int i = 0; i < m; i++) {
+                const int ch = i / JL_CHUNK, r = i % JL_CHUNK, ln = r / 16, pi = (r % 16) / 2;
+                qT[(size_t)ch * JL_CHUNK + ((size_t)pi * 64 + ln) * 2 + (r & 1)] = qcen[i];
+            }
         }
     }
     const size_t qfirst = (cnsm && !dtw) ? qexact_off : qbytes;  // the exact-pass block is staged later (see below)
@@ -531,28 +554,31 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
         std::memcpy(hp + (size_t)m * 8, qu.data(), (size_t)m * 8);
         std::memcpy(hp + (size_t)m * 16, ql.data(), (size_t)m * 8);
     }
-    if (rbytes) std::memcpy(hp + qbytes, pl.runs.data(), rbytes);
     KVM_TP("  query prep + staging");
-    HIPCHK(ctx, hipMemcpyAsync(ctx->b_query.p, hp, qfirst, hipMemcpyHostToDevice, stream));
+    // one H2D copy: the query block and, right behind it, the runs (32 B each; the tile list -- 16 B per tile -- is
+    // expanded from them on the GPU, by the kernel that also zeroes the counters)
+    // (for cNSM-ED the span covers the exact-pass block, which is filled in and copied again further down, in stream
+    // order, before its only reader -- the exact pass -- is launched)
+    HIPCHK(ctx, hipMemcpyAsync(ctx->b_query.p, hp, rbytes ? qbytes + rbytes : qfirst, hipMemcpyHostToDevice, stream));
+    const kvm_run *d_runs = (const kvm_run *)((const char *)ctx->b_query.p + qbytes);
     if (rbytes) {
-        // runs (16 B each) go up; the tile list (16 B per <= tile_max candidates) is expanded on the GPU
-        HIPCHK(ctx, hipMemcpyAsync(ctx->b_aux2.p, hp + qbytes, rbytes, hipMemcpyHostToDevice, stream));
         if (hybrid)
-            HIPCHK(ctx, kvm_launch_expand_tiles_hybrid((const kvm_run *)ctx->b_aux2.p, (int64_t)pl.runs.size(),
-                                                       (kvm_tile *)ctx->b_tiles.p,
-                                                       (kvm_tile *)ctx->b_tiles.p + pl.n_tiles, stream));
+            HIPCHK(ctx, kvm_launch_expand_tiles_hybrid(d_runs, pl.n_runs, (kvm_tile *)ctx->b_tiles.p,
+                                                       (kvm_tile *)ctx->b_tiles.p + pl.n_tiles,
+                                                       (unsigned long long *)ctx->b_counters.p, stream));
         else
-            HIPCHK(ctx, kvm_launch_expand_tiles((const kvm_run *)ctx->b_aux2.p, (int64_t)pl.runs.size(), tile_max,
-                                                (kvm_tile *)ctx->b_tiles.p, stream));
+            HIPCHK(ctx, kvm_launch_expand_tiles(d_runs, pl.n_runs, tile_max, (kvm_tile *)ctx->b_tiles.p,
+                                                (unsigned long long *)ctx->b_counters.p, stream));
+    } else {
+        HIPCHK(ctx, hipMemsetAsync(ctx->b_counters.p, 0, KVM_CNT_TOTAL * sizeof(unsigned long long), stream));
     }
-    HIPCHK(ctx, hipMemsetAsync(ctx->b_counters.p, 0, KVM_CNT_TOTAL * sizeof(unsigned long long), stream));
     qd.q = (const double *)ctx->b_query.p;
     qd.qc = dtw ? nullptr : (const double *)((const char *)ctx->b_query.p + qmain);
     qd.q_pref = dtw ? nullptr
                     : (const double2 *)((const char *)ctx->b_query.p + qmain + (size_t)m * 8 +
                                         KVM_SERIES_PAD * sizeof(double));
     qd.q_pref8 = dtw ? nullptr : qd.q_pref + (nchunks4 + 1);
-    qd.qT = dtw ? nullptr : (const double *)((const char *)ctx->b_query.p + qmain + qdot0);
+    qd.qT = use_qT ? (const double *)((const char *)ctx->b_query.p + qmain + qdot0) : nullptr;
     qd.qu = dtw ? qd.q + m : nullptr;
     qd.ql = dtw ? qd.q + 2 * (size_t)m : nullptr;
     unsigned long long *counters = (unsigned long long *)ctx->b_counters.p;
@@ -564,10 +590,10 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
     std::memset(&rws, 0, sizeof rws);
     if (cnsm && pl.windows > 0) {
         const size_t sbytes = (size_t)pl.windows * sizeof(double2);
-        const size_t nbytes = ((size_t)pl.windows + 15) / 16 * 16, mbytes = pl.runs.size() * sizeof(int32_t);
+        const size_t nbytes = ((size_t)pl.windows + 15) / 16 * 16, mbytes = (size_t)pl.n_runs * sizeof(int32_t);
         if ((rc = ensure(ctx, ctx->b_scratch, sbytes + nbytes + mbytes + 64))) return rc;
-        rws.runs = (const kvm_run *)ctx->b_aux2.p;
-        rws.n_runs = (int64_t)pl.runs.size();
+        rws.runs = d_runs;
+        rws.n_runs = pl.n_runs;
         rws.stats = (double2 *)ctx->b_scratch.p;
         rws.need = (unsigned char *)ctx->b_scratch.p + sbytes;
         rws.run_maxk = (int32_t *)((char *)ctx->b_scratch.p + sbytes + nbytes);
@@ -692,18 +718,23 @@ static int verify_host(kvm_ctx *ctx, int variant, const double *query, int32_t m
     KVM_TP("run_variant (launch)");
     // One synchronisation in the common case: the counters and the first KVM_SPEC_ANSWERS answers are copied back
     // together (answers are rare); a second copy only when there are more.
-    constexpr int64_t KVM_SPEC_ANSWERS = 1024;
+    static_assert(KVM_CNT_TOTAL <= 256 && (KVM_SPEC_ANSWERS % 2) == 0, "readback kernel layout");
     unsigned long long hc[KVM_CNT_TOTAL] = {0};
     const int64_t spec = std::min<int64_t>(KVM_SPEC_ANSWERS, worst);
-    std::vector<int32_t> off((size_t)spec);
-    std::vector<double> dist((size_t)spec);
+    std::vector<int32_t> off;
+    std::vector<double> dist;
     if (pl.n_tiles + pl.n_tiles_b > 0) {
-        HIPCHK(ctx, hipMemcpyAsync(hc, ctx->b_counters.p, sizeof hc, hipMemcpyDeviceToHost, ctx->stream));
-        if (spec) {
-            HIPCHK(ctx, hipMemcpyAsync(off.data(), out.d_off, (size_t)spec * 4, hipMemcpyDeviceToHost, ctx->stream));
-            HIPCHK(ctx, hipMemcpyAsync(dist.data(), out.d_dist, (size_t)spec * 8, hipMemcpyDeviceToHost, ctx->stream));
-        }
+        if (!ctx->h_readback)
+            HIPCHK(ctx, hipHostMalloc(&ctx->h_readback, KVM_CNT_TOTAL * 8 + KVM_SPEC_ANSWERS * 12 + 64, hipHostMallocDefault));
+        HIPCHK(ctx, kvm_launch_readback((const unsigned long long *)ctx->b_counters.p, out.d_off, out.d_dist, spec,
+                                        ctx->h_readback, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        std::memcpy(hc, ctx->h_readback, sizeof hc);
+        const int64_t got = std::min<int64_t>((int64_t)hc[KVM_CNT_ANSWERS], spec);
+        const int32_t *hoff = (const int32_t *)((const unsigned long long *)ctx->h_readback + KVM_CNT_TOTAL);
+        const double *hdist = (const double *)(hoff + ((spec + 1) & ~(int64_t)1));
+        off.assign(hoff, hoff + got);
+        dist.assign(hdist, hdist + got);
     }
     KVM_TP("sync + counters D2H");
     const int64_t cnt = (int64_t)hc[KVM_CNT_ANSWERS];

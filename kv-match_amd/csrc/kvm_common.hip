@@ -30,7 +30,9 @@ hipError_t kvm_launch_bswap64(uint64_t *d, int64_t n, hipStream_t s) {
 // class-A tile if it exceeds 32 candidates, else one class-B tile (<= 32 candidates).
 __global__ __launch_bounds__(256) void kvm_expand_tiles_hybrid_kernel(const kvm_run *__restrict__ runs, int64_t n_runs,
                                                                       kvm_tile *__restrict__ tilesA,
-                                                                      kvm_tile *__restrict__ tilesB) {
+                                                                      kvm_tile *__restrict__ tilesB,
+                                                                      unsigned long long *__restrict__ counters) {
+    if (blockIdx.x == 0 && threadIdx.x < KVM_CNT_TOTAL) counters[threadIdx.x] = 0;
     const int lane = threadIdx.x & 63;
     const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= n_runs) return;
@@ -56,10 +58,10 @@ __global__ __launch_bounds__(256) void kvm_expand_tiles_hybrid_kernel(const kvm_
 }
 
 hipError_t kvm_launch_expand_tiles_hybrid(const kvm_run *runs, int64_t n_runs, kvm_tile *tilesA, kvm_tile *tilesB,
-                                          hipStream_t s) {
+                                          unsigned long long *counters, hipStream_t s) {
     if (n_runs <= 0) return hipSuccess;
     hipLaunchKernelGGL(kvm_expand_tiles_hybrid_kernel, dim3((unsigned)((n_runs + 3) / 4)), dim3(256), 0, s, runs, n_runs,
-                       tilesA, tilesB);
+                       tilesA, tilesB, counters);
     return hipGetLastError();
 }
 
@@ -81,6 +83,31 @@ __global__ __launch_bounds__(256) void kvm_pack_answers_kernel(const int32_t *__
     }
 }
 
+// Result readback without a copy command: one small block stores the counters and the first `spec` answers into
+// device-mapped pinned host memory; the host only has to wait for the stream.
+__global__ __launch_bounds__(256) void kvm_readback_kernel(const unsigned long long *__restrict__ counters,
+                                                           const int32_t *__restrict__ off,
+                                                           const double *__restrict__ dist, int64_t spec,
+                                                           unsigned long long *__restrict__ host) {
+    const int t = threadIdx.x;
+    if (t < KVM_CNT_TOTAL) host[t] = counters[t];
+    const int64_t cnt = (int64_t)counters[KVM_CNT_ANSWERS];
+    const int64_t take = cnt < spec ? cnt : spec;
+    int32_t *hoff = reinterpret_cast<int32_t *>(host + KVM_CNT_TOTAL);
+    double *hdist = reinterpret_cast<double *>(hoff + ((spec + 1) & ~(int64_t)1));  // 8-byte aligned
+    for (int64_t i = t; i < take; i += 256) {
+        hoff[i] = off[i];
+        hdist[i] = dist[i];
+    }
+}
+
+hipError_t kvm_launch_readback(const unsigned long long *counters, const int32_t *off, const double *dist, int64_t spec,
+                               void *host, hipStream_t s) {
+    hipLaunchKernelGGL(kvm_readback_kernel, dim3(1), dim3(256), 0, s, counters, off, dist, spec,
+                       (unsigned long long *)host);
+    return hipGetLastError();
+}
+
 hipError_t kvm_launch_pack_answers(const int32_t *off, const double *dist, const int64_t *count, int64_t pack_cap,
                                    double2 *packed, hipStream_t s) {
     hipLaunchKernelGGL(kvm_pack_answers_kernel, dim3((unsigned)((pack_cap + 256) / 256)), dim3(256), 0, s, off, dist, count,
@@ -92,7 +119,9 @@ hipError_t kvm_launch_pack_answers(const int32_t *off, const double *dist, const
 // Runs -> tiles.  The host clips the phase-1 intervals into runs (K/QueryEngine.java:346-354) and knows each run's
 // first tile index; one wavefront per run writes its tile descriptors (16 B each, coalesced).
 __global__ __launch_bounds__(256) void kvm_expand_tiles_kernel(const kvm_run *__restrict__ runs, int64_t n_runs,
-                                                               int32_t tile_max, kvm_tile *__restrict__ tiles) {
+                                                               int32_t tile_max, kvm_tile *__restrict__ tiles,
+                                                               unsigned long long *__restrict__ counters) {
+    if (blockIdx.x == 0 && threadIdx.x < KVM_CNT_TOTAL) counters[threadIdx.x] = 0;  // (saves a fill launch per call)
     const int lane = threadIdx.x & 63;
     const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= n_runs) return;
@@ -109,10 +138,10 @@ __global__ __launch_bounds__(256) void kvm_expand_tiles_kernel(const kvm_run *__
 }
 
 hipError_t kvm_launch_expand_tiles(const kvm_run *runs, int64_t n_runs, int32_t tile_max, kvm_tile *tiles,
-                                   hipStream_t s) {
+                                   unsigned long long *counters, hipStream_t s) {
     if (n_runs <= 0) return hipSuccess;
     hipLaunchKernelGGL(kvm_expand_tiles_kernel, dim3((unsigned)((n_runs + 3) / 4)), dim3(256), 0, s, runs, n_runs,
-                       tile_max, tiles);
+                       tile_max, tiles, counters);
     return hipGetLastError();
 }
 
