@@ -614,7 +614,7 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
                                          counters, ctx->num_cu, stream));
         else if (ed_kernel == 3)
             HIPCHK(ctx, kvm_launch_ed_dot(ctx->d_series, ctx->d_prefix, ctx->n, qd, d_tiles, pl.n_tiles, d_tiles + pl.n_tiles,
-                                          pl.n_tiles_b, surv, pl.windows, counters, stream));
+                                          pl.n_tiles_b, surv, pl.windows, counters, ctx->num_cu, stream));
         else if (ed_kernel == 2)
             HIPCHK(ctx, kvm_launch_ed_tiled(ctx->d_series, ctx->d_prefix, ctx->n, qd, d_tiles, n_tiles, surv,
                                             pl.windows, counters, stream));

@@ -26,6 +26,11 @@
 // hipcc scalarises HIP's double2 and re-pairs it as ds_read2_b64, whose 8-B banking rules conflict 4-way here.
 #include "kvm_internal.h"
 
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+
 typedef double ed4_d2 __attribute__((ext_vector_type(2)));
 
 #define EDD_ROWS 8
@@ -58,9 +63,14 @@ struct edd_cstat {
 };
 
 // One wavefront: 8 tiles (rows) of the list `tiles`, starting at tile index t0.
+// Window split: with f > 1 (f = 2 or 4, never with ABANDON) the unit is shared by f consecutive waves of the
+// workgroup; wave `part` accumulates chunks [nchunks part / f, nchunks (part + 1) / f), parts > 0 hand their
+// accumulators to part 0 through LDS behind one workgroup barrier, and part 0 finishes the candidates.  A unit is then
+// 1/f as long, which is what lets a few thousand units drain evenly from 2048 wave slots (see the launcher).
+// Every wave of a splitting workgroup reaches the barrier exactly once, whether or not it has work (`active`).
 template <int CI, bool NORM, bool ABANDON>
 __device__ __forceinline__ void edd_body(const edd_args &A, const kvm_tile *__restrict__ tiles, int64_t n_tiles, int64_t t0,
-                                         double2 *lds_wave2) {
+                                         double2 *lds_wave2, const int part, const int f, const bool active) {
     using cfg = edd_cfg<CI>;
     constexpr int JC = cfg::JC;
     const int lane = threadIdx.x & 63;
@@ -139,6 +149,7 @@ __device__ __forceinline__ void edd_body(const edd_args &A, const kvm_tile *__re
     };
 
     // ---- which of my CI candidates are alive (bit a of `vm`); `fm`: degenerate sigma, survives unconditionally ----
+    bool work = active;  // wave-uniform
     unsigned vm = 0, fm = 0;
 #pragma unroll
     for (int a = 0; a < CI; a++) {
@@ -156,8 +167,8 @@ __device__ __forceinline__ void edd_body(const edd_args &A, const kvm_tile *__re
         unsigned cntp = (unsigned)__popc(vm);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) cntp += __shfl_xor(cntp, o, 64);
-        if (lane == 0 && cntp) atomicAdd(&A.counters[KVM_CNT_PASS_FILTER], (unsigned long long)cntp);
-        if (cntp == 0) return;  // nothing in this wave passed the (alpha, beta) filter
+        if (lane == 0 && cntp && part == 0) atomicAdd(&A.counters[KVM_CNT_PASS_FILTER], (unsigned long long)cntp);
+        if (cntp == 0) work = false;  // nothing in this wave passed the (alpha, beta) filter
     }
 
     double stage[EDD_ROWS + 1][EDD_LOADS];
@@ -191,13 +202,16 @@ __device__ __forceinline__ void edd_body(const edd_args &A, const kvm_tile *__re
     double acc[CI];
 #pragma unroll
     for (int a = 0; a < CI; a++) acc[a] = 0.0;
-    load_chunk(0);
-    store_chunk();
+    const int ch_lo = nchunks * part / f, ch_hi = nchunks * (part + 1) / f;
+    if (work && ch_lo < ch_hi) {
+        load_chunk(ch_lo * JC);
+        store_chunk();
+    }
     const ed4_d2 *X2 = reinterpret_cast<const ed4_d2 *>(lds_wave2) + (row * (EDD_RS / 2) + cfg::row_shift(row) / 2 + (CI / 2) * lc);
     const ed4_d2 *Q2 = reinterpret_cast<const ed4_d2 *>(lds_wave2) + EDD_ROWS * (EDD_RS / 2);
-    for (int ch = 0; ch < nchunks; ch++) {
+    for (int ch = ch_lo; work && ch < ch_hi; ch++) {
         const int j0 = ch * JC;
-        const bool more = ch + 1 < nchunks;
+        const bool more = ch + 1 < ch_hi;
         if (more) load_chunk(j0 + JC);
         const int jlim = min(JC, m - j0);
         if (jlim == JC) {
@@ -257,7 +271,7 @@ __device__ __forceinline__ void edd_body(const edd_args &A, const kvm_tile *__re
             // early abandon (reference behaviour): partial sums of squares only grow, so a candidate whose distance
             // over the first J points already exceeds the pruning threshold is out.  Checked after the first chunk
             // (random candidates die here) and every 8 chunks afterwards.
-            if (ABANDON && (ch == 0 || (ch & 7) == 7)) {
+            if (ABANDON && (ch == 0 || (ch & 7) == 7)) {  // (f == 1 here: no barrier below to miss)
                 const int J = j0 + JC;
                 const double2 qp = q_pref[ch + 1];
 #pragma unroll
@@ -272,6 +286,21 @@ __device__ __forceinline__ void edd_body(const edd_args &A, const kvm_tile *__re
             }
             store_chunk();
         }
+    }
+    if (f > 1) {
+        // hand-over of the partial sums: parts 1 .. f-1 -> part 0, through the senders' own (now idle) LDS regions
+        if (part > 0 && work) {
+#pragma unroll
+            for (int a = 0; a < CI; a++) wlds[a * 64 + lane] = acc[a];
+        }
+        __syncthreads();
+        if (part > 0 || !work) return;
+        for (int p = 1; p < f; p++) {
+#pragma unroll
+            for (int a = 0; a < CI; a++) acc[a] += wlds[p * EDD_WAVE_LDS + a * 64 + lane];
+        }
+    } else if (!work) {
+        return;
     }
 #pragma unroll
     for (int a = 0; a < CI; a++) {
@@ -290,34 +319,92 @@ __device__ __forceinline__ void edd_body(const edd_args &A, const kvm_tile *__re
     }
 }
 
-// One launch covers both tile classes: wave units [0, unitsA) run the CI=8 body on `tilesA`, the rest the CI=4 body on
-// `tilesB` (a unit = 8 tiles).
+// One launch covers both tile classes.  Workgroups [0, blocksA) run the CI=8 body on `tilesA`, the rest the CI=4 body on
+// `tilesB`; a unit = 8 tiles, shared by fA (fB) consecutive waves of a workgroup when the window is split.
 template <bool NORM, bool ABANDON>
 __global__ __launch_bounds__(256, 2) void kvm_ed_dot_kernel(edd_args A, const kvm_tile *__restrict__ tilesA, int64_t nA,
-                                                            const kvm_tile *__restrict__ tilesB, int64_t nB) {
+                                                            const kvm_tile *__restrict__ tilesB, int64_t nB, int fA, int fB,
+                                                            int64_t blocksA) {
     // declared as double2 so that the window/query reads are provably 16-B aligned (ds_read_b128)
     __shared__ __attribute__((aligned(256))) double2 lds_all2[4 * EDD_WAVE_LDS / 2];
     const int wave = threadIdx.x >> 6;
     double2 *lds_wave2 = lds_all2 + wave * (EDD_WAVE_LDS / 2);
-    const int64_t unit = (int64_t)blockIdx.x * 4 + wave;
-    const int64_t unitsA = (nA + EDD_ROWS - 1) / EDD_ROWS;
-    if (unit < unitsA) {
-        edd_body<8, NORM, ABANDON>(A, tilesA, nA, unit * EDD_ROWS, lds_wave2);
+    if ((int64_t)blockIdx.x < blocksA) {
+        const int64_t slot = (int64_t)blockIdx.x * 4 + wave, t0 = (slot / fA) * EDD_ROWS;
+        edd_body<8, NORM, ABANDON>(A, tilesA, nA, t0, lds_wave2, (int)(slot % fA), fA, t0 < nA);
     } else {
-        const int64_t t0 = (unit - unitsA) * EDD_ROWS;
-        if (t0 < nB) edd_body<4, NORM, ABANDON>(A, tilesB, nB, t0, lds_wave2);
+        const int64_t slot = ((int64_t)blockIdx.x - blocksA) * 4 + wave, t0 = (slot / fB) * EDD_ROWS;
+        edd_body<4, NORM, ABANDON>(A, tilesB, nB, t0, lds_wave2, (int)(slot % fB), fB, t0 < nB);
     }
+}
+
+// Earliest finish time of `parts` identical jobs of length d on g1 slots free at t1 and g2 slots free at t2 (greedy
+// list scheduling = optimal for identical jobs): smallest T with g1 floor((T-t1)/d) + g2 floor((T-t2)/d) >= parts.
+static double edd_finish(double parts, double d, double g1, double t1, double g2, double t2) {
+    if (parts <= 0) return 0.0;
+    double best = 1e300;
+    for (int pass = 0; pass < 2; pass++) {
+        const double tb = pass ? t2 : t1, gb = pass ? g2 : g1;
+        if (gb <= 0) continue;
+        // candidate finish times tb + k d; find the smallest feasible k by bisection
+        double lo = 1, hi = parts + 1;
+        auto cap = [&](double T) {
+            double c = 0;
+            if (g1 > 0 && T >= t1) c += g1 * std::floor((T - t1) / d + 1e-9);
+            if (g2 > 0 && T >= t2) c += g2 * std::floor((T - t2) / d + 1e-9);
+            return c;
+        };
+        while (lo < hi) {
+            const double mid = std::floor((lo + hi) / 2);
+            if (cap(tb + mid * d) >= parts) hi = mid; else lo = mid + 1;
+        }
+        best = std::min(best, tb + lo * d);
+    }
+    return best;
+}
+// Modelled makespan (in class-A unit times) of unitsA / unitsB units split fA / fB ways on `slots` wave slots:
+// class-A parts first (list order = launch order), then class-B parts into the slots as they free up.
+static double edd_makespan(double unitsA, double unitsB, int fA, int fB, double slots) {
+    const double costB = 0.6;  // measured: a CI=4 unit takes ~0.6 of a CI=8 unit
+    const double pa = unitsA * fA, da = 1.0 / fA;
+    const double full = std::floor(pa / slots), rem = pa - full * slots;
+    const double t1 = full * da, t2 = rem > 0 ? (full + 1) * da : t1;  // slots - rem free at t1, rem at t2
+    const double endB = edd_finish(unitsB * fB, costB / fB, slots - rem, t1, rem, t2);
+    return std::max(endB, t2) * (1.0 + 0.01 * (fA > 1) + 0.01 * (fB > 1));
 }
 
 hipError_t kvm_launch_ed_dot(const double *series, const double2 *prefix, int64_t n, const kvm_query_dev &qd,
                              const kvm_tile *tilesA, int64_t nA, const kvm_tile *tilesB, int64_t nB, kvm_surv *surv,
-                             int64_t cap, unsigned long long *counters, hipStream_t s) {
+                             int64_t cap, unsigned long long *counters, int num_cu, hipStream_t s) {
     (void)n;
     if (nA + nB <= 0) return hipSuccess;
-    const int64_t units = (nA + EDD_ROWS - 1) / EDD_ROWS + (nB + EDD_ROWS - 1) / EDD_ROWS;
-    dim3 grid((unsigned)((units + 3) / 4)), block(256);
+    const int64_t unitsA = (nA + EDD_ROWS - 1) / EDD_ROWS, unitsB = (nB + EDD_ROWS - 1) / EDD_ROWS;
+    // Window split (see edd_body): only worth it while the units are few compared with the 8 wave slots per CU, and
+    // impossible with early abandon (waves leave early).  Pick the split pair with the smallest modelled makespan.
+    int fA = 1, fB = 1;
+    const double slots = (double)num_cu * 8;
+    if (!qd.early_abandon && (double)(unitsA + unitsB) < 16.0 * slots) {
+        double best = 1e300;
+        for (int a = 1; a <= 4; a *= 2)
+            for (int b = 1; b <= 4; b *= 2) {
+                const double t = edd_makespan((double)unitsA, (double)unitsB, a, b, slots);
+                if (t < best - 1e-9) best = t, fA = a, fB = b;
+            }
+    }
+    if (const char *e = getenv("KVM_ED_SPLIT")) {  // experiments: "fA,fB"
+        int a = 0, b = 0;
+        if (sscanf(e, "%d,%d", &a, &b) == 2 && (a == 1 || a == 2 || a == 4) && (b == 1 || b == 2 || b == 4) && !qd.early_abandon)
+            fA = a, fB = b;
+        if (getenv("KVM_TRACE"))
+            fprintf(stderr, "[kvm] ed_dot unitsA %lld unitsB %lld split %d,%d model %.3f (1,1: %.3f)\n", (long long)unitsA,
+                    (long long)unitsB, fA, fB, edd_makespan((double)unitsA, (double)unitsB, fA, fB, slots),
+                    edd_makespan((double)unitsA, (double)unitsB, 1, 1, slots));
+    }
+    const int64_t blocksA = (unitsA * fA + 3) / 4, blocksB = (unitsB * fB + 3) / 4;
+    dim3 grid((unsigned)(blocksA + blocksB)), block(256);
     edd_args A{series, prefix, qd, surv, cap, counters};
-#define LAUNCH(NORM, AB) hipLaunchKernelGGL((kvm_ed_dot_kernel<NORM, AB>), grid, block, 0, s, A, tilesA, nA, tilesB, nB)
+#define LAUNCH(NORM, AB) \
+    hipLaunchKernelGGL((kvm_ed_dot_kernel<NORM, AB>), grid, block, 0, s, A, tilesA, nA, tilesB, nB, fA, fB, blocksA)
     if (qd.normalised) {
         if (qd.early_abandon) LAUNCH(true, true); else LAUNCH(true, false);
     } else {

@@ -156,7 +156,7 @@ hipError_t kvm_launch_ed_jl(const double *series, const double2 *prefix, int64_t
 #define ED8_JC 128  // 4 candidates per lane / 8 candidates per lane
 hipError_t kvm_launch_ed_dot(const double *series, const double2 *prefix, int64_t n, const kvm_query_dev &qd,
                              const kvm_tile *tilesA, int64_t nA, const kvm_tile *tilesB, int64_t nB, kvm_surv *surv,
-                             int64_t cap, unsigned long long *counters, hipStream_t s);
+                             int64_t cap, unsigned long long *counters, int num_cu, hipStream_t s);
 // Exact final pass (kvm_exact.hip)
 hipError_t kvm_launch_exact_ed(const double *series, const kvm_query_dev &qd, const double *q_exact,
                                const int32_t *order, const kvm_surv *surv, const unsigned long long *d_n_surv,
