@@ -120,6 +120,7 @@ extern "C" int kvm_close(kvm_ctx *ctx) {
         if (b->p) hipFree(b->p);
     if (ctx->h_pinned) hipHostFree(ctx->h_pinned);
     if (ctx->h_readback) hipHostFree(ctx->h_readback);
+    if (ctx->h_readback2) hipHostFree(ctx->h_readback2);
     hipEventDestroy(ctx->ev0);
     hipEventDestroy(ctx->ev1);
     hipEventDestroy(ctx->ev_staged);
@@ -555,6 +556,20 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
         std::memcpy(hp + (size_t)m * 16, ql.data(), (size_t)m * 8);
     }
     KVM_TP("  query prep + staging");
+    // scratch of the running-sum replay of the exact pass (cNSM): flags + {mean,std} per window, counts per run
+    kvm_replay_ws rws;
+    std::memset(&rws, 0, sizeof rws);
+    if (cnsm && pl.windows > 0) {
+        const size_t sbytes = (size_t)pl.windows * sizeof(double2);
+        const size_t nbytes = ((size_t)pl.windows + 15) / 16 * 16, mbytes = (size_t)pl.n_runs * sizeof(int32_t);
+        if ((rc = ensure(ctx, ctx->b_scratch, sbytes + nbytes + mbytes + 64))) return rc;
+        rws.runs = (const kvm_run *)((const char *)ctx->b_query.p + qbytes);
+        rws.n_runs = pl.n_runs;
+        rws.stats = (double2 *)ctx->b_scratch.p;
+        rws.need = (unsigned char *)ctx->b_scratch.p + sbytes;
+        rws.run_maxk = (int32_t *)((char *)ctx->b_scratch.p + sbytes + nbytes);
+        (void)nbytes;  // (cleared run by run by the tile-expansion kernel)
+    }
     // one H2D copy: the query block and, right behind it, the runs (32 B each; the tile list -- 16 B per tile -- is
     // expanded from them on the GPU, by the kernel that also zeroes the counters)
     // (for cNSM-ED the span covers the exact-pass block, which is filled in and copied again further down, in stream
@@ -565,10 +580,11 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
         if (hybrid)
             HIPCHK(ctx, kvm_launch_expand_tiles_hybrid(d_runs, pl.n_runs, (kvm_tile *)ctx->b_tiles.p,
                                                        (kvm_tile *)ctx->b_tiles.p + pl.n_tiles,
-                                                       (unsigned long long *)ctx->b_counters.p, stream));
+                                                       (unsigned long long *)ctx->b_counters.p, rws.need, rws.run_maxk,
+                                                       stream));
         else
             HIPCHK(ctx, kvm_launch_expand_tiles(d_runs, pl.n_runs, tile_max, (kvm_tile *)ctx->b_tiles.p,
-                                                (unsigned long long *)ctx->b_counters.p, stream));
+                                                (unsigned long long *)ctx->b_counters.p, rws.need, rws.run_maxk, stream));
     } else {
         HIPCHK(ctx, hipMemsetAsync(ctx->b_counters.p, 0, KVM_CNT_TOTAL * sizeof(unsigned long long), stream));
     }
@@ -585,20 +601,6 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
     const kvm_tile *d_tiles = (const kvm_tile *)ctx->b_tiles.p;
     const int64_t n_tiles = pl.n_tiles;
 
-    // scratch of the running-sum replay of the exact pass (cNSM): flags + {mean,std} per window, counts per run
-    kvm_replay_ws rws;
-    std::memset(&rws, 0, sizeof rws);
-    if (cnsm && pl.windows > 0) {
-        const size_t sbytes = (size_t)pl.windows * sizeof(double2);
-        const size_t nbytes = ((size_t)pl.windows + 15) / 16 * 16, mbytes = (size_t)pl.n_runs * sizeof(int32_t);
-        if ((rc = ensure(ctx, ctx->b_scratch, sbytes + nbytes + mbytes + 64))) return rc;
-        rws.runs = d_runs;
-        rws.n_runs = pl.n_runs;
-        rws.stats = (double2 *)ctx->b_scratch.p;
-        rws.need = (unsigned char *)ctx->b_scratch.p + sbytes;
-        rws.run_maxk = (int32_t *)((char *)ctx->b_scratch.p + sbytes + nbytes);
-        HIPCHK(ctx, hipMemsetAsync(rws.need, 0, nbytes + mbytes, stream));
-    }
     if (kernel_ns) *kernel_ns = 0;
     ctx->last_kernel_ns = 0;
     KVM_TP("  H2D enqueue");
@@ -625,17 +627,41 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
         if (cnsm) {
             // cNSM-ED exact pass: the reference sums over the |zQ|-descending permutation (stable sort with
             // Double.compare(|o2|, |o1|), K/NormQueryEngine.java:443-452).  Computed here, while the pruning kernel runs.
-            std::vector<std::pair<double, int32_t>> keyed((size_t)m);
-            for (int i = 0; i < m; i++) keyed[(size_t)i] = {std::fabs(q[i]), i};
-            std::stable_sort(keyed.begin(), keyed.end(),
-                             [](const std::pair<double, int32_t> &a, const std::pair<double, int32_t> &b) {
-                                 return a.first > b.first;
-                             });
+            // Stable LSD radix sort on the bit patterns: for |x| the IEEE-754 pattern is monotone, NaN (canonicalised as
+            // Double.compare does) sorts above +Inf, and complementing the key turns ascending into descending.
             double *zqs = (double *)(hp + qexact_off);
             int32_t *order = (int32_t *)(hp + qexact_off + (size_t)m * 8);
-            for (int i = 0; i < m; i++) {
-                order[i] = keyed[(size_t)i].second;
-                zqs[i] = q[order[i]];
+            {
+                std::vector<uint64_t> ka((size_t)m), kb((size_t)m);
+                std::vector<int32_t> ia((size_t)m), ib((size_t)m);
+                for (int i = 0; i < m; i++) {
+                    double a = std::fabs(q[i]);
+                    uint64_t u;
+                    std::memcpy(&u, &a, 8);
+                    if (a != a) u = 0x7ff8000000000000ULL;
+                    ka[(size_t)i] = ~u;
+                    ia[(size_t)i] = i;
+                }
+                for (int pass = 0; pass < 8; pass++) {
+                    const int sh = pass * 8;
+                    size_t hist[257] = {0};
+                    for (int i = 0; i < m; i++) hist[((ka[(size_t)i] >> sh) & 255u) + 1]++;
+                    bool one_bucket = false;
+                    for (int b = 1; b <= 256; b++) one_bucket |= hist[b] == (size_t)m;
+                    if (one_bucket) continue;  // every key has the same digit: the pass would be the identity
+                    for (int b = 0; b < 256; b++) hist[b + 1] += hist[b];
+                    for (int i = 0; i < m; i++) {
+                        const size_t d = hist[(ka[(size_t)i] >> sh) & 255u]++;
+                        kb[d] = ka[(size_t)i];
+                        ib[d] = ia[(size_t)i];
+                    }
+                    ka.swap(kb);
+                    ia.swap(ib);
+                }
+                for (int i = 0; i < m; i++) {
+                    order[i] = ia[(size_t)i];
+                    zqs[i] = q[order[i]];
+                }
             }
             HIPCHK(ctx, hipMemcpyAsync((char *)ctx->b_query.p + qexact_off, hp + qexact_off, (size_t)m * 12,
                                        hipMemcpyHostToDevice, stream));
@@ -743,11 +769,23 @@ static int verify_host(kvm_ctx *ctx, int variant, const double *query, int32_t m
     off.resize((size_t)cnt);
     dist.resize((size_t)cnt);
     if (cnt > spec) {
-        HIPCHK(ctx, hipMemcpyAsync(off.data() + spec, out.d_off + spec, (size_t)(cnt - spec) * 4, hipMemcpyDeviceToHost,
-                                   ctx->stream));
-        HIPCHK(ctx, hipMemcpyAsync(dist.data() + spec, out.d_dist + spec, (size_t)(cnt - spec) * 8,
-                                   hipMemcpyDeviceToHost, ctx->stream));
+        // more answers than the readback kernel carries: the rest through a pinned buffer (grow-only)
+        const size_t rest = (size_t)(cnt - spec);
+        if (ctx->h_readback2_cap < rest * 12 + 64) {
+            if (ctx->h_readback2) HIPCHK(ctx, hipHostFree(ctx->h_readback2));
+            ctx->h_readback2 = nullptr;
+            ctx->h_readback2_cap = 0;
+            const size_t want = std::max<size_t>(rest * 12 + 64, (size_t)1 << 20);
+            HIPCHK(ctx, hipHostMalloc(&ctx->h_readback2, want, hipHostMallocDefault));
+            ctx->h_readback2_cap = want;
+        }
+        double *pd = (double *)ctx->h_readback2;
+        int32_t *po = (int32_t *)(pd + rest);
+        HIPCHK(ctx, hipMemcpyAsync(pd, out.d_dist + spec, rest * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(po, out.d_off + spec, rest * 4, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        std::memcpy(dist.data() + spec, pd, rest * 8);
+        std::memcpy(off.data() + spec, po, rest * 4);
     }
     KVM_TP("answers D2H");
     // answers.sort(Comparator.comparing(Pair::getSecond)) -- stable on an offset-ascending list

@@ -84,6 +84,8 @@ struct kvm_ctx {
     // grow-only scratch
     kvm_dev_buf b_query, b_tiles, b_out_off, b_out_dist, b_counters, b_cands, b_cands2, b_aux, b_aux2, b_scratch;
     void *h_pinned = nullptr;
+    void *h_readback2 = nullptr;  // pinned: answers beyond the first KVM_SPEC_ANSWERS (grow-only)
+    size_t h_readback2_cap = 0;
     void *h_readback = nullptr;  // pinned, device-mapped: the readback kernel stores counters + first answers here
     size_t h_pinned_cap = 0;
     int64_t opt_early_abandon = 1, opt_lb_cascade = 1, opt_ed_kernel = 0, opt_timing = 0, opt_dp_kernel = 0;
@@ -103,16 +105,17 @@ struct kvm_result {
 // ---- kernel launchers (each file implements its own) -----------------------------------------------
 // common
 hipError_t kvm_launch_bswap64(uint64_t *d, int64_t n, hipStream_t s);
-// (both expansion kernels also zero the KVM_CNT_TOTAL counters)
+// (both expansion kernels also zero the KVM_CNT_TOTAL counters and, when `need` is given, the replay scratch)
 hipError_t kvm_launch_expand_tiles(const kvm_run *runs, int64_t n_runs, int32_t tile_max, kvm_tile *tiles,
-                                   unsigned long long *counters, hipStream_t s);
+                                   unsigned long long *counters, unsigned char *need, int32_t *run_maxk, hipStream_t s);
 // hybrid ED tiling: class A = 64-candidate tiles (full tiles and remainders > 32), class B = remainders <= 32
 hipError_t kvm_launch_expand_tiles_hybrid(const kvm_run *runs, int64_t n_runs, kvm_tile *tilesA, kvm_tile *tilesB,
-                                          unsigned long long *counters, hipStream_t s);
+                                          unsigned long long *counters, unsigned char *need, int32_t *run_maxk,
+                                          hipStream_t s);
 hipError_t kvm_launch_prefix(const double *x, double2 *prefix, int64_t n, hipStream_t s);
 // counters + the first `spec` answers, stored straight into device-mapped pinned host memory:
 // [KVM_CNT_TOTAL x u64 | spec x int32 | spec x f64]
-#define KVM_SPEC_ANSWERS 1024
+#define KVM_SPEC_ANSWERS 4096
 hipError_t kvm_launch_readback(const unsigned long long *counters, const int32_t *off, const double *dist, int64_t spec,
                                void *host, hipStream_t s);
 hipError_t kvm_launch_pack_answers(const int32_t *off, const double *dist, const int64_t *count, int64_t pack_cap,
