@@ -38,7 +38,9 @@ struct kvm_replay_ws {
     int64_t n_runs;
     unsigned char *need;   // [windows] 1 = some survivor needs the reference's mean/std of this window
     int32_t *run_maxk;     // [n_runs]  number of leading windows of the run that must be replayed (0 = none)
-    double2 *stats;        // [windows] {mean, std} as the reference's running sums give them
+    double2 *stats;        // [windows] {ex, ex2}: the reference's running sums when the flagged window completes
+    int32_t *run_list;     // [n_runs]  indices of the runs with run_maxk > 0, in marking order
+    unsigned long long *run_list_n;  // number of entries (counters[KVM_CNT_REPLAY_RUNS])
 };
 
 // Tile = up to `count` consecutive candidates taken from one run.
@@ -197,6 +199,7 @@ hipError_t kvm_launch_dtw_dp(const double *series, int64_t n, const kvm_query_de
 #define KVM_CNT_CANDS2 8  // #records in cands2 (after Keogh)
 #define KVM_CNT_RECHECKED 9           // evaluations done by the exact pass
 #define KVM_CNT_PASS_FILTER_EXACT 10  // candidates passing the exact (alpha, beta) test
+#define KVM_CNT_REPLAY_RUNS 11        // runs queued for the running-sum replay
 #define KVM_CNT_TOTAL 16
 
 // ---- device helpers ---------------------------------------------------------------------------------
