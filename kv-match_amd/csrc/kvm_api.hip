@@ -460,9 +460,11 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
     const int ed_kernel = ctx->opt_ed_kernel != 0 ? (int)ctx->opt_ed_kernel : (env_ed_kernel ? env_ed_kernel : 3);
     auto tp_ = std::chrono::steady_clock::now();
     // 32-candidate tiles for the LDS-tiled kernels (ED pruners, fused DTW lower-bound stage), 64 otherwise
-    const int32_t tile_max = (!dtw && ed_kernel == 4) ? 16
+    const int32_t tile_max = (!dtw && ed_kernel == 4) ? 16 : (cnsm && !dtw && ed_kernel == 3) ? KVM_TILE_MAX
                              : ((!dtw && ed_kernel >= 2) || (dtw && ctx->opt_lb_cascade)) ? KVM_TILE_TILED : KVM_TILE_MAX;
-    const bool hybrid = !dtw && ed_kernel == 3;
+    // cNSM-ED with the dot pruner: uniform 64-candidate tiles first, trimmed and classified on the device by the filter
+    const bool retile = cnsm && !dtw && ed_kernel == 3;
+    const bool hybrid = !dtw && ed_kernel == 3 && !retile;
     // query block: q | (qu | ql for DTW) | pad || (qc | pad | q_pref | q_pref8 | qT for ED) || (zQ sorted | order: cNSM-ED
     // exact pass); the runs follow it in the pinned staging buffer, where build_plan writes them directly
     const int nchunks4 = (m + ED4_JC - 1) / ED4_JC, nchunks8 = (m + ED8_JC - 1) / ED8_JC;
@@ -526,7 +528,7 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
         qpref8[(size_t)nchunks8] = make_double2(p1, p2);
     }
     const size_t rbytes = (size_t)pl.n_runs * sizeof(kvm_run);
-    const size_t tbytes = (size_t)(pl.n_tiles + pl.n_tiles_b) * sizeof(kvm_tile);
+    const size_t tbytes = (size_t)(retile ? 3 * pl.n_tiles : pl.n_tiles + pl.n_tiles_b) * sizeof(kvm_tile);
     // (KVM_SERIES_PAD spare doubles after q: the tiled ED kernel stages whole query chunks without bounds checks)
     if ((rc = ensure(ctx, ctx->b_query, qbytes + rbytes + 64))) return rc;
     if ((rc = ensure(ctx, ctx->b_tiles, tbytes + 64))) return rc;
@@ -613,12 +615,18 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
         // pruning pass (fast kernels, guard band) -> survivors -> exact pass in the reference's operation order
         if ((rc = ensure(ctx, ctx->b_cands, (size_t)pl.windows * sizeof(kvm_surv) + 64))) return rc;
         kvm_surv *surv = (kvm_surv *)ctx->b_cands.p;
-        if (ed_kernel == 4)
+        if (retile) {
+            kvm_tile *tA = (kvm_tile *)ctx->b_tiles.p + pl.n_tiles, *tB = tA + pl.n_tiles;
+            HIPCHK(ctx, kvm_launch_retile_cnsm(ctx->d_series, ctx->d_prefix, qd, d_tiles, pl.n_tiles, tA, tB,
+                                               counters + KVM_CNT_TILES_A, stream));
+            HIPCHK(ctx, kvm_launch_ed_dot(ctx->d_series, ctx->d_prefix, ctx->n, qd, tA, pl.n_tiles, tB, pl.n_tiles, surv,
+                                          pl.windows, counters, ctx->num_cu, counters + KVM_CNT_TILES_A, stream));
+        } else if (ed_kernel == 4)
             HIPCHK(ctx, kvm_launch_ed_jl(ctx->d_series, ctx->d_prefix, ctx->n, qd, d_tiles, n_tiles, surv, pl.windows,
                                          counters, ctx->num_cu, stream));
         else if (ed_kernel == 3)
             HIPCHK(ctx, kvm_launch_ed_dot(ctx->d_series, ctx->d_prefix, ctx->n, qd, d_tiles, pl.n_tiles, d_tiles + pl.n_tiles,
-                                          pl.n_tiles_b, surv, pl.windows, counters, ctx->num_cu, stream));
+                                          pl.n_tiles_b, surv, pl.windows, counters, ctx->num_cu, nullptr, stream));
         else if (ed_kernel == 2)
             HIPCHK(ctx, kvm_launch_ed_tiled(ctx->d_series, ctx->d_prefix, ctx->n, qd, d_tiles, n_tiles, surv,
                                             pl.windows, counters, stream));
@@ -765,6 +773,9 @@ static int verify_host(kvm_ctx *ctx, int variant, const double *query, int32_t m
         dist.assign(hdist, hdist + got);
     }
     KVM_TP("sync + counters D2H");
+    if (kvm_trace_on())
+        fprintf(stderr, "[kvm] tiles %lld+%lld  retiled A %llu B %llu  pruner survivors %llu\n", (long long)pl.n_tiles,
+                (long long)pl.n_tiles_b, hc[KVM_CNT_TILES_A], hc[KVM_CNT_TILES_B], hc[KVM_CNT_CANDS1]);
     const int64_t cnt = (int64_t)hc[KVM_CNT_ANSWERS];
     if (cnt > worst) return fail(ctx, KVM_ERR_DEVICE, "answer buffer overflow (internal error)");
     kvm_result *r = new kvm_result();

@@ -319,12 +319,78 @@ __device__ __forceinline__ void edd_body(const edd_args &A, const kvm_tile *__re
     }
 }
 
+// cNSM: trim every 64-candidate tile to the span of its candidates that pass the guarded (alpha, beta) filter and sort
+// the trimmed tiles into the two classes of the pruner (33..64 -> A, 1..32 -> B); tiles without a passing candidate
+// disappear.  The filter is selective in practice and its survivors are contiguous stretches of a run (mean and sigma
+// move slowly with the offset), so the pruner's O(m) work shrinks by about the selectivity.  One wavefront per tile,
+// one lane per candidate; 64 tiles per workgroup are collected in LDS and appended with one pair of global atomics
+// (one atomic per tile on a single address cost 0.3 ms at 24 000 tiles); list order is whatever the atomics give.
+#define RETILE_PER_BLOCK 64  // tiles per workgroup: 4 waves x 16 tiles; one pair of global atomics per workgroup
+__global__ __launch_bounds__(256) void kvm_retile_cnsm_kernel(const double *__restrict__ series,
+                                                              const double2 *__restrict__ prefix, kvm_query_dev qd,
+                                                              const kvm_tile *__restrict__ tiles, int64_t n_tiles,
+                                                              kvm_tile *__restrict__ tilesA, kvm_tile *__restrict__ tilesB,
+                                                              unsigned long long *__restrict__ d_counts) {
+    __shared__ kvm_tile outA[RETILE_PER_BLOCK], outB[RETILE_PER_BLOCK];
+    __shared__ int nA, nB;
+    __shared__ unsigned long long baseA, baseB;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) nA = nB = 0;
+    __syncthreads();
+    const int64_t t0 = (int64_t)blockIdx.x * RETILE_PER_BLOCK + wave * (RETILE_PER_BLOCK / 4);
+    for (int i = 0; i < RETILE_PER_BLOCK / 4; i++) {
+        const int64_t t = t0 + i;
+        if (t >= n_tiles) break;  // wave-uniform
+        const kvm_tile tl = tiles[t];
+        bool ok = false;
+        if (lane < tl.count) {
+            double mean, sd;
+            kvm_window_mean_std(prefix, series, (int64_t)tl.start - 1 + lane, qd.m, mean, sd);
+            ok = kvm_cnsm_filter_guarded(mean, sd, qd.meanQ, qd.stdQ, qd.alpha, qd.beta, kvm_sigma_guard(mean, sd));
+        }
+        const unsigned long long mask = __ballot(ok);
+        if (mask != 0 && lane == 0) {
+            const int first = __ffsll((long long)mask) - 1, last = 63 - __clzll((long long)mask);
+            kvm_tile out;
+            out.start = tl.start + first;
+            out.count = last - first + 1;
+            out.run_start = tl.run_start;
+            out.pad = 0;
+            if (out.count > 32) outA[atomicAdd(&nA, 1)] = out;
+            else outB[atomicAdd(&nB, 1)] = out;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        baseA = nA ? atomicAdd(&d_counts[0], (unsigned long long)nA) : 0;
+        baseB = nB ? atomicAdd(&d_counts[1], (unsigned long long)nB) : 0;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < nA) tilesA[baseA + threadIdx.x] = outA[threadIdx.x];
+    if ((int)threadIdx.x < nB) tilesB[baseB + threadIdx.x] = outB[threadIdx.x];
+}
+
+hipError_t kvm_launch_retile_cnsm(const double *series, const double2 *prefix, const kvm_query_dev &qd, const kvm_tile *tiles,
+                                  int64_t n_tiles, kvm_tile *tilesA, kvm_tile *tilesB, unsigned long long *d_counts,
+                                  hipStream_t s) {
+    if (n_tiles <= 0) return hipSuccess;
+    hipLaunchKernelGGL(kvm_retile_cnsm_kernel, dim3((unsigned)((n_tiles + RETILE_PER_BLOCK - 1) / RETILE_PER_BLOCK)), dim3(256),
+                       0, s, series, prefix, qd, tiles, n_tiles, tilesA, tilesB, d_counts);
+    return hipGetLastError();
+}
+
 // One launch covers both tile classes.  Workgroups [0, blocksA) run the CI=8 body on `tilesA`, the rest the CI=4 body on
 // `tilesB`; a unit = 8 tiles, shared by fA (fB) consecutive waves of a workgroup when the window is split.
 template <bool NORM, bool ABANDON>
 __global__ __launch_bounds__(256, 2) void kvm_ed_dot_kernel(edd_args A, const kvm_tile *__restrict__ tilesA, int64_t nA,
                                                             const kvm_tile *__restrict__ tilesB, int64_t nB, int fA, int fB,
-                                                            int64_t blocksA) {
+                                                            int64_t blocksA,
+                                                            const unsigned long long *__restrict__ d_counts) {
+    if (d_counts) {  // tile lists built on the device (kvm_retile_cnsm_kernel): the launch only knows upper bounds
+        nA = (int64_t)d_counts[0];
+        nB = (int64_t)d_counts[1];
+        blocksA = (((nA + EDD_ROWS - 1) / EDD_ROWS) * fA + 3) / 4;
+    }
     // declared as double2 so that the window/query reads are provably 16-B aligned (ds_read_b128)
     __shared__ __attribute__((aligned(256))) double2 lds_all2[4 * EDD_WAVE_LDS / 2];
     const int wave = threadIdx.x >> 6;
@@ -334,6 +400,7 @@ __global__ __launch_bounds__(256, 2) void kvm_ed_dot_kernel(edd_args A, const kv
         edd_body<8, NORM, ABANDON>(A, tilesA, nA, t0, lds_wave2, (int)(slot % fA), fA, t0 < nA);
     } else {
         const int64_t slot = ((int64_t)blockIdx.x - blocksA) * 4 + wave, t0 = (slot / fB) * EDD_ROWS;
+        if (d_counts && ((int64_t)blockIdx.x - blocksA) * 4 / fB * EDD_ROWS >= nB) return;  // whole workgroup past the list
         edd_body<4, NORM, ABANDON>(A, tilesB, nB, t0, lds_wave2, (int)(slot % fB), fB, t0 < nB);
     }
 }
@@ -375,7 +442,8 @@ static double edd_makespan(double unitsA, double unitsB, int fA, int fB, double 
 
 hipError_t kvm_launch_ed_dot(const double *series, const double2 *prefix, int64_t n, const kvm_query_dev &qd,
                              const kvm_tile *tilesA, int64_t nA, const kvm_tile *tilesB, int64_t nB, kvm_surv *surv,
-                             int64_t cap, unsigned long long *counters, int num_cu, hipStream_t s) {
+                             int64_t cap, unsigned long long *counters, int num_cu, const unsigned long long *d_counts,
+                             hipStream_t s) {
     (void)n;
     if (nA + nB <= 0) return hipSuccess;
     const int64_t unitsA = (nA + EDD_ROWS - 1) / EDD_ROWS, unitsB = (nB + EDD_ROWS - 1) / EDD_ROWS;
@@ -383,7 +451,11 @@ hipError_t kvm_launch_ed_dot(const double *series, const double2 *prefix, int64_
     // impossible with early abandon (waves leave early).  Pick the split pair with the smallest modelled makespan.
     int fA = 1, fB = 1;
     const double slots = (double)num_cu * 8;
-    if (!qd.early_abandon && (double)(unitsA + unitsB) < 16.0 * slots) {
+    if (!qd.early_abandon && d_counts) {
+        // device-built lists (cNSM): the real counts are unknown here and usually far below the bounds (a selective
+        // filter leaves a few hundred units for 2048 wave slots), so split as far as a workgroup allows
+        if ((double)(unitsA + unitsB) < 16.0 * slots) fA = fB = 4;
+    } else if (!qd.early_abandon && (double)(unitsA + unitsB) < 16.0 * slots) {
         double best = 1e300;
         for (int a = 1; a <= 4; a *= 2)
             for (int b = 1; b <= 4; b *= 2) {
@@ -404,7 +476,7 @@ hipError_t kvm_launch_ed_dot(const double *series, const double2 *prefix, int64_
     dim3 grid((unsigned)(blocksA + blocksB)), block(256);
     edd_args A{series, prefix, qd, surv, cap, counters};
 #define LAUNCH(NORM, AB) \
-    hipLaunchKernelGGL((kvm_ed_dot_kernel<NORM, AB>), grid, block, 0, s, A, tilesA, nA, tilesB, nB, fA, fB, blocksA)
+    hipLaunchKernelGGL((kvm_ed_dot_kernel<NORM, AB>), grid, block, 0, s, A, tilesA, nA, tilesB, nB, fA, fB, blocksA, d_counts)
     if (qd.normalised) {
         if (qd.early_abandon) LAUNCH(true, true); else LAUNCH(true, false);
     } else {

@@ -161,7 +161,13 @@ hipError_t kvm_launch_ed_jl(const double *series, const double2 *prefix, int64_t
 #define ED8_JC 128  // 4 candidates per lane / 8 candidates per lane
 hipError_t kvm_launch_ed_dot(const double *series, const double2 *prefix, int64_t n, const kvm_query_dev &qd,
                              const kvm_tile *tilesA, int64_t nA, const kvm_tile *tilesB, int64_t nB, kvm_surv *surv,
-                             int64_t cap, unsigned long long *counters, int num_cu, hipStream_t s);
+                             int64_t cap, unsigned long long *counters, int num_cu, const unsigned long long *d_counts,
+                             hipStream_t s);
+// cNSM: 64-candidate tiles -> trimmed class-A / class-B tile lists of the candidates passing the guarded (alpha, beta)
+// filter; the list lengths go to d_counts[0..1] (kvm_launch_ed_dot then takes nA, nB as upper bounds)
+hipError_t kvm_launch_retile_cnsm(const double *series, const double2 *prefix, const kvm_query_dev &qd, const kvm_tile *tiles,
+                                  int64_t n_tiles, kvm_tile *tilesA, kvm_tile *tilesB, unsigned long long *d_counts,
+                                  hipStream_t s);
 // Exact final pass (kvm_exact.hip)
 hipError_t kvm_launch_exact_ed(const double *series, const kvm_query_dev &qd, const double *q_exact,
                                const int32_t *order, const kvm_surv *surv, const unsigned long long *d_n_surv,
@@ -200,6 +206,8 @@ hipError_t kvm_launch_dtw_dp(const double *series, int64_t n, const kvm_query_de
 #define KVM_CNT_RECHECKED 9           // evaluations done by the exact pass
 #define KVM_CNT_PASS_FILTER_EXACT 10  // candidates passing the exact (alpha, beta) test
 #define KVM_CNT_REPLAY_RUNS 11        // runs queued for the running-sum replay
+#define KVM_CNT_TILES_A 12            // cNSM-ED: trimmed tile lists built on the device (kvm_retile_cnsm_kernel)
+#define KVM_CNT_TILES_B 13
 #define KVM_CNT_TOTAL 16
 
 // ---- device helpers ---------------------------------------------------------------------------------
