@@ -63,7 +63,7 @@ struct edd_cstat {
 };
 
 // One wavefront: 8 tiles (rows) of the list `tiles`, starting at tile index t0.
-// Window split: with f > 1 (f = 2 or 4, never with ABANDON) the unit is shared by f consecutive waves of the
+// Window split: with f > 1 (f = 2 or 4) the unit is shared by f consecutive waves of the
 // workgroup; wave `part` accumulates chunks [nchunks part / f, nchunks (part + 1) / f), parts > 0 hand their
 // accumulators to part 0 through LDS behind one workgroup barrier, and part 0 finishes the candidates.  A unit is then
 // 1/f as long, which is what lets a few thousand units drain evenly from 2048 wave slots (see the launcher).
@@ -103,14 +103,16 @@ __device__ __forceinline__ void edd_body(const edd_args &A, const kvm_tile *__re
     const double qbar = qd.q_mean;
     const double2 qtot = q_pref[nchunks];
 
-    // Shifted sums of the first J points of candidate a's window, re-based to the row shift; for cNSM also the
-    // window's mean - c_row, sigma and sigma guard (always from the full window).
-    auto stats = [&](int a, int J) -> edd_cstat {
+    // Shifted sums of points [jlo, J) of candidate a's window, re-based to the row shift; for cNSM also the window's
+    // mean - c_row, sigma and sigma guard (always from the full window).
+    auto stats = [&](int a, int jlo, int J) -> edd_cstat {
         edd_cstat st;
         double s1, s2, cb;
         const int64_t w0 = (int64_t)mine.start - 1 + c0 + a;
-        const int len0 = NORM ? m : J;
-        kvm_window_shifted_sums(prefix, series, w0, len0, s1, s2, cb);
+        const bool full = jlo == 0 && J == m;
+        const int64_t r0 = (NORM || full) ? w0 : w0 + jlo;
+        const int len0 = (NORM || full) ? m : J - jlo;
+        kvm_window_shifted_sums(prefix, series, r0, len0, s1, s2, cb);
         double dc = cb - c_row;
         double S1 = s1 + len0 * dc, S2 = s2 + (2.0 * dc) * s1 + len0 * (dc * dc);
         st.mc = 0.0; st.sg = 1.0; st.g = 0.0;
@@ -118,18 +120,20 @@ __device__ __forceinline__ void edd_body(const edd_args &A, const kvm_tile *__re
             st.mc = S1 / m;
             st.sg = sqrt(S2 / m - st.mc * st.mc);
             st.g = kvm_sigma_guard(c_row + st.mc, st.sg);
-            if (J != m) {
-                kvm_window_shifted_sums(prefix, series, w0, J, s1, s2, cb);
+            if (!full) {
+                const int len = J - jlo;
+                kvm_window_shifted_sums(prefix, series, w0 + jlo, len, s1, s2, cb);
                 dc = cb - c_row;
-                S1 = s1 + J * dc;
-                S2 = s2 + (2.0 * dc) * s1 + J * (dc * dc);
+                S1 = s1 + len * dc;
+                S2 = s2 + (2.0 * dc) * s1 + len * (dc * dc);
             }
         }
         st.s1J = S1;
         st.s2J = S2;
         return st;
     };
-    // correlation-form distance over the first J points and its guard band
+    // correlation-form distance over a range of J points (st, acc and the query sums qp all taken over that range) and
+    // its guard band
     auto dist_form = [&](const edd_cstat &st, double acc, int J, const double2 qp, double &slack) -> double {
         if (!NORM) {
             const double d = qbar - c_row;
@@ -156,7 +160,7 @@ __device__ __forceinline__ void edd_body(const edd_args &A, const kvm_tile *__re
         if (c0 + a < mine.count) {
             bool ok = true;
             if (NORM) {
-                const edd_cstat st = stats(a, m);
+                const edd_cstat st = stats(a, 0, m);
                 ok = kvm_cnsm_filter_guarded(c_row + st.mc, st.sg, qd.meanQ, qd.stdQ, qd.alpha, qd.beta, st.g);
                 if (ok && (!(st.sg == st.sg) || !(st.sg > 0.0))) fm |= 1u << a;  // exact pass decides
             }
@@ -268,21 +272,30 @@ __device__ __forceinline__ void edd_body(const edd_args &A, const kvm_tile *__re
             }
         }
         if (more) {
-            // early abandon (reference behaviour): partial sums of squares only grow, so a candidate whose distance
-            // over the first J points already exceeds the pruning threshold is out.  Checked after the first chunk
-            // (random candidates die here) and every 8 chunks afterwards.
-            if (ABANDON && (ch == 0 || (ch & 7) == 7)) {  // (f == 1 here: no barrier below to miss)
-                const int J = j0 + JC;
-                const double2 qp = q_pref[ch + 1];
-#pragma unroll
+            // early abandon (reference behaviour): the distance is a sum of non-negative terms, so a candidate whose
+            // terms over ANY range of points already exceed the pruning threshold is out.  Each part tests the range
+            // it has accumulated so far: after its first chunk (random candidates die here) and every 8 chunks.
+            if (ABANDON && (ch == ch_lo || ((ch - ch_lo) & 7) == 7)) {
+                const int jlo = ch_lo * JC, J = j0 + JC;
+                const double2 qa = q_pref[ch + 1], qb = q_pref[ch_lo];
+                const double2 qp = make_double2(qa.x - qb.x, qa.y - qb.y);
+                // (a rolled loop: this runs once per 8 chunks, and unrolling its eight prefix-sum evaluations around
+                // the hot loop's live registers made the compiler spill)
+#pragma nounroll
                 for (int a = 0; a < CI; a++) {
+                    double av = acc[0];
+#pragma unroll
+                    for (int k = 1; k < CI; k++) av = (a == k) ? acc[k] : av;
                     if (((vm >> a) & 1u) && !((fm >> a) & 1u)) {
                         double slack;
-                        const edd_cstat st = stats(a, J);
-                        if (dist_form(st, acc[a], J, qp, slack) > eps2 + slack) vm &= ~(1u << a);
+                        const edd_cstat st = stats(a, jlo, J);
+                        if (dist_form(st, av, J - jlo, qp, slack) > eps2 + slack) vm &= ~(1u << a);
                     }
                 }
-                if (!__any(vm != 0)) return;
+                if (!__any(vm != 0)) {
+                    if (f == 1) return;
+                    break;  // split unit: the other parts wait at the barrier below
+                }
             }
             store_chunk();
         }
@@ -292,12 +305,14 @@ __device__ __forceinline__ void edd_body(const edd_args &A, const kvm_tile *__re
         if (part > 0 && work) {
 #pragma unroll
             for (int a = 0; a < CI; a++) wlds[a * 64 + lane] = acc[a];
+            if (ABANDON) reinterpret_cast<unsigned *>(wlds + CI * 64)[lane] = vm;  // candidates this part has seen die
         }
         __syncthreads();
         if (part > 0 || !work) return;
         for (int p = 1; p < f; p++) {
 #pragma unroll
             for (int a = 0; a < CI; a++) acc[a] += wlds[p * EDD_WAVE_LDS + a * 64 + lane];
+            if (ABANDON) vm &= reinterpret_cast<const unsigned *>(wlds + p * EDD_WAVE_LDS + CI * 64)[lane];
         }
     } else if (!work) {
         return;
@@ -308,7 +323,7 @@ __device__ __forceinline__ void edd_body(const edd_args &A, const kvm_tile *__re
             bool keep = (fm >> a) & 1u;
             if (!keep) {
                 double slack;
-                const edd_cstat st = stats(a, m);
+                const edd_cstat st = stats(a, 0, m);
                 keep = dist_form(st, acc[a], m, qtot, slack) <= eps2 + slack;
             }
             if (keep) {
@@ -385,11 +400,15 @@ template <bool NORM, bool ABANDON>
 __global__ __launch_bounds__(256, 2) void kvm_ed_dot_kernel(edd_args A, const kvm_tile *__restrict__ tilesA, int64_t nA,
                                                             const kvm_tile *__restrict__ tilesB, int64_t nB, int fA, int fB,
                                                             int64_t blocksA,
-                                                            const unsigned long long *__restrict__ d_counts) {
+                                                            const unsigned long long *__restrict__ d_counts,
+                                                            int64_t split_units) {
     if (d_counts) {  // tile lists built on the device (kvm_retile_cnsm_kernel): the launch only knows upper bounds
         nA = (int64_t)d_counts[0];
         nB = (int64_t)d_counts[1];
-        blocksA = (((nA + EDD_ROWS - 1) / EDD_ROWS) * fA + 3) / 4;
+        // the grid was sized for a 4-way split of the bounds; split only if the real lists are short
+        const int64_t uA = (nA + EDD_ROWS - 1) / EDD_ROWS, uB = (nB + EDD_ROWS - 1) / EDD_ROWS;
+        fA = fB = (uA + uB <= split_units) ? 4 : 1;
+        blocksA = (uA * fA + 3) / 4;
     }
     // declared as double2 so that the window/query reads are provably 16-B aligned (ds_read_b128)
     __shared__ __attribute__((aligned(256))) double2 lds_all2[4 * EDD_WAVE_LDS / 2];
@@ -451,11 +470,21 @@ hipError_t kvm_launch_ed_dot(const double *series, const double2 *prefix, int64_
     // impossible with early abandon (waves leave early).  Pick the split pair with the smallest modelled makespan.
     int fA = 1, fB = 1;
     const double slots = (double)num_cu * 8;
-    if (!qd.early_abandon && d_counts) {
+    int64_t split_units = 0;
+    if (d_counts) {
         // device-built lists (cNSM): the real counts are unknown here and usually far below the bounds (a selective
-        // filter leaves a few hundred units for 2048 wave slots), so split as far as a workgroup allows
-        if ((double)(unitsA + unitsB) < 16.0 * slots) fA = fB = 4;
-    } else if (!qd.early_abandon && (double)(unitsA + unitsB) < 16.0 * slots) {
+        // filter leaves a few hundred units for 2048 wave slots): the grid covers a 4-way split of the bounds and the
+        // kernel decides from the real counts (early abandon: only when the list cannot fill the chip anyway)
+        split_units = -1;  // (bounds too large to size the grid for a split: the kernel then never splits)
+        if ((double)(unitsA + unitsB) < 16.0 * slots) {
+            fA = fB = 4;
+            split_units = qd.early_abandon ? (int64_t)(slots / 2) : (int64_t)(4 * slots);
+        }
+    } else if (qd.early_abandon) {
+        // unit durations are unpredictable; split only when the list cannot fill the chip anyway (latency-bound)
+        if ((double)(unitsA + unitsB) * 4.0 <= slots) fA = fB = 4;
+        else if ((double)(unitsA + unitsB) * 2.0 <= slots) fA = fB = 2;
+    } else if ((double)(unitsA + unitsB) < 16.0 * slots) {
         double best = 1e300;
         for (int a = 1; a <= 4; a *= 2)
             for (int b = 1; b <= 4; b *= 2) {
@@ -465,7 +494,7 @@ hipError_t kvm_launch_ed_dot(const double *series, const double2 *prefix, int64_
     }
     if (const char *e = getenv("KVM_ED_SPLIT")) {  // experiments: "fA,fB"
         int a = 0, b = 0;
-        if (sscanf(e, "%d,%d", &a, &b) == 2 && (a == 1 || a == 2 || a == 4) && (b == 1 || b == 2 || b == 4) && !qd.early_abandon)
+        if (sscanf(e, "%d,%d", &a, &b) == 2 && (a == 1 || a == 2 || a == 4) && (b == 1 || b == 2 || b == 4))
             fA = a, fB = b;
         if (getenv("KVM_TRACE"))
             fprintf(stderr, "[kvm] ed_dot unitsA %lld unitsB %lld split %d,%d model %.3f (1,1: %.3f)\n", (long long)unitsA,
@@ -476,7 +505,8 @@ hipError_t kvm_launch_ed_dot(const double *series, const double2 *prefix, int64_
     dim3 grid((unsigned)(blocksA + blocksB)), block(256);
     edd_args A{series, prefix, qd, surv, cap, counters};
 #define LAUNCH(NORM, AB) \
-    hipLaunchKernelGGL((kvm_ed_dot_kernel<NORM, AB>), grid, block, 0, s, A, tilesA, nA, tilesB, nB, fA, fB, blocksA, d_counts)
+    hipLaunchKernelGGL((kvm_ed_dot_kernel<NORM, AB>), grid, block, 0, s, A, tilesA, nA, tilesB, nB, fA, fB, blocksA, d_counts, \
+                       split_units)
     if (qd.normalised) {
         if (qd.early_abandon) LAUNCH(true, true); else LAUNCH(true, false);
     } else {
