@@ -23,87 +23,108 @@
 #define EX_VALS 2048     // distance terms per chunk (1 double each)  == 4 * EX_STEPS
 #define EX_BUF (4 * EX_STEPS)  // doubles per LDS buffer; two buffers per workgroup (32 KiB)
 
-// lane 0: acc += buf[0..cnt) strictly in order.  Two register sets of 16 values alternate: the LDS reads of the next 16
-// are in flight while the current 16 are added, so the chain runs at the latency of a dependent v_add_f64 alone.
+// ---- the sequential chains -----------------------------------------------------------------------------------------
+// One lane adds values from LDS strictly in order.  A dependent v_add_f64 issues every ~10 cycles
+// (profiles/micro/chain_bench.hip), so the loop is at its floor only if no LDS latency is ever exposed: two register
+// sets alternate, the reads of one are in flight while the other is added.  hipcc would not keep that shape -- it
+// sank the prefetch next to its use, or renamed the sets and waited on the copies (26-31 cycles per step measured with
+// profiles/micro/replay_timing.hip) -- so the reads and their waits are written as inline asm: the compiler sees plain
+// register operands, the s_waitcnt that makes a set valid carries the set and the running sums as operands (nothing
+// that uses them can move above it), and lgkmcnt(8) means "all but the 8 youngest reads", i.e. the other set's.
+typedef double ex_d2 __attribute__((ext_vector_type(2)));
+#define EX_LDS_READ(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:" #off : "=v"(dst) : "v"(addr))
+#define EX_READ8(set, addr, stride)                                                                                      \
+    do {                                                                                                                 \
+        if (stride == 16) {                                                                                              \
+            EX_LDS_READ(set[0], addr, 0); EX_LDS_READ(set[1], addr, 16); EX_LDS_READ(set[2], addr, 32);                  \
+            EX_LDS_READ(set[3], addr, 48); EX_LDS_READ(set[4], addr, 64); EX_LDS_READ(set[5], addr, 80);                 \
+            EX_LDS_READ(set[6], addr, 96); EX_LDS_READ(set[7], addr, 112);                                               \
+        } else {                                                                                                         \
+            EX_LDS_READ(set[0], addr, 0); EX_LDS_READ(set[1], addr, 32); EX_LDS_READ(set[2], addr, 64);                  \
+            EX_LDS_READ(set[3], addr, 96); EX_LDS_READ(set[4], addr, 128); EX_LDS_READ(set[5], addr, 160);               \
+            EX_LDS_READ(set[6], addr, 192); EX_LDS_READ(set[7], addr, 224);                                              \
+        }                                                                                                                \
+    } while (0)
+#define EX_WAIT8(set, s0, s1)                                                                                            \
+    asm volatile("s_waitcnt lgkmcnt(8)"                                                                                  \
+                 : "+v"(set[0]), "+v"(set[1]), "+v"(set[2]), "+v"(set[3]), "+v"(set[4]), "+v"(set[5]), "+v"(set[6]),     \
+                   "+v"(set[7]), "+v"(s0), "+v"(s1)::"memory")
+#define EX_WAIT0(set, s0, s1)                                                                                            \
+    asm volatile("s_waitcnt lgkmcnt(0)"                                                                                  \
+                 : "+v"(set[0]), "+v"(set[1]), "+v"(set[2]), "+v"(set[3]), "+v"(set[4]), "+v"(set[5]), "+v"(set[6]),     \
+                   "+v"(set[7]), "+v"(s0), "+v"(s1)::"memory")
+__device__ __forceinline__ unsigned ex_lds_addr(const void *p) { return (unsigned)(uintptr_t)p; }  // low half of a generic LDS address
+
+// lane: acc += buf[0..cnt) strictly in order (16 values per register set).
 __device__ __forceinline__ double ex_seq_add(const double *buf, int cnt, double acc) {
-    constexpr int R = 8;  // double2 per set
-    double2 a[R], b[R];
-    int t = 0;
-    if (cnt >= 2 * R) {
+    ex_d2 a[8], b[8];
+    double dummy = 0.0;
+    const int rounds = cnt / 32;  // a round = both sets = 32 values
+    if (rounds > 0) {
+        const unsigned base = ex_lds_addr(buf);
+        EX_READ8(a, base, 16);
+        for (int r = 0; r < rounds; r++) {
+            const unsigned ab = base + (unsigned)(r * 256 + 128);
+            const unsigned an = base + (unsigned)((r + 1 < rounds ? r + 1 : 0) * 256);  // (last: re-reads the head, unused)
+            EX_READ8(b, ab, 16);
+            EX_WAIT8(a, acc, dummy);
 #pragma unroll
-        for (int u = 0; u < R; u++) a[u] = *reinterpret_cast<const double2 *>(buf + 2 * u);
+            for (int u = 0; u < 8; u++) {
+                acc += a[u].x;
+                acc += a[u].y;
+            }
+            EX_READ8(a, an, 16);
+            EX_WAIT8(b, acc, dummy);
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                acc += b[u].x;
+                acc += b[u].y;
+            }
+        }
+        EX_WAIT0(a, acc, dummy);  // drain the last (unused) prefetch before the compiler's own LDS code
     }
-    while (t + 2 * R <= cnt) {
-        const bool more1 = t + 4 * R <= cnt;
-        if (more1) {
-#pragma unroll
-            for (int u = 0; u < R; u++) b[u] = *reinterpret_cast<const double2 *>(buf + t + 2 * R + 2 * u);
-        }
-#pragma unroll
-        for (int u = 0; u < R; u++) {
-            acc += a[u].x;
-            acc += a[u].y;
-        }
-        t += 2 * R;
-        if (!more1) break;
-        const bool more2 = t + 4 * R <= cnt;
-        if (more2) {
-#pragma unroll
-            for (int u = 0; u < R; u++) a[u] = *reinterpret_cast<const double2 *>(buf + t + 2 * R + 2 * u);
-        }
-#pragma unroll
-        for (int u = 0; u < R; u++) {
-            acc += b[u].x;
-            acc += b[u].y;
-        }
-        t += 2 * R;
-        if (!more2) break;
-    }
-    for (; t < cnt; t++) acc += buf[t];
+    for (int t = rounds * 32; t < cnt; t++) acc += buf[t];
     return acc;
 }
 
 // Warm-up steps of the running-sum replay (no window complete yet): ex += d, ex2 += d*d for steps [0, n), each step 4
-// doubles apart in `buf`; same two-set prefetch.
-__device__ __forceinline__ void ex_seq_add2(const double *buf, int n, double &ex, double &ex2) {
-    constexpr int R = 8;
-    double2 a[R], b[R];
-    int t = 0;
-    if (n >= R) {
+// doubles (32 B) apart in `buf`: {d, d*d, ., .}; 8 steps per register set.
+__device__ __forceinline__ void ex_seq_add2(const double *buf, int n, double &ex_io, double &ex2_io) {
+    ex_d2 a[8], b[8];
+    double ex = ex_io, ex2 = ex2_io;
+    const int rounds = n / 16;
+    if (rounds > 0) {
+        const unsigned base = ex_lds_addr(buf);
+        EX_READ8(a, base, 32);
+        for (int r = 0; r < rounds; r++) {
+            const unsigned ab = base + (unsigned)(r * 512 + 256);
+            const unsigned an = base + (unsigned)((r + 1 < rounds ? r + 1 : 0) * 512);
+            EX_READ8(b, ab, 32);
+            EX_WAIT8(a, ex, ex2);
 #pragma unroll
-        for (int u = 0; u < R; u++) a[u] = *reinterpret_cast<const double2 *>(buf + 4 * u);
+            for (int u = 0; u < 8; u++) {
+                ex += a[u].x;
+                ex2 += a[u].y;
+            }
+            EX_READ8(a, an, 32);
+            EX_WAIT8(b, ex, ex2);
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                ex += b[u].x;
+                ex2 += b[u].y;
+            }
+        }
+        EX_WAIT0(a, ex, ex2);
     }
-    while (t + R <= n) {
-        const bool more1 = t + 2 * R <= n;
-        if (more1) {
-#pragma unroll
-            for (int u = 0; u < R; u++) b[u] = *reinterpret_cast<const double2 *>(buf + 4 * (t + R + u));
-        }
-#pragma unroll
-        for (int u = 0; u < R; u++) {
-            ex += a[u].x;
-            ex2 += a[u].y;
-        }
-        t += R;
-        if (!more1) break;
-        const bool more2 = t + 2 * R <= n;
-        if (more2) {
-#pragma unroll
-            for (int u = 0; u < R; u++) a[u] = *reinterpret_cast<const double2 *>(buf + 4 * (t + R + u));
-        }
-#pragma unroll
-        for (int u = 0; u < R; u++) {
-            ex += b[u].x;
-            ex2 += b[u].y;
-        }
-        t += R;
-        if (!more2) break;
-    }
-    for (; t < n; t++) {
+    for (int t = rounds * 16; t < n; t++) {
         ex += buf[4 * t];
         ex2 += buf[4 * t + 1];
     }
+    ex_io = ex;
+    ex2_io = ex2;
 }
+
+#define EX_FENCE2(a, b) asm volatile("" : "+v"(a), "+v"(b)::"memory")
 
 // Producer side of the running-sum replay: steps [c0, c0+cnt) of the run that starts at 0-based point b; per step
 // {d, d*d, o, o*o} where o is the point leaving the window after that step (T[j] of K/NormQueryEngine.java:523).
@@ -117,8 +138,12 @@ __device__ __forceinline__ void ex_produce_replay(const double *__restrict__ x, 
     for (int i = 0; i < PER; i++) {
         const int t = ptid + i * pthreads;
         const int64_t g = c0 + t;
-        d[i] = (t < cnt) ? x[b + g] : 0.0;
-        o[i] = (t < cnt && g >= m - 1 && g < total - 1) ? x[b + g - m + 1] : 0.0;
+        // unconditional loads from clamped (always valid) addresses, selection afterwards: a load under a condition
+        // becomes a branch with its own wait, and nine of those in a row cost 5 us per chunk
+        const int64_t gd = g < total ? g : total - 1, go = g >= m - 1 ? g - m + 1 : 0;
+        const double dv = x[b + gd], ov = x[b + (go < total ? go : total - 1)];
+        d[i] = (t < cnt) ? dv : 0.0;
+        o[i] = (t < cnt && g >= m - 1 && g < total - 1) ? ov : 0.0;
     }
 #pragma unroll
     for (int i = 0; i < PER; i++) {
@@ -160,9 +185,14 @@ __global__ __launch_bounds__(256) void kvm_replay_mark_kernel(const REC *__restr
     }
 }
 
+#ifdef KVM_EX_TIMING  // diagnostics only (profiles/micro/replay_timing.hip): cycle stamps of block 0's consumer and one producer
+__device__ unsigned long long kvm_dbg[8192];
+#define EX_STAMP(slot) do { if (blockIdx.x == 0) kvm_dbg[slot] = __builtin_readcyclecounter(); } while (0)
+#else
+#define EX_STAMP(slot) do { } while (0)
+#endif
 __global__ __launch_bounds__(EX_THREADS) void kvm_replay_runs_kernel(const double *__restrict__ x, int m, kvm_replay_ws ws) {
     __shared__ __attribute__((aligned(16))) double bufs[2 * EX_BUF];
-    __shared__ unsigned char flags[2][EX_STEPS];
     // one workgroup per QUEUED run (launching one per run of the query costs ~100 us of empty workgroups at 15 000 runs)
     if ((unsigned long long)blockIdx.x >= *ws.run_list_n) return;
   for (unsigned long long li = blockIdx.x; li < *ws.run_list_n; li += gridDim.x) {
@@ -174,23 +204,9 @@ __global__ __launch_bounds__(EX_THREADS) void kvm_replay_runs_kernel(const doubl
     const int tid = threadIdx.x;
     const bool consumer = tid < 64;
     const int ptid = tid - 64, pthreads = EX_THREADS - 64;
-    const unsigned char *need = ws.need + run.win_base;
     auto produce = [&](int64_t c0, int buf) {
         const int cnt = (int)min((int64_t)EX_STEPS, total - c0);
-        constexpr int PER = (EX_STEPS + (EX_THREADS - 64) - 1) / (EX_THREADS - 64);
-        unsigned char f[PER];
-#pragma unroll
-        for (int i = 0; i < PER; i++) {
-            const int t = ptid + i * pthreads;
-            const int64_t k = c0 + t - (m - 1);  // window completed by step c0 + t
-            f[i] = (t < cnt && k >= 0) ? need[k] : 0;
-        }
         ex_produce_replay(x, b, total, m, c0, cnt, bufs + buf * EX_BUF, ptid, pthreads);
-#pragma unroll
-        for (int i = 0; i < PER; i++) {
-            const int t = ptid + i * pthreads;
-            if (t < cnt) flags[buf][t] = f[i];
-        }
     };
     double ex = 0.0, ex2 = 0.0;
     const int nch = (int)((total + EX_STEPS - 1) / EX_STEPS);
@@ -200,55 +216,66 @@ __global__ __launch_bounds__(EX_THREADS) void kvm_replay_runs_kernel(const doubl
         const int64_t c0 = (int64_t)c * EX_STEPS;
         if (consumer) {
             if (tid == 0) {
+                EX_STAMP(4 * c + 0);
                 const double *buf = bufs + (c & 1) * EX_BUF;
-                const unsigned char *fl = flags[c & 1];
                 const int cnt = (int)min((int64_t)EX_STEPS, total - c0);
                 const int n_add = (int)max((int64_t)0, min((int64_t)cnt, (int64_t)(m - 1) - c0));  // no window complete yet
                 ex_seq_add2(buf, n_add, ex, ex2);
-                // window steps, 4 at a time with the next 4 (values and flags) already in flight
-                constexpr int R = 4;
-                double2 dv[2][R], ov[2][R];
-                unsigned char fv[2][R];
-                auto fetch = [&](int t0, int set) {
+                // Window steps.  Branch-free: the departing point's terms are zero where the reference does not
+                // subtract (the producer writes 0.0 for the last step; x - 0.0 == x bit for bit), and {ex, ex2} is
+                // stored for EVERY window (the readers only look at the flagged ones), so a round is straight-line
+                // code and its LDS reads stay one round ahead (see ex_seq_add).
+                {
+                    constexpr int R = 4;
+                    double2 dv[2][R], ov[2][R];
+                    double ex_l = ex, ex2_l = ex2;
+                    double2 *st_out = ws.stats + run.win_base + (c0 - (int64_t)(m - 1));  // + t = window completed by step t
+                    const int nw = cnt - n_add, rounds = nw / (2 * R);
+                    auto fetch = [&](int t0, int set) {
 #pragma unroll
-                    for (int u = 0; u < R; u++) {
-                        const int tt = min(t0 + u, EX_STEPS - 1);  // (clamped: the tail of a set may lie past cnt, unused)
-                        dv[set][u] = *reinterpret_cast<const double2 *>(buf + 4 * tt);
-                        ov[set][u] = *reinterpret_cast<const double2 *>(buf + 4 * tt + 2);
-                        fv[set][u] = fl[tt];
+                        for (int u = 0; u < R; u++) {
+                            dv[set][u] = *reinterpret_cast<const double2 *>(buf + 4 * (t0 + u));
+                            ov[set][u] = *reinterpret_cast<const double2 *>(buf + 4 * (t0 + u) + 2);
+                        }
+                    };
+                    auto consume = [&](int t0, int set) {
+#pragma unroll
+                        for (int u = 0; u < R; u++) {
+                            ex_l += dv[set][u].x;                          // K/NormQueryEngine.java:498
+                            ex2_l += dv[set][u].y;                         // :499
+                            st_out[t0 + u] = make_double2(ex_l, ex2_l);    // -> mean, std (:507-508) in the readers
+                            ex_l -= ov[set][u].x;                          // :523
+                            ex2_l -= ov[set][u].y;                         // :524
+                        }
+                    };
+                    if (rounds > 0) fetch(n_add, 0);
+                    for (int r = 0; r < rounds; r++) {
+                        const int t = n_add + r * 2 * R;
+                        fetch(t + R, 1);
+                        EX_FENCE2(ex_l, ex2_l);
+                        consume(t, 0);
+                        fetch((r + 1 < rounds) ? t + 2 * R : n_add, 0);
+                        EX_FENCE2(ex_l, ex2_l);
+                        consume(t + R, 1);
                     }
-                };
-                auto step = [&](int t, const double2 d, const double2 o, const unsigned char f) {
-                    const int64_t g = c0 + t;
-                    ex += d.x;   // K/NormQueryEngine.java:498
-                    ex2 += d.y;  // :499
-                    // the running sums of a flagged window go out raw: mean = ex/m (:507) and std = sqrt(ex2/m - mean^2)
-                    // (:508) are formed by the readers, in parallel -- two divisions and a square root per flagged
-                    // window would otherwise sit in this one-lane sequential loop (~400 cycles each)
-                    if (f) ws.stats[run.win_base + (g - (m - 1))] = make_double2(ex, ex2);
-                    if (g < total - 1) {
-                        ex -= o.x;   // :523
-                        ex2 -= o.y;  // :524
+                    for (int t = n_add + rounds * 2 * R; t < cnt; t++) {
+                        const double2 d = *reinterpret_cast<const double2 *>(buf + 4 * t);
+                        const double2 o = *reinterpret_cast<const double2 *>(buf + 4 * t + 2);
+                        ex_l += d.x;
+                        ex2_l += d.y;
+                        st_out[t] = make_double2(ex_l, ex2_l);
+                        ex_l -= o.x;
+                        ex2_l -= o.y;
                     }
-                };
-                int t = n_add;
-                if (t < cnt) fetch(t, 0);
-                while (t < cnt) {
-                    fetch(t + R, 1);
-#pragma unroll
-                    for (int u = 0; u < R; u++)
-                        if (t + u < cnt) step(t + u, dv[0][u], ov[0][u], fv[0][u]);
-                    t += R;
-                    if (t >= cnt) break;
-                    fetch(t + R, 0);
-#pragma unroll
-                    for (int u = 0; u < R; u++)
-                        if (t + u < cnt) step(t + u, dv[1][u], ov[1][u], fv[1][u]);
-                    t += R;
+                    ex = ex_l;
+                    ex2 = ex2_l;
                 }
+                EX_STAMP(4 * c + 1);
             }
         } else if (c + 1 < nch) {
+            if (tid == 64) EX_STAMP(4 * c + 2);
             produce(c0 + EX_STEPS, (c + 1) & 1);
+            if (tid == 64) EX_STAMP(4 * c + 3);
         }
         __syncthreads();
     }
@@ -325,9 +352,15 @@ __global__ __launch_bounds__(EX_THREADS) void kvm_exact_ed_kernel(const double *
             for (int i = 0; i < PER; i++) {
                 const int e = ptid + i * pthreads, sidx = (e / EX_GVALS) & (EX_GROUP - 1), t = e % EX_GVALS;
                 const bool ok = e < EX_VALS && t < cnt && s_active[sidx];
-                qv[i] = ok ? q_exact[c0 + t] : 0.0;
-                if (NORM) ord[i] = ok ? order[c0 + t] : 0;
-                else ord[i] = ok ? c0 + t : 0;
+                const int kk = c0 + t < m ? c0 + t : m - 1;  // clamped: loads are unconditional (a load under a
+                const double qq = q_exact[kk];                // condition becomes a branch with its own wait)
+                qv[i] = ok ? qq : 0.0;
+                if (NORM) {
+                    const int32_t oo = order[kk];
+                    ord[i] = ok ? oo : 0;
+                } else {
+                    ord[i] = ok ? kk : 0;
+                }
             }
 #pragma unroll
             for (int i = 0; i < PER; i++) {
