@@ -144,7 +144,8 @@ void kvm_result_free(kvm_result *r);
 #define KVM_OPT_LB_CASCADE 2     /* 1 (default): LB_Kim/LB_Keogh cascade before the DTW DP; 0: DP on
                                     every filter-passing candidate */
 #define KVM_OPT_ED_KERNEL 3      /* ED pruning kernel: 0 auto (default = 3), 1 wave-per-candidate, 2 LDS-tiled
-                                    direct form, 3 LDS-tiled correlation form */
+                                    direct form, 3 LDS-tiled correlation form, 4 correlation form with the lanes
+                                    along the window (experimental).  All return identical answers. */
 #define KVM_OPT_TIMING 4         /* 1: record HIP-event kernel times into KVM_STAT_KERNEL_NS */
 #define KVM_OPT_DP_KERNEL 5      /* 0 auto (default: register-resident band when rho <= 1023), 1 generic LDS form */
 int kvm_set_option(kvm_ctx *ctx, int32_t option, int64_t value);
