@@ -563,16 +563,14 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
     std::memset(&rws, 0, sizeof rws);
     if (cnsm && pl.windows > 0) {
         const size_t sbytes = (size_t)pl.windows * sizeof(double2);
-        const size_t nbytes = ((size_t)pl.windows + 15) / 16 * 16, mbytes = (size_t)pl.n_runs * sizeof(int32_t);
-        if ((rc = ensure(ctx, ctx->b_scratch, sbytes + nbytes + 2 * mbytes + 64))) return rc;
+        const size_t mbytes = (size_t)pl.n_runs * sizeof(int32_t);
+        if ((rc = ensure(ctx, ctx->b_scratch, sbytes + 2 * mbytes + 64))) return rc;
         rws.runs = (const kvm_run *)((const char *)ctx->b_query.p + qbytes);
         rws.n_runs = pl.n_runs;
         rws.stats = (double2 *)ctx->b_scratch.p;
-        rws.need = (unsigned char *)ctx->b_scratch.p + sbytes;
-        rws.run_maxk = (int32_t *)((char *)ctx->b_scratch.p + sbytes + nbytes);
+        rws.run_maxk = (int32_t *)((char *)ctx->b_scratch.p + sbytes);
         rws.run_list = rws.run_maxk + pl.n_runs;
         rws.run_list_n = (unsigned long long *)ctx->b_counters.p + KVM_CNT_REPLAY_RUNS;
-        (void)nbytes;  // (cleared run by run by the tile-expansion kernel)
     }
     // one H2D copy: the query block and, right behind it, the runs (32 B each; the tile list -- 16 B per tile -- is
     // expanded from them on the GPU, by the kernel that also zeroes the counters)
@@ -584,11 +582,10 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
         if (hybrid)
             HIPCHK(ctx, kvm_launch_expand_tiles_hybrid(d_runs, pl.n_runs, (kvm_tile *)ctx->b_tiles.p,
                                                        (kvm_tile *)ctx->b_tiles.p + pl.n_tiles,
-                                                       (unsigned long long *)ctx->b_counters.p, rws.need, rws.run_maxk,
-                                                       stream));
+                                                       (unsigned long long *)ctx->b_counters.p, rws.run_maxk, stream));
         else
             HIPCHK(ctx, kvm_launch_expand_tiles(d_runs, pl.n_runs, tile_max, (kvm_tile *)ctx->b_tiles.p,
-                                                (unsigned long long *)ctx->b_counters.p, rws.need, rws.run_maxk, stream));
+                                                (unsigned long long *)ctx->b_counters.p, rws.run_maxk, stream));
     } else {
         HIPCHK(ctx, hipMemsetAsync(ctx->b_counters.p, 0, KVM_CNT_TOTAL * sizeof(unsigned long long), stream));
     }

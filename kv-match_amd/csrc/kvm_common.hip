@@ -32,17 +32,13 @@ __global__ __launch_bounds__(256) void kvm_expand_tiles_hybrid_kernel(const kvm_
                                                                       kvm_tile *__restrict__ tilesA,
                                                                       kvm_tile *__restrict__ tilesB,
                                                                       unsigned long long *__restrict__ counters,
-                                                                      unsigned char *__restrict__ need,
-                                                                      int32_t *__restrict__ run_maxk) {
+                                                                             int32_t *__restrict__ run_maxk) {
     if (blockIdx.x == 0 && threadIdx.x < KVM_CNT_TOTAL) counters[threadIdx.x] = 0;
     const int lane = threadIdx.x & 63;
     const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= n_runs) return;
     const kvm_run run = runs[r];
-    if (need) {
-        for (int i = lane; i < run.count; i += 64) need[run.win_base + i] = 0;
-        if (lane == 0) run_maxk[r] = 0;
-    }
+    if (run_maxk && lane == 0) run_maxk[r] = 0;
     const int full = run.count / 64, rem = run.count % 64;
     const int nA = full + (rem > 32 ? 1 : 0);
     for (int t = lane; t < nA; t += 64) {
@@ -64,11 +60,10 @@ __global__ __launch_bounds__(256) void kvm_expand_tiles_hybrid_kernel(const kvm_
 }
 
 hipError_t kvm_launch_expand_tiles_hybrid(const kvm_run *runs, int64_t n_runs, kvm_tile *tilesA, kvm_tile *tilesB,
-                                          unsigned long long *counters, unsigned char *need, int32_t *run_maxk,
-                                          hipStream_t s) {
+                                          unsigned long long *counters, int32_t *run_maxk, hipStream_t s) {
     if (n_runs <= 0) return hipSuccess;
     hipLaunchKernelGGL(kvm_expand_tiles_hybrid_kernel, dim3((unsigned)((n_runs + 3) / 4)), dim3(256), 0, s, runs, n_runs,
-                       tilesA, tilesB, counters, need, run_maxk);
+                       tilesA, tilesB, counters, run_maxk);
     return hipGetLastError();
 }
 
@@ -128,17 +123,13 @@ hipError_t kvm_launch_pack_answers(const int32_t *off, const double *dist, const
 __global__ __launch_bounds__(256) void kvm_expand_tiles_kernel(const kvm_run *__restrict__ runs, int64_t n_runs,
                                                                int32_t tile_max, kvm_tile *__restrict__ tiles,
                                                                unsigned long long *__restrict__ counters,
-                                                               unsigned char *__restrict__ need,
                                                                int32_t *__restrict__ run_maxk) {
     if (blockIdx.x == 0 && threadIdx.x < KVM_CNT_TOTAL) counters[threadIdx.x] = 0;  // (saves a fill launch per call)
     const int lane = threadIdx.x & 63;
     const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= n_runs) return;
     const kvm_run run = runs[r];
-    if (need) {  // cNSM: clear the replay scratch of this run (flags per window, windows-to-replay count)
-        for (int i = lane; i < run.count; i += 64) need[run.win_base + i] = 0;
-        if (lane == 0) run_maxk[r] = 0;
-    }
+    if (run_maxk && lane == 0) run_maxk[r] = 0;  // cNSM: clear the replay scratch of this run (windows-to-replay count)
     const int nt = (run.count + tile_max - 1) / tile_max;
     for (int t = lane; t < nt; t += 64) {
         kvm_tile tl;
@@ -151,10 +142,10 @@ __global__ __launch_bounds__(256) void kvm_expand_tiles_kernel(const kvm_run *__
 }
 
 hipError_t kvm_launch_expand_tiles(const kvm_run *runs, int64_t n_runs, int32_t tile_max, kvm_tile *tiles,
-                                   unsigned long long *counters, unsigned char *need, int32_t *run_maxk, hipStream_t s) {
+                                   unsigned long long *counters, int32_t *run_maxk, hipStream_t s) {
     if (n_runs <= 0) return hipSuccess;
     hipLaunchKernelGGL(kvm_expand_tiles_kernel, dim3((unsigned)((n_runs + 3) / 4)), dim3(256), 0, s, runs, n_runs,
-                       tile_max, tiles, counters, need, run_maxk);
+                       tile_max, tiles, counters, run_maxk);
     return hipGetLastError();
 }
 

@@ -179,7 +179,6 @@ __global__ __launch_bounds__(256) void kvm_replay_mark_kernel(const REC *__restr
         if (rec.start < 0) continue;
         const int64_t r = ex_find_run(ws.runs, ws.n_runs, rec.run_start);
         const int32_t k = rec.start - rec.run_start;
-        ws.need[ws.runs[r].win_base + k] = 1;
         if (atomicMax(&ws.run_maxk[r], k + 1) == 0)  // first mark of this run: queue it for the replay
             ws.run_list[atomicAdd(ws.run_list_n, 1ULL)] = (int32_t)r;
     }

@@ -31,12 +31,11 @@ struct kvm_run {
     int64_t win_base;   // ordinal of the run's first window among all windows of the query (exclusive prefix of counts)
 };
 
-// Scratch of the running-sum replay (kvm_exact.hip): one flag and one {mean, std} slot per window of the query,
-// one "windows needed" count per run.
+// Scratch of the running-sum replay (kvm_exact.hip): one {ex, ex2} slot per window of the query, one "windows
+// needed" count per run, the queue of runs to replay.
 struct kvm_replay_ws {
     const kvm_run *runs;
     int64_t n_runs;
-    unsigned char *need;   // [windows] 1 = some survivor needs the reference's mean/std of this window
     int32_t *run_maxk;     // [n_runs]  number of leading windows of the run that must be replayed (0 = none)
     double2 *stats;        // [windows] {ex, ex2}: the reference's running sums when the flagged window completes
     int32_t *run_list;     // [n_runs]  indices of the runs with run_maxk > 0, in marking order
@@ -107,13 +106,12 @@ struct kvm_result {
 // ---- kernel launchers (each file implements its own) -----------------------------------------------
 // common
 hipError_t kvm_launch_bswap64(uint64_t *d, int64_t n, hipStream_t s);
-// (both expansion kernels also zero the KVM_CNT_TOTAL counters and, when `need` is given, the replay scratch)
+// (both expansion kernels also zero the KVM_CNT_TOTAL counters and, when `run_maxk` is given, the replay scratch)
 hipError_t kvm_launch_expand_tiles(const kvm_run *runs, int64_t n_runs, int32_t tile_max, kvm_tile *tiles,
-                                   unsigned long long *counters, unsigned char *need, int32_t *run_maxk, hipStream_t s);
+                                   unsigned long long *counters, int32_t *run_maxk, hipStream_t s);
 // hybrid ED tiling: class A = 64-candidate tiles (full tiles and remainders > 32), class B = remainders <= 32
 hipError_t kvm_launch_expand_tiles_hybrid(const kvm_run *runs, int64_t n_runs, kvm_tile *tilesA, kvm_tile *tilesB,
-                                          unsigned long long *counters, unsigned char *need, int32_t *run_maxk,
-                                          hipStream_t s);
+                                          unsigned long long *counters, int32_t *run_maxk, hipStream_t s);
 hipError_t kvm_launch_prefix(const double *x, double2 *prefix, int64_t n, hipStream_t s);
 // counters + the first `spec` answers, stored straight into device-mapped pinned host memory:
 // [KVM_CNT_TOTAL x u64 | spec x int32 | spec x f64]

@@ -11,12 +11,11 @@ int main() {
     double *x; hipMalloc(&x, n * 8); hipMemcpy(x, h.data(), n * 8, hipMemcpyHostToDevice);
     kvm_run run{1, 1, 0, -1, 0};
     kvm_run *d_runs; hipMalloc(&d_runs, sizeof run); hipMemcpy(d_runs, &run, sizeof run, hipMemcpyHostToDevice);
-    unsigned char *need; hipMalloc(&need, 64); hipMemset(need, 1, 64);
     int32_t one = 1, zero = 0, *maxk, *list; hipMalloc(&maxk, 4); hipMalloc(&list, 4);
     hipMemcpy(maxk, &one, 4, hipMemcpyHostToDevice); hipMemcpy(list, &zero, 4, hipMemcpyHostToDevice);
     unsigned long long n1 = 1, *d_n; hipMalloc(&d_n, 8); hipMemcpy(d_n, &n1, 8, hipMemcpyHostToDevice);
     double2 *stats; hipMalloc(&stats, 1024);
-    kvm_replay_ws ws{d_runs, 1, need, maxk, stats, list, d_n};
+    kvm_replay_ws ws{d_runs, 1, maxk, stats, list, d_n};
     for (int rep = 0; rep < 3; rep++) {
         hipLaunchKernelGGL(kvm_replay_runs_kernel, dim3(1), dim3(EX_THREADS), 0, 0, x, m, ws);
         hipDeviceSynchronize();
