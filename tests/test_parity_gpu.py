@@ -545,6 +545,32 @@ def test_many_answers_and_tiny_series(world):
             oracle.cnsm_dtw(t, qq, Ls, Rs, 0, 2.0, 4, 2.0, 5.0), tag="tiny dtw")
 
 
+def test_cnsm_ed_scattered_filter_passes_retile_and_split(world):
+    """cNSM-ED with a filter that passes scattered, short stretches of each run: the device-side retile (trimmed tiles,
+    class A/B lists built with atomics), the device-side window-split decision and the early abandon over ranges all
+    have to agree with the oracle, whatever the (nondeterministic) order of the lists."""
+    kvmatch, datagen, series, ctx = world
+    rng = np.random.default_rng(99)
+    n = 120_000
+    # noise whose level and spread change every few hundred points: mean/std of a short window jump around, so the
+    # (alpha, beta) filter passes isolated windows and short stretches
+    seg = rng.integers(150, 600, 400)
+    s = np.concatenate([rng.normal(rng.uniform(-2, 2), rng.uniform(0.3, 2.0), int(k)) for k in seg])[:n].copy()
+    n = len(s)
+    for m, eps, alpha, beta in [(64, 7.0, 1.04, 0.15), (200, 14.0, 1.02, 0.1), (1000, 35.0, 1.01, 0.05), (3000, 60.0, 1.005, 0.03)]:
+        qoff = int(rng.integers(1, n - m))
+        q = datagen.plant_copies(s, qoff, m, [int(rng.integers(1, n - m))], [1.0], [0.0], 0.01, seed=m)
+        ctx.load_series(s)
+        L, R = datagen.gen_intervals(n, m, 30_000, 300.0, must_cover=[qoff], seed=m)
+        want = oracle.cnsm_ed(s, q, L, R, 0, eps, alpha, beta)
+        for ab in (1, 0):
+            ctx.set_option(kvmatch.OPT_EARLY_ABANDON, ab)
+            got = kvmatch.NormQueryEngine(ctx).verify((L, R), 1, q, eps, alpha, beta)
+            compare(got, want, tag=f"scattered m={m} abandon={ab}")
+            assert 0 < got.stats[1] < got.stats[0] / 2  # the filter really is selective here
+    ctx.set_option(kvmatch.OPT_EARLY_ABANDON, 1)
+
+
 def test_window_means_for_index_build(world):
     """sliding means for w in WuList = {25, 50, 100, 200, 400} (K/IndexBuilder.java) from the prefix
     sums; compared with exactly-rounded sums (math.fsum) and with the reference's running-sum loop restated in numpy."""
