@@ -11,15 +11,43 @@ single-GPU path sorts (K/QueryEngine.java:373).
 import numpy as np
 
 
-def split_intervals(left, right, world, rank):
-    """Contiguous shard `rank` of `world` of the candidate list, balanced by candidate count.
+def split_intervals(left, right, world, rank, mode="auto"):
+    """Shard `rank` of `world` of the candidate list, balanced by candidate count.  Returns (left, right) int32 arrays;
+    every candidate offset appears in exactly one shard and cntCandidate summed over shards equals the unsharded one.
 
-    Returns (left, right) int32 arrays.  Intervals are cut where a shard boundary falls inside them; the pieces of a
-    cut interval are adjacent (not merged) which is fine for phase 2: every candidate offset appears in exactly
-    one shard.  cntCandidate summed over shards equals the unsharded cntCandidate."""
+    mode "interleaved": whole intervals are dealt out, always to the rank holding the fewest candidates so far among
+        the next `world` intervals (a round of the deal), so neighbouring intervals land on different ranks.  The
+        expensive candidates of a DTW query cluster around the matches (a few adjacent intervals carry all the DPs),
+        so this is what balances the GPUs; and because no interval is cut, a sharded cNSM run restarts its running sums
+        exactly where the unsharded one does (bit-identical answers).
+    mode "contiguous": contiguous slices of the candidate sequence, cut inside an interval where a boundary falls
+        (the pieces of a cut interval are adjacent, not merged); exact balance even for a handful of long intervals.
+    mode "auto" (default): interleaved when there are at least 8 intervals per rank, else contiguous."""
     left = np.asarray(left, dtype=np.int64)
     right = np.asarray(right, dtype=np.int64)
     counts = np.maximum(right - left + 1, 0)
+    k = len(left)
+    if mode == "auto":
+        mode = "interleaved" if k >= 8 * world else "contiguous"
+    if mode == "interleaved":
+        if world == 1:
+            keep = counts > 0
+            return left[keep].astype(np.int32), right[keep].astype(np.int32)
+        # rounds of `world` consecutive intervals; inside a round the longest interval goes to the rank that is
+        # lightest so far.  Vectorised: ranks sorted by load (ascending) meet the round's intervals sorted by length
+        # (descending).  The loads stay within one interval length of each other.
+        owner = np.empty(k, dtype=np.int64)
+        load = np.zeros(world, dtype=np.int64)
+        for base in range(0, k, world):
+            c = counts[base:base + world]
+            by_len = np.argsort(-c, kind="stable")
+            by_load = np.argsort(load, kind="stable")[:len(c)]
+            owner[base + by_len] = by_load
+            np.add.at(load, by_load, c[by_len])
+        mine = (owner == rank) & (counts > 0)
+        return left[mine].astype(np.int32), right[mine].astype(np.int32)
+    if mode != "contiguous":
+        raise ValueError("mode must be 'auto', 'interleaved' or 'contiguous'")
     total = int(counts.sum())
     lo = (total * rank) // world        # first global candidate index of this shard
     hi = (total * (rank + 1)) // world  # one past the last

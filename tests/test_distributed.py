@@ -28,10 +28,23 @@ def test_split_intervals_partitions_every_candidate_once(built):
             left = np.cumsum(gaps + np.concatenate(([0], lens[:-1]))).astype(np.int32)
             right = (left + lens - 1).astype(np.int32)
             allc = np.concatenate([np.arange(l, r + 1) for l, r in zip(left, right)])
+            for mode in ("interleaved", "auto"):
+                parts, sizes = [], []
+                for rank in range(world):
+                    l, r = D.split_intervals(left, right, world, rank, mode=mode)
+                    assert np.all(r >= l) and np.all(np.diff(l) > 0)   # still sorted and disjoint
+                    if mode == "interleaved":  # whole intervals only
+                        assert set(zip(l.tolist(), r.tolist())) <= set(zip(left.tolist(), right.tolist()))
+                    c = np.concatenate([np.arange(a, b + 1) for a, b in zip(l, r)]) if len(l) else np.empty(0, int)
+                    parts.append(c)
+                    sizes.append(len(c))
+                assert np.array_equal(np.sort(np.concatenate(parts)), allc)   # nothing lost or duplicated
+                if mode == "interleaved":
+                    assert max(sizes) - min(sizes) <= int(lens.max())         # balanced to one interval
             got = []
             sizes = []
             for rank in range(world):
-                l, r = D.split_intervals(left, right, world, rank)
+                l, r = D.split_intervals(left, right, world, rank, mode="contiguous")
                 assert np.all(r >= l)
                 c = np.concatenate([np.arange(a, b + 1) for a, b in zip(l, r)]) if len(l) else np.empty(0, int)
                 sizes.append(len(c))
