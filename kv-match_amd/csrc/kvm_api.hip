@@ -460,8 +460,9 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
     const int ed_kernel = ctx->opt_ed_kernel != 0 ? (int)ctx->opt_ed_kernel : (env_ed_kernel ? env_ed_kernel : 3);
     auto tp_ = std::chrono::steady_clock::now();
     // 32-candidate tiles for the LDS-tiled kernels (ED pruners, fused DTW lower-bound stage), 64 otherwise
+    // (DTW cascade: 64-candidate tiles first, trimmed and cut to <= 32 on the device by kvm_retile_dtw_kernel)
     const int32_t tile_max = (!dtw && ed_kernel == 4) ? 16 : (cnsm && !dtw && ed_kernel == 3) ? KVM_TILE_MAX
-                             : ((!dtw && ed_kernel >= 2) || (dtw && ctx->opt_lb_cascade)) ? KVM_TILE_TILED : KVM_TILE_MAX;
+                             : (!dtw && ed_kernel >= 2) ? KVM_TILE_TILED : KVM_TILE_MAX;
     // cNSM-ED with the dot pruner: uniform 64-candidate tiles first, trimmed and classified on the device by the filter
     const bool retile = cnsm && !dtw && ed_kernel == 3;
     const bool hybrid = !dtw && ed_kernel == 3 && !retile;
@@ -528,7 +529,7 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
         qpref8[(size_t)nchunks8] = make_double2(p1, p2);
     }
     const size_t rbytes = (size_t)pl.n_runs * sizeof(kvm_run);
-    const size_t tbytes = (size_t)(retile ? 3 * pl.n_tiles : pl.n_tiles + pl.n_tiles_b) * sizeof(kvm_tile);
+    const size_t tbytes = (size_t)((retile || dtw) ? 3 * pl.n_tiles : pl.n_tiles + pl.n_tiles_b) * sizeof(kvm_tile);
     // (KVM_SERIES_PAD spare doubles after q: the tiled ED kernel stages whole query chunks without bounds checks)
     if ((rc = ensure(ctx, ctx->b_query, qbytes + rbytes + 64))) return rc;
     if ((rc = ensure(ctx, ctx->b_tiles, tbytes + 64))) return rc;
@@ -682,9 +683,14 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
         const int use_lb = (int)ctx->opt_lb_cascade;
         if ((rc = ensure(ctx, ctx->b_cands, (size_t)pl.windows * sizeof(kvm_cand) + 64))) return rc;
         kvm_cand *c1 = (kvm_cand *)ctx->b_cands.p;
-        if (use_lb)  // fused, LDS-tiled: (alpha, beta) filter + LB_Kim + LB_Keogh(query envelope) over all candidates
-            HIPCHK(ctx, kvm_launch_dtw_lb_tiled(ctx->d_series, ctx->d_prefix, ctx->n, qd, d_tiles, n_tiles, c1, counters,
-                                                stream));
+        if (use_lb) {
+            // (alpha, beta) filter + LB_Kim for every candidate, survivors re-tiled on the device; then the fused,
+            // LDS-tiled LB_Keogh(query envelope) over the trimmed tiles
+            kvm_tile *t2 = (kvm_tile *)ctx->b_tiles.p + n_tiles;  // room for 2 n_tiles entries
+            HIPCHK(ctx, kvm_launch_retile_dtw(ctx->d_series, ctx->d_prefix, qd, d_tiles, n_tiles, t2, counters, stream));
+            HIPCHK(ctx, kvm_launch_dtw_lb_tiled(ctx->d_series, ctx->d_prefix, ctx->n, qd, t2, 2 * n_tiles, c1, counters,
+                                                counters + KVM_CNT_TILES_A, stream));
+        }
         else
             HIPCHK(ctx, kvm_launch_dtw_filter(ctx->d_series, ctx->d_prefix, ctx->n, qd, d_tiles, n_tiles, 0, c1,
                                               counters, stream));

@@ -28,18 +28,76 @@ typedef double lb4_d2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ double lb4_dsq(double a, double b) { return (a - b) * (a - b); }
 
+// LB_Kim, K/utils/DtwUtils.java:149-189 (the full bound, no early returns); tt = first point of the window.
+__device__ __forceinline__ double lb4_kim(const double *__restrict__ tt, const double *__restrict__ q, int m, double mu, double s) {
+    double d, l;
+    const double x0 = (tt[0] - mu) / s, y0 = (tt[m - 1] - mu) / s;
+    l = lb4_dsq(x0, q[0]) + lb4_dsq(y0, q[m - 1]);
+    const double x1 = (tt[1] - mu) / s;
+    d = fmin(lb4_dsq(x1, q[0]), lb4_dsq(x0, q[1]));
+    d = fmin(d, lb4_dsq(x1, q[1]));
+    l += d;
+    const double y1 = (tt[m - 2] - mu) / s;
+    d = fmin(lb4_dsq(y1, q[m - 1]), lb4_dsq(y0, q[m - 2]));
+    d = fmin(d, lb4_dsq(y1, q[m - 2]));
+    l += d;
+    const double x2 = (tt[2] - mu) / s;
+    d = fmin(lb4_dsq(x0, q[2]), lb4_dsq(x1, q[2]));
+    d = fmin(d, lb4_dsq(x2, q[2]));
+    d = fmin(d, lb4_dsq(x2, q[1]));
+    d = fmin(d, lb4_dsq(x2, q[0]));
+    l += d;
+    const double y2 = (tt[m - 3] - mu) / s;
+    d = fmin(lb4_dsq(y0, q[m - 3]), lb4_dsq(y1, q[m - 3]));
+    d = fmin(d, lb4_dsq(y2, q[m - 3]));
+    d = fmin(d, lb4_dsq(y2, q[m - 2]));
+    d = fmin(d, lb4_dsq(y2, q[m - 1]));
+    l += d;
+    return l;
+}
+
+// (alpha, beta) filter + LB_Kim of one candidate with the pruning arithmetic (prefix-sum mean/std, guard bands); also
+// returns the values stage 1 keeps per candidate.  `w0` = 0-based window start.
+template <bool NORM>
+__device__ __forceinline__ void lb4_prefilter(const double *__restrict__ series, const double2 *__restrict__ prefix,
+                                              const kvm_query_dev &qd, int64_t w0, bool &pass_filter, bool &pass_kim,
+                                              double &mean, double &sd, double &inv, double &nmi, double &lim) {
+    const int m = qd.m;
+    mean = 0.0; sd = 1.0; inv = 1.0; nmi = 0.0;
+    lim = qd.eps2 * (1.0 + 1e-9);
+    pass_filter = true;
+    if (NORM) {
+        kvm_window_mean_std(prefix, series, w0, m, mean, sd);
+        const double g = kvm_sigma_guard(mean, sd);
+        pass_filter = kvm_cnsm_filter_guarded(mean, sd, qd.meanQ, qd.stdQ, qd.alpha, qd.beta, g);
+        lim = qd.eps2 + kvm_eps2_slack(qd.eps2, m, g, 16.0);
+        if (!(sd == sd) || !(sd > 0.0)) {  // degenerate sigma: no bound, the exact pass decides
+            sd = __builtin_nan("");
+            lim = __builtin_huge_val();
+            inv = 0.0;
+            nmi = 0.0;
+        } else {
+            inv = 1.0 / sd;
+            nmi = -mean * inv;
+        }
+    }
+    pass_kim = pass_filter;
+    if (pass_filter && m >= 6 && sd == sd) pass_kim = lb4_kim(series + w0, qd.q, m, mean, sd) <= lim;
+}
+
 template <bool NORM>
 __global__ __launch_bounds__(256, 2) void kvm_dtw_lb_tiled_kernel(const double *__restrict__ series,
                                                                   const double2 *__restrict__ prefix, kvm_query_dev qd,
                                                                   const kvm_tile *__restrict__ tiles, int64_t n_tiles,
                                                                   kvm_cand *__restrict__ out,
-                                                                  unsigned long long *__restrict__ counters) {
+                                                                  unsigned long long *__restrict__ counters,
+                                                                  const unsigned long long *__restrict__ d_n_tiles) {
     __shared__ __attribute__((aligned(256))) double2 lds_all2[4 * LB4_WAVE_LDS / 2];
+    if (d_n_tiles) n_tiles = (int64_t)*d_n_tiles;  // tile list built on the device: the launch only knows a bound
     double *lds_all = reinterpret_cast<double *>(lds_all2);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int row = lane >> 3, lc = lane & 7;
     const int m = qd.m;
-    const double *__restrict__ q = qd.q;
     double *wlds = lds_all + wave * LB4_WAVE_LDS;
     double *ulds = wlds + LB4_ROWS * LB4_RS, *llds = ulds + LB4_ROWLEN;
     const int nchunks = (m + LB4_JC - 1) / LB4_JC;
@@ -64,54 +122,12 @@ __global__ __launch_bounds__(256, 2) void kvm_dtw_lb_tiled_kernel(const double *
         mean[a] = 0.0; sd[a] = 1.0; inv[a] = 1.0; nmi[a] = 0.0; lb[a] = 0.0;
         lim[a] = qd.eps2 * (1.0 + 1e-9);
         if (v[a]) {
-            const int64_t w0 = (int64_t)mine.start - 1 + c0 + a;  // 0-based window start
-            if (NORM) {
-                kvm_window_mean_std(prefix, series, w0, m, mean[a], sd[a]);
-                const double g = kvm_sigma_guard(mean[a], sd[a]);
-                v[a] = kvm_cnsm_filter_guarded(mean[a], sd[a], qd.meanQ, qd.stdQ, qd.alpha, qd.beta, g);
-                lim[a] = qd.eps2 + kvm_eps2_slack(qd.eps2, m, g, 16.0);
-                if (!(sd[a] == sd[a]) || !(sd[a] > 0.0)) {  // degenerate sigma: no bound, the exact pass decides
-                    sd[a] = __builtin_nan("");
-                    lim[a] = __builtin_huge_val();
-                    inv[a] = 0.0;
-                    nmi[a] = 0.0;
-                } else {
-                    inv[a] = 1.0 / sd[a];
-                    nmi[a] = -mean[a] * inv[a];
-                }
-            }
-            if (v[a]) {
-                n_filter++;
-                if (m >= 6 && sd[a] == sd[a]) {  // LB_Kim, K/utils/DtwUtils.java:149-189 (full bound, no early returns)
-                    const double *__restrict__ tt = series + w0;
-                    const double mu = mean[a], s = sd[a];
-                    double d, l;
-                    const double x0 = (tt[0] - mu) / s, y0 = (tt[m - 1] - mu) / s;
-                    l = lb4_dsq(x0, q[0]) + lb4_dsq(y0, q[m - 1]);
-                    const double x1 = (tt[1] - mu) / s;
-                    d = fmin(lb4_dsq(x1, q[0]), lb4_dsq(x0, q[1]));
-                    d = fmin(d, lb4_dsq(x1, q[1]));
-                    l += d;
-                    const double y1 = (tt[m - 2] - mu) / s;
-                    d = fmin(lb4_dsq(y1, q[m - 1]), lb4_dsq(y0, q[m - 2]));
-                    d = fmin(d, lb4_dsq(y1, q[m - 2]));
-                    l += d;
-                    const double x2 = (tt[2] - mu) / s;
-                    d = fmin(lb4_dsq(x0, q[2]), lb4_dsq(x1, q[2]));
-                    d = fmin(d, lb4_dsq(x2, q[2]));
-                    d = fmin(d, lb4_dsq(x2, q[1]));
-                    d = fmin(d, lb4_dsq(x2, q[0]));
-                    l += d;
-                    const double y2 = (tt[m - 3] - mu) / s;
-                    d = fmin(lb4_dsq(y0, q[m - 3]), lb4_dsq(y1, q[m - 3]));
-                    d = fmin(d, lb4_dsq(y2, q[m - 3]));
-                    d = fmin(d, lb4_dsq(y2, q[m - 2]));
-                    d = fmin(d, lb4_dsq(y2, q[m - 1]));
-                    l += d;
-                    v[a] = l <= lim[a];
-                }
-                if (v[a]) n_kim++;
-            }
+            bool pf, pk;
+            lb4_prefilter<NORM>(series, prefix, qd, (int64_t)mine.start - 1 + c0 + a, pf, pk, mean[a], sd[a], inv[a], nmi[a],
+                                lim[a]);
+            n_filter += pf;
+            n_kim += pk;
+            v[a] = pk;
         }
     }
     {
@@ -122,7 +138,7 @@ __global__ __launch_bounds__(256, 2) void kvm_dtw_lb_tiled_kernel(const double *
             f += __shfl_xor(f, o, 64);
             k += __shfl_xor(k, o, 64);
         }
-        if (lane == 0) {
+        if (lane == 0 && !d_n_tiles) {  // (with device-built tiles the retile kernel has counted every candidate)
             if (NORM && f) atomicAdd(&counters[KVM_CNT_PASS_FILTER], (unsigned long long)f);
             if (k) atomicAdd(&counters[KVM_CNT_PASS_KIM], (unsigned long long)k);
         }
@@ -224,17 +240,95 @@ __global__ __launch_bounds__(256, 2) void kvm_dtw_lb_tiled_kernel(const double *
     }
 }
 
+// DTW retile: the (alpha, beta) filter and LB_Kim for EVERY candidate, one lane each (64 candidates of a tile in
+// parallel: stage 1 above evaluates them four per lane, one after the other, which made it the slowest kernel of a
+// query with few answers), then every 64-candidate tile is trimmed to the span of its survivors, cut into <= 32-candidate
+// tiles for stage 1 and appended to a device-side list (64 tiles per workgroup collected in LDS, one global atomic).
+template <bool NORM>
+__global__ __launch_bounds__(256) void kvm_retile_dtw_kernel(const double *__restrict__ series,
+                                                             const double2 *__restrict__ prefix, kvm_query_dev qd,
+                                                             const kvm_tile *__restrict__ tiles, int64_t n_tiles,
+                                                             kvm_tile *__restrict__ out_tiles,
+                                                             unsigned long long *__restrict__ counters) {
+    __shared__ kvm_tile outs[2 * 64];
+    __shared__ int n_out;
+    __shared__ unsigned n_f, n_k;
+    __shared__ unsigned long long base;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) {
+        n_out = 0;
+        n_f = 0;
+        n_k = 0;
+    }
+    __syncthreads();
+    const int64_t t0 = (int64_t)blockIdx.x * 64 + wave * 16;
+    unsigned cf = 0, ck = 0;
+    for (int i = 0; i < 16; i++) {
+        const int64_t t = t0 + i;
+        if (t >= n_tiles) break;  // wave-uniform
+        const kvm_tile tl = tiles[t];
+        bool pf = false, pk = false;
+        if (lane < tl.count) {
+            double mean, sd, inv, nmi, lim;
+            lb4_prefilter<NORM>(series, prefix, qd, (int64_t)tl.start - 1 + lane, pf, pk, mean, sd, inv, nmi, lim);
+        }
+        const unsigned long long mf = __ballot(pf), mk = __ballot(pk);
+        cf += (unsigned)__popcll(mf);
+        ck += (unsigned)__popcll(mk);
+        if (mk != 0 && lane == 0) {
+            const int first = __ffsll((long long)mk) - 1, last = 63 - __clzll((long long)mk);
+            kvm_tile o;
+            o.run_start = tl.run_start;
+            o.pad = 0;
+            o.start = tl.start + first;
+            o.count = min(32, last - first + 1);
+            outs[atomicAdd(&n_out, 1)] = o;
+            if (last - first + 1 > 32) {
+                o.start = tl.start + first + 32;
+                o.count = last - first + 1 - 32;
+                outs[atomicAdd(&n_out, 1)] = o;
+            }
+        }
+    }
+    if (lane == 0) {
+        if (cf) atomicAdd(&n_f, cf);
+        if (ck) atomicAdd(&n_k, ck);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        base = n_out ? atomicAdd(&counters[KVM_CNT_TILES_A], (unsigned long long)n_out) : 0;
+        if (NORM && n_f) atomicAdd(&counters[KVM_CNT_PASS_FILTER], (unsigned long long)n_f);
+        if (n_k) atomicAdd(&counters[KVM_CNT_PASS_KIM], (unsigned long long)n_k);
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < n_out) out_tiles[base + threadIdx.x] = outs[threadIdx.x];
+}
+
+hipError_t kvm_launch_retile_dtw(const double *series, const double2 *prefix, const kvm_query_dev &qd, const kvm_tile *tiles,
+                                 int64_t n_tiles, kvm_tile *out_tiles, unsigned long long *counters, hipStream_t s) {
+    if (n_tiles <= 0) return hipSuccess;
+    const dim3 grid((unsigned)((n_tiles + 63) / 64));
+    if (qd.normalised)
+        hipLaunchKernelGGL((kvm_retile_dtw_kernel<true>), grid, dim3(256), 0, s, series, prefix, qd, tiles, n_tiles, out_tiles,
+                           counters);
+    else
+        hipLaunchKernelGGL((kvm_retile_dtw_kernel<false>), grid, dim3(256), 0, s, series, prefix, qd, tiles, n_tiles, out_tiles,
+                           counters);
+    return hipGetLastError();
+}
+
+// `d_n_tiles` != nullptr: `tiles` was built on the device and holds *d_n_tiles entries; `n_tiles` is then an upper bound.
 hipError_t kvm_launch_dtw_lb_tiled(const double *series, const double2 *prefix, int64_t n, const kvm_query_dev &qd,
                                    const kvm_tile *tiles, int64_t n_tiles, kvm_cand *out, unsigned long long *counters,
-                                   hipStream_t s) {
+                                   const unsigned long long *d_n_tiles, hipStream_t s) {
     (void)n;
     if (n_tiles <= 0) return hipSuccess;
     const int64_t blocks = (n_tiles + 4 * LB4_ROWS - 1) / (4 * LB4_ROWS);
     if (qd.normalised)
         hipLaunchKernelGGL((kvm_dtw_lb_tiled_kernel<true>), dim3((unsigned)blocks), dim3(256), 0, s, series, prefix, qd, tiles,
-                           n_tiles, out, counters);
+                           n_tiles, out, counters, d_n_tiles);
     else
         hipLaunchKernelGGL((kvm_dtw_lb_tiled_kernel<false>), dim3((unsigned)blocks), dim3(256), 0, s, series, prefix, qd,
-                           tiles, n_tiles, out, counters);
+                           tiles, n_tiles, out, counters, d_n_tiles);
     return hipGetLastError();
 }
