@@ -689,7 +689,7 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
             kvm_tile *t2 = (kvm_tile *)ctx->b_tiles.p + n_tiles;  // room for 2 n_tiles entries
             HIPCHK(ctx, kvm_launch_retile_dtw(ctx->d_series, ctx->d_prefix, qd, d_tiles, n_tiles, t2, counters, stream));
             HIPCHK(ctx, kvm_launch_dtw_lb_tiled(ctx->d_series, ctx->d_prefix, ctx->n, qd, t2, 2 * n_tiles, c1, counters,
-                                                counters + KVM_CNT_TILES_A, stream));
+                                                counters + KVM_CNT_TILES_A, ctx->num_cu, stream));
         }
         else
             HIPCHK(ctx, kvm_launch_dtw_filter(ctx->d_series, ctx->d_prefix, ctx->n, qd, d_tiles, n_tiles, 0, c1,

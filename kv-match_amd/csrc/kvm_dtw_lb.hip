@@ -91,7 +91,8 @@ __global__ __launch_bounds__(256, 2) void kvm_dtw_lb_tiled_kernel(const double *
                                                                   const kvm_tile *__restrict__ tiles, int64_t n_tiles,
                                                                   kvm_cand *__restrict__ out,
                                                                   unsigned long long *__restrict__ counters,
-                                                                  const unsigned long long *__restrict__ d_n_tiles) {
+                                                                  const unsigned long long *__restrict__ d_n_tiles,
+                                                                  int64_t split_units) {
     __shared__ __attribute__((aligned(256))) double2 lds_all2[4 * LB4_WAVE_LDS / 2];
     if (d_n_tiles) n_tiles = (int64_t)*d_n_tiles;  // tile list built on the device: the launch only knows a bound
     double *lds_all = reinterpret_cast<double *>(lds_all2);
@@ -102,8 +103,16 @@ __global__ __launch_bounds__(256, 2) void kvm_dtw_lb_tiled_kernel(const double *
     double *ulds = wlds + LB4_ROWS * LB4_RS, *llds = ulds + LB4_ROWLEN;
     const int nchunks = (m + LB4_JC - 1) / LB4_JC;
 
-    const int64_t t0 = ((int64_t)blockIdx.x * 4 + wave) * LB4_ROWS;
-    if (t0 >= n_tiles) return;
+    // Window split (as in kvm_ed_dot.hip): when the tile list is short -- a query with few answers leaves a few hundred
+    // candidates, and a lone wavefront needs ~0.25 ms for the m points of one that survives to the end -- the four waves
+    // of a workgroup share one unit of 8 tiles, each summing a quarter of the chunks (lower bounds are sums of
+    // non-negative terms); parts 1..3 hand their partial sums to part 0 through LDS behind one workgroup barrier.
+    const int64_t units = (n_tiles + LB4_ROWS - 1) / LB4_ROWS;
+    const int f = units <= split_units ? 4 : 1;
+    const int64_t slot = (int64_t)blockIdx.x * 4 + wave;
+    const int part = (int)(slot % f);
+    const int64_t t0 = (slot / f) * LB4_ROWS;
+    if (t0 >= n_tiles) return;  // (f == 4: the whole workgroup leaves; f == 1: no barrier below)
     int32_t rstart[LB4_ROWS];
 #pragma unroll
     for (int r = 0; r < LB4_ROWS; r++) rstart[r] = (t0 + r < n_tiles) ? tiles[t0 + r].start : 1;
@@ -115,6 +124,7 @@ __global__ __launch_bounds__(256, 2) void kvm_dtw_lb_tiled_kernel(const double *
     // ---- per candidate: mean/std, (alpha, beta) filter, LB_Kim ----
     bool v[4];
     double mean[4], sd[4], inv[4], nmi[4], lim[4], lb[4];
+    bool work = true;  // wave-uniform
     unsigned n_filter = 0, n_kim = 0;
 #pragma unroll
     for (int a = 0; a < 4; a++) {
@@ -138,11 +148,12 @@ __global__ __launch_bounds__(256, 2) void kvm_dtw_lb_tiled_kernel(const double *
             f += __shfl_xor(f, o, 64);
             k += __shfl_xor(k, o, 64);
         }
-        if (lane == 0 && !d_n_tiles) {  // (with device-built tiles the retile kernel has counted every candidate)
+        if (lane == 0 && !d_n_tiles && part == 0) {  // (with device-built tiles the retile kernel has counted every candidate)
             if (NORM && f) atomicAdd(&counters[KVM_CNT_PASS_FILTER], (unsigned long long)f);
             if (k) atomicAdd(&counters[KVM_CNT_PASS_KIM], (unsigned long long)k);
         }
-        if (k == 0) return;  // nothing left in this wave
+        if (k == 0 && f == 1) return;  // nothing left in this wave
+        work = k != 0;
     }
 
     // ---- LB_Keogh on the query envelope, tiled ----
@@ -180,15 +191,18 @@ __global__ __launch_bounds__(256, 2) void kvm_dtw_lb_tiled_kernel(const double *
         lb[a] = __builtin_fma(t_, t_, lb[a]);                                         \
     } while (0)
 
-    load_chunk(0);
-    store_chunk();
+    const int ch_lo = nchunks * part / f, ch_hi = nchunks * (part + 1) / f;
+    if (work && ch_lo < ch_hi) {
+        load_chunk(ch_lo * LB4_JC);
+        store_chunk();
+    }
     const lb4_d2 *X2 = reinterpret_cast<const lb4_d2 *>(lds_all2) +
                        (wave * (LB4_WAVE_LDS / 2) + row * (LB4_RS / 2) + ((row >> 1) & 1) + 2 * lc);
     const lb4_d2 *U2 = reinterpret_cast<const lb4_d2 *>(lds_all2) + (wave * (LB4_WAVE_LDS / 2) + LB4_ROWS * (LB4_RS / 2));
     const lb4_d2 *L2 = U2 + LB4_ROWLEN / 2;
-    for (int ch = 0; ch < nchunks; ch++) {
+    for (int ch = ch_lo; work && ch < ch_hi; ch++) {
         const int j0 = ch * LB4_JC;
-        const bool more = ch + 1 < nchunks;
+        const bool more = ch + 1 < ch_hi;
         if (more) load_chunk(j0 + LB4_JC);
         const int jlim = min(LB4_JC, m - j0);
         if (jlim == LB4_JC) {
@@ -215,11 +229,26 @@ __global__ __launch_bounds__(256, 2) void kvm_dtw_lb_tiled_kernel(const double *
             bool alive = false;
 #pragma unroll
             for (int a = 0; a < 4; a++) alive |= v[a] && lb[a] <= lim[a];
-            if (!__any(alive)) return;  // lower bounds only grow
+            if (!__any(alive)) {  // lower bounds only grow: this part's own sum already rules every candidate out
+                if (f == 1) return;
+                break;
+            }
             store_chunk();
         }
     }
 #undef LB4_TERM
+    if (f > 1) {
+        if (part > 0 && work) {
+#pragma unroll
+            for (int a = 0; a < 4; a++) wlds[a * 64 + lane] = lb[a];
+        }
+        __syncthreads();
+        if (part > 0 || !work) return;
+        for (int p = 1; p < f; p++) {
+#pragma unroll
+            for (int a = 0; a < 4; a++) lb[a] += wlds[p * LB4_WAVE_LDS + a * 64 + lane];
+        }
+    }
     // survivors of the filter, LB_Kim and LB_Keogh(query envelope): wave-aggregated append
 #pragma unroll
     for (int a = 0; a < 4; a++) {
@@ -317,18 +346,24 @@ hipError_t kvm_launch_retile_dtw(const double *series, const double2 *prefix, co
     return hipGetLastError();
 }
 
-// `d_n_tiles` != nullptr: `tiles` was built on the device and holds *d_n_tiles entries; `n_tiles` is then an upper bound.
+// `d_n_tiles` != nullptr: `tiles` was built on the device and holds *d_n_tiles entries; `n_tiles` is then an upper bound
+// and the kernel splits the window over the four waves of a workgroup when the real list is short.
 hipError_t kvm_launch_dtw_lb_tiled(const double *series, const double2 *prefix, int64_t n, const kvm_query_dev &qd,
                                    const kvm_tile *tiles, int64_t n_tiles, kvm_cand *out, unsigned long long *counters,
-                                   const unsigned long long *d_n_tiles, hipStream_t s) {
+                                   const unsigned long long *d_n_tiles, int num_cu, hipStream_t s) {
     (void)n;
     if (n_tiles <= 0) return hipSuccess;
-    const int64_t blocks = (n_tiles + 4 * LB4_ROWS - 1) / (4 * LB4_ROWS);
+    const int64_t units = (n_tiles + LB4_ROWS - 1) / LB4_ROWS;
+    // split (one unit per workgroup) when the units could not even give every SIMD one wave; the grid must cover the
+    // bound in that layout, which is only affordable for moderate bounds
+    const bool may_split = d_n_tiles && units <= (int64_t)num_cu * 8 * 64;
+    const int64_t split_units = may_split ? (int64_t)num_cu * 4 : -1;
+    const int64_t blocks = may_split ? units : (units + 3) / 4;
     if (qd.normalised)
         hipLaunchKernelGGL((kvm_dtw_lb_tiled_kernel<true>), dim3((unsigned)blocks), dim3(256), 0, s, series, prefix, qd, tiles,
-                           n_tiles, out, counters, d_n_tiles);
+                           n_tiles, out, counters, d_n_tiles, split_units);
     else
         hipLaunchKernelGGL((kvm_dtw_lb_tiled_kernel<false>), dim3((unsigned)blocks), dim3(256), 0, s, series, prefix, qd,
-                           tiles, n_tiles, out, counters, d_n_tiles);
+                           tiles, n_tiles, out, counters, d_n_tiles, split_units);
     return hipGetLastError();
 }

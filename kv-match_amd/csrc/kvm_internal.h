@@ -181,7 +181,7 @@ hipError_t kvm_launch_dtw_filter(const double *series, const double2 *prefix, in
                                  unsigned long long *counters, hipStream_t s);
 hipError_t kvm_launch_dtw_lb_tiled(const double *series, const double2 *prefix, int64_t n, const kvm_query_dev &qd,
                                    const kvm_tile *tiles, int64_t n_tiles, kvm_cand *out, unsigned long long *counters,
-                                   const unsigned long long *d_n_tiles, hipStream_t s);
+                                   const unsigned long long *d_n_tiles, int num_cu, hipStream_t s);
 // DTW: filter + LB_Kim for every candidate (one lane each), 64-candidate tiles -> trimmed <= 32-candidate tiles of the
 // survivors; list length -> counters[KVM_CNT_TILES_A], PASS_FILTER / PASS_KIM counted here
 hipError_t kvm_launch_retile_dtw(const double *series, const double2 *prefix, const kvm_query_dev &qd, const kvm_tile *tiles,
