@@ -120,10 +120,10 @@ hipError_t kvm_launch_dtw_filter(const double *series, const double2 *prefix, in
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Stage 2: one wavefront per survivor.  LB_Keogh (query envelope, K/utils/DtwUtils.java:206-222) and
-// LB_Keogh on the data envelope (K/utils/DtwUtils.java:238-257), both summed over all m positions in
-// lane-strided order (the reference's order[] permutation and early exit only change the summation
-// order / skip work).  A candidate survives iff both bounds are <= eps^2.
+// Stage 2: one WORKGROUP per survivor.  LB_Keogh (query envelope, K/utils/DtwUtils.java:206-222) and LB_Keogh on
+// the data envelope (K/utils/DtwUtils.java:238-257), both summed over all m positions in lane-strided order (the
+// reference's order[] permutation and early exit only change the summation order / skip work).  A candidate
+// survives iff both bounds are <= eps^2.
 //
 // The per-position contributions of the larger bound feed the DP's early abandon in the reference as a suffix
 // sum cb[] (K/NormQueryEngineDtw.java:576-587, used at K/utils/DtwUtils.java:324-326).  Here the positions are
@@ -131,6 +131,10 @@ hipError_t kvm_launch_dtw_filter(const double *series, const double2 *prefix, in
 //     suffix[s] = sum of cb[pos] over pos >= s * seg_len
 // (16 doubles per survivor instead of m), which is all the DP kernel needs because it tests for abandonment
 // every 64 macro-steps anyway.  A coarse suffix is a subset sum of non-negative terms, i.e. still a lower bound.
+//
+// The four waves of the workgroup take four segments each.  With thousands of survivors the kernel is memory-bound
+// (~6 TB/s of L2 + HBM reads) and the layout does not matter; with a few hundred (a query with few answers) it is a
+// chain of global-load latencies per survivor, which this cuts by four (80 -> 25 us).
 __global__ __launch_bounds__(256) void kvm_dtw_keogh_kernel(const double *__restrict__ series,
                                                             const double *__restrict__ env_u,
                                                             const double *__restrict__ env_l, kvm_query_dev qd,
@@ -138,21 +142,20 @@ __global__ __launch_bounds__(256) void kvm_dtw_keogh_kernel(const double *__rest
                                                             const unsigned long long *__restrict__ d_n_in,
                                                             kvm_cand *__restrict__ out, double *__restrict__ out_suffix,
                                                             int32_t seg_len, unsigned long long *__restrict__ counters) {
-    __shared__ double segs[4][2][KVM_DTW_NSEG];
+    __shared__ double segs[2][KVM_DTW_NSEG];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned long long n_in = *d_n_in;
     const int m = qd.m;
     const double eps2 = qd.eps2;
-    for (unsigned long long idx = (unsigned long long)blockIdx.x * 4 + wave; idx < n_in;
-         idx += (unsigned long long)gridDim.x * 4) {
-        const kvm_cand c = in[idx];
+    for (unsigned long long idx = blockIdx.x; idx < n_in; idx += gridDim.x) {
+        const kvm_cand c = in[idx];  // (the same record in every thread: all branches on it are workgroup-uniform)
         const double *__restrict__ x = series + (c.start - 1);
         const double inv = 1.0 / c.std;
         // pruning threshold: eps^2 plus the guard band that covers the sigma uncertainty (cNSM) and summation order
         const double lim = qd.normalised ? eps2 + kvm_eps2_slack(eps2, m, kvm_sigma_guard(c.mean, c.std), 16.0)
                                          : eps2 * (1.0 + 1e-9);
         if (!(c.std == c.std)) {  // degenerate sigma in the pruning arithmetic: no bound, the exact pass decides
-            if (lane == 0) {
+            if (threadIdx.x == 0) {
                 atomicAdd(&counters[KVM_CNT_PASS_KEOGH], 1ULL);
                 atomicAdd(&counters[KVM_CNT_PASS_KEOGH2], 1ULL);
                 const unsigned long long o = atomicAdd(&counters[KVM_CNT_CANDS2], 1ULL);
@@ -161,8 +164,7 @@ __global__ __launch_bounds__(256) void kvm_dtw_keogh_kernel(const double *__rest
             }
             continue;
         }
-        double lb1 = 0.0;
-        for (int s = 0; s < KVM_DTW_NSEG; s++) {
+        for (int s = wave; s < KVM_DTW_NSEG; s += 4) {
             const int j1 = min(m, (s + 1) * seg_len);
             double p = 0.0;
 #pragma unroll 4
@@ -175,16 +177,22 @@ __global__ __launch_bounds__(256) void kvm_dtw_keogh_kernel(const double *__rest
                 p += d;
             }
             p = kvm_wave_sum(p);
-            if (lane == 0) segs[wave][0][s] = p;
-            lb1 += p;
+            if (lane == 0) segs[0][s] = p;
         }
-        if (!(lb1 <= lim)) continue;
+        __syncthreads();
+        double lb1 = 0.0;
+#pragma unroll
+        for (int s = 0; s < KVM_DTW_NSEG; s++) lb1 += segs[0][s];
+        if (!(lb1 <= lim)) {
+            __syncthreads();  // segs[0] is rewritten by the next survivor
+            continue;
+        }
         bool pass2 = true;
         double lb2 = 0.0;
         if (env_u) {
             const double *__restrict__ uu = env_u + (c.start - 1);
             const double *__restrict__ ll = env_l + (c.start - 1);
-            for (int s = 0; s < KVM_DTW_NSEG; s++) {
+            for (int s = wave; s < KVM_DTW_NSEG; s += 4) {
                 const int j1 = min(m, (s + 1) * seg_len);
                 double p = 0.0;
 #pragma unroll 4
@@ -197,27 +205,29 @@ __global__ __launch_bounds__(256) void kvm_dtw_keogh_kernel(const double *__rest
                     p += d;
                 }
                 p = kvm_wave_sum(p);
-                if (lane == 0) segs[wave][1][s] = p;
-                lb2 += p;
+                if (lane == 0) segs[1][s] = p;
             }
+            __syncthreads();
+#pragma unroll
+            for (int s = 0; s < KVM_DTW_NSEG; s++) lb2 += segs[1][s];
             pass2 = lb2 <= lim;
         }
-        unsigned long long o = 0;
-        if (lane == 0) {
+        if (threadIdx.x == 0) {
             atomicAdd(&counters[KVM_CNT_PASS_KEOGH], 1ULL);
             if (pass2) {
                 atomicAdd(&counters[KVM_CNT_PASS_KEOGH2], 1ULL);
-                o = atomicAdd(&counters[KVM_CNT_CANDS2], 1ULL);
+                const unsigned long long o = atomicAdd(&counters[KVM_CNT_CANDS2], 1ULL);
                 out[o] = c;
                 // larger bound wins, as K/NormQueryEngineDtw.java:577-587; suffix over segments
                 const int which = (env_u && !(lb1 > lb2)) ? 1 : 0;
                 double run = 0.0;
                 for (int s = KVM_DTW_NSEG - 1; s >= 0; s--) {
-                    run += segs[wave][which][s];
+                    run += segs[which][s];
                     out_suffix[o * KVM_DTW_NSEG + s] = run;
                 }
             }
         }
+        __syncthreads();  // segs are rewritten by the next survivor
     }
 }
 
@@ -227,7 +237,7 @@ hipError_t kvm_launch_dtw_keogh(const double *series, const double *env_u, const
                                 unsigned long long *counters, hipStream_t s) {
     (void)n;
     if (max_in <= 0) return hipSuccess;
-    int64_t blocks = (max_in + 3) / 4;
+    int64_t blocks = max_in;  // one workgroup per survivor, 8 resident per CU
     if (blocks > 256 * 8) blocks = 256 * 8;
     hipLaunchKernelGGL(kvm_dtw_keogh_kernel, dim3((unsigned)blocks), dim3(256), 0, s, series, env_u, env_l, qd, in,
                        d_n_in, out, out_suffix, seg_len, counters);
