@@ -87,59 +87,23 @@ __device__ __forceinline__ double ex_seq_add(const double *buf, int cnt, double 
     return acc;
 }
 
-// Warm-up steps of the running-sum replay (no window complete yet): ex += d, ex2 += d*d for steps [0, n), each step 4
-// doubles (32 B) apart in `buf`: {d, d*d, ., .}; 8 steps per register set.
-__device__ __forceinline__ void ex_seq_add2(const double *buf, int n, double &ex_io, double &ex2_io) {
-    ex_d2 a[8], b[8];
-    double ex = ex_io, ex2 = ex2_io;
-    const int rounds = n / 16;
-    if (rounds > 0) {
-        const unsigned base = ex_lds_addr(buf);
-        EX_READ8(a, base, 32);
-        for (int r = 0; r < rounds; r++) {
-            const unsigned ab = base + (unsigned)(r * 512 + 256);
-            const unsigned an = base + (unsigned)((r + 1 < rounds ? r + 1 : 0) * 512);
-            EX_READ8(b, ab, 32);
-            EX_WAIT8(a, ex, ex2);
-#pragma unroll
-            for (int u = 0; u < 8; u++) {
-                ex += a[u].x;
-                ex2 += a[u].y;
-            }
-            EX_READ8(a, an, 32);
-            EX_WAIT8(b, ex, ex2);
-#pragma unroll
-            for (int u = 0; u < 8; u++) {
-                ex += b[u].x;
-                ex2 += b[u].y;
-            }
-        }
-        EX_WAIT0(a, ex, ex2);
-    }
-    for (int t = rounds * 16; t < n; t++) {
-        ex += buf[4 * t];
-        ex2 += buf[4 * t + 1];
-    }
-    ex_io = ex;
-    ex2_io = ex2;
-}
-
 #define EX_FENCE2(a, b) asm volatile("" : "+v"(a), "+v"(b)::"memory")
 
-// Producer side of the running-sum replay: steps [c0, c0+cnt) of the run that starts at 0-based point b; per step
-// {d, d*d, o, o*o} where o is the point leaving the window after that step (T[j] of K/NormQueryEngine.java:523).
+// Producer side of the running-sum replay: steps [c0, c0+cnt) of the run that starts at 0-based point b.  A buffer is
+// four arrays of EX_RSTEPS doubles: D[t] = the point entering at step t, D2[t] = D[t]*D[t], O[t] = the point leaving
+// the window after that step (T[j] of K/NormQueryEngine.java:523; 0.0 where the reference does not subtract), O2 = O*O.
+#define EX_RSTEPS (EX_BUF / 4)  // replay steps per chunk (512)
+#define EX_RPROD (EX_THREADS - 128)  // producer threads of the replay kernel (waves 2 and 3)
 __device__ __forceinline__ void ex_produce_replay(const double *__restrict__ x, int64_t b, int64_t total, int m, int64_t c0,
-                                                  int cnt, double *buf, int ptid, int pthreads) {
+                                                  int cnt, double *buf, int ptid) {
     // all loads of this thread's steps are issued before the first is used: one global-load latency per chunk, not
-    // one per step (the consumer needs only ~2 us per chunk, so a producer that waits per step would be the bottleneck)
-    constexpr int PER = (EX_STEPS + (EX_THREADS - 64) - 1) / (EX_THREADS - 64);
+    // one per step; unconditional loads from clamped (always valid) addresses, selection afterwards
+    constexpr int PER = (EX_RSTEPS + EX_RPROD - 1) / EX_RPROD;
     double d[PER], o[PER];
 #pragma unroll
     for (int i = 0; i < PER; i++) {
-        const int t = ptid + i * pthreads;
+        const int t = ptid + i * EX_RPROD;
         const int64_t g = c0 + t;
-        // unconditional loads from clamped (always valid) addresses, selection afterwards: a load under a condition
-        // becomes a branch with its own wait, and nine of those in a row cost 5 us per chunk
         const int64_t gd = g < total ? g : total - 1, go = g >= m - 1 ? g - m + 1 : 0;
         const double dv = x[b + gd], ov = x[b + (go < total ? go : total - 1)];
         d[i] = (t < cnt) ? dv : 0.0;
@@ -147,10 +111,12 @@ __device__ __forceinline__ void ex_produce_replay(const double *__restrict__ x, 
     }
 #pragma unroll
     for (int i = 0; i < PER; i++) {
-        const int t = ptid + i * pthreads;
-        if (t < cnt) {
-            *reinterpret_cast<double2 *>(buf + 4 * t) = make_double2(d[i], d[i] * d[i]);
-            *reinterpret_cast<double2 *>(buf + 4 * t + 2) = make_double2(o[i], o[i] * o[i]);
+        const int t = ptid + i * EX_RPROD;
+        if (t < EX_RSTEPS) {  // (steps past cnt are written as zeros: the consumers' prefetch may read them)
+            buf[t] = d[i];
+            buf[EX_RSTEPS + t] = d[i] * d[i];
+            buf[2 * EX_RSTEPS + t] = o[i];
+            buf[3 * EX_RSTEPS + t] = o[i] * o[i];
         }
     }
 }
@@ -191,6 +157,10 @@ __device__ unsigned long long kvm_dbg[8192];
 #define EX_STAMP(slot) do { } while (0)
 #endif
 __global__ __launch_bounds__(EX_THREADS) void kvm_replay_runs_kernel(const double *__restrict__ x, int m, kvm_replay_ws ws) {
+    // Two consumer waves: lane 0 of wave 0 runs the `ex` chain, lane 0 of wave 1 the `ex2` chain (they never meet: the
+    // readers combine them).  A lone wavefront issues one fp64 operation per ~10 cycles whether or not it depends on
+    // the previous one (profiles/micro/chain_bench.hip: two interleaved chains take twice as long as one), so two
+    // chains in one lane cost 20 cycles per step; on two waves they cost 10.  Waves 2-3 produce.
     __shared__ __attribute__((aligned(16))) double bufs[2 * EX_BUF];
     // one workgroup per QUEUED run (launching one per run of the query costs ~100 us of empty workgroups at 15 000 runs)
     if ((unsigned long long)blockIdx.x >= *ws.run_list_n) return;
@@ -201,80 +171,75 @@ __global__ __launch_bounds__(EX_THREADS) void kvm_replay_runs_kernel(const doubl
     const int64_t b = (int64_t)run.start - 1;
     const int64_t total = (int64_t)(maxk - 1) + m;  // steps up to the last point of the last needed window
     const int tid = threadIdx.x;
-    const bool consumer = tid < 64;
-    const int ptid = tid - 64, pthreads = EX_THREADS - 64;
+    const int wave = tid >> 6;
+    const bool consumer = wave < 2;
+    const int ptid = tid - 128;
     auto produce = [&](int64_t c0, int buf) {
-        const int cnt = (int)min((int64_t)EX_STEPS, total - c0);
-        ex_produce_replay(x, b, total, m, c0, cnt, bufs + buf * EX_BUF, ptid, pthreads);
+        const int cnt = (int)min((int64_t)EX_RSTEPS, total - c0);
+        ex_produce_replay(x, b, total, m, c0, cnt, bufs + buf * EX_BUF, ptid);
     };
-    double ex = 0.0, ex2 = 0.0;
-    const int nch = (int)((total + EX_STEPS - 1) / EX_STEPS);
+    double acc = 0.0;  // ex (wave 0) or ex2 (wave 1)
+    const int nch = (int)((total + EX_RSTEPS - 1) / EX_RSTEPS);
     if (!consumer) produce(0, 0);
     __syncthreads();
     for (int c = 0; c < nch; c++) {
-        const int64_t c0 = (int64_t)c * EX_STEPS;
+        const int64_t c0 = (int64_t)c * EX_RSTEPS;
         if (consumer) {
-            if (tid == 0) {
-                EX_STAMP(4 * c + 0);
-                const double *buf = bufs + (c & 1) * EX_BUF;
-                const int cnt = (int)min((int64_t)EX_STEPS, total - c0);
+            if ((tid & 63) == 0) {
+                if (tid == 0) EX_STAMP(4 * c + 0);
+                // wave 0 reads D / O, wave 1 reads D2 / O2
+                const double *dbuf = bufs + (c & 1) * EX_BUF + wave * EX_RSTEPS, *obuf = dbuf + 2 * EX_RSTEPS;
+                const int cnt = (int)min((int64_t)EX_RSTEPS, total - c0);
                 const int n_add = (int)max((int64_t)0, min((int64_t)cnt, (int64_t)(m - 1) - c0));  // no window complete yet
-                ex_seq_add2(buf, n_add, ex, ex2);
-                // Window steps.  Branch-free: the departing point's terms are zero where the reference does not
-                // subtract (the producer writes 0.0 for the last step; x - 0.0 == x bit for bit), and {ex, ex2} is
-                // stored for EVERY window (the readers only look at the flagged ones), so a round is straight-line
-                // code and its LDS reads stay one round ahead (see ex_seq_add).
+                acc = ex_seq_add(dbuf, n_add, acc);  // K/NormQueryEngine.java:498 / :499
+                // Window steps.  Branch-free: the departing point's term is 0.0 where the reference does not subtract
+                // (x - 0.0 == x bit for bit), and the running sum is stored for EVERY window up to the last one a
+                // survivor needs (the readers look only at theirs), so a round is straight-line code whose LDS reads
+                // stay one round ahead.  ws.stats[k] = {ex, ex2}: each consumer stores its own half.
                 {
-                    constexpr int R = 4;
-                    double2 dv[2][R], ov[2][R];
-                    double ex_l = ex, ex2_l = ex2;
-                    double2 *st_out = ws.stats + run.win_base + (c0 - (int64_t)(m - 1));  // + t = window completed by step t
+                    constexpr int R = 4;  // steps per register set
+                    double dv[2][R], ov[2][R];
+                    double a_l = acc, dummy = 0.0;
+                    double *st_out = reinterpret_cast<double *>(ws.stats + run.win_base + (c0 - (int64_t)(m - 1))) + wave;
                     const int nw = cnt - n_add, rounds = nw / (2 * R);
                     auto fetch = [&](int t0, int set) {
 #pragma unroll
                         for (int u = 0; u < R; u++) {
-                            dv[set][u] = *reinterpret_cast<const double2 *>(buf + 4 * (t0 + u));
-                            ov[set][u] = *reinterpret_cast<const double2 *>(buf + 4 * (t0 + u) + 2);
+                            dv[set][u] = dbuf[t0 + u];
+                            ov[set][u] = obuf[t0 + u];
                         }
                     };
                     auto consume = [&](int t0, int set) {
 #pragma unroll
                         for (int u = 0; u < R; u++) {
-                            ex_l += dv[set][u].x;                          // K/NormQueryEngine.java:498
-                            ex2_l += dv[set][u].y;                         // :499
-                            st_out[t0 + u] = make_double2(ex_l, ex2_l);    // -> mean, std (:507-508) in the readers
-                            ex_l -= ov[set][u].x;                          // :523
-                            ex2_l -= ov[set][u].y;                         // :524
+                            a_l += dv[set][u];              // K/NormQueryEngine.java:498 / :499
+                            st_out[2 * (t0 + u)] = a_l;     // -> mean, std (:507-508) in the readers
+                            a_l -= ov[set][u];              // :523 / :524
                         }
                     };
                     if (rounds > 0) fetch(n_add, 0);
-                    for (int r = 0; r < rounds; r++) {
-                        const int t = n_add + r * 2 * R;
+                    for (int rr = 0; rr < rounds; rr++) {
+                        const int t = n_add + rr * 2 * R;
                         fetch(t + R, 1);
-                        EX_FENCE2(ex_l, ex2_l);
+                        EX_FENCE2(a_l, dummy);
                         consume(t, 0);
-                        fetch((r + 1 < rounds) ? t + 2 * R : n_add, 0);
-                        EX_FENCE2(ex_l, ex2_l);
+                        fetch((rr + 1 < rounds) ? t + 2 * R : n_add, 0);
+                        EX_FENCE2(a_l, dummy);
                         consume(t + R, 1);
                     }
                     for (int t = n_add + rounds * 2 * R; t < cnt; t++) {
-                        const double2 d = *reinterpret_cast<const double2 *>(buf + 4 * t);
-                        const double2 o = *reinterpret_cast<const double2 *>(buf + 4 * t + 2);
-                        ex_l += d.x;
-                        ex2_l += d.y;
-                        st_out[t] = make_double2(ex_l, ex2_l);
-                        ex_l -= o.x;
-                        ex2_l -= o.y;
+                        a_l += dbuf[t];
+                        st_out[2 * t] = a_l;
+                        a_l -= obuf[t];
                     }
-                    ex = ex_l;
-                    ex2 = ex2_l;
+                    acc = a_l;
                 }
-                EX_STAMP(4 * c + 1);
+                if (tid == 0) EX_STAMP(4 * c + 1);
             }
         } else if (c + 1 < nch) {
-            if (tid == 64) EX_STAMP(4 * c + 2);
-            produce(c0 + EX_STEPS, (c + 1) & 1);
-            if (tid == 64) EX_STAMP(4 * c + 3);
+            if (tid == 128) EX_STAMP(4 * c + 2);
+            produce(c0 + EX_RSTEPS, (c + 1) & 1);
+            if (tid == 128) EX_STAMP(4 * c + 3);
         }
         __syncthreads();
     }

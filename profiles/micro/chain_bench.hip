@@ -5,9 +5,9 @@
 #include <vector>
 #define N 8192
 template <int MODE>
-__global__ __launch_bounds__(64) void chain(const double *src, double *out, int reps) {
+__global__ __launch_bounds__(256) void chain(const double *src, double *out, int reps) {
     __shared__ double buf[N];
-    for (int i = threadIdx.x; i < N; i += 64) buf[i] = src[i];
+    for (int i = threadIdx.x; i < N; i += blockDim.x) buf[i] = src[i];
     __syncthreads();
     double acc = 0.0, acc2 = 0.0;
     if (threadIdx.x == 0) {
@@ -60,6 +60,7 @@ __global__ __launch_bounds__(64) void chain(const double *src, double *out, int 
         }
         out[0] = acc + acc2;
     }
+    __syncthreads();  // (with 256 threads: three waves park here while lane 0 of wave 0 runs the chain)
 }
 int main() {
     std::vector<double> h(N);
@@ -79,6 +80,12 @@ int main() {
     run(chain<1>, "one chain, prefetch", 1);
     run(chain<2>, "two chains (x->acc, y->acc2), prefetch", 1);
     run(chain<3>, "register-only dependent adds", 1);
+    {   // the same two-chain loop with three more waves of the workgroup parked at a barrier
+        for (int w = 0; w < 2; w++) hipLaunchKernelGGL(chain<2>, dim3(1), dim3(256), 0, 0, d, o, reps);
+        hipEventRecord(e0); hipLaunchKernelGGL(chain<2>, dim3(1), dim3(256), 0, 0, d, o, reps); hipEventRecord(e1);
+        hipEventSynchronize(e1); float ms2; hipEventElapsedTime(&ms2, e0, e1);
+        printf("%-44s %8.1f us per pass = %.2f ns per element\n", "two chains, 256-thread workgroup", ms2 * 1e3 / reps, ms2 * 1e6 / reps / N);
+    }
     // under load: the same with 1024 blocks resident
     for (int w = 0; w < 2; w++) hipLaunchKernelGGL(chain<1>, dim3(1024), dim3(64), 0, 0, d, o, reps);
     hipEventRecord(e0); hipLaunchKernelGGL(chain<1>, dim3(1024), dim3(64), 0, 0, d, o, reps); hipEventRecord(e1);
