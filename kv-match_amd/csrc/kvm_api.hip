@@ -618,13 +618,15 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
             HIPCHK(ctx, kvm_launch_retile_cnsm(ctx->d_series, ctx->d_prefix, qd, d_tiles, pl.n_tiles, tA, tB,
                                                counters + KVM_CNT_TILES_A, stream));
             HIPCHK(ctx, kvm_launch_ed_dot(ctx->d_series, ctx->d_prefix, ctx->n, qd, tA, pl.n_tiles, tB, pl.n_tiles, surv,
-                                          pl.windows, counters, ctx->num_cu, counters + KVM_CNT_TILES_A, stream));
+                                          pl.windows, counters, ctx->num_cu, counters + KVM_CNT_TILES_A, out.d_off, out.d_dist, out.cap,
+                                          stream));
         } else if (ed_kernel == 4)
             HIPCHK(ctx, kvm_launch_ed_jl(ctx->d_series, ctx->d_prefix, ctx->n, qd, d_tiles, n_tiles, surv, pl.windows,
                                          counters, ctx->num_cu, stream));
         else if (ed_kernel == 3)
             HIPCHK(ctx, kvm_launch_ed_dot(ctx->d_series, ctx->d_prefix, ctx->n, qd, d_tiles, pl.n_tiles, d_tiles + pl.n_tiles,
-                                          pl.n_tiles_b, surv, pl.windows, counters, ctx->num_cu, nullptr, stream));
+                                          pl.n_tiles_b, surv, pl.windows, counters, ctx->num_cu, nullptr, out.d_off, out.d_dist,
+                                          out.cap, stream));
         else if (ed_kernel == 2)
             HIPCHK(ctx, kvm_launch_ed_tiled(ctx->d_series, ctx->d_prefix, ctx->n, qd, d_tiles, n_tiles, surv,
                                             pl.windows, counters, stream));

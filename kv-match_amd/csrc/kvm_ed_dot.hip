@@ -25,6 +25,7 @@
 // (conflict-free; SQ_LDS_BANK_CONFLICT ~ 1 % of LDS cycles).  The loads are written with a clang ext_vector type:
 // hipcc scalarises HIP's double2 and re-pairs it as ds_read2_b64, whose 8-B banking rules conflict 4-way here.
 #include "kvm_internal.h"
+#include "kvm_seqadd.h"
 
 #include <algorithm>
 #include <cmath>
@@ -56,7 +57,11 @@ struct edd_args {
     kvm_surv *surv;
     int64_t cap;
     unsigned long long *counters;
+    int32_t *out_off;   // answer buffers (RSM: a wave that ends with a few survivors evaluates them exactly itself)
+    double *out_dist;
+    int64_t out_cap;
 };
+#define EDD_INLINE_MAX 4  // survivors per wave-unit that are evaluated in place (more: handed to kvm_exact_ed_kernel)
 
 struct edd_cstat {
     double s1J, s2J, mc, sg, g;
@@ -317,6 +322,7 @@ __device__ __forceinline__ void edd_body(const edd_args &A, const kvm_tile *__re
     } else if (!work) {
         return;
     }
+    unsigned keepm = 0;
 #pragma unroll
     for (int a = 0; a < CI; a++) {
         if ((vm >> a) & 1u) {
@@ -326,10 +332,56 @@ __device__ __forceinline__ void edd_body(const edd_args &A, const kvm_tile *__re
                 const edd_cstat st = stats(a, 0, m);
                 keep = dist_form(st, acc[a], m, qtot, slack) <= eps2 + slack;
             }
-            if (keep) {
-                unsigned long long idx = atomicAdd(&A.counters[KVM_CNT_CANDS1], 1ULL);
-                if ((int64_t)idx < A.cap) A.surv[idx] = kvm_surv{mine.start + c0 + a, mine.run_start};
+            if (keep) keepm |= 1u << a;
+        }
+    }
+    if (!NORM && A.out_off) {
+        // RSM: the exact evaluation of a survivor (K/QueryEngine.java:355-358: terms (x-q)*(x-q), added in order) is a
+        // 40 us chain of dependent additions in one lane whatever kernel runs it.  Done here, by the wave that found
+        // the survivor, it overlaps with the rest of the pruning kernel instead of following it (the separate exact
+        // pass was 6 % of a phase-2 call).  Only for a few survivors per wave; more go to kvm_exact_ed_kernel.
+        int ns = __popc(keepm);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) ns += __shfl_xor(ns, o, 64);
+        if (ns > 0 && ns <= EDD_INLINE_MAX) {
+            const double *__restrict__ qx = qd.q;
+            for (int it = 0; it < ns; it++) {
+                const unsigned long long owners = __ballot(keepm != 0);
+                const int L = __ffsll((long long)owners) - 1;                       // wave-uniform: first lane with a survivor
+                const int a_me = keepm ? __ffs((int)keepm) - 1 : 0;
+                const int start = __shfl(mine.start + c0 + a_me, L, 64);           // its window start (1-based)
+                if (lane == L) keepm &= keepm - 1;                                   // taken
+                const double *__restrict__ xs = series + ((int64_t)start - 1);
+                double dist = 0.0;
+                for (int j0 = 0; j0 < m; j0 += 1024) {
+                    const int cnt = min(1024, m - j0);
+#pragma unroll
+                    for (int i = 0; i < 16; i++) {
+                        const int j = j0 + i * 64 + lane;
+                        const double xv = xs[j < m ? j : m - 1], qv = qx[j < m ? j : m - 1];
+                        wlds[i * 64 + lane] = (xv - qv) * (xv - qv);               // K/QueryEngine.java:357
+                    }
+                    if (lane == 0) dist = ex_seq_add(wlds, cnt, dist);              // :357, strictly in order
+                }
+                if (lane == 0) {
+                    atomicAdd(&A.counters[KVM_CNT_RECHECKED], 1ULL);
+                    if (dist <= eps2) {
+                        const unsigned long long o = atomicAdd(&A.counters[KVM_CNT_ANSWERS], 1ULL);
+                        if ((int64_t)o < A.out_cap) {
+                            A.out_off[o] = start;
+                            A.out_dist[o] = sqrt(dist);
+                        }
+                    }
+                }
             }
+            return;
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < CI; a++) {
+        if ((keepm >> a) & 1u) {
+            unsigned long long idx = atomicAdd(&A.counters[KVM_CNT_CANDS1], 1ULL);
+            if ((int64_t)idx < A.cap) A.surv[idx] = kvm_surv{mine.start + c0 + a, mine.run_start};
         }
     }
 }
@@ -462,7 +514,7 @@ static double edd_makespan(double unitsA, double unitsB, int fA, int fB, double 
 hipError_t kvm_launch_ed_dot(const double *series, const double2 *prefix, int64_t n, const kvm_query_dev &qd,
                              const kvm_tile *tilesA, int64_t nA, const kvm_tile *tilesB, int64_t nB, kvm_surv *surv,
                              int64_t cap, unsigned long long *counters, int num_cu, const unsigned long long *d_counts,
-                             hipStream_t s) {
+                             int32_t *out_off, double *out_dist, int64_t out_cap, hipStream_t s) {
     (void)n;
     if (nA + nB <= 0) return hipSuccess;
     const int64_t unitsA = (nA + EDD_ROWS - 1) / EDD_ROWS, unitsB = (nB + EDD_ROWS - 1) / EDD_ROWS;
@@ -503,7 +555,7 @@ hipError_t kvm_launch_ed_dot(const double *series, const double2 *prefix, int64_
     }
     const int64_t blocksA = (unitsA * fA + 3) / 4, blocksB = (unitsB * fB + 3) / 4;
     dim3 grid((unsigned)(blocksA + blocksB)), block(256);
-    edd_args A{series, prefix, qd, surv, cap, counters};
+    edd_args A{series, prefix, qd, surv, cap, counters, out_off, out_dist, out_cap};
 #define LAUNCH(NORM, AB) \
     hipLaunchKernelGGL((kvm_ed_dot_kernel<NORM, AB>), grid, block, 0, s, A, tilesA, nA, tilesB, nB, fA, fB, blocksA, d_counts, \
                        split_units)
