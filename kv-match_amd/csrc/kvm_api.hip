@@ -414,6 +414,7 @@ struct verify_out {
     int32_t *d_off;
     double *d_dist;
     int64_t cap;
+    bool own;  // true: answers go to the context's own buffers, sized by run_variant once the plan knows #windows
 };
 
 enum { V_RSM_ED = 0, V_CNSM_ED = 1, V_RSM_DTW = 2, V_CNSM_DTW = 3 };
@@ -433,7 +434,7 @@ static int ensure_envelope(kvm_ctx *ctx, int32_t rho) {
 // device in ctx->b_counters.  `stream` is the stream to launch on.
 static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m, const int32_t *left,
                        const int32_t *right, int32_t k, int32_t shift, double epsilon, int32_t rho, double alpha,
-                       double beta, plan &pl, verify_out out, hipStream_t stream, int64_t *kernel_ns) {
+                       double beta, plan &pl, verify_out &out, hipStream_t stream, int64_t *kernel_ns) {
     if (!ctx->d_series) return fail(ctx, KVM_ERR_NO_SERIES, "no series loaded");
     if (!query || m < 1 || k < 0 || (k > 0 && (!left || !right)))
         return fail(ctx, KVM_ERR_ILLEGAL_ARGUMENT, "bad query/interval arguments");
@@ -482,6 +483,13 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
     pl.runs = (kvm_run *)(hp + qbytes);
     rc = build_plan(ctx, cnsm, m, left, right, k, shift, tile_max, hybrid, pl);
     if (rc) return rc;
+    if (out.own) {  // capacity: every evaluated window may be an answer
+        if ((rc = ensure(ctx, ctx->b_out_off, (size_t)pl.windows * 4 + 64))) return rc;
+        if ((rc = ensure(ctx, ctx->b_out_dist, (size_t)pl.windows * 8 + 64))) return rc;
+        out.d_off = (int32_t *)ctx->b_out_off.p;
+        out.d_dist = (double *)ctx->b_out_dist.p;
+        out.cap = pl.windows;
+    }
     KVM_TP("  build_plan");
 
     // ---- query-side constants (host, sequential, exactly the reference's arithmetic) ----
@@ -744,18 +752,13 @@ static int verify_host(kvm_ctx *ctx, int variant, const double *query, int32_t m
     auto t0 = std::chrono::steady_clock::now();
     auto tp_ = t0;
     plan pl;
-    // capacity: every evaluated window may be an answer
-    int64_t worst = 0;
-    for (int32_t p = 0; p < k && left && right; p++) worst += std::max<int64_t>(0, (int64_t)right[p] - left[p] + 1);
     int rc;
-    if ((rc = ensure(ctx, ctx->b_out_off, (size_t)worst * 4 + 64))) return rc;
-    if ((rc = ensure(ctx, ctx->b_out_dist, (size_t)worst * 8 + 64))) return rc;
-    verify_out out{(int32_t *)ctx->b_out_off.p, (double *)ctx->b_out_dist.p, worst};
+    verify_out out{nullptr, nullptr, 0, true};
     int64_t kernel_ns = 0;
-    KVM_TP("ensure out");
     rc = run_variant(ctx, variant, query, m, left, right, k, shift, epsilon, rho, alpha, beta, pl, out, ctx->stream,
                      &kernel_ns);
     if (rc) return rc;
+    const int64_t worst = out.cap;
     KVM_TP("run_variant (launch)");
     // One synchronisation in the common case: the counters and the first KVM_SPEC_ANSWERS answers are copied back
     // together (answers are rare); a second copy only when there are more.
@@ -896,7 +899,7 @@ extern "C" int kvm_verify_device(kvm_ctx *ctx, int32_t variant, const double *qu
         return fail(ctx, KVM_ERR_ILLEGAL_ARGUMENT, "bad kvm_verify_device arguments");
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
     plan pl;
-    verify_out out{d_out_off, d_out_dist, cap};
+    verify_out out{d_out_off, d_out_dist, cap, false};
     int rc = run_variant(ctx, variant, query, m, left, right, k, shift, epsilon, rho, alpha, beta, pl, out, s, nullptr);
     if (rc) return rc;
     if (cnt_candidate) *cnt_candidate = pl.cnt_candidate;
