@@ -43,54 +43,6 @@ struct jl_args {
     int64_t n_units;
 };
 
-// raw operands of kvm_window_shifted_sums for a window spanning at most two prefix blocks (loads only, so that they
-// can be issued a chunk ahead of their use)
-struct jl_raw {
-    double2 pe, ps, pl;
-    double c0, c1;
-    bool at_start;
-    int32_t kind;  // 0: one block, 1: two blocks, 2: more (recomputed by the generic routine)
-    double k1;     // points of the window inside its last block
-};
-
-__device__ __forceinline__ jl_raw jl_issue_stats(const double2 *__restrict__ P, const double *__restrict__ x, int64_t s,
-                                                 int32_t len) {
-    // branch-free: every load is issued unconditionally from an address that is valid in all cases
-    jl_raw r;
-    const int64_t e = s + len - 1;
-    const int64_t bs = s >> KVM_PS_BLOCK_LOG2, be = e >> KVM_PS_BLOCK_LOG2;
-    const int64_t first_e = be << KVM_PS_BLOCK_LOG2, tail_s = ((bs + 1) << KVM_PS_BLOCK_LOG2) - 1;
-    r.c0 = x[bs << KVM_PS_BLOCK_LOG2];
-    r.c1 = x[first_e];
-    r.pe = P[e];
-    r.pl = P[tail_s < e ? tail_s : e];
-    r.ps = P[s > 0 ? s - 1 : 0];
-    r.at_start = (s & (KVM_PS_BLOCK - 1)) == 0;  // then the window starts its block and nothing is subtracted
-    r.kind = bs == be ? 0 : (be == bs + 1 ? 1 : 2);
-    r.k1 = (double)(e - first_e + 1);
-    return r;
-}
-// same arithmetic, in the same order, as kvm_window_shifted_sums
-__device__ __forceinline__ void jl_finish_stats(const jl_raw &r, const double2 *__restrict__ P, const double *__restrict__ x,
-                                                int64_t s, int32_t len, double &s1, double &s2, double &c) {
-    if (r.kind == 2) {
-        kvm_window_shifted_sums(P, x, s, len, s1, s2, c);
-        return;
-    }
-    c = r.c0;
-    const double psx = r.at_start ? 0.0 : r.ps.x, psy = r.at_start ? 0.0 : r.ps.y;
-    if (r.kind == 0) {
-        s1 = r.pe.x - psx;
-        s2 = r.pe.y - psy;
-    } else {
-        s1 = r.pl.x - psx;
-        s2 = r.pl.y - psy;
-        const double dc = r.c1 - c;
-        s1 += r.pe.x + r.k1 * dc;
-        s2 += r.pe.y + (2.0 * dc) * r.pe.x + r.k1 * (dc * dc);
-    }
-}
-
 __device__ __forceinline__ unsigned long long jl_readfirstlane64(unsigned long long v) {
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
     return ((unsigned long long)hi << 32) | lo;
@@ -152,7 +104,7 @@ __global__ __launch_bounds__(256, 2) void kvm_ed_jl_kernel(jl_args A) {
         // the next unit's descriptor stays in VGPRs (a uniform vector load) until the end of this unit: no wait here
         const kvm_tile nxt_v = tiles[u + 1 < u1 ? u + 1 : u];
         const int64_t w0 = (int64_t)cur.start - 1 + (mycand < cur.count ? mycand : cur.count - 1);  // this lane's candidate, 0-based
-        jl_raw raw = {};
+        kvm_raw_sums raw = {};
 
         double acc[JL_CI];
 #pragma unroll
@@ -170,7 +122,7 @@ __global__ __launch_bounds__(256, 2) void kvm_ed_jl_kernel(jl_args A) {
             // prefetch: the next chunk of this unit, or chunk 0 of the next unit
             load_x(last ? series + ((int64_t)nxt_v.start - 1) : series + ((int64_t)cur.start - 1 + (int64_t)(k + 1) * JL_CHUNK));
             const jl_d2 *qn = qT + (last ? 0 : (int64_t)(k + 1) * JL_PAIRS) + lane;
-            if (last) raw = jl_issue_stats(prefix, series, w0, m);
+            if (last) raw = kvm_issue_window_sums(prefix, series, w0, m);
             // The prefetch is issued above the FMA block and consumed below it.  Both fences are empty asm statements
             // that take every accumulator as an operand and clobber memory: the loads cannot sink below the first one,
             // the FMAs cannot rise above it, and the wait for the prefetch (store_x) cannot rise above the second.
@@ -242,7 +194,7 @@ __global__ __launch_bounds__(256, 2) void kvm_ed_jl_kernel(jl_args A) {
         bool passed = false, keep = false;
         if (alive) {
             double s1, s2, cb;
-            jl_finish_stats(raw, prefix, series, w0, m, s1, s2, cb);
+            kvm_finish_window_sums(raw, prefix, series, w0, m, s1, s2, cb);
             const double dc = cb - c_cur;
             const double S1 = s1 + m * dc, S2 = s2 + (2.0 * dc) * s1 + m * (dc * dc);  // sums of (x - c_cur), (x - c_cur)^2
             if (!NORM) {

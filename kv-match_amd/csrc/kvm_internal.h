@@ -254,6 +254,57 @@ __device__ __forceinline__ void kvm_window_shifted_sums(const double2 *__restric
     }
 }
 
+// Two-phase form of kvm_window_shifted_sums: all loads first (unconditional, clamped addresses), arithmetic later --
+// lets a kernel put the loads of several windows in flight together instead of paying 2-3 dependent latencies each.
+// raw operands of kvm_window_shifted_sums for a window spanning at most two prefix blocks (loads only, so that they
+// can be issued a chunk ahead of their use)
+struct kvm_raw_sums {
+    double2 pe, ps, pl;
+    double c0, c1;
+    bool at_start;
+    int32_t kind;  // 0: one block, 1: two blocks, 2: more (recomputed by the generic routine)
+    double k1;     // points of the window inside its last block
+};
+
+__device__ __forceinline__ kvm_raw_sums kvm_issue_window_sums(const double2 *__restrict__ P, const double *__restrict__ x, int64_t s,
+                                                 int32_t len) {
+    // branch-free: every load is issued unconditionally from an address that is valid in all cases
+    kvm_raw_sums r;
+    const int64_t e = s + len - 1;
+    const int64_t bs = s >> KVM_PS_BLOCK_LOG2, be = e >> KVM_PS_BLOCK_LOG2;
+    const int64_t first_e = be << KVM_PS_BLOCK_LOG2, tail_s = ((bs + 1) << KVM_PS_BLOCK_LOG2) - 1;
+    r.c0 = x[bs << KVM_PS_BLOCK_LOG2];
+    r.c1 = x[first_e];
+    r.pe = P[e];
+    r.pl = P[tail_s < e ? tail_s : e];
+    r.ps = P[s > 0 ? s - 1 : 0];
+    r.at_start = (s & (KVM_PS_BLOCK - 1)) == 0;  // then the window starts its block and nothing is subtracted
+    r.kind = bs == be ? 0 : (be == bs + 1 ? 1 : 2);
+    r.k1 = (double)(e - first_e + 1);
+    return r;
+}
+// same arithmetic, in the same order, as kvm_window_shifted_sums
+__device__ __forceinline__ void kvm_finish_window_sums(const kvm_raw_sums &r, const double2 *__restrict__ P, const double *__restrict__ x,
+                                                int64_t s, int32_t len, double &s1, double &s2, double &c) {
+    if (r.kind == 2) {
+        kvm_window_shifted_sums(P, x, s, len, s1, s2, c);
+        return;
+    }
+    c = r.c0;
+    const double psx = r.at_start ? 0.0 : r.ps.x, psy = r.at_start ? 0.0 : r.ps.y;
+    if (r.kind == 0) {
+        s1 = r.pe.x - psx;
+        s2 = r.pe.y - psy;
+    } else {
+        s1 = r.pl.x - psx;
+        s2 = r.pl.y - psy;
+        const double dc = r.c1 - c;
+        s1 += r.pe.x + r.k1 * dc;
+        s2 += r.pe.y + (2.0 * dc) * r.pe.x + r.k1 * (dc * dc);
+    }
+}
+
+
 // mean / std of the window 0-based [s, s+m) from the shifted block prefix sums.
 __device__ __forceinline__ void kvm_window_mean_std(const double2 *__restrict__ P, const double *__restrict__ x,
                                                     int64_t s, int32_t m, double &mean, double &std) {
