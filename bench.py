@@ -309,6 +309,15 @@ def main():
             r_ = eng.verify((fl, fr), 1, q, a.epsilon)
             ex["full_scan_rsm_ed_candidates_per_s"] = r_.cnt_candidate / (time.perf_counter() - t1)
             ex["full_scan_answers"] = len(r_)
+            # index build input: sliding window means of the whole series, w = 50 (K/IndexBuilder.java:232-247)
+            cnt_w = min(n - 49, 20_000_000)  # (the API returns host doubles: keep the D2H part of the call bounded)
+            ctx.window_means(50, first=1, count=cnt_w)
+            t1 = time.perf_counter()
+            ctx.window_means(50, first=1, count=cnt_w)
+            ex["window_means_w50_points_per_s_incl_d2h"] = cnt_w / (time.perf_counter() - t1)
+            kns = lib.kvm_last_kernel_ns(h)
+            if kns > 0:
+                ex["window_means_w50_points_per_s_kernel"] = cnt_w / (kns * 1e-9)
         except Exception as e:  # extras must never take the headline down
             ex["error"] = repr(e)
         out["extras"] = ex

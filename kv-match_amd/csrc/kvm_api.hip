@@ -256,10 +256,17 @@ extern "C" int kvm_window_means(kvm_ctx *ctx, int32_t w, int32_t first, int64_t 
     HIPCHK(ctx, hipSetDevice(ctx->device));
     int rc = ensure(ctx, ctx->b_scratch, (size_t)count * 8);
     if (rc) return rc;
+    if (ctx->opt_timing) HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
     HIPCHK(ctx, kvm_launch_window_means(ctx->d_series, ctx->d_prefix, w, (int64_t)first - 1, count,
                                         (double *)ctx->b_scratch.p, ctx->stream));
+    if (ctx->opt_timing) HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(out, ctx->b_scratch.p, (size_t)count * 8, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->opt_timing) {  // kernel time alone (the D2H of `count` doubles dominates the call): kvm_last_kernel_ns
+        float ms = 0.f;
+        HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+        ctx->last_kernel_ns = (int64_t)(ms * 1e6);
+    }
     return KVM_OK;
 }
 
