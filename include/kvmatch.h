@@ -93,6 +93,21 @@ int kvm_read_time_series(kvm_ctx *ctx, int32_t left, int32_t length, double *out
  * are these means rounded to 0.05, K/utils/MeanIntervalUtils.java:51-61).  `out` is a HOST array of `count` doubles. */
 int kvm_window_means(kvm_ctx *ctx, int32_t w, int32_t first, int64_t count, double *out);
 
+/* Index build, step 1 ("fixed-width index rows") of K/IndexBuilder.java:186-300 for one window length w, bit for bit:
+ * the row key MeanIntervalUtils.toRound(mean) (K/utils/MeanIntervalUtils.java:50-60) of every window position, with
+ * `mean = ex / w` from the reference's own running sums (restarted every EPOCH = 100000 points, replayed exactly on the
+ * GPU), and consecutive positions with the same key joined into intervals of at most IndexNode.MAXIMUM_DIFF - 1 = 255
+ * positions (:267).  The result lists the intervals in position order: keys[i], first[i], last[i] (1-based window
+ * positions).  Grouping them by key into IndexNode rows (:270-284) and step 2 (:308-347) stay on the host.
+ * 1 <= w <= min(n, 100000).  The result is owned by the library until kvm_index_rows_free. */
+typedef struct kvm_index_rows kvm_index_rows;
+int kvm_index_rows_build(kvm_ctx *ctx, int32_t w, kvm_index_rows **out);
+int64_t kvm_index_rows_count(const kvm_index_rows *r);
+const double *kvm_index_rows_keys(const kvm_index_rows *r);
+const int32_t *kvm_index_rows_first(const kvm_index_rows *r);
+const int32_t *kvm_index_rows_last(const kvm_index_rows *r);
+void kvm_index_rows_free(kvm_index_rows *r);
+
 /* ---- phase 2: the four verification entry points ------------------------------------------------ */
 
 /* RSM-ED.  Replaces K/QueryEngine.java:338-363 (+ sort :373). */

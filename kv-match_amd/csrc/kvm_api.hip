@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <mutex>
 #include <numeric>
 
 #include "kvm_internal.h"
@@ -23,6 +24,8 @@
 #define KVM_TILE_TILED 32               // candidates per tile of the LDS-tiled ED kernel (== ED_ROW_CAND)
 
 static thread_local std::string g_open_err;
+
+static void idx_block_drop();  // pinned result block of the index build, kept per process
 
 static int fail(kvm_ctx *ctx, int code, const std::string &msg) {
     if (ctx) ctx->err = msg; else g_open_err = msg;
@@ -121,6 +124,7 @@ extern "C" int kvm_close(kvm_ctx *ctx) {
     if (ctx->h_pinned) hipHostFree(ctx->h_pinned);
     if (ctx->h_readback) hipHostFree(ctx->h_readback);
     if (ctx->h_readback2) hipHostFree(ctx->h_readback2);
+    idx_block_drop();
     hipEventDestroy(ctx->ev0);
     hipEventDestroy(ctx->ev1);
     hipEventDestroy(ctx->ev_staged);
@@ -268,6 +272,115 @@ extern "C" int kvm_window_means(kvm_ctx *ctx, int32_t w, int32_t first, int64_t 
         ctx->last_kernel_ns = (int64_t)(ms * 1e6);
     }
     return KVM_OK;
+}
+
+// ---- index build, step 1 (kvm_index.hip) ----------------------------------------------------------------------
+// The result lives in one pinned host block (keys | first | last) that the device-to-host copies land in directly; one
+// freed block is kept per process for the next build (the five window lengths of one index build reuse it).
+struct kvm_index_rows {
+    void *block = nullptr;
+    size_t cap = 0;
+    int64_t count = 0;
+    const double *keys = nullptr;
+    const int32_t *first = nullptr, *last = nullptr;
+};
+static std::mutex g_idx_mu;
+static void *g_idx_block = nullptr;
+static size_t g_idx_cap = 0;
+
+static void *idx_block_take(size_t bytes, size_t *cap) {
+    {
+        std::lock_guard<std::mutex> lk(g_idx_mu);
+        if (g_idx_block && g_idx_cap >= bytes) {
+            void *p = g_idx_block;
+            *cap = g_idx_cap;
+            g_idx_block = nullptr;
+            g_idx_cap = 0;
+            return p;
+        }
+    }
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes, hipHostMallocPortable) != hipSuccess) return nullptr;
+    *cap = bytes;
+    return p;
+}
+static void idx_block_give(void *p, size_t cap) {
+    if (!p) return;
+    void *drop = p;
+    {
+        std::lock_guard<std::mutex> lk(g_idx_mu);
+        if (cap > g_idx_cap) {
+            drop = g_idx_block;
+            g_idx_block = p;
+            g_idx_cap = cap;
+        }
+    }
+    if (drop) hipHostFree(drop);
+}
+static void idx_block_drop() {
+    void *p = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_idx_mu);
+        p = g_idx_block;
+        g_idx_block = nullptr;
+        g_idx_cap = 0;
+    }
+    if (p) hipHostFree(p);
+}
+
+extern "C" int kvm_index_rows_build(kvm_ctx *ctx, int32_t w, kvm_index_rows **out) {
+    if (!ctx) return KVM_ERR_INVALID_HANDLE;
+    if (!out) return fail(ctx, KVM_ERR_ILLEGAL_ARGUMENT, "null result pointer");
+    *out = nullptr;
+    if (!ctx->d_series) return fail(ctx, KVM_ERR_NO_SERIES, "no series loaded");
+    if (w < 1 || w > 100000 || (int64_t)w > ctx->n)
+        return fail(ctx, KVM_ERR_ILLEGAL_ARGUMENT, "kvm_index_rows_build: window length outside [1, min(n, EPOCH)]");
+    const int64_t count = ctx->n - w + 1;
+    if (count > 0x7fffffffLL) return fail(ctx, KVM_ERR_ILLEGAL_ARGUMENT, "kvm_index_rows_build: series too long");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    kvm_index_dev dev;
+    if (ctx->opt_timing) hipEventRecord(ctx->ev0, ctx->stream);
+    const int rc = kvm_index_intervals_device(ctx, w, count, &dev, ctx->stream);
+    if (rc) return fail(ctx, rc, "kvm_index_rows_build: device pass failed (out of device memory?)");
+    if (ctx->opt_timing) hipEventRecord(ctx->ev1, ctx->stream);
+    kvm_index_rows *r = new kvm_index_rows();
+    const size_t total = (size_t)dev.total, keys_bytes = (total * 8 + 63) & ~(size_t)63, fl_bytes = (total * 4 + 63) & ~(size_t)63;
+    r->block = idx_block_take(keys_bytes + 2 * fl_bytes + 64, &r->cap);
+    if (!r->block) {
+        kvm_index_dev_free(&dev);
+        delete r;
+        return fail(ctx, KVM_ERR_DEVICE, "kvm_index_rows_build: out of pinned host memory");
+    }
+    char *base = (char *)r->block;
+    const bool ok = hipMemcpyAsync(base, dev.keys, total * 8, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
+                    hipMemcpyAsync(base + keys_bytes, dev.first, total * 4, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
+                    hipMemcpyAsync(base + keys_bytes + fl_bytes, dev.last, total * 4, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
+                    hipStreamSynchronize(ctx->stream) == hipSuccess;
+    kvm_index_dev_free(&dev);
+    if (!ok) {
+        idx_block_give(r->block, r->cap);
+        delete r;
+        return fail(ctx, KVM_ERR_DEVICE, "kvm_index_rows_build: readback failed");
+    }
+    if (ctx->opt_timing) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) == hipSuccess) ctx->last_kernel_ns = (int64_t)(ms * 1e6);
+    }
+    r->count = (int64_t)total;
+    r->keys = (const double *)base;
+    r->first = (const int32_t *)(base + keys_bytes);
+    r->last = (const int32_t *)(base + keys_bytes + fl_bytes);
+    *out = r;
+    return KVM_OK;
+}
+extern "C" int64_t kvm_index_rows_count(const kvm_index_rows *r) { return r ? r->count : 0; }
+extern "C" const double *kvm_index_rows_keys(const kvm_index_rows *r) { return r ? r->keys : nullptr; }
+extern "C" const int32_t *kvm_index_rows_first(const kvm_index_rows *r) { return r ? r->first : nullptr; }
+extern "C" const int32_t *kvm_index_rows_last(const kvm_index_rows *r) { return r ? r->last : nullptr; }
+extern "C" void kvm_index_rows_free(kvm_index_rows *r) {
+    if (!r) return;
+    idx_block_give(r->block, r->cap);
+    delete r;
 }
 
 extern "C" int32_t kvm_resolve_rho(double r, int32_t m) {

@@ -212,6 +212,17 @@ hipError_t kvm_launch_dtw_dp(const double *series, int64_t n, const kvm_query_de
 #define KVM_CNT_TILES_B 13
 #define KVM_CNT_TOTAL 16
 
+// kvm_index.hip: index build step 1 on the device
+struct kvm_index_dev {
+    unsigned long long *keys = nullptr;  // key bit patterns, one per interval
+    int32_t *first = nullptr, *last = nullptr;
+    int64_t total = 0;
+    void *blocks[9] = {};
+};
+int kvm_index_intervals_device(kvm_ctx *ctx, int32_t w, int64_t count, kvm_index_dev *d, hipStream_t s);
+void kvm_index_dev_free(kvm_index_dev *d);
+
+
 // ---- device helpers ---------------------------------------------------------------------------------
 #ifdef __HIPCC__
 // Shifted sums of the 0-based range [s, s+len): returns S1 = sum(x - c), S2 = sum(x - c)^2 and the shift c (= the

@@ -43,6 +43,24 @@ public:
         check(kvm_read_time_series(ctx_, left, length, out.data()), ctx_);
         return out;
     }
+    // Step 1 of IndexBuilder.buildIndexes for window length w (K/IndexBuilder.java:186-300): intervals of consecutive
+    // window positions with the same row key, in position order; `fn(key, first, last)` is called once per interval
+    // (the host groups them into IndexNode rows, :270-284, and runs step 2).
+    template <class Fn>
+    void indexRows(int32_t w, Fn &&fn) {
+        kvm_index_rows *r = nullptr;
+        check(kvm_index_rows_build(ctx_, w, &r), ctx_);
+        const int64_t cnt = kvm_index_rows_count(r);
+        const double *keys = kvm_index_rows_keys(r);
+        const int32_t *first = kvm_index_rows_first(r), *last = kvm_index_rows_last(r);
+        try {
+            for (int64_t i = 0; i < cnt; i++) fn(keys[i], first[i], last[i]);
+        } catch (...) {
+            kvm_index_rows_free(r);
+            throw;
+        }
+        kvm_index_rows_free(r);
+    }
     kvm_ctx *handle() const { return ctx_; }
 
     static void check(int rc, const kvm_ctx *ctx) {

@@ -117,6 +117,24 @@ class Phase2Context:
         _lib.check(self._lib.kvm_window_means(self._h, int(w), int(first), int(count), out.ctypes.data), self._h)
         return out
 
+    def index_rows(self, w):
+        """Step 1 of the index build for window length w (K/IndexBuilder.java:186-300): the intervals of consecutive
+        window positions sharing one row key, in position order, as (keys, first, last) arrays -- the reference's own
+        running sums and MeanIntervalUtils.toRound, bit for bit."""
+        import ctypes as C
+        h = C.c_void_p()
+        _lib.check(self._lib.kvm_index_rows_build(self._h, int(w), C.byref(h)), self._h)
+        try:
+            cnt = int(self._lib.kvm_index_rows_count(h))
+            if cnt == 0:
+                return np.empty(0), np.empty(0, dtype=np.int32), np.empty(0, dtype=np.int32)
+            keys = np.ctypeslib.as_array(self._lib.kvm_index_rows_keys(h), shape=(cnt,)).copy()
+            first = np.ctypeslib.as_array(self._lib.kvm_index_rows_first(h), shape=(cnt,)).copy()
+            last = np.ctypeslib.as_array(self._lib.kvm_index_rows_last(h), shape=(cnt,)).copy()
+        finally:
+            self._lib.kvm_index_rows_free(h)
+        return keys, first, last
+
     def set_option(self, option, value):
         _lib.check(self._lib.kvm_set_option(self._h, int(option), int(value)), self._h)
 

@@ -969,3 +969,109 @@ double kvo_dtw_full(const double *A, const double *B, int m, int r) {
     free(cb);
     return v;
 }
+
+/* ================================================================================================================
+ * Index build, step 1 ("fixed-width index rows"), K/IndexBuilder.java:186-300 for one window length w, on a data file
+ * of exactly n points (K/operator/file/TimeSeriesFileOperator.java readAllTimeSeries).  Test infrastructure, like the
+ * rest of this file (the GPU side is kvm_index_rows).
+ *
+ * The builder streams the series in buffers of EPOCH = 100000 points (:136); every buffer after the first starts with
+ * the last w-1 points of the previous one (:203-208), and the running sums ex / ex2 restart at every buffer (:232-233)
+ * -- "for reducing the floating point error" (:135).  For every window position loc (1-based start offset, :257)
+ *     mean = ex / w (:247),  key = MeanIntervalUtils.toRound(mean) (:263, K/utils/MeanIntervalUtils.java:50-60)
+ * and consecutive positions with the same key (Double.equals, i.e. bit pattern) extend the current interval of that
+ * key's row until it spans MAXIMUM_DIFF - 1 = 255 positions (:266, K/common/entity/IndexNode.java:31); otherwise a new
+ * interval [loc, loc] is started.  Output: the intervals in position order, each with its key.  (Grouping them into
+ * rows by key -- the HashMap of :192,:270-276 -- and step 2's row merging are host logic on top of this list.)
+ * ================================================================================================================ */
+double kvo_to_round(double value) { /* K/utils/MeanIntervalUtils.java:50-60, posOfD = 2 */
+    value *= 10.0;                  /* Math.pow(10, posOfD - 1) == 10.0 */
+    double intValue = floor(value);
+    double diff = value - intValue;
+    double retValue = intValue;
+    if (double_compare(diff, 0.5) >= 0) retValue += 0.5;
+    retValue *= 0.1;                /* Math.pow(10, -posOfD + 1) == 0.1 (the double nearest to 1/10) */
+    return retValue;
+}
+
+static int double_equals(double a, double b) { /* Double.equals: doubleToLongBits equality (NaN == NaN, 0.0 != -0.0) */
+    if (a != a && b != b) return 1;
+    uint64_t ua, ub;
+    memcpy(&ua, &a, 8);
+    memcpy(&ub, &b, 8);
+    return ua == ub;
+}
+
+/* Returns the number of intervals (also when it exceeds cap: only the first cap are written); mean_out (optional,
+ * n - w + 1 doubles) receives the reference's mean of every window position. */
+int64_t kvo_index_rows(const double *series, int64_t n, int32_t w, double *keys, int32_t *first, int32_t *last,
+                       int64_t cap, double *mean_out) {
+    const int EPOCH = 100000;                                            /* :136 */
+    if (w < 1 || w > EPOCH || n < w) return 0;
+    double *buffer = (double *)malloc(sizeof(double) * EPOCH);           /* :147 */
+    double *t = (double *)malloc(sizeof(double) * 2 * (size_t)w);        /* :146 */
+    int64_t cnt_rows = 0, next = 0;                                      /* next: index of the next unread point */
+    int has_last = 0;
+    double lastMeanRound = 0.0;
+    int64_t cur_first = 0;
+    int done = 0;
+    int64_t it = 0;
+    while (!done) {                                                      /* :195 */
+        int ep;
+        if (it == 0) {                                                   /* :197-204 */
+            for (int k = 0; k < w - 1; k++)
+                if (next < n) buffer[k] = series[next++];
+        } else {
+            for (int k = 0; k < w - 1; k++) buffer[k] = buffer[EPOCH - w + 1 + k]; /* :205-208 */
+        }
+        ep = w - 1;                                                      /* :211 */
+        while (ep < EPOCH) {                                             /* :212-220 */
+            if (next < n) buffer[ep++] = series[next++];
+            else break;
+        }
+        if (ep <= w - 1) {                                               /* :224-225 */
+            done = 1;
+        } else {
+            double ex = 0, ex2 = 0;                                      /* :232-233 */
+            for (int i = 0; i < ep; i++) {                               /* :234 */
+                double d = buffer[i];
+                ex += d;                                                 /* :239 */
+                ex2 += d * d;                                            /* :240 */
+                t[i % w] = d;                                            /* :243 */
+                t[(i % w) + w] = d;                                      /* :246 */
+                if (i >= w - 1) {                                        /* :249 */
+                    double mean = ex / w;                                /* :250 */
+                    int j = (i + 1) % w;                                 /* :255 */
+                    int64_t loc = it * (int64_t)(EPOCH - w + 1) + i - w + 1 + 1; /* :258 */
+                    if (loc > n) {                                       /* :259-262 */
+                        done = 1;
+                        break;
+                    }
+                    double curMeanRound = kvo_to_round(mean);            /* :264 */
+                    if (mean_out) mean_out[loc - 1] = mean;
+                    if (!has_last || !double_equals(lastMeanRound, curMeanRound) ||
+                        loc - cur_first == 256 - 1) {                    /* :267 (IndexNode.MAXIMUM_DIFF - 1) */
+                        if (cnt_rows < cap) {                            /* new interval [loc, loc], :277 */
+                            keys[cnt_rows] = curMeanRound;
+                            first[cnt_rows] = (int32_t)loc;
+                            last[cnt_rows] = (int32_t)loc;
+                        }
+                        cnt_rows++;
+                        cur_first = loc;
+                        lastMeanRound = curMeanRound;
+                        has_last = 1;
+                    } else if (cnt_rows - 1 < cap) {
+                        last[cnt_rows - 1] = (int32_t)loc;               /* :283 */
+                    }
+                    ex -= t[j];                                          /* :287 */
+                    ex2 -= t[j] * t[j];                                  /* :288 */
+                }
+            }
+            if (ep < EPOCH) done = 1;                                    /* :293-294 */
+            else it++;
+        }
+    }
+    free(buffer);
+    free(t);
+    return cnt_rows;
+}

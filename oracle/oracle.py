@@ -60,6 +60,10 @@ def load():
     lib.kvo_read_time_series_file.argtypes = [C.c_char_p, i32, i32, i32, vp]
     lib.kvo_resolve_rho.restype = C.c_int
     lib.kvo_resolve_rho.argtypes = [f64, i32]
+    lib.kvo_index_rows.restype = i64
+    lib.kvo_index_rows.argtypes = [vp, i64, i32, vp, vp, vp, i64, vp]
+    lib.kvo_to_round.restype = f64
+    lib.kvo_to_round.argtypes = [f64]
     lib.kvo_query_stats.restype = None
     lib.kvo_query_stats.argtypes = [vp, i32, vp, vp]
     lib.kvo_sort_answers.restype = None
@@ -205,3 +209,24 @@ def query_stats(q):
     a, b = C.c_double(), C.c_double()
     load().kvo_query_stats(q.ctypes.data, q.size, C.byref(a), C.byref(b))
     return a.value, b.value
+
+
+def to_round(value):
+    """MeanIntervalUtils.toRound (K/utils/MeanIntervalUtils.java:50-60)."""
+    return float(load().kvo_to_round(float(value)))
+
+
+def index_rows(series, w, want_means=False):
+    """Index build step 1 (K/IndexBuilder.java:186-300) for window length w: (keys, first, last[, means]) -- the
+    intervals of consecutive window positions with the same row key, in position order, cut at 255 positions."""
+    s = np.ascontiguousarray(series, dtype=np.float64)
+    n = s.size
+    cap = max(n - int(w) + 1, 0)
+    keys = np.empty(cap, dtype=np.float64)
+    first = np.empty(cap, dtype=np.int32)
+    last = np.empty(cap, dtype=np.int32)
+    means = np.empty(cap, dtype=np.float64) if want_means else None
+    cnt = load().kvo_index_rows(s.ctypes.data, n, int(w), keys.ctypes.data, first.ctypes.data, last.ctypes.data, cap,
+                                means.ctypes.data if want_means else None)
+    out = (keys[:cnt].copy(), first[:cnt].copy(), last[:cnt].copy())
+    return out + (means,) if want_means else out

@@ -201,3 +201,48 @@ def test_generator_distribution(built):
     c = datagen.gen_series(300_000, seed=6)
     assert np.array_equal(a, b) and not np.array_equal(a, c)
     assert np.isfinite(a).all() and a.std() > 0.5 and np.abs(a).max() < 5000
+
+
+def test_to_round_known_values(built):
+    """MeanIntervalUtils.toRound (K/utils/MeanIntervalUtils.java:50-60): round down to a multiple of 0.05 in the
+    reference's own operation order (x10, floor, +0.5 when the fraction is >= 0.5, x0.1)."""
+    import math
+    for v, want in [(0.0, 0.0), (1.234, 12.0 * 0.1), (1.25, 12.5 * 0.1), (1.2999, 12.5 * 0.1), (-0.01, -0.5 * 0.1),
+                    (-0.96, -10.0 * 0.1), (7.05, 70.5 * 0.1), (123.449, 1234.0 * 0.1)]:
+        got = oracle.to_round(v)
+        assert got == want or (math.isnan(got) and math.isnan(want)), (v, got, want)
+    assert math.isnan(oracle.to_round(float("nan")))
+
+
+def test_index_rows_restatement_vs_python_loop(built):
+    """Index build step 1 (K/IndexBuilder.java:186-300): the C restatement against a plain Python loop over the same
+    buffers (EPOCH = 100000 points carrying w - 1), including a series longer than two buffers; structural checks."""
+    import math
+    rng = np.random.default_rng(5)
+    s = np.cumsum(rng.uniform(-1.0, 1.0, 230_000)) * 0.05
+    for w in (25, 400):
+        keys, first, last, means = oracle.index_rows(s, w, want_means=True)
+        n = len(s)
+        # tiling of [1, n - w + 1], lengths <= 255, key changes or a full interval at every boundary
+        assert first[0] == 1 and last[-1] == n - w + 1
+        assert np.array_equal(first[1:], last[:-1] + 1)
+        assert (last - first).max() <= 254
+        same = keys[1:] == keys[:-1]
+        assert np.all((last[:-1] - first[:-1] == 254) | ~same)
+        # python loop, buffer by buffer
+        E = 100_000
+        want_means = np.empty(n - w + 1)
+        base = 0
+        while base + w - 1 < n:
+            buf = s[base:base + E].tolist()
+            ex = 0.0
+            for i, d in enumerate(buf):
+                ex += d
+                if i >= w - 1:
+                    want_means[base + i - w + 1] = ex / w
+                    ex -= buf[i - w + 1]
+            base += E - w + 1
+        assert np.array_equal(means, want_means)
+        want_keys = [math.floor(v * 10.0) + (0.5 if v * 10.0 - math.floor(v * 10.0) >= 0.5 else 0.0) for v in want_means.tolist()]
+        want_keys = np.array(want_keys) * 0.1
+        assert np.array_equal(np.repeat(keys, last - first + 1), want_keys)

@@ -593,6 +593,36 @@ def test_window_means_for_index_build(world):
         ctx.window_means(100, first=len(s) - 50, count=10)
 
 
+def test_index_rows_bit_identical_to_reference_loop(world):
+    """index build step 1 (K/IndexBuilder.java:186-300) on the GPU -- row keys and interval
+    boundaries identical to the restated reference loop, bit for bit, for every WuList window length, on series shorter
+    than, equal to and longer than the reference's EPOCH = 100000 buffers (running-sum restarts), and on a series with
+    long constant stretches (intervals cut at 255 positions)."""
+    kvmatch, datagen, series, ctx = world
+    rng = np.random.default_rng(77)
+    flat = np.repeat(rng.uniform(-3, 3, 400), 700)[:250_123]
+    cases = [("short", series[:3_000].copy()), ("one buffer", series[:100_000].copy()),
+             ("buffer+1", series[:100_001].copy()), ("walk", series[:350_017].copy()), ("flat", flat)]
+    for tag, s in cases:
+        ctx.load_series(s)
+        for w in (25, 50, 100, 200, 400):
+            keys, first, last = ctx.index_rows(w)
+            wk, wf, wl = oracle.index_rows(s, w)
+            assert len(keys) == len(wk), (tag, w, len(keys), len(wk))
+            assert np.array_equal(first, wf) and np.array_equal(last, wl), (tag, w)
+            assert np.array_equal(keys.view(np.int64), wk.view(np.int64)), (tag, w)
+    s = series[:5_000].copy()
+    ctx.load_series(s)
+    for w in (1, 4_999, 5_000):
+        keys, first, last = ctx.index_rows(w)
+        wk, wf, wl = oracle.index_rows(s, w)
+        assert np.array_equal(first, wf) and np.array_equal(last, wl) and np.array_equal(keys.view(np.int64), wk.view(np.int64)), w
+    with pytest.raises(kvmatch.KvMatchIllegalArgument):
+        ctx.index_rows(5_001)
+    with pytest.raises(kvmatch.KvMatchIllegalArgument):
+        ctx.index_rows(0)
+
+
 def test_randomised_sweep_all_variants(world):
     """Seeded random sweep over series shape, query length, thresholds and interval layouts: 240 verifications, each
     compared bit for bit with the oracle."""
