@@ -309,6 +309,19 @@ def main():
             r_ = eng.verify((fl, fr), 1, q, a.epsilon)
             ex["full_scan_rsm_ed_candidates_per_s"] = r_.cnt_candidate / (time.perf_counter() - t1)
             ex["full_scan_answers"] = len(r_)
+            # the reference's own full-scan executors as a GPU mode (kvmatch/ucr.py): cNSM-ED in segments of 50 000 offsets
+            # (running sums restart per segment), cNSM-DTW in the executor's EPOCH buffers (bit-identical to it)
+            ue = kvmatch.UcrEdQueryExecutor(ctx, n, m, q, a.epsilon, 1.5, 2.0, segment=50_000)
+            ue.run()
+            t1 = time.perf_counter()
+            ue.run()
+            ex["full_scan_ucr_ed_segmented_candidates_per_s"] = ue.answers.cnt_candidate / (time.perf_counter() - t1)
+            ud = kvmatch.UcrDtwQueryExecutor(ctx, n, m2, q2, 3.0, 204, 1.5, 2.0)
+            ud.run()
+            t1 = time.perf_counter()
+            ud.run()
+            ex["full_scan_ucr_dtw_m4096_candidates_per_s"] = ud.answers.cnt_candidate / (time.perf_counter() - t1)
+            ex["full_scan_ucr_dtw_stats"] = {"pass_filter": ud.answers.stats[1], "dp": ud.answers.stats[4], "answers": len(ud.answers)}
             # index build input: sliding window means of the whole series, w = 50 (K/IndexBuilder.java:232-247)
             cnt_w = min(n - 49, 20_000_000)  # (the API returns host doubles: keep the D2H part of the call bounded)
             ctx.window_means(50, first=1, count=cnt_w)

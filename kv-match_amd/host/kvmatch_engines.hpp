@@ -5,6 +5,7 @@
 #pragma once
 #include <cstdint>
 #include <stdexcept>
+#include <algorithm>
 #include <string>
 #include <utility>
 #include <vector>
@@ -168,6 +169,72 @@ public:
     }
 private:
     Phase2Context &c_;
+};
+
+// Index-free full scans (experiments/ucr/UcrEdQueryExecutor.java, UcrDtwQueryExecutor.java): the same phase-2 path on a
+// candidate list that covers the series; see kvmatch/ucr.py for how the cut of the list reproduces each executor.
+namespace detail {
+inline void segments(int64_t first, int64_t last, int64_t length, std::vector<int32_t> &l, std::vector<int32_t> &r) {
+    for (int64_t f = first; f <= last; f += length) {
+        l.push_back((int32_t)f);
+        r.push_back((int32_t)std::min(f + length - 1, last));
+    }
+}
+}  // namespace detail
+
+// run(): answers sorted by distance, 1-based offsets (UcrEdQueryExecutor.java:161).  segment == 0: one running-sum chain
+// over the whole series as the reference keeps it (sequential); segment > 0: sums restart every `segment` offsets.
+class UcrEdQueryExecutor {
+public:
+    UcrEdQueryExecutor(Phase2Context &c, int64_t N, const std::vector<double> &queryData, double Epsilon, double Alpha,
+                       double Beta, int64_t segment = 0)
+        : c_(c), N_(N), q_(queryData), eps_(Epsilon), alpha_(Alpha), beta_(Beta), segment_(segment) {}
+    Answers run() {
+        const int64_t M = (int64_t)q_.size(), last = N_ - M + 1;
+        if (M < 1 || N_ < M || N_ > kvm_series_length(c_.handle())) throw IllegalArgumentException("N outside [M, series length]");
+        std::vector<int32_t> l, r;
+        detail::segments(1, last, segment_ > 0 ? segment_ : last, l, r);
+        kvm_result *res = nullptr;
+        Phase2Context::check(kvm_verify_cnsm_ed(c_.handle(), q_.data(), (int32_t)M, l.data(), r.data(), (int32_t)l.size(), 0,
+                                                eps_, alpha_, beta_, &res), c_.handle());
+        return detail::collect(res);
+    }
+private:
+    Phase2Context &c_;
+    int64_t N_;
+    std::vector<double> q_;
+    double eps_, alpha_, beta_;
+    int64_t segment_;
+};
+
+// run(): answers sorted by distance, 0-BASED offsets as the reference reports them (UcrDtwQueryExecutor.java:283);
+// EPOCH = 100000 buffers (:97) == intervals of EPOCH - M + 1 offsets.  Rho is the band half-width in points.
+class UcrDtwQueryExecutor {
+public:
+    static constexpr int64_t EPOCH = 100000;
+    UcrDtwQueryExecutor(Phase2Context &c, int64_t N, const std::vector<double> &queryData, double Epsilon, int32_t Rho,
+                        double Alpha, double Beta)
+        : c_(c), N_(N), q_(queryData), eps_(Epsilon), rho_(Rho), alpha_(Alpha), beta_(Beta) {}
+    Answers run() {
+        const int64_t M = (int64_t)q_.size();
+        if (M < 1 || M > EPOCH || N_ < M || N_ > kvm_series_length(c_.handle()))
+            throw IllegalArgumentException("N outside [M, series length] or M > EPOCH");
+        std::vector<int32_t> l, r;
+        detail::segments(1, N_ - M + 1, EPOCH - M + 1, l, r);
+        kvm_result *res = nullptr;
+        Phase2Context::check(kvm_verify_cnsm_dtw(c_.handle(), q_.data(), (int32_t)M, l.data(), r.data(), (int32_t)l.size(), 0,
+                                                 eps_, rho_, alpha_, beta_, &res), c_.handle());
+        Answers a = detail::collect(res);
+        for (Answer &x : a.answers) x.first -= 1;
+        return a;
+    }
+private:
+    Phase2Context &c_;
+    int64_t N_;
+    std::vector<double> q_;
+    double eps_;
+    int32_t rho_;
+    double alpha_, beta_;
 };
 
 }  // namespace kvmatch

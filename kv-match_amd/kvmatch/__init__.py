@@ -6,3 +6,4 @@ from ._lib import (KvMatchDeviceError, KvMatchIllegalArgument, KvMatchIOError, L
                    STAT_PASS_LB_KEOGH2, STAT_PASS_LB_KIM, STAT_RECHECKED, STAT_WINDOWS)
 from .engine import (Answers, NormQueryEngine, NormQueryEngineDtw, Phase2Context, QueryEngine, QueryEngineDtw,  # noqa
                      StatisticInfo)
+from .ucr import UcrDtwQueryExecutor, UcrEdQueryExecutor  # noqa

@@ -244,12 +244,13 @@ class QueryEngineDtw(_EngineBase):
 class NormQueryEngineDtw(_EngineBase):
     """cNSM-DTW (K/NormQueryEngineDtw.java).  ``verify`` replaces lines 457-603."""
 
-    def verify(self, valid_positions, last_segment, query_data, epsilon, rho, alpha, beta, statistics=None):
+    def verify(self, valid_positions, last_segment, query_data, epsilon, rho, alpha, beta, statistics=None, resolved=False):
+        """``resolved=True``: `rho` is already the band half-width in points (not the r <= 1 fraction form)."""
         q = self._query(query_data)
         left, right = _as_intervals(valid_positions)
         res = C.c_void_p()
         c = self.ctx
-        r = c._lib.kvm_resolve_rho(float(rho), q.size)
+        r = int(rho) if resolved else c._lib.kvm_resolve_rho(float(rho), q.size)
         _lib.check(c._lib.kvm_verify_cnsm_dtw(c._h, q.ctypes.data, q.size, left.ctypes.data, right.ctypes.data,
                                               left.size, self._shift(last_segment), float(epsilon), r, float(alpha),
                                               float(beta), C.byref(res)), c._h)

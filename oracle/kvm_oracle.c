@@ -1075,3 +1075,218 @@ int64_t kvo_index_rows(const double *series, int64_t n, int32_t w, double *keys,
     free(t);
     return cnt_rows;
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* Index-free full scans: the UCR-suite style executors the reference's experiments use as ground truth
+ * (K/experiments/NormQueryTestGroupBySelectivity.java:115-126, NormQueryDtwTestGroupBySelectivity.java:116).
+ * `U/` = src/main/java/cn/edu/fudan/dsm/kvmatch/experiments/ucr/.  The scanner (readAllTimeSeries) is restated as a
+ * pass over the first n points of the series; N == n (the reference's `++cnt <= N` guard, U/UcrEdQueryExecutor.java:60-63,
+ * skips the count at node boundaries and is only a loose upper limit). */
+
+/* U/UcrEdQueryExecutor.java:96-175.  One pair of running sums over the WHOLE series (never restarted); answers are
+ * 1-based offsets (`i - M + 2`, :161).  The inner loop abandons on `sum < bsf` (:88), acceptance is `dist <= eps^2`. */
+int64_t kvo_ucr_ed(const double *series, int n, const double *queryData, int M, double Epsilon, double Alpha, double Beta,
+                   int32_t *out_off, double *out_dist, int64_t cap, int64_t *stats) {
+    kvo_answers answers = {out_off, out_dist, cap, 0, 0};
+    int64_t windows = 0, passed = 0;
+    double ex = 0, ex2 = 0;
+    double *Q = (double *)malloc((size_t)M * sizeof(double));
+    for (int i = 0; i < M; i++) { /* :98-103 */
+        double d = queryData[i];
+        ex += d;
+        ex2 += d * d;
+        Q[i] = d;
+    }
+    double meanQ = ex / M; /* :106-108 */
+    double stdQ = ex2 / M;
+    stdQ = sqrt(stdQ - meanQ * meanQ);
+    for (int i = 0; i < M; i++) Q[i] = (Q[i] - meanQ) / stdQ;
+    int *order = (int *)malloc((size_t)M * sizeof(int));
+    kvo_index *Q_tmp = (kvo_index *)malloc((size_t)M * sizeof(kvo_index));
+    for (int i = 0; i < M; i++) {
+        Q_tmp[i].value = Q[i];
+        Q_tmp[i].index = i;
+    }
+    stable_sort_index(Q_tmp, M, cmp_abs_desc); /* :119-123, Double.compare(|o2|, |o1|) */
+    for (int i = 0; i < M; i++) {
+        Q[i] = Q_tmp[i].value;
+        order[i] = Q_tmp[i].index;
+    }
+    double *t = (double *)calloc((size_t)2 * M, sizeof(double));
+    const double bsf = Epsilon * Epsilon;
+    ex = ex2 = 0;
+    for (int i = 0; i < n; i++) { /* :143-171 */
+        double d = series[i];
+        ex += d;
+        ex2 += d * d;
+        t[i % M] = d;
+        t[(i % M) + M] = d;
+        if (i >= M - 1) {
+            int j = (i + 1) % M;
+            windows++;
+            double mean = ex / M;
+            double std = ex2 / M;
+            std = sqrt(std - mean * mean);
+            if (fabs(mean - meanQ) <= Beta && (std / stdQ) <= Alpha && (std / stdQ) >= 1.0 / Alpha) {
+                passed++;
+                double sum = 0; /* distance(), :85-92 */
+                for (int k = 0; k < M && sum < bsf; k++) {
+                    double x = (t[(order[k] + j)] - mean) / std;
+                    sum += (x - Q[k]) * (x - Q[k]);
+                }
+                if (sum <= Epsilon * Epsilon) answers_add(&answers, i - M + 2, sqrt(sum));
+            }
+            ex -= t[j];
+            ex2 -= t[j] * t[j];
+        }
+    }
+    free(Q); free(order); free(Q_tmp); free(t);
+    if (answers.overflow) return KVO_ERR_CAPACITY;
+    stable_sort_answers(out_off, out_dist, answers.cnt);
+    if (stats) {
+        memset(stats, 0, KVO_NSTAT * sizeof(int64_t));
+        stats[0] = windows;
+        stats[1] = answers.cnt;
+        stats[2] = windows;
+        stats[3] = passed;
+    }
+    return answers.cnt;
+}
+
+/* U/UcrDtwQueryExecutor.java:84-315.  Buffers of EPOCH = 100000 points carrying M - 1 (:97,168-197); running sums
+ * and the data envelope restart per buffer (:204,213-214); answers are 0-BASED offsets
+ * (`it * (EPOCH - M + 1) + i - M + 1`, :283).  cb1/cb2 are reused without clearing (:157-161); a stale entry is only
+ * ever read after a bound has already reached bsf.  The query order uses the truncating comparator of
+ * K/NormQueryEngineDtw.java:475-490 (same stable-sort stand-in as kvo_query_cnsm_dtw). */
+int64_t kvo_ucr_dtw(const double *series, int n, const double *queryData, int M, double Epsilon, int Rho, double Alpha,
+                    double Beta, int32_t *out_off, double *out_dist, int64_t cap, int64_t *stats) {
+    const int EPOCH = 100000;
+    if (M > EPOCH || M < 1) return KVO_ERR_ILLEGAL_ARGUMENT;
+    kvo_answers answers = {out_off, out_dist, cap, 0, 0};
+    int64_t windows = 0, passed = 0, pKim = 0, pK1 = 0, pK2 = 0, cells = 0;
+    double *q = (double *)malloc((size_t)M * sizeof(double));
+    double *qo = (double *)malloc((size_t)M * sizeof(double));
+    double *uo = (double *)malloc((size_t)M * sizeof(double));
+    double *lo = (double *)malloc((size_t)M * sizeof(double));
+    int *order = (int *)malloc((size_t)M * sizeof(int));
+    kvo_index *Q_tmp = (kvo_index *)malloc((size_t)M * sizeof(kvo_index));
+    double *u = (double *)malloc((size_t)M * sizeof(double));
+    double *l = (double *)malloc((size_t)M * sizeof(double));
+    double *cb = (double *)calloc((size_t)M, sizeof(double));
+    double *cb1 = (double *)calloc((size_t)M, sizeof(double));
+    double *cb2 = (double *)calloc((size_t)M, sizeof(double));
+    double *t = (double *)calloc((size_t)2 * M, sizeof(double));
+    double *tz = (double *)malloc((size_t)M * sizeof(double));
+    double *buffer = (double *)calloc((size_t)EPOCH, sizeof(double));
+    double *u_buff = (double *)malloc((size_t)EPOCH * sizeof(double));
+    double *l_buff = (double *)malloc((size_t)EPOCH * sizeof(double));
+    double ex = 0, ex2 = 0;
+    for (int i = 0; i < M; i++) { /* :118-123 */
+        double d = queryData[i];
+        ex += d;
+        ex2 += d * d;
+        q[i] = d;
+    }
+    double meanQ = ex / M; /* :126-131 */
+    double stdQ = ex2 / M;
+    stdQ = sqrt(stdQ - meanQ * meanQ);
+    for (int i = 0; i < M; i++) q[i] = (q[i] - meanQ) / stdQ;
+    kvo_lower_upper_lemire(q, M, Rho, l, u); /* :134 */
+    for (int i = 0; i < M; i++) {
+        Q_tmp[i].value = q[i];
+        Q_tmp[i].index = i;
+    }
+    stable_sort_index(Q_tmp, M, cmp_abs_desc_trunc); /* :140-143 */
+    for (int i = 0; i < M; i++) { /* :146-154 */
+        int o = Q_tmp[i].index;
+        order[i] = o;
+        qo[i] = q[o];
+        uo[i] = u[o];
+        lo[i] = l[o];
+    }
+    const double bsf = Epsilon * Epsilon;
+    int64_t next = 0; /* scanner position */
+    int done = 0, it = 0;
+    while (!done) {
+        if (it == 0) { /* :170-180 */
+            for (int k = 0; k < M - 1; k++)
+                if (next < n) buffer[k] = series[next++];
+        } else { /* :181-185 */
+            for (int k = 0; k < M - 1; k++) buffer[k] = buffer[EPOCH - M + 1 + k];
+        }
+        int ep = M - 1; /* :188-198 */
+        while (ep < EPOCH) {
+            if (next >= n) break;
+            buffer[ep] = series[next++];
+            ep++;
+        }
+        if (ep <= M - 1) { /* :202 */
+            done = 1;
+        } else {
+            kvo_lower_upper_lemire(buffer, ep, Rho, l_buff, u_buff); /* :205 */
+            ex = 0;
+            ex2 = 0;
+            for (int i = 0; i < ep; i++) { /* :215-296 */
+                double d = buffer[i];
+                ex += d;
+                ex2 += d * d;
+                t[i % M] = d;
+                t[(i % M) + M] = d;
+                if (i >= M - 1) {
+                    windows++;
+                    double mean = ex / M;
+                    double std = ex2 / M;
+                    std = sqrt(std - mean * mean);
+                    int j = (i + 1) % M;
+                    int I = i - (M - 1);
+                    if (fabs(mean - meanQ) <= Beta && (std / stdQ) <= Alpha && (std / stdQ) >= 1.0 / Alpha) {
+                        passed++;
+                        double lb_kim = kvo_lb_kim_hierarchy(t, q, j, M, mean, std, bsf);
+                        if (lb_kim <= Epsilon * Epsilon) {
+                            pKim++;
+                            double lb_k = kvo_lb_keogh_cumulative(order, t, uo, lo, cb1, j, M, mean, std, bsf);
+                            if (lb_k <= Epsilon * Epsilon) {
+                                pK1++;
+                                for (int k = 0; k < M; k++) tz[k] = (t[(k + j)] - mean) / std;
+                                double lb_k2 = kvo_lb_keogh_data_cumulative(order, qo, cb2, I, l_buff, u_buff, M, mean, std, bsf);
+                                if (lb_k2 <= Epsilon * Epsilon) {
+                                    pK2++;
+                                    if (lb_k > lb_k2) {
+                                        cb[M - 1] = cb1[M - 1];
+                                        for (int k = M - 2; k >= 0; k--) cb[k] = cb[k + 1] + cb1[k];
+                                    } else {
+                                        cb[M - 1] = cb2[M - 1];
+                                        for (int k = M - 2; k >= 0; k--) cb[k] = cb[k + 1] + cb2[k];
+                                    }
+                                    double dist = kvo_dtw(tz, q, cb, M, Rho, bsf, &cells);
+                                    if (dist <= Epsilon * Epsilon)
+                                        answers_add(&answers, (int32_t)((int64_t)it * (EPOCH - M + 1) + i - M + 1), sqrt(dist));
+                                }
+                            }
+                        }
+                    }
+                    ex -= t[j];
+                    ex2 -= t[j] * t[j];
+                }
+            }
+            if (ep < EPOCH) done = 1; /* :299-303 */
+            else it++;
+        }
+    }
+    free(q); free(qo); free(uo); free(lo); free(order); free(Q_tmp); free(u); free(l);
+    free(cb); free(cb1); free(cb2); free(t); free(tz); free(buffer); free(u_buff); free(l_buff);
+    if (answers.overflow) return KVO_ERR_CAPACITY;
+    stable_sort_answers(out_off, out_dist, answers.cnt);
+    if (stats) {
+        memset(stats, 0, KVO_NSTAT * sizeof(int64_t));
+        stats[0] = windows;
+        stats[1] = answers.cnt;
+        stats[2] = windows;
+        stats[3] = passed;
+        stats[4] = pKim;
+        stats[5] = pK1;
+        stats[6] = pK2;
+        stats[7] = cells;
+    }
+    return answers.cnt;
+}

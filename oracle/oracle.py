@@ -60,6 +60,10 @@ def load():
     lib.kvo_read_time_series_file.argtypes = [C.c_char_p, i32, i32, i32, vp]
     lib.kvo_resolve_rho.restype = C.c_int
     lib.kvo_resolve_rho.argtypes = [f64, i32]
+    lib.kvo_ucr_ed.restype = i64
+    lib.kvo_ucr_ed.argtypes = [vp, i32, vp, i32, f64, f64, f64, vp, vp, i64, vp]
+    lib.kvo_ucr_dtw.restype = i64
+    lib.kvo_ucr_dtw.argtypes = [vp, i32, vp, i32, f64, i32, f64, f64, vp, vp, i64, vp]
     lib.kvo_index_rows.restype = i64
     lib.kvo_index_rows.argtypes = [vp, i64, i32, vp, vp, vp, i64, vp]
     lib.kvo_to_round.restype = f64
@@ -125,6 +129,34 @@ def cnsm_dtw(series, query, left, right, shift, eps, rho, alpha, beta):
     cnt = load().kvo_query_cnsm_dtw(s.ctypes.data, s.size, q.ctypes.data, q.size, l.ctypes.data, r.ctypes.data,
                                     l.size, int(shift), float(eps), int(rho), float(alpha), float(beta),
                                     off.ctypes.data, dist.ctypes.data, cap, st.ctypes.data)
+    return _done(cnt, off, dist, st)
+
+
+def ucr_ed(series, query, eps, alpha, beta):
+    """U/UcrEdQueryExecutor.java:96-175 (index-free cNSM-ED full scan, one running sum over the whole series);
+    1-based offsets."""
+    s = np.ascontiguousarray(series, dtype=np.float64)
+    q = np.ascontiguousarray(query, dtype=np.float64)
+    cap = max(s.size - q.size + 1, 0) + 1
+    off = np.empty(cap, dtype=np.int32)
+    dist = np.empty(cap, dtype=np.float64)
+    st = np.zeros(NSTAT, dtype=np.int64)
+    cnt = load().kvo_ucr_ed(s.ctypes.data, s.size, q.ctypes.data, q.size, float(eps), float(alpha), float(beta),
+                            off.ctypes.data, dist.ctypes.data, cap, st.ctypes.data)
+    return _done(cnt, off, dist, st)
+
+
+def ucr_dtw(series, query, eps, rho, alpha, beta):
+    """U/UcrDtwQueryExecutor.java:84-315 (index-free cNSM-DTW full scan in EPOCH = 100000 buffers); 0-BASED offsets,
+    as the reference reports them (:283)."""
+    s = np.ascontiguousarray(series, dtype=np.float64)
+    q = np.ascontiguousarray(query, dtype=np.float64)
+    cap = max(s.size - q.size + 1, 0) + 1
+    off = np.empty(cap, dtype=np.int32)
+    dist = np.empty(cap, dtype=np.float64)
+    st = np.zeros(NSTAT, dtype=np.int64)
+    cnt = load().kvo_ucr_dtw(s.ctypes.data, s.size, q.ctypes.data, q.size, float(eps), int(rho), float(alpha),
+                             float(beta), off.ctypes.data, dist.ctypes.data, cap, st.ctypes.data)
     return _done(cnt, off, dist, st)
 
 

@@ -246,3 +246,30 @@ def test_index_rows_restatement_vs_python_loop(built):
         want_keys = [math.floor(v * 10.0) + (0.5 if v * 10.0 - math.floor(v * 10.0) >= 0.5 else 0.0) for v in want_means.tolist()]
         want_keys = np.array(want_keys) * 0.1
         assert np.array_equal(np.repeat(keys, last - first + 1), want_keys)
+
+
+def test_ucr_executors_equal_engine_restatements_on_the_matching_candidate_lists(built):
+    """SURVEY 8f rank 4, and a second, independent check of the restatements: the UCR-style full-scan executors
+    (U/UcrEdQueryExecutor.java, U/UcrDtwQueryExecutor.java) and the engines' phase 2 are separate reference code for the
+    same search.  UcrEd == NormQueryEngine on the single interval [1, n-m+1]; UcrDtw == NormQueryEngineDtw on intervals
+    of EPOCH - m + 1 offsets (0-based offsets); both bit for bit."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "kv-match_amd"))
+    from kvmatch import datagen
+    from kvmatch.ucr import segments, EPOCH
+    n, m = 230_000, 256
+    s = datagen.gen_series(n, seed=3)
+    q = datagen.plant_copies(s, 20_000, m, [99_900, 150_000, 229_000], [1.0, 1.3, 0.7], [0.0, 0.4, -0.5], 0.03)
+    eps, alpha, beta, rho = 2.5, 1.5, 1.0, 12
+    L, R = np.array([1], dtype=np.int32), np.array([n - m + 1], dtype=np.int32)
+    uo, ud, ust = oracle.ucr_ed(s, q, eps, alpha, beta)
+    eo, ed, est = oracle.cnsm_ed(s, q, L, R, 0, eps, alpha, beta)
+    assert len(uo) >= 3 and np.array_equal(uo, eo) and np.array_equal(ud, ed)
+    assert ust["pass_filter"] == est["pass_filter"] and ust["windows"] == est["windows"]
+    Ls, Rs = segments(1, n - m + 1, EPOCH - m + 1)
+    assert len(Ls) == 3 and Ls[1] == EPOCH - m + 2 and Rs[-1] == n - m + 1
+    uo, ud, ust = oracle.ucr_dtw(s, q, eps, rho, alpha, beta)
+    eo, ed, est = oracle.cnsm_dtw(s, q, Ls, Rs, 0, eps, rho, alpha, beta)
+    assert len(uo) >= 3 and np.array_equal(uo, eo - 1) and np.array_equal(ud, ed)
+    for k in ("windows", "pass_filter", "pass_kim", "pass_keogh", "pass_keogh2"):
+        assert ust[k] == est[k], k

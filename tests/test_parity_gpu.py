@@ -623,6 +623,44 @@ def test_index_rows_bit_identical_to_reference_loop(world):
         ctx.index_rows(0)
 
 
+def test_ucr_full_scan_executors(world):
+    """the index-free full scans (U/UcrEdQueryExecutor.java, U/UcrDtwQueryExecutor.java) as a GPU
+    mode, against the restated executors -- offsets, order and distances bit-identical; series longer than two of the
+    DTW executor's EPOCH buffers, answers planted across a buffer boundary.  The segmented ED mode restarts the running
+    sums per segment (engine semantics): bit-identical to the engine restatement on that list, and the same answers as
+    the single-chain executor up to the last bits of the distances."""
+    kvmatch, datagen, series, ctx = world
+    from kvmatch.ucr import segments, EPOCH
+    n, m = 230_000, 256
+    s = series[:n].copy()
+    q = datagen.plant_copies(s, 20_000, m, [99_400, 99_900, 150_000, 229_000], [1.0, 1.0, 1.3, 0.7], [0.0, 0.0, 0.4, -0.5], 0.03)
+    ctx.load_series(s)
+    eps, alpha, beta, rho = 2.5, 1.5, 1.0, 12
+    ex = kvmatch.UcrEdQueryExecutor(ctx, n, m, q, eps, alpha, beta)
+    wo, wd, wst = oracle.ucr_ed(s, q, eps, alpha, beta)
+    assert ex.run() == len(wo) >= 4
+    assert np.array_equal(ex.answers.offsets, wo) and np.array_equal(ex.answers.distances, wd)
+    assert ex.answers.stats[1] == wst["pass_filter"]
+    seg = kvmatch.UcrEdQueryExecutor(ctx, n, m, q, eps, alpha, beta, segment=10_000)
+    assert seg.run() == len(wo)
+    L, R = segments(1, n - m + 1, 10_000)
+    compare(seg.answers, oracle.cnsm_ed(s, q, L, R, 0, eps, alpha, beta), tag="segmented ucr_ed")
+    assert sorted(seg.answers.offsets.tolist()) == sorted(wo.tolist())
+    od = dict(zip(wo.tolist(), wd.tolist()))
+    assert rel_close(seg.answers.distances, np.array([od[o] for o in seg.answers.offsets.tolist()]), abs_floor=1e-9)
+    dx = kvmatch.UcrDtwQueryExecutor(ctx, n, m, q, eps, rho, alpha, beta)
+    wo, wd, wst = oracle.ucr_dtw(s, q, eps, rho, alpha, beta)
+    assert dx.run() == len(wo) >= 4
+    assert np.array_equal(dx.answers.offsets, wo) and np.array_equal(dx.answers.distances, wd)
+    assert dx.answers.stats[1] == wst["pass_filter"]
+    # N < series length: only the first N points are scanned
+    half = kvmatch.UcrDtwQueryExecutor(ctx, 120_000, m, q, eps, rho, alpha, beta)
+    wo, wd, _ = oracle.ucr_dtw(s[:120_000], q, eps, rho, alpha, beta)
+    assert half.run() == len(wo) and np.array_equal(half.answers.offsets, wo) and np.array_equal(half.answers.distances, wd)
+    with pytest.raises(kvmatch.KvMatchIllegalArgument):
+        kvmatch.UcrEdQueryExecutor(ctx, n + 1, m, q, eps, alpha, beta)
+
+
 def test_randomised_sweep_all_variants(world):
     """Seeded random sweep over series shape, query length, thresholds and interval layouts: 240 verifications, each
     compared bit for bit with the oracle."""
