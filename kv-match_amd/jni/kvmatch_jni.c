@@ -96,6 +96,52 @@ JNIEXPORT jobject JNICALL Java_cn_edu_fudan_dsm_kvmatch_gpu_Phase2Gpu_cnsmDtw(JN
     (void)self;
     KVM_JNI_BODY(kvm_verify_cnsm_dtw(ctx, pq, m, (const int32_t *)pl, (const int32_t *)pr, k, shift, eps, rho, alpha, beta, &res))
 }
+
+/* TimeSeriesOperator.readTimeSeries(left, length) from HBM (K/operator/TimeSeriesOperator.java:38) */
+JNIEXPORT jdoubleArray JNICALL Java_cn_edu_fudan_dsm_kvmatch_gpu_Phase2Gpu_readTimeSeries(JNIEnv *env, jclass c, jlong h,
+                                                                                       jint left, jint length) {
+    (void)c;
+    kvm_ctx *ctx = (kvm_ctx *)(intptr_t)h;
+    jdoubleArray out = (*env)->NewDoubleArray(env, length > 0 ? length : 0);
+    if (!out) return 0;
+    double *p = PIN(out);
+    int rc = kvm_read_time_series(ctx, left, length, p);
+    (*env)->ReleasePrimitiveArrayCritical(env, out, p, 0);
+    if (rc) { throw_for(env, ctx, rc); return 0; }
+    return out;
+}
+
+/* Index build step 1 (K/IndexBuilder.java:186-300): build, bulk accessors, free */
+JNIEXPORT jlong JNICALL Java_cn_edu_fudan_dsm_kvmatch_gpu_Phase2Gpu_indexRowsBuild(JNIEnv *env, jclass c, jlong h, jint w) {
+    (void)c;
+    kvm_ctx *ctx = (kvm_ctx *)(intptr_t)h;
+    kvm_index_rows *rows = 0;
+    int rc = kvm_index_rows_build(ctx, w, &rows);
+    if (rc) { throw_for(env, ctx, rc); return 0; }
+    return (jlong)(intptr_t)rows;
+}
+JNIEXPORT jlong JNICALL Java_cn_edu_fudan_dsm_kvmatch_gpu_Phase2Gpu_indexRowsCount(JNIEnv *env, jclass c, jlong rows) {
+    (void)env; (void)c;
+    return kvm_index_rows_count((const kvm_index_rows *)(intptr_t)rows);
+}
+/* copies intervals [from, from + keys.length) into the caller's arrays */
+JNIEXPORT void JNICALL Java_cn_edu_fudan_dsm_kvmatch_gpu_Phase2Gpu_indexRowsGet(JNIEnv *env, jclass c, jlong rows, jlong from,
+        jdoubleArray keys, jintArray first, jintArray last) {
+    (void)c;
+    const kvm_index_rows *r = (const kvm_index_rows *)(intptr_t)rows;
+    jsize cnt = (*env)->GetArrayLength(env, keys);
+    if (from < 0 || from + cnt > kvm_index_rows_count(r)) {
+        (*env)->ThrowNew(env, (*env)->FindClass(env, "java/lang/IllegalArgumentException"), "index rows range");
+        return;
+    }
+    (*env)->SetDoubleArrayRegion(env, keys, 0, cnt, kvm_index_rows_keys(r) + from);
+    (*env)->SetIntArrayRegion(env, first, 0, cnt, (const jint *)(kvm_index_rows_first(r) + from));
+    (*env)->SetIntArrayRegion(env, last, 0, cnt, (const jint *)(kvm_index_rows_last(r) + from));
+}
+JNIEXPORT void JNICALL Java_cn_edu_fudan_dsm_kvmatch_gpu_Phase2Gpu_indexRowsFree(JNIEnv *env, jclass c, jlong rows) {
+    (void)env; (void)c;
+    kvm_index_rows_free((kvm_index_rows *)(intptr_t)rows);
+}
 #else
 /* no <jni.h> in this toolchain: nothing to build */
 typedef int kvm_jni_not_built;
