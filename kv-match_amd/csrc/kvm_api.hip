@@ -696,7 +696,8 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
         if ((rc = ensure(ctx, ctx->b_scratch, sbytes + 2 * mbytes + 64))) return rc;
         rws.runs = (const kvm_run *)((const char *)ctx->b_query.p + qbytes);
         rws.n_runs = pl.n_runs;
-        rws.stats = (double2 *)ctx->b_scratch.p;
+        rws.stats = (double *)ctx->b_scratch.p;
+        rws.stats_plane = pl.windows;
         rws.run_maxk = (int32_t *)((char *)ctx->b_scratch.p + sbytes);
         rws.run_list = rws.run_maxk + pl.n_runs;
         rws.run_list_n = (unsigned long long *)ctx->b_counters.p + KVM_CNT_REPLAY_RUNS;

@@ -133,12 +133,12 @@ __global__ __launch_bounds__(EX_THREADS) void kvm_replay_runs_kernel(const doubl
                 // Window steps.  Branch-free: the departing point's term is 0.0 where the reference does not subtract
                 // (x - 0.0 == x bit for bit), and the running sum is stored for EVERY window up to the last one a
                 // survivor needs (the readers look only at theirs), so a round is straight-line code whose LDS reads
-                // stay one round ahead.  ws.stats[k] = {ex, ex2}: each consumer stores its own half.
+                // stay one round ahead.  ws.stats plane 0 = ex, plane 1 = ex2: each consumer stores its own plane.
                 {
                     constexpr int R = 4;  // steps per register set
                     double dv[2][R], ov[2][R];
                     double a_l = acc, dummy = 0.0;
-                    double *st_out = reinterpret_cast<double *>(ws.stats + run.win_base + (c0 - (int64_t)(m - 1))) + wave;
+                    double *st_out = ws.stats + (int64_t)wave * ws.stats_plane + run.win_base + (c0 - (int64_t)(m - 1));
                     const int nw = cnt - n_add, rounds = nw / (2 * R);
                     auto fetch = [&](int t0, int set) {
 #pragma unroll
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(EX_THREADS) void kvm_replay_runs_kernel(const doubl
 #pragma unroll
                         for (int u = 0; u < R; u++) {
                             a_l += dv[set][u];              // K/NormQueryEngine.java:498 / :499
-                            st_out[2 * (t0 + u)] = a_l;     // -> mean, std (:507-508) in the readers
+                            st_out[t0 + u] = a_l;           // -> mean, std (:507-508) in the readers
                             a_l -= ov[set][u];              // :523 / :524
                         }
                     };
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(EX_THREADS) void kvm_replay_runs_kernel(const doubl
                     }
                     for (int t = n_add + rounds * 2 * R; t < cnt; t++) {
                         a_l += dbuf[t];
-                        st_out[2 * t] = a_l;
+                        st_out[t] = a_l;
                         a_l -= obuf[t];
                     }
                     acc = a_l;
@@ -229,9 +229,9 @@ __global__ __launch_bounds__(EX_THREADS) void kvm_exact_ed_kernel(const double *
                 if (NORM) {
                     // the reference's running sums of this window (replayed per run by kvm_replay_runs_kernel)
                     const int64_t r = ex_find_run(ws.runs, ws.n_runs, sv.run_start);
-                    const double2 st = ws.stats[ws.runs[r].win_base + (sv.start - sv.run_start)];
-                    mean = st.x / m;                     // K/NormQueryEngine.java:507
-                    std = sqrt(st.y / m - mean * mean);  // :508
+                    const int64_t wi = ws.runs[r].win_base + (sv.start - sv.run_start);
+                    mean = ws.stats[wi] / m;                                     // K/NormQueryEngine.java:507
+                    std = sqrt(ws.stats[ws.stats_plane + wi] / m - mean * mean);  // :508
                     if (!kvm_cnsm_filter(mean, std, qd.meanQ, qd.stdQ, qd.alpha, qd.beta)) active = 0;
                     else atomicAdd(&counters[KVM_CNT_PASS_FILTER_EXACT], 1ULL);
                 }
@@ -351,9 +351,9 @@ __global__ __launch_bounds__(256) void kvm_exact_stats_apply_kernel(kvm_query_de
          i += (unsigned long long)gridDim.x * blockDim.x) {
         kvm_cand c = cands[i];
         const int64_t r = ex_find_run(ws.runs, ws.n_runs, c.run_start);
-        const double2 st = ws.stats[ws.runs[r].win_base + (c.start - c.run_start)];  // {ex, ex2} of the replay
-        const double mean = st.x / qd.m;                        // K/NormQueryEngineDtw.java:550
-        const double std = sqrt(st.y / qd.m - mean * mean);     // :551
+        const int64_t wi = ws.runs[r].win_base + (c.start - c.run_start);  // ex, ex2 of the replay
+        const double mean = ws.stats[wi] / qd.m;                                      // K/NormQueryEngineDtw.java:550
+        const double std = sqrt(ws.stats[ws.stats_plane + wi] / qd.m - mean * mean);  // :551
         c.mean = mean;
         c.std = std;
         if (!kvm_cnsm_filter(mean, std, qd.meanQ, qd.stdQ, qd.alpha, qd.beta)) c.start = -c.start;

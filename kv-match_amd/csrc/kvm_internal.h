@@ -37,7 +37,8 @@ struct kvm_replay_ws {
     const kvm_run *runs;
     int64_t n_runs;
     int32_t *run_maxk;     // [n_runs]  number of leading windows of the run that must be replayed (0 = none)
-    double2 *stats;        // [windows] {ex, ex2}: the reference's running sums when the flagged window completes
+    double *stats;         // [2][windows] plane 0 = ex, plane 1 = ex2: the reference's running sums when the window completes
+    int64_t stats_plane;   // windows (offset of plane 1); one plane per consumer wave: contiguous 8-byte stores
     int32_t *run_list;     // [n_runs]  indices of the runs with run_maxk > 0, in marking order
     unsigned long long *run_list_n;  // number of entries (counters[KVM_CNT_REPLAY_RUNS])
 };
