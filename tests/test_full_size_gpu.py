@@ -1,0 +1,92 @@
+"""GPU parity at BASELINE.json's FULL sizes (-m gpu): n = 1e8 points, m = 8192 / 4096, 1e6 candidates in phase-1-shaped
+intervals (configs[1..3]).  The oracle (with the reference's early abandoning) is fast enough on these lists to compare
+against directly; on top of that, size-independent properties: the self match and every planted copy are found, the
+answers do not depend on the pruning kernel, the early-abandon switch or on how the list is sharded, and cntCandidate is
+additive over shards."""
+import numpy as np
+import pytest
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+N = 100_000_000
+
+
+@pytest.fixture(scope="module")
+def big(built):
+    import kvmatch
+    from kvmatch import datagen
+    series = datagen.gen_series(N)
+    m = 8192
+    qoff = N // 3 + 17
+    planted = [N // 7, N // 2 + 1000, N - 3 * m]
+    q = datagen.plant_copies(series, qoff, m, planted, [1.0, 1.0, 1.0], [0.0, 0.02, -0.03], 0.01)
+    ctx = kvmatch.Phase2Context(0)
+    ctx.load_series(series)
+    yield kvmatch, datagen, series, ctx, q, qoff, planted
+    ctx.close()
+
+
+def same(got, want):
+    return len(got) == len(want[0]) and np.array_equal(got.offsets, want[0]) and np.array_equal(got.distances, want[1])
+
+
+def test_rsm_ed_and_cnsm_ed_config_2_3(big):
+    kvmatch, datagen, series, ctx, q, qoff, planted = big
+    from kvmatch import distributed
+    m = 8192
+    L, R = datagen.gen_intervals(N, m, 1_000_000, 64.0, must_cover=[qoff] + planted, seed=1)
+    assert int((R.astype(np.int64) - L + 1).sum()) >= 1_000_000
+    want = oracle.rsm_ed(series, q, L, R, 0, 10.0)
+    eng = kvmatch.QueryEngine(ctx)
+    for kern in (0, 1, 2, 3, 4):          # every pruning kernel, abandon on and off: one answer list
+        ctx.set_option(kvmatch.OPT_ED_KERNEL, kern)
+        for ab in (1, 0):
+            ctx.set_option(kvmatch.OPT_EARLY_ABANDON, ab)
+            got = eng.verify((L, R), 1, q, 10.0)
+            assert same(got, want), (kern, ab)
+            assert got.cnt_candidate == want[2]["cnt_candidate"]
+    ctx.set_option(kvmatch.OPT_ED_KERNEL, 0)
+    ctx.set_option(kvmatch.OPT_EARLY_ABANDON, 1)
+    offs = set(want[0].tolist())
+    assert qoff in offs and all(p in offs for p in planted)
+    assert want[1][0] == 0.0 and want[0][0] == qoff                       # the self match, distance exactly 0
+    # sharding invariance: the union of the shards' answers is the unsharded list, cntCandidate is additive
+    for world in (2, 8):
+        o, d, c = [], [], 0
+        for rank in range(world):
+            l, r = distributed.split_intervals(L, R, world, rank)
+            a = eng.verify((l, r), 1, q, 10.0)
+            o.append(a.offsets); d.append(a.distances); c += a.cnt_candidate
+        so, sd = distributed.sort_answers(np.concatenate(o), np.concatenate(d))
+        assert c == want[2]["cnt_candidate"] and np.array_equal(so, want[0]) and np.array_equal(sd, want[1])
+    # cNSM-ED, configs[2]: alpha / beta from SURVEY 8d
+    neng = kvmatch.NormQueryEngine(ctx)
+    for eps, alpha, beta in ((1.0, 1.1, 44.974 * 0.5), (10.0, 2.0, 10.0)):
+        want = oracle.cnsm_ed(series, q, L, R, 0, eps, alpha, beta)
+        for ab in (1, 0):
+            ctx.set_option(kvmatch.OPT_EARLY_ABANDON, ab)
+            got = neng.verify((L, R), 1, q, eps, alpha, beta)
+            assert same(got, want), (eps, alpha, beta, ab)
+            assert got.stats[1] == want[2]["pass_filter"]
+        assert qoff in set(want[0].tolist())
+    ctx.set_option(kvmatch.OPT_EARLY_ABANDON, 1)
+
+
+def test_dtw_config_4(big):
+    kvmatch, datagen, series, ctx, q8, qoff, planted = big
+    m, rho = 4096, 204
+    q = series[qoff - 1: qoff - 1 + m].copy()
+    L, R = datagen.gen_intervals(N, m, 100_000, 64.0, must_cover=[qoff, planted[1]], seed=2)
+    want = oracle.cnsm_dtw(series, q, L, R, 0, 3.0, rho, 2.0, 10.0)
+    got = kvmatch.NormQueryEngineDtw(ctx).verify((L, R), 1, q, 3.0, 0.05, 2.0, 10.0)
+    assert same(got, want) and got.cnt_candidate == want[2]["cnt_candidate"]
+    assert qoff in set(want[0].tolist()) and want[1][0] == 0.0
+    ctx.set_option(kvmatch.OPT_LB_CASCADE, 0)                              # the cascade is only an optimisation
+    got = kvmatch.NormQueryEngineDtw(ctx).verify((L[:200], R[:200]), 1, q, 3.0, 0.05, 2.0, 10.0)
+    ctx.set_option(kvmatch.OPT_LB_CASCADE, 1)
+    assert same(got, oracle.cnsm_dtw(series, q, L[:200], R[:200], 0, 3.0, rho, 2.0, 10.0))
+    want = oracle.rsm_dtw(series, q, L, R, 0, 6.0, rho)
+    got = kvmatch.QueryEngineDtw(ctx).verify((L, R), 1, q, 6.0, 0.05)
+    assert same(got, want) and qoff in set(want[0].tolist())
