@@ -41,11 +41,10 @@ __global__ __launch_bounds__(256) void kvm_dtw_filter_kernel(const double *__res
     double lim = qd.eps2 * (1.0 + 1e-9);  // pruning threshold of the lower bounds: eps^2 plus the guard band
     if (alive) {
         if (NORM) {
-            kvm_window_mean_std(prefix, series, (int64_t)start - 1, m, mean, std);
-            const double g = kvm_sigma_guard(mean, std);
-            pass_filter = kvm_cnsm_filter_guarded(mean, std, qd.meanQ, qd.stdQ, qd.alpha, qd.beta, g);
-            lim = qd.eps2 + kvm_eps2_slack(qd.eps2, m, g, 16.0);
-            if (!(std == std) || !(std > 0.0)) { std = __builtin_nan(""); lim = __builtin_huge_val(); }  // exact pass decides
+            const kvm_stat_guard sg = kvm_window_mean_std_g(prefix, series, (int64_t)start - 1, m, mean, std);
+            pass_filter = kvm_cnsm_filter_guarded(mean, std, qd.meanQ, qd.stdQ, qd.alpha, qd.beta, sg);
+            lim = qd.eps2 + kvm_eps2_slack(qd.eps2, m, sg.g, 16.0);
+            if (!(std == std) || !(std > 0.0) || kvm_guard_degenerate(sg.g)) { std = __builtin_nan(""); lim = __builtin_huge_val(); }  // exact pass decides
         } else {
             pass_filter = true;
         }
@@ -100,6 +99,7 @@ __global__ __launch_bounds__(256) void kvm_dtw_filter_kernel(const double *__res
         c.run_start = tile.run_start;
         c.mean = mean;
         c.std = std;
+        c.lim = lim;
         out[base + __popcll(below)] = c;
     }
 }
@@ -152,8 +152,7 @@ __global__ __launch_bounds__(256) void kvm_dtw_keogh_kernel(const double *__rest
         const double *__restrict__ x = series + (c.start - 1);
         const double inv = 1.0 / c.std;
         // pruning threshold: eps^2 plus the guard band that covers the sigma uncertainty (cNSM) and summation order
-        const double lim = qd.normalised ? eps2 + kvm_eps2_slack(eps2, m, kvm_sigma_guard(c.mean, c.std), 16.0)
-                                         : eps2 * (1.0 + 1e-9);
+        const double lim = qd.normalised ? c.lim : eps2 * (1.0 + 1e-9);
         if (!(c.std == c.std)) {  // degenerate sigma in the pruning arithmetic: no bound, the exact pass decides
             if (threadIdx.x == 0) {
                 atomicAdd(&counters[KVM_CNT_PASS_KEOGH], 1ULL);

@@ -67,11 +67,10 @@ __device__ __forceinline__ void lb4_prefilter(const double *__restrict__ series,
     lim = qd.eps2 * (1.0 + 1e-9);
     pass_filter = true;
     if (NORM) {
-        kvm_window_mean_std(prefix, series, w0, m, mean, sd);
-        const double g = kvm_sigma_guard(mean, sd);
-        pass_filter = kvm_cnsm_filter_guarded(mean, sd, qd.meanQ, qd.stdQ, qd.alpha, qd.beta, g);
-        lim = qd.eps2 + kvm_eps2_slack(qd.eps2, m, g, 16.0);
-        if (!(sd == sd) || !(sd > 0.0)) {  // degenerate sigma: no bound, the exact pass decides
+        const kvm_stat_guard sg = kvm_window_mean_std_g(prefix, series, w0, m, mean, sd);
+        pass_filter = kvm_cnsm_filter_guarded(mean, sd, qd.meanQ, qd.stdQ, qd.alpha, qd.beta, sg);
+        lim = qd.eps2 + kvm_eps2_slack(qd.eps2, m, sg.g, 16.0);
+        if (!(sd == sd) || !(sd > 0.0) || kvm_guard_degenerate(sg.g)) {  // degenerate sigma: no bound, the exact pass decides
             sd = __builtin_nan("");
             lim = __builtin_huge_val();
             inv = 0.0;
@@ -264,6 +263,7 @@ __global__ __launch_bounds__(256, 2) void kvm_dtw_lb_tiled_kernel(const double *
             c.run_start = mine.run_start;
             c.mean = mean[a];
             c.std = sd[a];
+            c.lim = lim[a];
             out[base + __popcll(bal & ((1ULL << lane) - 1ULL))] = c;
         }
     }

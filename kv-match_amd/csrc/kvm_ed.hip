@@ -32,13 +32,12 @@ __global__ __launch_bounds__(256) void kvm_ed_wave_kernel(const double *__restri
         double mean = 0.0, inv = 1.0, lim = eps2 * (1.0 + 1e-9);  // pruning threshold = eps^2 + guard band
         if (NORM) {
             double std;
-            kvm_window_mean_std(prefix, series, (int64_t)start - 1, m, mean, std);
-            const double g = kvm_sigma_guard(mean, std);
-            if (!kvm_cnsm_filter_guarded(mean, std, qd.meanQ, qd.stdQ, qd.alpha, qd.beta, g)) continue;  // wave-uniform
+            const kvm_stat_guard sg = kvm_window_mean_std_g(prefix, series, (int64_t)start - 1, m, mean, std);
+            if (!kvm_cnsm_filter_guarded(mean, std, qd.meanQ, qd.stdQ, qd.alpha, qd.beta, sg)) continue;  // wave-uniform
             passed++;
             inv = 1.0 / std;
-            lim = eps2 + kvm_eps2_slack(eps2, m, g, 4.0);
-            if (!(std == std) || !(std > 0.0)) { inv = 0.0; lim = __builtin_huge_val(); }  // exact pass decides
+            lim = eps2 + kvm_eps2_slack(eps2, m, sg.g, 4.0);
+            if (!(std == std) || !(std > 0.0) || kvm_guard_degenerate(sg.g)) { inv = 0.0; lim = __builtin_huge_val(); }  // exact pass decides
         }
         double acc = 0.0;
         bool dead = false;
@@ -61,7 +60,7 @@ __global__ __launch_bounds__(256) void kvm_ed_wave_kernel(const double *__restri
         }
         if (dead) continue;
         const double total = kvm_wave_sum(acc);
-        if (total <= lim && lane == 0) {
+        if (!(total > lim) && lane == 0) {  // (NaN total: a NaN / Inf point in the window -- the exact pass rejects it)
             unsigned long long idx = atomicAdd(&counters[KVM_CNT_CANDS1], 1ULL);
             if ((int64_t)idx < cap) surv[idx] = kvm_surv{start, tile.run_start};
         }

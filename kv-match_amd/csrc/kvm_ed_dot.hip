@@ -64,7 +64,9 @@ struct edd_args {
 #define EDD_INLINE_MAX 4  // survivors per wave-unit that are evaluated in place (more: handed to kvm_exact_ed_kernel)
 
 struct edd_cstat {
-    double s1J, s2J, mc, sg, g;
+    double s1J, s2J, mc, sg;
+    double e1J, e2J;     // absolute error bounds of s1J, s2J (prefix magnitudes + re-basing, kvm_prefix_err)
+    kvm_stat_guard gd;   // cNSM: sigma guard, uncertainty of the mean, bound on the reference's sigma
 };
 
 // One wavefront: 8 tiles (rows) of the list `tiles`, starting at tile index t0.
@@ -112,29 +114,44 @@ __device__ __forceinline__ void edd_body(const edd_args &A, const kvm_tile *__re
     // mean - c_row, sigma and sigma guard (always from the full window).
     auto stats = [&](int a, int jlo, int J) -> edd_cstat {
         edd_cstat st;
-        double s1, s2, cb;
+        double s1, s2, cb, pm;
         const int64_t w0 = (int64_t)mine.start - 1 + c0 + a;
         const bool full = jlo == 0 && J == m;
         const int64_t r0 = (NORM || full) ? w0 : w0 + jlo;
         const int len0 = (NORM || full) ? m : J - jlo;
-        kvm_window_shifted_sums(prefix, series, r0, len0, s1, s2, cb);
-        double dc = cb - c_row;
-        double S1 = s1 + len0 * dc, S2 = s2 + (2.0 * dc) * s1 + len0 * (dc * dc);
-        st.mc = 0.0; st.sg = 1.0; st.g = 0.0;
+        // re-based sums and their error bounds: the prefix entries (a spike earlier in the block leaves them large) and
+        // the re-basing products each lose a few ulps of their own magnitude
+        auto rebase = [&](int len, double &S1, double &S2, double &E1, double &E2) {
+            const double dc = cb - c_row;
+            const kvm_sum_err e = kvm_prefix_err(pm);
+            S1 = s1 + len * dc;
+            S2 = s2 + (2.0 * dc) * s1 + len * (dc * dc);
+            E1 = e.e1 + 1e-15 * (fabs(s1) + len * fabs(dc));
+            E2 = e.e2 + 2.0 * fabs(dc) * e.e1 + 1e-15 * (fabs(s2) + 2.0 * fabs(dc * s1) + len * (dc * dc));
+        };
+        kvm_window_shifted_sums(prefix, series, r0, len0, s1, s2, cb, &pm);
+        double S1, S2, E1, E2;
+        rebase(len0, S1, S2, E1, E2);
+        st.mc = 0.0; st.sg = 1.0;
+        st.gd.g = 0.0; st.gd.mean_err = 0.0; st.gd.std_hi = 0.0;
         if (NORM) {
             st.mc = S1 / m;
-            st.sg = sqrt(S2 / m - st.mc * st.mc);
-            st.g = kvm_sigma_guard(c_row + st.mc, st.sg);
+            const double var = S2 / m - st.mc * st.mc, mean = c_row + st.mc;
+            st.sg = sqrt(var);
+            st.gd.mean_err = E1 / m;
+            const double var_err = E2 / m + 2.0 * fabs(st.mc) * st.gd.mean_err;
+            st.gd.g = kvm_sigma_guard(mean, st.sg, var_err / (2.0 * var) + st.gd.mean_err / st.sg);
+            st.gd.std_hi = sqrt(fmax(var, 0.0) + var_err + 1e-8 * (mean * mean + fabs(var)));
             if (!full) {
                 const int len = J - jlo;
-                kvm_window_shifted_sums(prefix, series, w0 + jlo, len, s1, s2, cb);
-                dc = cb - c_row;
-                S1 = s1 + len * dc;
-                S2 = s2 + (2.0 * dc) * s1 + len * (dc * dc);
+                kvm_window_shifted_sums(prefix, series, w0 + jlo, len, s1, s2, cb, &pm);
+                rebase(len, S1, S2, E1, E2);
             }
         }
         st.s1J = S1;
         st.s2J = S2;
+        st.e1J = E1;
+        st.e2J = E2;
         return st;
     };
     // correlation-form distance over a range of J points (st, acc and the query sums qp all taken over that range) and
@@ -144,15 +161,19 @@ __device__ __forceinline__ void edd_body(const edd_args &A, const kvm_tile *__re
             const double d = qbar - c_row;
             const double cross = acc + d * st.s1J;
             const double qq = qp.y + (2.0 * d) * qp.x + J * (d * d);
-            slack = eps2 * 1e-9 + 1e-11 * (fabs(st.s2J) + 2.0 * fabs(acc) + 2.0 * fabs(d * st.s1J) + fabs(qq));
+            slack = eps2 * 1e-9 + 1e-11 * (fabs(st.s2J) + 2.0 * fabs(acc) + 2.0 * fabs(d * st.s1J) + fabs(qq)) +
+                    st.e2J + 2.0 * fabs(d) * st.e1J;
             return st.s2J - 2.0 * cross + qq;
         } else {
             const double mc = st.mc, inv = 1.0 / st.sg;
             const double xx = st.s2J - (2.0 * mc) * st.s1J + J * (mc * mc);           // sum (x-mu)^2
             const double xz = acc + qbar * st.s1J - mc * (qp.x + J * qbar);           // sum (x-mu) zq, zq = qc + qbar
             const double zz = qp.y + (2.0 * qbar) * qp.x + J * (qbar * qbar);         // sum zq^2
-            slack = eps2 * 1e-9 + kvm_eps2_slack(eps2, m, st.g, 4.0) +
-                    1e-11 * (fabs(xx) * inv * inv + 2.0 * (fabs(acc) + fabs(qbar * st.s1J) + fabs(mc * qp.x)) * inv + fabs(zz));
+            // (over a partial range the distance depends on the mean to first order: sum_J z_x - sum_J zq is not zero)
+            slack = eps2 * 1e-9 + kvm_eps2_slack(eps2, m, st.gd.g, 4.0) +
+                    1e-11 * (fabs(xx) * inv * inv + 2.0 * (fabs(acc) + fabs(qbar * st.s1J) + fabs(mc * qp.x)) * inv + fabs(zz)) +
+                    (st.e2J + 2.0 * fabs(mc) * st.e1J) * inv * inv + 2.0 * inv * fabs(qbar) * st.e1J +
+                    2.0 * inv * (fabs(st.s1J - J * mc) * inv + fabs(qp.x + J * qbar)) * st.gd.mean_err;
             return xx * inv * inv - 2.0 * xz * inv + zz;
         }
     };
@@ -166,8 +187,8 @@ __device__ __forceinline__ void edd_body(const edd_args &A, const kvm_tile *__re
             bool ok = true;
             if (NORM) {
                 const edd_cstat st = stats(a, 0, m);
-                ok = kvm_cnsm_filter_guarded(c_row + st.mc, st.sg, qd.meanQ, qd.stdQ, qd.alpha, qd.beta, st.g);
-                if (ok && (!(st.sg == st.sg) || !(st.sg > 0.0))) fm |= 1u << a;  // exact pass decides
+                ok = kvm_cnsm_filter_guarded(c_row + st.mc, st.sg, qd.meanQ, qd.stdQ, qd.alpha, qd.beta, st.gd);
+                if (ok && (!(st.sg == st.sg) || !(st.sg > 0.0) || kvm_guard_degenerate(st.gd.g))) fm |= 1u << a;  // exact pass decides
             }
             if (ok) vm |= 1u << a;
         }
@@ -330,7 +351,7 @@ __device__ __forceinline__ void edd_body(const edd_args &A, const kvm_tile *__re
             if (!keep) {
                 double slack;
                 const edd_cstat st = stats(a, 0, m);
-                keep = dist_form(st, acc[a], m, qtot, slack) <= eps2 + slack;
+                keep = !(dist_form(st, acc[a], m, qtot, slack) > eps2 + slack);  // (NaN: a poisoned prefix block -> keep)
             }
             if (keep) keepm |= 1u << a;
         }
@@ -412,8 +433,8 @@ __global__ __launch_bounds__(256) void kvm_retile_cnsm_kernel(const double *__re
         bool ok = false;
         if (lane < tl.count) {
             double mean, sd;
-            kvm_window_mean_std(prefix, series, (int64_t)tl.start - 1 + lane, qd.m, mean, sd);
-            ok = kvm_cnsm_filter_guarded(mean, sd, qd.meanQ, qd.stdQ, qd.alpha, qd.beta, kvm_sigma_guard(mean, sd));
+            const kvm_stat_guard sg = kvm_window_mean_std_g(prefix, series, (int64_t)tl.start - 1 + lane, qd.m, mean, sd);
+            ok = kvm_cnsm_filter_guarded(mean, sd, qd.meanQ, qd.stdQ, qd.alpha, qd.beta, sg);
         }
         const unsigned long long mask = __ballot(ok);
         if (mask != 0 && lane == 0) {

@@ -193,23 +193,32 @@ __global__ __launch_bounds__(256, 2) void kvm_ed_jl_kernel(jl_args A) {
         bool alive = (lane & 3) == 0 && mycand < cur.count;
         bool passed = false, keep = false;
         if (alive) {
-            double s1, s2, cb;
-            kvm_finish_window_sums(raw, prefix, series, w0, m, s1, s2, cb);
+            double s1, s2, cb, pmag;
+            kvm_finish_window_sums(raw, prefix, series, w0, m, s1, s2, cb, &pmag);
             const double dc = cb - c_cur;
             const double S1 = s1 + m * dc, S2 = s2 + (2.0 * dc) * s1 + m * (dc * dc);  // sums of (x - c_cur), (x - c_cur)^2
+            // error bounds of S1, S2: prefix magnitudes + re-basing (same rule as kvm_ed_dot.hip)
+            const kvm_sum_err pe = kvm_prefix_err(pmag);
+            const double E1 = pe.e1 + 1e-15 * (fabs(s1) + m * fabs(dc));
+            const double E2 = pe.e2 + 2.0 * fabs(dc) * pe.e1 + 1e-15 * (fabs(s2) + 2.0 * fabs(dc * s1) + m * (dc * dc));
             if (!NORM) {
                 const double d = qbar - c_cur;
                 const double cross = r1 + d * S1;
                 const double qq = qtot.y + (2.0 * d) * qtot.x + m * (d * d);
-                const double slack = eps2 * 1e-9 + 1e-11 * (fabs(S2) + 2.0 * fabs(r1) + 2.0 * fabs(d * S1) + fabs(qq));
-                keep = (S2 - 2.0 * cross + qq) <= eps2 + slack;
+                const double slack = eps2 * 1e-9 + 1e-11 * (fabs(S2) + 2.0 * fabs(r1) + 2.0 * fabs(d * S1) + fabs(qq)) +
+                                     E2 + 2.0 * fabs(d) * E1;
+                keep = !((S2 - 2.0 * cross + qq) > eps2 + slack);  // (NaN: poisoned prefix block -> keep)
             } else {
                 const double mc = S1 / m;  // mean - c_cur
-                const double sg = sqrt(S2 / m - mc * mc);
-                const double g = kvm_sigma_guard(c_cur + mc, sg);
-                passed = kvm_cnsm_filter_guarded(c_cur + mc, sg, qd.meanQ, qd.stdQ, qd.alpha, qd.beta, g);
+                const double var = S2 / m - mc * mc, sg = sqrt(var), mean = c_cur + mc;
+                kvm_stat_guard gd;
+                gd.mean_err = E1 / m;
+                const double var_err = E2 / m + 2.0 * fabs(mc) * gd.mean_err;
+                gd.g = kvm_sigma_guard(mean, sg, var_err / (2.0 * var) + gd.mean_err / sg);
+                gd.std_hi = sqrt(fmax(var, 0.0) + var_err + 1e-8 * (mean * mean + fabs(var)));
+                passed = kvm_cnsm_filter_guarded(mean, sg, qd.meanQ, qd.stdQ, qd.alpha, qd.beta, gd);
                 if (passed) {
-                    if (!(sg == sg) || !(sg > 0.0)) {
+                    if (!(sg == sg) || !(sg > 0.0) || kvm_guard_degenerate(gd.g)) {
                         keep = true;  // degenerate sigma: the exact pass decides
                     } else {
                         const double inv = 1.0 / sg;
@@ -217,9 +226,10 @@ __global__ __launch_bounds__(256, 2) void kvm_ed_jl_kernel(jl_args A) {
                         const double xz = r1 + qbar * S1 - mc * (qtot.x + m * qbar);
                         const double zz = qtot.y + (2.0 * qbar) * qtot.x + m * (qbar * qbar);
                         const double slack =
-                            eps2 * 1e-9 + kvm_eps2_slack(eps2, m, g, 4.0) +
-                            1e-11 * (fabs(xx) * inv * inv + 2.0 * (fabs(r1) + fabs(qbar * S1) + fabs(mc * qtot.x)) * inv + fabs(zz));
-                        keep = (xx * inv * inv - 2.0 * xz * inv + zz) <= eps2 + slack;
+                            eps2 * 1e-9 + kvm_eps2_slack(eps2, m, gd.g, 4.0) +
+                            1e-11 * (fabs(xx) * inv * inv + 2.0 * (fabs(r1) + fabs(qbar * S1) + fabs(mc * qtot.x)) * inv + fabs(zz)) +
+                            (E2 + 2.0 * fabs(mc) * E1) * inv * inv + 2.0 * inv * fabs(qbar) * E1;
+                        keep = !((xx * inv * inv - 2.0 * xz * inv + zz) > eps2 + slack);
                     }
                 }
             }

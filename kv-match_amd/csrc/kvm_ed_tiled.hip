@@ -76,18 +76,16 @@ __global__ __launch_bounds__(256, 3) void kvm_ed_tiled_kernel(const double *__re
     double lim0 = eps2 * (1.0 + 1e-9), lim1 = lim0;
     if (NORM) {
         if (v0) {
-            kvm_window_mean_std(prefix, series, (int64_t)my_start - 1 + c0, m, mean0, sd0);
-            const double g = kvm_sigma_guard(mean0, sd0);
-            v0 = kvm_cnsm_filter_guarded(mean0, sd0, qd.meanQ, qd.stdQ, qd.alpha, qd.beta, g);
-            lim0 = (eps2 + kvm_eps2_slack(eps2, m, g, 4.0)) * (sd0 * sd0);
-            if (!(sd0 == sd0) || !(sd0 > 0.0)) { mean0 = 0.0; sd0 = 0.0; lim0 = __builtin_huge_val(); }  // exact pass decides
+            const kvm_stat_guard sg = kvm_window_mean_std_g(prefix, series, (int64_t)my_start - 1 + c0, m, mean0, sd0);
+            v0 = kvm_cnsm_filter_guarded(mean0, sd0, qd.meanQ, qd.stdQ, qd.alpha, qd.beta, sg);
+            lim0 = (eps2 + kvm_eps2_slack(eps2, m, sg.g, 4.0)) * (sd0 * sd0);
+            if (!(sd0 == sd0) || !(sd0 > 0.0) || kvm_guard_degenerate(sg.g)) { mean0 = 0.0; sd0 = 0.0; lim0 = __builtin_huge_val(); }  // exact pass decides
         }
         if (v1) {
-            kvm_window_mean_std(prefix, series, (int64_t)my_start + c0, m, mean1, sd1);
-            const double g = kvm_sigma_guard(mean1, sd1);
-            v1 = kvm_cnsm_filter_guarded(mean1, sd1, qd.meanQ, qd.stdQ, qd.alpha, qd.beta, g);
-            lim1 = (eps2 + kvm_eps2_slack(eps2, m, g, 4.0)) * (sd1 * sd1);
-            if (!(sd1 == sd1) || !(sd1 > 0.0)) { mean1 = 0.0; sd1 = 0.0; lim1 = __builtin_huge_val(); }
+            const kvm_stat_guard sg = kvm_window_mean_std_g(prefix, series, (int64_t)my_start + c0, m, mean1, sd1);
+            v1 = kvm_cnsm_filter_guarded(mean1, sd1, qd.meanQ, qd.stdQ, qd.alpha, qd.beta, sg);
+            lim1 = (eps2 + kvm_eps2_slack(eps2, m, sg.g, 4.0)) * (sd1 * sd1);
+            if (!(sd1 == sd1) || !(sd1 > 0.0) || kvm_guard_degenerate(sg.g)) { mean1 = 0.0; sd1 = 0.0; lim1 = __builtin_huge_val(); }
         }
         const unsigned long long b0 = __ballot(v0), b1 = __ballot(v1);
         if (lane == 0 && (b0 | b1))
@@ -187,7 +185,7 @@ __global__ __launch_bounds__(256, 3) void kvm_ed_tiled_kernel(const double *__re
         if (more) {
             if (ABANDON) {
                 // partial sums only grow: once both candidates of every lane exceed their pruning threshold the wave is done
-                const bool alive = (v0 && acc0 <= lim0) || (v1 && acc1 <= lim1);
+                const bool alive = (v0 && !(acc0 > lim0)) || (v1 && !(acc1 > lim1));
                 if (!__any(alive)) return;
             }
             store_chunk();  // program order: after this chunk's LDS reads
@@ -197,11 +195,11 @@ __global__ __launch_bounds__(256, 3) void kvm_ed_tiled_kernel(const double *__re
 #undef ED_GROUP
 #undef ED_FETCH
     // survivors of the pruning pass; the exact pass (kvm_exact.hip) computes the reference's distance and decides
-    if (v0 && acc0 <= lim0) {
+    if (v0 && !(acc0 > lim0)) {
         unsigned long long idx = atomicAdd(&counters[KVM_CNT_CANDS1], 1ULL);
         if ((int64_t)idx < cap) surv[idx] = kvm_surv{my_start + c0, my_run};
     }
-    if (v1 && acc1 <= lim1) {
+    if (v1 && !(acc1 > lim1)) {
         unsigned long long idx = atomicAdd(&counters[KVM_CNT_CANDS1], 1ULL);
         if ((int64_t)idx < cap) surv[idx] = kvm_surv{my_start + c0 + 1, my_run};
     }

@@ -63,6 +63,7 @@ struct kvm_cand {
     int32_t run_start;  // first window start offset of its run
     double mean;
     double std;
+    double lim;         // cNSM: pruning limit of the lower bounds for THIS candidate (eps^2 + its guard band, stage 1)
 };
 
 struct kvm_dev_buf {
@@ -228,14 +229,20 @@ void kvm_index_dev_free(kvm_index_dev *d);
 #ifdef __HIPCC__
 // Shifted sums of the 0-based range [s, s+len): returns S1 = sum(x - c), S2 = sum(x - c)^2 and the shift c (= the
 // first point of the block that contains s), from the block-restarted shifted prefix sums.
+// `pm` (optional): the largest magnitude behind the subtraction -- max of the prefix entries P.y used and of the
+// re-basing terms k*dc^2 -- from which kvm_prefix_err bounds the absolute rounding error of s1 and s2: a spike earlier
+// in the block leaves the prefix sums large long after it has left every window.
 __device__ __forceinline__ void kvm_window_shifted_sums(const double2 *__restrict__ P, const double *__restrict__ x,
-                                                        int64_t s, int32_t len, double &s1, double &s2, double &c) {
+                                                        int64_t s, int32_t len, double &s1, double &s2, double &c,
+                                                        double *pm = nullptr) {
+    double mag = 0.0;
     const int64_t e = s + len - 1;
     const int64_t bs = s >> KVM_PS_BLOCK_LOG2, be = e >> KVM_PS_BLOCK_LOG2;
     c = x[bs << KVM_PS_BLOCK_LOG2];  // shift of the first block; everything is re-based to it
     const bool at_start = (s & (KVM_PS_BLOCK - 1)) == 0;
     if (bs == be) {
         const double2 pe = P[e];
+        mag = fabs(pe.y);  // (P.y is non-decreasing inside a block: P[s-1].y <= P[e].y)
         if (at_start) {
             s1 = pe.x;
             s2 = pe.y;
@@ -246,6 +253,7 @@ __device__ __forceinline__ void kvm_window_shifted_sums(const double2 *__restric
         }
     } else {
         const double2 pl = P[((bs + 1) << KVM_PS_BLOCK_LOG2) - 1];  // tail of the first block
+        mag = fabs(pl.y);
         if (at_start) {
             s1 = pl.x;
             s2 = pl.y;
@@ -262,8 +270,24 @@ __device__ __forceinline__ void kvm_window_shifted_sums(const double2 *__restric
             const double k = (double)(lastp - first + 1);
             s1 += t.x + k * dc;
             s2 += t.y + (2.0 * dc) * t.x + k * (dc * dc);
+            mag = fmax(mag, fabs(t.y) + k * (dc * dc));
         }
     }
+    if (pm) *pm = mag;
+}
+
+// Absolute error bounds of (s1, s2) as returned by kvm_window_shifted_sums, from the magnitude `pm` behind them.
+// kvm_prefix_kernel adds <= ~28 roundings per entry: |dP.y| <= 3e-15 P.y, and by Cauchy-Schwarz over <= 16 384 points
+// |dP.x| <= 28 u sum|x - c_b| <= 4e-13 sqrt(P.y); two to three entries are combined.  Margins of ~50.  NaN in, NaN out
+// (every pruning test is written so that NaN keeps the candidate).
+struct kvm_sum_err {
+    double e1, e2;
+};
+__device__ __forceinline__ kvm_sum_err kvm_prefix_err(double pm) {
+    kvm_sum_err r;
+    r.e1 = 2e-11 * sqrt(pm);
+    r.e2 = 1e-12 * pm;
+    return r;
 }
 
 // Two-phase form of kvm_window_shifted_sums: all loads first (unconditional, clamped addresses), arithmetic later --
@@ -297,9 +321,10 @@ __device__ __forceinline__ kvm_raw_sums kvm_issue_window_sums(const double2 *__r
 }
 // same arithmetic, in the same order, as kvm_window_shifted_sums
 __device__ __forceinline__ void kvm_finish_window_sums(const kvm_raw_sums &r, const double2 *__restrict__ P, const double *__restrict__ x,
-                                                int64_t s, int32_t len, double &s1, double &s2, double &c) {
+                                                int64_t s, int32_t len, double &s1, double &s2, double &c,
+                                                double *pm = nullptr) {
     if (r.kind == 2) {
-        kvm_window_shifted_sums(P, x, s, len, s1, s2, c);
+        kvm_window_shifted_sums(P, x, s, len, s1, s2, c, pm);
         return;
     }
     c = r.c0;
@@ -314,6 +339,7 @@ __device__ __forceinline__ void kvm_finish_window_sums(const kvm_raw_sums &r, co
         s1 += r.pe.x + r.k1 * dc;
         s2 += r.pe.y + (2.0 * dc) * r.pe.x + r.k1 * (dc * dc);
     }
+    if (pm) *pm = r.kind == 0 ? fabs(r.pe.y) : fmax(fabs(r.pl.y), fabs(r.pe.y) + r.k1 * ((r.c1 - c) * (r.c1 - c)));
 }
 
 
@@ -334,24 +360,62 @@ __device__ __forceinline__ bool kvm_cnsm_filter(double mean, double std, double 
 }
 
 // ---- guard bands of the pruning kernels (the exact pass decides inside them) ----
-// Relative uncertainty between this library's sigma (shifted prefix sums) and the reference's (running sums,
-// sqrt(ex2/m - mean^2)): the reference loses about E[x^2]/var ulps times the drift of ~1e4 additions.
-__device__ __forceinline__ double kvm_sigma_guard(double mean, double std) {
+// Every pruning test has the form `drop only if value > limit`, so a NaN anywhere (a NaN / Inf point poisons the prefix
+// sums up to the end of its block) keeps the candidate for the exact pass, which follows the reference's arithmetic.
+//
+// g = relative uncertainty between this library's sigma and the reference's (running sums, sqrt(ex2/m - mean^2)):
+//   * the reference loses about E[x^2]/var ulps times the drift of ~1e4 additions;
+//   * `gx`: this library's own share, from the prefix magnitudes (kvm_prefix_err): d(var)/(2 var) + d(mean)/sigma.
+// g >= KVM_G_DEGENERATE (also NaN / zero variance): mean and sigma carry no information, nothing may be pruned on them.
+#define KVM_G_DEGENERATE 0.25
+__device__ __forceinline__ double kvm_sigma_guard(double mean, double std, double gx = 0.0) {
     const double var = std * std;
-    const double g = 1e-9 + 1e-12 * ((mean * mean + var) / var);
-    return (g < 0.25) ? g : 0.25;  // also catches NaN / zero variance
+    const double g = 1e-9 + 1e-12 * ((mean * mean + var) / var) + gx;
+    return (g < KVM_G_DEGENERATE) ? g : KVM_G_DEGENERATE;  // also catches NaN / zero variance
 }
-// (alpha, beta) test widened by the guard; NaN sigma (variance rounded below zero) is left to the exact pass.
+__device__ __forceinline__ bool kvm_guard_degenerate(double g) { return !(g < KVM_G_DEGENERATE); }
+// What the guarded filter needs besides mean and sigma: the guard, the absolute uncertainty of the mean, and an upper
+// bound on the sigma the REFERENCE can arrive at (its own cancellation noise included) for windows whose variance is
+// lost in rounding -- a constant stretch has sigma 0 here and 1e-7-ish noise (or NaN) there.
+struct kvm_stat_guard {
+    double g, mean_err, std_hi;
+};
+__device__ __forceinline__ kvm_stat_guard kvm_make_stat_guard(double c, double s1, double s2, int32_t m, double pm) {
+    kvm_stat_guard r;
+    const double ms = s1 / m, var = s2 / m - ms * ms, mean = c + ms;
+    const kvm_sum_err e = kvm_prefix_err(pm);
+    r.mean_err = e.e1 / m;
+    const double var_err = e.e2 / m + 2.0 * fabs(ms) * r.mean_err;
+    r.g = kvm_sigma_guard(mean, sqrt(var), var_err / (2.0 * var) + r.mean_err / sqrt(var));
+    r.std_hi = sqrt(fmax(var, 0.0) + var_err + 1e-8 * (mean * mean + fabs(var)));
+    return r;
+}
+// mean / std / guard in one go (prefix-magnitude share included)
+__device__ __forceinline__ kvm_stat_guard kvm_window_mean_std_g(const double2 *__restrict__ P, const double *__restrict__ x,
+                                                                int64_t s, int32_t m, double &mean, double &std) {
+    double s1, s2, c, pm;
+    kvm_window_shifted_sums(P, x, s, m, s1, s2, c, &pm);
+    const double ms = s1 / m;
+    mean = c + ms;
+    std = sqrt(s2 / m - ms * ms);
+    return kvm_make_stat_guard(c, s1, s2, m, pm);
+}
+// (alpha, beta) test widened by the guard.  With a degenerate guard (NaN sigma, variance rounded below zero, prefix sums
+// too coarse for this window) only the one thing that is still certain is tested: a sigma that cannot reach the lower
+// limit; everything else is left to the exact pass.
 __device__ __forceinline__ bool kvm_cnsm_filter_guarded(double mean, double std, double meanQ, double stdQ, double alpha,
-                                                        double beta, double g) {
-    if (!(std == std)) return true;
-    const double gm = 1e-9 * fmax(1.0, fmax(fabs(mean), fabs(meanQ)));
+                                                        double beta, const kvm_stat_guard &sg) {
+    if (!(std == std) || kvm_guard_degenerate(sg.g)) return !(sg.std_hi / stdQ < (1.0 / alpha) * 0.5);
+    const double gm = 1e-9 * fmax(1.0, fmax(fabs(mean), fabs(meanQ))) + sg.mean_err;
     const double ratio = std / stdQ;
-    return fabs(mean - meanQ) <= beta + gm && ratio <= alpha * (1.0 + g) && ratio >= (1.0 / alpha) * (1.0 - g);
+    return !(fabs(mean - meanQ) > beta + gm) && !(ratio > alpha * (1.0 + sg.g)) && !(ratio < (1.0 / alpha) * (1.0 - sg.g));
 }
-// Slack on eps^2 for a z-normalised distance computed with a sigma that is off by relative g: d(dist^2) ~ 2 g sqrt(m) dist.
+// Slack on eps^2 for a z-normalised distance (or lower bound) computed with a mean / sigma that are off by relative g:
+// first order 2 g sqrt(m dist) at dist ~ eps^2, second order g^2 m (what is left when eps = 0).  Infinite for a
+// degenerate guard.
 __device__ __forceinline__ double kvm_eps2_slack(double eps2, int32_t m, double g, double factor) {
-    return eps2 * 1e-9 + factor * g * sqrt((double)m * eps2);
+    if (kvm_guard_degenerate(g)) return __builtin_huge_val();
+    return eps2 * 1e-9 + factor * (g * sqrt((double)m * eps2) + g * g * m);
 }
 
 __device__ __forceinline__ double kvm_wave_sum(double v) {

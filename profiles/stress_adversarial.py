@@ -1,0 +1,16 @@
+#!/usr/bin/env python3
+"""Adversarial parity run (longer version of tests/test_adversarial_gpu.py; cases in tests/adversarial.py).
+`stress_adversarial.py [rounds]`, SEED in the environment."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "kv-match_amd")); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import kvmatch
+from kvmatch import datagen
+from oracle import oracle
+import adversarial
+rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 6
+ctx = kvmatch.Phase2Context(0)
+total, bad, quirk = adversarial.run(kvmatch, datagen, oracle, ctx, rounds, int(os.environ.get("SEED", "11")),
+                                    log=lambda s: print(s, flush=True))
+print("verifications", total, "mismatches", bad, "tie-quirk divergences", quirk)
+sys.exit(1 if bad else 0)

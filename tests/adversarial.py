@@ -1,0 +1,116 @@
+"""Adversarial parity cases shared by tests/test_adversarial_gpu.py and profiles/stress_adversarial.py: inputs chosen
+to sit ON the decision boundaries or to break naive arithmetic -- exact ties with eps^2 (integer-valued data),
+alpha = 1 / beta = 0 filters around exact copies, piecewise-constant data (sigma = 0), huge level offsets (cancellation),
+wide dynamic range (a burst leaves the prefix sums of its block large), tiny and odd query lengths, single-offset
+intervals, eps = 0, NaN / Inf points in the series -- all four variants against the oracle, bit for bit.
+
+One class of divergence is expected and counted separately (SURVEY 8a, fact iii): DtwUtils.dtw returns
+`min_cost + cb[i+r+1]` as soon as that lower bound is `>= bsf` (K/utils/DtwUtils.java:324-326) and the callers accept
+`dist <= eps^2`, so a candidate whose lower bound EQUALS eps^2 exactly is accepted by the reference with the distance
+eps although its DTW distance may be larger.  On continuous data that tie has measure zero; on integer / half-integer
+data with an integer eps^2 it is common.  This library returns the candidates whose banded DTW distance is <= eps^2;
+`tie_quirk` below recognises the reference's extra answers (all at distance exactly eps, everything else identical)."""
+import numpy as np
+
+KINDS = ("ints", "steps", "offset", "range", "halfint", "nan")
+
+
+def make(kind, n, r):
+    if kind == "ints":      # small integers: every distance is an exactly representable integer
+        return r.integers(-6, 7, n).astype(np.float64)
+    if kind == "steps":     # piecewise constant: long windows with sigma == 0, many exact ties
+        return np.repeat(r.integers(-3, 4, n // 97 + 1).astype(np.float64), 97)[:n]
+    if kind == "offset":    # random walk riding on a huge level
+        return np.cumsum(r.uniform(-1, 1, n)) + 1e7
+    if kind == "range":     # wide dynamic range
+        return r.normal(0, 1, n) * np.exp(r.uniform(-6, 8, n // 1000 + 1).repeat(1000)[:n])
+    if kind == "halfint":   # multiples of 0.5 around zero: exact products and sums
+        return r.integers(-9, 10, n) * 0.5
+    if kind == "nan":       # a handful of NaN / Inf points in an otherwise ordinary series
+        s = np.cumsum(r.uniform(-1, 1, n)) * 0.1
+        idx = r.integers(0, n, 6)
+        s[idx[:3]] = np.nan; s[idx[3:5]] = np.inf; s[idx[5]] = -np.inf
+        return s
+    raise ValueError(kind)
+
+
+def tie_quirk(got, want, eps):
+    """True when `want` (reference) == `got` plus extra answers that all sit at distance exactly eps."""
+    wo, wd = want[0], want[1]
+    g = dict(zip(got.offsets.tolist(), got.distances.tolist()))
+    w = dict(zip(wo.tolist(), wd.tolist()))
+    if not set(g) <= set(w):
+        return False
+    if any(w[o] != d and not (np.isnan(w[o]) and np.isnan(d)) for o, d in g.items()):
+        return False
+    return all(w[o] == eps for o in set(w) - set(g))
+
+
+def run(kvmatch, datagen, oracle, ctx, rounds, seed, kinds=KINDS, n_range=(30_000, 120_000), log=None):
+    """Returns (verifications, mismatches, tie_quirk_divergences)."""
+    rng = np.random.default_rng(seed)
+    total = bad = quirk = 0
+
+    def same(a, o, tag, eps, dtw):
+        nonlocal total, bad, quirk
+        total += 1
+        oo, od, oc = o[0], o[1], o[2]
+        ok = len(a) == len(oo) and np.array_equal(a.offsets, oo) and np.array_equal(a.distances, od, equal_nan=True) \
+            and a.cnt_candidate == oc["cnt_candidate"]
+        if ok:
+            return
+        if dtw and a.cnt_candidate == oc["cnt_candidate"] and tie_quirk(a, o, eps):
+            quirk += 1
+            return
+        bad += 1
+        if log:
+            log(f"MISMATCH {tag} got {len(a)} want {len(oo)}")
+
+    for rd in range(rounds):
+        for kind in kinds:
+            n = int(rng.integers(*n_range))
+            s = make(kind, n, rng)
+            m = int(rng.choice([25, 31, 64, 100, 257, 1024, 2500]))
+            rho = int(rng.choice([0, 1, max(1, m // 20), max(1, m // 10)]))
+            for attempt in range(50):       # a query window that is finite and not constant (stdQ > 0)
+                qoff = int(rng.integers(1, n - m + 1))
+                w = s[qoff - 1: qoff - 1 + m]
+                if np.all(np.isfinite(w)) and np.std(w) > 0:
+                    break
+            pl = [int(p) for p in rng.integers(1, n - m + 1, 3)]     # exact copies (noise 0), the third shifted by +1
+            q = datagen.plant_copies(s, qoff, m, pl, [1.0, 1.0, 1.0], [0.0, 0.0, 1.0], 0.0, seed=rd)
+            ctx.load_series(s)
+            lists = []
+            L, R = datagen.gen_intervals(n, m, int(rng.integers(500, 8000)), float(rng.choice([1.0, 8.0, 64.0, 400.0])),
+                                         must_cover=[qoff] + pl, seed=rd)
+            lists.append(("gen", L, R))
+            pts = np.unique(np.concatenate([rng.integers(1, n - m + 1, 300), [qoff] + pl])).astype(np.int32)
+            pts = pts[np.concatenate(([True], np.diff(pts) > 1))]       # single-offset intervals, non-adjacent
+            lists.append(("points", pts, pts.copy()))
+            lists.append(("full", np.array([1], dtype=np.int32), np.array([n - m + 1], dtype=np.int32)))
+            # thresholds: zero, an exactly achievable distance (the +1 shifted copy: eps^2 == m on exact data), a generic one
+            d0 = float(np.sum((s[pl[2] - 1: pl[2] - 1 + m] - q) ** 2))
+            eps_tie = float(np.sqrt(d0)) if np.isfinite(d0) and d0 > 0 and np.sqrt(d0) ** 2 == d0 else 1.0
+            for name, L, R in lists:
+                for eps in (0.0, eps_tie, float(rng.uniform(0.5, 4.0))):
+                    for alpha, beta in ((1.0, 0.0), (1.0, 1.0), (1.5, 0.5), (1e9, 1e9)):
+                        tag = f"{kind} rd={rd} n={n} m={m} list={name} eps={eps:.4f} a={alpha} b={beta} rho={rho}"
+                        for ab in (1, 0):
+                            ctx.set_option(kvmatch.OPT_EARLY_ABANDON, ab)
+                            if alpha == 1.0 and beta == 0.0:
+                                same(kvmatch.QueryEngine(ctx).verify((L, R), 1, q, eps), oracle.rsm_ed(s, q, L, R, 0, eps),
+                                     "rsm_ed " + tag + f" ab={ab}", eps, False)
+                            same(kvmatch.NormQueryEngine(ctx).verify((L, R), 1, q, eps, alpha, beta),
+                                 oracle.cnsm_ed(s, q, L, R, 0, eps, alpha, beta), "cnsm_ed " + tag + f" ab={ab}", eps, False)
+                        if name != "full" or n < 60_000:
+                            ctx.set_option(kvmatch.OPT_EARLY_ABANDON, 1)
+                            if alpha == 1.0 and beta == 0.0:
+                                r2 = max(rho, 2)     # (the engine reads rho <= 1 as a fraction of m)
+                                same(kvmatch.QueryEngineDtw(ctx).verify((L, R), 1, q, eps, r2),
+                                     oracle.rsm_dtw(s, q, L, R, 0, eps, r2), "rsm_dtw " + tag, eps, True)
+                            same(kvmatch.NormQueryEngineDtw(ctx).verify((L, R), 1, q, eps, rho, alpha, beta, resolved=True),
+                                 oracle.cnsm_dtw(s, q, L, R, 0, eps, rho, alpha, beta), "cnsm_dtw " + tag, eps, True)
+        if log:
+            log(f"round {rd}: verifications {total} mismatches {bad} tie-quirk divergences {quirk}")
+    ctx.set_option(kvmatch.OPT_EARLY_ABANDON, 1)
+    return total, bad, quirk
