@@ -261,6 +261,9 @@ hipError_t kvm_launch_dtw_keogh(const double *series, const double *env_u, const
 // tests only ever discard candidates whose DTW distance exceeds eps^2.)
 extern __shared__ double kvm_dp_lds[];
 
+// `scratch` != nullptr: the two band rows and the window do not fit the LDS (m + 2 rho > 20 000 or so) and live in a
+// per-workgroup slice of global memory instead -- same code, one wavefront per workgroup, so the workgroup barrier
+// (a workgroup-scope fence) orders its stores and loads through the CU's own L1.
 template <bool ABANDON>
 __global__ __launch_bounds__(64) void kvm_dtw_dp_lds_kernel(const double *__restrict__ series, kvm_query_dev qd,
                                                             const kvm_cand *__restrict__ in,
@@ -268,12 +271,13 @@ __global__ __launch_bounds__(64) void kvm_dtw_dp_lds_kernel(const double *__rest
                                                             const unsigned long long *__restrict__ d_n_in,
                                                             int32_t *__restrict__ out_off,
                                                             double *__restrict__ out_dist, int64_t cap,
-                                                            unsigned long long *__restrict__ counters) {
+                                                            unsigned long long *__restrict__ counters,
+                                                            double *scratch) {
     const int lane = threadIdx.x;
     const int m = qd.m, r = qd.rho;
     const double eps2 = qd.eps2;
     const double *__restrict__ B = qd.q;
-    double *E = kvm_dp_lds;      // r+1 entries
+    double *E = scratch ? scratch + (size_t)blockIdx.x * ((size_t)2 * (r + 1) + m) : kvm_dp_lds;  // r+1 entries
     double *O = E + (r + 1);     // r+1 entries (only r used)
     double *A = O + (r + 1);     // m entries: the (z-normalised) candidate window
     const unsigned long long n_in = *d_n_in;
@@ -655,14 +659,20 @@ hipError_t kvm_launch_dtw_dp(const double *series, int64_t n, const kvm_query_de
         if (need <= 4) return launch_dp_reg<4>(series, qd, in, suffix, seg_len, d_n_in, max_in, out_off, out_dist, cap, counters, num_cu, s);
         return launch_dp_reg<8>(series, qd, in, suffix, seg_len, d_n_in, max_in, out_off, out_dist, cap, counters, num_cu, s);
     }
-    // generic LDS form (any r)
-    size_t lds = ((size_t)2 * (qd.rho + 1) + qd.m) * sizeof(double);
-    if (lds > 160 * 1024) return hipErrorInvalidValue;
-    int per_cu = (int)((160 * 1024) / lds);
+    // generic form (any r): band rows + window in LDS when they fit, else in a stream-ordered global scratch
+    const size_t need_bytes = ((size_t)2 * (qd.rho + 1) + qd.m) * sizeof(double);
+    const bool in_lds = need_bytes <= 160 * 1024;
+    const size_t lds = in_lds ? need_bytes : 0;
+    int per_cu = in_lds ? (int)((160 * 1024) / need_bytes) : 4;
     if (per_cu > 8) per_cu = 8;
     if (per_cu < 1) per_cu = 1;
     int64_t blocks = (int64_t)num_cu * per_cu;
     if (blocks > max_in) blocks = max_in;
+    double *scratch = nullptr;
+    if (!in_lds) {
+        hipError_t e = hipMallocAsync((void **)&scratch, need_bytes * (size_t)blocks, s);
+        if (e != hipSuccess) return e;
+    }
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(
             qd.early_abandon ? (const void *)kvm_dtw_dp_lds_kernel<true> : (const void *)kvm_dtw_dp_lds_kernel<false>,
@@ -671,9 +681,13 @@ hipError_t kvm_launch_dtw_dp(const double *series, int64_t n, const kvm_query_de
     }
     if (qd.early_abandon)
         hipLaunchKernelGGL((kvm_dtw_dp_lds_kernel<true>), dim3((unsigned)blocks), dim3(64), lds, s, series, qd, in,
-                           suffix, seg_len, d_n_in, out_off, out_dist, cap, counters);
+                           suffix, seg_len, d_n_in, out_off, out_dist, cap, counters, scratch);
     else
         hipLaunchKernelGGL((kvm_dtw_dp_lds_kernel<false>), dim3((unsigned)blocks), dim3(64), lds, s, series, qd, in,
-                           suffix, seg_len, d_n_in, out_off, out_dist, cap, counters);
+                           suffix, seg_len, d_n_in, out_off, out_dist, cap, counters, scratch);
+    if (scratch) {
+        const hipError_t e1 = hipGetLastError(), e2 = hipFreeAsync(scratch, s);
+        return e1 != hipSuccess ? e1 : e2;
+    }
     return hipGetLastError();
 }

@@ -1,0 +1,58 @@
+"""Edge sizes against the oracle: very long queries (m up to 60 000: windows over several prefix blocks, wide DTW bands),
+n == m, one million single-offset intervals, odd parameters."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "kv-match_amd")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import numpy as np, kvmatch
+from kvmatch import datagen
+import oracle
+ctx = kvmatch.Phase2Context(0)
+bad = 0
+def same(tag, a, o):
+    global bad
+    ok = len(a) == len(o[0]) and np.array_equal(a.offsets, o[0]) and np.array_equal(a.distances, o[1]) and a.cnt_candidate == o[2]["cnt_candidate"]
+    print(("ok  " if ok else "BAD ") + tag, len(a), len(o[0]), flush=True)
+    bad += 0 if ok else 1
+base = datagen.gen_series(2_000_000, seed=5)
+for m in (16384, 20000, 33000, 60000):
+    n = 600_000
+    s = base[:n].copy()
+    qoff = 123_457
+    q = datagen.plant_copies(s, qoff, m, [300_000, n - m - 5], [1.0, 1.1], [0.0, 0.3], 0.01, seed=m)
+    ctx.load_series(s)
+    L, R = datagen.gen_intervals(n, m, 3000, 40.0, must_cover=[qoff, 300_000, n - m - 5], seed=3)
+    eps = 0.05 * np.sqrt(m)
+    for ab in (1, 0):
+        ctx.set_option(kvmatch.OPT_EARLY_ABANDON, ab)
+        same(f"rsm_ed m={m} ab={ab}", kvmatch.QueryEngine(ctx).verify((L, R), 1, q, eps), oracle.rsm_ed(s, q, L, R, 0, eps))
+        same(f"cnsm_ed m={m} ab={ab}", kvmatch.NormQueryEngine(ctx).verify((L, R), 1, q, eps, 1.5, 5.0), oracle.cnsm_ed(s, q, L, R, 0, eps, 1.5, 5.0))
+    ctx.set_option(kvmatch.OPT_EARLY_ABANDON, 1)
+    L2, R2 = L[:40], R[:40]
+    must = np.array([qoff, 300_000], dtype=np.int32)
+    L2 = np.unique(np.concatenate([L2, must])); R2 = np.array([r for r in L2], dtype=np.int32) + 3
+    for rho in (0.01, 0.05):
+        r = int(rho * m)
+        t0 = time.time()
+        same(f"rsm_dtw m={m} rho={r}", kvmatch.QueryEngineDtw(ctx).verify((L2, R2), 1, q, eps, rho), oracle.rsm_dtw(s, q, L2, R2, 0, eps, r))
+        same(f"cnsm_dtw m={m} rho={r}", kvmatch.NormQueryEngineDtw(ctx).verify((L2, R2), 1, q, eps, rho, 1.5, 5.0), oracle.cnsm_dtw(s, q, L2, R2, 0, eps, r, 1.5, 5.0))
+        print("   dtw pair took %.1f s" % (time.time() - t0), flush=True)
+# n == m: one candidate
+s = base[:5000].copy(); ctx.load_series(s); q = s.copy()
+one = (np.array([1], dtype=np.int32), np.array([1], dtype=np.int32))
+same("n==m rsm_ed", kvmatch.QueryEngine(ctx).verify(one, 1, q, 0.0), oracle.rsm_ed(s, q, *one, 0, 0.0))
+same("n==m cnsm_ed", kvmatch.NormQueryEngine(ctx).verify(one, 1, q, 0.0, 1.0, 0.0), oracle.cnsm_ed(s, q, *one, 0, 0.0, 1.0, 0.0))
+same("n==m cnsm_dtw", kvmatch.NormQueryEngineDtw(ctx).verify(one, 1, q, 0.0, 0.05, 1.0, 0.0), oracle.cnsm_dtw(s, q, *one, 0, 0.0, 250, 1.0, 0.0))
+# one million single-offset intervals (every second offset)
+n, m = 2_000_000, 256
+s = base[:n].copy(); qoff = 777_777
+q = datagen.plant_copies(s, qoff, m, [1_000_001, 1_500_001], [1.0, 1.0], [0.0, 0.1], 0.02, seed=9)
+ctx.load_series(s)
+L = np.arange(1, n - m, 2, dtype=np.int32)[:1_000_000]; R = L.copy()
+t0 = time.time(); a = kvmatch.QueryEngine(ctx).verify((L, R), 1, q, 3.0); dt = time.time() - t0
+same(f"1e6 single-offset intervals rsm_ed ({dt*1e3:.1f} ms)", a, oracle.rsm_ed(s, q, L, R, 0, 3.0))
+t0 = time.time(); a = kvmatch.NormQueryEngine(ctx).verify((L, R), 1, q, 3.0, 1.5, 5.0); dt = time.time() - t0
+same(f"1e6 single-offset intervals cnsm_ed ({dt*1e3:.1f} ms)", a, oracle.cnsm_ed(s, q, L, R, 0, 3.0, 1.5, 5.0))
+t0 = time.time(); a = kvmatch.NormQueryEngineDtw(ctx).verify((L[:200_000], R[:200_000]), 1, q, 3.0, 0.05, 1.5, 5.0); dt = time.time() - t0
+same(f"2e5 single-offset intervals cnsm_dtw ({dt*1e3:.1f} ms)", a, oracle.cnsm_dtw(s, q, L[:200_000], R[:200_000], 0, 3.0, 12, 1.5, 5.0))
+print("bad", bad)
+sys.exit(1 if bad else 0)

@@ -661,6 +661,31 @@ def test_ucr_full_scan_executors(world):
         kvmatch.UcrEdQueryExecutor(ctx, n + 1, m, q, eps, alpha, beta)
 
 
+def test_long_queries_and_wide_bands(world):
+    """Bands wider than the register DP holds (rho > 511) run the generic anti-diagonal kernel: band rows + window in LDS
+    while they fit (m + 2 rho <= ~20 000 points), else in a global scratch; windows longer than a prefix-sum block
+    (16 384 points) span three blocks.  All against the oracle, bit for bit."""
+    kvmatch, datagen, series, ctx = world
+    n = 120_000
+    s = series[:n].copy()
+    for m, rho in ((3_000, 600), (20_000, 1_000), (40_000, 520)):
+        qoff = 31_337
+        q = datagen.plant_copies(s, qoff, m, [70_001], [1.05], [0.2], 0.01, seed=m)
+        ctx.load_series(s)
+        L = np.array([qoff - 2, 50_000, 70_000], dtype=np.int32)
+        R = np.array([qoff + 2, 50_003, 70_002], dtype=np.int32)
+        eps = 0.05 * np.sqrt(m)
+        compare(kvmatch.QueryEngine(ctx).verify((L, R), 1, q, eps), oracle.rsm_ed(s, q, L, R, 0, eps), tag=f"rsm_ed m={m}")
+        compare(kvmatch.NormQueryEngine(ctx).verify((L, R), 1, q, eps, 1.5, 5.0),
+                oracle.cnsm_ed(s, q, L, R, 0, eps, 1.5, 5.0), tag=f"cnsm_ed m={m}")
+        got = kvmatch.QueryEngineDtw(ctx).verify((L, R), 1, q, eps, rho)
+        compare(got, oracle.rsm_dtw(s, q, L, R, 0, eps, rho), tag=f"rsm_dtw m={m} rho={rho}")
+        assert qoff in got.offsets.tolist()
+        compare(kvmatch.NormQueryEngineDtw(ctx).verify((L, R), 1, q, eps, rho, 1.5, 5.0),
+                oracle.cnsm_dtw(s, q, L, R, 0, eps, rho, 1.5, 5.0), tag=f"cnsm_dtw m={m} rho={rho}")
+    ctx.load_series(series)
+
+
 def test_randomised_sweep_all_variants(world):
     """Seeded random sweep over series shape, query length, thresholds and interval layouts: 240 verifications, each
     compared bit for bit with the oracle."""
