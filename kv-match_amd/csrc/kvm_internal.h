@@ -286,7 +286,8 @@ struct kvm_sum_err {
 __device__ __forceinline__ kvm_sum_err kvm_prefix_err(double pm) {
     kvm_sum_err r;
     r.e1 = 2e-11 * sqrt(pm);
-    r.e2 = 1e-12 * pm;
+    r.e2 = 1e-12 * pm + 1e-314;  // + the absolute quantum of squares that land among the denormals (|x| ~ 1e-155 and below):
+                                 //   <= 2.5e-324 per product, up to ~4e9 products behind a running or a prefix sum
     return r;
 }
 

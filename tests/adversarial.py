@@ -12,7 +12,7 @@ data with an integer eps^2 it is common.  This library returns the candidates wh
 `tie_quirk` below recognises the reference's extra answers (all at distance exactly eps, everything else identical)."""
 import numpy as np
 
-KINDS = ("ints", "steps", "offset", "range", "halfint", "nan")
+KINDS = ("ints", "steps", "offset", "range", "halfint", "nan", "tiny", "huge")
 
 
 def make(kind, n, r):
@@ -31,6 +31,10 @@ def make(kind, n, r):
         idx = r.integers(0, n, 6)
         s[idx[:3]] = np.nan; s[idx[3:5]] = np.inf; s[idx[5]] = -np.inf
         return s
+    if kind == "tiny":      # squares underflow to zero / denormals
+        return np.cumsum(r.uniform(-1, 1, n)) * 1e-158
+    if kind == "huge":      # squares overflow to infinity in places
+        return np.cumsum(r.uniform(-1, 1, n)) * np.where(r.uniform(0, 1, n // 500 + 1).repeat(500)[:n] < 0.2, 1e153, 1e3)
     raise ValueError(kind)
 
 
