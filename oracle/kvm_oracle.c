@@ -1053,6 +1053,10 @@ int64_t kvo_index_rows(const double *series, int64_t n, int32_t w, double *keys,
                         loc - cur_first == 256 - 1) {                    /* :267 (IndexNode.MAXIMUM_DIFF - 1) */
                         if (cnt_rows < cap) {                            /* new interval [loc, loc], :277 */
                             keys[cnt_rows] = curMeanRound;
+                            if (curMeanRound != curMeanRound) { /* one NaN key (Double.equals / doubleToLongBits) */
+                                const uint64_t canon = 0x7ff8000000000000ULL;
+                                memcpy(&keys[cnt_rows], &canon, 8);
+                            }
                             first[cnt_rows] = (int32_t)loc;
                             last[cnt_rows] = (int32_t)loc;
                         }
