@@ -107,6 +107,15 @@ const double *kvm_index_rows_keys(const kvm_index_rows *r);
 const int32_t *kvm_index_rows_first(const kvm_index_rows *r);
 const int32_t *kvm_index_rows_last(const kvm_index_rows *r);
 void kvm_index_rows_free(kvm_index_rows *r);
+/* The same intervals collected into the rows the reference builds -- one IndexNode per distinct key
+ * (K/IndexBuilder.java:270-284) -- and ordered the way step 2 walks them, by DESCENDING key (Double.compareTo; :318):
+ * keys/first/last are sorted by (key descending, position ascending), group g is the row with key
+ * group_keys[g] and holds the intervals [group_offsets[g], group_offsets[g + 1]).  kvm_index_rows_groups is 0 for a
+ * result of kvm_index_rows_build. */
+int kvm_index_rows_build_grouped(kvm_ctx *ctx, int32_t w, kvm_index_rows **out);
+int64_t kvm_index_rows_groups(const kvm_index_rows *r);
+const double *kvm_index_rows_group_keys(const kvm_index_rows *r);
+const int32_t *kvm_index_rows_group_offsets(const kvm_index_rows *r);
 
 /* ---- phase 2: the four verification entry points ------------------------------------------------ */
 

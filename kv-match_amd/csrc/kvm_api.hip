@@ -283,6 +283,9 @@ struct kvm_index_rows {
     int64_t count = 0;
     const double *keys = nullptr;
     const int32_t *first = nullptr, *last = nullptr;
+    int64_t n_groups = 0;               // grouped build only
+    const double *group_keys = nullptr;
+    const int32_t *group_off = nullptr;
 };
 static std::mutex g_idx_mu;
 static void *g_idx_block = nullptr;
@@ -328,7 +331,7 @@ static void idx_block_drop() {
     if (p) hipHostFree(p);
 }
 
-extern "C" int kvm_index_rows_build(kvm_ctx *ctx, int32_t w, kvm_index_rows **out) {
+static int index_rows_build(kvm_ctx *ctx, int32_t w, bool grouped, kvm_index_rows **out) {
     if (!ctx) return KVM_ERR_INVALID_HANDLE;
     if (!out) return fail(ctx, KVM_ERR_ILLEGAL_ARGUMENT, "null result pointer");
     *out = nullptr;
@@ -340,21 +343,29 @@ extern "C" int kvm_index_rows_build(kvm_ctx *ctx, int32_t w, kvm_index_rows **ou
     HIPCHK(ctx, hipSetDevice(ctx->device));
     kvm_index_dev dev;
     if (ctx->opt_timing) hipEventRecord(ctx->ev0, ctx->stream);
-    const int rc = kvm_index_intervals_device(ctx, w, count, &dev, ctx->stream);
+    int rc = kvm_index_intervals_device(ctx, w, count, &dev, ctx->stream);
     if (rc) return fail(ctx, rc, "kvm_index_rows_build: device pass failed (out of device memory?)");
+    if (grouped && (rc = kvm_index_group_device(&dev, ctx->stream))) {
+        kvm_index_dev_free(&dev);
+        return fail(ctx, rc, "kvm_index_rows_build_grouped: grouping pass failed (out of device memory?)");
+    }
     if (ctx->opt_timing) hipEventRecord(ctx->ev1, ctx->stream);
     kvm_index_rows *r = new kvm_index_rows();
     const size_t total = (size_t)dev.total, keys_bytes = (total * 8 + 63) & ~(size_t)63, fl_bytes = (total * 4 + 63) & ~(size_t)63;
-    r->block = idx_block_take(keys_bytes + 2 * fl_bytes + 64, &r->cap);
+    const size_t ng = (size_t)dev.n_groups, gk_bytes = (ng * 8 + 63) & ~(size_t)63, go_bytes = ((ng + 1) * 4 + 63) & ~(size_t)63;
+    r->block = idx_block_take(keys_bytes + 2 * fl_bytes + gk_bytes + go_bytes + 64, &r->cap);
     if (!r->block) {
         kvm_index_dev_free(&dev);
         delete r;
         return fail(ctx, KVM_ERR_DEVICE, "kvm_index_rows_build: out of pinned host memory");
     }
     char *base = (char *)r->block;
+    char *gbase = base + keys_bytes + 2 * fl_bytes;
     const bool ok = hipMemcpyAsync(base, dev.keys, total * 8, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
                     hipMemcpyAsync(base + keys_bytes, dev.first, total * 4, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
                     hipMemcpyAsync(base + keys_bytes + fl_bytes, dev.last, total * 4, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
+                    (ng == 0 || (hipMemcpyAsync(gbase, dev.group_keys, ng * 8, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
+                                 hipMemcpyAsync(gbase + gk_bytes, dev.group_off, (ng + 1) * 4, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess)) &&
                     hipStreamSynchronize(ctx->stream) == hipSuccess;
     kvm_index_dev_free(&dev);
     if (!ok) {
@@ -370,9 +381,19 @@ extern "C" int kvm_index_rows_build(kvm_ctx *ctx, int32_t w, kvm_index_rows **ou
     r->keys = (const double *)base;
     r->first = (const int32_t *)(base + keys_bytes);
     r->last = (const int32_t *)(base + keys_bytes + fl_bytes);
+    if (ng) {
+        r->n_groups = (int64_t)ng;
+        r->group_keys = (const double *)gbase;
+        r->group_off = (const int32_t *)(gbase + gk_bytes);
+    }
     *out = r;
     return KVM_OK;
 }
+extern "C" int kvm_index_rows_build(kvm_ctx *ctx, int32_t w, kvm_index_rows **out) { return index_rows_build(ctx, w, false, out); }
+extern "C" int kvm_index_rows_build_grouped(kvm_ctx *ctx, int32_t w, kvm_index_rows **out) { return index_rows_build(ctx, w, true, out); }
+extern "C" int64_t kvm_index_rows_groups(const kvm_index_rows *r) { return r ? r->n_groups : 0; }
+extern "C" const double *kvm_index_rows_group_keys(const kvm_index_rows *r) { return r ? r->group_keys : nullptr; }
+extern "C" const int32_t *kvm_index_rows_group_offsets(const kvm_index_rows *r) { return r ? r->group_off : nullptr; }
 extern "C" int64_t kvm_index_rows_count(const kvm_index_rows *r) { return r ? r->count : 0; }
 extern "C" const double *kvm_index_rows_keys(const kvm_index_rows *r) { return r ? r->keys : nullptr; }
 extern "C" const int32_t *kvm_index_rows_first(const kvm_index_rows *r) { return r ? r->first : nullptr; }

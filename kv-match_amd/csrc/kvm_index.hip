@@ -161,9 +161,9 @@ void kvm_index_dev_free(kvm_index_dev *d) {
         if (b) hipFree(b);
         b = nullptr;
     }
-    d->keys = nullptr;
-    d->first = d->last = nullptr;
-    d->total = 0;
+    d->keys = d->group_keys = nullptr;
+    d->first = d->last = d->group_off = nullptr;
+    d->total = d->n_groups = 0;
 }
 
 // The whole device pass: running sums -> keys -> runs of equal keys -> intervals of <= 255 positions, left in device
@@ -240,5 +240,82 @@ int kvm_index_intervals_device(kvm_ctx *ctx, int32_t w, int64_t count, kvm_index
     d->first = d_fl;
     d->last = d_fl + total;
     d->total = total;
+    return KVM_OK;
+}
+
+// ---- grouping: the rows of step 1 (K/IndexBuilder.java:270-284 collects the intervals of one key in one IndexNode; step 2,
+// :310-318, walks the rows by DESCENDING key) -------------------------------------------------------------------------
+// Sort key: the bit pattern mapped so that unsigned order == Double.compareTo order (-0.0 < 0.0, NaN above +Inf),
+// complemented for descending order.  The radix sort is stable, so the intervals of a key stay in position order.
+__device__ __forceinline__ unsigned long long kvm_key_to_sortable_desc(unsigned long long u) {
+    const unsigned long long asc = (u >> 63) ? ~u : (u | 0x8000000000000000ULL);
+    return ~asc;
+}
+__device__ __forceinline__ unsigned long long kvm_sortable_desc_to_key(unsigned long long v) {
+    const unsigned long long asc = ~v;
+    return (asc >> 63) ? (asc & 0x7fffffffffffffffULL) : ~asc;
+}
+__global__ __launch_bounds__(256) void kvm_index_pack_kernel(const unsigned long long *__restrict__ keys, const int32_t *__restrict__ first,
+                                                             const int32_t *__restrict__ last, int64_t total,
+                                                             unsigned long long *__restrict__ skey, unsigned long long *__restrict__ val) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        skey[i] = kvm_key_to_sortable_desc(keys[i]);
+        val[i] = ((unsigned long long)(uint32_t)first[i] << 32) | (uint32_t)last[i];
+    }
+}
+__global__ __launch_bounds__(256) void kvm_index_unpack_kernel(const unsigned long long *__restrict__ skey, const unsigned long long *__restrict__ val,
+                                                               int64_t total, unsigned long long *__restrict__ keys,
+                                                               int32_t *__restrict__ first, int32_t *__restrict__ last) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        keys[i] = kvm_sortable_desc_to_key(skey[i]);
+        first[i] = (int32_t)(val[i] >> 32);
+        last[i] = (int32_t)(val[i] & 0xffffffffULL);
+    }
+}
+__global__ __launch_bounds__(256) void kvm_index_group_keys_kernel(unsigned long long *__restrict__ gk, int32_t n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) gk[i] = kvm_sortable_desc_to_key(gk[i]);
+}
+
+int kvm_index_group_device(kvm_index_dev *d, hipStream_t s) {
+    const int64_t total = d->total;
+    if (total <= 0) return KVM_OK;
+    int slot = 9;
+    auto alloc = [&](void **p, size_t bytes) {
+        if (slot >= 16 || hipMalloc(p, bytes + 64) != hipSuccess) return false;
+        d->blocks[slot++] = *p;
+        return true;
+    };
+    unsigned long long *sk_in = nullptr, *sk_out = nullptr, *v_in = nullptr, *v_out = nullptr;
+    int32_t *g_cnt = nullptr, *g_num = nullptr;
+    bool ok = alloc((void **)&sk_in, (size_t)total * 8) && alloc((void **)&sk_out, (size_t)total * 8) &&
+              alloc((void **)&v_in, (size_t)total * 8) && alloc((void **)&v_out, (size_t)total * 8) &&
+              alloc((void **)&g_cnt, (size_t)(total + 1) * 4) && alloc((void **)&g_num, 64);
+    if (!ok) return KVM_ERR_DEVICE;
+    const unsigned grid = (unsigned)std::min<int64_t>((total + 255) / 256, 65536);
+    hipLaunchKernelGGL(kvm_index_pack_kernel, dim3(grid), dim3(256), 0, s, d->keys, d->first, d->last, total, sk_in, v_in);
+    size_t tb_sort = 0, tb_rle = 0, tb_scan = 0;
+    ok = hipcub::DeviceRadixSort::SortPairs(nullptr, tb_sort, sk_in, sk_out, v_in, v_out, (int)total, 0, 64, s) == hipSuccess &&
+         hipcub::DeviceRunLengthEncode::Encode(nullptr, tb_rle, sk_out, sk_in, g_cnt, g_num, (int)total, s) == hipSuccess &&
+         hipcub::DeviceScan::ExclusiveSum(nullptr, tb_scan, g_cnt, g_cnt, (int)total + 1, s) == hipSuccess;
+    size_t tb = std::max(tb_sort, std::max(tb_rle, tb_scan));
+    void *d_temp = nullptr;
+    ok = ok && alloc(&d_temp, tb);
+    size_t t1 = tb, t2 = tb, t3 = tb;
+    ok = ok && hipcub::DeviceRadixSort::SortPairs(d_temp, t1, sk_in, sk_out, v_in, v_out, (int)total, 0, 64, s) == hipSuccess;
+    if (ok) hipLaunchKernelGGL(kvm_index_unpack_kernel, dim3(grid), dim3(256), 0, s, sk_out, v_out, total, d->keys, d->first, d->last);
+    // distinct keys and their interval counts (sk_in and v_in are free again: group keys / offsets go there)
+    ok = ok && hipcub::DeviceRunLengthEncode::Encode(d_temp, t2, sk_out, sk_in, g_cnt, g_num, (int)total, s) == hipSuccess;
+    int32_t ng = 0;
+    ok = ok && hipMemcpyAsync(&ng, g_num, 4, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
+    if (!ok || ng <= 0 || ng > total) return KVM_ERR_DEVICE;
+    int32_t *g_off = reinterpret_cast<int32_t *>(v_in);
+    ok = hipMemsetAsync(g_cnt + ng, 0, 4, s) == hipSuccess &&
+         hipcub::DeviceScan::ExclusiveSum(d_temp, t3, g_cnt, g_off, ng + 1, s) == hipSuccess;
+    hipLaunchKernelGGL(kvm_index_group_keys_kernel, dim3((unsigned)((ng + 255) / 256)), dim3(256), 0, s, sk_in, ng);
+    if (!ok || hipGetLastError() != hipSuccess) return KVM_ERR_DEVICE;
+    d->group_keys = sk_in;
+    d->group_off = g_off;
+    d->n_groups = ng;
     return KVM_OK;
 }

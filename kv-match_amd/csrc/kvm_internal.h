@@ -219,9 +219,14 @@ struct kvm_index_dev {
     unsigned long long *keys = nullptr;  // key bit patterns, one per interval
     int32_t *first = nullptr, *last = nullptr;
     int64_t total = 0;
-    void *blocks[9] = {};
+    // after kvm_index_group_device: intervals ordered by (key descending, position), one group per distinct key
+    unsigned long long *group_keys = nullptr;
+    int32_t *group_off = nullptr;  // [n_groups + 1]
+    int64_t n_groups = 0;
+    void *blocks[16] = {};
 };
 int kvm_index_intervals_device(kvm_ctx *ctx, int32_t w, int64_t count, kvm_index_dev *d, hipStream_t s);
+int kvm_index_group_device(kvm_index_dev *d, hipStream_t s);
 void kvm_index_dev_free(kvm_index_dev *d);
 
 

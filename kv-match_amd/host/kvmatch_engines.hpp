@@ -62,6 +62,24 @@ public:
         }
         kvm_index_rows_free(r);
     }
+    // The same intervals collected into rows: `row(key, first, last, count)` once per distinct key, in the order of
+    // step 2 (descending key, K/IndexBuilder.java:318), with pointers to the row's `count` intervals in position order.
+    template <class Fn>
+    void indexRowsGrouped(int32_t w, Fn &&row) {
+        kvm_index_rows *r = nullptr;
+        check(kvm_index_rows_build_grouped(ctx_, w, &r), ctx_);
+        const int64_t ng = kvm_index_rows_groups(r);
+        const double *gk = kvm_index_rows_group_keys(r);
+        const int32_t *go = kvm_index_rows_group_offsets(r);
+        const int32_t *first = kvm_index_rows_first(r), *last = kvm_index_rows_last(r);
+        try {
+            for (int64_t g = 0; g < ng; g++) row(gk[g], first + go[g], last + go[g], go[g + 1] - go[g]);
+        } catch (...) {
+            kvm_index_rows_free(r);
+            throw;
+        }
+        kvm_index_rows_free(r);
+    }
     kvm_ctx *handle() const { return ctx_; }
 
     static void check(int rc, const kvm_ctx *ctx) {

@@ -120,6 +120,32 @@ JNIEXPORT jlong JNICALL Java_cn_edu_fudan_dsm_kvmatch_gpu_Phase2Gpu_indexRowsBui
     if (rc) { throw_for(env, ctx, rc); return 0; }
     return (jlong)(intptr_t)rows;
 }
+/* grouped == true: intervals ordered by (key descending, position), rows via indexRowsGroups / indexRowsGetGroups */
+JNIEXPORT jlong JNICALL Java_cn_edu_fudan_dsm_kvmatch_gpu_Phase2Gpu_indexRowsBuildGrouped(JNIEnv *env, jclass c, jlong h, jint w) {
+    (void)c;
+    kvm_ctx *ctx = (kvm_ctx *)(intptr_t)h;
+    kvm_index_rows *rows = 0;
+    int rc = kvm_index_rows_build_grouped(ctx, w, &rows);
+    if (rc) { throw_for(env, ctx, rc); return 0; }
+    return (jlong)(intptr_t)rows;
+}
+JNIEXPORT jlong JNICALL Java_cn_edu_fudan_dsm_kvmatch_gpu_Phase2Gpu_indexRowsGroups(JNIEnv *env, jclass c, jlong rows) {
+    (void)env; (void)c;
+    return kvm_index_rows_groups((const kvm_index_rows *)(intptr_t)rows);
+}
+/* keys[g], offsets[g] for all groups (offsets has groups + 1 entries) */
+JNIEXPORT void JNICALL Java_cn_edu_fudan_dsm_kvmatch_gpu_Phase2Gpu_indexRowsGetGroups(JNIEnv *env, jclass c, jlong rows,
+        jdoubleArray keys, jintArray offsets) {
+    (void)c;
+    const kvm_index_rows *r = (const kvm_index_rows *)(intptr_t)rows;
+    jsize ng = (jsize)kvm_index_rows_groups(r);
+    if ((*env)->GetArrayLength(env, keys) != ng || (*env)->GetArrayLength(env, offsets) != ng + 1) {
+        (*env)->ThrowNew(env, (*env)->FindClass(env, "java/lang/IllegalArgumentException"), "index rows groups");
+        return;
+    }
+    (*env)->SetDoubleArrayRegion(env, keys, 0, ng, kvm_index_rows_group_keys(r));
+    (*env)->SetIntArrayRegion(env, offsets, 0, ng + 1, (const jint *)kvm_index_rows_group_offsets(r));
+}
 JNIEXPORT jlong JNICALL Java_cn_edu_fudan_dsm_kvmatch_gpu_Phase2Gpu_indexRowsCount(JNIEnv *env, jclass c, jlong rows) {
     (void)env; (void)c;
     return kvm_index_rows_count((const kvm_index_rows *)(intptr_t)rows);

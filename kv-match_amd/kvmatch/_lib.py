@@ -27,7 +27,8 @@ SYMBOLS = [
     "kvm_load_series_f64", "kvm_load_series_be64", "kvm_load_series_file", "kvm_attach_series_device",
     "kvm_series_length", "kvm_read_time_series", "kvm_window_means",
     "kvm_index_rows_build", "kvm_index_rows_count", "kvm_index_rows_keys", "kvm_index_rows_first", "kvm_index_rows_last",
-    "kvm_index_rows_free",
+    "kvm_index_rows_free", "kvm_index_rows_build_grouped", "kvm_index_rows_groups", "kvm_index_rows_group_keys",
+    "kvm_index_rows_group_offsets",
     "kvm_verify_rsm_ed", "kvm_verify_cnsm_ed", "kvm_verify_rsm_dtw", "kvm_verify_cnsm_dtw", "kvm_resolve_rho",
     "kvm_result_count", "kvm_result_candidates", "kvm_result_elapsed_ms", "kvm_result_offsets",
     "kvm_result_distances", "kvm_result_stat", "kvm_result_free",
@@ -87,6 +88,10 @@ def load():
         "kvm_index_rows_first": (pi, [vp]),
         "kvm_index_rows_last": (pi, [vp]),
         "kvm_index_rows_free": (None, [vp]),
+        "kvm_index_rows_build_grouped": (C.c_int, [vp, i32, C.POINTER(vp)]),
+        "kvm_index_rows_groups": (i64, [vp]),
+        "kvm_index_rows_group_keys": (pd, [vp]),
+        "kvm_index_rows_group_offsets": (pi, [vp]),
         "kvm_verify_rsm_ed": (C.c_int, [vp, vp, i32, vp, vp, i32, i32, f64, C.POINTER(vp)]),
         "kvm_verify_cnsm_ed": (C.c_int, [vp, vp, i32, vp, vp, i32, i32, f64, f64, f64, C.POINTER(vp)]),
         "kvm_verify_rsm_dtw": (C.c_int, [vp, vp, i32, vp, vp, i32, i32, f64, i32, C.POINTER(vp)]),

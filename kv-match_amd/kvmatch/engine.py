@@ -117,23 +117,31 @@ class Phase2Context:
         _lib.check(self._lib.kvm_window_means(self._h, int(w), int(first), int(count), out.ctypes.data), self._h)
         return out
 
-    def index_rows(self, w):
+    def index_rows(self, w, grouped=False):
         """Step 1 of the index build for window length w (K/IndexBuilder.java:186-300): the intervals of consecutive
-        window positions sharing one row key, in position order, as (keys, first, last) arrays -- the reference's own
-        running sums and MeanIntervalUtils.toRound, bit for bit."""
+        window positions sharing one row key as (keys, first, last) arrays -- the reference's own running sums and
+        MeanIntervalUtils.toRound, bit for bit.  grouped=False: in position order (what the loop appends).
+        grouped=True: collected into rows, ordered by (key descending, position) as step 2 walks them (:318); returns
+        (keys, first, last, group_keys, group_offsets) with row g = intervals [group_offsets[g], group_offsets[g+1])."""
         import ctypes as C
         h = C.c_void_p()
-        _lib.check(self._lib.kvm_index_rows_build(self._h, int(w), C.byref(h)), self._h)
+        build = self._lib.kvm_index_rows_build_grouped if grouped else self._lib.kvm_index_rows_build
+        _lib.check(build(self._h, int(w), C.byref(h)), self._h)
         try:
             cnt = int(self._lib.kvm_index_rows_count(h))
             if cnt == 0:
-                return np.empty(0), np.empty(0, dtype=np.int32), np.empty(0, dtype=np.int32)
+                out = (np.empty(0), np.empty(0, dtype=np.int32), np.empty(0, dtype=np.int32))
+                return out + (np.empty(0), np.zeros(1, dtype=np.int32)) if grouped else out
             keys = np.ctypeslib.as_array(self._lib.kvm_index_rows_keys(h), shape=(cnt,)).copy()
             first = np.ctypeslib.as_array(self._lib.kvm_index_rows_first(h), shape=(cnt,)).copy()
             last = np.ctypeslib.as_array(self._lib.kvm_index_rows_last(h), shape=(cnt,)).copy()
+            if grouped:
+                ng = int(self._lib.kvm_index_rows_groups(h))
+                gk = np.ctypeslib.as_array(self._lib.kvm_index_rows_group_keys(h), shape=(ng,)).copy()
+                go = np.ctypeslib.as_array(self._lib.kvm_index_rows_group_offsets(h), shape=(ng + 1,)).copy()
         finally:
             self._lib.kvm_index_rows_free(h)
-        return keys, first, last
+        return (keys, first, last, gk, go) if grouped else (keys, first, last)
 
     def set_option(self, option, value):
         _lib.check(self._lib.kvm_set_option(self._h, int(option), int(value)), self._h)

@@ -262,3 +262,18 @@ def index_rows(series, w, want_means=False):
                                 means.ctypes.data if want_means else None)
     out = (keys[:cnt].copy(), first[:cnt].copy(), last[:cnt].copy())
     return out + (means,) if want_means else out
+
+
+def index_rows_grouped(series, w):
+    """index_rows collected the way K/IndexBuilder.java does it: one row (IndexNode) per distinct key, its intervals in
+    the order they were appended (:270-284), rows ordered by descending key as step 2 sorts them
+    (`-o1.getFirst().compareTo(o2.getFirst())`, :318).  Returns (keys, first, last, group_keys, group_offsets)."""
+    keys, first, last = index_rows(series, w)
+    bits = keys.view(np.uint64)
+    # Double.compareTo order on the bit patterns: negatives reversed below positives, NaN above +Inf
+    asc = np.where(bits >> np.uint64(63) != 0, ~bits, bits | np.uint64(1 << 63))
+    order = np.argsort(~asc, kind="stable")            # descending key, append order inside a key
+    k2, f2, l2 = keys[order], first[order], last[order]
+    b2 = k2.view(np.uint64)
+    starts = np.concatenate(([0], np.nonzero(b2[1:] != b2[:-1])[0] + 1)) if len(b2) else np.zeros(0, dtype=np.int64)
+    return k2, f2, l2, k2[starts], np.concatenate((starts, [len(k2)])).astype(np.int32)

