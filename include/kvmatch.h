@@ -117,6 +117,16 @@ int64_t kvm_index_rows_groups(const kvm_index_rows *r);
 const double *kvm_index_rows_group_keys(const kvm_index_rows *r);
 const int32_t *kvm_index_rows_group_offsets(const kvm_index_rows *r);
 
+/* Phase-2 time model for the phase-1 early-termination test (K/QueryEngine.java:316-327 and the same lines of the other
+ * three engines): estimated T_2 in milliseconds of this library for `disjoint_windows` candidate intervals holding
+ * `candidate_offsets` offsets and a query of `length` points,
+ *     T_2 = C + A * disjoint_windows + B * (candidate_offsets / 1e5) * length,
+ * i.e. the reference's own formula (PHASE_2_TIME_ESTIMATE_COEFFICIENT_A/B/INTERCEPT, K/QueryEngine.java:55-57) with
+ * the constants re-fitted on an MI355X (profiles/fit_cost_model.py -> profiles/r01_phase2_cost_model.json; the Java
+ * constants are 4.07 / 0.27 for RSM-ED and 9.72 / 0.0107 for the others, five to six orders of magnitude larger).
+ * `variant`: 0 rsm_ed, 1 cnsm_ed, 2 rsm_dtw, 3 cnsm_dtw.  Pure function; < 0 for an unknown variant. */
+double kvm_phase2_time_estimate_ms(int32_t variant, int64_t disjoint_windows, int64_t candidate_offsets, int32_t length);
+
 /* ---- phase 2: the four verification entry points ------------------------------------------------ */
 
 /* RSM-ED.  Replaces K/QueryEngine.java:338-363 (+ sort :373). */

@@ -111,6 +111,13 @@ JNIEXPORT jdoubleArray JNICALL Java_cn_edu_fudan_dsm_kvmatch_gpu_Phase2Gpu_readT
     return out;
 }
 
+/* phase-2 time model for the early-termination test (K/QueryEngine.java:316-327) */
+JNIEXPORT jdouble JNICALL Java_cn_edu_fudan_dsm_kvmatch_gpu_Phase2Gpu_phase2TimeEstimateMs(JNIEnv *env, jclass c, jint variant,
+        jlong windows, jlong offsets, jint length) {
+    (void)env; (void)c;
+    return kvm_phase2_time_estimate_ms(variant, windows, offsets, length);
+}
+
 /* Index build step 1 (K/IndexBuilder.java:186-300): build, bulk accessors, free */
 JNIEXPORT jlong JNICALL Java_cn_edu_fudan_dsm_kvmatch_gpu_Phase2Gpu_indexRowsBuild(JNIEnv *env, jclass c, jlong h, jint w) {
     (void)c;

@@ -68,6 +68,12 @@ def _as_intervals(valid_positions):
     return left, right
 
 
+def phase2_time_estimate_ms(variant, disjoint_windows, candidate_offsets, length):
+    """The reference's phase-2 cost model with MI355X constants (K/QueryEngine.java:55-57,316-327); variant 0 rsm_ed,
+    1 cnsm_ed, 2 rsm_dtw, 3 cnsm_dtw."""
+    return float(_lib.load().kvm_phase2_time_estimate_ms(int(variant), int(disjoint_windows), int(candidate_offsets), int(length)))
+
+
 class Phase2Context:
     """One HIP device + one staged series; the analogue of the engine constructor
     ``QueryEngine(int n, String storageType)`` (K/QueryEngine.java:70) which opens the TimeSeriesOperator."""

@@ -6,7 +6,7 @@ The reference stops phase 1 early when its estimate of phase-2 time exceeds the 
 to the JAVA phase 2 (A = 4.0708, B = 0.26983, K/QueryEngine.java:55-57; A = 9.7228, B = 0.010674 for the other three
 engines).  With phase 2 on an MI355X these constants are off by orders of magnitude, so phase 1 should stop far
 earlier.  This script measures T_2 of the library (reference behaviour: early abandon on) over a grid of
-(#intervals, #offsets, m) for RSM-ED and cNSM-DTW and fits  T_2[ms] = C + A * #intervals + B * (#offsets/1e5) * m.
+(#intervals, #offsets, m) for the four variants and fits  T_2[ms] = C + A * #intervals + B * (#offsets/1e5) * m.
 Output: JSON on stdout (committed as profiles/r01_phase2_cost_model.json)."""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -17,7 +17,7 @@ from kvmatch import datagen
 n = 20_000_000
 series = datagen.gen_series(n, seed=77)
 ctx = kvmatch.Phase2Context(0); ctx.load_series(series)
-rows = {"rsm_ed": [], "cnsm_dtw": []}
+rows = {"rsm_ed": [], "cnsm_ed": [], "rsm_dtw": [], "cnsm_dtw": []}
 for m in (1024, 4096, 8192):
     qoff = n // 3
     q = series[qoff - 1: qoff - 1 + m].copy()
@@ -25,8 +25,10 @@ for m in (1024, 4096, 8192):
         for mean_len in (4.0, 64.0, 1024.0):
             L, R = datagen.gen_intervals(n, m, offsets, mean_len, must_cover=[qoff], seed=5)
             for name, eng, args in (("rsm_ed", kvmatch.QueryEngine(ctx), (10.0,)),
+                                    ("cnsm_ed", kvmatch.NormQueryEngine(ctx), (10.0, 1.5, 5.0)),
+                                    ("rsm_dtw", kvmatch.QueryEngineDtw(ctx), (10.0, 0.05)),
                                     ("cnsm_dtw", kvmatch.NormQueryEngineDtw(ctx), (10.0, 0.05, 1.5, 5.0))):
-                if name == "cnsm_dtw" and (m == 8192 or offsets > 1_000_000):
+                if name.endswith("dtw") and (m == 8192 or offsets > 1_000_000):
                     continue
                 eng.verify((L, R), 1, q, *args)
                 ts = []

@@ -60,3 +60,18 @@ def test_open_fails_loudly_without_gpu(built):
     import kvmatch
     with pytest.raises(kvmatch.KvMatchDeviceError):
         kvmatch.Phase2Context(0)
+
+
+def test_phase2_time_estimate_is_the_reference_formula(built):
+    """kvm_phase2_time_estimate_ms: the formula of K/QueryEngine.java:319 with this library's constants -- affine in
+    #intervals and in #offsets * length, orders of magnitude below the Java constants, no GPU needed."""
+    import kvmatch
+    f = kvmatch.phase2_time_estimate_ms
+    for v in range(4):
+        c = f(v, 0, 0, 1024)
+        assert 0.05 < c < 1.0
+        a = f(v, 1000, 0, 1024) - c
+        b = f(v, 0, 100_000, 1000) - c
+        assert 1e-3 < a < 1e-2 and 0 < b < 0.1                       # Java: 4 071 ms resp. 270 ms for RSM-ED
+        assert abs(f(v, 2000, 200_000, 1000) - (c + 2 * a + 2 * b)) < 1e-12
+    assert f(7, 1, 1, 1) < 0
