@@ -221,43 +221,6 @@ def main():
                        "note": "frac > 1: 63 of every 64 algorithmic bytes are served from LDS/L2 (traffic = measured HBM "
                                "bytes per launch); the kernel's binding resource is the fp64 vector pipe (valu_frac)"}
 
-    # ---- CPU baseline: the oracle (a C port of the reference loops), rank 0, N=1 only --------------------
-    if rank == 0 and world == 1 and a.cpu_baseline and wl == "rsm_ed":
-        sys.path.insert(0, os.path.join(ROOT, "oracle"))
-        import oracle  # test infrastructure: used here only as the timed CPU baseline / checker
-        t1 = time.perf_counter()
-        o_off, o_dist, o_st = oracle.rsm_ed(series, q, my_l, my_r, 0, a.epsilon, no_abandon=True)
-        cpu_s = time.perf_counter() - t1
-        t1 = time.perf_counter()
-        oracle.rsm_ed(series, q, my_l, my_r, 0, a.epsilon, no_abandon=False)
-        cpu_ab_s = time.perf_counter() - t1
-        out["cpu_baseline"] = {
-            "value": o_st["windows"] / cpu_s, "unit": "candidates/s", "cores": 1, "kind": "port",
-            "sample": f"all {o_st['windows']} candidates of the N=1 workload, early abandon off (same work as "
-                      f"`value`), single thread; C restatement of K/QueryEngine.java:338-363 (no JDK on the box, "
-                      f"avoids Java boxing so it flatters the CPU side)",
-            "value_early_abandon": o_st["windows"] / cpu_ab_s,
-            "seconds": cpu_s,
-        }
-        # the same loop on all host cores: a child process (no GPU context there) forks one worker per core
-        try:
-            import subprocess
-            ncores = min(os.cpu_count() or 1, 64)
-            cp = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline.py"), str(n), str(m),
-                                 str(a.candidates), str(a.epsilon), str(ncores)], capture_output=True, text=True,
-                                timeout=300)
-            allc = json.loads(cp.stdout.strip().splitlines()[-1])
-            out["cpu_baseline"]["all_cores"] = {"cores": allc["cores"], "value": allc["no_abandon"]["candidates_per_s"],
-                                                "value_early_abandon": allc["early_abandon"]["candidates_per_s"],
-                                                "note": "same port, interval shards over forked worker processes"}
-        except Exception as e:
-            out["cpu_baseline"]["all_cores"] = {"error": repr(e)}
-        same = sorted(o_off.tolist()) == sorted(head_offs.tolist())
-        od = dict(zip(o_off.tolist(), o_dist.tolist()))
-        close = same and all(abs(d - od[o]) <= max(1e-6 * max(d, od[o]), 1e-9)
-                             for o, d in zip(head_offs.tolist(), head_dists.tolist()))
-        out["parity_vs_oracle"] = bool(same and close)
-
     # ---- extras (N=1): the other variants on the same staged series ---------------------------------------
     if rank == 0 and world == 1 and a.extras and wl == "rsm_ed":
         ex = {}
@@ -334,6 +297,44 @@ def main():
         except Exception as e:  # extras must never take the headline down
             ex["error"] = repr(e)
         out["extras"] = ex
+
+    # ---- CPU baseline: the oracle (a C port of the reference loops), rank 0, N=1 only --------------------
+    # (after the extras: its all-cores leg leaves the host busy for a while, which the sync-heavy DTW cascade feels)
+    if rank == 0 and world == 1 and a.cpu_baseline and wl == "rsm_ed":
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import oracle  # test infrastructure: used here only as the timed CPU baseline / checker
+        t1 = time.perf_counter()
+        o_off, o_dist, o_st = oracle.rsm_ed(series, q, my_l, my_r, 0, a.epsilon, no_abandon=True)
+        cpu_s = time.perf_counter() - t1
+        t1 = time.perf_counter()
+        oracle.rsm_ed(series, q, my_l, my_r, 0, a.epsilon, no_abandon=False)
+        cpu_ab_s = time.perf_counter() - t1
+        out["cpu_baseline"] = {
+            "value": o_st["windows"] / cpu_s, "unit": "candidates/s", "cores": 1, "kind": "port",
+            "sample": f"all {o_st['windows']} candidates of the N=1 workload, early abandon off (same work as "
+                      f"`value`), single thread; C restatement of K/QueryEngine.java:338-363 (no JDK on the box, "
+                      f"avoids Java boxing so it flatters the CPU side)",
+            "value_early_abandon": o_st["windows"] / cpu_ab_s,
+            "seconds": cpu_s,
+        }
+        # the same loop on all host cores: a child process (no GPU context there) forks one worker per core
+        try:
+            import subprocess
+            ncores = min(os.cpu_count() or 1, 64)
+            cp = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline.py"), str(n), str(m),
+                                 str(a.candidates), str(a.epsilon), str(ncores)], capture_output=True, text=True,
+                                timeout=300)
+            allc = json.loads(cp.stdout.strip().splitlines()[-1])
+            out["cpu_baseline"]["all_cores"] = {"cores": allc["cores"], "value": allc["no_abandon"]["candidates_per_s"],
+                                                "value_early_abandon": allc["early_abandon"]["candidates_per_s"],
+                                                "note": "same port, interval shards over forked worker processes"}
+        except Exception as e:
+            out["cpu_baseline"]["all_cores"] = {"error": repr(e)}
+        same = sorted(o_off.tolist()) == sorted(head_offs.tolist())
+        od = dict(zip(o_off.tolist(), o_dist.tolist()))
+        close = same and all(abs(d - od[o]) <= max(1e-6 * max(d, od[o]), 1e-9)
+                             for o, d in zip(head_offs.tolist(), head_dists.tolist()))
+        out["parity_vs_oracle"] = bool(same and close)
 
     ctx.close()
     if rank == 0:
