@@ -109,6 +109,47 @@ struct kvm_result {
 // common
 hipError_t kvm_launch_bswap64(uint64_t *d, int64_t n, hipStream_t s);
 // (both expansion kernels also zero the KVM_CNT_TOTAL counters and, when `run_maxk` is given, the replay scratch)
+// One interval of the candidate list -> its clipped run and tile counts (window start offsets of [left, right]:
+// max(1, left-shift) .. min(right-shift, n-m+1), K/QueryEngine.java:346-354).  The host sums these over the list
+// (build_plan: launch geometry, buffer sizes), the device turns them into the runs with their prefix sums
+// (kvm_plan_runs_kernel); both use this one rule.
+struct kvm_plan_item {
+    int64_t lo;        // first window start
+    int64_t c64;       // hi - lo + 1 before clamping at zero (the RSM range check needs it: c64 + m - 1 points are fetched)
+    uint32_t c;        // windows (0: clipped away)
+    uint32_t tiles_a;  // tiles (class A tiles in hybrid mode)
+    uint32_t tiles_b;  // hybrid mode: 1 if the run has a class-B remainder tile
+};
+#ifdef __HIPCC__
+__host__ __device__
+#endif
+static inline void kvm_plan_tiles(uint32_t c, bool hybrid, int tile_log2, uint32_t &tiles_a, uint32_t &tiles_b) {
+    if (hybrid) {  // correlation-form ED pruner: 64-candidate tiles + <= 32-candidate remainders (kvm_ed_dot.hip)
+        const uint32_t rem = c & 63u;
+        tiles_a = (c >> 6) + (rem > 32u ? 1u : 0u);
+        tiles_b = (rem - 1u) < 32u ? 1u : 0u;
+    } else {
+        tiles_a = (c + (1u << tile_log2) - 1u) >> tile_log2;
+        tiles_b = 0u;
+    }
+}
+#ifdef __HIPCC__
+__host__ __device__
+#endif
+static inline kvm_plan_item kvm_plan_interval(int64_t l, int64_t r, int64_t shift, int64_t hi_max, bool hybrid, int tile_log2) {
+    kvm_plan_item it;
+    int64_t lo = l - shift, hi = r - shift;
+    lo = lo < 1 ? 1 : lo;
+    hi = hi > hi_max ? hi_max : hi;
+    const int64_t c64 = hi - lo + 1;
+    it.lo = lo;
+    it.c64 = c64;
+    it.c = c64 > 0 ? (uint32_t)c64 : 0u;
+    kvm_plan_tiles(it.c, hybrid, tile_log2, it.tiles_a, it.tiles_b);
+    return it;
+}
+hipError_t kvm_launch_plan_runs(const int32_t *left, const int32_t *right, int32_t k, int32_t shift, int64_t hi_max, bool hybrid,
+                                int tile_log2, kvm_run *runs, void *scratch, hipStream_t s);
 hipError_t kvm_launch_expand_tiles(const kvm_run *runs, int64_t n_runs, int32_t tile_max, kvm_tile *tiles,
                                    unsigned long long *counters, int32_t *run_maxk, hipStream_t s);
 // hybrid ED tiling: class A = 64-candidate tiles (full tiles and remainders > 32), class B = remainders <= 32
