@@ -669,6 +669,22 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
     }
     KVM_TP("  build_plan");
 
+    // The interval list goes to the device first and the runs are built from it there (kvm_plan_runs_kernel, ~12 us)
+    // while the host prepares the query block below.  Device layout: query block | left | right | runs | plan scratch.
+    const size_t rbytes = (size_t)pl.n_runs * sizeof(kvm_run);
+    const size_t plan_scratch = ((size_t)(k > 0 ? k : 0) / 256 + 1) * 32;  // block totals of kvm_launch_plan_runs
+    if ((rc = ensure(ctx, ctx->b_query, qbytes + lr_bytes + rbytes + plan_scratch + 64))) return rc;
+    kvm_run *d_runs_w = (kvm_run *)((char *)ctx->b_query.p + qbytes + lr_bytes);
+    if (rbytes) {
+        HIPCHK(ctx, hipMemcpyAsync((char *)ctx->b_query.p + qbytes, hp + qbytes, lr_bytes, hipMemcpyHostToDevice, stream));
+        int tile_log2 = 0;
+        while ((1 << tile_log2) < tile_max) tile_log2++;
+        HIPCHK(ctx, kvm_launch_plan_runs((const int32_t *)((const char *)ctx->b_query.p + qbytes),
+                                         (const int32_t *)((const char *)ctx->b_query.p + qbytes + lr_half), k, shift,
+                                         ctx->n - m + 1, hybrid, tile_log2, d_runs_w,
+                                         (char *)ctx->b_query.p + qbytes + lr_bytes + ((rbytes + 31) & ~(size_t)31), stream));
+    }
+
     // ---- query-side constants (host, sequential, exactly the reference's arithmetic) ----
     std::vector<double> q(query, query + m), qu, ql;
     kvm_query_dev qd;
@@ -713,11 +729,8 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
         qpref[(size_t)nchunks4] = make_double2(p1, p2);
         qpref8[(size_t)nchunks8] = make_double2(p1, p2);
     }
-    const size_t rbytes = (size_t)pl.n_runs * sizeof(kvm_run);
     const size_t tbytes = (size_t)((retile || dtw) ? 3 * pl.n_tiles : pl.n_tiles + pl.n_tiles_b) * sizeof(kvm_tile);
     // (KVM_SERIES_PAD spare doubles after q: the tiled ED kernel stages whole query chunks without bounds checks)
-    const size_t plan_scratch = ((size_t)(k > 0 ? k : 0) / 256 + 1) * 32;  // block totals of kvm_launch_plan_runs
-    if ((rc = ensure(ctx, ctx->b_query, qbytes + lr_bytes + rbytes + plan_scratch + 64))) return rc;
     if ((rc = ensure(ctx, ctx->b_tiles, tbytes + 64))) return rc;
     if ((rc = ensure(ctx, ctx->b_counters, KVM_CNT_TOTAL * sizeof(unsigned long long)))) return rc;
     // zero pads: after q (| qu | ql), after qc, and the tail of qT
@@ -760,20 +773,10 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
         rws.run_list = rws.run_maxk + pl.n_runs;
         rws.run_list_n = (unsigned long long *)ctx->b_counters.p + KVM_CNT_REPLAY_RUNS;
     }
-    // one H2D copy: the query block and, right behind it, the interval list (8 B per interval); the runs (32 B each) and
-    // from them the tile list (16 B per tile) are built on the GPU, the latter by the kernel that also zeroes the counters
-    // (for cNSM-ED the span covers the exact-pass block, which is filled in and copied again further down, in stream
-    // order, before its only reader -- the exact pass -- is launched)
-    HIPCHK(ctx, hipMemcpyAsync(ctx->b_query.p, hp, rbytes ? qbytes + lr_bytes : qfirst, hipMemcpyHostToDevice, stream));
-    kvm_run *d_runs_w = (kvm_run *)((char *)ctx->b_query.p + qbytes + lr_bytes);
-    if (rbytes) {
-        int tile_log2 = 0;
-        while ((1 << tile_log2) < tile_max) tile_log2++;
-        HIPCHK(ctx, kvm_launch_plan_runs((const int32_t *)((const char *)ctx->b_query.p + qbytes),
-                                         (const int32_t *)((const char *)ctx->b_query.p + qbytes + lr_half), k, shift,
-                                         ctx->n - m + 1, hybrid, tile_log2, d_runs_w,
-                                         (char *)ctx->b_query.p + qbytes + lr_bytes + ((rbytes + 31) & ~(size_t)31), stream));
-    }
+    // the query block (the tile list -- 16 B per tile -- is expanded from the runs on the GPU, by the kernel that also
+    // zeroes the counters; for cNSM-ED the exact-pass block is filled in and copied further down, in stream order, before
+    // its only reader -- the exact pass -- is launched)
+    HIPCHK(ctx, hipMemcpyAsync(ctx->b_query.p, hp, qfirst, hipMemcpyHostToDevice, stream));
     const kvm_run *d_runs = d_runs_w;
     if (rbytes) {
         if (hybrid)
