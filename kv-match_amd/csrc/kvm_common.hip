@@ -51,13 +51,17 @@ __global__ __launch_bounds__(PLAN_THREADS) void kvm_plan_totals_kernel(const int
 __global__ __launch_bounds__(PLAN_THREADS) void kvm_plan_runs_kernel(const int32_t *__restrict__ left, const int32_t *__restrict__ right,
                                                                     int32_t k, int32_t shift, int64_t hi_max, int hybrid,
                                                                     int tile_log2, const plan_sums *__restrict__ block_tot,
-                                                                    kvm_run *__restrict__ runs) {
+                                                                    int scanned, kvm_run *__restrict__ runs) {
     __shared__ plan_sums wave_tot[PLAN_THREADS / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // totals of the blocks before this one
+    // totals of the blocks before this one: summed here (few blocks), or already scanned by kvm_plan_scan_kernel
     plan_sums before{0, 0, 0, 0};
-    for (int64_t b = tid; b < (int64_t)blockIdx.x; b += PLAN_THREADS) before = plan_add(before, block_tot[b]);
-    before = plan_block_sum(before, wave_tot);
+    if (scanned) {
+        before = block_tot[blockIdx.x];
+    } else {
+        for (int64_t b = tid; b < (int64_t)blockIdx.x; b += PLAN_THREADS) before = plan_add(before, block_tot[b]);
+        before = plan_block_sum(before, wave_tot);
+    }
     const int64_t p = (int64_t)blockIdx.x * PLAN_THREADS + tid;
     kvm_plan_item it;
     it.lo = 1; it.c64 = 0; it.c = 0; it.tiles_a = 0; it.tiles_b = 0;
@@ -84,16 +88,47 @@ __global__ __launch_bounds__(PLAN_THREADS) void kvm_plan_runs_kernel(const int32
     }
 }
 
+// Long lists (more than PLAN_SCAN_ABOVE blocks): the block totals are turned into exclusive prefixes in place by one
+// workgroup (contiguous slice per thread, block scan of the slice sums) so that kvm_plan_runs_kernel does not sum
+// O(blocks) totals per block.
+#define PLAN_SCAN_ABOVE 1024
+__global__ __launch_bounds__(1024) void kvm_plan_scan_kernel(plan_sums *__restrict__ block_tot, int64_t blocks) {
+    __shared__ plan_sums wave_tot[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t per = (blocks + 1023) / 1024;
+    const int64_t b0 = min(blocks, (int64_t)tid * per), b1 = min(blocks, b0 + per);
+    plan_sums mine{0, 0, 0, 0};
+    for (int64_t b = b0; b < b1; b++) mine = plan_add(mine, block_tot[b]);
+    plan_sums inc = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const plan_sums t = plan_shfl_up(inc, o);
+        if (lane >= o) inc = plan_add(inc, t);
+    }
+    if (lane == 63) wave_tot[wave] = inc;
+    __syncthreads();
+    plan_sums run{0, 0, 0, 0};
+    for (int w = 0; w < wave; w++) run = plan_add(run, wave_tot[w]);
+    run = plan_add(run, plan_sums{inc.nr - mine.nr, inc.ta - mine.ta, inc.tb - mine.tb, inc.w - mine.w});
+    for (int64_t b = b0; b < b1; b++) {
+        const plan_sums t = block_tot[b];
+        block_tot[b] = run;
+        run = plan_add(run, t);
+    }
+}
+
 // `scratch`: 32 B per 256 intervals (block totals)
 hipError_t kvm_launch_plan_runs(const int32_t *left, const int32_t *right, int32_t k, int32_t shift, int64_t hi_max, bool hybrid,
                                 int tile_log2, kvm_run *runs, void *scratch, hipStream_t s) {
     if (k <= 0) return hipSuccess;
-    const unsigned blocks = (unsigned)(((int64_t)k + PLAN_THREADS - 1) / PLAN_THREADS);
+    const int64_t blocks = ((int64_t)k + PLAN_THREADS - 1) / PLAN_THREADS;
     plan_sums *bt = reinterpret_cast<plan_sums *>(scratch);
-    hipLaunchKernelGGL(kvm_plan_totals_kernel, dim3(blocks), dim3(PLAN_THREADS), 0, s, left, right, k, shift, hi_max, hybrid ? 1 : 0,
-                       tile_log2, bt);
-    hipLaunchKernelGGL(kvm_plan_runs_kernel, dim3(blocks), dim3(PLAN_THREADS), 0, s, left, right, k, shift, hi_max, hybrid ? 1 : 0,
-                       tile_log2, bt, runs);
+    hipLaunchKernelGGL(kvm_plan_totals_kernel, dim3((unsigned)blocks), dim3(PLAN_THREADS), 0, s, left, right, k, shift, hi_max,
+                       hybrid ? 1 : 0, tile_log2, bt);
+    const int scanned = blocks > PLAN_SCAN_ABOVE;
+    if (scanned) hipLaunchKernelGGL(kvm_plan_scan_kernel, dim3(1), dim3(1024), 0, s, bt, blocks);
+    hipLaunchKernelGGL(kvm_plan_runs_kernel, dim3((unsigned)blocks), dim3(PLAN_THREADS), 0, s, left, right, k, shift, hi_max,
+                       hybrid ? 1 : 0, tile_log2, bt, scanned, runs);
     return hipGetLastError();
 }
 

@@ -54,5 +54,16 @@ t0 = time.time(); a = kvmatch.NormQueryEngine(ctx).verify((L, R), 1, q, 3.0, 1.5
 same(f"1e6 single-offset intervals cnsm_ed ({dt*1e3:.1f} ms)", a, oracle.cnsm_ed(s, q, L, R, 0, 3.0, 1.5, 5.0))
 t0 = time.time(); a = kvmatch.NormQueryEngineDtw(ctx).verify((L[:200_000], R[:200_000]), 1, q, 3.0, 0.05, 1.5, 5.0); dt = time.time() - t0
 same(f"2e5 single-offset intervals cnsm_dtw ({dt*1e3:.1f} ms)", a, oracle.cnsm_dtw(s, q, L[:200_000], R[:200_000], 0, 3.0, 12, 1.5, 5.0))
+# ten million single-offset intervals (the plan's scanned-totals path: 39 063 blocks)
+n, m = 25_000_000, 64
+s = datagen.gen_series(n, seed=6); qoff = 7_777_777
+q = datagen.plant_copies(s, qoff, m, [10_000_001, 15_000_001], [1.0, 1.0], [0.0, 0.1], 0.02, seed=10)
+ctx.load_series(s)
+L = np.arange(1, n - m, 2, dtype=np.int32)[:10_000_000]; R = L.copy()
+kvmatch.QueryEngine(ctx).verify((L, R), 1, q, 1.0)
+t0 = time.time(); a = kvmatch.QueryEngine(ctx).verify((L, R), 1, q, 1.0); dt = time.time() - t0
+same(f"1e7 single-offset intervals rsm_ed ({dt*1e3:.1f} ms)", a, oracle.rsm_ed(s, q, L, R, 0, 1.0))
+t0 = time.time(); a = kvmatch.NormQueryEngine(ctx).verify((L, R), 1, q, 1.0, 1.5, 5.0); dt = time.time() - t0
+same(f"1e7 single-offset intervals cnsm_ed ({dt*1e3:.1f} ms)", a, oracle.cnsm_ed(s, q, L, R, 0, 1.0, 1.5, 5.0))
 print("bad", bad)
 sys.exit(1 if bad else 0)
