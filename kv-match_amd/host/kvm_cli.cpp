@@ -35,6 +35,24 @@ int main(int argc, char **argv) {
         show("RSM-DTW ", kvmatch::QueryEngineDtw(ctx).verify(iv, 1, q, eps, 0.05));
         show("cNSM-ED ", kvmatch::NormQueryEngine(ctx).verify(iv, 1, q, eps, 1.5, 5.0));
         show("cNSM-DTW", kvmatch::NormQueryEngineDtw(ctx).verify(iv, 1, q, eps, 0.05, 1.5, 5.0));
+        // index-free full scans (experiments/ucr/*), step 1 of the index build, the phase-2 time model
+        show("UCR-ED  ", kvmatch::UcrEdQueryExecutor(ctx, n, q, eps, 1.5, 5.0, 50000).run());
+        show("UCR-DTW ", kvmatch::UcrDtwQueryExecutor(ctx, n, q, eps, kvm_resolve_rho(0.05, m), 1.5, 5.0).run());
+        int64_t intervals = 0, covered = 0;
+        ctx.indexRows(50, [&](double, int32_t first, int32_t last) { intervals++; covered += last - first + 1; });
+        int64_t rows = 0, grouped = 0;
+        double prev_key = 0;
+        bool descending = true;
+        ctx.indexRowsGrouped(50, [&](double key, const int32_t *, const int32_t *, int32_t count) {
+            if (rows > 0 && !(key < prev_key)) descending = false;
+            prev_key = key;
+            rows++;
+            grouped += count;
+        });
+        printf("index w=50: %lld intervals covering %lld positions, %lld rows (%s), grouped intervals %lld\n", (long long)intervals,
+               (long long)covered, (long long)rows, descending ? "keys descending" : "KEYS NOT DESCENDING", (long long)grouped);
+        printf("T_2 model (rsm_ed, %lld intervals, %lld offsets, m=%d): %.4f ms\n", (long long)k, (long long)(n / 100), m,
+               kvm_phase2_time_estimate_ms(0, k, n / 100, m));
     } catch (const kvmatch::IllegalArgumentException &e) {
         fprintf(stderr, "IllegalArgumentException: %s\n", e.what());
         return 1;

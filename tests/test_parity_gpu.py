@@ -709,6 +709,45 @@ def test_index_rows_grouped(world):
     ctx.load_series(series)
 
 
+def test_cpp_host_mirror_cli(world):
+    """The C++ host mirror (kv-match_amd/host/kvmatch_engines.hpp) through its CLI driver: same seeded inputs as the Python
+    mirror, same answers -- engines, full-scan executors, index rows (plain and grouped), phase-2 time model."""
+    import os, re, subprocess
+    kvmatch, datagen, series, ctx = world
+    cli = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "kv-match_amd", "host", "kvm_cli")
+    n, m, eps = 400_000, 512, 4.0
+    out = subprocess.run([cli, str(n), str(m), str(eps)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    lines = {l.split()[0] + (" " + l.split()[1] if l.split()[1] in ("ED", "DTW") else ""): l for l in out.stdout.splitlines() if l.strip()}
+    s = datagen.gen_series(n)
+    qoff = n // 3 + 17
+    q = s[qoff - 1: qoff - 1 + m].copy()
+    L, R = datagen.gen_intervals(n, m, n // 100, 64.0, must_cover=[qoff], seed=1)
+    c2 = kvmatch.Phase2Context(0)
+    c2.load_series(s)
+    rho = c2._lib.kvm_resolve_rho(0.05, m)
+    want = {"RSM-ED": kvmatch.QueryEngine(c2).verify((L, R), 1, q, eps),
+            "RSM-DTW": kvmatch.QueryEngineDtw(c2).verify((L, R), 1, q, eps, 0.05),
+            "cNSM-ED": kvmatch.NormQueryEngine(c2).verify((L, R), 1, q, eps, 1.5, 5.0),
+            "cNSM-DTW": kvmatch.NormQueryEngineDtw(c2).verify((L, R), 1, q, eps, 0.05, 1.5, 5.0)}
+    ue = kvmatch.UcrEdQueryExecutor(c2, n, m, q, eps, 1.5, 5.0, segment=50_000); ue.run()
+    ud = kvmatch.UcrDtwQueryExecutor(c2, n, m, q, eps, rho, 1.5, 5.0); ud.run()
+    want["UCR-ED"], want["UCR-DTW"] = ue.answers, ud.answers
+    for name, a in want.items():
+        line = next(l for l in out.stdout.splitlines() if l.startswith(name))
+        mo = re.search(r"Best: (-?\d+), distance: (\S+) .*#answers: (\d+)", line)
+        assert mo, line
+        assert int(mo.group(1)) == int(a.offsets[0]) and int(mo.group(3)) == len(a), (name, line)
+        assert abs(float(mo.group(2)) - a.distances[0]) <= 1e-5 * max(1.0, a.distances[0]), (name, line)
+    keys, first, last, gk, go = c2.index_rows(50, grouped=True)
+    idx = next(l for l in out.stdout.splitlines() if l.startswith("index w=50"))
+    nums = [int(x) for x in re.findall(r"\d+", idx)]
+    assert nums[1] == len(keys) and nums[2] == n - 49 and nums[3] == len(gk) and nums[4] == len(keys) and "keys descending" in idx
+    t2 = float(re.search(r"([0-9.]+) ms", next(l for l in out.stdout.splitlines() if l.startswith("T_2 model"))).group(1))
+    assert abs(t2 - kvmatch.phase2_time_estimate_ms(0, len(L), n // 100, m)) < 1e-3
+    c2.close()
+
+
 def test_randomised_sweep_all_variants(world):
     """Seeded random sweep over series shape, query length, thresholds and interval layouts: 240 verifications, each
     compared bit for bit with the oracle."""
