@@ -94,6 +94,7 @@ struct kvm_ctx {
     int64_t opt_early_abandon = 1, opt_lb_cascade = 1, opt_ed_kernel = 0, opt_timing = 0, opt_dp_kernel = 0;
     int num_cu = 256;
     int64_t last_kernel_ns = 0;
+    bool timing_pending = false;  // ev0/ev1 recorded, elapsed time not read yet (read lazily: no mid-pipeline sync)
     std::string err;
 };
 
