@@ -690,11 +690,11 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
     if ((rc = ensure(ctx, ctx->b_query, qbytes + lr_bytes + rbytes + plan_scratch + 64))) return rc;
     kvm_run *d_runs_w = (kvm_run *)((char *)ctx->b_query.p + qbytes + lr_bytes);
     if (rbytes) {
-        HIPCHK(ctx, hipMemcpyAsync((char *)ctx->b_query.p + qbytes, hp + qbytes, lr_bytes, hipMemcpyHostToDevice, stream));
         int tile_log2 = 0;
         while ((1 << tile_log2) < tile_max) tile_log2++;
-        HIPCHK(ctx, kvm_launch_plan_runs((const int32_t *)((const char *)ctx->b_query.p + qbytes),
-                                         (const int32_t *)((const char *)ctx->b_query.p + qbytes + lr_half), k, shift,
+        // (the first plan kernel reads the interval list straight from the pinned staging buffer and leaves the device copy)
+        HIPCHK(ctx, kvm_launch_plan_runs(pl.left, pl.right, (int32_t *)((char *)ctx->b_query.p + qbytes),
+                                         (int32_t *)((char *)ctx->b_query.p + qbytes + lr_half), k, shift,
                                          ctx->n - m + 1, hybrid, tile_log2, d_runs_w,
                                          (char *)ctx->b_query.p + qbytes + lr_bytes + ((rbytes + 31) & ~(size_t)31), stream));
     }
@@ -790,7 +790,7 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
     // the query block (the tile list -- 16 B per tile -- is expanded from the runs on the GPU, by the kernel that also
     // zeroes the counters; for cNSM-ED the exact-pass block is filled in and copied further down, in stream order, before
     // its only reader -- the exact pass -- is launched)
-    HIPCHK(ctx, hipMemcpyAsync(ctx->b_query.p, hp, qfirst, hipMemcpyHostToDevice, stream));
+    HIPCHK(ctx, kvm_launch_upload(ctx->b_query.p, hp, qfirst, stream));
     const kvm_run *d_runs = d_runs_w;
     if (rbytes) {
         if (hybrid)
@@ -887,8 +887,7 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
                     zqs[i] = q[order[i]];
                 }
             }
-            HIPCHK(ctx, hipMemcpyAsync((char *)ctx->b_query.p + qexact_off, hp + qexact_off, (size_t)m * 12,
-                                       hipMemcpyHostToDevice, stream));
+            HIPCHK(ctx, kvm_launch_upload((char *)ctx->b_query.p + qexact_off, hp + qexact_off, (size_t)m * 12, stream));
         }
         const double *q_exact = cnsm ? (const double *)((const char *)ctx->b_query.p + qexact_off) : qd.q;
         const int32_t *d_order =

@@ -37,13 +37,23 @@ __device__ __forceinline__ plan_sums plan_item_sums(const kvm_plan_item &it) {
     return plan_sums{it.c > 0 ? 1 : 0, (long long)it.tiles_a, (long long)it.tiles_b, (long long)it.c};
 }
 
-__global__ __launch_bounds__(PLAN_THREADS) void kvm_plan_totals_kernel(const int32_t *__restrict__ left, const int32_t *__restrict__ right,
+// `src_left` / `src_right` may be the pinned host staging buffer itself (zero-copy over PCIe: 8 B per interval, no copy
+// command and no copy-engine signal in front of the kernel); the kernel leaves a device copy in `left` / `right` for
+// kvm_plan_runs_kernel.
+__global__ __launch_bounds__(PLAN_THREADS) void kvm_plan_totals_kernel(const int32_t *__restrict__ src_left,
+                                                                      const int32_t *__restrict__ src_right,
+                                                                      int32_t *__restrict__ left, int32_t *__restrict__ right,
                                                                       int32_t k, int32_t shift, int64_t hi_max, int hybrid,
                                                                       int tile_log2, plan_sums *__restrict__ block_tot) {
     __shared__ plan_sums wave_tot[PLAN_THREADS / 64];
     const int64_t p = (int64_t)blockIdx.x * PLAN_THREADS + threadIdx.x;
     plan_sums mine{0, 0, 0, 0};
-    if (p < k) mine = plan_item_sums(kvm_plan_interval(left[p], right[p], shift, hi_max, hybrid != 0, tile_log2));
+    if (p < k) {
+        const int32_t l = src_left[p], r = src_right[p];
+        left[p] = l;
+        right[p] = r;
+        mine = plan_item_sums(kvm_plan_interval(l, r, shift, hi_max, hybrid != 0, tile_log2));
+    }
     const plan_sums t = plan_block_sum(mine, wave_tot);
     if (threadIdx.x == 0) block_tot[blockIdx.x] = t;
 }
@@ -118,13 +128,14 @@ __global__ __launch_bounds__(1024) void kvm_plan_scan_kernel(plan_sums *__restri
 }
 
 // `scratch`: 32 B per 256 intervals (block totals)
-hipError_t kvm_launch_plan_runs(const int32_t *left, const int32_t *right, int32_t k, int32_t shift, int64_t hi_max, bool hybrid,
-                                int tile_log2, kvm_run *runs, void *scratch, hipStream_t s) {
+hipError_t kvm_launch_plan_runs(const int32_t *src_left, const int32_t *src_right, int32_t *left, int32_t *right, int32_t k,
+                                int32_t shift, int64_t hi_max, bool hybrid, int tile_log2, kvm_run *runs, void *scratch,
+                                hipStream_t s) {
     if (k <= 0) return hipSuccess;
     const int64_t blocks = ((int64_t)k + PLAN_THREADS - 1) / PLAN_THREADS;
     plan_sums *bt = reinterpret_cast<plan_sums *>(scratch);
-    hipLaunchKernelGGL(kvm_plan_totals_kernel, dim3((unsigned)blocks), dim3(PLAN_THREADS), 0, s, left, right, k, shift, hi_max,
-                       hybrid ? 1 : 0, tile_log2, bt);
+    hipLaunchKernelGGL(kvm_plan_totals_kernel, dim3((unsigned)blocks), dim3(PLAN_THREADS), 0, s, src_left, src_right, left, right,
+                       k, shift, hi_max, hybrid ? 1 : 0, tile_log2, bt);
     const int scanned = blocks > PLAN_SCAN_ABOVE;
     if (scanned) hipLaunchKernelGGL(kvm_plan_scan_kernel, dim3(1), dim3(1024), 0, s, bt, blocks);
     hipLaunchKernelGGL(kvm_plan_runs_kernel, dim3((unsigned)blocks), dim3(PLAN_THREADS), 0, s, left, right, k, shift, hi_max,
@@ -237,6 +248,22 @@ hipError_t kvm_launch_readback(const unsigned long long *counters, const int32_t
                                void *host, hipStream_t s) {
     hipLaunchKernelGGL(kvm_readback_kernel, dim3(1), dim3(256), 0, s, counters, off, dist, spec,
                        (unsigned long long *)host);
+    return hipGetLastError();
+}
+
+// Small host -> device uploads without a copy command: the source is the pinned staging buffer, read over PCIe with
+// 8-byte loads (a copy command costs its own ~8 us plus ~10 us of copy-engine signalling before the next kernel starts).
+__global__ __launch_bounds__(256) void kvm_upload_kernel(unsigned long long *__restrict__ dst, const unsigned long long *__restrict__ src,
+                                                         int64_t n8) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+// (offsets inside the staging buffer are multiples of 8; a length that is not is rounded up into the block's padding)
+hipError_t kvm_launch_upload(void *dst, const void *src_pinned, size_t bytes, hipStream_t s) {
+    if (bytes == 0) return hipSuccess;
+    const int64_t n8 = (int64_t)((bytes + 7) / 8);
+    const unsigned blocks = (unsigned)std::min<int64_t>((n8 + 255) / 256, 512);
+    hipLaunchKernelGGL(kvm_upload_kernel, dim3(blocks), dim3(256), 0, s, (unsigned long long *)dst,
+                       (const unsigned long long *)src_pinned, n8);
     return hipGetLastError();
 }
 

@@ -149,8 +149,10 @@ static inline kvm_plan_item kvm_plan_interval(int64_t l, int64_t r, int64_t shif
     kvm_plan_tiles(it.c, hybrid, tile_log2, it.tiles_a, it.tiles_b);
     return it;
 }
-hipError_t kvm_launch_plan_runs(const int32_t *left, const int32_t *right, int32_t k, int32_t shift, int64_t hi_max, bool hybrid,
-                                int tile_log2, kvm_run *runs, void *scratch, hipStream_t s);
+hipError_t kvm_launch_plan_runs(const int32_t *src_left, const int32_t *src_right, int32_t *left, int32_t *right, int32_t k,
+                                int32_t shift, int64_t hi_max, bool hybrid, int tile_log2, kvm_run *runs, void *scratch,
+                                hipStream_t s);
+hipError_t kvm_launch_upload(void *dst, const void *src_pinned, size_t bytes, hipStream_t s);
 hipError_t kvm_launch_expand_tiles(const kvm_run *runs, int64_t n_runs, int32_t tile_max, kvm_tile *tiles,
                                    unsigned long long *counters, int32_t *run_maxk, hipStream_t s);
 // hybrid ED tiling: class A = 64-candidate tiles (full tiles and remainders > 32), class B = remainders <= 32
