@@ -726,20 +726,33 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
     std::vector<double> qcen;
     std::vector<double2> qpref, qpref8;
     if (!dtw) {
-        double sum = 0;
-        for (int i = 0; i < m; i++) sum += q[i];
-        qd.q_mean = sum / m;
+        // (pruner-side quantities, guard-banded: the summation order is free, so four interleaved partial sums keep the
+        // adders busy -- the plain sequential loops cost ~20 us of the host's critical path at m = 8192)
+        double s4[4] = {0, 0, 0, 0};
+        int i4 = 0;
+        for (; i4 + 4 <= m; i4 += 4)
+            for (int u = 0; u < 4; u++) s4[u] += q[i4 + u];
+        for (; i4 < m; i4++) s4[0] += q[i4];
+        qd.q_mean = ((s4[0] + s4[1]) + (s4[2] + s4[3])) / m;
         qcen.resize(m);
         qpref.resize((size_t)nchunks4 + 1);
         qpref8.resize((size_t)nchunks8 + 1);
-        double p1 = 0, p2 = 0;
-        for (int i = 0; i < m; i++) {
-            if (i % ED4_JC == 0) qpref[(size_t)(i / ED4_JC)] = make_double2(p1, p2);
-            if (i % ED8_JC == 0) qpref8[(size_t)(i / ED8_JC)] = make_double2(p1, p2);
-            qcen[i] = q[i] - qd.q_mean;
-            p1 += qcen[i];
-            p2 += qcen[i] * qcen[i];
+        static_assert(ED4_JC % 4 == 0 && ED8_JC % 4 == 0, "chunk boundaries fall between groups of four");
+        double a1[4] = {0, 0, 0, 0}, a2[4] = {0, 0, 0, 0};
+        const double qm = qd.q_mean;
+        int i = 0;
+        for (; i < m; i += 4) {
+            if (i % ED4_JC == 0) qpref[(size_t)(i / ED4_JC)] = make_double2((a1[0] + a1[1]) + (a1[2] + a1[3]), (a2[0] + a2[1]) + (a2[2] + a2[3]));
+            if (i % ED8_JC == 0) qpref8[(size_t)(i / ED8_JC)] = make_double2((a1[0] + a1[1]) + (a1[2] + a1[3]), (a2[0] + a2[1]) + (a2[2] + a2[3]));
+            const int lim = std::min(4, m - i);
+            for (int u = 0; u < lim; u++) {
+                const double c = q[i + u] - qm;
+                qcen[i + u] = c;
+                a1[u] += c;
+                a2[u] += c * c;
+            }
         }
+        const double p1 = (a1[0] + a1[1]) + (a1[2] + a1[3]), p2 = (a2[0] + a2[1]) + (a2[2] + a2[3]);
         qpref[(size_t)nchunks4] = make_double2(p1, p2);
         qpref8[(size_t)nchunks8] = make_double2(p1, p2);
     }

@@ -558,12 +558,22 @@ hipError_t kvm_launch_ed_dot(const double *series, const double2 *prefix, int64_
         if ((double)(unitsA + unitsB) * 4.0 <= slots) fA = fB = 4;
         else if ((double)(unitsA + unitsB) * 2.0 <= slots) fA = fB = 2;
     } else if ((double)(unitsA + unitsB) < 16.0 * slots) {
-        double best = 1e300;
-        for (int a = 1; a <= 4; a *= 2)
-            for (int b = 1; b <= 4; b *= 2) {
-                const double t = edd_makespan((double)unitsA, (double)unitsB, a, b, slots);
-                if (t < best - 1e-9) best = t, fA = a, fB = b;
-            }
+        // (the model costs a few microseconds of the host's critical path: remember the last shape -- a query stream
+        // over one index tends to repeat it)
+        struct memo_t { int64_t a, b; int cu, fa, fb; };
+        static thread_local memo_t memo = {-1, -1, 0, 1, 1};
+        if (memo.a == unitsA && memo.b == unitsB && memo.cu == num_cu) {
+            fA = memo.fa;
+            fB = memo.fb;
+        } else {
+            double best = 1e300;
+            for (int a = 1; a <= 4; a *= 2)
+                for (int b = 1; b <= 4; b *= 2) {
+                    const double t = edd_makespan((double)unitsA, (double)unitsB, a, b, slots);
+                    if (t < best - 1e-9) best = t, fA = a, fB = b;
+                }
+            memo = {unitsA, unitsB, num_cu, fA, fB};
+        }
     }
     if (const char *e = getenv("KVM_ED_SPLIT")) {  // experiments: "fA,fB"
         int a = 0, b = 0;
