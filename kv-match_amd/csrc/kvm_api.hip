@@ -421,10 +421,10 @@ extern "C" void kvm_index_rows_free(kvm_index_rows *r) {
 // Constants of profiles/r01_phase2_cost_model.json (least squares over 18-36 (intervals, offsets, m) points per variant,
 // early abandon on, one MI355X): {C [ms], A [ms per interval], B [ms per 1e5 offset-points]}
 extern "C" double kvm_phase2_time_estimate_ms(int32_t variant, int64_t disjoint_windows, int64_t candidate_offsets, int32_t length) {
-    static const double K[4][3] = {{0.1232, 4.160e-6, 5.246e-7},   // rsm_ed
-                                   {0.1701, 3.537e-6, 2.300e-6},   // cnsm_ed
-                                   {0.5069, 3.906e-6, 1.038e-5},   // rsm_dtw
-                                   {0.5462, 5.025e-6, 6.785e-5}};  // cnsm_dtw
+    static const double K[4][3] = {{0.1281, 1.609e-6, 4.784e-7},   // rsm_ed
+                                   {0.1618, 1.846e-6, 2.270e-6},   // cnsm_ed
+                                   {0.5110, 1.538e-6, 1.007e-5},   // rsm_dtw
+                                   {0.5485, 3.273e-6, 6.738e-5}};  // cnsm_dtw
     if (variant < 0 || variant > 3) return -1.0;
     return K[variant][0] + K[variant][1] * (double)disjoint_windows + K[variant][2] * ((double)candidate_offsets / 1e5) * (double)length;
 }
