@@ -554,7 +554,7 @@ int64_t kvo_query_cnsm_ed(const double *series, int n, const double *queryData, 
     double stdQ = sqrt(ex2 / queryLength - meanQ * meanQ);
 
     /* z-normalise + reorder (:438-452) */
-    double *zQ = (double *)malloc((size_t)queryLength * sizeof(double));
+    double *zQ = (double *)calloc((size_t)queryLength, sizeof(double));
     for (int i = 0; i < queryLength; i++) zQ[i] = (queryData[i] - meanQ) / stdQ;
     int *order = (int *)malloc((size_t)queryLength * sizeof(int));
     kvo_index *Q_tmp = (kvo_index *)malloc((size_t)queryLength * sizeof(kvo_index));
@@ -673,7 +673,7 @@ int64_t kvo_query_rsm_dtw(const double *series, int n, const double *queryData, 
     kvo_answers answers = {out_off, out_dist, cap, 0, 0};
     int64_t cntCandidate = 0, windows = 0, pKim = 0, pK1 = 0, pK2 = 0, cells = 0;
 
-    double *Q = (double *)malloc((size_t)length * sizeof(double));
+    double *Q = (double *)calloc((size_t)length, sizeof(double));
     for (int i = 0; i < length; i++) Q[i] = queryData[i];
     double *u = (double *)malloc((size_t)length * sizeof(double));
     double *l = (double *)malloc((size_t)length * sizeof(double));
@@ -792,7 +792,7 @@ int64_t kvo_query_cnsm_dtw(const double *series, int n, const double *queryData,
     double meanQ = ex / queryLength;
     double stdQ = sqrt(ex2 / queryLength - meanQ * meanQ);
 
-    double *zQ = (double *)malloc((size_t)queryLength * sizeof(double));
+    double *zQ = (double *)calloc((size_t)queryLength, sizeof(double));
     for (int i = 0; i < queryLength; i++) zQ[i] = (queryData[i] - meanQ) / stdQ;
     double *u = (double *)malloc((size_t)queryLength * sizeof(double));
     double *l = (double *)malloc((size_t)queryLength * sizeof(double));
