@@ -649,10 +649,12 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
     auto tp_ = std::chrono::steady_clock::now();
     // 32-candidate tiles for the LDS-tiled kernels (ED pruners, fused DTW lower-bound stage), 64 otherwise
     // (DTW cascade: 64-candidate tiles first, trimmed and cut to <= 32 on the device by kvm_retile_dtw_kernel)
-    const int32_t tile_max = (!dtw && ed_kernel == 4) ? 16 : (cnsm && !dtw && ed_kernel == 3) ? KVM_TILE_MAX
+    // cNSM-ED with the dot pruner: uniform 64-candidate tiles first, trimmed and classified on the device by the filter;
+    // RSM-ED with early abandoning: the same, trimmed by the head of the window (kvm_retile_rsm_kernel)
+    const bool retile_rsm = !cnsm && !dtw && ed_kernel == 3 && ctx->opt_early_abandon;
+    const bool retile = (cnsm && !dtw && ed_kernel == 3) || retile_rsm;
+    const int32_t tile_max = (!dtw && ed_kernel == 4) ? 16 : retile ? KVM_TILE_MAX
                              : (!dtw && ed_kernel >= 2) ? KVM_TILE_TILED : KVM_TILE_MAX;
-    // cNSM-ED with the dot pruner: uniform 64-candidate tiles first, trimmed and classified on the device by the filter
-    const bool retile = cnsm && !dtw && ed_kernel == 3;
     const bool hybrid = !dtw && ed_kernel == 3 && !retile;
     // query block: q | (qu | ql for DTW) | pad || (qc | pad | q_pref | q_pref8 | qT for ED) || (zQ sorted | order: cNSM-ED
     // exact pass); the runs follow it in the pinned staging buffer, where build_plan writes them directly
@@ -842,8 +844,12 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
         kvm_surv *surv = (kvm_surv *)ctx->b_cands.p;
         if (retile) {
             kvm_tile *tA = (kvm_tile *)ctx->b_tiles.p + pl.n_tiles, *tB = tA + pl.n_tiles;
-            HIPCHK(ctx, kvm_launch_retile_cnsm(ctx->d_series, ctx->d_prefix, qd, d_tiles, pl.n_tiles, tA, tB,
-                                               counters + KVM_CNT_TILES_A, stream));
+            if (retile_rsm)
+                HIPCHK(ctx, kvm_launch_retile_rsm(ctx->d_series, qd, d_tiles, pl.n_tiles, tA, tB, counters + KVM_CNT_TILES_A,
+                                                  stream));
+            else
+                HIPCHK(ctx, kvm_launch_retile_cnsm(ctx->d_series, ctx->d_prefix, qd, d_tiles, pl.n_tiles, tA, tB,
+                                                   counters + KVM_CNT_TILES_A, stream));
             HIPCHK(ctx, kvm_launch_ed_dot(ctx->d_series, ctx->d_prefix, ctx->n, qd, tA, pl.n_tiles, tB, pl.n_tiles, surv,
                                           pl.windows, counters, ctx->num_cu, counters + KVM_CNT_TILES_A, out.d_off, out.d_dist, out.cap,
                                           stream));

@@ -154,6 +154,23 @@ __device__ __forceinline__ void edd_body(const edd_args &A, const kvm_tile *__re
         st.e2J = E2;
         return st;
     };
+    // RSM only: `stats` of the range [jlo, J) of candidate a from loads issued earlier (kvm_issue_window_sums)
+    auto stats_from = [&](const kvm_raw_sums &raw, int a, int jlo, int J) -> edd_cstat {
+        edd_cstat st;
+        double s1, s2, cb, pm;
+        const int64_t w0 = (int64_t)mine.start - 1 + c0 + a;
+        const int len0 = J - jlo;
+        kvm_finish_window_sums(raw, prefix, series, w0 + jlo, len0, s1, s2, cb, &pm);
+        const double dc = cb - c_row;
+        const kvm_sum_err e = kvm_prefix_err(pm);
+        st.s1J = s1 + len0 * dc;
+        st.s2J = s2 + (2.0 * dc) * s1 + len0 * (dc * dc);
+        st.e1J = e.e1 + 1e-15 * (fabs(s1) + len0 * fabs(dc));
+        st.e2J = e.e2 + 2.0 * fabs(dc) * e.e1 + 1e-15 * (fabs(s2) + 2.0 * fabs(dc * s1) + len0 * (dc * dc));
+        st.mc = 0.0; st.sg = 1.0;
+        st.gd.g = 0.0; st.gd.mean_err = 0.0; st.gd.std_hi = 0.0;
+        return st;
+    };
     // correlation-form distance over a range of J points (st, acc and the query sums qp all taken over that range) and
     // its guard band
     auto dist_form = [&](const edd_cstat &st, double acc, int J, const double2 qp, double &slack) -> double {
@@ -300,22 +317,47 @@ __device__ __forceinline__ void edd_body(const edd_args &A, const kvm_tile *__re
         if (more) {
             // early abandon (reference behaviour): the distance is a sum of non-negative terms, so a candidate whose
             // terms over ANY range of points already exceed the pruning threshold is out.  Each part tests the range
-            // it has accumulated so far: after its first chunk (random candidates die here) and every 8 chunks.
-            if (ABANDON && (ch == ch_lo || ((ch - ch_lo) & 7) == 7)) {
+            // it has accumulated so far: after its chunks 1, 2 and 4 (random candidates die here; a wave goes on while ANY of
+            // its 512 candidates lives, so the stragglers are worth catching early) and then every 8 chunks.
+            if (ABANDON && ((ch - ch_lo) < 4 ? (ch - ch_lo) != 2 : ((ch - ch_lo) & 7) == 7)) {
                 const int jlo = ch_lo * JC, J = j0 + JC;
                 const double2 qa = q_pref[ch + 1], qb = q_pref[ch_lo];
                 const double2 qp = make_double2(qa.x - qb.x, qa.y - qb.y);
                 // (a rolled loop: this runs once per 8 chunks, and unrolling its eight prefix-sum evaluations around
                 // the hot loop's live registers made the compiler spill)
+                if constexpr (!NORM) {
+                    // RSM: the prefix-sum loads of candidate a + 1 are issued before candidate a is finished (the rolled
+                    // loop otherwise pays one memory latency per candidate: with abandoning on, this check is most of
+                    // what a wave does).  Unconditional, from a valid address whether or not the candidate exists.
+                    auto issue = [&](int a) {
+                        const int64_t w0 = (int64_t)mine.start - 1 + ((c0 + a < mine.count) ? c0 + a : 0);
+                        return kvm_issue_window_sums(prefix, series, w0 + jlo, J - jlo);
+                    };
+                    kvm_raw_sums nxt = issue(0);
 #pragma nounroll
-                for (int a = 0; a < CI; a++) {
-                    double av = acc[0];
+                    for (int a = 0; a < CI; a++) {
+                        const kvm_raw_sums cur = nxt;
+                        nxt = issue(a + 1 < CI ? a + 1 : a);
+                        double av = acc[0];
 #pragma unroll
-                    for (int k = 1; k < CI; k++) av = (a == k) ? acc[k] : av;
-                    if (((vm >> a) & 1u) && !((fm >> a) & 1u)) {
-                        double slack;
-                        const edd_cstat st = stats(a, jlo, J);
-                        if (dist_form(st, av, J - jlo, qp, slack) > eps2 + slack) vm &= ~(1u << a);
+                        for (int k = 1; k < CI; k++) av = (a == k) ? acc[k] : av;
+                        if (((vm >> a) & 1u) && !((fm >> a) & 1u)) {
+                            double slack;
+                            const edd_cstat st = stats_from(cur, a, jlo, J);
+                            if (dist_form(st, av, J - jlo, qp, slack) > eps2 + slack) vm &= ~(1u << a);
+                        }
+                    }
+                } else {
+#pragma nounroll
+                    for (int a = 0; a < CI; a++) {
+                        double av = acc[0];
+#pragma unroll
+                        for (int k = 1; k < CI; k++) av = (a == k) ? acc[k] : av;
+                        if (((vm >> a) & 1u) && !((fm >> a) & 1u)) {
+                            double slack;
+                            const edd_cstat st = stats(a, jlo, J);
+                            if (dist_form(st, av, J - jlo, qp, slack) > eps2 + slack) vm &= ~(1u << a);
+                        }
                     }
                 }
                 if (!__any(vm != 0)) {
@@ -456,6 +498,105 @@ __global__ __launch_bounds__(256) void kvm_retile_cnsm_kernel(const double *__re
     __syncthreads();
     if ((int)threadIdx.x < nA) tilesA[baseA + threadIdx.x] = outA[threadIdx.x];
     if ((int)threadIdx.x < nB) tilesB[baseB + threadIdx.x] = outB[threadIdx.x];
+}
+
+// RSM with the reference's early abandoning: the same trimming with the first EDR_HEAD points of the window as the
+// predicate -- the sum of (x - q)^2 over any part of the window is a lower bound of the distance, and a candidate of a
+// random list is dead after a hundred points.  Without it the pruner abandons per WAVE (512 candidates: one straggler
+// keeps all of them computing to the next check) and a call cannot be shorter than the one unit that holds an answer
+// (0.2 ms at m = 8192); with it the dead tiles never reach the pruner and the few that remain are split four ways.
+// One lane per candidate, coalesced window loads, the query head by scalar loads.  `dead only if > limit`: NaN keeps.
+#define EDR_HEAD 128
+#define EDR_PER_BLOCK 16  // tiles per workgroup (4 per wave): almost every workgroup ends without a survivor, i.e. without
+                          // atomics, so small workgroups cost nothing and put six times as many waves on a CU
+__global__ __launch_bounds__(256) void kvm_retile_rsm_kernel(const double *__restrict__ series, kvm_query_dev qd,
+                                                             const kvm_tile *__restrict__ tiles, int64_t n_tiles,
+                                                             kvm_tile *__restrict__ tilesA, kvm_tile *__restrict__ tilesB,
+                                                             unsigned long long *__restrict__ d_counts) {
+    __shared__ kvm_tile outA[EDR_PER_BLOCK], outB[EDR_PER_BLOCK];
+    __shared__ int nA, nB;
+    __shared__ unsigned long long baseA, baseB;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) nA = nB = 0;
+    __syncthreads();
+    const int head = qd.m < EDR_HEAD ? qd.m : EDR_HEAD;
+    const double lim = qd.eps2 * (1.0 + 1e-9);  // (fused, other summation order than the reference's loop: < 1e-13 relative)
+    // The 64 + EDR_HEAD - 1 points a tile needs are staged once per tile in wave-private LDS (three coalesced loads per
+    // lane, the next tile's in flight during the arithmetic); a lane then walks its own window there.  Reading the
+    // window from global memory lane by lane cost one load latency per point: 167 us for 24 626 tiles; staged: ~15.
+    __shared__ double xs[4][64 + EDR_HEAD];
+    const double *__restrict__ qs = qd.q;  // uniform addresses: scalar loads, SGPR operands (no LDS traffic for the query)
+    double *xw = xs[wave];
+    const int64_t t0 = (int64_t)blockIdx.x * EDR_PER_BLOCK + wave * (EDR_PER_BLOCK / 4);
+    auto fetch = [&](int64_t t, kvm_tile &tl, double &v0, double &v1, double &v2) {
+        tl = tiles[t < n_tiles ? t : n_tiles - 1];
+        const double *__restrict__ x = series + ((int64_t)tl.start - 1 + lane);  // (unguarded: the series is padded)
+        v0 = x[0];
+        v1 = x[64];
+        v2 = x[128];
+    };
+    kvm_tile tl_n;
+    double n0, n1, n2;
+    fetch(t0, tl_n, n0, n1, n2);
+    for (int i = 0; i < EDR_PER_BLOCK / 4; i++) {
+        const int64_t t = t0 + i;
+        if (t >= n_tiles) break;  // wave-uniform
+        const kvm_tile tl = tl_n;
+        xw[lane] = n0;
+        xw[64 + lane] = n1;
+        xw[128 + lane] = n2;
+        if (i + 1 < EDR_PER_BLOCK / 4) fetch(t + 1, tl_n, n0, n1, n2);
+        // blocks of 16 points: all their LDS reads and scalar loads are issued before the first use (the rolled loop
+        // waited for one LDS read and one scalar load per two points)
+        double a0 = 0.0, a1 = 0.0;
+        int j = 0;
+        for (; j + 16 <= head; j += 16) {
+            double xv[16], qv[16];
+#pragma unroll
+            for (int u = 0; u < 16; u++) {
+                xv[u] = xw[lane + j + u];
+                qv[u] = qs[j + u];
+            }
+#pragma unroll
+            for (int u = 0; u < 16; u += 2) {
+                const double d0 = xv[u] - qv[u], d1 = xv[u + 1] - qv[u + 1];
+                a0 = __builtin_fma(d0, d0, a0);
+                a1 = __builtin_fma(d1, d1, a1);
+            }
+        }
+        for (; j < head; j++) {
+            const double d0 = xw[lane + j] - qs[j];
+            a0 = __builtin_fma(d0, d0, a0);
+        }
+        const bool ok = lane < tl.count && !(a0 + a1 > lim);
+        const unsigned long long mask = __ballot(ok);
+        if (mask != 0 && lane == 0) {
+            const int first = __ffsll((long long)mask) - 1, last = 63 - __clzll((long long)mask);
+            kvm_tile out;
+            out.start = tl.start + first;
+            out.count = last - first + 1;
+            out.run_start = tl.run_start;
+            out.pad = 0;
+            if (out.count > 32) outA[atomicAdd(&nA, 1)] = out;
+            else outB[atomicAdd(&nB, 1)] = out;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        baseA = nA ? atomicAdd(&d_counts[0], (unsigned long long)nA) : 0;
+        baseB = nB ? atomicAdd(&d_counts[1], (unsigned long long)nB) : 0;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < nA) tilesA[baseA + threadIdx.x] = outA[threadIdx.x];
+    if ((int)threadIdx.x < nB) tilesB[baseB + threadIdx.x] = outB[threadIdx.x];
+}
+
+hipError_t kvm_launch_retile_rsm(const double *series, const kvm_query_dev &qd, const kvm_tile *tiles, int64_t n_tiles,
+                                 kvm_tile *tilesA, kvm_tile *tilesB, unsigned long long *d_counts, hipStream_t s) {
+    if (n_tiles <= 0) return hipSuccess;
+    hipLaunchKernelGGL(kvm_retile_rsm_kernel, dim3((unsigned)((n_tiles + EDR_PER_BLOCK - 1) / EDR_PER_BLOCK)), dim3(256),
+                       0, s, series, qd, tiles, n_tiles, tilesA, tilesB, d_counts);
+    return hipGetLastError();
 }
 
 hipError_t kvm_launch_retile_cnsm(const double *series, const double2 *prefix, const kvm_query_dev &qd, const kvm_tile *tiles,

@@ -209,6 +209,8 @@ hipError_t kvm_launch_ed_dot(const double *series, const double2 *prefix, int64_
                              int32_t *out_off, double *out_dist, int64_t out_cap, hipStream_t s);
 // cNSM: 64-candidate tiles -> trimmed class-A / class-B tile lists of the candidates passing the guarded (alpha, beta)
 // filter; the list lengths go to d_counts[0..1] (kvm_launch_ed_dot then takes nA, nB as upper bounds)
+hipError_t kvm_launch_retile_rsm(const double *series, const kvm_query_dev &qd, const kvm_tile *tiles, int64_t n_tiles,
+                                 kvm_tile *tilesA, kvm_tile *tilesB, unsigned long long *d_counts, hipStream_t s);
 hipError_t kvm_launch_retile_cnsm(const double *series, const double2 *prefix, const kvm_query_dev &qd, const kvm_tile *tiles,
                                   int64_t n_tiles, kvm_tile *tilesA, kvm_tile *tilesB, unsigned long long *d_counts,
                                   hipStream_t s);
