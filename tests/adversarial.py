@@ -10,6 +10,8 @@ One class of divergence is expected and counted separately (SURVEY 8a, fact iii)
 eps although its DTW distance may be larger.  On continuous data that tie has measure zero; on integer / half-integer
 data with an integer eps^2 it is common.  This library returns the candidates whose banded DTW distance is <= eps^2;
 `tie_quirk` below recognises the reference's extra answers (all at distance exactly eps, everything else identical)."""
+import time
+
 import numpy as np
 
 KINDS = ("ints", "steps", "offset", "range", "halfint", "nan", "tiny", "huge")
@@ -54,6 +56,17 @@ def run(kvmatch, datagen, oracle, ctx, rounds, seed, kinds=KINDS, n_range=(30_00
     """Returns (verifications, mismatches, tie_quirk_divergences)."""
     rng = np.random.default_rng(seed)
     total = bad = quirk = 0
+    t_gpu = t_cpu = 0.0
+
+    def gpu(fn):
+        nonlocal t_gpu
+        t = time.perf_counter(); r = fn(); t_gpu += time.perf_counter() - t
+        return r
+
+    def cpu(fn):
+        nonlocal t_cpu
+        t = time.perf_counter(); r = fn(); t_cpu += time.perf_counter() - t
+        return r
 
     def same(a, o, tag, eps, dtw):
         nonlocal total, bad, quirk
@@ -102,18 +115,20 @@ def run(kvmatch, datagen, oracle, ctx, rounds, seed, kinds=KINDS, n_range=(30_00
                         for ab in (1, 0):
                             ctx.set_option(kvmatch.OPT_EARLY_ABANDON, ab)
                             if alpha == 1.0 and beta == 0.0:
-                                same(kvmatch.QueryEngine(ctx).verify((L, R), 1, q, eps), oracle.rsm_ed(s, q, L, R, 0, eps),
+                                same(gpu(lambda: kvmatch.QueryEngine(ctx).verify((L, R), 1, q, eps)), cpu(lambda: oracle.rsm_ed(s, q, L, R, 0, eps)),
                                      "rsm_ed " + tag + f" ab={ab}", eps, False)
-                            same(kvmatch.NormQueryEngine(ctx).verify((L, R), 1, q, eps, alpha, beta),
-                                 oracle.cnsm_ed(s, q, L, R, 0, eps, alpha, beta), "cnsm_ed " + tag + f" ab={ab}", eps, False)
+                            same(gpu(lambda: kvmatch.NormQueryEngine(ctx).verify((L, R), 1, q, eps, alpha, beta)),
+                                 cpu(lambda: oracle.cnsm_ed(s, q, L, R, 0, eps, alpha, beta)), "cnsm_ed " + tag + f" ab={ab}", eps, False)
                         if name != "full" or n < 60_000:
                             ctx.set_option(kvmatch.OPT_EARLY_ABANDON, 1)
                             if alpha == 1.0 and beta == 0.0:
                                 r2 = max(rho, 2)     # (the engine reads rho <= 1 as a fraction of m)
-                                same(kvmatch.QueryEngineDtw(ctx).verify((L, R), 1, q, eps, r2),
-                                     oracle.rsm_dtw(s, q, L, R, 0, eps, r2), "rsm_dtw " + tag, eps, True)
-                            same(kvmatch.NormQueryEngineDtw(ctx).verify((L, R), 1, q, eps, rho, alpha, beta, resolved=True),
-                                 oracle.cnsm_dtw(s, q, L, R, 0, eps, rho, alpha, beta), "cnsm_dtw " + tag, eps, True)
+                                same(gpu(lambda: kvmatch.QueryEngineDtw(ctx).verify((L, R), 1, q, eps, r2)),
+                                     cpu(lambda: oracle.rsm_dtw(s, q, L, R, 0, eps, r2)), "rsm_dtw " + tag, eps, True)
+                            same(gpu(lambda: kvmatch.NormQueryEngineDtw(ctx).verify((L, R), 1, q, eps, rho, alpha, beta, resolved=True)),
+                                 cpu(lambda: oracle.cnsm_dtw(s, q, L, R, 0, eps, rho, alpha, beta)), "cnsm_dtw " + tag, eps, True)
+            if log:
+                log(f"  {kind} rd={rd} n={n} m={m}: library {t_gpu:.1f} s, oracle {t_cpu:.1f} s so far")
         if log:
             log(f"round {rd}: verifications {total} mismatches {bad} tie-quirk divergences {quirk}")
     ctx.set_option(kvmatch.OPT_EARLY_ABANDON, 1)
