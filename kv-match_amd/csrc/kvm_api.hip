@@ -421,10 +421,10 @@ extern "C" void kvm_index_rows_free(kvm_index_rows *r) {
 // Constants of profiles/r01_phase2_cost_model.json (least squares over 18-36 (intervals, offsets, m) points per variant,
 // early abandon on, one MI355X): {C [ms], A [ms per interval], B [ms per 1e5 offset-points]}
 extern "C" double kvm_phase2_time_estimate_ms(int32_t variant, int64_t disjoint_windows, int64_t candidate_offsets, int32_t length) {
-    static const double K[4][3] = {{0.1281, 1.609e-6, 4.784e-7},   // rsm_ed
-                                   {0.1618, 1.846e-6, 2.270e-6},   // cnsm_ed
-                                   {0.5110, 1.538e-6, 1.007e-5},   // rsm_dtw
-                                   {0.5485, 3.273e-6, 6.738e-5}};  // cnsm_dtw
+    static const double K[4][3] = {{0.1285, 1.914e-6, 2.590e-7},   // rsm_ed
+                                   {0.1762, 1.832e-6, 2.377e-6},   // cnsm_ed
+                                   {0.5072, 1.571e-6, 1.057e-5},   // rsm_dtw
+                                   {0.5456, 3.443e-6, 6.786e-5}};  // cnsm_dtw
     if (variant < 0 || variant > 3) return -1.0;
     return K[variant][0] + K[variant][1] * (double)disjoint_windows + K[variant][2] * ((double)candidate_offsets / 1e5) * (double)length;
 }
