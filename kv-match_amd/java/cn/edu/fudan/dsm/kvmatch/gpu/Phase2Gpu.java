@@ -1,0 +1,50 @@
+/*
+ * Phase2Gpu.java -- the Java side of the drop-in (INTEGRATION.md section 2): thin natives over libkvmatch_jni.so
+ * (kv-match_amd/jni/kvmatch_jni.c), which wraps the C ABI of include/kvmatch.h.  Shipped as source: this repository's build
+ * image has no JDK; a maintainer drops the file into src/main/java of KV-match and compiles it with the project.
+ */
+package cn.edu.fudan.dsm.kvmatch.gpu;
+
+import cn.edu.fudan.dsm.kvmatch.common.Pair;
+import java.io.IOException;
+import java.util.ArrayList;
+import java.util.List;
+
+/** One instance per engine (engines are not re-entrant, neither is a kvm_ctx). */
+public final class Phase2Gpu implements AutoCloseable {
+    static { System.loadLibrary("kvmatch_jni"); }
+    private long ctx;                                   // kvm_ctx*
+
+    public Phase2Gpu(int device, String dataFile, int n) throws IOException {
+        ctx = open(device);
+        loadSeriesFile(ctx, dataFile, n);               // files/data-{N}, staged once (kvm_load_series_file)
+    }
+    // returns offsets[] / distances[] already sorted by distance; stats = {cntCandidate}
+    public static final class Result { public int[] offsets; public double[] distances; public long cntCandidate; }
+
+    public native Result rsmEd  (long ctx, double[] q, int[] left, int[] right, int shift, double eps);
+    public native Result cnsmEd (long ctx, double[] q, int[] left, int[] right, int shift, double eps, double alpha, double beta);
+    public native Result rsmDtw (long ctx, double[] q, int[] left, int[] right, int shift, double eps, int rho);
+    public native Result cnsmDtw(long ctx, double[] q, int[] left, int[] right, int shift, double eps, int rho, double alpha, double beta);
+    // optional: TimeSeriesOperator.readTimeSeries from HBM; index build step 1 (see the end of section 3)
+    public static native double[] readTimeSeries(long ctx, int left, int length);
+    public static native double phase2TimeEstimateMs(int variant, long disjointWindows, long candidateOffsets, int length);
+    public static native long indexRowsBuild(long ctx, int w);
+    public static native long indexRowsBuildGrouped(long ctx, int w);
+    public static native long indexRowsGroups(long rows);
+    public static native void indexRowsGetGroups(long rows, double[] keys, int[] offsets);
+    public static native long indexRowsCount(long rows);
+    public static native void indexRowsGet(long rows, long from, double[] keys, int[] first, int[] last);
+    public static native void indexRowsFree(long rows);
+    private static native long open(int device) throws IOException;
+    private static native void loadSeriesFile(long ctx, String path, long n) throws IOException;
+    private static native void close(long ctx);
+    public long handle() { return ctx; }
+    @Override public void close() { if (ctx != 0) { close(ctx); ctx = 0; } }
+
+    public static List<Pair<Integer, Double>> toAnswers(Result r) {
+        List<Pair<Integer, Double>> a = new ArrayList<>(r.offsets.length);
+        for (int i = 0; i < r.offsets.length; i++) a.add(new Pair<>(r.offsets[i], r.distances[i]));
+        return a;
+    }
+}

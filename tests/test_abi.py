@@ -75,3 +75,19 @@ def test_phase2_time_estimate_is_the_reference_formula(built):
         assert 1e-3 < a < 1e-2 and 0 < b < 0.1                       # Java: 4 071 ms resp. 270 ms for RSM-ED
         assert abs(f(v, 2000, 200_000, 1000) - (c + 2 * a + 2 * b)) < 1e-12
     assert f(7, 1, 1, 1) < 0
+
+
+def test_java_adapter_natives_match_the_jni_shim():
+    """Every `native` method of the shipped Java adapter (kv-match_amd/java/.../Phase2Gpu.java) has its JNI export in
+    kv-match_amd/jni/kvmatch_jni.c and vice versa (neither can be compiled in this image: no JDK)."""
+    import os, re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    java = open(os.path.join(root, "kv-match_amd", "java", "cn", "edu", "fudan", "dsm", "kvmatch", "gpu", "Phase2Gpu.java")).read()
+    jni = open(os.path.join(root, "kv-match_amd", "jni", "kvmatch_jni.c")).read()
+    natives = set(re.findall(r"\bnative\s+[\w\[\]<>.]+\s+(\w+)\s*\(", java))
+    exports = set(re.findall(r"Java_cn_edu_fudan_dsm_kvmatch_gpu_Phase2Gpu_(\w+)\s*\(", jni))
+    assert natives == exports and len(natives) >= 16, (natives ^ exports)
+    # and every C-ABI function the shim calls is declared in the header
+    header = open(os.path.join(root, "include", "kvmatch.h")).read()
+    for fn in set(re.findall(r"\b(kvm_\w+)\s*\(", jni)):
+        assert re.search(r"\b" + fn + r"\s*\(", header), fn
