@@ -91,3 +91,12 @@ def test_java_adapter_natives_match_the_jni_shim():
     header = open(os.path.join(root, "include", "kvmatch.h")).read()
     for fn in set(re.findall(r"\b(kvm_\w+)\s*\(", jni)):
         assert re.search(r"\b" + fn + r"\s*\(", header), fn
+
+
+def test_cpp_host_mirror_compiles():
+    """kv-match_amd/host/kvmatch_engines.hpp (the C++ mirror of the reference's engine classes) against include/kvmatch.h."""
+    import os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run(["g++", "-std=c++17", "-Wall", "-Werror", "-fsyntax-only", "-I", os.path.join(root, "include"),
+                        os.path.join(root, "kv-match_amd", "host", "kvm_cli.cpp")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
