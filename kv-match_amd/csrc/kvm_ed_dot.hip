@@ -317,9 +317,11 @@ __device__ __forceinline__ void edd_body(const edd_args &A, const kvm_tile *__re
         if (more) {
             // early abandon (reference behaviour): the distance is a sum of non-negative terms, so a candidate whose
             // terms over ANY range of points already exceed the pruning threshold is out.  Each part tests the range
-            // it has accumulated so far: after its chunks 1, 2 and 4 (random candidates die here; a wave goes on while ANY of
-            // its 512 candidates lives, so the stragglers are worth catching early) and then every 8 chunks.
-            if (ABANDON && ((ch - ch_lo) < 4 ? (ch - ch_lo) != 2 : ((ch - ch_lo) & 7) == 7)) {
+            // it has accumulated so far: after its first chunk (random candidates die here) and, unless the unit is split,
+            // every 8 chunks (a split unit belongs to a short list: the launch lasts as long as its longest unit whatever
+            // the others do, a wave leaves only when all its 512 candidates are dead, and each check costs more
+            // than the chunk it might save).
+            if (ABANDON && (ch == ch_lo || (f == 1 && ((ch - ch_lo) & 7) == 7))) {
                 const int jlo = ch_lo * JC, J = j0 + JC;
                 const double2 qa = q_pref[ch + 1], qb = q_pref[ch_lo];
                 const double2 qp = make_double2(qa.x - qb.x, qa.y - qb.y);
