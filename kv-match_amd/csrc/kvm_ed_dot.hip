@@ -451,6 +451,41 @@ __device__ __forceinline__ void edd_body(const edd_args &A, const kvm_tile *__re
     }
 }
 
+// ---- tile trimming shared by the two retile kernels: a tile keeps the span of its surviving candidates (bit l of `mask` =
+// lane l's candidate survives), goes to class A (33..64) or B (1..32), and is collected in LDS; one pair of global
+// atomics per workgroup appends the collected tiles (one atomic per tile on a single address cost 0.3 ms at 24 000 tiles).
+template <int CAP>
+struct retile_out {
+    kvm_tile a[CAP], b[CAP];
+    int na, nb;
+    unsigned long long base_a, base_b;
+};
+template <int CAP>
+__device__ __forceinline__ void retile_collect(retile_out<CAP> &o, const kvm_tile &tl, unsigned long long mask) {
+    if (mask == 0 || (threadIdx.x & 63) != 0) return;
+    const int first = __ffsll((long long)mask) - 1, last = 63 - __clzll((long long)mask);
+    kvm_tile out;
+    out.start = tl.start + first;
+    out.count = last - first + 1;
+    out.run_start = tl.run_start;
+    out.pad = 0;
+    if (out.count > 32) o.a[atomicAdd(&o.na, 1)] = out;
+    else o.b[atomicAdd(&o.nb, 1)] = out;
+}
+// (all threads of the workgroup; list order is whatever the atomics give)
+template <int CAP>
+__device__ __forceinline__ void retile_flush(retile_out<CAP> &o, kvm_tile *__restrict__ tilesA, kvm_tile *__restrict__ tilesB,
+                                             unsigned long long *__restrict__ d_counts) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        o.base_a = o.na ? atomicAdd(&d_counts[0], (unsigned long long)o.na) : 0;
+        o.base_b = o.nb ? atomicAdd(&d_counts[1], (unsigned long long)o.nb) : 0;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < o.na; i += blockDim.x) tilesA[o.base_a + i] = o.a[i];
+    for (int i = threadIdx.x; i < o.nb; i += blockDim.x) tilesB[o.base_b + i] = o.b[i];
+}
+
 // cNSM: trim every 64-candidate tile to the span of its candidates that pass the guarded (alpha, beta) filter and sort
 // the trimmed tiles into the two classes of the pruner (33..64 -> A, 1..32 -> B); tiles without a passing candidate
 // disappear.  The filter is selective in practice and its survivors are contiguous stretches of a run (mean and sigma
@@ -463,11 +498,9 @@ __global__ __launch_bounds__(256) void kvm_retile_cnsm_kernel(const double *__re
                                                               const kvm_tile *__restrict__ tiles, int64_t n_tiles,
                                                               kvm_tile *__restrict__ tilesA, kvm_tile *__restrict__ tilesB,
                                                               unsigned long long *__restrict__ d_counts) {
-    __shared__ kvm_tile outA[RETILE_PER_BLOCK], outB[RETILE_PER_BLOCK];
-    __shared__ int nA, nB;
-    __shared__ unsigned long long baseA, baseB;
+    __shared__ retile_out<RETILE_PER_BLOCK> out;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) nA = nB = 0;
+    if (threadIdx.x == 0) out.na = out.nb = 0;
     __syncthreads();
     const int64_t t0 = (int64_t)blockIdx.x * RETILE_PER_BLOCK + wave * (RETILE_PER_BLOCK / 4);
     for (int i = 0; i < RETILE_PER_BLOCK / 4; i++) {
@@ -480,26 +513,9 @@ __global__ __launch_bounds__(256) void kvm_retile_cnsm_kernel(const double *__re
             const kvm_stat_guard sg = kvm_window_mean_std_g(prefix, series, (int64_t)tl.start - 1 + lane, qd.m, mean, sd);
             ok = kvm_cnsm_filter_guarded(mean, sd, qd.meanQ, qd.stdQ, qd.alpha, qd.beta, sg);
         }
-        const unsigned long long mask = __ballot(ok);
-        if (mask != 0 && lane == 0) {
-            const int first = __ffsll((long long)mask) - 1, last = 63 - __clzll((long long)mask);
-            kvm_tile out;
-            out.start = tl.start + first;
-            out.count = last - first + 1;
-            out.run_start = tl.run_start;
-            out.pad = 0;
-            if (out.count > 32) outA[atomicAdd(&nA, 1)] = out;
-            else outB[atomicAdd(&nB, 1)] = out;
-        }
+        retile_collect(out, tl, __ballot(ok));
     }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        baseA = nA ? atomicAdd(&d_counts[0], (unsigned long long)nA) : 0;
-        baseB = nB ? atomicAdd(&d_counts[1], (unsigned long long)nB) : 0;
-    }
-    __syncthreads();
-    if ((int)threadIdx.x < nA) tilesA[baseA + threadIdx.x] = outA[threadIdx.x];
-    if ((int)threadIdx.x < nB) tilesB[baseB + threadIdx.x] = outB[threadIdx.x];
+    retile_flush(out, tilesA, tilesB, d_counts);
 }
 
 // RSM with the reference's early abandoning: the same trimming with the first EDR_HEAD points of the window as the
@@ -515,11 +531,9 @@ __global__ __launch_bounds__(256) void kvm_retile_rsm_kernel(const double *__res
                                                              const kvm_tile *__restrict__ tiles, int64_t n_tiles,
                                                              kvm_tile *__restrict__ tilesA, kvm_tile *__restrict__ tilesB,
                                                              unsigned long long *__restrict__ d_counts) {
-    __shared__ kvm_tile outA[EDR_PER_BLOCK], outB[EDR_PER_BLOCK];
-    __shared__ int nA, nB;
-    __shared__ unsigned long long baseA, baseB;
+    __shared__ retile_out<EDR_PER_BLOCK> out;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) nA = nB = 0;
+    if (threadIdx.x == 0) out.na = out.nb = 0;
     __syncthreads();
     const int head = qd.m < EDR_HEAD ? qd.m : EDR_HEAD;
     const double lim = qd.eps2 * (1.0 + 1e-9);  // (fused, other summation order than the reference's loop: < 1e-13 relative)
@@ -571,26 +585,9 @@ __global__ __launch_bounds__(256) void kvm_retile_rsm_kernel(const double *__res
             a0 = __builtin_fma(d0, d0, a0);
         }
         const bool ok = lane < tl.count && !(a0 + a1 > lim);
-        const unsigned long long mask = __ballot(ok);
-        if (mask != 0 && lane == 0) {
-            const int first = __ffsll((long long)mask) - 1, last = 63 - __clzll((long long)mask);
-            kvm_tile out;
-            out.start = tl.start + first;
-            out.count = last - first + 1;
-            out.run_start = tl.run_start;
-            out.pad = 0;
-            if (out.count > 32) outA[atomicAdd(&nA, 1)] = out;
-            else outB[atomicAdd(&nB, 1)] = out;
-        }
+        retile_collect(out, tl, __ballot(ok));
     }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        baseA = nA ? atomicAdd(&d_counts[0], (unsigned long long)nA) : 0;
-        baseB = nB ? atomicAdd(&d_counts[1], (unsigned long long)nB) : 0;
-    }
-    __syncthreads();
-    if ((int)threadIdx.x < nA) tilesA[baseA + threadIdx.x] = outA[threadIdx.x];
-    if ((int)threadIdx.x < nB) tilesB[baseB + threadIdx.x] = outB[threadIdx.x];
+    retile_flush(out, tilesA, tilesB, d_counts);
 }
 
 hipError_t kvm_launch_retile_rsm(const double *series, const kvm_query_dev &qd, const kvm_tile *tiles, int64_t n_tiles,
