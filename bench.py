@@ -13,12 +13,22 @@ The headline runs with early abandoning OFF, i.e. every candidate is evaluated o
 only mode whose work is data-independent (with abandoning on, random candidates die after ~12 points and the
 number measures launch overhead; it is reported separately as value_early_abandon).
 
-Multi-GPU: weak scaling -- every rank verifies its own contiguous shard of 1e6 candidates of a world*1e6 list
-(series replicated), then ONE all-gather (RCCL) of the surviving (offset, distance) pairs.
+A step is a STREAM of `--queries-per-step` such passes (default: 100 for the ED workloads, 10 for cNSM-DTW, 8 for the
+mixed stream), so that the timed region of the default run is seconds, not milliseconds; `value` = candidates
+verified per second over the stream, `ms_per_query` = one pass.
+
+Multi-GPU: one process per GPU.  `python bench.py --gpus N` (N > 1) without a launcher starts
+`python -m torch.distributed.run --nproc-per-node N` on itself as a child process BEFORE any GPU call and relays its
+output; it never silently runs on one rank.  `--scaling weak` (default): every rank verifies its own shard of 1e6
+candidates of a world*1e6 list (series replicated); `--scaling strong`: the 1e6-candidate list is split over the ranks.
+Either way ONE all-gather (RCCL) of the surviving (offset, distance) pairs per query.
 """
 import argparse
 import json
 import os
+import shutil
+import socket
+import subprocess
 import sys
 import time
 
@@ -34,6 +44,7 @@ from kvmatch import datagen, distributed  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
 FP64_VALU_PEAK_TFLOPS = 78.6  # vendor vector fp64 peak, FMA = 2 flop
+FP64_VALU_PEAK_TOPS_NOFMA = 39.3  # the same pipe issuing non-fusable fp64 operations (the DTW DP: sub, mul, min, min, add)
 
 
 def parse():
@@ -48,6 +59,10 @@ def parse():
     ap.add_argument("--extras", type=int, default=1, help="also measure cNSM-ED / cNSM-DTW (N=1 only)")
     ap.add_argument("--cpu-baseline", type=int, default=1)
     ap.add_argument("--ed-kernel", type=int, default=0)
+    ap.add_argument("--queries-per-step", type=int, default=0,
+                    help="phase-2 passes (queries of the stream) per step; 0 = per-workload default")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: --candidates per GPU; strong: --candidates in total, split over the GPUs")
     ap.add_argument("--workload", default="rsm_ed", choices=["rsm_ed", "cnsm_ed", "cnsm_dtw", "mixed"],
                     help="rsm_ed = BASELINE configs[1] (headline); cnsm_ed = configs[2]; cnsm_dtw = configs[3] "
                          "(m=4096, rho=5%%); mixed = configs[4]-style stream alternating all four variants")
@@ -74,19 +89,109 @@ def timed_steps(fn, steps, warmup, world):
     return dt
 
 
+def roofline_block(wl, plans, k_ns, stage_stats, m):
+    """Roofline of the workload's dominant kernel.  None of these kernels is HBM-bound (a tile of 64 consecutive candidates
+    needs m+63 points, not 64*m: 63 of every 64 algorithmic bytes are served from LDS): the binding roof is the fp64
+    vector pipe, so `bound` says so; the HBM view (8*m algorithmic bytes per candidate) is kept as secondary
+    fields.  `achieved` = algorithmic operations of one launch / the kernel's average HIP-event duration in this run."""
+    variants = [v for v, _, _, _ in plans]
+    dtw_i = [i for i, v in enumerate(variants) if v == 3] or [i for i, v in enumerate(variants) if v == 2]
+    if dtw_i:
+        # DTW: the banded DP (K/utils/DtwUtils.java:269-337), 5 non-fusable fp64 operations per cell
+        i = dtw_i[0]
+        v = variants[i]
+        ns = [t for j, t in k_ns if j == i and t > 0]
+        ks = float(np.mean(ns)) * 1e-9 if ns else 0.0
+        rho = int(kvmatch._lib.load().kvm_resolve_rho(0.05, m))
+        cells = m * (2 * rho + 1) - rho * (rho + 1)
+        dps = stage_stats[v][kvmatch.STAT_PASS_LB_KEOGH2]
+        ops = dps * cells * 5.0
+        ach = ops / ks / 1e12 if ks > 0 else 0.0
+        return {"bound": "fp64_valu", "achieved": ach, "peak": FP64_VALU_PEAK_TOPS_NOFMA, "unit": "TFLOP/s",
+                "frac": ach / FP64_VALU_PEAK_TOPS_NOFMA, "traffic": None,
+                "kernel": "kvm_dtw_dp_reg_kernel (banded DP, early abandon off: every candidate that reaches it runs all cells)",
+                "kernel_ms": ks * 1e3, "dp_candidates_per_launch": dps, "cells_per_candidate": cells,
+                "cells_per_s": dps * cells / ks if ks > 0 else 0.0,
+                "note": "peak = vector fp64 issue rate without FMA (78.6 TFLOP/s / 2); HBM traffic of the DP is negligible "
+                        "(8*m bytes per candidate), see profiles/ for the LDS / occupancy counters"}
+    i = 0
+    v = variants[0]
+    ns = [t for j, t in k_ns if j == i and t > 0]
+    ks = float(np.mean(ns)) * 1e-9 if ns else 0.0
+    st = stage_stats[v]
+    windows = st[kvmatch.STAT_WINDOWS]
+    # cNSM-ED: only the candidates passing the (alpha, beta) filter reach the O(m) pruner (K/NormQueryEngine.java:511)
+    evaluated = st[kvmatch.STAT_PASS_FILTER] if v == 1 else windows
+    fma_flops = evaluated * m * 2.0  # the correlation-form pruner executes ONE fma per (candidate, point)
+    ach = fma_flops / ks / 1e12 if ks > 0 else 0.0
+    algo_bytes = evaluated * 8.0 * m  # SURVEY 8d: 8*m algorithmic bytes per candidate
+    traffic, tsrc = None, None
+    tpath = os.path.join(ROOT, "profiles", "ed_traffic.json")
+    if v == 0 and os.path.exists(tpath):
+        try:
+            tj = json.load(open(tpath))
+            traffic, tsrc = tj.get("hbm_bytes_per_launch"), "profiles/ed_traffic.json: " + tj.get("source", "stored rocprofv3 --pmc pass")
+        except Exception:
+            traffic = None
+    return {"bound": "fp64_valu", "achieved": ach, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": ach / FP64_VALU_PEAK_TFLOPS, "traffic": traffic,
+            "traffic_source": (tsrc + " -- NOT measured by this run (gpurun refuses --pmc together with tracing)") if tsrc else None,
+            "kernel": "kvm_ed_dot_kernel (ED pruning pass incl. the in-place exact evaluation of its survivors" +
+                      ("; cNSM: + the (alpha, beta) retile before it)" if v == 1 else ")"),
+            "kernel_ms": ks * 1e3, "candidates_evaluated_per_launch": evaluated,
+            "executed_fma_tflops": ach,
+            "reference_arithmetic_tflops": evaluated * m * 3.0 / ks / 1e12 if ks > 0 else 0.0,  # sub, mul, add per term (SURVEY 8d)
+            "algorithmic_bytes_per_launch": algo_bytes,
+            "hbm_algorithmic_gbs": algo_bytes / ks / 1e9 if ks > 0 else 0.0,
+            "hbm_measured_gbs": (traffic / ks / 1e9) if (traffic and ks > 0) else None,
+            "hbm_peak_gbs": HBM_PEAK_GBS,
+            "note": "bound = fp64 vector pipe: 63 of every 64 algorithmic bytes are served from LDS (tile reuse), so the "
+                    "algorithmic-byte rate exceeds the HBM peak by construction; hbm_measured_gbs is the real HBM rate"}
+
+
+def self_launch(n_gpus):
+    """`python bench.py --gpus N` without a launcher: start one rank per GPU through torch.distributed.run as a CHILD
+    process (this process has made no GPU call: an exec or a fork after HIP initialisation is not allowed on the pool)
+    and relay its output and exit code."""
+    have = torch.cuda.device_count()  # (counting devices does not initialise the GPU)
+    if have < n_gpus:
+        print(f"bench.py: --gpus {n_gpus} but only {have} GPU(s) are visible; refusing to run fewer ranks", file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     a = parse()
+    if a.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if a.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(self_launch(a.gpus))  # one process per GPU; nothing in THIS process has touched the GPU yet
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus and world > 1:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: refusing to report a line for the wrong rank count")
     torch.cuda.set_device(local_rank)
     use_dist = "RANK" in os.environ and "MASTER_PORT" in os.environ  # launched by torch.distributed.run
+    rccl_ranks = 0
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        rccl_ranks = dist.get_world_size()
+        if rccl_ranks != a.gpus:
+            raise SystemExit(f"--gpus {a.gpus} but the RCCL group has {rccl_ranks} ranks")
     n, m = a.n, a.m
+    wl = a.workload
+    qps = a.queries_per_step if a.queries_per_step > 0 else {"rsm_ed": 100, "cnsm_ed": 100, "cnsm_dtw": 10, "mixed": 8}[wl]
+    # weak scaling: the list grows with the world (fixed work per GPU); strong: the list is fixed and split
+    total_list = a.candidates * world if a.scaling == "weak" else a.candidates
 
     # ---- inputs: every rank builds the same series (replicated), deterministic from the seed ------------
     t0 = time.perf_counter()
@@ -94,7 +199,7 @@ def main():
     qoff = n // 3 + 17
     planted = [n // 7, n // 2 + 1000, n - 3 * m]
     q = datagen.plant_copies(series, qoff, m, planted, [1.0, 1.0, 1.0], [0.0, 0.02, -0.03], 0.01)
-    left, right = datagen.gen_intervals(n, m, a.candidates * world, 64.0, must_cover=[qoff] + planted, seed=1)
+    left, right = datagen.gen_intervals(n, m, total_list, 64.0, must_cover=[qoff] + planted, seed=1)
     my_l, my_r = distributed.split_intervals(left, right, world, rank)
     my_cands = int((my_r.astype(np.int64) - my_l + 1).sum())
     ctx = kvmatch.Phase2Context(local_rank)
@@ -104,11 +209,10 @@ def main():
     setup_s = time.perf_counter() - t0
 
     # per-workload query parameters (BASELINE.json configs)
-    wl = a.workload
     if wl == "cnsm_dtw":
         m = 4096
         q = series[qoff - 1: qoff - 1 + m].copy()
-        left, right = datagen.gen_intervals(n, m, a.candidates * world, 64.0, must_cover=[qoff], seed=2)
+        left, right = datagen.gen_intervals(n, m, total_list, 64.0, must_cover=[qoff], seed=2)
         my_l, my_r = distributed.split_intervals(left, right, world, rank)
         my_cands = int((my_r.astype(np.int64) - my_l + 1).sum())
     # (variant id of kvm_verify_device, engine class, positional args after epsilon, keyword args for ShardedVerifier)
@@ -130,48 +234,52 @@ def main():
 
     sharded = [distributed.ShardedVerifier(ctx, v, my_cands) for v, _, _, _ in plans] if use_dist else None
 
-    def step():
+    def one_query():
         i = step_no[0] % len(plans)  # "mixed": the query stream cycles through the four variants
         step_no[0] += 1
         if use_dist:
             # device-resident shard verification + ONE all-gather of the surviving (offset, distance) pairs (RCCL)
             offs, dists = sharded[i].verify((my_l, my_r), 1, q, a.epsilon, **plans[i][3])
-            last["windows"] = my_cands
         else:
             ans = engines[i].verify((my_l, my_r), 1, q, a.epsilon, *plans[i][2])
             offs, dists = ans.offsets, ans.distances
-            last["windows"] = ans.stats[kvmatch.STAT_WINDOWS]
-        kernel_ns.append(int(lib.kvm_last_kernel_ns(h)))
+        kernel_ns.append((i, int(lib.kvm_last_kernel_ns(h))))  # HIP events around the dominant kernel, on its own stream
         last["offs"], last["dists"] = offs, dists
+
+    def step():
+        for _ in range(qps):
+            one_query()
 
     # ---- headline: early abandon off ---------------------------------------------------------------------
     ctx.set_option(kvmatch.OPT_EARLY_ABANDON, 0)
+    # first calls allocate scratch (and build the rho envelope for DTW); through the host API on this rank's shard, which
+    # also returns the per-stage counters the roofline block needs (the sharded path returns answers only)
+    stage_stats = {}
+    for i, (v, _, pos, _) in enumerate(plans):
+        r_ = engines[i].verify((my_l, my_r), 1, q, a.epsilon, *pos)
+        stage_stats[v] = list(r_.stats)
     for _ in plans:
-        step()  # first calls allocate scratch (and build the rho envelope for DTW)
+        one_query()
     step_no[0] = 0
     kernel_ns.clear()
     dt = timed_steps(step, a.steps, a.warmup, world)
-    k_ns = kernel_ns[-a.steps:]
+    k_ns = kernel_ns[-a.steps * qps:]
     total_cands = my_cands
     if world > 1:
         t = torch.tensor([my_cands], dtype=torch.int64, device="cuda")
         dist.all_reduce(t)
         total_cands = int(t.item())
-    value = total_cands * a.steps / dt
+    value = total_cands * a.steps * qps / dt
     head_offs, head_dists = last["offs"].copy(), last["dists"].copy()
-    windows = last["windows"]
-    avg_kernel_s = float(np.mean(k_ns)) * 1e-9
-    algo_bytes = windows * 8.0 * m  # 8*m algorithmic bytes per candidate
-    achieved = algo_bytes / avg_kernel_s / 1e9 if avg_kernel_s > 0 else 0.0
 
     # ---- same workload with the reference's early abandoning on (reported, not the headline) -------------
     ctx.set_option(kvmatch.OPT_EARLY_ABANDON, 1)
     step_no[0] = 0
-    n_ab = max(3, a.steps // 2) // len(plans) * len(plans) or len(plans)
-    dt_ab = timed_steps(step, n_ab, len(plans), world)
-    value_ab = total_cands * n_ab / dt_ab
-    step_no[0] = (a.steps - 1) % len(plans)
-    step()
+    n_ab = max(2, a.steps // 4)
+    dt_ab = timed_steps(step, n_ab, 1, world)
+    value_ab = total_cands * n_ab * qps / dt_ab
+    step_no[0] = len(plans) - 1 if len(plans) > 1 else 0
+    one_query()
     ab_match = bool(np.array_equal(head_offs, last["offs"])) if len(plans) == 1 else None
 
     out = {
@@ -182,11 +290,13 @@ def main():
         "value": value,
         "unit": "candidates/s",
         "n_gpus": world,
+        "rccl_ranks": rccl_ranks,
         "steps": a.steps,
         "warmup": a.warmup,
         "ms_per_step": dt / a.steps * 1e3,
+        "ms_per_query": dt / (a.steps * qps) * 1e3,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": a.scaling,
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic (seeded restatement of K/DataGenerator.java; query + 3 noisy copies planted)",
@@ -194,6 +304,7 @@ def main():
                                 "cnsm_ed": "cNSM-ED phase 2, alpha=2 beta=10 (BASELINE configs[2])",
                                 "cnsm_dtw": "cNSM-DTW phase 2, rho=5%, alpha=2 beta=10 (BASELINE configs[3])",
                                 "mixed": "mixed ED+DTW query stream (BASELINE configs[4] style)"}[wl], "n": n, "m": m,
+                   "queries_per_step": qps, "candidates_per_query_per_gpu": my_cands,
                    "candidates_per_gpu": my_cands, "intervals_per_gpu": int(len(my_l)), "epsilon": a.epsilon,
                    "early_abandon": False, "parallelism": f"candidate shards x{world}, series replicated",
                    "answers": int(len(head_offs)), "ed_kernel": a.ed_kernel},
@@ -201,25 +312,7 @@ def main():
         "early_abandon_same_answers": ab_match,
         "setup_s": setup_s,
     }
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "ed_traffic.json")
-    if os.path.exists(tpath):
-        try:
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
-    out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                       "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                       "kernel": "kvm_ed_dot_kernel<false,false> (RSM-ED pruning pass; the exact pass adds ~0.05 ms per call)", "kernel_ms": avg_kernel_s * 1e3,
-                       "algorithmic_bytes_per_launch": algo_bytes,
-                       # the reference's arithmetic is 3 flops per term (sub, mul, add); the correlation
-                       # form executes ONE fma per term, which is what the VALU fraction is taken from
-                       "algorithmic_fp64_tflops": windows * m * 3.0 / avg_kernel_s / 1e12 if avg_kernel_s > 0 else 0.0,
-                       "executed_fma_tflops": windows * m * 2.0 / avg_kernel_s / 1e12 if avg_kernel_s > 0 else 0.0,
-                       "fp64_valu_peak_tflops": FP64_VALU_PEAK_TFLOPS,
-                       "valu_frac": (windows * m * 2.0 / avg_kernel_s / 1e12 / FP64_VALU_PEAK_TFLOPS) if avg_kernel_s > 0 else 0.0,
-                       "note": "frac > 1: 63 of every 64 algorithmic bytes are served from LDS/L2 (traffic = measured HBM "
-                               "bytes per launch); the kernel's binding resource is the fp64 vector pipe (valu_frac)"}
+    out["roofline"] = roofline_block(wl, plans, k_ns, stage_stats, m)
 
     # ---- extras (N=1): the other variants on the same staged series ---------------------------------------
     if rank == 0 and world == 1 and a.extras and wl == "rsm_ed":
@@ -309,17 +402,21 @@ def main():
         t1 = time.perf_counter()
         oracle.rsm_ed(series, q, my_l, my_r, 0, a.epsilon, no_abandon=False)
         cpu_ab_s = time.perf_counter() - t1
+        # the reference's own Java loop could only be timed with a JDK on this box (and the Maven artefacts its sources
+        # import): probe instead of assuming
+        java, javac = shutil.which("java"), shutil.which("javac")
         out["cpu_baseline"] = {
             "value": o_st["windows"] / cpu_s, "unit": "candidates/s", "cores": 1, "kind": "port",
-            "sample": f"all {o_st['windows']} candidates of the N=1 workload, early abandon off (same work as "
-                      f"`value`), single thread; C restatement of K/QueryEngine.java:338-363 (no JDK on the box, "
-                      f"avoids Java boxing so it flatters the CPU side)",
+            "jdk_probe": {"java": java, "javac": javac},
+            "sample": f"all {o_st['windows']} candidates of one query of the N=1 workload, early abandon off (same work "
+                      f"per query as `value`), single thread; C restatement of K/QueryEngine.java:338-363 "
+                      f"({'a JDK is present but the reference needs un-vendored Maven artefacts' if java else 'no JDK on this box: java/javac not on PATH'}; "
+                      f"the port avoids Java boxing, so it flatters the CPU side)",
             "value_early_abandon": o_st["windows"] / cpu_ab_s,
             "seconds": cpu_s,
         }
         # the same loop on all host cores: a child process (no GPU context there) forks one worker per core
         try:
-            import subprocess
             ncores = min(os.cpu_count() or 1, 64)
             cp = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline.py"), str(n), str(m),
                                  str(a.candidates), str(a.epsilon), str(ncores)], capture_output=True, text=True,

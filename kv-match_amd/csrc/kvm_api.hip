@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <memory>
 #include <mutex>
 #include <numeric>
 
@@ -82,6 +83,10 @@ extern "C" int kvm_open(int device, kvm_ctx **out) {
         (e = hipEventCreate(&ctx->ev0)) != hipSuccess || (e = hipEventCreate(&ctx->ev1)) != hipSuccess ||
         (e = hipEventCreateWithFlags(&ctx->ev_staged, hipEventDisableTiming)) != hipSuccess) {
         std::string msg = std::string("kvm_open: ") + hipGetErrorString(e);
+        if (ctx->ev0) hipEventDestroy(ctx->ev0);
+        if (ctx->ev1) hipEventDestroy(ctx->ev1);
+        if (ctx->ev_staged) hipEventDestroy(ctx->ev_staged);
+        if (ctx->stream) hipStreamDestroy(ctx->stream);
         delete ctx;
         return fail(nullptr, KVM_ERR_DEVICE, msg);
     }
@@ -90,6 +95,9 @@ extern "C" int kvm_open(int device, kvm_ctx **out) {
         ctx->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         if (std::strstr(prop.gcnArchName, "gfx950") == nullptr) {
             std::string msg = std::string("kvm_open: built for gfx950 only, device is ") + prop.gcnArchName;
+            hipEventDestroy(ctx->ev0);
+            hipEventDestroy(ctx->ev1);
+            hipEventDestroy(ctx->ev_staged);
             hipStreamDestroy(ctx->stream);
             delete ctx;
             return fail(nullptr, KVM_ERR_DEVICE, msg);
@@ -128,6 +136,7 @@ extern "C" int kvm_close(kvm_ctx *ctx) {
     hipEventDestroy(ctx->ev0);
     hipEventDestroy(ctx->ev1);
     hipEventDestroy(ctx->ev_staged);
+    if (ctx->ev_env) hipEventDestroy(ctx->ev_env);
     hipStreamDestroy(ctx->stream);
     delete ctx;
     return KVM_OK;
@@ -178,12 +187,23 @@ extern "C" int64_t kvm_get_option(const kvm_ctx *ctx, int32_t option) {
 
 // ---- series staging -----------------------------------------------------------------------------------
 
-static int finish_load(kvm_ctx *ctx) {
+static int finish_load_steps(kvm_ctx *ctx) {
     // prefix sums for per-window mean/std (replaces the running ex/ex2 of K/NormQueryEngine.java:497-509)
     HIPCHK(ctx, hipMalloc((void **)&ctx->d_prefix, (size_t)ctx->n * sizeof(double2)));
     HIPCHK(ctx, kvm_launch_prefix(ctx->d_series, ctx->d_prefix, ctx->n, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return KVM_OK;
+}
+// A series is either fully staged (values + prefix sums) or absent: on any failure (16 B per point of prefix sums may not
+// fit) the context drops the half-loaded series, so that later calls report KVM_ERR_NO_SERIES instead of reading a null
+// prefix array.
+static int finish_load(kvm_ctx *ctx) {
+    const int rc = finish_load_steps(ctx);
+    if (rc != KVM_OK) {
+        hipStreamSynchronize(ctx->stream);
+        free_series(ctx);
+    }
+    return rc;
 }
 
 static int alloc_series(kvm_ctx *ctx, int64_t n) {
@@ -204,7 +224,10 @@ extern "C" int kvm_load_series_f64(kvm_ctx *ctx, const double *host_values, int6
     if (!host_values) return fail(ctx, KVM_ERR_ILLEGAL_ARGUMENT, "null series");
     int rc = alloc_series(ctx, n);
     if (rc) return rc;
-    HIPCHK(ctx, hipMemcpyAsync(ctx->d_series, host_values, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+    if (hipMemcpyAsync(ctx->d_series, host_values, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
+        free_series(ctx);
+        return fail(ctx, KVM_ERR_DEVICE, "copying the series to the device failed");
+    }
     return finish_load(ctx);
 }
 
@@ -213,14 +236,20 @@ extern "C" int kvm_load_series_be64(kvm_ctx *ctx, const void *be_bytes, int64_t 
     if (!be_bytes) return fail(ctx, KVM_ERR_ILLEGAL_ARGUMENT, "null series");
     int rc = alloc_series(ctx, n);
     if (rc) return rc;
-    HIPCHK(ctx, hipMemcpyAsync(ctx->d_series, be_bytes, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, kvm_launch_bswap64((uint64_t *)ctx->d_series, n, ctx->stream));
+    if (hipMemcpyAsync(ctx->d_series, be_bytes, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+        kvm_launch_bswap64((uint64_t *)ctx->d_series, n, ctx->stream) != hipSuccess) {
+        hipStreamSynchronize(ctx->stream);
+        free_series(ctx);
+        return fail(ctx, KVM_ERR_DEVICE, "staging the big-endian series failed");
+    }
     return finish_load(ctx);
 }
 
 extern "C" int kvm_load_series_file(kvm_ctx *ctx, const char *path, int64_t n) {
     if (!ctx) return KVM_ERR_INVALID_HANDLE;
     if (!path) return fail(ctx, KVM_ERR_ILLEGAL_ARGUMENT, "null path");
+    if (n < 1 || n > 2147483647LL)  // (before the file is touched: a bad length is the caller's error, not an I/O error)
+        return fail(ctx, KVM_ERR_ILLEGAL_ARGUMENT, "series length must be in [1, 2^31-1]");
     int fd = open(path, O_RDONLY);
     if (fd < 0) return fail(ctx, KVM_ERR_IO, std::string("cannot open ") + path);
     struct stat st;
@@ -243,7 +272,10 @@ extern "C" int kvm_attach_series_device(kvm_ctx *ctx, const double *device_value
     // referenced after this call returns
     int rc = alloc_series(ctx, n);
     if (rc) return rc;
-    HIPCHK(ctx, hipMemcpyAsync(ctx->d_series, device_values, (size_t)n * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    if (hipMemcpyAsync(ctx->d_series, device_values, (size_t)n * 8, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) {
+        free_series(ctx);
+        return fail(ctx, KVM_ERR_DEVICE, "copying the device series failed");
+    }
     return finish_load(ctx);
 }
 
@@ -606,13 +638,25 @@ struct verify_out {
 
 enum { V_RSM_ED = 0, V_CNSM_ED = 1, V_RSM_DTW = 2, V_CNSM_DTW = 3 };
 
-static int ensure_envelope(kvm_ctx *ctx, int32_t rho) {
-    if (ctx->env_rho == rho && ctx->d_env_u) return KVM_OK;
+// The envelope is built on the stream of the call that needs it (its consumers run on that stream).  A cached envelope
+// may have been built on ANOTHER stream by an earlier kvm_verify_device call that returned without synchronising: the
+// event recorded behind the build orders this call's stream after it.
+static int ensure_envelope(kvm_ctx *ctx, int32_t rho, hipStream_t stream) {
+    if (ctx->env_rho == rho && ctx->d_env_u) {
+        if (ctx->ev_env && ctx->env_stream != stream) HIPCHK(ctx, hipStreamWaitEvent(stream, ctx->ev_env, 0));
+        return KVM_OK;
+    }
     if (!ctx->d_env_u) {
         HIPCHK(ctx, hipMalloc((void **)&ctx->d_env_u, (size_t)ctx->n * 8));
         HIPCHK(ctx, hipMalloc((void **)&ctx->d_env_l, (size_t)ctx->n * 8));
     }
-    HIPCHK(ctx, kvm_launch_envelope(ctx->d_series, ctx->n, rho, ctx->d_env_u, ctx->d_env_l, ctx->stream));
+    ctx->env_rho = -1;
+    // (a rebuild for another rho overwrites arrays the previous call's kernels may still be reading on another stream:
+    // run_variant has already waited for that call's ev_staged, which is recorded behind all of them)
+    HIPCHK(ctx, kvm_launch_envelope(ctx->d_series, ctx->n, rho, ctx->d_env_u, ctx->d_env_l, stream));
+    if (!ctx->ev_env) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_env, hipEventDisableTiming));
+    HIPCHK(ctx, hipEventRecord(ctx->ev_env, stream));
+    ctx->env_stream = stream;
     ctx->env_rho = rho;
     return KVM_OK;
 }
@@ -935,7 +979,7 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
         const int32_t seg_len = (((m + KVM_DTW_NSEG - 1) / KVM_DTW_NSEG) + 63) / 64 * 64;
         if (use_lb) {
             if ((rc = ensure(ctx, ctx->b_cands2, (size_t)pl.windows * sizeof(kvm_cand) + 64))) return rc;
-            if ((rc = ensure_envelope(ctx, rho))) return rc;
+            if ((rc = ensure_envelope(ctx, rho, stream))) return rc;
             if ((rc = ensure(ctx, ctx->b_aux, (size_t)pl.windows * KVM_DTW_NSEG * sizeof(double) + 64))) return rc;
             kvm_cand *c2 = (kvm_cand *)ctx->b_cands2.p;
             HIPCHK(ctx, kvm_launch_dtw_keogh(ctx->d_series, ctx->d_env_u, ctx->d_env_l, ctx->n, qd, c1,
@@ -1006,7 +1050,8 @@ static int verify_host(kvm_ctx *ctx, int variant, const double *query, int32_t m
                 (long long)pl.n_tiles_b, hc[KVM_CNT_TILES_A], hc[KVM_CNT_TILES_B], hc[KVM_CNT_CANDS1]);
     const int64_t cnt = (int64_t)hc[KVM_CNT_ANSWERS];
     if (cnt > worst) return fail(ctx, KVM_ERR_DEVICE, "answer buffer overflow (internal error)");
-    kvm_result *r = new kvm_result();
+    std::unique_ptr<kvm_result> r_owner(new kvm_result());  // (released into *result at the end; freed on every error return)
+    kvm_result *r = r_owner.get();
     off.resize((size_t)cnt);
     dist.resize((size_t)cnt);
     if (cnt > spec) {
@@ -1087,7 +1132,7 @@ static int verify_host(kvm_ctx *ctx, int variant, const double *query, int32_t m
     r->stats[KVM_STAT_KERNEL_NS] = kernel_ns;
     auto t1 = std::chrono::steady_clock::now();
     r->elapsed_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
-    *result = r;
+    *result = r_owner.release();
     return KVM_OK;
 }
 

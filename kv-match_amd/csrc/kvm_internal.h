@@ -84,6 +84,8 @@ struct kvm_ctx {
     // cached data envelope for LB_Keogh2 (per rho)
     double *d_env_u = nullptr, *d_env_l = nullptr;
     int32_t env_rho = -1;
+    hipEvent_t ev_env = nullptr;     // recorded behind the envelope build
+    hipStream_t env_stream = nullptr;  // the stream it was built on
     // grow-only scratch
     kvm_dev_buf b_query, b_tiles, b_out_off, b_out_dist, b_counters, b_cands, b_cands2, b_aux, b_aux2, b_scratch;
     void *h_pinned = nullptr;

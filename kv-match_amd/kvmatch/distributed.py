@@ -146,16 +146,16 @@ class ShardedVerifier:
         self.host = torch.empty((self.world * (self.pack_cap + 1), 2), dtype=torch.float64).pin_memory()
         self.cnt_candidate = 0
 
-    def verify(self, valid_positions, last_segment, query_data, epsilon, rho=0, alpha=1.0, beta=0.0):
+    def verify(self, valid_positions, last_segment, query_data, epsilon, rho=0, alpha=1.0, beta=0.0, resolved=None):
         import ctypes as C
         import torch
         import torch.distributed as dist
         from . import _lib
-        from .engine import WU0, _as_intervals
+        from .engine import WU0, _as_intervals, resolve_rho
         left, right = _as_intervals(valid_positions)
         q = np.ascontiguousarray(query_data, dtype=np.float64)
         c = self.ctx
-        r = c._lib.kvm_resolve_rho(float(rho), q.size) if self.variant >= 2 else 0
+        r = resolve_rho(rho, q.size, resolved) if self.variant >= 2 else 0
         cnt_cand = C.c_int64(0)
         stream = torch.cuda.current_stream(self.dev).cuda_stream
         _lib.check(c._lib.kvm_verify_device(

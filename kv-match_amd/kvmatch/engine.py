@@ -55,17 +55,34 @@ class Answers:
 
 
 def _as_intervals(valid_positions):
-    """Accept [(left, right), ...], an (k,2) array, or a (left[], right[]) tuple of arrays."""
-    if isinstance(valid_positions, tuple) and len(valid_positions) == 2 and np.ndim(valid_positions[0]) == 1:
-        left, right = valid_positions
+    """Accept [(left, right), ...] (any sequence of pairs), a (k, 2) array, or a 2-tuple of one-dimensional NUMPY arrays
+    (left[], right[]).  Only numpy arrays select the second form: a tuple of two pairs such as ((1, 5), (10, 20)) is two
+    intervals, [1, 5] and [10, 20], as in the reference's List<Interval>."""
+    if (isinstance(valid_positions, tuple) and len(valid_positions) == 2
+            and all(isinstance(x, np.ndarray) and x.ndim == 1 for x in valid_positions)):
+        left, right = (np.asarray(x, dtype=np.int64) for x in valid_positions)
     else:
         arr = np.asarray(valid_positions, dtype=np.int64).reshape(-1, 2)
         left, right = arr[:, 0], arr[:, 1]
-    left = np.ascontiguousarray(left, dtype=np.int32)
-    right = np.ascontiguousarray(right, dtype=np.int32)
     if left.shape != right.shape:
         raise _lib.KvMatchIllegalArgument("left/right length mismatch")
-    return left, right
+    if left.size and (min(left.min(), right.min()) < -2**31 or max(left.max(), right.max()) > 2**31 - 1):
+        raise _lib.KvMatchIllegalArgument("interval bounds must fit a Java int")  # (never wrapped silently)
+    return np.ascontiguousarray(left, dtype=np.int32), np.ascontiguousarray(right, dtype=np.int32)
+
+
+def resolve_rho(rho, m, resolved=None):
+    """Band half-width in points.  The reference's query(..., int rho) takes points (K/QueryEngineDtw.java:165); its REPL
+    reads a double r and resolves `r <= 1 -> floor(r * m), else floor(r)` (:135-140).  Here an integer argument is
+    points, a float goes through the prompt rule; `resolved=True/False` forces one reading."""
+    if resolved is None:
+        resolved = isinstance(rho, (int, np.integer)) and not isinstance(rho, bool)
+    if resolved:
+        r = int(rho)
+        if r < 0 or r > 2**31 - 1:
+            raise _lib.KvMatchIllegalArgument("rho must be in [0, 2^31-1]")
+        return r
+    return int(_lib.load().kvm_resolve_rho(float(rho), int(m)))
 
 
 def phase2_time_estimate_ms(variant, disjoint_windows, candidate_offsets, length):
@@ -240,15 +257,16 @@ class NormQueryEngine(_EngineBase):
 
 
 class QueryEngineDtw(_EngineBase):
-    """RSM-DTW (K/QueryEngineDtw.java).  ``verify`` replaces lines 349-452.  ``rho`` follows the reference's
-    prompt rule: values <= 1 are a fraction of the query length (K/QueryEngineDtw.java:135-140)."""
+    """RSM-DTW (K/QueryEngineDtw.java).  ``verify`` replaces lines 349-452.  ``rho``: an int is the band half-width in
+    points (the reference's ``query(..., int rho)``), a float follows the REPL's prompt rule (values <= 1 are a fraction of
+    the query length, K/QueryEngineDtw.java:135-140); see ``resolve_rho``."""
 
-    def verify(self, valid_positions, last_segment, query_data, epsilon, rho, statistics=None):
+    def verify(self, valid_positions, last_segment, query_data, epsilon, rho, statistics=None, resolved=None):
         q = self._query(query_data)
         left, right = _as_intervals(valid_positions)
         res = C.c_void_p()
         c = self.ctx
-        r = c._lib.kvm_resolve_rho(float(rho), q.size)
+        r = resolve_rho(rho, q.size, resolved)
         _lib.check(c._lib.kvm_verify_rsm_dtw(c._h, q.ctypes.data, q.size, left.ctypes.data, right.ctypes.data,
                                              left.size, self._shift(last_segment), float(epsilon), r,
                                              C.byref(res)), c._h)
@@ -258,13 +276,13 @@ class QueryEngineDtw(_EngineBase):
 class NormQueryEngineDtw(_EngineBase):
     """cNSM-DTW (K/NormQueryEngineDtw.java).  ``verify`` replaces lines 457-603."""
 
-    def verify(self, valid_positions, last_segment, query_data, epsilon, rho, alpha, beta, statistics=None, resolved=False):
-        """``resolved=True``: `rho` is already the band half-width in points (not the r <= 1 fraction form)."""
+    def verify(self, valid_positions, last_segment, query_data, epsilon, rho, alpha, beta, statistics=None, resolved=None):
+        """``rho``: int = points, float = the REPL's fraction rule (``resolve_rho``); ``resolved`` forces one reading."""
         q = self._query(query_data)
         left, right = _as_intervals(valid_positions)
         res = C.c_void_p()
         c = self.ctx
-        r = int(rho) if resolved else c._lib.kvm_resolve_rho(float(rho), q.size)
+        r = resolve_rho(rho, q.size, resolved)
         _lib.check(c._lib.kvm_verify_cnsm_dtw(c._h, q.ctypes.data, q.size, left.ctypes.data, right.ctypes.data,
                                               left.size, self._shift(last_segment), float(epsilon), r, float(alpha),
                                               float(beta), C.byref(res)), c._h)

@@ -122,7 +122,7 @@ def run(kvmatch, datagen, oracle, ctx, rounds, seed, kinds=KINDS, n_range=(30_00
                         if name != "full" or n < 60_000:
                             ctx.set_option(kvmatch.OPT_EARLY_ABANDON, 1)
                             if alpha == 1.0 and beta == 0.0:
-                                r2 = max(rho, 2)     # (the engine reads rho <= 1 as a fraction of m)
+                                r2 = int(rho)        # (an int rho is the band half-width in points)
                                 same(gpu(lambda: kvmatch.QueryEngineDtw(ctx).verify((L, R), 1, q, eps, r2)),
                                      cpu(lambda: oracle.rsm_dtw(s, q, L, R, 0, eps, r2)), "rsm_dtw " + tag, eps, True)
                             same(gpu(lambda: kvmatch.NormQueryEngineDtw(ctx).verify((L, R), 1, q, eps, rho, alpha, beta, resolved=True)),

@@ -136,7 +136,7 @@ def test_shift_clipping_empty_and_errors(world):
         assert len(a) == 0 and a.cnt_candidate == 0
     # interval wholly beyond the series: IllegalArgumentException, as readTimeSeries throws
     with pytest.raises(kvmatch.KvMatchIllegalArgument):
-        kvmatch.QueryEngine(ctx).verify(([30_000], [30_010]), 1, q, 1.0)
+        kvmatch.QueryEngine(ctx).verify([(30_000, 30_010)], 1, q, 1.0)
     with pytest.raises(oracle.OracleError):
         oracle.rsm_ed(s, q, [30_000], [30_010], 0, 1.0)
     # readTimeSeries range errors (K/operator/file/TimeSeriesFileOperator.java:55-57)
@@ -329,6 +329,33 @@ def test_device_resident_verifier_matches_host_api(world):
             assert np.array_equal(offs, host[variant].offsets), variant
             assert np.array_equal(dists, host[variant].distances), variant
             assert v.cnt_candidate == host[variant].cnt_candidate
+
+
+def test_verify_device_on_a_foreign_stream_with_a_fresh_rho(world):
+    """kvm_verify_device on a non-blocking, non-default stream: the data envelope of a rho the context has not seen yet
+    must be built on (or ordered before) THAT stream -- LB_Keogh on the data envelope reads it in the same call.  Then the
+    cached envelope is reused from a second foreign stream (ordered by the event recorded behind the build)."""
+    import torch
+    kvmatch = world[0]
+    from kvmatch import distributed as D
+    ctx = world[3]
+    s, q, L, R = planted(world, 300)
+    cands = int((R.astype(np.int64) - L + 1).sum())
+    dev = torch.device(f"cuda:{ctx.device}")
+    for rho in (37, 91):  # not used by any other test of this session's context
+        host = kvmatch.NormQueryEngineDtw  # host API answers AFTER the device call, so the device call sees a cold cache
+        streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+        got = []
+        for st in streams:
+            with torch.cuda.stream(st):
+                v = D.ShardedVerifier(ctx, 3, cands)
+                got.append(v.verify((L, R), 1, q, 4.0, rho=rho, alpha=1.5, beta=2.0))
+        want = host(ctx).verify((L, R), 1, q, 4.0, rho, 1.5, 2.0)
+        for offs, dists in got:
+            assert np.array_equal(offs, want.offsets), rho
+            assert np.array_equal(dists, want.distances), rho
+        ref = oracle.cnsm_dtw(s, q, L, R, 0, 4.0, rho, 1.5, 2.0)
+        assert np.array_equal(want.offsets, ref[0]) and np.array_equal(want.distances, ref[1])
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -790,9 +817,11 @@ def test_randomised_sweep_all_variants(world):
                 oracle.rsm_ed(s, q, L2, R2, shift, eps), tag="rsm_ed " + tag)
         compare(kvmatch.NormQueryEngine(ctx).verify((L2, R2), last_segment, q, eps, alpha, beta),
                 oracle.cnsm_ed(s, q, L2, R2, shift, eps, alpha, beta), tag="cnsm_ed " + tag)
-        compare(kvmatch.QueryEngineDtw(ctx).verify((L2, R2), last_segment, q, eps, rho),
+        # (a float rho goes through the prompt rule, an int is points: alternate the two spellings)
+        rho_arg = float(rho) if trial % 2 else int(rho_resolved)
+        compare(kvmatch.QueryEngineDtw(ctx).verify((L2, R2), last_segment, q, eps, rho_arg),
                 oracle.rsm_dtw(s, q, L2, R2, shift, eps, rho_resolved), tag="rsm_dtw " + tag)
-        compare(kvmatch.NormQueryEngineDtw(ctx).verify((L2, R2), last_segment, q, eps, rho, alpha, beta),
+        compare(kvmatch.NormQueryEngineDtw(ctx).verify((L2, R2), last_segment, q, eps, rho_arg, alpha, beta),
                 oracle.cnsm_dtw(s, q, L2, R2, shift, eps, rho_resolved, alpha, beta), tag="cnsm_dtw " + tag)
         cases += 4
     assert cases == 240
