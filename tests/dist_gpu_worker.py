@@ -1,0 +1,50 @@
+"""Worker of tests/test_distributed_gpu.py: one rank of a 2-rank job, BOTH ranks on cuda:0 (the test box has one GPU).
+RCCL refuses two ranks on one device ("invalid usage"), so the group is gloo -- which moves CUDA tensors too; what is
+exercised above world 1 on hardware is everything else of the multi-GPU path: split_intervals, kvm_verify_device (answers
+stay in HBM, caller's stream), kvm_pack_answers_device, the fixed-size all_gather_into_tensor of device tensors, the
+exact-size fallback exchange, and the merge.  Writes r{rank}.npz per variant into the directory given as argv[1]."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "kv-match_amd"))
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+import kvmatch  # noqa: E402
+from kvmatch import datagen, distributed as D  # noqa: E402
+
+
+def main():
+    out_dir = sys.argv[1]
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo")
+    n, m, qoff = 400_000, 256, 123_456
+    series = datagen.gen_series(n, seed=4242)
+    planted = [50_000, 300_000]
+    q = datagen.plant_copies(series, qoff, m, planted, [1.0, 1.1], [0.0, 0.3], 0.02, seed=5)
+    left, right = datagen.gen_intervals(n, m, 60_000, 32.0, must_cover=[qoff] + planted, seed=6)
+    l, r = D.split_intervals(left, right, world, rank)
+    cands = int((r.astype(np.int64) - l + 1).sum())
+    args = [dict(epsilon=6.0), dict(epsilon=4.0, alpha=1.5, beta=2.0), dict(epsilon=6.0, rho=12),
+            dict(epsilon=4.0, rho=12, alpha=1.5, beta=2.0)]
+    with kvmatch.Phase2Context(0) as ctx:
+        ctx.load_series(series)
+        for variant in range(4):
+            for pack_cap in (4096, 2):  # 2 forces the exact-size second exchange
+                v = D.ShardedVerifier(ctx, variant, cands, pack_cap=pack_cap)
+                offs, dists = v.verify((l, r), 1, q, **args[variant])
+                cnt = torch.tensor([v.cnt_candidate], dtype=torch.int64)
+                dist.all_reduce(cnt)
+                np.savez(os.path.join(out_dir, f"v{variant}_p{pack_cap}_r{rank}.npz"), offs=offs, dists=dists,
+                         cnt=int(cnt.item()), shard=cands)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

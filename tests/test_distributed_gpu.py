@@ -1,0 +1,49 @@
+"""-m gpu: the sharded device-resident path above world 1 on hardware -- two ranks sharing the box's single GPU (see
+tests/dist_gpu_worker.py for why the group is gloo there), against the unsharded oracle."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_sharded_verifier_two_ranks_one_device(built, tmp_path):
+    from kvmatch import datagen
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cp = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                         "--master-addr", "127.0.0.1", "--master-port", str(port),
+                         os.path.join(ROOT, "tests", "dist_gpu_worker.py"), str(tmp_path)],
+                        env=env, capture_output=True, text=True, timeout=600)
+    assert cp.returncode == 0, cp.stdout[-2000:] + cp.stderr[-4000:]
+    n, m, qoff = 400_000, 256, 123_456
+    series = datagen.gen_series(n, seed=4242)
+    planted = [50_000, 300_000]
+    q = datagen.plant_copies(series, qoff, m, planted, [1.0, 1.1], [0.0, 0.3], 0.02, seed=5)
+    left, right = datagen.gen_intervals(n, m, 60_000, 32.0, must_cover=[qoff] + planted, seed=6)
+    want = [oracle.rsm_ed(series, q, left, right, 0, 6.0), oracle.cnsm_ed(series, q, left, right, 0, 4.0, 1.5, 2.0),
+            oracle.rsm_dtw(series, q, left, right, 0, 6.0, 12), oracle.cnsm_dtw(series, q, left, right, 0, 4.0, 12, 1.5, 2.0)]
+    for variant in range(4):
+        w_off, w_dist, w_st = want[variant]
+        assert len(w_off) >= 2 and qoff in w_off.tolist()
+        for pack_cap in (4096, 2):
+            shards = 0
+            for rank in range(2):
+                z = np.load(tmp_path / f"v{variant}_p{pack_cap}_r{rank}.npz")
+                # whole intervals are dealt out (interleaved split), so even the cNSM running sums restart where the
+                # unsharded run restarts them: every rank holds the oracle's list bit for bit
+                assert np.array_equal(z["offs"], w_off), (variant, pack_cap, rank)
+                assert np.array_equal(z["dists"], w_dist), (variant, pack_cap, rank)
+                assert int(z["cnt"]) == w_st["cnt_candidate"]
+                shards += int(z["shard"])
+            assert shards == w_st["cnt_candidate"]
