@@ -169,7 +169,9 @@ void kvm_result_free(kvm_result *r);
 #define KVM_STAT_PASS_LB_KEOGH2 4 /* passed LB_Keogh, data envelope = DP launched (DTW) */
 #define KVM_STAT_KERNEL_NS 5     /* device time of the dominant kernel(s), ns (HIP events) */
 #define KVM_STAT_RECHECKED 6     /* knife-edge candidates re-evaluated in reference order */
-#define KVM_STAT_COUNT 7
+#define KVM_STAT_DTW_SEQUENTIAL 7 /* DTW: candidates within rounding of a tie with eps^2, decided by the sequential
+                                   * reference-ordered path (0 on continuous data) */
+#define KVM_STAT_COUNT 8
 
 /* ---- knobs (measurement only; defaults reproduce the reference's behaviour) ---------------------- */
 

@@ -471,6 +471,22 @@ static bool kvm_trace_on() {
     if (v < 0) v = getenv("KVM_TRACE") ? 1 : 0;
     return v == 1;
 }
+// KVM_DEBUG_SYNC=1 in the environment: wait for the stream after every stage of a DTW call and name it on stderr (finds a
+// kernel that does not return)
+static bool kvm_debug_sync_on() {
+    static int v = -1;
+    if (v < 0) v = getenv("KVM_DEBUG_SYNC") ? 1 : 0;
+    return v == 1;
+}
+#define KVM_DBG_SYNC(ctx, stream, label)                                                                      \
+    do {                                                                                                      \
+        if (kvm_debug_sync_on()) {                                                                            \
+            fprintf(stderr, "[kvm-dbg] %s ...", label);                                                       \
+            fflush(stderr);                                                                                   \
+            hipError_t e_ = hipStreamSynchronize(stream);                                                     \
+            fprintf(stderr, " %s\n", hipGetErrorString(e_));                                                  \
+        }                                                                                                     \
+    } while (0)
 #define KVM_TP(label)                                                                                         \
     do {                                                                                                      \
         if (kvm_trace_on()) {                                                                                 \
@@ -484,6 +500,7 @@ static bool kvm_trace_on() {
 // ---- plan: intervals -> runs -> tiles -------------------------------------------------------------------
 
 struct plan {
+    int32_t *chunk_lo = nullptr, *chunk_hi = nullptr;  // cNSM-DTW: data range of the chunk each interval is fetched in
     int32_t *left = nullptr, *right = nullptr;  // copies of the interval list in the pinned staging buffer (the runs are
     int64_t n_runs = 0;         // built from them on the GPU, kvm_plan_runs_kernel); n_runs = non-empty clipped intervals
     int64_t n_tiles = 0;        // tiles (class A tiles in hybrid mode)
@@ -567,6 +584,11 @@ static int build_plan(kvm_ctx *ctx, bool cnsm, int32_t m, const int32_t *left, c
                 snprintf(msg, sizeof msg, "left: %lld, length: %lld", (long long)begin, (long long)(end - begin + 1));
                 return fail(ctx, KVM_ERR_ILLEGAL_ARGUMENT, msg);
             }
+            if (pl.chunk_lo)  // the data envelope of the DTW cascade is built per fetched chunk (K/NormQueryEngineDtw.java:522-524)
+                for (int32_t p = beginIdx; p <= endIdx; p++) {
+                    pl.chunk_lo[p] = (int32_t)begin;
+                    pl.chunk_hi[p] = (int32_t)end;
+                }
         }
     }
     // totals only (launch geometry, buffer sizes): the per-run prefix sums are formed on the device from the same rule
@@ -665,7 +687,8 @@ static int ensure_envelope(kvm_ctx *ctx, int32_t rho, hipStream_t stream) {
 // device in ctx->b_counters.  `stream` is the stream to launch on.
 static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m, const int32_t *left,
                        const int32_t *right, int32_t k, int32_t shift, double epsilon, int32_t rho, double alpha,
-                       double beta, plan &pl, verify_out &out, hipStream_t stream, int64_t *kernel_ns) {
+                       double beta, plan &pl, verify_out &out, hipStream_t stream, int64_t *kernel_ns,
+                       kvm_query_dev &dtw_qd, kvm_dtw_aux &dtw_ax) {
     if (!ctx->d_series) return fail(ctx, KVM_ERR_NO_SERIES, "no series loaded");
     if (!query || m < 1 || k < 0 || (k > 0 && (!left || !right)))
         return fail(ctx, KVM_ERR_ILLEGAL_ARGUMENT, "bad query/interval arguments");
@@ -709,15 +732,22 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
     const bool use_qT = !dtw && ed_kernel == 4;
     const size_t qdot = dtw ? 0 : qdot0 + (use_qT ? (size_t)nchT * JL_CHUNK * 8 : 0);
     const size_t qexact_off = qmain + qdot;
-    const size_t qbytes = (qexact_off + ((cnsm && !dtw) ? (size_t)m * 12 : 0) + 15) / 16 * 16;
-    // the interval list follows the query block (left | right, each padded to 16 B); the runs built from it on the
-    // device follow that
-    const size_t lr_half = ((size_t)(k > 0 ? k : 0) * 4 + 15) / 16 * 16, lr_bytes = 2 * lr_half;
+    // DTW: the reference's summation order of the LB_Keogh loops and the query / its envelope in that order
+    // (uo | lo | qo | order) behind the main block
+    const size_t qbytes = (qexact_off + ((cnsm && !dtw) ? (size_t)m * 12 : 0) + (dtw ? (size_t)m * 28 : 0) + 15) / 16 * 16;
+    // the interval list follows the query block (left | right, each padded to 16 B; cNSM-DTW: + the chunk bounds per
+    // interval); the runs built from it on the device follow that
+    const bool chunks = cnsm && dtw;
+    const size_t lr_half = ((size_t)(k > 0 ? k : 0) * 4 + 15) / 16 * 16, lr_bytes = (chunks ? 4 : 2) * lr_half;
     int rc = ensure_pinned(ctx, qbytes + lr_bytes + 64);
     if (rc) return rc;
     char *hp = (char *)ctx->h_pinned;
     pl.left = (int32_t *)(hp + qbytes);
     pl.right = (int32_t *)(hp + qbytes + lr_half);
+    if (chunks) {
+        pl.chunk_lo = (int32_t *)(hp + qbytes + 2 * lr_half);
+        pl.chunk_hi = (int32_t *)(hp + qbytes + 3 * lr_half);
+    }
     rc = build_plan(ctx, cnsm, m, left, right, k, shift, tile_max, hybrid, pl);
     if (rc) return rc;
     if (out.own) {  // capacity: every evaluated window may be an answer
@@ -733,8 +763,10 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
     // while the host prepares the query block below.  Device layout: query block | left | right | runs | plan scratch.
     const size_t rbytes = (size_t)pl.n_runs * sizeof(kvm_run);
     const size_t plan_scratch = ((size_t)(k > 0 ? k : 0) / 256 + 1) * 32;  // block totals of kvm_launch_plan_runs
-    if ((rc = ensure(ctx, ctx->b_query, qbytes + lr_bytes + rbytes + plan_scratch + 64))) return rc;
+    const size_t rc_off = qbytes + lr_bytes + ((rbytes + 31) & ~(size_t)31) + ((plan_scratch + 31) & ~(size_t)31);
+    if ((rc = ensure(ctx, ctx->b_query, rc_off + (chunks ? (size_t)pl.n_runs * sizeof(int2) : 0) + 64))) return rc;
     kvm_run *d_runs_w = (kvm_run *)((char *)ctx->b_query.p + qbytes + lr_bytes);
+    int2 *d_run_chunk = chunks ? (int2 *)((char *)ctx->b_query.p + rc_off) : nullptr;
     if (rbytes) {
         int tile_log2 = 0;
         while ((1 << tile_log2) < tile_max) tile_log2++;
@@ -742,7 +774,8 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
         HIPCHK(ctx, kvm_launch_plan_runs(pl.left, pl.right, (int32_t *)((char *)ctx->b_query.p + qbytes),
                                          (int32_t *)((char *)ctx->b_query.p + qbytes + lr_half), k, shift,
                                          ctx->n - m + 1, hybrid, tile_log2, d_runs_w,
-                                         (char *)ctx->b_query.p + qbytes + lr_bytes + ((rbytes + 31) & ~(size_t)31), stream));
+                                         (char *)ctx->b_query.p + qbytes + lr_bytes + ((rbytes + 31) & ~(size_t)31), stream,
+                                         pl.chunk_lo, pl.chunk_hi, d_run_chunk));
     }
 
     // ---- query-side constants (host, sequential, exactly the reference's arithmetic) ----
@@ -829,6 +862,44 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
     if (dtw) {
         std::memcpy(hp + (size_t)m * 8, qu.data(), (size_t)m * 8);
         std::memcpy(hp + (size_t)m * 16, ql.data(), (size_t)m * 8);
+        // The reference's summation order of the LB_Keogh loops.  RSM-DTW: the reorder is commented out, order = identity
+        // (K/QueryEngineDtw.java:364-383).  cNSM-DTW: Arrays.sort with the comparator (int)(|o2| - |o1|)
+        // (K/NormQueryEngineDtw.java:475-478) -- inconsistent (the truncation makes most pairs "equal"), so the result
+        // depends on the sorting algorithm; this is a bottom-up stable merge sort (widths 1, 2, 4, ...; the right element is
+        // taken only when the comparator says "smaller"), the stand-in for TimSort that DESIGN.md section 2 documents.
+        double *h_uo = (double *)(hp + qexact_off), *h_lo = h_uo + m, *h_qo = h_lo + m;
+        int32_t *h_order = (int32_t *)(h_qo + m);
+        std::vector<int32_t> ord((size_t)m), tmp((size_t)m);
+        for (int i = 0; i < m; i++) ord[(size_t)i] = i;
+        if (cnsm) {
+            auto java_int = [](double v) -> int {  // (int) of a double: NaN -> 0, saturating
+                if (v != v) return 0;
+                if (v >= 2147483647.0) return 2147483647;
+                if (v <= -2147483648.0) return -2147483647 - 1;
+                return (int)v;
+            };
+            for (int w = 1; w < m; w *= 2) {
+                for (int lo = 0; lo < m; lo += 2 * w) {
+                    const int mid = std::min(lo + w, m), hi = std::min(lo + 2 * w, m);
+                    int i = lo, j = mid, o = lo;
+                    while (i < mid && j < hi) {
+                        // cmp(a[j], a[i]) < 0 with cmp(o1, o2) = (int)(|o2.value| - |o1.value|)
+                        if (java_int(std::fabs(q[(size_t)ord[(size_t)i]]) - std::fabs(q[(size_t)ord[(size_t)j]])) < 0) tmp[(size_t)o++] = ord[(size_t)j++];
+                        else tmp[(size_t)o++] = ord[(size_t)i++];
+                    }
+                    while (i < mid) tmp[(size_t)o++] = ord[(size_t)i++];
+                    while (j < hi) tmp[(size_t)o++] = ord[(size_t)j++];
+                }
+                ord.swap(tmp);
+            }
+        }
+        for (int i = 0; i < m; i++) {
+            const int o = ord[(size_t)i];
+            h_order[i] = o;
+            h_uo[i] = qu[(size_t)o];
+            h_lo[i] = ql[(size_t)o];
+            h_qo[i] = q[(size_t)o];
+        }
     }
     KVM_TP("  query prep + staging");
     // scratch of the running-sum replay of the exact pass (cNSM): flags + {mean,std} per window, counts per run
@@ -960,49 +1031,90 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
     } else {
         const int use_lb = (int)ctx->opt_lb_cascade;
         if ((rc = ensure(ctx, ctx->b_cands, (size_t)pl.windows * sizeof(kvm_cand) + 64))) return rc;
+        if ((rc = ensure(ctx, ctx->b_cands2, (size_t)pl.windows * sizeof(kvm_cand) + 64))) return rc;  // ambiguous candidates
+        if ((rc = ensure_envelope(ctx, rho, stream))) return rc;
+        if ((rc = ensure(ctx, ctx->b_aux, (size_t)kvm_dtw_dp_max_waves(ctx->num_cu) * 8 * (size_t)rho * sizeof(double) + 64))) return rc;
         kvm_cand *c1 = (kvm_cand *)ctx->b_cands.p;
+        kvm_dtw_aux &ax = dtw_ax;
+        const double *d_dtw = (const double *)((const char *)ctx->b_query.p + qexact_off);
+        ax.uo = d_dtw;
+        ax.lo = d_dtw + m;
+        ax.qo = d_dtw + 2 * (size_t)m;
+        ax.order = (const int32_t *)(d_dtw + 3 * (size_t)m);
+        ax.env_u = ctx->d_env_u;
+        ax.env_l = ctx->d_env_l;
+        ax.runs = d_runs_w;
+        ax.n_runs = pl.n_runs;
+        ax.run_chunk = d_run_chunk;
+        ax.patch = (double *)ctx->b_aux.p;
+        ax.ambig = (kvm_cand *)ctx->b_cands2.p;
+        ax.cb_exact = nullptr;
+        ax.tau = 1e-12 + 5e-16 * (double)m;  // a wave-parallel sum of m terms against the same terms added one by one
+        KVM_DBG_SYNC(ctx, stream, "plan / upload / envelope");
         if (use_lb) {
-            // (alpha, beta) filter + LB_Kim for every candidate, survivors re-tiled on the device; then the fused,
-            // LDS-tiled LB_Keogh(query envelope) over the trimmed tiles
-            kvm_tile *t2 = (kvm_tile *)ctx->b_tiles.p + n_tiles;  // room for 2 n_tiles entries
+            // (alpha, beta) filter + LB_Kim for every candidate, survivors re-tiled on the device; then LB_Keogh on the
+            // query envelope, in the reference's order, as a screen
+            kvm_tile *t2 = (kvm_tile *)ctx->b_tiles.p + n_tiles;
             HIPCHK(ctx, kvm_launch_retile_dtw(ctx->d_series, ctx->d_prefix, qd, d_tiles, n_tiles, t2, counters, stream));
-            HIPCHK(ctx, kvm_launch_dtw_lb_tiled(ctx->d_series, ctx->d_prefix, ctx->n, qd, t2, 2 * n_tiles, c1, counters,
-                                                counters + KVM_CNT_TILES_A, ctx->num_cu, stream));
-        }
-        else
-            HIPCHK(ctx, kvm_launch_dtw_filter(ctx->d_series, ctx->d_prefix, ctx->n, qd, d_tiles, n_tiles, 0, c1,
+            KVM_DBG_SYNC(ctx, stream, "retile_dtw");
+            HIPCHK(ctx, kvm_launch_dtw_screen(ctx->d_series, ctx->d_prefix, qd, ax, t2, n_tiles, counters + KVM_CNT_TILES_A, c1,
                                               counters, stream));
-        const kvm_cand *dp_in = c1;
-        const unsigned long long *dp_n = counters + KVM_CNT_CANDS1;
-        const double *dp_suffix = nullptr;
-        // segment length of the coarse LB_Keogh suffix: a multiple of 64 so that segments align with the lane-strided loops
-        const int32_t seg_len = (((m + KVM_DTW_NSEG - 1) / KVM_DTW_NSEG) + 63) / 64 * 64;
-        if (use_lb) {
-            if ((rc = ensure(ctx, ctx->b_cands2, (size_t)pl.windows * sizeof(kvm_cand) + 64))) return rc;
-            if ((rc = ensure_envelope(ctx, rho, stream))) return rc;
-            if ((rc = ensure(ctx, ctx->b_aux, (size_t)pl.windows * KVM_DTW_NSEG * sizeof(double) + 64))) return rc;
-            kvm_cand *c2 = (kvm_cand *)ctx->b_cands2.p;
-            HIPCHK(ctx, kvm_launch_dtw_keogh(ctx->d_series, ctx->d_env_u, ctx->d_env_l, ctx->n, qd, c1,
-                                             counters + KVM_CNT_CANDS1, pl.windows, c2, (double *)ctx->b_aux.p, seg_len,
-                                             counters, stream));
-            dp_in = c2;
-            dp_n = counters + KVM_CNT_CANDS2;
-            dp_suffix = (const double *)ctx->b_aux.p;
+            KVM_DBG_SYNC(ctx, stream, "dtw_screen");
+        } else {
+            HIPCHK(ctx, kvm_launch_dtw_filter(ctx->d_series, ctx->d_prefix, ctx->n, qd, d_tiles, n_tiles, 0, c1, counters,
+                                              stream));
         }
-        // cNSM: replay the reference's running sums for the candidates that reach the DP (exact mean/std and
-        // exact (alpha, beta) decision), so that the DP -- bit-exact per cell -- returns the reference's distance
+        const unsigned long long *dp_n = counters + KVM_CNT_CANDS1;
+        // cNSM: replay the reference's running sums for the candidates that reach the deciding stage (exact mean/std and
+        // exact (alpha, beta) decision), so that every value it forms is the reference's own
         if (cnsm)
-            HIPCHK(ctx, kvm_launch_exact_stats(ctx->d_series, qd, const_cast<kvm_cand *>(dp_in), dp_n, pl.windows, rws,
-                                               counters, ctx->num_cu, stream));
+            HIPCHK(ctx, kvm_launch_exact_stats(ctx->d_series, qd, c1, dp_n, pl.windows, rws, counters, ctx->num_cu, stream));
+        KVM_DBG_SYNC(ctx, stream, "exact_stats");
         if (ctx->opt_timing) HIPCHK(ctx, hipEventRecord(ctx->ev0, stream));  // time the DP kernel alone
-        HIPCHK(ctx, kvm_launch_dtw_dp(ctx->d_series, ctx->n, qd, dp_in, dp_suffix, seg_len, dp_n, pl.windows, out.d_off, out.d_dist,
-                                      out.cap, counters, ctx->num_cu, ctx->opt_dp_kernel == 1 ? 1 : 0, stream));
+        HIPCHK(ctx, kvm_launch_dtw_dp(ctx->d_series, ctx->n, qd, ax, c1, dp_n, pl.windows, out.d_off, out.d_dist, out.cap,
+                                      counters, ctx->num_cu, ctx->opt_dp_kernel == 1 ? 1 : 0, stream));
+        KVM_DBG_SYNC(ctx, stream, "dtw_dp");
+        dtw_qd = qd;
     }
     HIPCHK(ctx, hipEventRecord(ctx->ev_staged, stream));  // every copy out of h_pinned has been enqueued before this point
     ctx->staged_pending = true;
     if (ctx->opt_timing) {
         if (dtw) HIPCHK(ctx, hipEventRecord(ctx->ev1, stream));  // (ED: ev1 was recorded right after the ED kernel)
         ctx->timing_pending = true;  // read by finish_timing() after the call's synchronisation / in kvm_last_kernel_ns
+    }
+    return KVM_OK;
+}
+
+// DTW: the candidates the DP kernel could not decide within rounding (counters[KVM_CNT_AMBIG] of them, in ctx->b_cands2)
+// go through the sequential reference-ordered path (kvm_dtw_ref.hip), in batches that fit a bounded slot buffer (2m
+// doubles per candidate), each followed by a DP run that reads the exact cb[] arrays.  Answers are appended through the
+// same counters.  Called after the main pipeline's counters have reached the host (one extra synchronisation, only when
+// such candidates exist: never on continuous data, routinely on integer-valued data and for eps = 0).
+static int dtw_resolve_ambiguous(kvm_ctx *ctx, const kvm_query_dev &qd, const kvm_dtw_aux &ax, int64_t n_ambig, verify_out &out,
+                                 hipStream_t stream) {
+    if (n_ambig <= 0) return KVM_OK;
+    const size_t per = (size_t)2 * qd.m * sizeof(double);
+    int64_t batch = std::max<int64_t>(1, (int64_t)(((size_t)1 << 30) / per));
+    if (batch > n_ambig) batch = n_ambig;
+    int rc = ensure(ctx, ctx->b_aux2, (size_t)batch * per + 64);
+    if (rc) return rc;
+    unsigned long long *counters = (unsigned long long *)ctx->b_counters.p;
+    kvm_cand *cands = (kvm_cand *)ctx->b_cands2.p;
+    double *slots = (double *)ctx->b_aux2.p;
+    kvm_dtw_aux ax2 = ax;
+    ax2.cb_exact = slots;
+    ax2.ambig = nullptr;
+    if (kvm_trace_on())
+        fprintf(stderr, "[kvm] dtw sequential path: %lld candidates, m %d rho %d, batches of %lld\n", (long long)n_ambig, qd.m,
+                qd.rho, (long long)batch);
+    for (int64_t off = 0; off < n_ambig; off += batch) {
+        const int64_t nb = std::min(batch, n_ambig - off);
+        HIPCHK(ctx, kvm_launch_dtw_ref_chains(ctx->d_series, qd, ax, cands + off, nb, slots, stream));
+        KVM_DBG_SYNC(ctx, stream, "dtw_ref_chains");
+        HIPCHK(ctx, kvm_launch_set_u64(counters + KVM_CNT_CANDS2, (unsigned long long)nb, counters + KVM_CNT_QUEUE, 0ULL, stream));
+        HIPCHK(ctx, kvm_launch_dtw_dp(ctx->d_series, ctx->n, qd, ax2, cands + off, counters + KVM_CNT_CANDS2, nb, out.d_off,
+                                      out.d_dist, out.cap, counters, ctx->num_cu, ctx->opt_dp_kernel == 1 ? 1 : 0, stream));
+        KVM_DBG_SYNC(ctx, stream, "dtw_dp (exact cb)");
     }
     return KVM_OK;
 }
@@ -1019,10 +1131,14 @@ static int verify_host(kvm_ctx *ctx, int variant, const double *query, int32_t m
     int rc;
     verify_out out{nullptr, nullptr, 0, true};
     int64_t kernel_ns = 0;
+    kvm_query_dev dtw_qd;
+    kvm_dtw_aux dtw_ax;
     rc = run_variant(ctx, variant, query, m, left, right, k, shift, epsilon, rho, alpha, beta, pl, out, ctx->stream,
-                     &kernel_ns);
+                     &kernel_ns, dtw_qd, dtw_ax);
     if (rc) return rc;
     const int64_t worst = out.cap;
+    const bool is_dtw = variant == V_RSM_DTW || variant == V_CNSM_DTW;
+    int64_t n_sequential = 0;
     KVM_TP("run_variant (launch)");
     // One synchronisation in the common case: the counters and the first KVM_SPEC_ANSWERS answers are copied back
     // together (answers are rare); a second copy only when there are more.
@@ -1031,18 +1147,25 @@ static int verify_host(kvm_ctx *ctx, int variant, const double *query, int32_t m
     const int64_t spec = std::min<int64_t>(KVM_SPEC_ANSWERS, worst);
     std::vector<int32_t> off;
     std::vector<double> dist;
-    if (pl.n_tiles + pl.n_tiles_b > 0) {
+    for (int pass = 0; pass < 2 && pl.n_tiles + pl.n_tiles_b > 0; pass++) {
         if (!ctx->h_readback)
             HIPCHK(ctx, hipHostMalloc(&ctx->h_readback, KVM_CNT_TOTAL * 8 + KVM_SPEC_ANSWERS * 12 + 64, hipHostMallocDefault));
         HIPCHK(ctx, kvm_launch_readback((const unsigned long long *)ctx->b_counters.p, out.d_off, out.d_dist, spec,
                                         ctx->h_readback, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         std::memcpy(hc, ctx->h_readback, sizeof hc);
+        if (pass == 0 && is_dtw && hc[KVM_CNT_AMBIG] > 0) {
+            // candidates within rounding of a tie with eps^2: sequential reference-ordered path, then read back again
+            n_sequential = (int64_t)hc[KVM_CNT_AMBIG];
+            if ((rc = dtw_resolve_ambiguous(ctx, dtw_qd, dtw_ax, n_sequential, out, ctx->stream))) return rc;
+            continue;
+        }
         const int64_t got = std::min<int64_t>((int64_t)hc[KVM_CNT_ANSWERS], spec);
         const int32_t *hoff = (const int32_t *)((const unsigned long long *)ctx->h_readback + KVM_CNT_TOTAL);
         const double *hdist = (const double *)(hoff + ((spec + 1) & ~(int64_t)1));
         off.assign(hoff, hoff + got);
         dist.assign(hdist, hdist + got);
+        break;
     }
     KVM_TP("sync + counters D2H");
     if (kvm_trace_on())
@@ -1121,11 +1244,11 @@ static int verify_host(kvm_ctx *ctx, int variant, const double *query, int32_t m
     const bool dtw = variant == V_RSM_DTW || variant == V_CNSM_DTW;
     r->stats[KVM_STAT_PASS_FILTER] = cnsm ? (int64_t)hc[KVM_CNT_PASS_FILTER] : pl.windows;
     r->stats[KVM_STAT_RECHECKED] = (int64_t)hc[KVM_CNT_RECHECKED];
+    r->stats[KVM_STAT_DTW_SEQUENTIAL] = n_sequential;
     if (dtw) {
         r->stats[KVM_STAT_PASS_LB_KIM] = (int64_t)hc[KVM_CNT_PASS_KIM];
         r->stats[KVM_STAT_PASS_LB_KEOGH] = ctx->opt_lb_cascade ? (int64_t)hc[KVM_CNT_PASS_KEOGH] : (int64_t)hc[KVM_CNT_PASS_KIM];
-        r->stats[KVM_STAT_PASS_LB_KEOGH2] =
-            ctx->opt_lb_cascade ? (int64_t)hc[KVM_CNT_PASS_KEOGH2] : (int64_t)hc[KVM_CNT_PASS_KIM];
+        r->stats[KVM_STAT_PASS_LB_KEOGH2] = (int64_t)hc[KVM_CNT_PASS_KEOGH2];  // DP runs started
     }
     finish_timing(ctx);
     kernel_ns = ctx->last_kernel_ns;
@@ -1167,9 +1290,21 @@ extern "C" int kvm_verify_device(kvm_ctx *ctx, int32_t variant, const double *qu
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
     plan pl;
     verify_out out{d_out_off, d_out_dist, cap, false};
-    int rc = run_variant(ctx, variant, query, m, left, right, k, shift, epsilon, rho, alpha, beta, pl, out, s, nullptr);
+    kvm_query_dev dtw_qd;
+    kvm_dtw_aux dtw_ax;
+    int rc = run_variant(ctx, variant, query, m, left, right, k, shift, epsilon, rho, alpha, beta, pl, out, s, nullptr, dtw_qd,
+                         dtw_ax);
     if (rc) return rc;
     if (cnt_candidate) *cnt_candidate = pl.cnt_candidate;
+    if (variant >= V_RSM_DTW && pl.n_tiles + pl.n_tiles_b > 0) {
+        // DTW: the number of candidates that need the sequential reference-ordered path is only known on the device;
+        // this one small read is the only point where a kvm_verify_device call waits for the stream
+        unsigned long long n_ambig = 0;
+        HIPCHK(ctx, hipMemcpyAsync(&n_ambig, (unsigned long long *)ctx->b_counters.p + KVM_CNT_AMBIG, sizeof n_ambig,
+                                   hipMemcpyDeviceToHost, s));
+        HIPCHK(ctx, hipStreamSynchronize(s));
+        if (n_ambig > 0 && (rc = dtw_resolve_ambiguous(ctx, dtw_qd, dtw_ax, (int64_t)n_ambig, out, s))) return rc;
+    }
     if (pl.n_tiles + pl.n_tiles_b == 0) {
         HIPCHK(ctx, hipMemsetAsync(d_out_count, 0, sizeof(int64_t), s));
     } else {

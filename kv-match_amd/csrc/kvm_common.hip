@@ -61,7 +61,10 @@ __global__ __launch_bounds__(PLAN_THREADS) void kvm_plan_totals_kernel(const int
 __global__ __launch_bounds__(PLAN_THREADS) void kvm_plan_runs_kernel(const int32_t *__restrict__ left, const int32_t *__restrict__ right,
                                                                     int32_t k, int32_t shift, int64_t hi_max, int hybrid,
                                                                     int tile_log2, const plan_sums *__restrict__ block_tot,
-                                                                    int scanned, kvm_run *__restrict__ runs) {
+                                                                    int scanned, kvm_run *__restrict__ runs,
+                                                                    const int32_t *__restrict__ chunk_lo,
+                                                                    const int32_t *__restrict__ chunk_hi,
+                                                                    int2 *__restrict__ run_chunk) {
     __shared__ plan_sums wave_tot[PLAN_THREADS / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // totals of the blocks before this one: summed here (few blocks), or already scanned by kvm_plan_scan_kernel
@@ -95,6 +98,7 @@ __global__ __launch_bounds__(PLAN_THREADS) void kvm_plan_runs_kernel(const int32
         r.tile_base_b = it.tiles_b ? off.tb + inc.tb - mine.tb : -1;
         r.win_base = off.w + inc.w - mine.w;
         runs[off.nr + inc.nr - mine.nr] = r;
+        if (run_chunk) run_chunk[off.nr + inc.nr - mine.nr] = make_int2(chunk_lo[p], chunk_hi[p]);
     }
 }
 
@@ -130,7 +134,7 @@ __global__ __launch_bounds__(1024) void kvm_plan_scan_kernel(plan_sums *__restri
 // `scratch`: 32 B per 256 intervals (block totals)
 hipError_t kvm_launch_plan_runs(const int32_t *src_left, const int32_t *src_right, int32_t *left, int32_t *right, int32_t k,
                                 int32_t shift, int64_t hi_max, bool hybrid, int tile_log2, kvm_run *runs, void *scratch,
-                                hipStream_t s) {
+                                hipStream_t s, const int32_t *chunk_lo, const int32_t *chunk_hi, int2 *run_chunk) {
     if (k <= 0) return hipSuccess;
     const int64_t blocks = ((int64_t)k + PLAN_THREADS - 1) / PLAN_THREADS;
     plan_sums *bt = reinterpret_cast<plan_sums *>(scratch);
@@ -139,7 +143,20 @@ hipError_t kvm_launch_plan_runs(const int32_t *src_left, const int32_t *src_righ
     const int scanned = blocks > PLAN_SCAN_ABOVE;
     if (scanned) hipLaunchKernelGGL(kvm_plan_scan_kernel, dim3(1), dim3(1024), 0, s, bt, blocks);
     hipLaunchKernelGGL(kvm_plan_runs_kernel, dim3((unsigned)blocks), dim3(PLAN_THREADS), 0, s, left, right, k, shift, hi_max,
-                       hybrid ? 1 : 0, tile_log2, bt, scanned, runs);
+                       hybrid ? 1 : 0, tile_log2, bt, scanned, runs, chunk_lo, chunk_hi, run_chunk);
+    return hipGetLastError();
+}
+
+// two device words set in stream order (count + work-queue head of a follow-up DP launch)
+__global__ void kvm_set_u64_kernel(unsigned long long *a, unsigned long long va, unsigned long long *b, unsigned long long vb) {
+    if (threadIdx.x == 0) {
+        *a = va;
+        if (b) *b = vb;
+    }
+}
+hipError_t kvm_launch_set_u64(unsigned long long *a, unsigned long long va, unsigned long long *b, unsigned long long vb,
+                              hipStream_t s) {
+    hipLaunchKernelGGL(kvm_set_u64_kernel, dim3(1), dim3(64), 0, s, a, va, b, vb);
     return hipGetLastError();
 }
 

@@ -1,18 +1,22 @@
-// kvm_dtw.hip -- DTW verification cascade (RSM-DTW, cNSM-DTW) for gfx950.
+// kvm_dtw.hip -- the deciding stage of the DTW cascade (RSM-DTW, cNSM-DTW) for gfx950.
 //
-// Replaces K/QueryEngineDtw.java:401-451 and K/NormQueryEngineDtw.java:540-599 plus the static
-// functions of K/utils/DtwUtils.java.  Stages (each a kernel, survivors compacted between stages):
-//   1. filter  : per-window mean/std from the prefix sums, (alpha,beta) test (cNSM only), LB_Kim.
-//   2. keogh   : LB_Keogh against the query envelope and against the (global) data envelope.
-//   3. dp      : Sakoe-Chiba banded DP, one wavefront per surviving candidate.
-// The answer set is {filter-passing candidates with banded DTW <= eps^2}: the lower bounds only prune
-// (SURVEY 8a "semantic facts"), so stages 1-2 can be switched off (KVM_OPT_LB_CASCADE=0) without
-// changing any answer.
-//
-// Every DP cell performs exactly the reference's operations, min(min(x,y),z) + (a-b)*(a-b)
-// (K/utils/DtwUtils.java:316), in fp64 without contraction, so the DP value is bit-identical to the
-// reference's for identical inputs regardless of the order in which cells are visited.
-#include "kvm_internal.h"
+// Replaces K/QueryEngineDtw.java:401-451 and K/NormQueryEngineDtw.java:540-599 plus the static functions of
+// K/utils/DtwUtils.java, for the candidates the screens (kvm_dtw_lb.hip) could not certainly drop.  One wavefront per
+// candidate, with the replayed (reference-exact) mean/std:
+//   prologue : lbKimHierarchy as written (:149-189); lbKeoghCumulative and lbKeoghDataCumulative (:206-257) as
+//              wave-parallel ORDERED scans of exactly rounded terms -- the reference stops each loop at its first partial
+//              sum >= eps^2 and passes on iff the value is <= eps^2; the data envelope clipped at the ends of the fetched
+//              chunk as lowerUpperLemire builds it (:50-91);
+//   DP       : Sakoe-Chiba banded DP swept by anti-diagonals; every cell performs exactly the reference's operations,
+//              min(min(x,y),z) + (a-b)*(a-b) (:316), in fp64 without contraction, so the cell values are bit-identical to
+//              the reference's regardless of the order in which cells are visited;
+//   row test : the reference returns `min_cost + cb[i+r+1]` at the first row where that is >= eps^2 (:324-326) and the
+//              callers accept `<= eps^2`: the row minima are tracked alongside the sweep and tested against the suffix
+//              sums of the larger LB_Keogh bound's terms (K/NormQueryEngineDtw.java:576-587).
+// Whatever lands within rounding of eps^2 in a wave-parallel sum is "ambiguous" and goes to the sequential path
+// (kvm_dtw_ref.hip), which returns exact cb[] arrays for a second run of the same DP that compares without tolerance.
+// With KVM_OPT_LB_CASCADE=0 the screens are skipped and this stage sees every filter-passing candidate: same answers.
+#include "kvm_dtw_ref.h"
 
 #define DTW_INF 1e20  // K/utils/DtwUtils.java:24
 
@@ -120,131 +124,192 @@ hipError_t kvm_launch_dtw_filter(const double *series, const double2 *prefix, in
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Stage 2: one WORKGROUP per survivor.  LB_Keogh (query envelope, K/utils/DtwUtils.java:206-222) and LB_Keogh on
-// the data envelope (K/utils/DtwUtils.java:238-257), both summed over all m positions in lane-strided order (the
-// reference's order[] permutation and early exit only change the summation order / skip work).  A candidate
-// survives iff both bounds are <= eps^2.
-//
-// The per-position contributions of the larger bound feed the DP's early abandon in the reference as a suffix
-// sum cb[] (K/NormQueryEngineDtw.java:576-587, used at K/utils/DtwUtils.java:324-326).  Here the positions are
-// grouped into KVM_DTW_NSEG segments of seg_len points; the kernel emits the COARSE suffix sums
-//     suffix[s] = sum of cb[pos] over pos >= s * seg_len
-// (16 doubles per survivor instead of m), which is all the DP kernel needs because it tests for abandonment
-// every 64 macro-steps anyway.  A coarse suffix is a subset sum of non-negative terms, i.e. still a lower bound.
-//
-// The four waves of the workgroup take four segments each.  With thousands of survivors the kernel is memory-bound
-// (~6 TB/s of L2 + HBM reads) and the layout does not matter; with a few hundred (a query with few answers) it is a
-// chain of global-load latencies per survivor, which this cuts by four (80 -> 25 us).
-__global__ __launch_bounds__(256) void kvm_dtw_keogh_kernel(const double *__restrict__ series,
-                                                            const double *__restrict__ env_u,
-                                                            const double *__restrict__ env_l, kvm_query_dev qd,
-                                                            const kvm_cand *__restrict__ in,
-                                                            const unsigned long long *__restrict__ d_n_in,
-                                                            kvm_cand *__restrict__ out, double *__restrict__ out_suffix,
-                                                            int32_t seg_len, unsigned long long *__restrict__ counters) {
-    __shared__ double segs[2][KVM_DTW_NSEG];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const unsigned long long n_in = *d_n_in;
-    const int m = qd.m;
-    const double eps2 = qd.eps2;
-    for (unsigned long long idx = blockIdx.x; idx < n_in; idx += gridDim.x) {
-        const kvm_cand c = in[idx];  // (the same record in every thread: all branches on it are workgroup-uniform)
-        const double *__restrict__ x = series + (c.start - 1);
-        const double inv = 1.0 / c.std;
-        // pruning threshold: eps^2 plus the guard band that covers the sigma uncertainty (cNSM) and summation order
-        const double lim = qd.normalised ? c.lim : eps2 * (1.0 + 1e-9);
-        if (!(c.std == c.std)) {  // degenerate sigma in the pruning arithmetic: no bound, the exact pass decides
-            if (threadIdx.x == 0) {
-                atomicAdd(&counters[KVM_CNT_PASS_KEOGH], 1ULL);
-                atomicAdd(&counters[KVM_CNT_PASS_KEOGH2], 1ULL);
-                const unsigned long long o = atomicAdd(&counters[KVM_CNT_CANDS2], 1ULL);
-                out[o] = c;
-                for (int s = 0; s < KVM_DTW_NSEG; s++) out_suffix[o * KVM_DTW_NSEG + s] = 0.0;
-            }
-            continue;
-        }
-        for (int s = wave; s < KVM_DTW_NSEG; s += 4) {
-            const int j1 = min(m, (s + 1) * seg_len);
-            double p = 0.0;
-#pragma unroll 4
-            for (int j = s * seg_len + lane; j < j1; j += 64) {
-                const double v = (x[j] - c.mean) * inv;
-                const double hi = qd.qu[j], lo = qd.ql[j];
-                double d = 0.0;
-                if (v > hi) d = dsq(v, hi);
-                else if (v < lo) d = dsq(v, lo);
-                p += d;
-            }
-            p = kvm_wave_sum(p);
-            if (lane == 0) segs[0][s] = p;
-        }
-        __syncthreads();
-        double lb1 = 0.0;
+// Shared by both DP forms: wave-cooperative pieces of the exact decision (all 64 lanes of the wavefront take part).
+enum { DP_REJECT = 0, DP_RUN = 1, DP_AMBIG = 2 };
+
+__device__ __forceinline__ double dp_scan_add(double v, int lane) {  // inclusive, in lane order
 #pragma unroll
-        for (int s = 0; s < KVM_DTW_NSEG; s++) lb1 += segs[0][s];
-        if (!(lb1 <= lim)) {
-            __syncthreads();  // segs[0] is rewritten by the next survivor
-            continue;
-        }
-        bool pass2 = true;
-        double lb2 = 0.0;
-        if (env_u) {
-            const double *__restrict__ uu = env_u + (c.start - 1);
-            const double *__restrict__ ll = env_l + (c.start - 1);
-            for (int s = wave; s < KVM_DTW_NSEG; s += 4) {
-                const int j1 = min(m, (s + 1) * seg_len);
-                double p = 0.0;
-#pragma unroll 4
-                for (int j = s * seg_len + lane; j < j1; j += 64) {
-                    const double hi = (uu[j] - c.mean) * inv, lo = (ll[j] - c.mean) * inv;
-                    const double qv = qd.q[j];
-                    double d = 0.0;
-                    if (qv > hi) d = dsq(qv, hi);
-                    else if (qv < lo) d = dsq(qv, lo);
-                    p += d;
-                }
-                p = kvm_wave_sum(p);
-                if (lane == 0) segs[1][s] = p;
-            }
-            __syncthreads();
+    for (int o = 1; o < 64; o <<= 1) {
+        const double t = __shfl_up(v, o, 64);
+        if (lane >= o) v += t;
+    }
+    return v;
+}
+__device__ __forceinline__ double dp_sel_max(double a, double b) { return (b > a) ? b : a; }  // pure selections, as the
+__device__ __forceinline__ double dp_sel_min(double a, double b) { return (b < a) ? b : a; }  // envelope is (:50-91)
+__device__ __forceinline__ void dp_scan_maxmin(double &mx, double &mn, int lane) {  // inclusive running max / min
 #pragma unroll
-            for (int s = 0; s < KVM_DTW_NSEG; s++) lb2 += segs[1][s];
-            pass2 = lb2 <= lim;
+    for (int o = 1; o < 64; o <<= 1) {
+        const double tx = __shfl_up(mx, o, 64), tn = __shfl_up(mn, o, 64);
+        if (lane >= o) {
+            mx = dp_sel_max(mx, tx);
+            mn = dp_sel_min(mn, tn);
         }
-        if (threadIdx.x == 0) {
-            atomicAdd(&counters[KVM_CNT_PASS_KEOGH], 1ULL);
-            if (pass2) {
-                atomicAdd(&counters[KVM_CNT_PASS_KEOGH2], 1ULL);
-                const unsigned long long o = atomicAdd(&counters[KVM_CNT_CANDS2], 1ULL);
-                out[o] = c;
-                // larger bound wins, as K/NormQueryEngineDtw.java:577-587; suffix over segments
-                const int which = (env_u && !(lb1 > lb2)) ? 1 : 0;
-                double run = 0.0;
-                for (int s = KVM_DTW_NSEG - 1; s >= 0; s--) {
-                    run += segs[which][s];
-                    out_suffix[o * KVM_DTW_NSEG + s] = run;
-                }
-            }
-        }
-        __syncthreads();  // segs are rewritten by the next survivor
     }
 }
 
-hipError_t kvm_launch_dtw_keogh(const double *series, const double *env_u, const double *env_l, int64_t n,
-                                const kvm_query_dev &qd, const kvm_cand *in, const unsigned long long *d_n_in,
-                                int64_t max_in, kvm_cand *out, double *out_suffix, int32_t seg_len,
-                                unsigned long long *counters, hipStream_t s) {
-    (void)n;
-    if (max_in <= 0) return hipSuccess;
-    int64_t blocks = max_in;  // one workgroup per survivor, 8 resident per CU
-    if (blocks > 256 * 8) blocks = 256 * 8;
-    hipLaunchKernelGGL(kvm_dtw_keogh_kernel, dim3((unsigned)blocks), dim3(256), 0, s, series, env_u, env_l, qd, in,
-                       d_n_in, out, out_suffix, seg_len, counters);
-    return hipGetLastError();
+// What the prologue hands to the sweep: which bound's terms form cb[] (0: query envelope, 1: data envelope), their
+// total, and the geometry of the clipped data envelope.
+struct dp_plan {
+    int which;
+    double total;
+    int32_t cbeg, cend, sb;  // fetched chunk [cbeg, cend] (1-based points); sb = first point of the suffix patch
+};
+
+// Upper / lower data envelope at 1-based point p as the reference builds it over the fetched chunk:
+// max / min of data[max(cbeg, p-r) .. min(cend, p+r)].  Interior points come from the whole-series envelope; within r of a
+// chunk end from the wave's patch: running max/min from cbeg (PM) and towards cend (SM), 2r entries each.
+__device__ __forceinline__ void dp_env_at(const kvm_dtw_aux &ax, const double *__restrict__ patch, int r, const dp_plan &pl,
+                                          int32_t p, double &U, double &L) {
+    if (p - r < pl.cbeg) {
+        const int t = min(pl.cend, p + r) - pl.cbeg;
+        U = patch[t];
+        L = patch[2 * r + t];
+    } else if (p + r > pl.cend) {
+        const int t = p - r - pl.sb;
+        U = patch[4 * r + t];
+        L = patch[6 * r + t];
+    } else {
+        U = ax.env_u[p - 1];
+        L = ax.env_l[p - 1];
+    }
+}
+
+// term k (natural window position) of the bound chosen for cb[]: cb1[k] / cb2[k] of K/NormQueryEngineDtw.java:559-575
+__device__ __forceinline__ double dp_cb_term(const double *__restrict__ x, const kvm_query_dev &qd, const kvm_dtw_aux &ax,
+                                             const double *__restrict__ patch, const dp_plan &pl, int32_t start, double mean,
+                                             double sd, int k) {
+    if (pl.which == 0) return dref_term_q((x[k] - mean) / sd, qd.qu[k], qd.ql[k]);
+    double U, L;
+    dp_env_at(ax, patch, qd.rho, pl, start + k, U, L);
+    return dref_term_d(qd.q[k], U, L, mean, sd);
+}
+
+// The cascade in front of the DP for one candidate (K/NormQueryEngineDtw.java:555-587), wave-cooperative.
+__device__ int dp_prologue(const double *__restrict__ series, const kvm_query_dev &qd, const kvm_dtw_aux &ax,
+                           const kvm_cand &c, int lane, double *__restrict__ patch, dp_plan &pl) {
+    const int m = qd.m, r = qd.rho;
+    const double E = qd.eps2, mean = c.mean, sd = c.std;
+    const double *__restrict__ x = series + (c.start - 1);
+    if (m >= 6) {  // (below that the reference's bound indexes outside the window; every entry point requires m >= 25)
+        const double kim = dref_kim(x, qd.q, m, mean, sd, E);
+        if (!(kim <= E)) return DP_REJECT;  // :556
+    }
+    const double Elo = E * (1.0 - ax.tau), Ehi = E * (1.0 + ax.tau);
+    // eps^2 == 0: the loops `lb < bsf` do not even start and row 0 of the DP already "reaches" bsf -- sequential path
+    if (!(0.0 < Elo)) return DP_AMBIG;
+    // ---- lbKeoghCumulative: terms in the reference's order, inclusive scan = its partial sums up to rounding ----
+    double carry = 0.0;
+    for (int base = 0; base < m; base += 64) {
+        const int i = base + lane;
+        double d = 0.0;
+        if (i < m) d = dref_term_q((x[ax.order[i]] - mean) / sd, ax.uo[i], ax.lo[i]);
+        const double S = dp_scan_add(d, lane) + carry;
+        const unsigned long long bal = __ballot(i < m && !(S < Elo));
+        if (bal) {  // the reference's loop stops here; it passes the candidate on only if the value is <= eps^2
+            const double Sf = kvm_readlane_f64(S, __ffsll((long long)bal) - 1);
+            return (Sf > Ehi) ? DP_REJECT : DP_AMBIG;
+        }
+        carry = kvm_readlane_f64(S, 63);
+    }
+    const double S1 = carry;  // (< eps^2 (1 - tau): the loop ran to the end, cb1[] is complete)
+    // ---- the data envelope at the ends of the fetched chunk ----
+    dref_chunk(ax, m, c.run_start, pl.cbeg, pl.cend);
+    pl.sb = max(pl.cbeg, pl.cend - 2 * r + 1);
+    const int32_t s1 = c.start, e1 = c.start + m - 1;
+    if (r > 0 && (s1 - r < pl.cbeg || e1 + r > pl.cend)) {
+        if (s1 - r < pl.cbeg) {
+            const int32_t last = min(pl.cend, pl.cbeg + 2 * r - 1);
+            double cx = -__builtin_huge_val(), cn = __builtin_huge_val();
+            for (int32_t base = pl.cbeg; base <= last; base += 64) {
+                const int32_t t = base + lane;
+                const double v = series[min(t, last) - 1];
+                double mx = v, mn = v;  // (lanes past `last` repeat the last point: no effect on a running max / min)
+                dp_scan_maxmin(mx, mn, lane);
+                mx = dp_sel_max(cx, mx);
+                mn = dp_sel_min(cn, mn);
+                if (t <= last) {
+                    patch[t - pl.cbeg] = mx;
+                    patch[2 * r + (t - pl.cbeg)] = mn;
+                }
+                cx = kvm_readlane_f64(mx, 63);
+                cn = kvm_readlane_f64(mn, 63);
+            }
+        }
+        if (e1 + r > pl.cend) {
+            double cx = -__builtin_huge_val(), cn = __builtin_huge_val();
+            for (int32_t base = pl.cend; base >= pl.sb; base -= 64) {
+                const int32_t t = base - lane;
+                const double v = series[max(t, pl.sb) - 1];
+                double mx = v, mn = v;
+                dp_scan_maxmin(mx, mn, lane);
+                mx = dp_sel_max(cx, mx);
+                mn = dp_sel_min(cn, mn);
+                if (t >= pl.sb) {
+                    patch[4 * r + (t - pl.sb)] = mx;
+                    patch[6 * r + (t - pl.sb)] = mn;
+                }
+                cx = kvm_readlane_f64(mx, 63);
+                cn = kvm_readlane_f64(mn, 63);
+            }
+        }
+        __threadfence();  // the patch is read back by other lanes of this wavefront (through the CU's L1)
+    }
+    // ---- lbKeoghDataCumulative, same form ----
+    carry = 0.0;
+    for (int base = 0; base < m; base += 64) {
+        const int i = base + lane;
+        double d = 0.0;
+        if (i < m) {
+            double U, L;
+            dp_env_at(ax, patch, r, pl, c.start + ax.order[i], U, L);
+            d = dref_term_d(ax.qo[i], U, L, mean, sd);
+        }
+        const double S = dp_scan_add(d, lane) + carry;
+        const unsigned long long bal = __ballot(i < m && !(S < Elo));
+        if (bal) {
+            const double Sf = kvm_readlane_f64(S, __ffsll((long long)bal) - 1);
+            return (Sf > Ehi) ? DP_REJECT : DP_AMBIG;
+        }
+        carry = kvm_readlane_f64(S, 63);
+    }
+    const double S2 = carry;
+    // ---- `if (lbK > lbK2)` (K/NormQueryEngineDtw.java:577): which bound's terms become cb[] ----
+    if (S1 == 0.0 && S2 == 0.0) {  // every term of both is zero: cb[] is all zeros either way
+        pl.which = 1;
+        pl.total = 0.0;
+    } else if (fabs(S1 - S2) > ax.tau * fmax(S1, S2)) {
+        pl.which = (S1 > S2) ? 0 : 1;
+        pl.total = (S1 > S2) ? S1 : S2;
+    } else {
+        return DP_AMBIG;  // the two sequential sums may compare either way
+    }
+    return DP_RUN;
+}
+
+// Row test over the macro-steps (register form) / rows (generic form) of one chunk: lane t holds the minimum `rv` of a
+// completed row i and tests `min_cost + cb[i + r + 1] >= bsf` (K/utils/DtwUtils.java:324-326), valid iff i + r < m - 1.
+//   approximate cb (cbv = total - prefix, off by <= 2 tau total <= 2 tau eps^2): a value within `tol` of eps^2 is ambiguous;
+//   exact cb (second run, arrays from kvm_dtw_ref.hip): the reference's comparison itself.
+// Returns 0: no row of the chunk reaches eps^2; 1: the first that does is certainly above (reject); 2: ambiguous;
+// 3: exact mode, first row >= eps^2, its value in `value` (an answer iff <= eps^2, i.e. == eps^2).
+__device__ __forceinline__ int dp_row_test(bool valid, double rv, double cbv, double E, double tol, bool exact, double &value) {
+    const double B = rv + cbv;
+    const unsigned long long bal = __ballot(valid && (exact ? (B >= E) : !(B < E - tol)));
+    if (!bal) return 0;
+    const double Bf = kvm_readlane_f64(B, __ffsll((long long)bal) - 1);
+    value = Bf;
+    if (exact) return 3;
+    return (Bf > E + tol) ? 1 : 2;
+}
+
+__device__ __forceinline__ void dp_emit_ambig(const kvm_dtw_aux &ax, unsigned long long *__restrict__ counters,
+                                              const kvm_cand &c, int lane) {
+    if (lane == 0) ax.ambig[atomicAdd(&counters[KVM_CNT_AMBIG], 1ULL)] = c;
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Stage 3 (generic LDS form): banded DP swept by anti-diagonals, one wavefront per candidate.
+// DP, generic form (any rho): banded DP swept by anti-diagonals, one wavefront per candidate, band rows in LDS.
 //
 // Band coordinate k = j - i + r in [0, 2r] (the reference's index into cost[], K/utils/DtwUtils.java:290).
 // On anti-diagonal d = i + j only cells with k == d + r (mod 2) exist; they depend on k-1 (y: same row)
@@ -255,19 +320,19 @@ hipError_t kvm_launch_dtw_keogh(const double *series, const double *env_u, const
 // Cells outside the matrix are never written and stay at INF = 1e20, which is what the reference
 // substitutes for them (K/utils/DtwUtils.java:297-311).
 //
-// Early abandon: every path crosses diagonal d or d-1, and costs only grow along a path, so
-// min(E u O) is a lower bound of the final DTW value; the candidate is dropped once it exceeds eps^2.
-// (The reference abandons per row with the LB_Keogh suffix sums, K/utils/DtwUtils.java:324-326; both
-// tests only ever discard candidates whose DTW distance exceeds eps^2.)
+// Row i is complete after diagonal i + min(m-1, i+r); the rows the reference tests (i + r < m - 1) complete on diagonal
+// 2i + r, in increasing order of i, so the first row whose bound reaches eps^2 is found in the reference's order.
 extern __shared__ double kvm_dp_lds[];
 
-// `scratch` != nullptr: the two band rows and the window do not fit the LDS (m + 2 rho > 20 000 or so) and live in a
-// per-workgroup slice of global memory instead -- same code, one wavefront per workgroup, so the workgroup barrier
-// (a workgroup-scope fence) orders its stores and loads through the CU's own L1.
+// doubles per candidate: band rows E, O (r+1 each), window A, cb[] and row minima (m each), envelope patch (8r)
+__host__ __device__ static inline size_t dp_lds_doubles(int m, int r) { return (size_t)2 * (r + 1) + (size_t)3 * m + (size_t)8 * r; }
+
+// `scratch` != nullptr: the arrays do not fit the LDS (m + 2 rho > 6 000 or so) and live in a per-workgroup slice of
+// global memory instead -- same code, one wavefront per workgroup, so the workgroup barrier (a workgroup-scope fence)
+// orders its stores and loads through the CU's own L1.
 template <bool ABANDON>
 __global__ __launch_bounds__(64) void kvm_dtw_dp_lds_kernel(const double *__restrict__ series, kvm_query_dev qd,
-                                                            const kvm_cand *__restrict__ in,
-                                                            const double *__restrict__ suffix, int32_t seg_len,
+                                                            kvm_dtw_aux ax, const kvm_cand *__restrict__ in,
                                                             const unsigned long long *__restrict__ d_n_in,
                                                             int32_t *__restrict__ out_off,
                                                             double *__restrict__ out_dist, int64_t cap,
@@ -277,29 +342,62 @@ __global__ __launch_bounds__(64) void kvm_dtw_dp_lds_kernel(const double *__rest
     const int m = qd.m, r = qd.rho;
     const double eps2 = qd.eps2;
     const double *__restrict__ B = qd.q;
-    double *E = scratch ? scratch + (size_t)blockIdx.x * ((size_t)2 * (r + 1) + m) : kvm_dp_lds;  // r+1 entries
+    double *E = scratch ? scratch + (size_t)blockIdx.x * dp_lds_doubles(m, r) : kvm_dp_lds;  // r+1 entries
     double *O = E + (r + 1);     // r+1 entries (only r used)
     double *A = O + (r + 1);     // m entries: the (z-normalised) candidate window
+    double *CB = A + m;          // m entries: cb[] (K/NormQueryEngineDtw.java:576-587)
+    double *RM = CB + m;         // m entries: row minima (min_cost of K/utils/DtwUtils.java:286,319-321)
+    double *patch = RM + m;      // 8r entries: data envelope at the chunk ends
     const unsigned long long n_in = *d_n_in;
+    const bool exact = ax.cb_exact != nullptr;
+    const double tol = 4.0 * ax.tau * eps2;
 
-    for (;;) {
-        unsigned long long idx = 0;
-        if (lane == 0) idx = atomicAdd(&counters[KVM_CNT_QUEUE], 1ULL);
-        idx = __shfl(idx, 0, 64);
+    // (one pop per iteration, at most n_in successful pops in the whole grid: the bound is a guard, every wave leaves)
+    for (unsigned long long pops = 0; pops <= n_in; pops++) {
+        unsigned long long popped = 0;
+        if (lane == 0) popped = atomicAdd(&counters[KVM_CNT_QUEUE], 1ULL);
+        const unsigned long long idx = kvm_uniform_u64(popped);  // (a scalar: see kvm_uniform_u64)
         if (idx >= n_in) break;
         const kvm_cand c = in[idx];
-        if (c.start < 0) continue;  // rejected by the exact (alpha, beta) test
+        if (c.start < 0) continue;  // rejected by the exact (alpha, beta) test / by the sequential path
         const double *__restrict__ x = series + (c.start - 1);
-        const double lim_rest = qd.normalised ? eps2 + kvm_eps2_slack(eps2, m, kvm_sigma_guard(c.mean, c.std), 16.0)
-                                              : eps2 * (1.0 + 1e-9);
+        dp_plan pl;
+        pl.which = 0; pl.total = 0.0; pl.cbeg = pl.cend = pl.sb = 0;
+        if (!exact) {
+            const int st = dp_prologue(series, qd, ax, c, lane, patch, pl);
+            if (st == DP_REJECT) continue;
+            if (st == DP_AMBIG) {
+                dp_emit_ambig(ax, counters, c, lane);
+                continue;
+            }
+        }
+        if (lane == 0) atomicAdd(&counters[KVM_CNT_PASS_KEOGH2], 1ULL);
+        // cb[]: exact arrays of the sequential path, or total - prefix of the chosen bound's terms
+        if (exact) {
+            const double *__restrict__ src = ax.cb_exact + (size_t)idx * 2 * m + (c.lim != 0.0 ? m : 0);
+            for (int k = lane; k < m; k += 64) CB[k] = src[k];
+        } else {
+            double pref = 0.0;
+            for (int base = 0; base < m; base += 64) {
+                const int k = base + lane;
+                const double t = k < m ? dp_cb_term(x, qd, ax, patch, pl, c.start, c.mean, c.std, k) : 0.0;
+                const double inc = dp_scan_add(t, lane);
+                if (k < m) CB[k] = pl.total - (pref + (inc - t));
+                pref += kvm_readlane_f64(inc, 63);
+            }
+        }
         // zT[k] = (T[k+j] - mean) / std   (K/NormQueryEngineDtw.java:564-567); RSM: mean 0, std 1 -> exact copy
-        for (int i = lane; i < m; i += 64) A[i] = (x[i] - c.mean) / c.std;
+        for (int i = lane; i < m; i += 64) {
+            A[i] = (x[i] - c.mean) / c.std;
+            RM[i] = DTW_INF;
+        }
         for (int e = lane; e <= r; e += 64) {
             E[e] = DTW_INF;
             O[e] = DTW_INF;
         }
         __syncthreads();
-        bool dead = false;
+        int decision = 0;  // 0 none yet, 1 reject, 2 ambiguous, 3 the reference returns `value` at a row
+        double value = 0.0;
         for (int d = 0; d <= 2 * m - 2; d++) {
             if (((d + r) & 1) == 0) {
                 for (int e = lane; e <= r; e += 64) {
@@ -315,6 +413,7 @@ __global__ __launch_bounds__(64) void kvm_dtw_dp_lds_kernel(const double *__rest
                             v = fmin(fmin(xx, yy), E[e]) + dd;
                         }
                         E[e] = v;
+                        if (v < RM[i]) RM[i] = v;  // (one cell per row on a diagonal: no two lanes share a row)
                     }
                 }
             } else {
@@ -322,41 +421,39 @@ __global__ __launch_bounds__(64) void kvm_dtw_dp_lds_kernel(const double *__rest
                     const int i = (d + r - 2 * o - 1) >> 1, j = d - i;
                     if (d + r - 2 * o - 1 >= 0 && i < m && j >= 0 && j < m) {
                         const double dd = dsq(A[i], B[j]);
+                        double v;
                         if (i == 0 && j == 0) {  // r odd: the origin is an odd-k cell
-                            O[o] = dd;
+                            v = dd;
                         } else {
                             const double xx = E[o + 1];
                             const double yy = E[o];
-                            O[o] = fmin(fmin(xx, yy), O[o]) + dd;
+                            v = fmin(fmin(xx, yy), O[o]) + dd;
                         }
+                        O[o] = v;
+                        if (v < RM[i]) RM[i] = v;
                     }
                 }
             }
             __syncthreads();
-            if (ABANDON && (d & 63) == 63 && d < 2 * m - 2) {
-                double mn = DTW_INF;
-                for (int e = lane; e <= r; e += 64) {
-                    mn = fmin(mn, E[e]);
-                    if (e <= r - 1) mn = fmin(mn, O[e]);
-                }
-                mn = kvm_wave_min(mn);
-                // rows and columns > (d + r) / 2 are untouched by every cell of the last two diagonals: their
-                // LB_Keogh contributions (coarse suffix) still have to be paid (K/utils/DtwUtils.java:324-326)
-                double rest = 0.0;
-                if (suffix) {
-                    const int sidx = ((d + r) / 2 + 1 + seg_len - 1) / seg_len;
-                    rest = sidx < KVM_DTW_NSEG ? suffix[idx * KVM_DTW_NSEG + sidx] : 0.0;
-                }
-                // `rest` comes from the pruning arithmetic (approximate sigma, other summation order): guard band
-                if (mn + rest > (rest > 0.0 ? lim_rest : eps2)) {
-                    dead = true;
-                    break;
+            // row i = (d - r) / 2 has just received its last cell (i, i + r): `if (i + r < m - 1 && min_cost + cb[i+r+1] >= bsf)`
+            if (decision == 0 && d >= r && ((d - r) & 1) == 0) {
+                const int i = (d - r) >> 1;
+                if (i + r < m - 1) {
+                    const int t = dp_row_test(lane == 0, RM[i], CB[i + r + 1], eps2, tol, exact, value);
+                    if (t) {
+                        decision = t;
+                        if (ABANDON) break;
+                    }
                 }
             }
         }
         __syncthreads();
-        if (!dead && lane == 0) {
-            const double v = (r & 1) ? O[(r - 1) >> 1] : E[r >> 1];  // cell (m-1, m-1): k = r
+        if (decision == 2) {
+            dp_emit_ambig(ax, counters, c, lane);
+            if (lane == 0) atomicAdd(&counters[KVM_CNT_PASS_KEOGH2], ~0ULL);  // (counted again when the exact run starts it)
+        } else if (decision != 1 && lane == 0) {
+            // no row reached eps^2: cell (m-1, m-1), k = r (:333-336); else the row bound the reference returned
+            const double v = decision == 3 ? value : ((r & 1) ? O[(r - 1) >> 1] : E[r >> 1]);
             if (v <= eps2) {
                 unsigned long long o = atomicAdd(&counters[KVM_CNT_ANSWERS], 1ULL);
                 if ((int64_t)o < cap) {
@@ -371,7 +468,7 @@ __global__ __launch_bounds__(64) void kvm_dtw_dp_lds_kernel(const double *__rest
 
 
 // ---------------------------------------------------------------------------------------------------
-// Stage 3 (register form): the same red/black anti-diagonal sweep with the whole band in VGPRs.
+// DP, register form: the same red/black anti-diagonal sweep with the whole band in VGPRs.
 //
 // Lane p owns V consecutive even-k cells E[pV..pV+V) and V odd-k cells O[pV..pV+V) (V = pow2 >= (r+1)/64).
 // One macro-step I performs the E-update of diagonal d = 2I - r and the O-update of diagonal d + 1:
@@ -393,6 +490,16 @@ __global__ __launch_bounds__(64) void kvm_dtw_dp_lds_kernel(const double *__rest
 //   * the band edge k = -1 is lane 0's left halo (DPP fill value INF); the band edge k = 2r+1 is the single cell
 //     O[r], which is reset to INF after every O-update (one v_cndmask pair).  Cells beyond it are never read
 //     by an in-band cell.
+//
+// Row minima (min_cost, :286,319-321).  The E and O cells a slot (lane p, index c) updates in macro-step I both belong
+// to row I - pV - c, and that row moves on to the next slot every macro-step -- exactly like the data value a[].  So the
+// minimum of a row travels with it: a register per slot under the same static renaming as a[], handed to the next lane
+// by one DPP move when the row leaves a lane's last slot (lane 0 starts every new row at INF), two v_min_f64 per slot
+// and macro-step.  Row i receives its last cell, E[r] (k = 2r), in macro-step i + r, in the lane / slot that also
+// holds the band-edge cell: that lane stores the finished minimum into a 64-entry LDS strip, and after every 64
+// macro-steps the wavefront tests the 64 finished rows in parallel (dp_row_test) -- in row order, so the first row
+// whose bound reaches eps^2 is the reference's.  The cb[] values the test needs are formed right there: total - prefix
+// of the chosen bound's terms, one term per lane and chunk.
 #define DTW_POS_BIG 1e10
 #define DTW_NEG_BIG (-1e10)
 
@@ -433,17 +540,16 @@ struct dp_buf {
 
 template <int V, int CSTAR, bool ABANDON>
 __global__ __launch_bounds__(256) void kvm_dtw_dp_reg_kernel(const double *__restrict__ series, kvm_query_dev qd,
-                                                             const kvm_cand *__restrict__ in,
-                                                             const double *__restrict__ suffix, int32_t seg_len,
+                                                             kvm_dtw_aux ax, const kvm_cand *__restrict__ in,
                                                              const unsigned long long *__restrict__ d_n_in,
                                                              int32_t *__restrict__ out_off,
                                                              double *__restrict__ out_dist, int64_t cap,
                                                              unsigned long long *__restrict__ counters) {
     constexpr int LIN = dp_buf<V>::LIN, LIVE = dp_buf<V>::LIVE;
-    constexpr int WAVE_LDS = 2 * LIN + 64 * V;  // buffer A, buffer B, result scratch
+    constexpr int WAVE_LDS = 2 * LIN + 64 * V + 64;  // buffer A, buffer B, result scratch, finished row minima
     __shared__ double lds_all[4 * WAVE_LDS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    double *bufA = lds_all + wave * WAVE_LDS, *bufB = bufA + LIN, *scratch = bufB + LIN;
+    double *bufA = lds_all + wave * WAVE_LDS, *bufB = bufA + LIN, *scratch = bufB + LIN, *bufR = scratch + 64 * V;
     const int m = qd.m, r = qd.rho;
     const double eps2 = qd.eps2;
     const double *__restrict__ Bq = qd.q;
@@ -452,18 +558,40 @@ __global__ __launch_bounds__(256) void kvm_dtw_dp_reg_kernel(const double *__res
     const int pV = lane * V;
     const bool edge_lane = lane == r / V;  // the band-edge cell O[r] is cell CSTAR (= r % V) of this lane
     const int kfin = (r & 1) ? ((r - 1) >> 1) : (r >> 1);  // index of cell (m-1, m-1) (k = r) in O (r odd) / E (r even)
+    const bool exact = ax.cb_exact != nullptr;
+    const double tol = 4.0 * ax.tau * eps2;
+    double *__restrict__ patch = ax.patch + (size_t)(blockIdx.x * 4 + wave) * 8 * (size_t)r;
 
-    for (;;) {
-        unsigned long long idx = 0;
-        if (lane == 0) idx = atomicAdd(&counters[KVM_CNT_QUEUE], 1ULL);
-        idx = __shfl(idx, 0, 64);
+    // (one pop per iteration, at most n_in successful pops in the whole grid: the bound is a guard, every wave leaves)
+    for (unsigned long long pops = 0; pops <= n_in; pops++) {
+        unsigned long long popped = 0;
+        if (lane == 0) popped = atomicAdd(&counters[KVM_CNT_QUEUE], 1ULL);
+        const unsigned long long idx = kvm_uniform_u64(popped);  // (a scalar: see kvm_uniform_u64)
         if (idx >= n_in) break;
         const kvm_cand cand = in[idx];
-        if (cand.start < 0) continue;  // rejected by the exact (alpha, beta) test
+        if (cand.start < 0) continue;  // rejected by the exact (alpha, beta) test / by the sequential path
         const double *__restrict__ x = series + (cand.start - 1);
         const double mean = cand.mean, sd = cand.std;
-        const double lim_rest = qd.normalised ? eps2 + kvm_eps2_slack(eps2, m, kvm_sigma_guard(mean, sd), 16.0)
-                                              : eps2 * (1.0 + 1e-9);
+        dp_plan pl;
+        pl.which = 0; pl.total = 0.0; pl.cbeg = pl.cend = pl.sb = 0;
+        if (!exact) {
+            const int st = dp_prologue(series, qd, ax, cand, lane, patch, pl);
+            if (st == DP_REJECT) continue;
+            if (st == DP_AMBIG) {
+                dp_emit_ambig(ax, counters, cand, lane);
+                continue;
+            }
+        }
+        if (lane == 0) atomicAdd(&counters[KVM_CNT_PASS_KEOGH2], 1ULL);
+        const double *__restrict__ cb_src = exact ? ax.cb_exact + (size_t)idx * 2 * m + (cand.lim != 0.0 ? m : 0) : nullptr;
+        // prefix of the cb terms below the first index the row test needs (cb[I0 + 1]: chunk Ic covers cb[Ic+1 .. Ic+64])
+        double pref = 0.0;
+        if (!exact) {
+            for (int base = 0; base <= I0; base += 64) {
+                const int k = base + lane;
+                pref += kvm_wave_sum((k <= I0 && k < m) ? dp_cb_term(x, qd, ax, patch, pl, cand.start, mean, sd, k) : 0.0);
+            }
+        }
         // buffer position p holds A[lowA + p] / B[lowB + p]
         int lowA = I0 - LIVE, lowB = I0 - r;
         // zT[k] = (T[k+j] - mean) / std (K/NormQueryEngineDtw.java:564-567); RSM: (x - 0) / 1 == x exactly
@@ -482,11 +610,12 @@ __global__ __launch_bounds__(256) void kvm_dtw_dp_reg_kernel(const double *__res
         fillA(0, LIVE + 64);
         fillB(0, LIVE + 64);
 
-        double E[V], O[V], a[V], b[V];
+        double E[V], O[V], a[V], b[V], R[V];
 #pragma unroll
         for (int c = 0; c < V; c++) {
             E[c] = DTW_INF;
             O[c] = DTW_INF;
+            R[c] = DTW_INF;
             a[c] = c >= 1 ? bufA[I0 - pV - c - lowA] : 0.0;
             b[c] = bufB[I0 - r + pV + c - lowB];
         }
@@ -505,8 +634,10 @@ __global__ __launch_bounds__(256) void kvm_dtw_dp_reg_kernel(const double *__res
         const double *pB = bufB + (I0 - r + pV + V - lowB);
         // halos: lane 0 (left) / lane 63 (right) never receive from a neighbour, so they keep this initial INF for ever
         double halo_l = DTW_INF, halo_r = DTW_INF;
-        bool dead = false, done = false;
+        bool done = false;
         double result = DTW_INF;
+        int decision = 0;  // 0 none yet, 1 reject, 2 ambiguous, 3 the reference returns `value` at a row
+        double value = 0.0;
         int chunk = 0;
 
         for (int Ic = I0; Ic <= Ilast && !done; Ic += 64) {
@@ -516,6 +647,8 @@ __global__ __launch_bounds__(256) void kvm_dtw_dp_reg_kernel(const double *__res
                 for (int s = 0; s < V; s++) {
                     const int I = Ic + blk * V + s;
                     const double a_new = pA[s], b_new = pB[s];
+                    // the row that left this lane's last slot moves on to the next lane; lane 0 starts a new row
+                    R[(V - s) % V] = dp_from_left(R[(V - s) % V], DTW_INF);
                     // ---- E-update (diagonal 2I - r) ----
                     halo_l = dp_from_left(O[V - 1], halo_l);
 #pragma unroll
@@ -550,9 +683,32 @@ __global__ __launch_bounds__(256) void kvm_dtw_dp_reg_kernel(const double *__res
                     }
                     // band edge k = 2r+1: O[r] must read as INF
                     O[CSTAR] = edge_lane ? DTW_INF : O[CSTAR];
+                    // ---- row minima ----
+#pragma unroll
+                    for (int c = 0; c < V; c++)
+                        R[((c - s) % V + V) % V] = dp_min(dp_min(R[((c - s) % V + V) % V], E[c]), O[c]);
+                    if (edge_lane) bufR[blk * V + s] = R[((CSTAR - s) % V + V) % V];  // row I - r is complete
                 }
                 pA += V;
                 pB += V;
+            }
+            // ---- row test of the rows finished in macro-steps Ic .. Ic+63 (lane t: row Ic + t - r) ----
+            if (decision == 0) {
+                const int I = Ic + lane, k = I + 1;  // needs cb[I + 1]
+                double cbv, term = 0.0;
+                if (exact) {
+                    cbv = (k < m) ? cb_src[k] : 0.0;
+                } else {
+                    term = (k < m) ? dp_cb_term(x, qd, ax, patch, pl, cand.start, mean, sd, k) : 0.0;
+                    const double inc = dp_scan_add(term, lane);
+                    cbv = pl.total - (pref + (inc - term));
+                    pref += kvm_readlane_f64(inc, 63);
+                }
+                const int t = dp_row_test(I >= r && I <= m - 2, bufR[lane], cbv, eps2, tol, exact, value);
+                if (t) {
+                    decision = t;
+                    if (ABANDON) break;
+                }
             }
             if (done) break;
             chunk++;
@@ -578,65 +734,49 @@ __global__ __launch_bounds__(256) void kvm_dtw_dp_reg_kernel(const double *__res
             // the 64 values the next chunk adds at the front of each window
             fillA(LIVE + 64 * chunk, 64);
             fillB(LIVE + 64 * chunk, 64);
-            if (ABANDON) {
-                double mn = DTW_INF;
-#pragma unroll
-                for (int c = 0; c < V; c++) mn = dp_min(mn, dp_min(E[c], O[c]));
-                mn = kvm_wave_min(mn);
-                // Every path crosses one of the last two diagonals (DTW >= mn); all their cells have row and column
-                // <= Ic+63, so the LB_Keogh contributions of the positions beyond are still to be paid
-                // (K/utils/DtwUtils.java:324-326 with the coarse suffix of stage 2).
-                double rest = 0.0;
-                if (suffix) {
-                    const int sidx = (Ic + 64 + seg_len - 1) / seg_len;
-                    rest = sidx < KVM_DTW_NSEG ? suffix[idx * KVM_DTW_NSEG + sidx] : 0.0;
-                }
-                // `rest` comes from the pruning arithmetic (approximate sigma, other summation order): guard band
-                if (mn + rest > (rest > 0.0 ? lim_rest : eps2)) {
-                    dead = true;
-                    break;
-                }
-            }
         }
-        if (!dead && lane == 0 && result <= eps2) {
-            unsigned long long o = atomicAdd(&counters[KVM_CNT_ANSWERS], 1ULL);
-            if ((int64_t)o < cap) {
-                out_off[o] = cand.start;
-                out_dist[o] = sqrt(result);
+        if (decision == 2) {
+            dp_emit_ambig(ax, counters, cand, lane);
+            if (lane == 0) atomicAdd(&counters[KVM_CNT_PASS_KEOGH2], ~0ULL);  // (counted again when the exact run starts it)
+        } else if (decision != 1 && lane == 0) {
+            const double v = decision == 3 ? value : result;  // (:325 the row bound / :333-336 the last cell)
+            if (v <= eps2) {
+                unsigned long long o = atomicAdd(&counters[KVM_CNT_ANSWERS], 1ULL);
+                if ((int64_t)o < cap) {
+                    out_off[o] = cand.start;
+                    out_dist[o] = sqrt(v);
+                }
             }
         }
     }
 }
 
 template <int V, int CSTAR>
-static hipError_t launch_dp_reg_c(const double *series, const kvm_query_dev &qd, const kvm_cand *in,
-                                  const double *suffix, int32_t seg_len, const unsigned long long *d_n_in,
-                                  int64_t max_in, int32_t *out_off, double *out_dist, int64_t cap,
-                                  unsigned long long *counters, int num_cu, hipStream_t s) {
-    // waves per SIMD = DP_BLOCKS_PER_CU (bounded by LDS: 4 waves x (2*LIN + 64V) doubles per workgroup)
-    const int lds_limit = (int)((160 * 1024) / (4 * (2 * dp_buf<V>::LIN + 64 * V) * sizeof(double)));
+static hipError_t launch_dp_reg_c(const double *series, const kvm_query_dev &qd, const kvm_dtw_aux &ax, const kvm_cand *in,
+                                  const unsigned long long *d_n_in, int64_t max_in, int32_t *out_off, double *out_dist,
+                                  int64_t cap, unsigned long long *counters, int num_cu, hipStream_t s) {
+    // waves per SIMD = DP_BLOCKS_PER_CU (bounded by LDS: 4 waves x (2*LIN + 64V + 64) doubles per workgroup)
+    const int lds_limit = (int)((160 * 1024) / (4 * (2 * dp_buf<V>::LIN + 64 * V + 64) * sizeof(double)));
     int64_t blocks = (int64_t)num_cu * (DP_BLOCKS_PER_CU < lds_limit ? DP_BLOCKS_PER_CU : lds_limit);
     if (blocks > (max_in + 3) / 4) blocks = (max_in + 3) / 4;
     if (qd.early_abandon)
         hipLaunchKernelGGL((kvm_dtw_dp_reg_kernel<V, CSTAR, true>), dim3((unsigned)blocks), dim3(256), 0, s, series, qd,
-                           in, suffix, seg_len, d_n_in, out_off, out_dist, cap, counters);
+                           ax, in, d_n_in, out_off, out_dist, cap, counters);
     else
         hipLaunchKernelGGL((kvm_dtw_dp_reg_kernel<V, CSTAR, false>), dim3((unsigned)blocks), dim3(256), 0, s, series, qd,
-                           in, suffix, seg_len, d_n_in, out_off, out_dist, cap, counters);
+                           ax, in, d_n_in, out_off, out_dist, cap, counters);
     return hipGetLastError();
 }
 
 // dispatch on the (launch-constant) position CSTAR = rho % V of the band-edge cell
 template <int V>
-static hipError_t launch_dp_reg(const double *series, const kvm_query_dev &qd, const kvm_cand *in,
-                                const double *suffix, int32_t seg_len, const unsigned long long *d_n_in,
-                                int64_t max_in, int32_t *out_off, double *out_dist, int64_t cap,
-                                unsigned long long *counters, int num_cu, hipStream_t s) {
+static hipError_t launch_dp_reg(const double *series, const kvm_query_dev &qd, const kvm_dtw_aux &ax, const kvm_cand *in,
+                                const unsigned long long *d_n_in, int64_t max_in, int32_t *out_off, double *out_dist,
+                                int64_t cap, unsigned long long *counters, int num_cu, hipStream_t s) {
 #define KVM_DP_CASE(C)                                                                                          \
     case C:                                                                                                     \
         if constexpr (C < V)                                                                                    \
-            return launch_dp_reg_c<V, C>(series, qd, in, suffix, seg_len, d_n_in, max_in, out_off, out_dist, cap, \
-                                         counters, num_cu, s);                                                  \
+            return launch_dp_reg_c<V, C>(series, qd, ax, in, d_n_in, max_in, out_off, out_dist, cap, counters, num_cu, s); \
         break;
     switch (qd.rho % V) {
         KVM_DP_CASE(0) KVM_DP_CASE(1) KVM_DP_CASE(2) KVM_DP_CASE(3)
@@ -646,21 +786,23 @@ static hipError_t launch_dp_reg(const double *series, const kvm_query_dev &qd, c
     return hipErrorInvalidValue;
 }
 
-hipError_t kvm_launch_dtw_dp(const double *series, int64_t n, const kvm_query_dev &qd, const kvm_cand *in,
-                             const double *suffix, int32_t seg_len, const unsigned long long *d_n_in, int64_t max_in, int32_t *out_off, double *out_dist,
+int64_t kvm_dtw_dp_max_waves(int num_cu) { return (int64_t)num_cu * 4 * DP_BLOCKS_PER_CU; }
+
+hipError_t kvm_launch_dtw_dp(const double *series, int64_t n, const kvm_query_dev &qd, const kvm_dtw_aux &ax, const kvm_cand *in,
+                             const unsigned long long *d_n_in, int64_t max_in, int32_t *out_off, double *out_dist,
                              int64_t cap, unsigned long long *counters, int num_cu, int force_lds, hipStream_t s) {
     (void)n;
     if (max_in <= 0) return hipSuccess;
     // register form: band of r+1 even-k cells over 64 lanes, V = pow2 cells per lane, V <= 8 (r <= 511)
     const int need = (qd.rho + 1 + 63) / 64;
     if (!force_lds && need <= 8 && qd.m >= 2) {
-        if (need <= 1) return launch_dp_reg<1>(series, qd, in, suffix, seg_len, d_n_in, max_in, out_off, out_dist, cap, counters, num_cu, s);
-        if (need <= 2) return launch_dp_reg<2>(series, qd, in, suffix, seg_len, d_n_in, max_in, out_off, out_dist, cap, counters, num_cu, s);
-        if (need <= 4) return launch_dp_reg<4>(series, qd, in, suffix, seg_len, d_n_in, max_in, out_off, out_dist, cap, counters, num_cu, s);
-        return launch_dp_reg<8>(series, qd, in, suffix, seg_len, d_n_in, max_in, out_off, out_dist, cap, counters, num_cu, s);
+        if (need <= 1) return launch_dp_reg<1>(series, qd, ax, in, d_n_in, max_in, out_off, out_dist, cap, counters, num_cu, s);
+        if (need <= 2) return launch_dp_reg<2>(series, qd, ax, in, d_n_in, max_in, out_off, out_dist, cap, counters, num_cu, s);
+        if (need <= 4) return launch_dp_reg<4>(series, qd, ax, in, d_n_in, max_in, out_off, out_dist, cap, counters, num_cu, s);
+        return launch_dp_reg<8>(series, qd, ax, in, d_n_in, max_in, out_off, out_dist, cap, counters, num_cu, s);
     }
-    // generic form (any r): band rows + window in LDS when they fit, else in a stream-ordered global scratch
-    const size_t need_bytes = ((size_t)2 * (qd.rho + 1) + qd.m) * sizeof(double);
+    // generic form (any r): arrays in LDS when they fit, else in a stream-ordered global scratch
+    const size_t need_bytes = dp_lds_doubles(qd.m, qd.rho) * sizeof(double);
     const bool in_lds = need_bytes <= 160 * 1024;
     const size_t lds = in_lds ? need_bytes : 0;
     int per_cu = in_lds ? (int)((160 * 1024) / need_bytes) : 4;
@@ -680,11 +822,11 @@ hipError_t kvm_launch_dtw_dp(const double *series, int64_t n, const kvm_query_de
         if (e != hipSuccess) return e;
     }
     if (qd.early_abandon)
-        hipLaunchKernelGGL((kvm_dtw_dp_lds_kernel<true>), dim3((unsigned)blocks), dim3(64), lds, s, series, qd, in,
-                           suffix, seg_len, d_n_in, out_off, out_dist, cap, counters, scratch);
+        hipLaunchKernelGGL((kvm_dtw_dp_lds_kernel<true>), dim3((unsigned)blocks), dim3(64), lds, s, series, qd, ax, in,
+                           d_n_in, out_off, out_dist, cap, counters, scratch);
     else
-        hipLaunchKernelGGL((kvm_dtw_dp_lds_kernel<false>), dim3((unsigned)blocks), dim3(64), lds, s, series, qd, in,
-                           suffix, seg_len, d_n_in, out_off, out_dist, cap, counters, scratch);
+        hipLaunchKernelGGL((kvm_dtw_dp_lds_kernel<false>), dim3((unsigned)blocks), dim3(64), lds, s, series, qd, ax, in,
+                           d_n_in, out_off, out_dist, cap, counters, scratch);
     if (scratch) {
         const hipError_t e1 = hipGetLastError(), e2 = hipFreeAsync(scratch, s);
         return e1 != hipSuccess ? e1 : e2;

@@ -63,15 +63,6 @@ __device__ __forceinline__ void ex_produce_replay(const double *__restrict__ x, 
 // Running-sum replay, one workgroup per run.  Survivors of one run share the prefix of the reference's running sums,
 // so the run is replayed ONCE, up to the last window any survivor needs, and {mean, std} is stored for every flagged
 // window.  (Replaying per survivor would repeat the prefix for each of them.)
-__device__ __forceinline__ int64_t ex_find_run(const kvm_run *__restrict__ runs, int64_t n_runs, int32_t run_start) {
-    int64_t lo = 0, hi = n_runs - 1;  // runs are sorted by start and disjoint
-    while (lo < hi) {
-        const int64_t mid = (lo + hi) >> 1;
-        if (runs[mid].start < run_start) lo = mid + 1; else hi = mid;
-    }
-    return lo;
-}
-
 template <typename REC>
 __global__ __launch_bounds__(256) void kvm_replay_mark_kernel(const REC *__restrict__ recs,
                                                               const unsigned long long *__restrict__ d_n,
@@ -81,7 +72,7 @@ __global__ __launch_bounds__(256) void kvm_replay_mark_kernel(const REC *__restr
          i += (unsigned long long)gridDim.x * blockDim.x) {
         const REC rec = recs[i];
         if (rec.start < 0) continue;
-        const int64_t r = ex_find_run(ws.runs, ws.n_runs, rec.run_start);
+        const int64_t r = kvm_find_run(ws.runs, ws.n_runs, rec.run_start);
         const int32_t k = rec.start - rec.run_start;
         if (atomicMax(&ws.run_maxk[r], k + 1) == 0)  // first mark of this run: queue it for the replay
             ws.run_list[atomicAdd(ws.run_list_n, 1ULL)] = (int32_t)r;
@@ -228,7 +219,7 @@ __global__ __launch_bounds__(EX_THREADS) void kvm_exact_ed_kernel(const double *
                 start = sv.start;
                 if (NORM) {
                     // the reference's running sums of this window (replayed per run by kvm_replay_runs_kernel)
-                    const int64_t r = ex_find_run(ws.runs, ws.n_runs, sv.run_start);
+                    const int64_t r = kvm_find_run(ws.runs, ws.n_runs, sv.run_start);
                     const int64_t wi = ws.runs[r].win_base + (sv.start - sv.run_start);
                     mean = ws.stats[wi] / m;                                     // K/NormQueryEngine.java:507
                     std = sqrt(ws.stats[ws.stats_plane + wi] / m - mean * mean);  // :508
@@ -350,7 +341,7 @@ __global__ __launch_bounds__(256) void kvm_exact_stats_apply_kernel(kvm_query_de
     for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (unsigned long long)gridDim.x * blockDim.x) {
         kvm_cand c = cands[i];
-        const int64_t r = ex_find_run(ws.runs, ws.n_runs, c.run_start);
+        const int64_t r = kvm_find_run(ws.runs, ws.n_runs, c.run_start);
         const int64_t wi = ws.runs[r].win_base + (c.start - c.run_start);  // ex, ex2 of the replay
         const double mean = ws.stats[wi] / qd.m;                                      // K/NormQueryEngineDtw.java:550
         const double std = sqrt(ws.stats[ws.stats_plane + wi] / qd.m - mean * mean);  // :551

@@ -151,10 +151,16 @@ static inline kvm_plan_item kvm_plan_interval(int64_t l, int64_t r, int64_t shif
     kvm_plan_tiles(it.c, hybrid, tile_log2, it.tiles_a, it.tiles_b);
     return it;
 }
+// `chunk_lo` / `chunk_hi` (optional, per interval; may be pinned host memory): the data range [lo, hi] (1-based points) of
+// the chunk the reference fetches for that interval (cNSM engines: greedy-merged chunks, K/NormQueryEngineDtw.java:492-520);
+// copied per non-empty run into `run_chunk` -- where the reference's data envelope is clipped (DTW only).
 hipError_t kvm_launch_plan_runs(const int32_t *src_left, const int32_t *src_right, int32_t *left, int32_t *right, int32_t k,
                                 int32_t shift, int64_t hi_max, bool hybrid, int tile_log2, kvm_run *runs, void *scratch,
-                                hipStream_t s);
+                                hipStream_t s, const int32_t *chunk_lo = nullptr, const int32_t *chunk_hi = nullptr,
+                                int2 *run_chunk = nullptr);
 hipError_t kvm_launch_upload(void *dst, const void *src_pinned, size_t bytes, hipStream_t s);
+hipError_t kvm_launch_set_u64(unsigned long long *a, unsigned long long va, unsigned long long *b, unsigned long long vb,
+                              hipStream_t s);
 hipError_t kvm_launch_expand_tiles(const kvm_run *runs, int64_t n_runs, int32_t tile_max, kvm_tile *tiles,
                                    unsigned long long *counters, int32_t *run_maxk, hipStream_t s);
 // hybrid ED tiling: class A = 64-candidate tiles (full tiles and remainders > 32), class B = remainders <= 32
@@ -226,23 +232,52 @@ hipError_t kvm_launch_exact_stats(const double *series, const kvm_query_dev &qd,
                                   unsigned long long *counters, int num_cu, hipStream_t s);
 
 // DTW cascade.
+//
+// The reference's answer set is NOT {candidates with banded DTW <= eps^2}: DtwUtils.dtw returns `min_cost + cb[i+r+1]` as
+// soon as that lower bound is >= bsf (K/utils/DtwUtils.java:324-326), the LB loops stop at the first partial sum >= bsf
+// (:210, :242) and every caller accepts `value <= eps^2` -- so a partial sum that lands EXACTLY on eps^2 passes, with
+// partially filled cb arrays behind it, and a row bound that lands exactly on eps^2 is reported as an answer at distance
+// eps.  On continuous data such ties have measure zero, on integer-valued data they are common.  The cascade here
+// reproduces them:
+//   * screens (approximate mean/std, any arithmetic) may only drop a candidate when the reference's own sequence of
+//     partial sums, IN THE REFERENCE'S ORDER, crosses eps^2 cleanly: the last partial below eps^2 - slack, the next above
+//     eps^2 + slack (kvm_retile_dtw_kernel for LB_Kim, kvm_dtw_screen_kernel for LB_Keogh);
+//   * the DP kernel decides everything else with the replayed (exact) mean/std: LB_Kim as the reference computes it, both
+//     LB_Keogh loops as wave-parallel ordered scans of exactly rounded terms (a prefix within tau of eps^2 is ambiguous),
+//     the row minima of the DP (tracked alongside the anti-diagonal sweep) against the suffix sums of the chosen bound;
+//   * what is ambiguous -- some compared quantity within rounding of eps^2 -- goes to the sequential, reference-ordered
+//     path (kvm_dtw_ref.hip) and comes back with exact cb[] arrays for a DP run that compares without tolerance.
+struct kvm_dtw_aux {
+    const int32_t *order;        // [m] summation order of the reference's LB_Keogh loops (identity for RSM-DTW)
+    const double *uo, *lo, *qo;  // [m] query envelope and query in that order (K/NormQueryEngineDtw.java:480-490)
+    const double *env_u, *env_l; // [n] data envelope of radius rho over the whole series (interior of every chunk)
+    const kvm_run *runs;         // runs of the query (chunk bounds: RSM = the run's own data range)
+    int64_t n_runs;
+    const int2 *run_chunk;       // cNSM: [n_runs] data range of the run's chunk; nullptr for RSM
+    double *patch;               // scratch: 8 * rho doubles per DP wave (running max / min at the chunk ends)
+    kvm_cand *ambig;             // out: candidates whose decision needs the sequential path
+    const double *cb_exact;      // in (second DP run only): [2m per candidate] exact cb arrays, see kvm_dtw_ref.hip
+    double tau;                  // relative tolerance between a wave-parallel sum and the reference's sequential one
+};
+hipError_t kvm_launch_dtw_screen(const double *series, const double2 *prefix, const kvm_query_dev &qd, const kvm_dtw_aux &ax,
+                                 const kvm_tile *tiles, int64_t n_tiles, const unsigned long long *d_n_tiles, kvm_cand *out,
+                                 unsigned long long *counters, hipStream_t s);
+// sequential reference-ordered evaluation of the ambiguous candidates: LB_Kim, both LB_Keogh loops with their exits,
+// the choice of the larger bound and its suffix sums (K/NormQueryEngineDtw.java:555-587); rejected candidates get
+// start = -start, the others their cb[] in slots[2m * index + (lim != 0 ? m : 0)]
+hipError_t kvm_launch_dtw_ref_chains(const double *series, const kvm_query_dev &qd, const kvm_dtw_aux &ax, kvm_cand *cands,
+                                     int64_t n, double *slots, hipStream_t s);
 hipError_t kvm_launch_dtw_filter(const double *series, const double2 *prefix, int64_t n, const kvm_query_dev &qd,
                                  const kvm_tile *tiles, int64_t n_tiles, int32_t use_lb, kvm_cand *out,
                                  unsigned long long *counters, hipStream_t s);
-hipError_t kvm_launch_dtw_lb_tiled(const double *series, const double2 *prefix, int64_t n, const kvm_query_dev &qd,
-                                   const kvm_tile *tiles, int64_t n_tiles, kvm_cand *out, unsigned long long *counters,
-                                   const unsigned long long *d_n_tiles, int num_cu, hipStream_t s);
 // DTW: filter + LB_Kim for every candidate (one lane each), 64-candidate tiles -> trimmed <= 32-candidate tiles of the
 // survivors; list length -> counters[KVM_CNT_TILES_A], PASS_FILTER / PASS_KIM counted here
 hipError_t kvm_launch_retile_dtw(const double *series, const double2 *prefix, const kvm_query_dev &qd, const kvm_tile *tiles,
                                  int64_t n_tiles, kvm_tile *out_tiles, unsigned long long *counters, hipStream_t s);
-#define KVM_DTW_NSEG 16  // coarse LB_Keogh suffix: segments per candidate (see kvm_dtw_keogh_kernel)
-hipError_t kvm_launch_dtw_keogh(const double *series, const double *env_u, const double *env_l, int64_t n,
-                                const kvm_query_dev &qd, const kvm_cand *in, const unsigned long long *d_n_in,
-                                int64_t max_in, kvm_cand *out, double *out_suffix, int32_t seg_len,
-                                unsigned long long *counters, hipStream_t s);
-hipError_t kvm_launch_dtw_dp(const double *series, int64_t n, const kvm_query_dev &qd, const kvm_cand *in,
-                             const double *suffix, int32_t seg_len, const unsigned long long *d_n_in, int64_t max_in, int32_t *out_off, double *out_dist,
+// waves of the DP launch that use a slice of kvm_dtw_aux::patch (the launch never starts more)
+int64_t kvm_dtw_dp_max_waves(int num_cu);
+hipError_t kvm_launch_dtw_dp(const double *series, int64_t n, const kvm_query_dev &qd, const kvm_dtw_aux &ax, const kvm_cand *in,
+                             const unsigned long long *d_n_in, int64_t max_in, int32_t *out_off, double *out_dist,
                              int64_t cap, unsigned long long *counters, int num_cu, int force_lds, hipStream_t s);
 
 // counters layout (unsigned long long[16])
@@ -260,6 +295,7 @@ hipError_t kvm_launch_dtw_dp(const double *series, int64_t n, const kvm_query_de
 #define KVM_CNT_REPLAY_RUNS 11        // runs queued for the running-sum replay
 #define KVM_CNT_TILES_A 12            // cNSM-ED: trimmed tile lists built on the device (kvm_retile_cnsm_kernel)
 #define KVM_CNT_TILES_B 13
+#define KVM_CNT_AMBIG 14              // DTW: candidates handed to the sequential reference-ordered path
 #define KVM_CNT_TOTAL 16
 
 // kvm_index.hip: index build step 1 on the device
@@ -470,6 +506,32 @@ __device__ __forceinline__ bool kvm_cnsm_filter_guarded(double mean, double std,
 __device__ __forceinline__ double kvm_eps2_slack(double eps2, int32_t m, double g, double factor) {
     if (kvm_guard_degenerate(g)) return __builtin_huge_val();
     return eps2 * 1e-9 + factor * (g * sqrt((double)m * eps2) + g * g * m);
+}
+
+// index of the run that starts at window offset `run_start` (runs are sorted by start and disjoint)
+__device__ __forceinline__ int64_t kvm_find_run(const kvm_run *__restrict__ runs, int64_t n_runs, int32_t run_start) {
+    int64_t lo = 0, hi = n_runs - 1;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (runs[mid].start < run_start) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// Wave-uniform values as SCALARS.  A value every lane agrees on must also look uniform to the compiler, or it lowers the
+// branches that depend on it as divergent control flow -- and a loop with a cross-lane operation (ds_bpermute, DPP) at
+// its head and "divergent" continue edges can then be restructured so that the operation runs with some lanes masked
+// off (seen in the DP kernels' work-queue loop: lane 0, which pops the queue, was parked in an outer loop while the other
+// lanes spun on a stale index).  v_readfirstlane / v_readlane put the value into SGPRs.
+__device__ __forceinline__ unsigned long long kvm_uniform_u64(unsigned long long v) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ double kvm_readlane_f64(double v, int src_lane) {  // src_lane must be wave-uniform
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
+    return __hiloint2double(hi, lo);
 }
 
 __device__ __forceinline__ double kvm_wave_sum(double v) {

@@ -18,7 +18,7 @@ KVM_ERR_NO_SERIES = -6
 KVM_ERR_UNSUPPORTED = -7
 
 STAT_WINDOWS, STAT_PASS_FILTER, STAT_PASS_LB_KIM, STAT_PASS_LB_KEOGH, STAT_PASS_LB_KEOGH2, STAT_KERNEL_NS, \
-    STAT_RECHECKED = range(7)
+    STAT_RECHECKED, STAT_DTW_SEQUENTIAL = range(8)
 OPT_EARLY_ABANDON, OPT_LB_CASCADE, OPT_ED_KERNEL, OPT_TIMING, OPT_DP_KERNEL = 1, 2, 3, 4, 5
 
 # every symbol include/kvmatch.h declares (checked by tests/test_abi.py)

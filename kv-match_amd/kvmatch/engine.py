@@ -200,7 +200,7 @@ class Phase2Context:
             else:
                 off = np.empty(0, dtype=np.int32)
                 dist = np.empty(0, dtype=np.float64)
-            stats = [int(lib.kvm_result_stat(res, i)) for i in range(7)]
+            stats = [int(lib.kvm_result_stat(res, i)) for i in range(8)]
             return Answers(off, dist, int(lib.kvm_result_candidates(res)), float(lib.kvm_result_elapsed_ms(res)),
                            stats)
         finally:

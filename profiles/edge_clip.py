@@ -6,7 +6,6 @@ sys.path.insert(0, os.path.join(ROOT, "kv-match_amd")); sys.path.insert(0, os.pa
 import numpy as np, kvmatch
 from kvmatch import datagen
 import oracle
-from adversarial import tie_quirk
 ctx = kvmatch.Phase2Context(0)
 rng = np.random.default_rng(int(os.environ.get("SEED", "4")))
 base = datagen.gen_series(300_000, seed=8)
@@ -45,8 +44,6 @@ for case in range(int(sys.argv[1]) if len(sys.argv) > 1 else 300):
             bad += 1; print("STATUS", name, case, sg, so, "n", n, "m", m, "seg", seg, L[:4], R[:4], flush=True); continue
         if sg != "ok":
             errs += 1; continue
-        if name.endswith("dtw") and a.cnt_candidate == w[2]["cnt_candidate"] and len(a) != len(w[0]) and tie_quirk(a, w, eps):
-            quirk += 1; continue          # the reference's lower-bound tie, here at eps = 0
         if not (len(a) == len(w[0]) and np.array_equal(a.offsets, w[0]) and np.array_equal(a.distances, w[1]) and a.cnt_candidate == w[2]["cnt_candidate"]):
             bad += 1; print("MISMATCH", name, case, len(a), len(w[0]), a.cnt_candidate, w[2]["cnt_candidate"], "n", n, "m", m, "seg", seg, "eps", eps, "qoff", qoff,
                             "got", a.offsets[:5], a.distances[:5], "want", w[0][:5], w[1][:5], "stats", a.stats[:6], {k_: w[2][k_] for k_ in ("pass_filter", "pass_kim", "pass_keogh", "pass_keogh2")}, flush=True)
