@@ -126,7 +126,7 @@ extern "C" int kvm_close(kvm_ctx *ctx) {
     hipStreamSynchronize(ctx->stream);
     free_series(ctx);
     kvm_dev_buf *bufs[] = {&ctx->b_query, &ctx->b_tiles, &ctx->b_out_off, &ctx->b_out_dist, &ctx->b_counters,
-                           &ctx->b_cands, &ctx->b_cands2, &ctx->b_aux,   &ctx->b_aux2,    &ctx->b_scratch};
+                           &ctx->b_cands, &ctx->b_cands2, &ctx->b_aux,   &ctx->b_aux2,    &ctx->b_scratch, &ctx->b_plans};
     for (kvm_dev_buf *b : bufs)
         if (b->p) hipFree(b->p);
     if (ctx->h_pinned) hipHostFree(ctx->h_pinned);
@@ -1071,8 +1071,9 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
             HIPCHK(ctx, kvm_launch_exact_stats(ctx->d_series, qd, c1, dp_n, pl.windows, rws, counters, ctx->num_cu, stream));
         KVM_DBG_SYNC(ctx, stream, "exact_stats");
         if (ctx->opt_timing) HIPCHK(ctx, hipEventRecord(ctx->ev0, stream));  // time the DP kernel alone
-        HIPCHK(ctx, kvm_launch_dtw_dp(ctx->d_series, ctx->n, qd, ax, c1, dp_n, pl.windows, out.d_off, out.d_dist, out.cap,
-                                      counters, ctx->num_cu, ctx->opt_dp_kernel == 1 ? 1 : 0, stream));
+        if ((rc = ensure(ctx, ctx->b_plans, kvm_dtw_plan_bytes(pl.windows) + 64))) return rc;
+        HIPCHK(ctx, kvm_launch_dtw_dp(ctx->d_series, ctx->n, qd, ax, c1, dp_n, pl.windows, ctx->b_plans.p, out.d_off, out.d_dist,
+                                      out.cap, counters, ctx->num_cu, ctx->opt_dp_kernel == 1 ? 1 : 0, stream));
         KVM_DBG_SYNC(ctx, stream, "dtw_dp");
         dtw_qd = qd;
     }
@@ -1112,8 +1113,9 @@ static int dtw_resolve_ambiguous(kvm_ctx *ctx, const kvm_query_dev &qd, const kv
         HIPCHK(ctx, kvm_launch_dtw_ref_chains(ctx->d_series, qd, ax, cands + off, nb, slots, stream));
         KVM_DBG_SYNC(ctx, stream, "dtw_ref_chains");
         HIPCHK(ctx, kvm_launch_set_u64(counters + KVM_CNT_CANDS2, (unsigned long long)nb, counters + KVM_CNT_QUEUE, 0ULL, stream));
-        HIPCHK(ctx, kvm_launch_dtw_dp(ctx->d_series, ctx->n, qd, ax2, cands + off, counters + KVM_CNT_CANDS2, nb, out.d_off,
-                                      out.d_dist, out.cap, counters, ctx->num_cu, ctx->opt_dp_kernel == 1 ? 1 : 0, stream));
+        HIPCHK(ctx, kvm_launch_dtw_dp(ctx->d_series, ctx->n, qd, ax2, cands + off, counters + KVM_CNT_CANDS2, nb, nullptr,
+                                      out.d_off, out.d_dist, out.cap, counters, ctx->num_cu, ctx->opt_dp_kernel == 1 ? 1 : 0,
+                                      stream));
         KVM_DBG_SYNC(ctx, stream, "dtw_dp (exact cb)");
     }
     return KVM_OK;

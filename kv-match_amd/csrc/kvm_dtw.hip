@@ -148,13 +148,18 @@ __device__ __forceinline__ void dp_scan_maxmin(double &mx, double &mn, int lane)
     }
 }
 
-// What the prologue hands to the sweep: which bound's terms form cb[] (0: query envelope, 1: data envelope), their
-// total, and the geometry of the clipped data envelope.
+// What the prologue (kvm_dtw_prep_kernel) hands to the sweep, one record per candidate: which bound's terms form cb[]
+// (0: query envelope, 1: data envelope; < 0: the candidate does not reach the DP), their total, and the geometry of the
+// clipped data envelope.
 struct dp_plan {
-    int which;
-    double total;
+    int32_t which;
     int32_t cbeg, cend, sb;  // fetched chunk [cbeg, cend] (1-based points); sb = first point of the suffix patch
+    double total;
+    double pad;
 };
+static_assert(sizeof(dp_plan) == 32, "one 32-byte record per candidate");
+#define DP_PLAN_REJECT (-1)
+#define DP_PLAN_AMBIG (-2)
 
 // Upper / lower data envelope at 1-based point p as the reference builds it over the fetched chunk:
 // max / min of data[max(cbeg, p-r) .. min(cend, p+r)].  Interior points come from the whole-series envelope; within r of a
@@ -173,6 +178,51 @@ __device__ __forceinline__ void dp_env_at(const kvm_dtw_aux &ax, const double *_
         U = ax.env_u[p - 1];
         L = ax.env_l[p - 1];
     }
+}
+
+// The wave's envelope patch for one candidate: running max / min of the data from cbeg upwards (entries [0, 2r) max,
+// [2r, 4r) min) and from cend downwards (entries [4r, 6r) / [6r, 8r), indexed from sb), computed only when the candidate's
+// window comes within r of that end of the chunk.  2r points each: a handful of wave scans.
+__device__ __forceinline__ void dp_build_patch(const double *__restrict__ series, int r, const dp_plan &pl, int32_t start, int m,
+                                               int lane, double *__restrict__ patch) {
+    const int32_t s1 = start, e1 = start + m - 1;
+    if (!(r > 0 && (s1 - r < pl.cbeg || e1 + r > pl.cend))) return;
+    if (s1 - r < pl.cbeg) {
+        const int32_t last = min(pl.cend, pl.cbeg + 2 * r - 1);
+        double cx = -__builtin_huge_val(), cn = __builtin_huge_val();
+        for (int32_t base = pl.cbeg; base <= last; base += 64) {
+            const int32_t t = base + lane;
+            const double v = series[min(t, last) - 1];
+            double mx = v, mn = v;  // (lanes past `last` repeat the last point: no effect on a running max / min)
+            dp_scan_maxmin(mx, mn, lane);
+            mx = dp_sel_max(cx, mx);
+            mn = dp_sel_min(cn, mn);
+            if (t <= last) {
+                patch[t - pl.cbeg] = mx;
+                patch[2 * r + (t - pl.cbeg)] = mn;
+            }
+            cx = kvm_readlane_f64(mx, 63);
+            cn = kvm_readlane_f64(mn, 63);
+        }
+    }
+    if (e1 + r > pl.cend) {
+        double cx = -__builtin_huge_val(), cn = __builtin_huge_val();
+        for (int32_t base = pl.cend; base >= pl.sb; base -= 64) {
+            const int32_t t = base - lane;
+            const double v = series[max(t, pl.sb) - 1];
+            double mx = v, mn = v;
+            dp_scan_maxmin(mx, mn, lane);
+            mx = dp_sel_max(cx, mx);
+            mn = dp_sel_min(cn, mn);
+            if (t >= pl.sb) {
+                patch[4 * r + (t - pl.sb)] = mx;
+                patch[6 * r + (t - pl.sb)] = mn;
+            }
+            cx = kvm_readlane_f64(mx, 63);
+            cn = kvm_readlane_f64(mn, 63);
+        }
+    }
+    __threadfence();  // the patch is read back by other lanes of this wavefront (through the CU's L1)
 }
 
 // term k (natural window position) of the bound chosen for cb[]: cb1[k] / cb2[k] of K/NormQueryEngineDtw.java:559-575
@@ -216,45 +266,7 @@ __device__ int dp_prologue(const double *__restrict__ series, const kvm_query_de
     // ---- the data envelope at the ends of the fetched chunk ----
     dref_chunk(ax, m, c.run_start, pl.cbeg, pl.cend);
     pl.sb = max(pl.cbeg, pl.cend - 2 * r + 1);
-    const int32_t s1 = c.start, e1 = c.start + m - 1;
-    if (r > 0 && (s1 - r < pl.cbeg || e1 + r > pl.cend)) {
-        if (s1 - r < pl.cbeg) {
-            const int32_t last = min(pl.cend, pl.cbeg + 2 * r - 1);
-            double cx = -__builtin_huge_val(), cn = __builtin_huge_val();
-            for (int32_t base = pl.cbeg; base <= last; base += 64) {
-                const int32_t t = base + lane;
-                const double v = series[min(t, last) - 1];
-                double mx = v, mn = v;  // (lanes past `last` repeat the last point: no effect on a running max / min)
-                dp_scan_maxmin(mx, mn, lane);
-                mx = dp_sel_max(cx, mx);
-                mn = dp_sel_min(cn, mn);
-                if (t <= last) {
-                    patch[t - pl.cbeg] = mx;
-                    patch[2 * r + (t - pl.cbeg)] = mn;
-                }
-                cx = kvm_readlane_f64(mx, 63);
-                cn = kvm_readlane_f64(mn, 63);
-            }
-        }
-        if (e1 + r > pl.cend) {
-            double cx = -__builtin_huge_val(), cn = __builtin_huge_val();
-            for (int32_t base = pl.cend; base >= pl.sb; base -= 64) {
-                const int32_t t = base - lane;
-                const double v = series[max(t, pl.sb) - 1];
-                double mx = v, mn = v;
-                dp_scan_maxmin(mx, mn, lane);
-                mx = dp_sel_max(cx, mx);
-                mn = dp_sel_min(cn, mn);
-                if (t >= pl.sb) {
-                    patch[4 * r + (t - pl.sb)] = mx;
-                    patch[6 * r + (t - pl.sb)] = mn;
-                }
-                cx = kvm_readlane_f64(mx, 63);
-                cn = kvm_readlane_f64(mn, 63);
-            }
-        }
-        __threadfence();  // the patch is read back by other lanes of this wavefront (through the CU's L1)
-    }
+    dp_build_patch(series, r, pl, c.start, m, lane, patch);
     // ---- lbKeoghDataCumulative, same form ----
     carry = 0.0;
     for (int base = 0; base < m; base += 64) {
@@ -308,6 +320,34 @@ __device__ __forceinline__ void dp_emit_ambig(const kvm_dtw_aux &ax, unsigned lo
     if (lane == 0) ax.ambig[atomicAdd(&counters[KVM_CNT_AMBIG], 1ULL)] = c;
 }
 
+// The prologue as its own kernel (one wavefront per candidate, grid-stride): it writes one dp_plan per candidate and
+// queues the ambiguous ones.  Kept out of the DP kernels so that their register allocation is the sweep's alone (with the
+// prologue inlined the register form needed 148 VGPRs -- three waves per SIMD instead of four -- and spilled 100 SGPRs).
+__global__ __launch_bounds__(256) void kvm_dtw_prep_kernel(const double *__restrict__ series, kvm_query_dev qd, kvm_dtw_aux ax,
+                                                           const kvm_cand *__restrict__ in,
+                                                           const unsigned long long *__restrict__ d_n_in,
+                                                           dp_plan *__restrict__ plans,
+                                                           unsigned long long *__restrict__ counters) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long n_in = *d_n_in;
+    const unsigned long long slot = (unsigned long long)blockIdx.x * 4 + wave, slots = (unsigned long long)gridDim.x * 4;
+    double *__restrict__ patch = ax.patch + (size_t)slot * 8 * (size_t)qd.rho;
+    for (unsigned long long idx = slot; idx < n_in; idx += slots) {
+        const kvm_cand c = in[idx];
+        dp_plan pl;
+        pl.which = DP_PLAN_REJECT; pl.total = 0.0; pl.pad = 0.0; pl.cbeg = pl.cend = pl.sb = 0;
+        if (c.start >= 0) {  // (negative: rejected by the exact (alpha, beta) test)
+            const int st = dp_prologue(series, qd, ax, c, lane, patch, pl);
+            if (st == DP_REJECT) pl.which = DP_PLAN_REJECT;
+            if (st == DP_AMBIG) {
+                pl.which = DP_PLAN_AMBIG;
+                dp_emit_ambig(ax, counters, c, lane);
+            }
+        }
+        if (lane == 0) plans[idx] = pl;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // DP, generic form (any rho): banded DP swept by anti-diagonals, one wavefront per candidate, band rows in LDS.
 //
@@ -333,6 +373,7 @@ __host__ __device__ static inline size_t dp_lds_doubles(int m, int r) { return (
 template <bool ABANDON>
 __global__ __launch_bounds__(64) void kvm_dtw_dp_lds_kernel(const double *__restrict__ series, kvm_query_dev qd,
                                                             kvm_dtw_aux ax, const kvm_cand *__restrict__ in,
+                                                            const dp_plan *__restrict__ plans,
                                                             const unsigned long long *__restrict__ d_n_in,
                                                             int32_t *__restrict__ out_off,
                                                             double *__restrict__ out_dist, int64_t cap,
@@ -362,14 +403,11 @@ __global__ __launch_bounds__(64) void kvm_dtw_dp_lds_kernel(const double *__rest
         if (c.start < 0) continue;  // rejected by the exact (alpha, beta) test / by the sequential path
         const double *__restrict__ x = series + (c.start - 1);
         dp_plan pl;
-        pl.which = 0; pl.total = 0.0; pl.cbeg = pl.cend = pl.sb = 0;
+        pl.which = 0; pl.total = 0.0; pl.pad = 0.0; pl.cbeg = pl.cend = pl.sb = 0;
         if (!exact) {
-            const int st = dp_prologue(series, qd, ax, c, lane, patch, pl);
-            if (st == DP_REJECT) continue;
-            if (st == DP_AMBIG) {
-                dp_emit_ambig(ax, counters, c, lane);
-                continue;
-            }
+            pl = plans[idx];
+            if (pl.which < 0) continue;  // dropped by the prologue, or queued for the sequential path
+            if (pl.which == 1) dp_build_patch(series, r, pl, c.start, m, lane, patch);
         }
         if (lane == 0) atomicAdd(&counters[KVM_CNT_PASS_KEOGH2], 1ULL);
         // cb[]: exact arrays of the sequential path, or total - prefix of the chosen bound's terms
@@ -538,9 +576,11 @@ struct dp_buf {
     static constexpr int LIN = LIVE + 64 * DP_EPOCH;     // doubles per buffer (V=4: 768 = 6 KiB)
 };
 
+// (V <= 4: at most 128 VGPRs, so that four wavefronts fit a SIMD -- the sweep is pure VALU issue and needs them)
 template <int V, int CSTAR, bool ABANDON>
-__global__ __launch_bounds__(256) void kvm_dtw_dp_reg_kernel(const double *__restrict__ series, kvm_query_dev qd,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(V <= 4 ? 4 : 2, V <= 4 ? 4 : 2))) void kvm_dtw_dp_reg_kernel(const double *__restrict__ series, kvm_query_dev qd,
                                                              kvm_dtw_aux ax, const kvm_cand *__restrict__ in,
+                                                             const dp_plan *__restrict__ plans,
                                                              const unsigned long long *__restrict__ d_n_in,
                                                              int32_t *__restrict__ out_off,
                                                              double *__restrict__ out_dist, int64_t cap,
@@ -573,14 +613,11 @@ __global__ __launch_bounds__(256) void kvm_dtw_dp_reg_kernel(const double *__res
         const double *__restrict__ x = series + (cand.start - 1);
         const double mean = cand.mean, sd = cand.std;
         dp_plan pl;
-        pl.which = 0; pl.total = 0.0; pl.cbeg = pl.cend = pl.sb = 0;
+        pl.which = 0; pl.total = 0.0; pl.pad = 0.0; pl.cbeg = pl.cend = pl.sb = 0;
         if (!exact) {
-            const int st = dp_prologue(series, qd, ax, cand, lane, patch, pl);
-            if (st == DP_REJECT) continue;
-            if (st == DP_AMBIG) {
-                dp_emit_ambig(ax, counters, cand, lane);
-                continue;
-            }
+            pl = plans[idx];
+            if (pl.which < 0) continue;  // dropped by the prologue, or queued for the sequential path
+            if (pl.which == 1) dp_build_patch(series, r, pl, cand.start, m, lane, patch);
         }
         if (lane == 0) atomicAdd(&counters[KVM_CNT_PASS_KEOGH2], 1ULL);
         const double *__restrict__ cb_src = exact ? ax.cb_exact + (size_t)idx * 2 * m + (cand.lim != 0.0 ? m : 0) : nullptr;
@@ -753,7 +790,7 @@ __global__ __launch_bounds__(256) void kvm_dtw_dp_reg_kernel(const double *__res
 
 template <int V, int CSTAR>
 static hipError_t launch_dp_reg_c(const double *series, const kvm_query_dev &qd, const kvm_dtw_aux &ax, const kvm_cand *in,
-                                  const unsigned long long *d_n_in, int64_t max_in, int32_t *out_off, double *out_dist,
+                                  const dp_plan *plans, const unsigned long long *d_n_in, int64_t max_in, int32_t *out_off, double *out_dist,
                                   int64_t cap, unsigned long long *counters, int num_cu, hipStream_t s) {
     // waves per SIMD = DP_BLOCKS_PER_CU (bounded by LDS: 4 waves x (2*LIN + 64V + 64) doubles per workgroup)
     const int lds_limit = (int)((160 * 1024) / (4 * (2 * dp_buf<V>::LIN + 64 * V + 64) * sizeof(double)));
@@ -761,22 +798,22 @@ static hipError_t launch_dp_reg_c(const double *series, const kvm_query_dev &qd,
     if (blocks > (max_in + 3) / 4) blocks = (max_in + 3) / 4;
     if (qd.early_abandon)
         hipLaunchKernelGGL((kvm_dtw_dp_reg_kernel<V, CSTAR, true>), dim3((unsigned)blocks), dim3(256), 0, s, series, qd,
-                           ax, in, d_n_in, out_off, out_dist, cap, counters);
+                           ax, in, plans, d_n_in, out_off, out_dist, cap, counters);
     else
         hipLaunchKernelGGL((kvm_dtw_dp_reg_kernel<V, CSTAR, false>), dim3((unsigned)blocks), dim3(256), 0, s, series, qd,
-                           ax, in, d_n_in, out_off, out_dist, cap, counters);
+                           ax, in, plans, d_n_in, out_off, out_dist, cap, counters);
     return hipGetLastError();
 }
 
 // dispatch on the (launch-constant) position CSTAR = rho % V of the band-edge cell
 template <int V>
 static hipError_t launch_dp_reg(const double *series, const kvm_query_dev &qd, const kvm_dtw_aux &ax, const kvm_cand *in,
-                                const unsigned long long *d_n_in, int64_t max_in, int32_t *out_off, double *out_dist,
+                                const dp_plan *plans, const unsigned long long *d_n_in, int64_t max_in, int32_t *out_off, double *out_dist,
                                 int64_t cap, unsigned long long *counters, int num_cu, hipStream_t s) {
 #define KVM_DP_CASE(C)                                                                                          \
     case C:                                                                                                     \
         if constexpr (C < V)                                                                                    \
-            return launch_dp_reg_c<V, C>(series, qd, ax, in, d_n_in, max_in, out_off, out_dist, cap, counters, num_cu, s); \
+            return launch_dp_reg_c<V, C>(series, qd, ax, in, plans, d_n_in, max_in, out_off, out_dist, cap, counters, num_cu, s); \
         break;
     switch (qd.rho % V) {
         KVM_DP_CASE(0) KVM_DP_CASE(1) KVM_DP_CASE(2) KVM_DP_CASE(3)
@@ -788,18 +825,31 @@ static hipError_t launch_dp_reg(const double *series, const kvm_query_dev &qd, c
 
 int64_t kvm_dtw_dp_max_waves(int num_cu) { return (int64_t)num_cu * 4 * DP_BLOCKS_PER_CU; }
 
+size_t kvm_dtw_plan_bytes(int64_t n) { return (size_t)n * sizeof(dp_plan); }
+
+// `plan_buf`: kvm_dtw_plan_bytes(max_in) bytes of scratch for the per-candidate plan records (unused when ax.cb_exact is
+// set: the second run on the sequential path's candidates has nothing left to decide in front of the DP)
 hipError_t kvm_launch_dtw_dp(const double *series, int64_t n, const kvm_query_dev &qd, const kvm_dtw_aux &ax, const kvm_cand *in,
-                             const unsigned long long *d_n_in, int64_t max_in, int32_t *out_off, double *out_dist,
+                             const unsigned long long *d_n_in, int64_t max_in, void *plan_buf, int32_t *out_off, double *out_dist,
                              int64_t cap, unsigned long long *counters, int num_cu, int force_lds, hipStream_t s) {
     (void)n;
     if (max_in <= 0) return hipSuccess;
+    dp_plan *plans = reinterpret_cast<dp_plan *>(plan_buf);
+    if (!ax.cb_exact) {
+        int64_t pblocks = (int64_t)num_cu * DP_BLOCKS_PER_CU;  // (as many waves as the patch scratch has slices)
+        if (pblocks > (max_in + 3) / 4) pblocks = (max_in + 3) / 4;
+        hipLaunchKernelGGL(kvm_dtw_prep_kernel, dim3((unsigned)pblocks), dim3(256), 0, s, series, qd, ax, in, d_n_in, plans,
+                           counters);
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
     // register form: band of r+1 even-k cells over 64 lanes, V = pow2 cells per lane, V <= 8 (r <= 511)
     const int need = (qd.rho + 1 + 63) / 64;
     if (!force_lds && need <= 8 && qd.m >= 2) {
-        if (need <= 1) return launch_dp_reg<1>(series, qd, ax, in, d_n_in, max_in, out_off, out_dist, cap, counters, num_cu, s);
-        if (need <= 2) return launch_dp_reg<2>(series, qd, ax, in, d_n_in, max_in, out_off, out_dist, cap, counters, num_cu, s);
-        if (need <= 4) return launch_dp_reg<4>(series, qd, ax, in, d_n_in, max_in, out_off, out_dist, cap, counters, num_cu, s);
-        return launch_dp_reg<8>(series, qd, ax, in, d_n_in, max_in, out_off, out_dist, cap, counters, num_cu, s);
+        if (need <= 1) return launch_dp_reg<1>(series, qd, ax, in, plans, d_n_in, max_in, out_off, out_dist, cap, counters, num_cu, s);
+        if (need <= 2) return launch_dp_reg<2>(series, qd, ax, in, plans, d_n_in, max_in, out_off, out_dist, cap, counters, num_cu, s);
+        if (need <= 4) return launch_dp_reg<4>(series, qd, ax, in, plans, d_n_in, max_in, out_off, out_dist, cap, counters, num_cu, s);
+        return launch_dp_reg<8>(series, qd, ax, in, plans, d_n_in, max_in, out_off, out_dist, cap, counters, num_cu, s);
     }
     // generic form (any r): arrays in LDS when they fit, else in a stream-ordered global scratch
     const size_t need_bytes = dp_lds_doubles(qd.m, qd.rho) * sizeof(double);
@@ -823,10 +873,10 @@ hipError_t kvm_launch_dtw_dp(const double *series, int64_t n, const kvm_query_de
     }
     if (qd.early_abandon)
         hipLaunchKernelGGL((kvm_dtw_dp_lds_kernel<true>), dim3((unsigned)blocks), dim3(64), lds, s, series, qd, ax, in,
-                           d_n_in, out_off, out_dist, cap, counters, scratch);
+                           plans, d_n_in, out_off, out_dist, cap, counters, scratch);
     else
         hipLaunchKernelGGL((kvm_dtw_dp_lds_kernel<false>), dim3((unsigned)blocks), dim3(64), lds, s, series, qd, ax, in,
-                           d_n_in, out_off, out_dist, cap, counters, scratch);
+                           plans, d_n_in, out_off, out_dist, cap, counters, scratch);
     if (scratch) {
         const hipError_t e1 = hipGetLastError(), e2 = hipFreeAsync(scratch, s);
         return e1 != hipSuccess ? e1 : e2;

@@ -87,7 +87,7 @@ struct kvm_ctx {
     hipEvent_t ev_env = nullptr;     // recorded behind the envelope build
     hipStream_t env_stream = nullptr;  // the stream it was built on
     // grow-only scratch
-    kvm_dev_buf b_query, b_tiles, b_out_off, b_out_dist, b_counters, b_cands, b_cands2, b_aux, b_aux2, b_scratch;
+    kvm_dev_buf b_query, b_tiles, b_out_off, b_out_dist, b_counters, b_cands, b_cands2, b_aux, b_aux2, b_scratch, b_plans;
     void *h_pinned = nullptr;
     void *h_readback2 = nullptr;  // pinned: answers beyond the first KVM_SPEC_ANSWERS (grow-only)
     size_t h_readback2_cap = 0;
@@ -276,8 +276,9 @@ hipError_t kvm_launch_retile_dtw(const double *series, const double2 *prefix, co
                                  int64_t n_tiles, kvm_tile *out_tiles, unsigned long long *counters, hipStream_t s);
 // waves of the DP launch that use a slice of kvm_dtw_aux::patch (the launch never starts more)
 int64_t kvm_dtw_dp_max_waves(int num_cu);
+size_t kvm_dtw_plan_bytes(int64_t n);  // scratch of kvm_launch_dtw_dp: one plan record per candidate
 hipError_t kvm_launch_dtw_dp(const double *series, int64_t n, const kvm_query_dev &qd, const kvm_dtw_aux &ax, const kvm_cand *in,
-                             const unsigned long long *d_n_in, int64_t max_in, int32_t *out_off, double *out_dist,
+                             const unsigned long long *d_n_in, int64_t max_in, void *plan_buf, int32_t *out_off, double *out_dist,
                              int64_t cap, unsigned long long *counters, int num_cu, int force_lds, hipStream_t s);
 
 // counters layout (unsigned long long[16])

@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libkvmatch_hip.so")
+# (KVM_LIB in the environment: another build of the same library, e.g. a tuning variant under profiles/)
+LIB_PATH = os.environ.get("KVM_LIB") or os.path.join(os.path.dirname(_HERE), "csrc", "libkvmatch_hip.so")
 
 KVM_OK = 0
 KVM_ERR_INVALID_HANDLE = -1

@@ -13,6 +13,6 @@ eng = kvmatch.QueryEngineDtw(ctx)
 rho = 204
 cells = m*(2*rho+1) - rho*(rho+1)
 for i in range(4):
-    a = eng.verify((L, R), 1, q, 10.0, 0.05)
+    a = eng.verify((L, R), 1, q, 1e6, 0.05)  # eps so large that nothing is dropped in front of the DP or abandoned in it
     ns = ctx._lib.kvm_last_kernel_ns(ctx._h)
     print("windows", a.stats[0], "dp kernel ms", ns*1e-6, "cells/s %.3e" % (a.stats[0]*cells/(ns*1e-9)), "cand/s %.3e" % (a.stats[0]/(ns*1e-9)))
