@@ -1,6 +1,9 @@
 /*
  * kvmatch_jni.c -- JNI shim over include/kvmatch.h for cn.edu.fudan.dsm.kvmatch.gpu.Phase2Gpu.
- * Not part of the default build: this image has no JDK.  Compiles only where <jni.h> is available.
+ * Not part of the default build: this image has no JDK.  Compiles only where <jni.h> is available
+ * (cc -shared -fPIC -I$JAVA_HOME/include -I$JAVA_HOME/include/linux kvmatch_jni.c -L../csrc -lkvmatch_hip).
+ * tests/test_abi.py type-checks it against a minimal declaration-only jni.h (tests/jni_stub/) and compares every
+ * export's C signature with the `native` declaration in Phase2Gpu.java.
  */
 #if defined(__has_include)
 #if __has_include(<jni.h>)
@@ -10,6 +13,9 @@
 
 #ifdef KVM_HAVE_JNI
 #include <jni.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
 #include "../../include/kvmatch.h"
 
 static void throw_for(JNIEnv *env, kvm_ctx *ctx, int rc) {
@@ -47,10 +53,14 @@ JNIEXPORT void JNICALL Java_cn_edu_fudan_dsm_kvmatch_gpu_Phase2Gpu_close(JNIEnv 
 static jobject make_result(JNIEnv *env, kvm_ctx *ctx, int rc, kvm_result *res) {
     if (rc) { throw_for(env, ctx, rc); return 0; }
     jclass cls = (*env)->FindClass(env, "cn/edu/fudan/dsm/kvmatch/gpu/Phase2Gpu$Result");
-    jobject o = (*env)->AllocObject(env, cls);
+    jobject o = cls ? (*env)->AllocObject(env, cls) : 0;
     jsize cnt = (jsize)kvm_result_count(res);
-    jintArray off = (*env)->NewIntArray(env, cnt);
-    jdoubleArray dist = (*env)->NewDoubleArray(env, cnt);
+    jintArray off = o ? (*env)->NewIntArray(env, cnt) : 0;
+    jdoubleArray dist = off ? (*env)->NewDoubleArray(env, cnt) : 0;
+    if (!dist) {  /* (a Java exception -- NoClassDefFoundError / OutOfMemoryError -- is pending) */
+        kvm_result_free(res);
+        return 0;
+    }
     if (cnt) {
         (*env)->SetIntArrayRegion(env, off, 0, cnt, (const jint *)kvm_result_offsets(res));
         (*env)->SetDoubleArrayRegion(env, dist, 0, cnt, kvm_result_distances(res));
@@ -62,17 +72,63 @@ static jobject make_result(JNIEnv *env, kvm_ctx *ctx, int rc, kvm_result *res) {
     return o;
 }
 
-#define PIN(arr) (*env)->GetPrimitiveArrayCritical(env, arr, 0)
-#define UNPIN(arr, p) (*env)->ReleasePrimitiveArrayCritical(env, arr, p, JNI_ABORT)
+/* Inputs are COPIED out of the Java heap (Get<Type>ArrayRegion) before the library is called: no array is pinned and no
+ * JNI critical region is open while the GPU works (a phase-2 call takes 0.2 ms .. 0.4 s; GetPrimitiveArrayCritical
+ * would stall the collector for all of it).  The copies are m*8 + 2k*4 bytes -- what the library itself moves into its
+ * pinned staging buffer in the first microseconds of the call. */
+typedef struct {
+    double *q;
+    jint *left, *right;
+    jsize m, k;
+} kvm_jni_in;
+
+static void in_free(kvm_jni_in *in) {
+    free(in->q);
+    free(in->left);
+    free(in->right);
+}
+
+/* returns 0 and leaves a pending Java exception on failure */
+static int in_copy(JNIEnv *env, jdoubleArray q, jintArray left, jintArray right, kvm_jni_in *in) {
+    memset(in, 0, sizeof *in);
+    if (!q || !left || !right) {
+        (*env)->ThrowNew(env, (*env)->FindClass(env, "java/lang/IllegalArgumentException"), "null array");
+        return 0;
+    }
+    in->m = (*env)->GetArrayLength(env, q);
+    in->k = (*env)->GetArrayLength(env, left);
+    if ((*env)->GetArrayLength(env, right) != in->k) {
+        (*env)->ThrowNew(env, (*env)->FindClass(env, "java/lang/IllegalArgumentException"), "left/right length mismatch");
+        return 0;
+    }
+    in->q = (double *)malloc((size_t)(in->m > 0 ? in->m : 1) * sizeof(double));
+    in->left = (jint *)malloc((size_t)(in->k > 0 ? in->k : 1) * sizeof(jint));
+    in->right = (jint *)malloc((size_t)(in->k > 0 ? in->k : 1) * sizeof(jint));
+    if (!in->q || !in->left || !in->right) {
+        in_free(in);
+        (*env)->ThrowNew(env, (*env)->FindClass(env, "java/lang/OutOfMemoryError"), "kvmatch_jni: staging copy");
+        return 0;
+    }
+    (*env)->GetDoubleArrayRegion(env, q, 0, in->m, in->q);
+    (*env)->GetIntArrayRegion(env, left, 0, in->k, in->left);
+    (*env)->GetIntArrayRegion(env, right, 0, in->k, in->right);
+    if ((*env)->ExceptionCheck(env)) {
+        in_free(in);
+        return 0;
+    }
+    return 1;
+}
 
 #define KVM_JNI_BODY(CALL)                                                                         \
     kvm_ctx *ctx = (kvm_ctx *)(intptr_t)h;                                                         \
-    jsize m = (*env)->GetArrayLength(env, q), k = (*env)->GetArrayLength(env, left);               \
-    double *pq = PIN(q);                                                                           \
-    jint *pl = PIN(left), *pr = PIN(right);                                                        \
+    kvm_jni_in in;                                                                                 \
+    if (!in_copy(env, q, left, right, &in)) return 0;                                              \
+    const double *pq = in.q;                                                                       \
+    const jint *pl = in.left, *pr = in.right;                                                      \
+    const jsize m = in.m, k = in.k;                                                                \
     kvm_result *res = 0;                                                                           \
     int rc = CALL;                                                                                 \
-    UNPIN(right, pr); UNPIN(left, pl); UNPIN(q, pq);                                               \
+    in_free(&in);                                                                                  \
     return make_result(env, ctx, rc, res);
 
 JNIEXPORT jobject JNICALL Java_cn_edu_fudan_dsm_kvmatch_gpu_Phase2Gpu_rsmEd(JNIEnv *env, jobject self, jlong h,
@@ -102,12 +158,20 @@ JNIEXPORT jdoubleArray JNICALL Java_cn_edu_fudan_dsm_kvmatch_gpu_Phase2Gpu_readT
                                                                                        jint left, jint length) {
     (void)c;
     kvm_ctx *ctx = (kvm_ctx *)(intptr_t)h;
-    jdoubleArray out = (*env)->NewDoubleArray(env, length > 0 ? length : 0);
-    if (!out) return 0;
-    double *p = PIN(out);
-    int rc = kvm_read_time_series(ctx, left, length, p);
-    (*env)->ReleasePrimitiveArrayCritical(env, out, p, 0);
-    if (rc) { throw_for(env, ctx, rc); return 0; }
+    const jsize cnt = length > 0 ? length : 0;
+    double *buf = (double *)malloc((size_t)(cnt > 0 ? cnt : 1) * sizeof(double));
+    if (!buf) {
+        (*env)->ThrowNew(env, (*env)->FindClass(env, "java/lang/OutOfMemoryError"), "kvmatch_jni: readTimeSeries");
+        return 0;
+    }
+    int rc = kvm_read_time_series(ctx, left, length, buf);  /* (range errors as the file operator raises them) */
+    jdoubleArray out = 0;
+    if (rc) {
+        throw_for(env, ctx, rc);
+    } else if ((out = (*env)->NewDoubleArray(env, cnt)) != 0) {
+        (*env)->SetDoubleArrayRegion(env, out, 0, cnt, buf);
+    }
+    free(buf);
     return out;
 }
 

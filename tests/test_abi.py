@@ -93,6 +93,39 @@ def test_java_adapter_natives_match_the_jni_shim():
         assert re.search(r"\b" + fn + r"\s*\(", header), fn
 
 
+def test_jni_shim_type_checks_and_signatures_match_the_java_natives():
+    """The JNI shim compiles (syntax + types, -Wall -Wextra -Werror) against a declaration-only jni.h (tests/jni_stub/: the
+    JNI types and the JNIEnv entry points the shim uses, as the JNI specification declares them), and every
+    Java_..._Phase2Gpu_<name> export has exactly the C signature that the `native` declaration of <name> in
+    Phase2Gpu.java maps to (JNI type mapping: int -> jint, long -> jlong, double -> jdouble, String -> jstring,
+    int[] -> jintArray, double[] -> jdoubleArray, objects -> jobject; static -> jclass receiver, instance -> jobject)."""
+    import subprocess
+    root = ROOT
+    shim = os.path.join(root, "kv-match_amd", "jni", "kvmatch_jni.c")
+    r = subprocess.run(["gcc", "-std=c11", "-fsyntax-only", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(root, "tests", "jni_stub"),
+                        shim], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    # the shim no longer holds JNI critical regions across a GPU call
+    src = re.sub(r"/\*.*?\*/", "", open(shim).read(), flags=re.S)
+    assert "GetPrimitiveArrayCritical" not in src
+    java = open(os.path.join(root, "kv-match_amd", "java", "cn", "edu", "fudan", "dsm", "kvmatch", "gpu", "Phase2Gpu.java")).read()
+    java = re.sub(r"/\*.*?\*/|//[^\n]*", "", java, flags=re.S)
+    jmap = {"int": "jint", "long": "jlong", "double": "jdouble", "void": "void", "String": "jstring", "int[]": "jintArray",
+            "double[]": "jdoubleArray", "Result": "jobject"}
+    natives = {}
+    for mods, ret, name, params in re.findall(r"((?:public|private|static|final|\s)*)\bnative\s+([\w\[\]]+)\s+(\w+)\s*\(([^)]*)\)", java):
+        ptypes = [jmap[" ".join(p.split()[:-1]).replace(" ", "")] for p in params.split(",") if p.strip()]
+        natives[name] = (jmap[ret], "jclass" if "static" in mods.split() else "jobject", ptypes)
+    exports = {}
+    for ret, name, params in re.findall(r"JNIEXPORT\s+(\w+)\s+JNICALL\s+Java_cn_edu_fudan_dsm_kvmatch_gpu_Phase2Gpu_(\w+)\s*\(([^)]*)\)", src):
+        ps = [re.match(r"^(.*?)\w+$", x.strip()).group(1).replace(" ", "") for x in params.split(",")]
+        assert ps[0] == "JNIEnv*", (name, ps)
+        exports[name] = (ret, ps[1], ps[2:])
+    assert set(natives) == set(exports) and len(natives) >= 16
+    for name in natives:
+        assert natives[name] == exports[name], (name, natives[name], exports[name])
+
+
 def test_cpp_host_mirror_compiles():
     """kv-match_amd/host/kvmatch_engines.hpp (the C++ mirror of the reference's engine classes) against include/kvmatch.h."""
     import os, subprocess
