@@ -1,0 +1,500 @@
+"""An INDEPENDENT pure-Python transliteration of the reference's four phase-2 blocks, written from the Java sources (not
+from oracle/kvm_oracle.c), statement for statement, to lower the risk that the C oracle mis-transcribes them:
+
+    rsm_ed    K/QueryEngine.java:341-363, sort :373
+    cnsm_ed   K/NormQueryEngine.java:192-198 (query statistics), :437-526, sort
+    rsm_dtw   K/QueryEngineDtw.java:352-449, sort
+    cnsm_dtw  K/NormQueryEngineDtw.java:205-211, :460-601, sort
+    DtwUtils  K/utils/DtwUtils.java:24-337, CircularArray K/common/CircularArray.java:21-110,
+    readTimeSeries range check K/operator/file/TimeSeriesFileOperator.java:55-57
+
+(K/ = /root/reference/src/main/java/cn/edu/fudan/dsm/kvmatch/.)  Python floats are IEEE-754 binary64, `a * b + c` is
+never fused and math.sqrt is correctly rounded, exactly like Java's double arithmetic; ints do not overflow at these
+sizes.  TEST INFRASTRUCTURE ONLY; it pins nothing by itself (no output of the Java code exists to compare with), it is a
+second, independently written reading of the same text, compared bit for bit with the C oracle in tests/test_oracle.py.
+
+The one place where Java's behaviour is not a function of the text alone: NormQueryEngineDtw sorts with the comparator
+(int)(|o2| - |o1|) (:475-478), which violates the Comparator contract, so the permutation depends on java.util.TimSort's
+merge pattern.  Like the oracle, this file uses a bottom-up stable merge sort there (documented stand-in)."""
+import functools
+import math
+
+INF = 1e20                      # DtwUtils.INF
+WU0 = 25                        # WuList[0]
+MAX_SCAN_DATA_LENGTH = 40000    # NormQueryEngine.MAX_SCAN_DATA_LENGTH / NormQueryEngineDtw
+
+
+class IllegalArgumentException(Exception):
+    pass
+
+
+def read_time_series(series, left, length):
+    """TimeSeriesFileOperator.readTimeSeries: 1-based, throws on a bad range."""
+    n = len(series)
+    if left < 1 or left + length - 1 > n or length < 1:
+        raise IllegalArgumentException(f"left: {left}, length: {length}")
+    return series[left - 1: left - 1 + length]
+
+
+def _java_double_compare(a, b):
+    """Double.compare: -0.0 < 0.0, NaN greater than everything and equal to itself."""
+    if a < b:
+        return -1
+    if a > b:
+        return 1
+    ba, bb = math.copysign(1.0, a) if a == a else 2.0, math.copysign(1.0, b) if b == b else 2.0
+    if a == b and a == 0.0:
+        return (ba > bb) - (ba < bb)
+    if a == b:
+        return 0
+    return (ba > bb) - (ba < bb)  # at least one NaN
+
+
+def _sorted_answers(answers):
+    # answers.sort(Comparator.comparing(Pair::getSecond)): List.sort is stable
+    return sorted(answers, key=functools.cmp_to_key(lambda p1, p2: _java_double_compare(p1[1], p2[1])))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+class CircularArray:
+    def __init__(self, capacity):
+        self.capacity = capacity
+        self.size = 0
+        self.dq = [0] * capacity
+        self.f = 0
+        self.r = capacity - 1
+
+    def push_back(self, v):
+        self.dq[self.r] = v
+        self.r -= 1
+        if self.r < 0:
+            self.r = self.capacity - 1
+        self.size += 1
+
+    def pop_front(self):
+        self.f -= 1
+        if self.f < 0:
+            self.f = self.capacity - 1
+        self.size -= 1
+
+    def pop_back(self):
+        self.r = (self.r + 1) % self.capacity
+        self.size -= 1
+
+    def front(self):
+        aux = self.f - 1
+        if aux < 0:
+            aux = self.capacity - 1
+        return self.dq[aux]
+
+    def back(self):
+        aux = (self.r + 1) % self.capacity
+        return self.dq[aux]
+
+    def is_empty(self):
+        return self.size == 0
+
+
+def lower_upper_lemire(t, length, r, l, u):
+    """DtwUtils.lowerUpperLemire (the array and the List version are the same code)."""
+    du = CircularArray(2 * r + 2)
+    dl = CircularArray(2 * r + 2)
+    du.push_back(0)
+    dl.push_back(0)
+    for i in range(1, length):
+        if i > r:
+            u[i - r - 1] = t[du.front()]
+            l[i - r - 1] = t[dl.front()]
+        if t[i] > t[i - 1]:
+            du.pop_back()
+            while not du.is_empty() and t[i] > t[du.back()]:
+                du.pop_back()
+        else:
+            dl.pop_back()
+            while not dl.is_empty() and t[i] < t[dl.back()]:
+                dl.pop_back()
+        du.push_back(i)
+        dl.push_back(i)
+        if i == 2 * r + 1 + du.front():
+            du.pop_front()
+        elif i == 2 * r + 1 + dl.front():
+            dl.pop_front()
+    for i in range(length, length + r + 1):
+        u[i - r - 1] = t[du.front()]
+        l[i - r - 1] = t[dl.front()]
+        if i - du.front() >= 2 * r + 1:
+            du.pop_front()
+        if i - dl.front() >= 2 * r + 1:
+            dl.pop_front()
+
+
+def _min(a, b):
+    return a if a < b else b
+
+
+def _div(a, b):
+    """Java double division: x / 0.0 is +-Infinity or NaN, never an exception."""
+    try:
+        return a / b
+    except ZeroDivisionError:
+        if a != a or a == 0.0:
+            return float("nan")
+        return math.copysign(float("inf"), a) * math.copysign(1.0, b)
+
+
+def _dist(v1, v2):
+    return (v1 - v2) * (v1 - v2)
+
+
+def lb_kim_hierarchy(t, q, j, length, mean, std, bsf):
+    x0 = _div(t[j] - mean, std)
+    y0 = _div(t[length - 1 + j] - mean, std)
+    lb = _dist(x0, q[0]) + _dist(y0, q[length - 1])
+    if lb >= bsf:
+        return lb
+    x1 = _div(t[j + 1] - mean, std)
+    d = _min(_dist(x1, q[0]), _dist(x0, q[1]))
+    d = _min(d, _dist(x1, q[1]))
+    lb += d
+    if lb >= bsf:
+        return lb
+    y1 = _div(t[length - 2 + j] - mean, std)
+    d = _min(_dist(y1, q[length - 1]), _dist(y0, q[length - 2]))
+    d = _min(d, _dist(y1, q[length - 2]))
+    lb += d
+    if lb >= bsf:
+        return lb
+    x2 = _div(t[j + 2] - mean, std)
+    d = _min(_dist(x0, q[2]), _dist(x1, q[2]))
+    d = _min(d, _dist(x2, q[2]))
+    d = _min(d, _dist(x2, q[1]))
+    d = _min(d, _dist(x2, q[0]))
+    lb += d
+    if lb >= bsf:
+        return lb
+    y2 = _div(t[length - 3 + j] - mean, std)
+    d = _min(_dist(y0, q[length - 3]), _dist(y1, q[length - 3]))
+    d = _min(d, _dist(y2, q[length - 3]))
+    d = _min(d, _dist(y2, q[length - 2]))
+    d = _min(d, _dist(y2, q[length - 1]))
+    lb += d
+    return lb
+
+
+def lb_keogh_cumulative(order, t, uo, lo, cb, j, length, mean, std, best_so_far):
+    lb = 0.0
+    i = 0
+    while i < length and lb < best_so_far:
+        x = _div(t[order[i] + j] - mean, std)
+        d = 0.0
+        if x > uo[i]:
+            d = _dist(x, uo[i])
+        elif x < lo[i]:
+            d = _dist(x, lo[i])
+        lb += d
+        cb[order[i]] = d
+        i += 1
+    return lb
+
+
+def lb_keogh_data_cumulative(order, qo, cb, I, l, u, length, mean, std, best_so_far):
+    lb = 0.0
+    i = 0
+    while i < length and lb < best_so_far:
+        uu = _div(u[order[i] + I] - mean, std)
+        ll = _div(l[order[i] + I] - mean, std)
+        d = 0.0
+        if qo[i] > uu:
+            d = _dist(qo[i], uu)
+        else:
+            if qo[i] < ll:
+                d = _dist(qo[i], ll)
+        lb += d
+        cb[order[i]] = d
+        i += 1
+    return lb
+
+
+def dtw(A, B, cb, m, r, bsf):
+    cost = [INF] * (2 * r + 1)
+    cost_prev = [INF] * (2 * r + 1)
+    k = 0
+    for i in range(m):
+        k = max(0, r - i)
+        min_cost = INF
+        for j in range(max(0, i - r), min(m - 1, i + r) + 1):
+            if i == 0 and j == 0:
+                cost[k] = _dist(A[0], B[0])
+                min_cost = cost[k]
+                k += 1
+                continue
+            y = INF if (j - 1 < 0 or k - 1 < 0) else cost[k - 1]
+            x = INF if (i - 1 < 0 or k + 1 > 2 * r) else cost_prev[k + 1]
+            z = INF if (i - 1 < 0 or j - 1 < 0) else cost_prev[k]
+            cost[k] = _min(_min(x, y), z) + _dist(A[i], B[j])
+            if cost[k] < min_cost:
+                min_cost = cost[k]
+            k += 1
+        if i + r < m - 1 and min_cost + cb[i + r + 1] >= bsf:
+            return min_cost + cb[i + r + 1]
+        cost, cost_prev = cost_prev, cost
+    k -= 1
+    return cost_prev[k]
+
+
+# ---------------------------------------------------------------------------------------------------------------
+def rsm_ed(series, query, left, right, last_segment, epsilon):
+    n, length = len(series), len(query)
+    answers = []
+    cnt_candidate = 0
+    for p in range(len(left)):
+        cnt_candidate += right[p] - left[p] + 1
+        begin = left[p] - (last_segment - 1) * WU0
+        end = right[p] - (last_segment - 1) * WU0 + length - 1
+        if begin < 1:
+            begin = 1
+        if end > n:
+            end = n
+        data = read_time_series(series, begin, end - begin + 1)
+        i = 0
+        while i + length - 1 < len(data):
+            distance = 0.0
+            j = 0
+            while j < length and distance <= epsilon * epsilon:
+                distance += (data[i + j] - query[j]) * (data[i + j] - query[j])
+                j += 1
+            if distance <= epsilon * epsilon:
+                answers.append((begin + i, math.sqrt(distance)))
+            i += 1
+    return _sorted_answers(answers), cnt_candidate
+
+
+def _query_stats(query):
+    ex = ex2 = 0.0
+    for value in query:
+        ex += value
+        ex2 += value * value
+    mean_q = ex / len(query)
+    std_q = math.sqrt(ex2 / len(query) - mean_q * mean_q)
+    return mean_q, std_q
+
+
+def _chunks(left, right, last_segment, query_length, n):
+    """The greedy chunk merge shared by both cNSM engines: yields (beginIdx, endIdx, begin, end)."""
+    idx = 0
+    size = len(left)
+    while idx < size:
+        begin_idx = end_idx = idx
+        begin = left[idx] - (last_segment - 1) * WU0
+        end = right[idx] - (last_segment - 1) * WU0 + query_length - 1
+        if begin < 1:
+            begin = 1
+        length = end - begin + 1
+        idx += 1
+        while idx < size:
+            begin = left[idx] - (last_segment - 1) * WU0
+            new_length = length + begin - end - 1
+            end = right[idx] - (last_segment - 1) * WU0 + query_length - 1
+            if end > n:
+                end = n
+            new_length += end - begin + 1
+            if new_length > MAX_SCAN_DATA_LENGTH:
+                break
+            end_idx = idx
+            length = new_length
+            idx += 1
+        begin = left[begin_idx] - (last_segment - 1) * WU0
+        end = right[end_idx] - (last_segment - 1) * WU0 + query_length - 1
+        if begin < 1:
+            begin = 1
+        if end > n:
+            end = n
+        yield begin_idx, end_idx, begin, end
+
+
+def cnsm_ed(series, query, left, right, last_segment, epsilon, alpha, beta):
+    n, query_length = len(series), len(query)
+    mean_q, std_q = _query_stats(query)
+    answers = []
+    cnt_candidate = 0
+    zq = [_div(query[i] - mean_q, std_q) for i in range(query_length)]
+    q_tmp = [(zq[i], i) for i in range(query_length)]
+    # Arrays.sort(Q_tmp, (o1, o2) -> Double.compare(Math.abs(o2.value), Math.abs(o1.value))): stable, consistent
+    q_tmp = sorted(q_tmp, key=functools.cmp_to_key(lambda o1, o2: _java_double_compare(abs(o2[0]), abs(o1[0]))))
+    zq = [v for v, _ in q_tmp]
+    order = [i for _, i in q_tmp]
+    for begin_idx, end_idx, begin, end in _chunks(left, right, last_segment, query_length, n):
+        data = read_time_series(series, begin, end - begin + 1)
+        for idx1 in range(begin_idx, end_idx + 1):
+            cnt_candidate += right[idx1] - left[idx1] + 1
+            ex = ex2 = 0.0
+            T = [0.0] * (2 * query_length)
+            begin1 = left[idx1] - (last_segment - 1) * WU0 - begin
+            end1 = right[idx1] - (last_segment - 1) * WU0 + query_length - 1 - begin
+            if begin1 < 0:
+                begin1 = 0
+            if end1 > len(data) - 1:
+                end1 = len(data) - 1
+            for i in range(begin1, end1 + 1):
+                d = data[i]
+                ex += d
+                ex2 += d * d
+                T[i % query_length] = d
+                T[(i % query_length) + query_length] = d
+                if i - begin1 >= query_length - 1:
+                    j = (i + 1) % query_length
+                    mean = ex / query_length
+                    v = ex2 / query_length - mean * mean
+                    std = math.sqrt(v) if v >= 0 else float("nan")   # Math.sqrt of a negative is NaN
+                    if abs(mean - mean_q) <= beta and _div(std, std_q) <= alpha and _div(std, std_q) >= _div(1.0, alpha):
+                        dist = 0.0
+                        k = 0
+                        while k < query_length and dist <= epsilon * epsilon:
+                            x = _div(T[order[k] + j] - mean, std)
+                            dist += (x - zq[k]) * (x - zq[k])
+                            k += 1
+                        if dist <= epsilon * epsilon:
+                            answers.append((begin + i - query_length + 1, math.sqrt(dist)))
+                    ex -= T[j]
+                    ex2 -= T[j] * T[j]
+    return _sorted_answers(answers), cnt_candidate
+
+
+def _dtw_decide(T, j, Q, order, qo, uo, lo, l_buff, u_buff, I, length, mean, std, rho, epsilon, normalise):
+    """The cascade both DTW engines run per window once mean / std are known; returns the distance or None."""
+    lb_kim = lb_kim_hierarchy(T, Q, j, length, mean, std, epsilon * epsilon)
+    if lb_kim <= epsilon * epsilon:
+        cb1 = [0.0] * length
+        lb_k = lb_keogh_cumulative(order, T, uo, lo, cb1, j, length, mean, std, epsilon * epsilon)
+        if lb_k <= epsilon * epsilon:
+            if normalise:
+                cT = [_div(T[k + j] - mean, std) for k in range(length)]   # NormQueryEngineDtw.java:564-567 (before lbK2)
+            cb2 = [0.0] * length
+            lb_k2 = lb_keogh_data_cumulative(order, qo, cb2, I, l_buff, u_buff, length, mean, std, epsilon * epsilon)
+            if lb_k2 <= epsilon * epsilon:
+                if not normalise:
+                    cT = T[j: j + length]                               # System.arraycopy(T, j, cT, 0, length)
+                cb = [0.0] * length
+                src = cb1 if lb_k > lb_k2 else cb2
+                cb[length - 1] = src[length - 1]
+                for k in range(length - 2, -1, -1):
+                    cb[k] = cb[k + 1] + src[k]
+                dist = dtw(cT, Q, cb, length, rho, epsilon * epsilon)
+                if dist <= epsilon * epsilon:
+                    return dist
+    return None
+
+
+def rsm_dtw(series, query, left, right, last_segment, epsilon, rho):
+    n, length = len(series), len(query)
+    answers = []
+    cnt_candidate = 0
+    Q = [query[i] for i in range(length)]
+    u, l = [0.0] * length, [0.0] * length
+    lower_upper_lemire(Q, length, rho, l, u)
+    order = list(range(length))           # the reorder is commented out (K/QueryEngineDtw.java:369-372): tmpQ stays as built
+    qo = [Q[o] for o in order]
+    uo = [u[o] for o in order]
+    lo = [l[o] for o in order]
+    for p in range(len(left)):
+        cnt_candidate += right[p] - left[p] + 1
+        begin = left[p] - (last_segment - 1) * WU0
+        end = right[p] - (last_segment - 1) * WU0 + length - 1
+        if begin < 1:
+            begin = 1
+        if end > n:
+            end = n
+        data = read_time_series(series, begin, end - begin + 1)
+        T = [0.0] * (2 * length)
+        u_buff, l_buff = [0.0] * len(data), [0.0] * len(data)
+        lower_upper_lemire(data, len(data), rho, l_buff, u_buff)
+        for i in range(len(data)):
+            d = data[i]
+            T[i % length] = d
+            T[(i % length) + length] = d
+            if i >= length - 1:
+                j = (i + 1) % length
+                dist = _dtw_decide(T, j, Q, order, qo, uo, lo, l_buff, u_buff, i - length + 1, length, 0, 1, rho, epsilon, False)
+                if dist is not None:
+                    answers.append((begin + i - length + 1, math.sqrt(dist)))
+    return _sorted_answers(answers), cnt_candidate
+
+
+def _stable_merge_sort(a, cmp):
+    """Bottom-up stable merge sort (the documented stand-in for TimSort under the inconsistent comparator)."""
+    n = len(a)
+    w = 1
+    while w < n:
+        tmp = []
+        for lo in range(0, n, 2 * w):
+            mid, hi = min(lo + w, n), min(lo + 2 * w, n)
+            i, j = lo, mid
+            while i < mid and j < hi:
+                if cmp(a[j], a[i]) < 0:
+                    tmp.append(a[j]); j += 1
+                else:
+                    tmp.append(a[i]); i += 1
+            tmp.extend(a[i:mid]); tmp.extend(a[j:hi])
+        a = tmp
+        w *= 2
+    return a
+
+
+def _java_int(v):
+    """(int) of a double: toward zero, NaN -> 0, saturating."""
+    if v != v:
+        return 0
+    if v >= 2147483647.0:
+        return 2147483647
+    if v <= -2147483648.0:
+        return -2147483648
+    return int(v)
+
+
+def cnsm_dtw(series, query, left, right, last_segment, epsilon, rho, alpha, beta):
+    n, query_length = len(series), len(query)
+    mean_q, std_q = _query_stats(query)
+    answers = []
+    cnt_candidate = 0
+    zq = [_div(query[i] - mean_q, std_q) for i in range(query_length)]
+    u, l = [0.0] * query_length, [0.0] * query_length
+    lower_upper_lemire(zq, query_length, rho, l, u)
+    tmp_q = [(zq[i], i) for i in range(query_length)]
+    tmp_q = _stable_merge_sort(tmp_q, lambda o1, o2: _java_int(abs(o2[0]) - abs(o1[0])))
+    order = [i for _, i in tmp_q]
+    qo = [zq[o] for o in order]
+    uo = [u[o] for o in order]
+    lo = [l[o] for o in order]
+    for begin_idx, end_idx, begin, end in _chunks(left, right, last_segment, query_length, n):
+        data = read_time_series(series, begin, end - begin + 1)
+        u_buff, l_buff = [0.0] * len(data), [0.0] * len(data)
+        lower_upper_lemire(data, len(data), rho, l_buff, u_buff)
+        for idx1 in range(begin_idx, end_idx + 1):
+            cnt_candidate += right[idx1] - left[idx1] + 1
+            ex = ex2 = 0.0
+            T = [0.0] * (2 * query_length)
+            begin1 = left[idx1] - (last_segment - 1) * WU0 - begin
+            end1 = right[idx1] - (last_segment - 1) * WU0 + query_length - 1 - begin
+            if begin1 < 0:
+                begin1 = 0
+            if end1 > len(data) - 1:
+                end1 = len(data) - 1
+            for i in range(begin1, end1 + 1):
+                d = data[i]
+                ex += d
+                ex2 += d * d
+                T[i % query_length] = d
+                T[(i % query_length) + query_length] = d
+                if i - begin1 >= query_length - 1:
+                    j = (i + 1) % query_length
+                    mean = ex / query_length
+                    v = ex2 / query_length - mean * mean
+                    std = math.sqrt(v) if v >= 0 else float("nan")
+                    if abs(mean - mean_q) <= beta and _div(std, std_q) <= alpha and _div(std, std_q) >= _div(1.0, alpha):
+                        dist = _dtw_decide(T, j, zq, order, qo, uo, lo, l_buff, u_buff, i - query_length + 1, query_length,
+                                           mean, std, rho, epsilon, True)
+                        if dist is not None:
+                            answers.append((begin + i - query_length + 1, math.sqrt(dist)))
+                    ex -= T[j]
+                    ex2 -= T[j] * T[j]
+    return _sorted_answers(answers), cnt_candidate
