@@ -79,6 +79,14 @@ int kvm_load_series_file(kvm_ctx *ctx, const char *path, int64_t n);
  * referenced after the call returns. */
 int kvm_attach_series_device(kvm_ctx *ctx, const double *device_values, int64_t n);
 
+/* Use the series `owner` has staged (values and prefix sums, read-only after staging) without copying it: one more
+ * context -- its own stream, staging and scratch buffers -- on the same device, so that several queries can be in flight
+ * against one resident series, each from its own host thread (a context is not re-entrant, like the reference's engine
+ * instances, K/QueryEngine.java:61-68; several engines over one data file are the reference's analogue).  `owner` must
+ * stay open, and must not load another series, for as long as `ctx` uses it.  Data envelopes (DTW) are cached per
+ * context. */
+int kvm_share_series(kvm_ctx *ctx, const kvm_ctx *owner);
+
 int64_t kvm_series_length(const kvm_ctx *ctx);
 
 /* TimeSeriesOperator.readTimeSeries(left, length) served from HBM

@@ -110,8 +110,8 @@ extern "C" int kvm_open(int device, kvm_ctx **out) {
 static void free_series(kvm_ctx *ctx) {
     if (ctx->own_series && ctx->d_series) hipFree(ctx->d_series);
     ctx->d_series = nullptr;
+    if (ctx->own_series && ctx->d_prefix) hipFree(ctx->d_prefix);  // (a shared series belongs to its owner context)
     ctx->own_series = false;
-    if (ctx->d_prefix) hipFree(ctx->d_prefix);
     ctx->d_prefix = nullptr;
     if (ctx->d_env_u) hipFree(ctx->d_env_u);
     if (ctx->d_env_l) hipFree(ctx->d_env_l);
@@ -277,6 +277,21 @@ extern "C" int kvm_attach_series_device(kvm_ctx *ctx, const double *device_value
         return fail(ctx, KVM_ERR_DEVICE, "copying the device series failed");
     }
     return finish_load(ctx);
+}
+
+extern "C" int kvm_share_series(kvm_ctx *ctx, const kvm_ctx *owner) {
+    if (!ctx || !owner) return KVM_ERR_INVALID_HANDLE;
+    if (ctx == owner) return fail(ctx, KVM_ERR_ILLEGAL_ARGUMENT, "a context cannot share its own series");
+    if (!owner->d_series || !owner->d_prefix) return fail(ctx, KVM_ERR_NO_SERIES, "the owner context has no series loaded");
+    if (owner->device != ctx->device) return fail(ctx, KVM_ERR_ILLEGAL_ARGUMENT, "contexts on different devices cannot share a series");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    free_series(ctx);
+    ctx->d_series = owner->d_series;  // values and prefix sums are read-only after staging
+    ctx->d_prefix = owner->d_prefix;
+    ctx->own_series = false;
+    ctx->n = owner->n;
+    return KVM_OK;
 }
 
 extern "C" int64_t kvm_series_length(const kvm_ctx *ctx) { return ctx ? ctx->n : KVM_ERR_INVALID_HANDLE; }

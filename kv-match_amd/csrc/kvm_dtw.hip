@@ -576,9 +576,8 @@ struct dp_buf {
     static constexpr int LIN = LIVE + 64 * DP_EPOCH;     // doubles per buffer (V=4: 768 = 6 KiB)
 };
 
-// (V <= 4: at most 128 VGPRs, so that four wavefronts fit a SIMD -- the sweep is pure VALU issue and needs them)
 template <int V, int CSTAR, bool ABANDON>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(V <= 4 ? 4 : 2, V <= 4 ? 4 : 2))) void kvm_dtw_dp_reg_kernel(const double *__restrict__ series, kvm_query_dev qd,
+__global__ __launch_bounds__(256) void kvm_dtw_dp_reg_kernel(const double *__restrict__ series, kvm_query_dev qd,
                                                              kvm_dtw_aux ax, const kvm_cand *__restrict__ in,
                                                              const dp_plan *__restrict__ plans,
                                                              const unsigned long long *__restrict__ d_n_in,

@@ -146,7 +146,12 @@ class ShardedVerifier:
         self.host = torch.empty((self.world * (self.pack_cap + 1), 2), dtype=torch.float64).pin_memory()
         self.cnt_candidate = 0
 
-    def verify(self, valid_positions, last_segment, query_data, epsilon, rho=0, alpha=1.0, beta=0.0, resolved=None):
+    def launch(self, valid_positions, last_segment, query_data, epsilon, rho=0, alpha=1.0, beta=0.0, resolved=None,
+               variant=None):
+        """Enqueue the verification of this rank's shard and the pack kernel on torch's current stream; nothing is
+        exchanged or copied to the host (the packed block [count | first pack_cap pairs] stays in self.packed).
+        `variant` overrides the verifier's own for this query (a mixed query stream)."""
+        variant = self.variant if variant is None else int(variant)
         import ctypes as C
         import torch
         import torch.distributed as dist
@@ -155,11 +160,11 @@ class ShardedVerifier:
         left, right = _as_intervals(valid_positions)
         q = np.ascontiguousarray(query_data, dtype=np.float64)
         c = self.ctx
-        r = resolve_rho(rho, q.size, resolved) if self.variant >= 2 else 0
+        r = resolve_rho(rho, q.size, resolved) if variant >= 2 else 0
         cnt_cand = C.c_int64(0)
         stream = torch.cuda.current_stream(self.dev).cuda_stream
         _lib.check(c._lib.kvm_verify_device(
-            c._h, self.variant, q.ctypes.data, q.size, left.ctypes.data, right.ctypes.data, left.size,
+            c._h, variant, q.ctypes.data, q.size, left.ctypes.data, right.ctypes.data, left.size,
             (int(last_segment) - 1) * WU0, float(epsilon), int(r), float(alpha), float(beta),
             C.c_void_p(self.out_off.data_ptr()), C.c_void_p(self.out_dist.data_ptr()), self.cap,
             C.c_void_p(self.count.data_ptr()), C.byref(cnt_cand), C.c_void_p(stream)), c._h)
@@ -169,6 +174,12 @@ class ShardedVerifier:
         _lib.check(c._lib.kvm_pack_answers_device(c._h, C.c_void_p(self.out_off.data_ptr()),
                                                   C.c_void_p(self.out_dist.data_ptr()), C.c_void_p(self.count.data_ptr()),
                                                   k, C.c_void_p(self.packed.data_ptr()), C.c_void_p(stream)), c._h)
+
+    def verify(self, valid_positions, last_segment, query_data, epsilon, rho=0, alpha=1.0, beta=0.0, resolved=None):
+        import torch
+        import torch.distributed as dist
+        self.launch(valid_positions, last_segment, query_data, epsilon, rho, alpha, beta, resolved)
+        k = self.pack_cap
         if self.world > 1:
             dist.all_gather_into_tensor(self.gathered, self.packed, group=self.group)
             self.host.copy_(self.gathered, non_blocking=True)
@@ -186,3 +197,124 @@ class ShardedVerifier:
         return gather_answers(self.out_off[:n_local], self.out_dist[:n_local], group=self.group) \
             if self.world > 1 else sort_answers(self.out_off[:n_local].cpu().numpy(),
                                                 self.out_dist[:n_local].cpu().numpy())
+
+
+class ShardedStream:
+    """A stream of sharded queries with `in_flight` of them overlapping on every rank.
+
+    Each slot has its own context (sharing the rank's resident series), its own HIP stream and its own device buffers;
+    slot threads run the device-resident verification and the pack kernel (kvm_verify_device, kvm_pack_answers_device) of
+    the queries dealt to them.  The exchange is NOT done by those threads: collectives must be issued in the same order on
+    every rank, so the calling thread alone performs the all-gathers, in query order, on its own stream, as each query's
+    packed block becomes ready -- the all-gather and the host copy of query i overlap the kernels of query i+1.
+
+        ss = ShardedStream(ctx, variant, max_candidates, in_flight=2)
+        results = ss.run([dict(valid_positions=(l, r), last_segment=1, query_data=q, epsilon=10.0), ...])
+        # -> [(offsets, distances), ...] in query order, the merged sorted answer list on every rank
+    """
+
+    def __init__(self, ctx, variant, max_candidates, in_flight=2, group=None, pack_cap=4096):
+        import torch
+        import torch.distributed as dist
+        from .engine import Phase2Context
+        self.group, self.variant = group, int(variant)
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.dev = torch.device(f"cuda:{ctx.device}")
+        self.pack_cap = int(pack_cap)
+        self.slots = []
+        for i in range(max(1, int(in_flight))):
+            c = ctx if i == 0 else Phase2Context(ctx.device).share_series(ctx)
+            if i:
+                from . import _lib
+                for opt in (_lib.OPT_EARLY_ABANDON, _lib.OPT_LB_CASCADE, _lib.OPT_ED_KERNEL, _lib.OPT_TIMING, _lib.OPT_DP_KERNEL):
+                    c.set_option(opt, ctx.get_option(opt))
+            v = ShardedVerifier(c, variant, max_candidates, group=group, pack_cap=pack_cap)
+            self.slots.append(dict(ctx=c, v=v, stream=torch.cuda.Stream(device=self.dev), ready=torch.cuda.Event()))
+        self.comm_stream = torch.cuda.Stream(device=self.dev)
+        k = self.pack_cap + 1
+        self.gathered = [torch.empty((self.world * k, 2), dtype=torch.float64, device=self.dev) for _ in self.slots]
+        self.host = [torch.empty((self.world * k, 2), dtype=torch.float64).pin_memory() for _ in self.slots]
+        self.cnt_candidate = []
+
+    def set_option(self, option, value):
+        for s in self.slots:
+            s["ctx"].set_option(option, value)
+
+    def kernel_ns(self):
+        return [int(s["ctx"]._lib.kvm_last_kernel_ns(s["ctx"]._h)) for s in self.slots]
+
+    def run(self, queries):
+        import threading
+        import torch
+        import torch.distributed as dist
+        queries = list(queries)
+        nq, ns = len(queries), len(self.slots)
+        produced = [threading.Event() for _ in range(nq)]
+        consumed = [threading.Event() for _ in range(nq)]
+        err = []
+        cnts = [0] * nq
+
+        def slot_thread(si):
+            s = self.slots[si]
+            try:
+                for qi in range(si, nq, ns):
+                    if qi - ns >= 0:
+                        consumed[qi - ns].wait()      # the slot's buffers are free again
+                    if err:
+                        return
+                    with torch.cuda.stream(s["stream"]):
+                        s["v"].launch(**queries[qi])  # verify + pack on the slot's stream, no synchronisation
+                        s["ready"].record(s["stream"])
+                    cnts[qi] = s["v"].cnt_candidate
+                    produced[qi].set()
+            except BaseException as e:  # noqa: BLE001
+                err.append(e)
+                for ev in produced:
+                    ev.set()
+
+        threads = [threading.Thread(target=slot_thread, args=(si,)) for si in range(ns)]
+        for t in threads:
+            t.start()
+        out = []
+        k = self.pack_cap
+        try:
+            for qi in range(nq):
+                produced[qi].wait()
+                if err:
+                    break
+                si = qi % ns
+                s = self.slots[si]
+                with torch.cuda.stream(self.comm_stream):
+                    self.comm_stream.wait_event(s["ready"])
+                    if self.world > 1:
+                        dist.all_gather_into_tensor(self.gathered[si], s["v"].packed, group=self.group)
+                        self.host[si].copy_(self.gathered[si], non_blocking=True)
+                    else:
+                        self.host[si][: k + 1].copy_(s["v"].packed, non_blocking=True)
+                    self.comm_stream.synchronize()
+                    host = self.host[si].numpy().reshape(self.world, k + 1, 2)
+                    counts = host[:, 0, 0].astype(np.int64)
+                    if counts.max() <= k:
+                        offs = np.concatenate([host[w, 1:1 + counts[w], 0] for w in range(self.world)]).astype(np.int32)
+                        dists = np.concatenate([host[w, 1:1 + counts[w], 1] for w in range(self.world)])
+                        out.append(sort_answers(offs, dists))
+                    else:  # rare: more answers than the packed block holds -> exact-size exchange of the slot's full lists
+                        n_local = int(s["v"].count.item())
+                        vo, vd = s["v"].out_off[:n_local], s["v"].out_dist[:n_local]
+                        out.append(gather_answers(vo, vd, group=self.group) if self.world > 1
+                                   else sort_answers(vo.cpu().numpy(), vd.cpu().numpy()))
+                consumed[qi].set()
+        finally:
+            for ev in consumed:
+                ev.set()
+            for t in threads:
+                t.join()
+        if err:
+            raise err[0]
+        self.cnt_candidate = cnts
+        return out
+
+    def close(self):
+        for s in self.slots[1:]:
+            s["ctx"].close()
+        self.slots = self.slots[:1]

@@ -60,7 +60,11 @@ def _as_intervals(valid_positions):
     intervals, [1, 5] and [10, 20], as in the reference's List<Interval>."""
     if (isinstance(valid_positions, tuple) and len(valid_positions) == 2
             and all(isinstance(x, np.ndarray) and x.ndim == 1 for x in valid_positions)):
-        left, right = (np.asarray(x, dtype=np.int64) for x in valid_positions)
+        left, right = valid_positions
+        if left.dtype == np.int32 and right.dtype == np.int32 and left.shape == right.shape:
+            # the hot path of a query stream: nothing to convert, nothing that could overflow a Java int
+            return np.ascontiguousarray(left), np.ascontiguousarray(right)
+        left, right = (np.asarray(x, dtype=np.int64) for x in (left, right))
     else:
         arr = np.asarray(valid_positions, dtype=np.int64).reshape(-1, 2)
         left, right = arr[:, 0], arr[:, 1]
@@ -120,6 +124,13 @@ class Phase2Context:
     def attach_device_series(self, data_ptr, n, keepalive=None):
         self._keep = keepalive
         _lib.check(self._lib.kvm_attach_series_device(self._h, C.c_void_p(int(data_ptr)), int(n)), self._h)
+
+    def share_series(self, owner):
+        """Use the series another context on the same device has staged, without copying it (kvm_share_series): one more
+        engine over the same data, for a second query in flight.  `owner` must outlive this context's use of it."""
+        self._keep = owner
+        _lib.check(self._lib.kvm_share_series(self._h, owner._h), self._h)
+        return self
 
     @property
     def n(self):
@@ -205,6 +216,73 @@ class Phase2Context:
                            stats)
         finally:
             lib.kvm_result_free(res)
+
+
+class QueryStream:
+    """Several queries in flight against one resident series: `in_flight` contexts on one device (the first is the
+    caller's, the others share its series -- kvm_share_series), each driven by its own host thread, the way a server would
+    run several of the reference's (non re-entrant) engine instances over one data file.  While one query's kernels run,
+    the next one's host work -- plan sums, query preparation, launches -- and its result read-back proceed, and the tail of
+    one pruning kernel overlaps the head of the next.
+
+        with QueryStream(ctx, in_flight=2) as qs:
+            results = qs.run([lambda c: QueryEngine(c).verify(iv, 1, q, eps), ...])   # results in job order
+
+    Every job is a callable taking the context it runs on (the ctypes calls release the GIL)."""
+
+    def __init__(self, ctx, in_flight=2):
+        self.ctxs = [ctx] + [Phase2Context(ctx.device).share_series(ctx) for _ in range(max(1, int(in_flight)) - 1)]
+        for c in self.ctxs[1:]:
+            for opt in (_lib.OPT_EARLY_ABANDON, _lib.OPT_LB_CASCADE, _lib.OPT_ED_KERNEL, _lib.OPT_TIMING, _lib.OPT_DP_KERNEL):
+                c.set_option(opt, ctx.get_option(opt))
+
+    def set_option(self, option, value):
+        for c in self.ctxs:
+            c.set_option(option, value)
+
+    def run(self, jobs):
+        import threading
+        jobs = list(jobs)
+        out = [None] * len(jobs)
+        if len(self.ctxs) == 1 or len(jobs) <= 1:
+            for i, job in enumerate(jobs):
+                out[i] = job(self.ctxs[0])
+            return out
+        nxt = [0]
+        lock = threading.Lock()
+        err = []
+
+        def worker(c):
+            while not err:
+                with lock:
+                    i = nxt[0]
+                    nxt[0] += 1
+                if i >= len(jobs):
+                    return
+                try:
+                    out[i] = jobs[i](c)
+                except BaseException as e:  # noqa: BLE001 (re-raised in the caller's thread)
+                    err.append(e)
+
+        threads = [threading.Thread(target=worker, args=(c,)) for c in self.ctxs]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        if err:
+            raise err[0]
+        return out
+
+    def close(self):
+        for c in self.ctxs[1:]:
+            c.close()
+        self.ctxs = self.ctxs[:1]
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
 
 
 class _EngineBase:

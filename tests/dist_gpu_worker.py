@@ -42,6 +42,17 @@ def main():
                 dist.all_reduce(cnt)
                 np.savez(os.path.join(out_dir, f"v{variant}_p{pack_cap}_r{rank}.npz"), offs=offs, dists=dists,
                          cnt=int(cnt.item()), shard=cands)
+        # the pipelined form: two queries in flight per rank (two contexts over the rank's resident series), the exchange
+        # issued by the calling thread alone, in query order; a mixed stream of all four variants, twice
+        ss = D.ShardedStream(ctx, 0, cands, in_flight=2)
+        queries = [dict(valid_positions=(l, r), last_segment=1, query_data=q, variant=v, **args[v]) for v in (0, 3, 1, 2, 0, 3, 2, 1)]
+        res = ss.run(queries)
+        cnts = torch.tensor(ss.cnt_candidate, dtype=torch.int64)
+        dist.all_reduce(cnts)
+        for i, (offs, dists) in enumerate(res):
+            np.savez(os.path.join(out_dir, f"stream{i}_r{rank}.npz"), offs=offs, dists=dists, cnt=int(cnts[i].item()),
+                     variant=queries[i]["variant"])
+        ss.close()
     dist.barrier()
     dist.destroy_process_group()
 

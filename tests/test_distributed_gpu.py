@@ -47,3 +47,10 @@ def test_sharded_verifier_two_ranks_one_device(built, tmp_path):
                 assert int(z["cnt"]) == w_st["cnt_candidate"]
                 shards += int(z["shard"])
             assert shards == w_st["cnt_candidate"]
+    # the pipelined stream (ShardedStream, two queries in flight per rank): every query of the mixed stream, on every rank
+    for i in range(8):
+        for rank in range(2):
+            z = np.load(tmp_path / f"stream{i}_r{rank}.npz")
+            w_off, w_dist, w_st = want[int(z["variant"])]
+            assert np.array_equal(z["offs"], w_off) and np.array_equal(z["dists"], w_dist), (i, rank)
+            assert int(z["cnt"]) == w_st["cnt_candidate"]
