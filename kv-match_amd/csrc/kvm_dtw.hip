@@ -222,7 +222,10 @@ __device__ __forceinline__ void dp_build_patch(const double *__restrict__ series
             cn = kvm_readlane_f64(mn, 63);
         }
     }
-    __threadfence();  // the patch is read back by other lanes of this wavefront (through the CU's L1)
+    // the patch is read back by other lanes of this wavefront, through the CU's own L1: a WORKGROUP-scope fence (wait for
+    // the stores; no cache action is needed inside a CU) -- an agent-scope __threadfence() writes the L2 back and cost
+    // ~0.15 ms per candidate here
+    __threadfence_block();
 }
 
 // term k (natural window position) of the bound chosen for cb[]: cb1[k] / cb2[k] of K/NormQueryEngineDtw.java:559-575
@@ -248,44 +251,58 @@ __device__ int dp_prologue(const double *__restrict__ series, const kvm_query_de
     const double Elo = E * (1.0 - ax.tau), Ehi = E * (1.0 + ax.tau);
     // eps^2 == 0: the loops `lb < bsf` do not even start and row 0 of the DP already "reaches" bsf -- sequential path
     if (!(0.0 < Elo)) return DP_AMBIG;
-    // ---- lbKeoghCumulative: terms in the reference's order, inclusive scan = its partial sums up to rounding ----
-    double carry = 0.0;
-    for (int base = 0; base < m; base += 64) {
-        const int i = base + lane;
-        double d = 0.0;
-        if (i < m) d = dref_term_q((x[ax.order[i]] - mean) / sd, ax.uo[i], ax.lo[i]);
-        const double S = dp_scan_add(d, lane) + carry;
-        const unsigned long long bal = __ballot(i < m && !(S < Elo));
-        if (bal) {  // the reference's loop stops here; it passes the candidate on only if the value is <= eps^2
-            const double Sf = kvm_readlane_f64(S, __ffsll((long long)bal) - 1);
-            return (Sf > Ehi) ? DP_REJECT : DP_AMBIG;
-        }
-        carry = kvm_readlane_f64(S, 63);
-    }
-    const double S1 = carry;  // (< eps^2 (1 - tau): the loop ran to the end, cb1[] is complete)
     // ---- the data envelope at the ends of the fetched chunk ----
     dref_chunk(ax, m, c.run_start, pl.cbeg, pl.cend);
     pl.sb = max(pl.cbeg, pl.cend - 2 * r + 1);
     dp_build_patch(series, r, pl, c.start, m, lane, patch);
-    // ---- lbKeoghDataCumulative, same form ----
-    carry = 0.0;
-    for (int base = 0; base < m; base += 64) {
-        const int i = base + lane;
-        double d = 0.0;
-        if (i < m) {
+    // ---- lbKeoghCumulative and lbKeoghDataCumulative: terms in the reference's order, inclusive scans = its partial sums
+    // up to rounding.  The two loops are independent of each other (each fills its own cb array from scratch), so they are
+    // scanned in the same rounds -- four 64-term chunks of each per round, loads and divisions issued together: a round is
+    // otherwise one exposed global-load latency and a surviving candidate needs m / 64 of them per loop.  The reference
+    // runs lbK first and lbK2 only if lbK passes; a CLEAN crossing of either (last partial certainly below eps^2, next
+    // certainly above) drops the candidate whatever the other does: if lbK stops on an exact tie it passes and lbK2,
+    // evaluated in full, drops it; if lbK2 would never be reached, lbK has dropped it already.  A crossing within rounding
+    // of eps^2 makes the candidate ambiguous unless the other loop drops it cleanly.
+    double carry1 = 0.0, carry2 = 0.0;
+    bool amb1 = false, amb2 = false;  // the loop has stopped at a partial within rounding of eps^2
+    for (int base = 0; base < m && !(amb1 && amb2); base += 256) {
+        double d1[4], d2[4];
+#pragma unroll
+        for (int h = 0; h < 4; h++) {
+            const int i = base + 64 * h + lane, ic = min(i, m - 1);
+            const int o = ax.order[ic];
+            const double t1 = dref_term_q((x[o] - mean) / sd, ax.uo[ic], ax.lo[ic]);
             double U, L;
-            dp_env_at(ax, patch, r, pl, c.start + ax.order[i], U, L);
-            d = dref_term_d(ax.qo[i], U, L, mean, sd);
+            dp_env_at(ax, patch, r, pl, c.start + o, U, L);
+            const double t2 = dref_term_d(ax.qo[ic], U, L, mean, sd);
+            d1[h] = i < m ? t1 : 0.0;
+            d2[h] = i < m ? t2 : 0.0;
         }
-        const double S = dp_scan_add(d, lane) + carry;
-        const unsigned long long bal = __ballot(i < m && !(S < Elo));
-        if (bal) {
-            const double Sf = kvm_readlane_f64(S, __ffsll((long long)bal) - 1);
-            return (Sf > Ehi) ? DP_REJECT : DP_AMBIG;
+#pragma unroll
+        for (int h = 0; h < 4; h++) {
+            const bool in = base + 64 * h + lane < m;
+            if (!amb1) {
+                const double S = dp_scan_add(d1[h], lane) + carry1;
+                const unsigned long long bal = __ballot(in && !(S < Elo));
+                if (bal) {  // the reference's loop stops here; it passes the candidate on only if the value is <= eps^2
+                    if (kvm_readlane_f64(S, __ffsll((long long)bal) - 1) > Ehi) return DP_REJECT;
+                    amb1 = true;
+                }
+                carry1 = kvm_readlane_f64(S, 63);
+            }
+            if (!amb2) {
+                const double S = dp_scan_add(d2[h], lane) + carry2;
+                const unsigned long long bal = __ballot(in && !(S < Elo));
+                if (bal) {
+                    if (kvm_readlane_f64(S, __ffsll((long long)bal) - 1) > Ehi) return DP_REJECT;
+                    amb2 = true;
+                }
+                carry2 = kvm_readlane_f64(S, 63);
+            }
         }
-        carry = kvm_readlane_f64(S, 63);
     }
-    const double S2 = carry;
+    if (amb1 || amb2) return DP_AMBIG;
+    const double S1 = carry1, S2 = carry2;  // (< eps^2 (1 - tau): both loops ran to the end, cb1[] and cb2[] are complete)
     // ---- `if (lbK > lbK2)` (K/NormQueryEngineDtw.java:577): which bound's terms become cb[] ----
     if (S1 == 0.0 && S2 == 0.0) {  // every term of both is zero: cb[] is all zeros either way
         pl.which = 1;
@@ -822,7 +839,7 @@ static hipError_t launch_dp_reg(const double *series, const kvm_query_dev &qd, c
     return hipErrorInvalidValue;
 }
 
-int64_t kvm_dtw_dp_max_waves(int num_cu) { return (int64_t)num_cu * 4 * DP_BLOCKS_PER_CU; }
+int64_t kvm_dtw_dp_max_waves(int num_cu) { return (int64_t)num_cu * 4 * 2 * DP_BLOCKS_PER_CU; }  // (the prep kernel's grid)
 
 size_t kvm_dtw_plan_bytes(int64_t n) { return (size_t)n * sizeof(dp_plan); }
 
@@ -835,7 +852,7 @@ hipError_t kvm_launch_dtw_dp(const double *series, int64_t n, const kvm_query_de
     if (max_in <= 0) return hipSuccess;
     dp_plan *plans = reinterpret_cast<dp_plan *>(plan_buf);
     if (!ax.cb_exact) {
-        int64_t pblocks = (int64_t)num_cu * DP_BLOCKS_PER_CU;  // (as many waves as the patch scratch has slices)
+        int64_t pblocks = (int64_t)num_cu * 2 * DP_BLOCKS_PER_CU;  // (as many waves as the patch scratch has slices)
         if (pblocks > (max_in + 3) / 4) pblocks = (max_in + 3) / 4;
         hipLaunchKernelGGL(kvm_dtw_prep_kernel, dim3((unsigned)pblocks), dim3(256), 0, s, series, qd, ax, in, d_n_in, plans,
                            counters);

@@ -8,6 +8,8 @@
 // here carry the guard band of the approximate mean/std, and survivors are decided by the exact stage (kvm_dtw.hip).
 #include "kvm_internal.h"
 
+#define SCREEN_TERMS 512  // leading terms (in the reference's order) the screen looks at
+
 __device__ __forceinline__ double lb4_dsq(double a, double b) { return (a - b) * (a - b); }
 
 // (alpha, beta) filter + LB_Kim of one candidate with the pruning arithmetic (prefix-sum mean/std, guard bands); also
@@ -82,7 +84,8 @@ __device__ __forceinline__ void lb4_prefilter(const double *__restrict__ series,
 // dropped iff that partial is also > eps^2 + slack (the reference then certainly stops at the same term with a value
 // certainly above eps^2); a partial inside the band -- it may equal eps^2 in the reference's arithmetic, in which case
 // the reference passes the candidate on with a partially filled cb1[] -- keeps it for the exact stage, like a sum that
-// never reaches the band.  The wavefront ends when all its lanes have stopped: a few terms for ordinary candidates.
+// has not reached the band after SCREEN_TERMS terms.  The wavefront ends when all its lanes have stopped: a few terms
+// for ordinary candidates.
 template <bool NORM>
 __global__ __launch_bounds__(256) void kvm_dtw_screen_kernel(const double *__restrict__ series,
                                                              const double2 *__restrict__ prefix, kvm_query_dev qd,
@@ -114,29 +117,54 @@ __global__ __launch_bounds__(256) void kvm_dtw_screen_kernel(const double *__res
     bool rejected = false;
     double p = 0.0;
     const double *__restrict__ xw = series + w0;
-    for (int i0 = 0; i0 < m && __any(alive); i0 += 8) {
-        double xv[8], uu[8], ll[8];
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-            const int i = min(i0 + u, m - 1);  // (clamped: loads are unconditional)
-            xv[u] = xw[ax.order[i]];
-            uu[u] = ax.uo[i];
-            ll[u] = ax.lo[i];
-        }
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-            const double z = NORM ? __builtin_fma(xv[u], inv, nmi) : xv[u];
-            double t_ = fmax(z - uu[u], ll[u] - z);
-            t_ = fmax(t_, 0.0);
-            const double pn = __builtin_fma(t_, t_, p);
-            const bool step = alive && (i0 + u < m);
-            p = step ? pn : p;
-            if (step && p >= lo_thr) {
-                rejected = p > lim;
-                alive = false;
-            }
+    // ---- phase 1: one lane per candidate, 8 terms per round; the loads of round k+1 are in flight while round k is
+    //      added up (a round is otherwise one exposed global-load latency: ~1 us, 0.5 ms for a window of 4 096 points)
+    double xa[8], ua[8], la[8], xb[8], ub[8], lb_[8];  // two register sets, named statically (no indexed register arrays)
+#define SCREEN_FETCH(I0, X, U, L)                                                              \
+    do {                                                                                       \
+        _Pragma("unroll") for (int u = 0; u < 8; u++) {                                        \
+            const int i_ = min((I0) + u, m - 1); /* clamped: loads are unconditional */        \
+            X[u] = xw[ax.order[i_]];                                                           \
+            U[u] = ax.uo[i_];                                                                  \
+            L[u] = ax.lo[i_];                                                                  \
+        }                                                                                      \
+    } while (0)
+#define SCREEN_ROUND(I0, X, U, L)                                                              \
+    do {                                                                                       \
+        _Pragma("unroll") for (int u = 0; u < 8; u++) {                                        \
+            const double z_ = NORM ? __builtin_fma(X[u], inv, nmi) : X[u];                     \
+            double t_ = fmax(z_ - U[u], L[u] - z_);                                            \
+            t_ = fmax(t_, 0.0);                                                                \
+            const double pn_ = __builtin_fma(t_, t_, p);                                       \
+            const bool step_ = alive && ((I0) + u < m);                                        \
+            p = step_ ? pn_ : p;                                                               \
+            if (step_ && p >= lo_thr) {                                                        \
+                rejected = p > lim;                                                            \
+                alive = false;                                                                 \
+            }                                                                                  \
+        }                                                                                      \
+    } while (0)
+    // Only the first SCREEN_TERMS terms are looked at: ordinary candidates cross eps^2 within a few terms, and a candidate
+    // that is still undecided after them goes to the exact stage, whose prologue continues the same ordered sums 64
+    // terms per step across a wavefront (a lane-per-candidate loop over a whole window is m / 8 exposed load latencies:
+    // 0.5 ms at m = 4 096, which one near-match per query used to cost; 512 terms: at most ~60 us).
+    const int m_scr = min(m, SCREEN_TERMS);
+    int i0 = 0;
+    if (__any(alive)) {
+        SCREEN_FETCH(0, xa, ua, la);
+        while (i0 < m_scr) {
+            if (!__any(alive)) break;
+            if (i0 + 8 < m_scr) SCREEN_FETCH(i0 + 8, xb, ub, lb_);
+            SCREEN_ROUND(i0, xa, ua, la);
+            i0 += 8;
+            if (i0 >= m_scr || !__any(alive)) break;
+            if (i0 + 8 < m_scr) SCREEN_FETCH(i0 + 8, xa, ua, la);
+            SCREEN_ROUND(i0, xb, ub, lb_);
+            i0 += 8;
         }
     }
+#undef SCREEN_FETCH
+#undef SCREEN_ROUND
     const bool keep = pk && !rejected;
     const unsigned long long bal = __ballot(keep);
     if (bal == 0ULL) return;
