@@ -1085,10 +1085,10 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
         if (cnsm)
             HIPCHK(ctx, kvm_launch_exact_stats(ctx->d_series, qd, c1, dp_n, pl.windows, rws, counters, ctx->num_cu, stream));
         KVM_DBG_SYNC(ctx, stream, "exact_stats");
-        if (ctx->opt_timing) HIPCHK(ctx, hipEventRecord(ctx->ev0, stream));  // time the DP kernel alone
         if ((rc = ensure(ctx, ctx->b_plans, kvm_dtw_plan_bytes(pl.windows) + 64))) return rc;
         HIPCHK(ctx, kvm_launch_dtw_dp(ctx->d_series, ctx->n, qd, ax, c1, dp_n, pl.windows, ctx->b_plans.p, out.d_off, out.d_dist,
-                                      out.cap, counters, ctx->num_cu, ctx->opt_dp_kernel == 1 ? 1 : 0, stream));
+                                      out.cap, counters, ctx->num_cu, ctx->opt_dp_kernel == 1 ? 1 : 0, stream,
+                                      ctx->opt_timing ? ctx->ev0 : nullptr));  // (timing: the DP kernel alone)
         KVM_DBG_SYNC(ctx, stream, "dtw_dp");
         dtw_qd = qd;
     }

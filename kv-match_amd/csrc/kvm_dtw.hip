@@ -686,7 +686,8 @@ __global__ __launch_bounds__(256) void kvm_dtw_dp_reg_kernel(const double *__res
         const double *pA = bufA + (I0 - pV - lowA);
         const double *pB = bufB + (I0 - r + pV + V - lowB);
         // halos: lane 0 (left) / lane 63 (right) never receive from a neighbour, so they keep this initial INF for ever
-        double halo_l = DTW_INF, halo_r = DTW_INF;
+        double halo_l = DTW_INF, halo_r = DTW_INF, r_in = DTW_INF;
+        const double edge_pen = edge_lane ? DTW_INF : 0.0;
         bool done = false;
         double result = DTW_INF;
         int decision = 0;  // 0 none yet, 1 reject, 2 ambiguous, 3 the reference returns `value` at a row
@@ -694,14 +695,16 @@ __global__ __launch_bounds__(256) void kvm_dtw_dp_reg_kernel(const double *__res
         int chunk = 0;
 
         for (int Ic = I0; Ic <= Ilast && !done; Ic += 64) {
+            double *pR = bufR;
 #pragma unroll 1
             for (int blk = 0; blk < 64 / V && !done; blk++) {
 #pragma unroll
                 for (int s = 0; s < V; s++) {
                     const int I = Ic + blk * V + s;
                     const double a_new = pA[s], b_new = pB[s];
-                    // the row that left this lane's last slot moves on to the next lane; lane 0 starts a new row
-                    R[(V - s) % V] = dp_from_left(R[(V - s) % V], DTW_INF);
+                    // the row that left this lane's last slot moves on to the next lane; lane 0 starts a new row: it
+                    // never receives, so its r_in keeps the INF it was initialised with (no constant to re-materialise)
+                    r_in = dp_from_left(R[(V - s) % V], r_in);
                     // ---- E-update (diagonal 2I - r) ----
                     halo_l = dp_from_left(O[V - 1], halo_l);
 #pragma unroll
@@ -734,16 +737,17 @@ __global__ __launch_bounds__(256) void kvm_dtw_dp_reg_kernel(const double *__res
                         result = scratch[kfin];
                         done = true;
                     }
-                    // band edge k = 2r+1: O[r] must read as INF
-                    O[CSTAR] = edge_lane ? DTW_INF : O[CSTAR];
-                    // ---- row minima ----
+                    // band edge k = 2r+1: O[r] must read as INF (>= 1e20: `edge_pen` is 1e20 in that lane, 0 elsewhere)
+                    O[CSTAR] += edge_pen;
+                    // ---- row minima (slot 0 takes over the row handed in from the left) ----
 #pragma unroll
                     for (int c = 0; c < V; c++)
-                        R[((c - s) % V + V) % V] = dp_min(dp_min(R[((c - s) % V + V) % V], E[c]), O[c]);
-                    if (edge_lane) bufR[blk * V + s] = R[((CSTAR - s) % V + V) % V];  // row I - r is complete
+                        R[((c - s) % V + V) % V] = dp_min(dp_min(c == 0 ? r_in : R[((c - s) % V + V) % V], E[c]), O[c]);
+                    if (edge_lane) pR[s] = R[((CSTAR - s) % V + V) % V];  // row I - r is complete
                 }
                 pA += V;
                 pB += V;
+                pR += V;
             }
             // ---- row test of the rows finished in macro-steps Ic .. Ic+63 (lane t: row Ic + t - r) ----
             if (decision == 0) {
@@ -847,7 +851,8 @@ size_t kvm_dtw_plan_bytes(int64_t n) { return (size_t)n * sizeof(dp_plan); }
 // set: the second run on the sequential path's candidates has nothing left to decide in front of the DP)
 hipError_t kvm_launch_dtw_dp(const double *series, int64_t n, const kvm_query_dev &qd, const kvm_dtw_aux &ax, const kvm_cand *in,
                              const unsigned long long *d_n_in, int64_t max_in, void *plan_buf, int32_t *out_off, double *out_dist,
-                             int64_t cap, unsigned long long *counters, int num_cu, int force_lds, hipStream_t s) {
+                             int64_t cap, unsigned long long *counters, int num_cu, int force_lds, hipStream_t s,
+                             hipEvent_t ev_dp_start) {
     (void)n;
     if (max_in <= 0) return hipSuccess;
     dp_plan *plans = reinterpret_cast<dp_plan *>(plan_buf);
@@ -857,6 +862,10 @@ hipError_t kvm_launch_dtw_dp(const double *series, int64_t n, const kvm_query_de
         hipLaunchKernelGGL(kvm_dtw_prep_kernel, dim3((unsigned)pblocks), dim3(256), 0, s, series, qd, ax, in, d_n_in, plans,
                            counters);
         const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    if (ev_dp_start) {  // (kernel timing: the DP alone, as rocprofv3 lists it)
+        const hipError_t e = hipEventRecord(ev_dp_start, s);
         if (e != hipSuccess) return e;
     }
     // register form: band of r+1 even-k cells over 64 lanes, V = pow2 cells per lane, V <= 8 (r <= 511)

@@ -279,7 +279,8 @@ int64_t kvm_dtw_dp_max_waves(int num_cu);
 size_t kvm_dtw_plan_bytes(int64_t n);  // scratch of kvm_launch_dtw_dp: one plan record per candidate
 hipError_t kvm_launch_dtw_dp(const double *series, int64_t n, const kvm_query_dev &qd, const kvm_dtw_aux &ax, const kvm_cand *in,
                              const unsigned long long *d_n_in, int64_t max_in, void *plan_buf, int32_t *out_off, double *out_dist,
-                             int64_t cap, unsigned long long *counters, int num_cu, int force_lds, hipStream_t s);
+                             int64_t cap, unsigned long long *counters, int num_cu, int force_lds, hipStream_t s,
+                             hipEvent_t ev_dp_start = nullptr);  // recorded between the prologue kernel and the DP
 
 // counters layout (unsigned long long[16])
 #define KVM_CNT_ANSWERS 0
