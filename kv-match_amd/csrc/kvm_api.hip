@@ -465,15 +465,22 @@ extern "C" void kvm_index_rows_free(kvm_index_rows *r) {
     delete r;
 }
 
-// Constants of profiles/r01_phase2_cost_model.json (least squares over 18-36 (intervals, offsets, m) points per variant,
-// early abandon on, one MI355X): {C [ms], A [ms per interval], B [ms per 1e5 offset-points]}
+// The reference's phase-2 time model T_2 = A * #intervals + B * (#offsets / 1e5) * m (K/QueryEngine.java:55-57,316-327) with
+// the terms this path adds: C, the launch chain of a call, and D, the one unit of work that holds an answer (a query drawn
+// from the series always has its self match) and walks the whole window -- m points for the ED engines, one banded DP of
+// m macro-steps x O(m) cells (rho = 5 percent of m) for the DTW engines.  Constants of profiles/r02_phase2_cost_model.json
+// (non-negative least squares on relative residuals, 27-48 (intervals, offsets, m) points per variant on n = 1e8, early
+// abandon on, selective queries, one MI355X): {C [ms], A [ms per interval], B [ms per 1e5 offset-points], D}.
 extern "C" double kvm_phase2_time_estimate_ms(int32_t variant, int64_t disjoint_windows, int64_t candidate_offsets, int32_t length) {
-    static const double K[4][3] = {{0.1285, 1.914e-6, 2.590e-7},   // rsm_ed
-                                   {0.1762, 1.832e-6, 2.377e-6},   // cnsm_ed
-                                   {0.5072, 1.571e-6, 1.057e-5},   // rsm_dtw
-                                   {0.5456, 3.443e-6, 6.786e-5}};  // cnsm_dtw
+    static const double K[4][4] = {{0.07796, 1.95e-06, 2.329e-07, 1.229e-05},   // rsm_ed
+                                   {0.1131, 2.113e-06, 5.408e-07, 1.779e-05},   // cnsm_ed
+                                   {0.3406, 2.52e-06, 1.571e-05, 4.804e-05},   // rsm_dtw
+                                   {0.3946, 2.649e-06, 3.748e-05, 4.889e-05}};  // cnsm_dtw
     if (variant < 0 || variant > 3) return -1.0;
-    return K[variant][0] + K[variant][1] * (double)disjoint_windows + K[variant][2] * ((double)candidate_offsets / 1e5) * (double)length;
+    const double m = (double)length;
+    const double floor_units = variant >= 2 ? m * m / 1e3 : m;
+    return K[variant][0] + K[variant][1] * (double)disjoint_windows + K[variant][2] * ((double)candidate_offsets / 1e5) * m +
+           K[variant][3] * floor_units;
 }
 
 extern "C" int32_t kvm_resolve_rho(double r, int32_t m) {

@@ -63,17 +63,21 @@ def test_open_fails_loudly_without_gpu(built):
 
 
 def test_phase2_time_estimate_is_the_reference_formula(built):
-    """kvm_phase2_time_estimate_ms: the formula of K/QueryEngine.java:319 with this library's constants -- affine in
-    #intervals and in #offsets * length, orders of magnitude below the Java constants, no GPU needed."""
+    """kvm_phase2_time_estimate_ms: the formula of K/QueryEngine.java:319 (affine in #intervals and in #offsets * length)
+    plus a per-call constant and the latency floor of the one unit that holds an answer (linear in m for ED, quadratic for
+    DTW with rho = 5 percent of m) -- orders of magnitude below the Java constants; no GPU needed."""
     import kvmatch
     f = kvmatch.phase2_time_estimate_ms
     for v in range(4):
-        c = f(v, 0, 0, 1024)
-        assert 0.05 < c < 1.0
-        a = f(v, 1000, 0, 1024) - c
-        b = f(v, 0, 100_000, 1000) - c
-        assert 1e-3 < a < 1e-2 and 0 < b < 0.1                       # Java: 4 071 ms resp. 270 ms for RSM-ED
-        assert abs(f(v, 2000, 200_000, 1000) - (c + 2 * a + 2 * b)) < 1e-12
+        base = f(v, 0, 0, 1024)
+        assert 0.05 < base < 1.0
+        a = f(v, 1000, 0, 1024) - base
+        b = f(v, 0, 100_000, 1024) - base
+        assert 1e-3 < a < 1e-2 and 0 < b < 0.1                       # Java: 4 071 ms resp. 276 ms for RSM-ED
+        assert abs(f(v, 2000, 200_000, 1024) - (base + 2 * a + 2 * b)) < 1e-12
+        # the floor term: grows with m alone (no intervals, no offsets); linearly for ED, quadratically for DTW
+        d1, d2 = f(v, 0, 0, 4096) - f(v, 0, 0, 2048), f(v, 0, 0, 8192) - f(v, 0, 0, 4096)
+        assert d1 > 0 and abs(d2 / d1 - (2.0 if v < 2 else 4.0)) < 1e-9
     assert f(7, 1, 1, 1) < 0
 
 
