@@ -89,6 +89,13 @@ int kvm_share_series(kvm_ctx *ctx, const kvm_ctx *owner);
 
 int64_t kvm_series_length(const kvm_ctx *ctx);
 
+/* Upper / lower envelope of radius rho of the staged series at points first .. first + count - 1 (1-based), into host
+ * arrays: DtwUtils.lowerUpperLemire over the whole series as one chunk (K/utils/DtwUtils.java:93-134; a pure selection,
+ * max / min of data[max(1, p - rho) .. min(n, p + rho)]).  Built on the GPU once per rho and cached; the DTW engines use
+ * it for every point at least rho away from both ends of the chunk the reference would have fetched (the chunk-end
+ * values are formed per candidate). */
+int kvm_data_envelope(kvm_ctx *ctx, int32_t rho, int32_t first, int64_t count, double *upper, double *lower);
+
 /* TimeSeriesOperator.readTimeSeries(left, length) served from HBM
  * (K/operator/TimeSeriesOperator.java:38; same range check and error as
  * K/operator/file/TimeSeriesFileOperator.java:55-57).  `out` receives `length` host doubles. */

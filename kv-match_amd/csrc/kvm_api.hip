@@ -705,6 +705,25 @@ static int ensure_envelope(kvm_ctx *ctx, int32_t rho, hipStream_t stream) {
     return KVM_OK;
 }
 
+// Upper / lower envelope of radius rho of the resident series, points first .. first + count - 1 (1-based): what
+// DtwUtils.lowerUpperLemire (K/utils/DtwUtils.java:93-134) returns for the whole series fetched as one chunk.  The DTW
+// engines use it for every point that is at least rho away from both ends of its fetched chunk.
+extern "C" int kvm_data_envelope(kvm_ctx *ctx, int32_t rho, int32_t first, int64_t count, double *upper, double *lower) {
+    if (!ctx) return KVM_ERR_INVALID_HANDLE;
+    if (!ctx->d_series) return fail(ctx, KVM_ERR_NO_SERIES, "no series loaded");
+    if (rho < 0 || first < 1 || count < 0 || (int64_t)first + count - 1 > ctx->n || !upper || !lower)
+        return fail(ctx, KVM_ERR_ILLEGAL_ARGUMENT, "bad kvm_data_envelope arguments");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int rc = ensure_envelope(ctx, rho, ctx->stream);
+    if (rc) return rc;
+    if (count > 0) {
+        HIPCHK(ctx, hipMemcpyAsync(upper, ctx->d_env_u + (first - 1), (size_t)count * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(lower, ctx->d_env_l + (first - 1), (size_t)count * 8, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return KVM_OK;
+}
+
 // Runs the kernels of one variant; survivors land (unsorted) in out.d_off/out.d_dist, counters stay on the
 // device in ctx->b_counters.  `stream` is the stream to launch on.
 static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m, const int32_t *left,

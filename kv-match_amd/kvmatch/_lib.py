@@ -26,7 +26,7 @@ OPT_EARLY_ABANDON, OPT_LB_CASCADE, OPT_ED_KERNEL, OPT_TIMING, OPT_DP_KERNEL = 1,
 SYMBOLS = [
     "kvm_open", "kvm_close", "kvm_last_error", "kvm_version",
     "kvm_load_series_f64", "kvm_load_series_be64", "kvm_load_series_file", "kvm_attach_series_device", "kvm_share_series",
-    "kvm_series_length", "kvm_read_time_series", "kvm_window_means",
+    "kvm_series_length", "kvm_read_time_series", "kvm_window_means", "kvm_data_envelope",
     "kvm_index_rows_build", "kvm_index_rows_count", "kvm_index_rows_keys", "kvm_index_rows_first", "kvm_index_rows_last",
     "kvm_index_rows_free", "kvm_index_rows_build_grouped", "kvm_index_rows_groups", "kvm_index_rows_group_keys",
     "kvm_index_rows_group_offsets", "kvm_phase2_time_estimate_ms",
@@ -81,6 +81,7 @@ def load():
         "kvm_load_series_file": (C.c_int, [vp, C.c_char_p, i64]),
         "kvm_attach_series_device": (C.c_int, [vp, vp, i64]),
         "kvm_share_series": (C.c_int, [vp, vp]),
+        "kvm_data_envelope": (C.c_int, [vp, i32, i32, i64, vp, vp]),
         "kvm_series_length": (i64, [vp]),
         "kvm_read_time_series": (C.c_int, [vp, i32, i32, vp]),
         "kvm_window_means": (C.c_int, [vp, i32, i32, i64, vp]),

@@ -142,6 +142,16 @@ class Phase2Context:
         _lib.check(self._lib.kvm_read_time_series(self._h, int(left), int(length), out.ctypes.data), self._h)
         return out
 
+    def data_envelope(self, rho, first=1, count=None):
+        """(upper, lower) envelope of radius rho of the staged series, DtwUtils.lowerUpperLemire over the whole series
+        (K/utils/DtwUtils.java:93-134)."""
+        if count is None:
+            count = self.n - (first - 1)
+        u = np.empty(max(int(count), 0), dtype=np.float64)
+        l = np.empty(max(int(count), 0), dtype=np.float64)
+        _lib.check(self._lib.kvm_data_envelope(self._h, int(rho), int(first), int(count), u.ctypes.data, l.ctypes.data), self._h)
+        return u, l
+
     def window_means(self, w, first=1, count=None):
         """Sliding means of length-w windows starting at 1-based offsets first .. first+count-1 (index build support,
         cf. K/IndexBuilder.java:232-247)."""

@@ -97,6 +97,23 @@ def test_cnsm_dtw(world, m, eps, rho, alpha, beta):
     assert 123_456 in got.offsets.tolist() and len(got) >= 2
 
 
+@pytest.mark.parametrize("rho", [0, 1, 7, 64, 204, 1500, 5000])
+def test_data_envelope_equals_lower_upper_lemire(world, rho):
+    """kvm_envelope_kernel (sparse-table sliding max / min in LDS) against the reference's deque algorithm restated in the
+    oracle (DtwUtils.lowerUpperLemire + CircularArray): every point, including the clipped ends, on data with long constant
+    stretches and repeated values (ties in the deque's comparisons)."""
+    kvmatch, datagen, series, ctx = world
+    s = series[:120_000].copy()
+    s[5_000:9_000] = 2.5                                  # a constant stretch longer than most radii
+    s[20_000:20_700] = np.round(s[20_000:20_700])         # many equal neighbours
+    ctx.load_series(s)
+    u, l = ctx.data_envelope(rho)
+    wl, wu = oracle.lower_upper_lemire(s, rho)
+    assert np.array_equal(u, wu) and np.array_equal(l, wl)
+    u2, l2 = ctx.data_envelope(rho, first=777, count=1234)
+    assert np.array_equal(u2, wu[776:776 + 1234]) and np.array_equal(l2, wl[776:776 + 1234])
+
+
 def test_all_offsets_equals_full_scan(world):
     """candidates = every offset: engine semantics == CsvTester / UCR full-scan semantics."""
     kvmatch, datagen, series, ctx = world
