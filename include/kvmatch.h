@@ -20,8 +20,30 @@
  *     (stable sort of an offset-ascending list, K/QueryEngine.java:373).
  *
  * Threading: one kvm_ctx per engine instance; calls on one ctx must be serialised by the caller
- * (the reference engines are not re-entrant either).  A ctx owns one HIP stream on one device.
+ * (the reference engines are not re-entrant either).  A ctx owns one HIP stream on one device, its
+ * pinned staging block and its scratch buffers.  Different contexts may be used from different host
+ * threads at the same time -- several queries in flight against one resident series: kvm_share_series.
  * Multi-GPU = one process (or at least one ctx) per GPU; see kv-match_amd/kvmatch/distributed.py.
+ * Process-wide state: (i) one pinned host block that the index-build calls (kvm_index_rows_build*) reuse
+ * across calls and contexts, behind a mutex (calls that need it at the same time allocate their own);
+ * (ii) a thread_local memo of the ED pruner's launch-shape model.  Nothing else is shared.
+ *
+ * Environment (read once per process; all optional, none changes an answer):
+ *   KVM_ED_KERNEL=1..4   default ED pruning kernel where KVM_OPT_ED_KERNEL is 0 (auto)
+ *   KVM_TRACE=1          per-stage host timings of every call on stderr
+ *   KVM_DEBUG_SYNC=1     DTW calls wait for the stream after every stage and name it on stderr
+ *   KVM_LIB=<path>       (Python binding only) load another build of this library
+ *
+ * DTW answer semantics.  The reference's DTW engines do not report {candidates with banded DTW <= eps^2}:
+ * DtwUtils.dtw returns `min_cost + cb[i+r+1]` as soon as that lower bound is >= eps^2 (K/utils/DtwUtils.java:
+ * 324-326), the LB_Keogh loops stop at the first partial sum >= eps^2 (:210, :242) and every caller accepts
+ * `value <= eps^2` -- a bound that lands EXACTLY on eps^2 makes the candidate an answer at distance eps.  On
+ * continuous data such ties have measure zero; on integer-valued data with an integer eps^2, and for eps = 0,
+ * they are common.  kvm_verify_rsm_dtw / kvm_verify_cnsm_dtw reproduce them: same answers, same distances as the
+ * Java loops (KVM_STAT_DTW_SEQUENTIAL counts the candidates that needed the sequential tie path).  The one thing not
+ * reproduced is the permutation java.util.TimSort leaves behind under NormQueryEngineDtw's inconsistent comparator
+ * (K/NormQueryEngineDtw.java:475-478); a stable merge sort stands in for it (it orders the LB_Keogh sums, i.e. it can
+ * only matter on such an exact tie of a cNSM-DTW candidate).
  *
  * Every function returns KVM_OK (0) or a negative status; kvm_last_error() gives the message.
  * The library never falls back to a CPU path: without a usable HIP device kvm_open fails.
@@ -179,9 +201,9 @@ void kvm_result_free(kvm_result *r);
 
 #define KVM_STAT_WINDOWS 0       /* candidate windows actually evaluated (after clipping) */
 #define KVM_STAT_PASS_FILTER 1   /* passed the (alpha, beta) filter (cNSM) */
-#define KVM_STAT_PASS_LB_KIM 2   /* passed LB_Kim (DTW) */
-#define KVM_STAT_PASS_LB_KEOGH 3 /* passed LB_Keogh, query envelope (DTW) */
-#define KVM_STAT_PASS_LB_KEOGH2 4 /* passed LB_Keogh, data envelope = DP launched (DTW) */
+#define KVM_STAT_PASS_LB_KIM 2   /* not dropped by the LB_Kim screen (DTW) */
+#define KVM_STAT_PASS_LB_KEOGH 3 /* not dropped by the LB_Keogh screen on the query envelope (DTW) */
+#define KVM_STAT_PASS_LB_KEOGH2 4 /* passed the whole cascade in the exact stage = DP runs started (DTW) */
 #define KVM_STAT_KERNEL_NS 5     /* device time of the dominant kernel(s), ns (HIP events) */
 #define KVM_STAT_RECHECKED 6     /* knife-edge candidates re-evaluated in reference order */
 #define KVM_STAT_DTW_SEQUENTIAL 7 /* DTW: candidates within rounding of a tie with eps^2, decided by the sequential
@@ -192,13 +214,13 @@ void kvm_result_free(kvm_result *r);
 
 #define KVM_OPT_EARLY_ABANDON 1  /* 1 (default): stop a distance once it exceeds eps^2, as the
                                     reference does; 0: evaluate every candidate over all m points */
-#define KVM_OPT_LB_CASCADE 2     /* 1 (default): LB_Kim/LB_Keogh cascade before the DTW DP; 0: DP on
-                                    every filter-passing candidate */
+#define KVM_OPT_LB_CASCADE 2     /* 1 (default): LB_Kim / LB_Keogh screens in front of the exact DTW stage; 0: every
+                                    filter-passing candidate goes to the exact stage.  Same answers either way. */
 #define KVM_OPT_ED_KERNEL 3      /* ED pruning kernel: 0 auto (default = 3), 1 wave-per-candidate, 2 LDS-tiled
                                     direct form, 3 LDS-tiled correlation form, 4 correlation form with the lanes
                                     along the window (experimental).  All return identical answers. */
 #define KVM_OPT_TIMING 4         /* 1: record HIP-event kernel times into KVM_STAT_KERNEL_NS */
-#define KVM_OPT_DP_KERNEL 5      /* 0 auto (default: register-resident band when rho <= 1023), 1 generic LDS form */
+#define KVM_OPT_DP_KERNEL 5      /* 0 auto (default: register-resident band when rho <= 511), 1 generic LDS form */
 int kvm_set_option(kvm_ctx *ctx, int32_t option, int64_t value);
 int64_t kvm_get_option(const kvm_ctx *ctx, int32_t option);
 /* Device time (ns, HIP events on the launch stream) of the verification kernels of the most recent
@@ -210,7 +232,9 @@ int64_t kvm_last_kernel_ns(const kvm_ctx *ctx);
 /* Same computation as kvm_verify_*, but survivors stay in device memory so that the host layer can
  * hand them to one RCCL all-gather.  `variant`: 0 rsm_ed, 1 cnsm_ed, 2 rsm_dtw,
  * 3 cnsm_dtw.  d_out_off / d_out_dist are device buffers of `cap` entries, d_out_count a device
- * int64.  Unsorted.  `stream` is a hipStream_t (NULL = the ctx stream). */
+ * int64.  Unsorted.  `stream` is a hipStream_t (NULL = the ctx stream).  The ED variants return without
+ * waiting for the stream; the DTW variants wait for it once (the number of candidates that need the sequential tie
+ * path is only known on the device, and that path's scratch is sized on the host). */
 int kvm_verify_device(kvm_ctx *ctx, int32_t variant, const double *query, int32_t m, const int32_t *left,
                       const int32_t *right, int32_t k, int32_t shift, double epsilon, int32_t rho, double alpha,
                       double beta, int32_t *d_out_off, double *d_out_dist, int64_t cap, int64_t *d_out_count,
