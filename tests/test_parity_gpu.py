@@ -114,6 +114,37 @@ def test_data_envelope_equals_lower_upper_lemire(world, rho):
     assert np.array_equal(u2, wu[776:776 + 1234]) and np.array_equal(l2, wl[776:776 + 1234])
 
 
+def test_query_stream_three_in_flight_matches_sequential(world):
+    """kvm_share_series + QueryStream: three contexts over one resident series, driven by three host threads, return for a
+    mixed stream of all four variants exactly what one context returns sequentially (and what the oracle returns)."""
+    kvmatch = world[0]
+    ctx = world[3]
+    s, q, L, R = planted(world, 300)
+    jobs_spec = [("rsm_ed", (5.0,)), ("cnsm_dtw", (4.0, 15, 1.5, 2.0)), ("cnsm_ed", (4.0, 1.5, 2.0)), ("rsm_dtw", (5.0, 15))] * 6
+    cls = {"rsm_ed": kvmatch.QueryEngine, "cnsm_ed": kvmatch.NormQueryEngine, "rsm_dtw": kvmatch.QueryEngineDtw,
+           "cnsm_dtw": kvmatch.NormQueryEngineDtw}
+    want = {"rsm_ed": oracle.rsm_ed(s, q, L, R, 0, 5.0), "cnsm_ed": oracle.cnsm_ed(s, q, L, R, 0, 4.0, 1.5, 2.0),
+            "rsm_dtw": oracle.rsm_dtw(s, q, L, R, 0, 5.0, 15), "cnsm_dtw": oracle.cnsm_dtw(s, q, L, R, 0, 4.0, 15, 1.5, 2.0)}
+    seen = set()
+
+    def job(name, args):
+        def run(c):
+            seen.add(id(c))
+            return cls[name](c).verify((L, R), 1, q, *args)
+        return run
+
+    with kvmatch.QueryStream(ctx, in_flight=3) as qs:
+        assert len(qs.ctxs) == 3 and all(c.n == ctx.n for c in qs.ctxs)
+        res = qs.run([job(n, a) for n, a in jobs_spec])
+        for (name, _), got in zip(jobs_spec, res):
+            compare(got, want[name], tag="stream " + name)
+        assert len(seen) >= 2                      # the jobs really were spread over several contexts
+        with pytest.raises(kvmatch.KvMatchIllegalArgument):
+            ctx.share_series(ctx)                  # a context cannot share its own series
+    # the owner is untouched after the sharing contexts are closed
+    compare(kvmatch.QueryEngine(ctx).verify((L, R), 1, q, 5.0), want["rsm_ed"], tag="owner after close")
+
+
 def test_all_offsets_equals_full_scan(world):
     """candidates = every offset: engine semantics == CsvTester / UCR full-scan semantics."""
     kvmatch, datagen, series, ctx = world
