@@ -375,9 +375,13 @@ __global__ __launch_bounds__(256) void kvm_prefix_kernel(const double *__restric
             off1 += wtot1[w];
             off2 += wtot2[w];
         }
-        // exclusive prefix of this thread = inclusive - own total
-        off1 += s1 - a1[3];
-        off2 += s2 - a2[3];
+        // exclusive prefix of this thread = the inclusive scan of the lane before it.  (NOT `inclusive - own total`: an
+        // entry must depend on the points before it only -- with a large value in the thread's own group, e.g. the first
+        // point of a burst 1e150 times the local scale, the subtraction wiped out the prefix of the three points in front
+        // of it and the error bounds of kvm_prefix_err, which follow the magnitude of the ENTRY, no longer held.)
+        const double e1 = __shfl_up(s1, 1, 64), e2 = __shfl_up(s2, 1, 64);
+        off1 += lane ? e1 : 0.0;
+        off2 += lane ? e2 : 0.0;
         if (i0 + 3 < n) {
 #pragma unroll
             for (int c = 0; c < 4; c++) P[i0 + c] = make_double2(off1 + a1[c], off2 + a2[c]);

@@ -40,9 +40,40 @@ def make(kind, n, r):
     raise ValueError(kind)
 
 
+def cases(datagen, rounds, seed, kinds=KINDS, n_range=(30_000, 120_000)):
+    """The seeded sequence of adversarial cases: yields (rd, kind, n, m, rho, s, q, qoff, pl, lists, eps_tie, eps_generic)
+    with lists = [(name, L, R), ...] and eps_generic one value per list."""
+    rng = np.random.default_rng(seed)
+    for rd in range(rounds):
+        for kind in kinds:
+            n = int(rng.integers(*n_range))
+            s = make(kind, n, rng)
+            m = int(rng.choice([25, 31, 64, 100, 257, 1024, 2500]))
+            rho = int(rng.choice([0, 1, max(1, m // 20), max(1, m // 10)]))
+            for attempt in range(50):       # a query window that is finite and not constant (stdQ > 0)
+                qoff = int(rng.integers(1, n - m + 1))
+                w = s[qoff - 1: qoff - 1 + m]
+                if np.all(np.isfinite(w)) and np.std(w) > 0:
+                    break
+            pl = [int(p) for p in rng.integers(1, n - m + 1, 3)]     # exact copies (noise 0), the third shifted by +1
+            q = datagen.plant_copies(s, qoff, m, pl, [1.0, 1.0, 1.0], [0.0, 0.0, 1.0], 0.0, seed=rd)
+            lists = []
+            L, R = datagen.gen_intervals(n, m, int(rng.integers(500, 8000)), float(rng.choice([1.0, 8.0, 64.0, 400.0])),
+                                         must_cover=[qoff] + pl, seed=rd)
+            lists.append(("gen", L, R))
+            pts = np.unique(np.concatenate([rng.integers(1, n - m + 1, 300), [qoff] + pl])).astype(np.int32)
+            pts = pts[np.concatenate(([True], np.diff(pts) > 1))]       # single-offset intervals, non-adjacent
+            lists.append(("points", pts, pts.copy()))
+            lists.append(("full", np.array([1], dtype=np.int32), np.array([n - m + 1], dtype=np.int32)))
+            # thresholds: zero, an exactly achievable distance (the +1 shifted copy: eps^2 == m on exact data), a generic one
+            d0 = float(np.sum((s[pl[2] - 1: pl[2] - 1 + m] - q) ** 2))
+            eps_tie = float(np.sqrt(d0)) if np.isfinite(d0) and d0 > 0 and np.sqrt(d0) ** 2 == d0 else 1.0
+            eps_generic = [float(rng.uniform(0.5, 4.0)) for _ in lists]
+            yield rd, kind, n, m, rho, s, q, qoff, pl, lists, eps_tie, eps_generic
+
+
 def run(kvmatch, datagen, oracle, ctx, rounds, seed, kinds=KINDS, n_range=(30_000, 120_000), log=None):
     """Returns (verifications, mismatches, DTW verifications that needed the sequential tie path)."""
-    rng = np.random.default_rng(seed)
     total = bad = quirk = 0
     t_gpu = t_cpu = 0.0
 
@@ -72,33 +103,15 @@ def run(kvmatch, datagen, oracle, ctx, rounds, seed, kinds=KINDS, n_range=(30_00
         if log:
             log(f"MISMATCH {tag} got {len(a)} want {len(oo)}")
 
-    for rd in range(rounds):
-        for kind in kinds:
-            n = int(rng.integers(*n_range))
-            s = make(kind, n, rng)
-            m = int(rng.choice([25, 31, 64, 100, 257, 1024, 2500]))
-            rho = int(rng.choice([0, 1, max(1, m // 20), max(1, m // 10)]))
-            for attempt in range(50):       # a query window that is finite and not constant (stdQ > 0)
-                qoff = int(rng.integers(1, n - m + 1))
-                w = s[qoff - 1: qoff - 1 + m]
-                if np.all(np.isfinite(w)) and np.std(w) > 0:
-                    break
-            pl = [int(p) for p in rng.integers(1, n - m + 1, 3)]     # exact copies (noise 0), the third shifted by +1
-            q = datagen.plant_copies(s, qoff, m, pl, [1.0, 1.0, 1.0], [0.0, 0.0, 1.0], 0.0, seed=rd)
+    last_rd = -1
+    for rd, kind, n, m, rho, s, q, qoff, pl, lists, eps_tie, eps_generic in cases(datagen, rounds, seed, kinds, n_range):
+        if rd != last_rd and last_rd >= 0 and log:
+            log(f"round {last_rd}: verifications {total} mismatches {bad} DTW verifications through the sequential tie path {quirk}")
+        last_rd = rd
+        if True:
             ctx.load_series(s)
-            lists = []
-            L, R = datagen.gen_intervals(n, m, int(rng.integers(500, 8000)), float(rng.choice([1.0, 8.0, 64.0, 400.0])),
-                                         must_cover=[qoff] + pl, seed=rd)
-            lists.append(("gen", L, R))
-            pts = np.unique(np.concatenate([rng.integers(1, n - m + 1, 300), [qoff] + pl])).astype(np.int32)
-            pts = pts[np.concatenate(([True], np.diff(pts) > 1))]       # single-offset intervals, non-adjacent
-            lists.append(("points", pts, pts.copy()))
-            lists.append(("full", np.array([1], dtype=np.int32), np.array([n - m + 1], dtype=np.int32)))
-            # thresholds: zero, an exactly achievable distance (the +1 shifted copy: eps^2 == m on exact data), a generic one
-            d0 = float(np.sum((s[pl[2] - 1: pl[2] - 1 + m] - q) ** 2))
-            eps_tie = float(np.sqrt(d0)) if np.isfinite(d0) and d0 > 0 and np.sqrt(d0) ** 2 == d0 else 1.0
-            for name, L, R in lists:
-                for eps in (0.0, eps_tie, float(rng.uniform(0.5, 4.0))):
+            for li, (name, L, R) in enumerate(lists):
+                for eps in (0.0, eps_tie, eps_generic[li]):
                     for alpha, beta in ((1.0, 0.0), (1.0, 1.0), (1.5, 0.5), (1e9, 1e9)):
                         tag = f"{kind} rd={rd} n={n} m={m} list={name} eps={eps:.4f} a={alpha} b={beta} rho={rho}"
                         for ab in (1, 0):
@@ -118,7 +131,7 @@ def run(kvmatch, datagen, oracle, ctx, rounds, seed, kinds=KINDS, n_range=(30_00
                                  cpu(lambda: oracle.cnsm_dtw(s, q, L, R, 0, eps, rho, alpha, beta)), "cnsm_dtw " + tag, eps, True)
             if log:
                 log(f"  {kind} rd={rd} n={n} m={m}: library {t_gpu:.1f} s, oracle {t_cpu:.1f} s so far")
-        if log:
-            log(f"round {rd}: verifications {total} mismatches {bad} DTW verifications through the sequential tie path {quirk}")
+    if log and last_rd >= 0:
+        log(f"round {last_rd}: verifications {total} mismatches {bad} DTW verifications through the sequential tie path {quirk}")
     ctx.set_option(kvmatch.OPT_EARLY_ABANDON, 1)
     return total, bad, quirk

@@ -145,6 +145,45 @@ def test_query_stream_three_in_flight_matches_sequential(world):
     compare(kvmatch.QueryEngine(ctx).verify((L, R), 1, q, 5.0), want["rsm_ed"], tag="owner after close")
 
 
+@pytest.mark.parametrize("scale,jump", [(1e-158, 1.0), (1.0, 1e12), (1e-3, 1e6)])
+def test_windows_ending_just_in_front_of_a_burst(world, scale, jump):
+    """The prefix sums of the 1-3 points in front of a value many orders of magnitude above the local scale (they share a
+    4-point group with it in kvm_prefix_kernel) must not feel it: round 2 found `inclusive - own total` there, which wiped
+    out their prefix and made the (alpha, beta) filter drop answers whose windows END right in front of the burst.  Exact
+    copies of the query are planted so that they end 1, 2 and 3 points in front of three bursts."""
+    kvmatch, datagen, series, ctx = world
+    rng = np.random.default_rng(5)
+    n, m = 40_000, 512
+    s = np.cumsum(rng.uniform(-1, 1, n)) * scale
+    q = s[9_000:9_000 + m].copy()
+    copies = []
+    for k, g in ((1, 20_003), (2, 24_007), (3, 28_011)):        # g = 0-based index of the burst's first point, g % 4 == 3
+        assert g % 4 == 3
+        s[g: g + 700] += jump
+        off = g - k - m + 2                                     # 1-based start of a window whose last point is 0-based g - k
+        s[off - 1: off - 1 + m] = q
+        copies.append(off)
+    ctx.load_series(s)
+    eps = 0.5 * np.sqrt(m)
+    # (a) phase-1-shaped: one short interval per copy, so that the reference's running sums start fresh in front of it
+    #     (in one long run they would still carry the rounding residue of the previous burst)
+    L = np.array([c - 40 for c in copies] + [8_990], dtype=np.int32)
+    R = np.array([c + 1 for c in copies] + [9_010], dtype=np.int32)
+    order = np.argsort(L)
+    L, R = L[order], R[order]
+    got = kvmatch.NormQueryEngine(ctx).verify((L, R), 1, q, eps, 1.5, 1e9)
+    compare(got, oracle.cnsm_ed(s, q, L, R, 0, eps, 1.5, 1e9), tag=f"burst scale={scale} jump={jump}")
+    assert all(c in set(got.offsets.tolist()) for c in copies) and 9_001 in set(got.offsets.tolist())
+    got = kvmatch.NormQueryEngineDtw(ctx).verify((L, R), 1, q, eps, 25, 1.5, 1e9)
+    compare(got, oracle.cnsm_dtw(s, q, L, R, 0, eps, 25, 1.5, 1e9), tag=f"burst dtw scale={scale}")
+    assert all(c in set(got.offsets.tolist()) for c in copies)
+    # (b) every offset in one run: whatever the reference's drifting sums make of it, the library makes the same
+    L, R = np.array([1], dtype=np.int32), np.array([n - m + 1], dtype=np.int32)
+    for alpha, beta in ((1.5, 1e9), (1.0000001, 1e-6 * scale + 1e-300)):
+        compare(kvmatch.NormQueryEngine(ctx).verify((L, R), 1, q, eps, alpha, beta), oracle.cnsm_ed(s, q, L, R, 0, eps, alpha, beta),
+                tag=f"burst full scale={scale} jump={jump} a={alpha}")
+
+
 def test_all_offsets_equals_full_scan(world):
     """candidates = every offset: engine semantics == CsvTester / UCR full-scan semantics."""
     kvmatch, datagen, series, ctx = world
