@@ -1090,7 +1090,9 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
         ax.patch = (double *)ctx->b_aux.p;
         ax.ambig = (kvm_cand *)ctx->b_cands2.p;
         ax.cb_exact = nullptr;
-        ax.tau = 1e-12 + 5e-16 * (double)m;  // a wave-parallel sum of m terms against the same terms added one by one
+        // a wave-parallel sum of m terms against the same terms added one by one (1e-12 + 5e-16 m), plus -- cNSM -- terms
+        // formed with a reciprocal instead of a division per term (<= 6u m sqrt(sum), see dp_term_q in kvm_dtw.hip)
+        ax.tau = 1e-12 + 5e-16 * (double)m + (cnsm ? 1e-15 * (double)m / std::sqrt(qd.eps2 > 0 ? qd.eps2 : 1.0) : 0.0);
         KVM_DBG_SYNC(ctx, stream, "plan / upload / envelope");
         if (use_lb) {
             // (alpha, beta) filter + LB_Kim for every candidate, survivors re-tiled on the device; then LB_Keogh on the

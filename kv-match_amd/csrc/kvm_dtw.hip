@@ -228,14 +228,32 @@ __device__ __forceinline__ void dp_build_patch(const double *__restrict__ series
     __threadfence_block();
 }
 
+// The terms of the wave-parallel sums are formed with ONE reciprocal per candidate instead of a division per term: the
+// sums are only compared within the tolerance tau, which carries the difference (a normalised value off by <= 3 ulp moves
+// a term (w - e)^2 by <= 6u sqrt(term) |w|; |w| <= sqrt(m) wherever a term is non-zero, so a whole sum moves by
+// <= 6u m sqrt(sum): the 1e-15 m / sqrt(eps^2) in kvm_dtw_aux::tau).  The divisions were 45 % of the prologue's
+// instructions.  Bit-exact terms are only needed where additions are replayed one by one (kvm_dtw_ref.hip) and in the DP
+// cells (fillA keeps its true division).
+__device__ __forceinline__ double dp_term_q(double x, double mean, double inv, double u, double l) {
+    return dref_term_q((x - mean) * inv, u, l);
+}
+__device__ __forceinline__ double dp_term_d(double qv, double U, double L, double mean, double inv) {
+    const double uu = (U - mean) * inv, ll = (L - mean) * inv;
+    double d = 0;
+    if (qv > uu) d = dref_dsq(qv, uu);
+    else if (qv < ll) d = dref_dsq(qv, ll);
+    return d;
+}
+
 // term k (natural window position) of the bound chosen for cb[]: cb1[k] / cb2[k] of K/NormQueryEngineDtw.java:559-575
 __device__ __forceinline__ double dp_cb_term(const double *__restrict__ x, const kvm_query_dev &qd, const kvm_dtw_aux &ax,
                                              const double *__restrict__ patch, const dp_plan &pl, int32_t start, double mean,
                                              double sd, int k) {
-    if (pl.which == 0) return dref_term_q((x[k] - mean) / sd, qd.qu[k], qd.ql[k]);
+    const double inv = 1.0 / sd;
+    if (pl.which == 0) return dp_term_q(x[k], mean, inv, qd.qu[k], qd.ql[k]);
     double U, L;
     dp_env_at(ax, patch, qd.rho, pl, start + k, U, L);
-    return dref_term_d(qd.q[k], U, L, mean, sd);
+    return dp_term_d(qd.q[k], U, L, mean, inv);
 }
 
 // The cascade in front of the DP for one candidate (K/NormQueryEngineDtw.java:555-587), wave-cooperative.
@@ -265,16 +283,17 @@ __device__ int dp_prologue(const double *__restrict__ series, const kvm_query_de
     // of eps^2 makes the candidate ambiguous unless the other loop drops it cleanly.
     double carry1 = 0.0, carry2 = 0.0;
     bool amb1 = false, amb2 = false;  // the loop has stopped at a partial within rounding of eps^2
+    const double inv_sd = 1.0 / sd;
     for (int base = 0; base < m && !(amb1 && amb2); base += 256) {
         double d1[4], d2[4];
 #pragma unroll
         for (int h = 0; h < 4; h++) {
             const int i = base + 64 * h + lane, ic = min(i, m - 1);
             const int o = ax.order[ic];
-            const double t1 = dref_term_q((x[o] - mean) / sd, ax.uo[ic], ax.lo[ic]);
+            const double t1 = dp_term_q(x[o], mean, inv_sd, ax.uo[ic], ax.lo[ic]);
             double U, L;
             dp_env_at(ax, patch, r, pl, c.start + o, U, L);
-            const double t2 = dref_term_d(ax.qo[ic], U, L, mean, sd);
+            const double t2 = dp_term_d(ax.qo[ic], U, L, mean, inv_sd);
             d1[h] = i < m ? t1 : 0.0;
             d2[h] = i < m ? t2 : 0.0;
         }

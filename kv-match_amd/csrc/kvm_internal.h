@@ -257,7 +257,8 @@ struct kvm_dtw_aux {
     double *patch;               // scratch: 8 * rho doubles per DP wave (running max / min at the chunk ends)
     kvm_cand *ambig;             // out: candidates whose decision needs the sequential path
     const double *cb_exact;      // in (second DP run only): [2m per candidate] exact cb arrays, see kvm_dtw_ref.hip
-    double tau;                  // relative tolerance between a wave-parallel sum and the reference's sequential one
+    double tau;                  // relative tolerance between a wave-parallel sum (terms formed with a reciprocal) and
+                                 // the reference's sequential one
 };
 hipError_t kvm_launch_dtw_screen(const double *series, const double2 *prefix, const kvm_query_dev &qd, const kvm_dtw_aux &ax,
                                  const kvm_tile *tiles, int64_t n_tiles, const unsigned long long *d_n_tiles, kvm_cand *out,
