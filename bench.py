@@ -387,6 +387,7 @@ def main():
             # (eps so large that no lower bound and no row bound ever reaches eps^2: every candidate sweeps all its cells)
             g3 = lambda: deng.verify((l3, r3), 1, q2, 1e6, 0.05, 1e9, 1e9)  # noqa: E731
             g3()
+            ctx.set_option(kvmatch.OPT_TIMING, 1)
             t1 = time.perf_counter()
             r_ = g3()
             dtp = time.perf_counter() - t1
@@ -395,6 +396,8 @@ def main():
             ex["dtw_dp_full_candidates_per_s"] = r_.stats[0] / dtp
             ex["dtw_dp_cells_per_s"] = r_.stats[0] * cells / dtp
             ex["dtw_dp_kernel_ms"] = lib.kvm_last_kernel_ns(h) * 1e-6
+            ex["dtw_dp_kernel_cells_per_s"] = r_.stats[0] * cells / (lib.kvm_last_kernel_ns(h) * 1e-9) if lib.kvm_last_kernel_ns(h) else None
+            ctx.set_option(kvmatch.OPT_TIMING, 0)
             ctx.set_option(kvmatch.OPT_LB_CASCADE, 1)
             ctx.set_option(kvmatch.OPT_EARLY_ABANDON, 1)
             # index-free full scan (UCR-ED semantics, K/experiments/ucr/UcrEdQueryExecutor.java): every offset a candidate
