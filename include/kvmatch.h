@@ -40,10 +40,10 @@
  * `value <= eps^2` -- a bound that lands EXACTLY on eps^2 makes the candidate an answer at distance eps.  On
  * continuous data such ties have measure zero; on integer-valued data with an integer eps^2, and for eps = 0,
  * they are common.  kvm_verify_rsm_dtw / kvm_verify_cnsm_dtw reproduce them: same answers, same distances as the
- * Java loops (KVM_STAT_DTW_SEQUENTIAL counts the candidates that needed the sequential tie path).  The one thing not
- * reproduced is the permutation java.util.TimSort leaves behind under NormQueryEngineDtw's inconsistent comparator
- * (K/NormQueryEngineDtw.java:475-478); a stable merge sort stands in for it (it orders the LB_Keogh sums, i.e. it can
- * only matter on such an exact tie of a cNSM-DTW candidate).
+ * Java loops (KVM_STAT_DTW_SEQUENTIAL counts the candidates that needed the sequential tie path).  The order cNSM-DTW
+ * sums its LB_Keogh bounds in is the permutation java.util.TimSort (JDK 8) leaves under NormQueryEngineDtw's
+ * contract-breaking comparator (K/NormQueryEngineDtw.java:475-478), restated in the library (kvm_cnsm_dtw_order,
+ * KVM_OPT_SORT_VIOLATION) -- including the queries on which that sort throws.
  *
  * Every function returns KVM_OK (0) or a negative status; kvm_last_error() gives the message.
  * The library never falls back to a CPU path: without a usable HIP device kvm_open fails.
@@ -188,6 +188,14 @@ int kvm_verify_cnsm_dtw(kvm_ctx *ctx, const double *query, int32_t m, const int3
 /* `r <= 1 -> floor(r*m) else floor(r)`  (K/QueryEngineDtw.java:135-140). */
 int32_t kvm_resolve_rho(double r, int32_t m);
 
+/* The permutation cNSM-DTW sums its LB_Keogh bounds in: order[i] = index of the i-th element of tmpQ after
+ * `Arrays.sort(tmpQ, (o1, o2) -> (int) (Math.abs(o2.value) - Math.abs(o1.value)))` on the z-normalised query
+ * (K/NormQueryEngineDtw.java:470-484), as JDK 8's TimSort leaves it.  Host only (no GPU call); `query` is the raw
+ * query, z-normalised here like the engine does.  Returns KVM_OK, or KVM_ERR_ILLEGAL_ARGUMENT for a query on which
+ * that sort throws "Comparison method violates its general contract!" (see KVM_OPT_SORT_VIOLATION): a caller can
+ * ask before submitting.  `order` may be NULL when only the verdict is wanted. */
+int kvm_cnsm_dtw_order(const double *query, int32_t m, int32_t *order);
+
 /* ---- results: List<Pair<Integer, Double>> answers + statistics[2..4] ---------------------------- */
 
 int64_t kvm_result_count(const kvm_result *r);        /* answers.size()   -> statistics[4] (K/QueryEngine.java:370) */
@@ -221,6 +229,15 @@ void kvm_result_free(kvm_result *r);
                                     along the window (experimental).  All return identical answers. */
 #define KVM_OPT_TIMING 4         /* 1: record HIP-event kernel times into KVM_STAT_KERNEL_NS */
 #define KVM_OPT_DP_KERNEL 5      /* 0 auto (default: register-resident band when rho <= 511), 1 generic LDS form */
+#define KVM_OPT_SORT_VIOLATION 6 /* cNSM-DTW only.  NormQueryEngineDtw sorts its query with a comparator that breaks
+                                    the Comparator contract (K/NormQueryEngineDtw.java:475-478); for some queries
+                                    (about half of white-noise ones, a few percent of random walks, no smooth one)
+                                    java.util.TimSort then throws IllegalArgumentException("Comparison method
+                                    violates its general contract!") and the reference's query() dies with it.
+                                    0 (default): kvm_verify_cnsm_dtw returns KVM_ERR_ILLEGAL_ARGUMENT with that
+                                    message for exactly those queries; 1: answer them anyway (lower bounds summed in
+                                    index order -- the answers are those of any successful order except at exact
+                                    ties with eps^2). */
 int kvm_set_option(kvm_ctx *ctx, int32_t option, int64_t value);
 int64_t kvm_get_option(const kvm_ctx *ctx, int32_t option);
 /* Device time (ns, HIP events on the launch stream) of the verification kernels of the most recent

@@ -19,6 +19,7 @@
 #include <numeric>
 
 #include "kvm_internal.h"
+#include "kvm_jsort.h"
 
 #define KVM_MAX_SCAN_DATA_LENGTH 40000  // K/NormQueryEngine.java:60, K/NormQueryEngineDtw.java:61
 #define KVM_TILE_MAX 64                 // candidates per tile: wave ED kernel, DTW filter (one lane each)
@@ -153,6 +154,7 @@ extern "C" int kvm_set_option(kvm_ctx *ctx, int32_t option, int64_t value) {
             return KVM_OK;
         case KVM_OPT_TIMING: ctx->opt_timing = value ? 1 : 0; return KVM_OK;
         case KVM_OPT_DP_KERNEL: ctx->opt_dp_kernel = value == 1 ? 1 : 0; return KVM_OK;
+        case KVM_OPT_SORT_VIOLATION: ctx->opt_sort_violation = value ? 1 : 0; return KVM_OK;
     }
     return fail(ctx, KVM_ERR_ILLEGAL_ARGUMENT, "unknown option");
 }
@@ -181,6 +183,7 @@ extern "C" int64_t kvm_get_option(const kvm_ctx *ctx, int32_t option) {
         case KVM_OPT_ED_KERNEL: return ctx->opt_ed_kernel;
         case KVM_OPT_TIMING: return ctx->opt_timing;
         case KVM_OPT_DP_KERNEL: return ctx->opt_dp_kernel;
+        case KVM_OPT_SORT_VIOLATION: return ctx->opt_sort_violation;
     }
     return KVM_ERR_ILLEGAL_ARGUMENT;
 }
@@ -488,6 +491,23 @@ extern "C" int32_t kvm_resolve_rho(double r, int32_t m) {
     return (int32_t)std::floor(r);
 }
 
+extern "C" int kvm_cnsm_dtw_order(const double *query, int32_t m, int32_t *order) {
+    if (!query || m < 1) return fail(nullptr, KVM_ERR_ILLEGAL_ARGUMENT, "kvm_cnsm_dtw_order: bad arguments");
+    // K/NormQueryEngineDtw.java:205-211 (statistics) and :461-464 (z-normalisation)
+    double ex = 0, ex2 = 0;
+    for (int i = 0; i < m; i++) {
+        ex += query[i];
+        ex2 += query[i] * query[i];
+    }
+    const double mean = ex / m, sd = std::sqrt(ex2 / m - mean * mean);
+    std::vector<double> zq((size_t)m);
+    for (int i = 0; i < m; i++) zq[(size_t)i] = (query[i] - mean) / sd;
+    std::vector<int32_t> ord((size_t)m);
+    const bool ok = kvm_jsort::cnsm_dtw_order(zq.data(), m, ord.data());
+    if (order) std::memcpy(order, ord.data(), (size_t)m * sizeof(int32_t));
+    return ok ? KVM_OK : fail(nullptr, KVM_ERR_ILLEGAL_ARGUMENT, "Comparison method violates its general contract!");
+}
+
 static bool kvm_trace_on() {
     static int v = -1;
     if (v < 0) v = getenv("KVM_TRACE") ? 1 : 0;
@@ -739,6 +759,45 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
     const bool dtw = variant == V_RSM_DTW || variant == V_CNSM_DTW;
     if (cnsm && !(alpha > 0)) return fail(ctx, KVM_ERR_ILLEGAL_ARGUMENT, "alpha must be > 0");
     if (dtw && rho < 0) return fail(ctx, KVM_ERR_ILLEGAL_ARGUMENT, "rho must be >= 0");
+    // ---- query-side constants (host, sequential, exactly the reference's arithmetic) ----
+    std::vector<double> q(query, query + m), qu, ql;
+    kvm_query_dev qd;
+    std::memset(&qd, 0, sizeof qd);
+    qd.m = m;
+    qd.rho = rho;
+    qd.eps2 = epsilon * epsilon;
+    qd.normalised = cnsm ? 1 : 0;
+    qd.early_abandon = (int32_t)ctx->opt_early_abandon;
+    qd.alpha = alpha;
+    qd.beta = beta;
+    if (cnsm) {
+        // K/NormQueryEngine.java:192-198 (phase 0) and :438-441 (z-normalisation)
+        double ex = 0, ex2 = 0;
+        for (int i = 0; i < m; i++) {
+            ex += query[i];
+            ex2 += query[i] * query[i];
+        }
+        qd.meanQ = ex / m;
+        qd.stdQ = std::sqrt(ex2 / m - qd.meanQ * qd.meanQ);
+        for (int i = 0; i < m; i++) q[i] = (query[i] - qd.meanQ) / qd.stdQ;
+    }
+    if (dtw) query_envelope(q, rho, qu, ql);
+    // The reference's summation order of the LB_Keogh loops.  RSM-DTW: the reorder is commented out, order = identity
+    // (K/QueryEngineDtw.java:364-383).  cNSM-DTW: Arrays.sort with the comparator (int)(|o2| - |o1|)
+    // (K/NormQueryEngineDtw.java:475-478) -- inconsistent, so the permutation is the one JDK 8's TimSort leaves
+    // (kvm_jsort.h), and the sort may fail the way Java throws: query() then ends in that IllegalArgumentException before
+    // it has read anything, so this comes first here too.  KVM_OPT_SORT_VIOLATION = 1 answers such a query anyway,
+    // summing in plain index order (the answers differ from a successful sort's only at exact ties with eps^2).
+    std::vector<int32_t> ord;
+    if (dtw) {
+        ord.resize((size_t)m);
+        for (int i = 0; i < m; i++) ord[(size_t)i] = i;
+        if (cnsm && !kvm_jsort::cnsm_dtw_order(q.data(), m, ord.data())) {
+            if (!ctx->opt_sort_violation)
+                return fail(ctx, KVM_ERR_ILLEGAL_ARGUMENT, "Comparison method violates its general contract!");
+            for (int i = 0; i < m; i++) ord[(size_t)i] = i;
+        }
+    }
     HIPCHK(ctx, hipSetDevice(ctx->device));
     // Scratch buffers and the pinned staging area are reused by every call: wait until the previous call's device
     // work has drained (kvm_verify_device returns without synchronising the caller's stream).
@@ -819,29 +878,6 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
                                          pl.chunk_lo, pl.chunk_hi, d_run_chunk));
     }
 
-    // ---- query-side constants (host, sequential, exactly the reference's arithmetic) ----
-    std::vector<double> q(query, query + m), qu, ql;
-    kvm_query_dev qd;
-    std::memset(&qd, 0, sizeof qd);
-    qd.m = m;
-    qd.rho = rho;
-    qd.eps2 = epsilon * epsilon;
-    qd.normalised = cnsm ? 1 : 0;
-    qd.early_abandon = (int32_t)ctx->opt_early_abandon;
-    qd.alpha = alpha;
-    qd.beta = beta;
-    if (cnsm) {
-        // K/NormQueryEngine.java:192-198 (phase 0) and :438-441 (z-normalisation)
-        double ex = 0, ex2 = 0;
-        for (int i = 0; i < m; i++) {
-            ex += query[i];
-            ex2 += query[i] * query[i];
-        }
-        qd.meanQ = ex / m;
-        qd.stdQ = std::sqrt(ex2 / m - qd.meanQ * qd.meanQ);
-        for (int i = 0; i < m; i++) q[i] = (query[i] - qd.meanQ) / qd.stdQ;
-    }
-    if (dtw) query_envelope(q, rho, qu, ql);
     // correlation-form ED pruner: centred query and its chunk-granular prefix sums
     std::vector<double> qcen;
     std::vector<double2> qpref, qpref8;
@@ -903,37 +939,8 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
     if (dtw) {
         std::memcpy(hp + (size_t)m * 8, qu.data(), (size_t)m * 8);
         std::memcpy(hp + (size_t)m * 16, ql.data(), (size_t)m * 8);
-        // The reference's summation order of the LB_Keogh loops.  RSM-DTW: the reorder is commented out, order = identity
-        // (K/QueryEngineDtw.java:364-383).  cNSM-DTW: Arrays.sort with the comparator (int)(|o2| - |o1|)
-        // (K/NormQueryEngineDtw.java:475-478) -- inconsistent (the truncation makes most pairs "equal"), so the result
-        // depends on the sorting algorithm; this is a bottom-up stable merge sort (widths 1, 2, 4, ...; the right element is
-        // taken only when the comparator says "smaller"), the stand-in for TimSort that DESIGN.md section 2 documents.
         double *h_uo = (double *)(hp + qexact_off), *h_lo = h_uo + m, *h_qo = h_lo + m;
         int32_t *h_order = (int32_t *)(h_qo + m);
-        std::vector<int32_t> ord((size_t)m), tmp((size_t)m);
-        for (int i = 0; i < m; i++) ord[(size_t)i] = i;
-        if (cnsm) {
-            auto java_int = [](double v) -> int {  // (int) of a double: NaN -> 0, saturating
-                if (v != v) return 0;
-                if (v >= 2147483647.0) return 2147483647;
-                if (v <= -2147483648.0) return -2147483647 - 1;
-                return (int)v;
-            };
-            for (int w = 1; w < m; w *= 2) {
-                for (int lo = 0; lo < m; lo += 2 * w) {
-                    const int mid = std::min(lo + w, m), hi = std::min(lo + 2 * w, m);
-                    int i = lo, j = mid, o = lo;
-                    while (i < mid && j < hi) {
-                        // cmp(a[j], a[i]) < 0 with cmp(o1, o2) = (int)(|o2.value| - |o1.value|)
-                        if (java_int(std::fabs(q[(size_t)ord[(size_t)i]]) - std::fabs(q[(size_t)ord[(size_t)j]])) < 0) tmp[(size_t)o++] = ord[(size_t)j++];
-                        else tmp[(size_t)o++] = ord[(size_t)i++];
-                    }
-                    while (i < mid) tmp[(size_t)o++] = ord[(size_t)i++];
-                    while (j < hi) tmp[(size_t)o++] = ord[(size_t)j++];
-                }
-                ord.swap(tmp);
-            }
-        }
         for (int i = 0; i < m; i++) {
             const int o = ord[(size_t)i];
             h_order[i] = o;

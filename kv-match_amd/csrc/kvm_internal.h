@@ -93,7 +93,8 @@ struct kvm_ctx {
     size_t h_readback2_cap = 0;
     void *h_readback = nullptr;  // pinned, device-mapped: the readback kernel stores counters + first answers here
     size_t h_pinned_cap = 0;
-    int64_t opt_early_abandon = 1, opt_lb_cascade = 1, opt_ed_kernel = 0, opt_timing = 0, opt_dp_kernel = 0;
+    int64_t opt_early_abandon = 1, opt_lb_cascade = 1, opt_ed_kernel = 0, opt_timing = 0, opt_dp_kernel = 0,
+            opt_sort_violation = 0;
     int num_cu = 256;
     int64_t last_kernel_ns = 0;
     bool timing_pending = false;  // ev0/ev1 recorded, elapsed time not read yet (read lazily: no mid-pipeline sync)

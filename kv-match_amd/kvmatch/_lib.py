@@ -20,7 +20,7 @@ KVM_ERR_UNSUPPORTED = -7
 
 STAT_WINDOWS, STAT_PASS_FILTER, STAT_PASS_LB_KIM, STAT_PASS_LB_KEOGH, STAT_PASS_LB_KEOGH2, STAT_KERNEL_NS, \
     STAT_RECHECKED, STAT_DTW_SEQUENTIAL = range(8)
-OPT_EARLY_ABANDON, OPT_LB_CASCADE, OPT_ED_KERNEL, OPT_TIMING, OPT_DP_KERNEL = 1, 2, 3, 4, 5
+OPT_EARLY_ABANDON, OPT_LB_CASCADE, OPT_ED_KERNEL, OPT_TIMING, OPT_DP_KERNEL, OPT_SORT_VIOLATION = 1, 2, 3, 4, 5, 6
 
 # every symbol include/kvmatch.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
@@ -31,6 +31,7 @@ SYMBOLS = [
     "kvm_index_rows_free", "kvm_index_rows_build_grouped", "kvm_index_rows_groups", "kvm_index_rows_group_keys",
     "kvm_index_rows_group_offsets", "kvm_phase2_time_estimate_ms",
     "kvm_verify_rsm_ed", "kvm_verify_cnsm_ed", "kvm_verify_rsm_dtw", "kvm_verify_cnsm_dtw", "kvm_resolve_rho",
+    "kvm_cnsm_dtw_order",
     "kvm_result_count", "kvm_result_candidates", "kvm_result_elapsed_ms", "kvm_result_offsets",
     "kvm_result_distances", "kvm_result_stat", "kvm_result_free",
     "kvm_set_option", "kvm_get_option", "kvm_last_kernel_ns", "kvm_verify_device", "kvm_pack_answers_device",
@@ -101,6 +102,7 @@ def load():
         "kvm_verify_rsm_dtw": (C.c_int, [vp, vp, i32, vp, vp, i32, i32, f64, i32, C.POINTER(vp)]),
         "kvm_verify_cnsm_dtw": (C.c_int, [vp, vp, i32, vp, vp, i32, i32, f64, i32, f64, f64, C.POINTER(vp)]),
         "kvm_resolve_rho": (i32, [f64, i32]),
+        "kvm_cnsm_dtw_order": (C.c_int, [vp, i32, vp]),
         "kvm_result_count": (i64, [vp]),
         "kvm_result_candidates": (i64, [vp]),
         "kvm_result_elapsed_ms": (f64, [vp]),

@@ -226,7 +226,8 @@ class ShardedStream:
             c = ctx if i == 0 else Phase2Context(ctx.device).share_series(ctx)
             if i:
                 from . import _lib
-                for opt in (_lib.OPT_EARLY_ABANDON, _lib.OPT_LB_CASCADE, _lib.OPT_ED_KERNEL, _lib.OPT_TIMING, _lib.OPT_DP_KERNEL):
+                for opt in (_lib.OPT_EARLY_ABANDON, _lib.OPT_LB_CASCADE, _lib.OPT_ED_KERNEL, _lib.OPT_TIMING, _lib.OPT_DP_KERNEL,
+                            _lib.OPT_SORT_VIOLATION):
                     c.set_option(opt, ctx.get_option(opt))
             v = ShardedVerifier(c, variant, max_candidates, group=group, pack_cap=pack_cap)
             self.slots.append(dict(ctx=c, v=v, stream=torch.cuda.Stream(device=self.dev), ready=torch.cuda.Event()))

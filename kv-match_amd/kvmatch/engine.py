@@ -89,6 +89,19 @@ def resolve_rho(rho, m, resolved=None):
     return int(_lib.load().kvm_resolve_rho(float(rho), int(m)))
 
 
+def cnsm_dtw_order(query):
+    """The order NormQueryEngineDtw sums its LB_Keogh bounds in: the permutation JDK 8's Arrays.sort leaves under the
+    comparator (int)(|o2| - |o1|) on the z-normalised query (K/NormQueryEngineDtw.java:470-484).  Host only.  Raises
+    KvMatchIllegalArgument("Comparison method violates its general contract!") for a query on which that sort throws --
+    the reference's query() dies there, and so does NormQueryEngineDtw.verify unless OPT_SORT_VIOLATION is set."""
+    q = np.ascontiguousarray(query, dtype=np.float64)
+    order = np.empty(q.size, dtype=np.int32)
+    rc = _lib.load().kvm_cnsm_dtw_order(q.ctypes.data, q.size, order.ctypes.data)
+    if rc:
+        _lib.check(rc, None)
+    return order
+
+
 def phase2_time_estimate_ms(variant, disjoint_windows, candidate_offsets, length):
     """The reference's phase-2 cost model with MI355X constants (K/QueryEngine.java:55-57,316-327); variant 0 rsm_ed,
     1 cnsm_ed, 2 rsm_dtw, 3 cnsm_dtw."""
@@ -243,7 +256,8 @@ class QueryStream:
     def __init__(self, ctx, in_flight=2):
         self.ctxs = [ctx] + [Phase2Context(ctx.device).share_series(ctx) for _ in range(max(1, int(in_flight)) - 1)]
         for c in self.ctxs[1:]:
-            for opt in (_lib.OPT_EARLY_ABANDON, _lib.OPT_LB_CASCADE, _lib.OPT_ED_KERNEL, _lib.OPT_TIMING, _lib.OPT_DP_KERNEL):
+            for opt in (_lib.OPT_EARLY_ABANDON, _lib.OPT_LB_CASCADE, _lib.OPT_ED_KERNEL, _lib.OPT_TIMING, _lib.OPT_DP_KERNEL,
+                        _lib.OPT_SORT_VIOLATION):
                 c.set_option(opt, ctx.get_option(opt))
 
     def set_option(self, option, value):

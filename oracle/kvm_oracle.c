@@ -526,12 +526,390 @@ static int cmp_abs_desc(const kvo_index *o1, const kvo_index *o2) {
 }
 
 /* (o1, o2) -> (int) (Math.abs(o2.value) - Math.abs(o1.value))  (K/NormQueryEngineDtw.java:475-478).
- * The truncation makes this comparator inconsistent; Java's TimSort result under it is
- * implementation-defined (and may throw).  DIVERGENCE: a stable merge sort is used here.  The
- * permutation only changes the summation order inside lbKeogh*, i.e. last-ulp effects on lower
- * bounds, never the DTW distance of an answer. */
+ * The truncation makes this comparator inconsistent ("equal" whenever the |values| are less than 1
+ * apart, not transitive), so the permutation Arrays.sort returns is a property of the JDK's sorting
+ * algorithm, and the sort may end in IllegalArgumentException.  kvo_java_timsort below restates it. */
 static int cmp_abs_desc_trunc(const kvo_index *o1, const kvo_index *o2) {
     return (int)(fabs(o2->value) - fabs(o1->value));
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* java.util.TimSort as Arrays.sort(T[], Comparator) runs it: TimSort.sort(a, 0, a.length, c, null, 0, 0).
+ * THIRD-PARTY DEPENDENCY absent from /root/reference: the JDK (pom.xml targets Java 1.8).  Restated from
+ * the published OpenJDK 8 source of java/util/TimSort.java (sort, countRunAndMakeAscending, binarySort,
+ * minRunLength, mergeCollapse [the JDK 8 form], mergeForceCollapse, mergeAt, gallopLeft, gallopRight,
+ * mergeLo, mergeHi).  No JDK is installed here, so this restatement is not checked against a JVM
+ * ("parity unpinned", like the rest of this file); tests/java_transliteration.py holds a second
+ * restatement and tests/test_transliteration.py compares the two.  What does not depend on the restatement
+ * being right in every detail: an array in which compare(a[i], a[i-1]) >= 0 for all i is one run and is
+ * returned unchanged -- under the comparator above that is every query whose |zQ| never rises by >= 1
+ * between neighbours, i.e. most smooth queries.
+ * Returns 0, or -1 where Java throws IllegalArgumentException("Comparison method violates its general
+ * contract!") (the array is then left partially merged, as in Java). */
+#define TS_MIN_MERGE 32
+#define TS_MIN_GALLOP 7
+
+typedef struct {
+    kvo_index *a;
+    index_cmp c;
+    int minGallop;
+    kvo_index *tmp;
+    int stackSize;
+    int runBase[64], runLen[64];
+} kvo_timsort;
+
+static int ts_count_run_and_make_ascending(kvo_index *a, int lo, int hi, index_cmp c) {
+    int runHi = lo + 1;
+    if (runHi == hi) return 1;
+    if (c(&a[runHi++], &a[lo]) < 0) { /* descending */
+        while (runHi < hi && c(&a[runHi], &a[runHi - 1]) < 0) runHi++;
+        for (int i = lo, j = runHi - 1; i < j; i++, j--) { /* reverseRange */
+            kvo_index t = a[i];
+            a[i] = a[j];
+            a[j] = t;
+        }
+    } else { /* ascending */
+        while (runHi < hi && c(&a[runHi], &a[runHi - 1]) >= 0) runHi++;
+    }
+    return runHi - lo;
+}
+
+static void ts_binary_sort(kvo_index *a, int lo, int hi, int start, index_cmp c) {
+    if (start == lo) start++;
+    for (; start < hi; start++) {
+        kvo_index pivot = a[start];
+        int left = lo, right = start;
+        while (left < right) {
+            int mid = (int)(((unsigned)left + (unsigned)right) >> 1);
+            if (c(&pivot, &a[mid]) < 0)
+                right = mid;
+            else
+                left = mid + 1;
+        }
+        memmove(&a[left + 1], &a[left], (size_t)(start - left) * sizeof(kvo_index));
+        a[left] = pivot;
+    }
+}
+
+static int ts_min_run_length(int n) {
+    int r = 0;
+    while (n >= TS_MIN_MERGE) {
+        r |= (n & 1);
+        n >>= 1;
+    }
+    return n + r;
+}
+
+static int ts_gallop_left(const kvo_index *key, const kvo_index *a, int base, int len, int hint, index_cmp c) {
+    int lastOfs = 0, ofs = 1;
+    if (c(key, &a[base + hint]) > 0) {
+        int maxOfs = len - hint;
+        while (ofs < maxOfs && c(key, &a[base + hint + ofs]) > 0) {
+            lastOfs = ofs;
+            ofs = (ofs << 1) + 1;
+            if (ofs <= 0) ofs = maxOfs;
+        }
+        if (ofs > maxOfs) ofs = maxOfs;
+        lastOfs += hint;
+        ofs += hint;
+    } else {
+        int maxOfs = hint + 1;
+        while (ofs < maxOfs && c(key, &a[base + hint - ofs]) <= 0) {
+            lastOfs = ofs;
+            ofs = (ofs << 1) + 1;
+            if (ofs <= 0) ofs = maxOfs;
+        }
+        if (ofs > maxOfs) ofs = maxOfs;
+        int t = lastOfs;
+        lastOfs = hint - ofs;
+        ofs = hint - t;
+    }
+    lastOfs++;
+    while (lastOfs < ofs) {
+        int m = lastOfs + ((ofs - lastOfs) >> 1);
+        if (c(key, &a[base + m]) > 0)
+            lastOfs = m + 1;
+        else
+            ofs = m;
+    }
+    return ofs;
+}
+
+static int ts_gallop_right(const kvo_index *key, const kvo_index *a, int base, int len, int hint, index_cmp c) {
+    int ofs = 1, lastOfs = 0;
+    if (c(key, &a[base + hint]) < 0) {
+        int maxOfs = hint + 1;
+        while (ofs < maxOfs && c(key, &a[base + hint - ofs]) < 0) {
+            lastOfs = ofs;
+            ofs = (ofs << 1) + 1;
+            if (ofs <= 0) ofs = maxOfs;
+        }
+        if (ofs > maxOfs) ofs = maxOfs;
+        int t = lastOfs;
+        lastOfs = hint - ofs;
+        ofs = hint - t;
+    } else {
+        int maxOfs = len - hint;
+        while (ofs < maxOfs && c(key, &a[base + hint + ofs]) >= 0) {
+            lastOfs = ofs;
+            ofs = (ofs << 1) + 1;
+            if (ofs <= 0) ofs = maxOfs;
+        }
+        if (ofs > maxOfs) ofs = maxOfs;
+        lastOfs += hint;
+        ofs += hint;
+    }
+    lastOfs++;
+    while (lastOfs < ofs) {
+        int m = lastOfs + ((ofs - lastOfs) >> 1);
+        if (c(key, &a[base + m]) < 0)
+            ofs = m;
+        else
+            lastOfs = m + 1;
+    }
+    return ofs;
+}
+
+static int ts_merge_lo(kvo_timsort *ts, int base1, int len1, int base2, int len2) {
+    kvo_index *a = ts->a, *tmp = ts->tmp;
+    index_cmp c = ts->c;
+    int cursor1 = 0, cursor2 = base2, dest = base1;
+    memcpy(tmp, &a[base1], (size_t)len1 * sizeof(kvo_index));
+    a[dest++] = a[cursor2++];
+    if (--len2 == 0) {
+        memcpy(&a[dest], &tmp[cursor1], (size_t)len1 * sizeof(kvo_index));
+        return 0;
+    }
+    if (len1 == 1) {
+        memmove(&a[dest], &a[cursor2], (size_t)len2 * sizeof(kvo_index));
+        a[dest + len2] = tmp[cursor1];
+        return 0;
+    }
+    int minGallop = ts->minGallop;
+    for (;;) {
+        int count1 = 0, count2 = 0;
+        do {
+            if (c(&a[cursor2], &tmp[cursor1]) < 0) {
+                a[dest++] = a[cursor2++];
+                count2++;
+                count1 = 0;
+                if (--len2 == 0) goto outer;
+            } else {
+                a[dest++] = tmp[cursor1++];
+                count1++;
+                count2 = 0;
+                if (--len1 == 1) goto outer;
+            }
+        } while ((count1 | count2) < minGallop);
+        do {
+            count1 = ts_gallop_right(&a[cursor2], tmp, cursor1, len1, 0, c);
+            if (count1 != 0) {
+                memcpy(&a[dest], &tmp[cursor1], (size_t)count1 * sizeof(kvo_index));
+                dest += count1;
+                cursor1 += count1;
+                len1 -= count1;
+                if (len1 <= 1) goto outer;
+            }
+            a[dest++] = a[cursor2++];
+            if (--len2 == 0) goto outer;
+            count2 = ts_gallop_left(&tmp[cursor1], a, cursor2, len2, 0, c);
+            if (count2 != 0) {
+                memmove(&a[dest], &a[cursor2], (size_t)count2 * sizeof(kvo_index));
+                dest += count2;
+                cursor2 += count2;
+                len2 -= count2;
+                if (len2 == 0) goto outer;
+            }
+            a[dest++] = tmp[cursor1++];
+            if (--len1 == 1) goto outer;
+            minGallop--;
+        } while ((count1 >= TS_MIN_GALLOP) | (count2 >= TS_MIN_GALLOP));
+        if (minGallop < 0) minGallop = 0;
+        minGallop += 2;
+    }
+outer:
+    ts->minGallop = minGallop < 1 ? 1 : minGallop;
+    if (len1 == 1) {
+        memmove(&a[dest], &a[cursor2], (size_t)len2 * sizeof(kvo_index));
+        a[dest + len2] = tmp[cursor1];
+    } else if (len1 == 0) {
+        return -1; /* "Comparison method violates its general contract!" */
+    } else {
+        memcpy(&a[dest], &tmp[cursor1], (size_t)len1 * sizeof(kvo_index));
+    }
+    return 0;
+}
+
+static int ts_merge_hi(kvo_timsort *ts, int base1, int len1, int base2, int len2) {
+    kvo_index *a = ts->a, *tmp = ts->tmp;
+    index_cmp c = ts->c;
+    const int tmpBase = 0;
+    memcpy(tmp, &a[base2], (size_t)len2 * sizeof(kvo_index));
+    int cursor1 = base1 + len1 - 1, cursor2 = tmpBase + len2 - 1, dest = base2 + len2 - 1;
+    a[dest--] = a[cursor1--];
+    if (--len1 == 0) {
+        memcpy(&a[dest - (len2 - 1)], &tmp[tmpBase], (size_t)len2 * sizeof(kvo_index));
+        return 0;
+    }
+    if (len2 == 1) {
+        dest -= len1;
+        cursor1 -= len1;
+        memmove(&a[dest + 1], &a[cursor1 + 1], (size_t)len1 * sizeof(kvo_index));
+        a[dest] = tmp[cursor2];
+        return 0;
+    }
+    int minGallop = ts->minGallop;
+    for (;;) {
+        int count1 = 0, count2 = 0;
+        do {
+            if (c(&tmp[cursor2], &a[cursor1]) < 0) {
+                a[dest--] = a[cursor1--];
+                count1++;
+                count2 = 0;
+                if (--len1 == 0) goto outer;
+            } else {
+                a[dest--] = tmp[cursor2--];
+                count2++;
+                count1 = 0;
+                if (--len2 == 1) goto outer;
+            }
+        } while ((count1 | count2) < minGallop);
+        do {
+            count1 = len1 - ts_gallop_right(&tmp[cursor2], a, base1, len1, len1 - 1, c);
+            if (count1 != 0) {
+                dest -= count1;
+                cursor1 -= count1;
+                len1 -= count1;
+                memmove(&a[dest + 1], &a[cursor1 + 1], (size_t)count1 * sizeof(kvo_index));
+                if (len1 == 0) goto outer;
+            }
+            a[dest--] = tmp[cursor2--];
+            if (--len2 == 1) goto outer;
+            count2 = len2 - ts_gallop_left(&a[cursor1], tmp, tmpBase, len2, len2 - 1, c);
+            if (count2 != 0) {
+                dest -= count2;
+                cursor2 -= count2;
+                len2 -= count2;
+                memcpy(&a[dest + 1], &tmp[cursor2 + 1], (size_t)count2 * sizeof(kvo_index));
+                if (len2 <= 1) goto outer;
+            }
+            a[dest--] = a[cursor1--];
+            if (--len1 == 0) goto outer;
+            minGallop--;
+        } while ((count1 >= TS_MIN_GALLOP) | (count2 >= TS_MIN_GALLOP));
+        if (minGallop < 0) minGallop = 0;
+        minGallop += 2;
+    }
+outer:
+    ts->minGallop = minGallop < 1 ? 1 : minGallop;
+    if (len2 == 1) {
+        dest -= len1;
+        cursor1 -= len1;
+        memmove(&a[dest + 1], &a[cursor1 + 1], (size_t)len1 * sizeof(kvo_index));
+        a[dest] = tmp[cursor2];
+    } else if (len2 == 0) {
+        return -1; /* "Comparison method violates its general contract!" */
+    } else {
+        memcpy(&a[dest - (len2 - 1)], &tmp[tmpBase], (size_t)len2 * sizeof(kvo_index));
+    }
+    return 0;
+}
+
+static int ts_merge_at(kvo_timsort *ts, int i) {
+    kvo_index *a = ts->a;
+    int base1 = ts->runBase[i], len1 = ts->runLen[i];
+    int base2 = ts->runBase[i + 1], len2 = ts->runLen[i + 1];
+    ts->runLen[i] = len1 + len2;
+    if (i == ts->stackSize - 3) {
+        ts->runBase[i + 1] = ts->runBase[i + 2];
+        ts->runLen[i + 1] = ts->runLen[i + 2];
+    }
+    ts->stackSize--;
+    int k = ts_gallop_right(&a[base2], a, base1, len1, 0, ts->c);
+    base1 += k;
+    len1 -= k;
+    if (len1 == 0) return 0;
+    len2 = ts_gallop_left(&a[base1 + len1 - 1], a, base2, len2, len2 - 1, ts->c);
+    if (len2 == 0) return 0;
+    return len1 <= len2 ? ts_merge_lo(ts, base1, len1, base2, len2) : ts_merge_hi(ts, base1, len1, base2, len2);
+}
+
+static int ts_merge_collapse(kvo_timsort *ts) {
+    while (ts->stackSize > 1) {
+        int n = ts->stackSize - 2;
+        if (n > 0 && ts->runLen[n - 1] <= ts->runLen[n] + ts->runLen[n + 1]) {
+            if (ts->runLen[n - 1] < ts->runLen[n + 1]) n--;
+            if (ts_merge_at(ts, n)) return -1;
+        } else if (ts->runLen[n] <= ts->runLen[n + 1]) {
+            if (ts_merge_at(ts, n)) return -1;
+        } else {
+            break;
+        }
+    }
+    return 0;
+}
+
+static int ts_merge_force_collapse(kvo_timsort *ts) {
+    while (ts->stackSize > 1) {
+        int n = ts->stackSize - 2;
+        if (n > 0 && ts->runLen[n - 1] < ts->runLen[n + 1]) n--;
+        if (ts_merge_at(ts, n)) return -1;
+    }
+    return 0;
+}
+
+static int kvo_java_timsort(kvo_index *a, int n, index_cmp c) {
+    int lo = 0, hi = n, nRemaining = n;
+    if (nRemaining < 2) return 0;
+    if (nRemaining < TS_MIN_MERGE) {
+        int initRunLen = ts_count_run_and_make_ascending(a, lo, hi, c);
+        ts_binary_sort(a, lo, hi, lo + initRunLen, c);
+        return 0;
+    }
+    kvo_timsort ts;
+    ts.a = a;
+    ts.c = c;
+    ts.minGallop = TS_MIN_GALLOP;
+    ts.stackSize = 0;
+    ts.tmp = (kvo_index *)malloc((size_t)n * sizeof(kvo_index)); /* Java grows tmp on demand; the size is not observable */
+    int minRun = ts_min_run_length(nRemaining), rc = 0;
+    do {
+        int runLen = ts_count_run_and_make_ascending(a, lo, hi, c);
+        if (runLen < minRun) {
+            int force = nRemaining <= minRun ? nRemaining : minRun;
+            ts_binary_sort(a, lo, lo + force, lo + runLen, c);
+            runLen = force;
+        }
+        ts.runBase[ts.stackSize] = lo;
+        ts.runLen[ts.stackSize] = runLen;
+        ts.stackSize++;
+        if ((rc = ts_merge_collapse(&ts)) != 0) break;
+        lo += runLen;
+        nRemaining -= runLen;
+    } while (nRemaining != 0);
+    if (rc == 0) rc = ts_merge_force_collapse(&ts);
+    free(ts.tmp);
+    return rc;
+}
+
+/* TEST SWITCH, not reference behaviour: 1 = where the sort above throws, carry on with the array in index order (the
+ * library's KVM_OPT_SORT_VIOLATION = 1), so that the verification arithmetic can still be compared on such queries. */
+static int kvo_lenient_sort = 0;
+void kvo_set_lenient_sort(int on) { kvo_lenient_sort = on ? 1 : 0; }
+
+/* The permutation NormQueryEngineDtw sorts its query into (K/NormQueryEngineDtw.java:470-484): order[i] = the
+ * index of the i-th element of tmpQ after Arrays.sort.  Returns KVO_OK or KVO_ERR_ILLEGAL_ARGUMENT where the
+ * sort throws (query() then ends in that IllegalArgumentException: nothing catches it). */
+int kvo_cnsm_dtw_order(const double *zQ, int queryLength, int *order) {
+    kvo_index *tmpQ = (kvo_index *)malloc((size_t)(queryLength > 0 ? queryLength : 1) * sizeof(kvo_index));
+    for (int i = 0; i < queryLength; i++) {
+        tmpQ[i].value = zQ[i];
+        tmpQ[i].index = i;
+    }
+    int rc = kvo_java_timsort(tmpQ, queryLength, cmp_abs_desc_trunc);
+    for (int i = 0; i < queryLength; i++) order[i] = tmpQ[i].index;
+    free(tmpQ);
+    return rc ? KVO_ERR_ILLEGAL_ARGUMENT : KVO_OK;
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -802,7 +1180,16 @@ int64_t kvo_query_cnsm_dtw(const double *series, int n, const double *queryData,
         tmpQ[i].value = zQ[i];
         tmpQ[i].index = i;
     }
-    stable_sort_index(tmpQ, queryLength, cmp_abs_desc_trunc);
+    if (kvo_java_timsort(tmpQ, queryLength, cmp_abs_desc_trunc)) { /* Arrays.sort throws: query() dies with it (:475) */
+        if (!kvo_lenient_sort) {
+            free(zQ); free(u); free(l); free(tmpQ);
+            return KVO_ERR_ILLEGAL_ARGUMENT;
+        }
+        for (int i = 0; i < queryLength; i++) {
+            tmpQ[i].value = zQ[i];
+            tmpQ[i].index = i;
+        }
+    }
     int *order = (int *)malloc((size_t)queryLength * sizeof(int));
     double *qo = (double *)malloc((size_t)queryLength * sizeof(double));
     double *uo = (double *)malloc((size_t)queryLength * sizeof(double));
@@ -1161,7 +1548,7 @@ int64_t kvo_ucr_ed(const double *series, int n, const double *queryData, int M, 
  * and the data envelope restart per buffer (:204,213-214); answers are 0-BASED offsets
  * (`it * (EPOCH - M + 1) + i - M + 1`, :283).  cb1/cb2 are reused without clearing (:157-161); a stale entry is only
  * ever read after a bound has already reached bsf.  The query order uses the truncating comparator of
- * K/NormQueryEngineDtw.java:475-490 (same stable-sort stand-in as kvo_query_cnsm_dtw). */
+ * K/NormQueryEngineDtw.java:475-478 (U/UcrDtwQueryExecutor.java:142-145): kvo_java_timsort, as in kvo_query_cnsm_dtw. */
 int64_t kvo_ucr_dtw(const double *series, int n, const double *queryData, int M, double Epsilon, int Rho, double Alpha,
                     double Beta, int32_t *out_off, double *out_dist, int64_t cap, int64_t *stats) {
     const int EPOCH = 100000;
@@ -1200,7 +1587,17 @@ int64_t kvo_ucr_dtw(const double *series, int n, const double *queryData, int M,
         Q_tmp[i].value = q[i];
         Q_tmp[i].index = i;
     }
-    stable_sort_index(Q_tmp, M, cmp_abs_desc_trunc); /* :140-143 */
+    if (kvo_java_timsort(Q_tmp, M, cmp_abs_desc_trunc)) { /* :142-145; Arrays.sort throws and run() dies with it */
+        if (!kvo_lenient_sort) {
+            free(q); free(qo); free(uo); free(lo); free(order); free(Q_tmp); free(u); free(l);
+            free(cb); free(cb1); free(cb2); free(t); free(tz); free(buffer); free(u_buff); free(l_buff);
+            return KVO_ERR_ILLEGAL_ARGUMENT;
+        }
+        for (int i = 0; i < M; i++) {
+            Q_tmp[i].value = q[i];
+            Q_tmp[i].index = i;
+        }
+    }
     for (int i = 0; i < M; i++) { /* :146-154 */
         int o = Q_tmp[i].index;
         order[i] = o;

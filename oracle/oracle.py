@@ -70,6 +70,10 @@ def load():
     lib.kvo_to_round.argtypes = [f64]
     lib.kvo_query_stats.restype = None
     lib.kvo_query_stats.argtypes = [vp, i32, vp, vp]
+    lib.kvo_cnsm_dtw_order.restype = C.c_int
+    lib.kvo_cnsm_dtw_order.argtypes = [vp, i32, vp]
+    lib.kvo_set_lenient_sort.restype = None
+    lib.kvo_set_lenient_sort.argtypes = [C.c_int]
     lib.kvo_sort_answers.restype = None
     lib.kvo_sort_answers.argtypes = [vp, vp, i64]
     _lib = lib
@@ -130,6 +134,30 @@ def cnsm_dtw(series, query, left, right, shift, eps, rho, alpha, beta):
                                     l.size, int(shift), float(eps), int(rho), float(alpha), float(beta),
                                     off.ctypes.data, dist.ctypes.data, cap, st.ctypes.data)
     return _done(cnt, off, dist, st)
+
+
+def set_lenient_sort(on):
+    """TEST SWITCH (not reference behaviour): where NormQueryEngineDtw's / UcrDtwQueryExecutor's Arrays.sort throws, carry
+    on in index order -- the counterpart of the library's OPT_SORT_VIOLATION = 1.  Returns the previous setting."""
+    global _lenient
+    prev = _lenient
+    load().kvo_set_lenient_sort(1 if on else 0)
+    _lenient = bool(on)
+    return prev
+
+
+_lenient = False
+
+
+def cnsm_dtw_order(zq):
+    """The permutation NormQueryEngineDtw's Arrays.sort leaves (JDK 8 TimSort under the truncating comparator);
+    raises OracleError(-2) where Java throws "Comparison method violates its general contract!"."""
+    z = np.ascontiguousarray(zq, dtype=np.float64)
+    order = np.empty(z.size, dtype=np.int32)
+    rc = load().kvo_cnsm_dtw_order(z.ctypes.data, z.size, order.ctypes.data)
+    if rc:
+        raise OracleError(rc)
+    return order
 
 
 def ucr_ed(series, query, eps, alpha, beta):

@@ -74,24 +74,54 @@ def cases(datagen, rounds, seed, kinds=KINDS, n_range=(30_000, 120_000)):
 
 def run(kvmatch, datagen, oracle, ctx, rounds, seed, kinds=KINDS, n_range=(30_000, 120_000), log=None):
     """Returns (verifications, mismatches, DTW verifications that needed the sequential tie path)."""
-    total = bad = quirk = 0
+    total = bad = quirk = thrown = 0
+    ctx.set_option(kvmatch.OPT_SORT_VIOLATION, 0)
+    oracle.set_lenient_sort(False)
     t_gpu = t_cpu = 0.0
 
     def gpu(fn):
         nonlocal t_gpu
-        t = time.perf_counter(); r = fn(); dt = time.perf_counter() - t; t_gpu += dt
-        if log and dt > 0.25:
+        t = time.perf_counter()
+        try:
+            r = fn()
+        except kvmatch.KvMatchIllegalArgument as e:       # (cNSM-DTW: the reference's Arrays.sort throws on this query)
+            r = ("illegal", str(e))
+        dt = time.perf_counter() - t; t_gpu += dt
+        if log and dt > 0.25 and not isinstance(r, tuple):
             log(f"  slow library call: {dt:.2f} s, {len(r)} answers of {r.cnt_candidate} candidates, stats {r.stats}")
         return r
 
     def cpu(fn):
         nonlocal t_cpu
-        t = time.perf_counter(); r = fn(); t_cpu += time.perf_counter() - t
+        t = time.perf_counter()
+        try:
+            r = fn()
+        except oracle.OracleError as e:
+            if e.code != -2:
+                raise
+            r = ("illegal", str(e))
+        t_cpu += time.perf_counter() - t
         return r
 
-    def same(a, o, tag, eps, dtw):
-        nonlocal total, bad, quirk
+    def same(a_fn, o_fn, tag, eps, dtw):
+        nonlocal total, bad, quirk, thrown
         total += 1
+        a, o = gpu(a_fn), cpu(o_fn)
+        if isinstance(a, tuple) or isinstance(o[0], str):       # an IllegalArgumentException: on both sides or it is a mismatch
+            if not (isinstance(a, tuple) and isinstance(o[0], str)):
+                bad += 1
+                if log:
+                    log(f"MISMATCH {tag}: only one side threw ({a if isinstance(a, tuple) else o})")
+                return
+            # the reference's sort threw on this query, on both sides: compare the arithmetic with the switch that carries on
+            thrown += 1
+            ctx.set_option(kvmatch.OPT_SORT_VIOLATION, 1)
+            prev = oracle.set_lenient_sort(True)
+            try:
+                a, o = gpu(a_fn), cpu(o_fn)
+            finally:
+                ctx.set_option(kvmatch.OPT_SORT_VIOLATION, 0)
+                oracle.set_lenient_sort(prev)
         oo, od, oc = o[0], o[1], o[2]
         ok = len(a) == len(oo) and np.array_equal(a.offsets, oo) and np.array_equal(a.distances, od, equal_nan=True) \
             and a.cnt_candidate == oc["cnt_candidate"]
@@ -117,21 +147,22 @@ def run(kvmatch, datagen, oracle, ctx, rounds, seed, kinds=KINDS, n_range=(30_00
                         for ab in (1, 0):
                             ctx.set_option(kvmatch.OPT_EARLY_ABANDON, ab)
                             if alpha == 1.0 and beta == 0.0:
-                                same(gpu(lambda: kvmatch.QueryEngine(ctx).verify((L, R), 1, q, eps)), cpu(lambda: oracle.rsm_ed(s, q, L, R, 0, eps)),
+                                same((lambda: kvmatch.QueryEngine(ctx).verify((L, R), 1, q, eps)), (lambda: oracle.rsm_ed(s, q, L, R, 0, eps)),
                                      "rsm_ed " + tag + f" ab={ab}", eps, False)
-                            same(gpu(lambda: kvmatch.NormQueryEngine(ctx).verify((L, R), 1, q, eps, alpha, beta)),
-                                 cpu(lambda: oracle.cnsm_ed(s, q, L, R, 0, eps, alpha, beta)), "cnsm_ed " + tag + f" ab={ab}", eps, False)
+                            same((lambda: kvmatch.NormQueryEngine(ctx).verify((L, R), 1, q, eps, alpha, beta)),
+                                 (lambda: oracle.cnsm_ed(s, q, L, R, 0, eps, alpha, beta)), "cnsm_ed " + tag + f" ab={ab}", eps, False)
                         if name != "full" or n < 60_000:
                             ctx.set_option(kvmatch.OPT_EARLY_ABANDON, 1)
                             if alpha == 1.0 and beta == 0.0:
                                 r2 = int(rho)        # (an int rho is the band half-width in points)
-                                same(gpu(lambda: kvmatch.QueryEngineDtw(ctx).verify((L, R), 1, q, eps, r2)),
-                                     cpu(lambda: oracle.rsm_dtw(s, q, L, R, 0, eps, r2)), "rsm_dtw " + tag, eps, True)
-                            same(gpu(lambda: kvmatch.NormQueryEngineDtw(ctx).verify((L, R), 1, q, eps, rho, alpha, beta, resolved=True)),
-                                 cpu(lambda: oracle.cnsm_dtw(s, q, L, R, 0, eps, rho, alpha, beta)), "cnsm_dtw " + tag, eps, True)
+                                same((lambda: kvmatch.QueryEngineDtw(ctx).verify((L, R), 1, q, eps, r2)),
+                                     (lambda: oracle.rsm_dtw(s, q, L, R, 0, eps, r2)), "rsm_dtw " + tag, eps, True)
+                            same((lambda: kvmatch.NormQueryEngineDtw(ctx).verify((L, R), 1, q, eps, rho, alpha, beta, resolved=True)),
+                                 (lambda: oracle.cnsm_dtw(s, q, L, R, 0, eps, rho, alpha, beta)), "cnsm_dtw " + tag, eps, True)
             if log:
                 log(f"  {kind} rd={rd} n={n} m={m}: library {t_gpu:.1f} s, oracle {t_cpu:.1f} s so far")
     if log and last_rd >= 0:
-        log(f"round {last_rd}: verifications {total} mismatches {bad} DTW verifications through the sequential tie path {quirk}")
+        log(f"round {last_rd}: verifications {total} mismatches {bad} DTW verifications through the sequential tie path {quirk}; "
+            f"queries on which the reference's sort throws (both sides, then compared with the switch on) {thrown}")
     ctx.set_option(kvmatch.OPT_EARLY_ABANDON, 1)
     return total, bad, quirk

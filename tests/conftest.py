@@ -12,6 +12,7 @@ for p in (ROOT, os.path.join(ROOT, "kv-match_amd"), os.path.join(ROOT, "oracle")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "strict_sort: run with the reference's behaviour where NormQueryEngineDtw's sort throws")
 
 
 @pytest.fixture(scope="session")
@@ -20,6 +21,39 @@ def built():
     import __graft_entry__ as ge
     ge.build()
     return True
+
+
+@pytest.fixture(autouse=True)
+def lenient_sort(request):
+    """NormQueryEngineDtw's Arrays.sort throws on a good part of the noisy synthetic queries the GPU tests use (DESIGN.md
+    section 2); the reference's query() dies there, and by default so do the oracle and the library.  What the GPU parity
+    tests are after is the verification arithmetic, so they run with the switch that carries on in index order -- on BOTH
+    sides (oracle.set_lenient_sort / OPT_SORT_VIOLATION on every context a test opens).  Tests marked `strict_sort` keep
+    the reference's behaviour: they are the ones that check the throw itself."""
+    if "gpu" not in request.keywords or request.node.get_closest_marker("strict_sort"):
+        yield
+        return
+    import kvmatch
+    import oracle
+    # contexts of module-scoped fixtures exist before this function-scoped one runs
+    shared = [request.getfixturevalue(name)[3] for name in ("world", "big") if name in request.fixturenames]
+    for c in shared:
+        c.set_option(kvmatch.OPT_SORT_VIOLATION, 1)
+    orig = kvmatch.Phase2Context.__init__
+
+    def opened_lenient(self, *a, **k):
+        orig(self, *a, **k)
+        self.set_option(kvmatch.OPT_SORT_VIOLATION, 1)
+
+    kvmatch.Phase2Context.__init__ = opened_lenient
+    prev = oracle.set_lenient_sort(True)
+    try:
+        yield
+    finally:
+        kvmatch.Phase2Context.__init__ = orig
+        oracle.set_lenient_sort(prev)
+        for c in shared:
+            c.set_option(kvmatch.OPT_SORT_VIOLATION, 0)
 
 
 @pytest.fixture(scope="session")

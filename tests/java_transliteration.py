@@ -15,7 +15,8 @@ second, independently written reading of the same text, compared bit for bit wit
 
 The one place where Java's behaviour is not a function of the text alone: NormQueryEngineDtw sorts with the comparator
 (int)(|o2| - |o1|) (:475-478), which violates the Comparator contract, so the permutation depends on java.util.TimSort's
-merge pattern.  Like the oracle, this file uses a bottom-up stable merge sort there (documented stand-in)."""
+merge pattern.  java_arrays_sort at the end of this file restates JDK 8's TimSort for that call; where it throws
+("Comparison method violates its general contract!") cnsm_dtw raises IllegalArgumentException like query() does."""
 import functools
 import math
 
@@ -420,26 +421,6 @@ def rsm_dtw(series, query, left, right, last_segment, epsilon, rho):
     return _sorted_answers(answers), cnt_candidate
 
 
-def _stable_merge_sort(a, cmp):
-    """Bottom-up stable merge sort (the documented stand-in for TimSort under the inconsistent comparator)."""
-    n = len(a)
-    w = 1
-    while w < n:
-        tmp = []
-        for lo in range(0, n, 2 * w):
-            mid, hi = min(lo + w, n), min(lo + 2 * w, n)
-            i, j = lo, mid
-            while i < mid and j < hi:
-                if cmp(a[j], a[i]) < 0:
-                    tmp.append(a[j]); j += 1
-                else:
-                    tmp.append(a[i]); i += 1
-            tmp.extend(a[i:mid]); tmp.extend(a[j:hi])
-        a = tmp
-        w *= 2
-    return a
-
-
 def _java_int(v):
     """(int) of a double: toward zero, NaN -> 0, saturating."""
     if v != v:
@@ -460,7 +441,10 @@ def cnsm_dtw(series, query, left, right, last_segment, epsilon, rho, alpha, beta
     u, l = [0.0] * query_length, [0.0] * query_length
     lower_upper_lemire(zq, query_length, rho, l, u)
     tmp_q = [(zq[i], i) for i in range(query_length)]
-    tmp_q = _stable_merge_sort(tmp_q, lambda o1, o2: _java_int(abs(o2[0]) - abs(o1[0])))
+    try:
+        java_arrays_sort(tmp_q, lambda o1, o2: _java_int(abs(o2[0]) - abs(o1[0])))
+    except ComparisonContractViolation as e:
+        raise IllegalArgumentException(str(e))
     order = [i for _, i in tmp_q]
     qo = [zq[o] for o in order]
     uo = [u[o] for o in order]
@@ -498,3 +482,397 @@ def cnsm_dtw(series, query, left, right, last_segment, epsilon, rho, alpha, beta
                     ex -= T[j]
                     ex2 -= T[j] * T[j]
     return _sorted_answers(answers), cnt_candidate
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# java.util.TimSort (OpenJDK 8, the JDK the reference's pom.xml targets: <source>1.8</source>), restated from its
+# published source: Arrays.sort(T[], Comparator) -> TimSort.sort(a, 0, a.length, c, null, 0, 0).  The JDK is a dependency
+# that is absent from /root/reference; it matters here because NormQueryEngineDtw sorts with a comparator that violates
+# the Comparator contract ((int)(|o2| - |o1|), K/NormQueryEngineDtw.java:475-478): the resulting permutation is then a
+# property of this algorithm -- its run detection, binary insertion, merge order and galloping -- not of the comparator.
+# In particular a query whose |zQ| never rises by >= 1 between neighbours is ONE non-descending run and comes back
+# unchanged, and the sort can end in IllegalArgumentException("Comparison method violates its general contract!").
+class ComparisonContractViolation(Exception):  # noqa: E302
+    """java.lang.IllegalArgumentException("Comparison method violates its general contract!") out of mergeLo / mergeHi."""
+
+
+_MIN_MERGE = 32
+_MIN_GALLOP = 7
+
+
+def _count_run_and_make_ascending(a, lo, hi, c):
+    run_hi = lo + 1
+    if run_hi == hi:
+        return 1
+    run_hi += 1
+    if c(a[run_hi - 1], a[lo]) < 0:                       # descending
+        while run_hi < hi and c(a[run_hi], a[run_hi - 1]) < 0:
+            run_hi += 1
+        i, j = lo, run_hi - 1                             # reverseRange(a, lo, runHi)
+        while i < j:
+            a[i], a[j] = a[j], a[i]
+            i += 1
+            j -= 1
+    else:                                                 # ascending
+        while run_hi < hi and c(a[run_hi], a[run_hi - 1]) >= 0:
+            run_hi += 1
+    return run_hi - lo
+
+
+def _binary_sort(a, lo, hi, start, c):
+    if start == lo:
+        start += 1
+    while start < hi:
+        pivot = a[start]
+        left, right = lo, start
+        while left < right:
+            mid = (left + right) >> 1
+            if c(pivot, a[mid]) < 0:
+                right = mid
+            else:
+                left = mid + 1
+        n = start - left
+        a[left + 1: left + 1 + n] = a[left: left + n]     # System.arraycopy(a, left, a, left + 1, n)
+        a[left] = pivot
+        start += 1
+
+
+def _min_run_length(n):
+    r = 0
+    while n >= _MIN_MERGE:
+        r |= (n & 1)
+        n >>= 1
+    return n + r
+
+
+def _gallop_left(key, a, base, length, hint, c):
+    last_ofs, ofs = 0, 1
+    if c(key, a[base + hint]) > 0:
+        max_ofs = length - hint
+        while ofs < max_ofs and c(key, a[base + hint + ofs]) > 0:
+            last_ofs = ofs
+            ofs = (ofs << 1) + 1
+        if ofs > max_ofs:
+            ofs = max_ofs
+        last_ofs += hint
+        ofs += hint
+    else:
+        max_ofs = hint + 1
+        while ofs < max_ofs and c(key, a[base + hint - ofs]) <= 0:
+            last_ofs = ofs
+            ofs = (ofs << 1) + 1
+        if ofs > max_ofs:
+            ofs = max_ofs
+        last_ofs, ofs = hint - ofs, hint - last_ofs
+    last_ofs += 1
+    while last_ofs < ofs:
+        m = last_ofs + ((ofs - last_ofs) >> 1)
+        if c(key, a[base + m]) > 0:
+            last_ofs = m + 1
+        else:
+            ofs = m
+    return ofs
+
+
+def _gallop_right(key, a, base, length, hint, c):
+    ofs, last_ofs = 1, 0
+    if c(key, a[base + hint]) < 0:
+        max_ofs = hint + 1
+        while ofs < max_ofs and c(key, a[base + hint - ofs]) < 0:
+            last_ofs = ofs
+            ofs = (ofs << 1) + 1
+        if ofs > max_ofs:
+            ofs = max_ofs
+        last_ofs, ofs = hint - ofs, hint - last_ofs
+    else:
+        max_ofs = length - hint
+        while ofs < max_ofs and c(key, a[base + hint + ofs]) >= 0:
+            last_ofs = ofs
+            ofs = (ofs << 1) + 1
+        if ofs > max_ofs:
+            ofs = max_ofs
+        last_ofs += hint
+        ofs += hint
+    last_ofs += 1
+    while last_ofs < ofs:
+        m = last_ofs + ((ofs - last_ofs) >> 1)
+        if c(key, a[base + m]) < 0:
+            ofs = m
+        else:
+            last_ofs = m + 1
+    return ofs
+
+
+class _TimSort:
+    def __init__(self, a, c):
+        self.a, self.c = a, c
+        self.min_gallop = _MIN_GALLOP
+        self.run_base, self.run_len = [], []
+
+    def push_run(self, base, length):
+        self.run_base.append(base)
+        self.run_len.append(length)
+
+    def merge_collapse(self):                              # the JDK 8 form
+        rl = self.run_len
+        while len(rl) > 1:
+            n = len(rl) - 2
+            if n > 0 and rl[n - 1] <= rl[n] + rl[n + 1]:
+                if rl[n - 1] < rl[n + 1]:
+                    n -= 1
+                self.merge_at(n)
+            elif rl[n] <= rl[n + 1]:
+                self.merge_at(n)
+            else:
+                break
+
+    def merge_force_collapse(self):
+        rl = self.run_len
+        while len(rl) > 1:
+            n = len(rl) - 2
+            if n > 0 and rl[n - 1] < rl[n + 1]:
+                n -= 1
+            self.merge_at(n)
+
+    def merge_at(self, i):
+        a, c = self.a, self.c
+        base1, len1 = self.run_base[i], self.run_len[i]
+        base2, len2 = self.run_base[i + 1], self.run_len[i + 1]
+        self.run_len[i] = len1 + len2
+        del self.run_base[i + 1]                           # (slides run i+2 over when i is the 3rd-last run; pops otherwise)
+        del self.run_len[i + 1]
+        k = _gallop_right(a[base2], a, base1, len1, 0, c)
+        base1 += k
+        len1 -= k
+        if len1 == 0:
+            return
+        len2 = _gallop_left(a[base1 + len1 - 1], a, base2, len2, len2 - 1, c)
+        if len2 == 0:
+            return
+        if len1 <= len2:
+            self.merge_lo(base1, len1, base2, len2)
+        else:
+            self.merge_hi(base1, len1, base2, len2)
+
+    def merge_lo(self, base1, len1, base2, len2):
+        a, c = self.a, self.c
+        tmp = a[base1: base1 + len1]
+        cursor1, cursor2, dest = 0, base2, base1
+        a[dest] = a[cursor2]
+        dest += 1
+        cursor2 += 1
+        len2 -= 1
+        if len2 == 0:
+            a[dest: dest + len1] = tmp[cursor1: cursor1 + len1]
+            return
+        if len1 == 1:
+            a[dest: dest + len2] = a[cursor2: cursor2 + len2]
+            a[dest + len2] = tmp[cursor1]
+            return
+        min_gallop = self.min_gallop
+        done = False
+        while not done:
+            count1 = count2 = 0
+            while True:
+                if c(a[cursor2], tmp[cursor1]) < 0:
+                    a[dest] = a[cursor2]
+                    dest += 1
+                    cursor2 += 1
+                    count2 += 1
+                    count1 = 0
+                    len2 -= 1
+                    if len2 == 0:
+                        done = True
+                        break
+                else:
+                    a[dest] = tmp[cursor1]
+                    dest += 1
+                    cursor1 += 1
+                    count1 += 1
+                    count2 = 0
+                    len1 -= 1
+                    if len1 == 1:
+                        done = True
+                        break
+                if not ((count1 | count2) < min_gallop):
+                    break
+            if done:
+                break
+            while True:
+                count1 = _gallop_right(a[cursor2], tmp, cursor1, len1, 0, c)
+                if count1 != 0:
+                    a[dest: dest + count1] = tmp[cursor1: cursor1 + count1]
+                    dest += count1
+                    cursor1 += count1
+                    len1 -= count1
+                    if len1 <= 1:
+                        done = True
+                        break
+                a[dest] = a[cursor2]
+                dest += 1
+                cursor2 += 1
+                len2 -= 1
+                if len2 == 0:
+                    done = True
+                    break
+                count2 = _gallop_left(tmp[cursor1], a, cursor2, len2, 0, c)
+                if count2 != 0:
+                    a[dest: dest + count2] = a[cursor2: cursor2 + count2]
+                    dest += count2
+                    cursor2 += count2
+                    len2 -= count2
+                    if len2 == 0:
+                        done = True
+                        break
+                a[dest] = tmp[cursor1]
+                dest += 1
+                cursor1 += 1
+                len1 -= 1
+                if len1 == 1:
+                    done = True
+                    break
+                min_gallop -= 1
+                if not (count1 >= _MIN_GALLOP or count2 >= _MIN_GALLOP):
+                    break
+            if done:
+                break
+            if min_gallop < 0:
+                min_gallop = 0
+            min_gallop += 2
+        self.min_gallop = 1 if min_gallop < 1 else min_gallop
+        if len1 == 1:
+            a[dest: dest + len2] = a[cursor2: cursor2 + len2]
+            a[dest + len2] = tmp[cursor1]
+        elif len1 == 0:
+            raise ComparisonContractViolation("Comparison method violates its general contract!")
+        else:
+            a[dest: dest + len1] = tmp[cursor1: cursor1 + len1]
+
+    def merge_hi(self, base1, len1, base2, len2):
+        a, c = self.a, self.c
+        tmp = a[base2: base2 + len2]
+        tmp_base = 0
+        cursor1 = base1 + len1 - 1
+        cursor2 = tmp_base + len2 - 1
+        dest = base2 + len2 - 1
+        a[dest] = a[cursor1]
+        dest -= 1
+        cursor1 -= 1
+        len1 -= 1
+        if len1 == 0:
+            a[dest - (len2 - 1): dest + 1] = tmp[tmp_base: tmp_base + len2]
+            return
+        if len2 == 1:
+            dest -= len1
+            cursor1 -= len1
+            a[dest + 1: dest + 1 + len1] = a[cursor1 + 1: cursor1 + 1 + len1]
+            a[dest] = tmp[cursor2]
+            return
+        min_gallop = self.min_gallop
+        done = False
+        while not done:
+            count1 = count2 = 0
+            while True:
+                if c(tmp[cursor2], a[cursor1]) < 0:
+                    a[dest] = a[cursor1]
+                    dest -= 1
+                    cursor1 -= 1
+                    count1 += 1
+                    count2 = 0
+                    len1 -= 1
+                    if len1 == 0:
+                        done = True
+                        break
+                else:
+                    a[dest] = tmp[cursor2]
+                    dest -= 1
+                    cursor2 -= 1
+                    count2 += 1
+                    count1 = 0
+                    len2 -= 1
+                    if len2 == 1:
+                        done = True
+                        break
+                if not ((count1 | count2) < min_gallop):
+                    break
+            if done:
+                break
+            while True:
+                count1 = len1 - _gallop_right(tmp[cursor2], a, base1, len1, len1 - 1, c)
+                if count1 != 0:
+                    dest -= count1
+                    cursor1 -= count1
+                    len1 -= count1
+                    a[dest + 1: dest + 1 + count1] = a[cursor1 + 1: cursor1 + 1 + count1]
+                    if len1 == 0:
+                        done = True
+                        break
+                a[dest] = tmp[cursor2]
+                dest -= 1
+                cursor2 -= 1
+                len2 -= 1
+                if len2 == 1:
+                    done = True
+                    break
+                count2 = len2 - _gallop_left(a[cursor1], tmp, tmp_base, len2, len2 - 1, c)
+                if count2 != 0:
+                    dest -= count2
+                    cursor2 -= count2
+                    len2 -= count2
+                    a[dest + 1: dest + 1 + count2] = tmp[cursor2 + 1: cursor2 + 1 + count2]
+                    if len2 <= 1:
+                        done = True
+                        break
+                a[dest] = a[cursor1]
+                dest -= 1
+                cursor1 -= 1
+                len1 -= 1
+                if len1 == 0:
+                    done = True
+                    break
+                min_gallop -= 1
+                if not (count1 >= _MIN_GALLOP or count2 >= _MIN_GALLOP):
+                    break
+            if done:
+                break
+            if min_gallop < 0:
+                min_gallop = 0
+            min_gallop += 2
+        self.min_gallop = 1 if min_gallop < 1 else min_gallop
+        if len2 == 1:
+            dest -= len1
+            cursor1 -= len1
+            a[dest + 1: dest + 1 + len1] = a[cursor1 + 1: cursor1 + 1 + len1]
+            a[dest] = tmp[cursor2]
+        elif len2 == 0:
+            raise ComparisonContractViolation("Comparison method violates its general contract!")
+        else:
+            a[dest - (len2 - 1): dest + 1] = tmp[tmp_base: tmp_base + len2]
+
+
+def java_arrays_sort(a, c):
+    """Arrays.sort(T[] a, Comparator c) of JDK 8, in place on the list `a`; may raise ComparisonContractViolation."""
+    lo, hi = 0, len(a)
+    n_remaining = hi - lo
+    if n_remaining < 2:
+        return a
+    if n_remaining < _MIN_MERGE:
+        init_run_len = _count_run_and_make_ascending(a, lo, hi, c)
+        _binary_sort(a, lo, hi, lo + init_run_len, c)
+        return a
+    ts = _TimSort(a, c)
+    min_run = _min_run_length(n_remaining)
+    while True:
+        run_len = _count_run_and_make_ascending(a, lo, hi, c)
+        if run_len < min_run:
+            force = n_remaining if n_remaining <= min_run else min_run
+            _binary_sort(a, lo, lo + force, lo + run_len, c)
+            run_len = force
+        ts.push_run(lo, run_len)
+        ts.merge_collapse()
+        lo += run_len
+        n_remaining -= run_len
+        if n_remaining == 0:
+            break
+    ts.merge_force_collapse()
+    return a

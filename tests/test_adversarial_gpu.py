@@ -9,6 +9,7 @@ import oracle
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.strict_sort
 def test_adversarial_inputs_all_variants(built):
     import kvmatch
     from kvmatch import datagen

@@ -927,3 +927,69 @@ def test_wide_bands_envelope_paths(world, m, rho):
             tag=f"wide band rsm {rho}")
     compare(kvmatch.NormQueryEngineDtw(ctx).verify((L, R), 1, q, eps, rho, 1.5, 3.0),
             oracle.cnsm_dtw(s, q, L, R, 0, eps, rho, 1.5, 3.0), tag=f"wide band cnsm {rho}")
+
+
+@pytest.mark.strict_sort
+def test_cnsm_dtw_sort_violation_like_the_reference_and_the_lenient_option(world):
+    """NormQueryEngineDtw's Arrays.sort throws "Comparison method violates its general contract!" on some queries
+    (K/NormQueryEngineDtw.java:475-478 under JDK 8's TimSort): the library then fails the same way, before touching
+    the candidates; OPT_SORT_VIOLATION = 1 answers anyway -- the set brute force gives (tests/bruteforce.py)."""
+    import bruteforce as bf
+    kvmatch, datagen, series, ctx = world
+    rng = np.random.default_rng(99)
+    m, rho, eps, alpha, beta = 64, 6, 5.0, 1.5, 5.0
+    for _ in range(100):
+        q = rng.normal(size=m)
+        try:
+            kvmatch.cnsm_dtw_order(q)
+        except kvmatch.KvMatchIllegalArgument:
+            break
+    else:
+        raise AssertionError("no violating query found")
+    s = rng.normal(size=4000)
+    for pos in (500, 2000, 3100):
+        s[pos:pos + m] = q * rng.uniform(0.8, 1.2) + rng.uniform(-1, 1) + rng.normal(size=m) * 0.05
+    L, R = np.array([1], dtype=np.int32), np.array([len(s) - m + 1], dtype=np.int32)
+    ctx.load_series(s)
+    eng = kvmatch.NormQueryEngineDtw(ctx)
+    with pytest.raises(oracle.OracleError):
+        oracle.cnsm_dtw(s, q, L, R, 0, eps, rho, alpha, beta)
+    with pytest.raises(kvmatch.KvMatchIllegalArgument, match="Comparison method violates its general contract!"):
+        eng.verify((L, R), 1, q, eps, rho, alpha, beta)
+    # zero candidates: the reference still sorts first and still throws
+    with pytest.raises(kvmatch.KvMatchIllegalArgument, match="general contract"):
+        eng.verify((L[:0], R[:0]), 1, q, eps, rho, alpha, beta)
+    # the context stays usable, and the other engines answer the same query
+    compare(kvmatch.QueryEngineDtw(ctx).verify((L, R), 1, q, eps, rho), oracle.rsm_dtw(s, q, L, R, 0, eps, rho), tag="rsm after violation")
+    compare(kvmatch.NormQueryEngine(ctx).verify((L, R), 1, q, eps, alpha, beta), oracle.cnsm_ed(s, q, L, R, 0, eps, alpha, beta),
+            tag="cnsm_ed after violation")
+    ctx.set_option(kvmatch.OPT_SORT_VIOLATION, 1)
+    try:
+        got = eng.verify((L, R), 1, q, eps, rho, alpha, beta)
+    finally:
+        ctx.set_option(kvmatch.OPT_SORT_VIOLATION, 0)
+    mq, sq = bf.znorm_stats(q)
+    zq = (q - mq) / sq
+    want = {}
+    for st in range(1, len(s) - m + 2):
+        w = s[st - 1: st - 1 + m]
+        mean, std = bf.znorm_stats(w)
+        if abs(mean - mq) <= beta and std / sq <= alpha and std / sq >= 1 / alpha:
+            v = oracle.dtw_full((w - mean) / std, zq, rho)
+            if v <= eps * eps:
+                want[st] = np.sqrt(v)
+    assert sorted(got.offsets.tolist()) == sorted(want) and len(want) >= 3
+    assert all(abs(want[o] - d) <= 1e-6 * max(1.0, d) for o, d in zip(got.offsets.tolist(), got.distances.tolist()))
+    assert all(p + 1 in want for p in (500, 2000, 3100))
+    # a query the sort accepts is unaffected by the option
+    q2 = s[1000:1000 + m].cumsum()
+    q2 = np.sin(np.arange(m) * 0.1) * 2 + 0.01 * q2
+    kvmatch.cnsm_dtw_order(q2)
+    a = eng.verify((L, R), 1, q2, eps, rho, alpha, beta)
+    ctx.set_option(kvmatch.OPT_SORT_VIOLATION, 1)
+    try:
+        b = eng.verify((L, R), 1, q2, eps, rho, alpha, beta)
+    finally:
+        ctx.set_option(kvmatch.OPT_SORT_VIOLATION, 0)
+    assert np.array_equal(a.offsets, b.offsets) and np.array_equal(a.distances, b.distances)
+    compare(a, oracle.cnsm_dtw(s, q2, L, R, 0, eps, rho, alpha, beta), tag="accepted query")
