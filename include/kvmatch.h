@@ -154,6 +154,30 @@ int64_t kvm_index_rows_groups(const kvm_index_rows *r);
 const double *kvm_index_rows_group_keys(const kvm_index_rows *r);
 const int32_t *kvm_index_rows_group_offsets(const kvm_index_rows *r);
 
+/* The whole IndexBuilder.run for one window length w (= Wu; K/IndexBuilder.java:186-347) and the bytes
+ * IndexFileOperator.writeAll puts into files/index-{N}-{Wu} (K/operator/file/IndexFileOperator.java:127-165): step 1 on
+ * the GPU (kvm_index_rows_build_grouped), then on the host step 2 -- adjacent rows merged by the reference's rule
+ * (:308-347, K/utils/IndexNodeUtils.java:30-90) --, IndexNode.toBytesCompact (K/common/entity/IndexNode.java:61-100) per
+ * row, the statistic triples (K/utils/ByteUtils.java:86-104) and the offset table.  Byte for byte the file the Java
+ * builder writes for the same series.  KVM_ERR_ILLEGAL_ARGUMENT when the series holds no window of length w,
+ * KVM_ERR_UNSUPPORTED when the file would reach 2 GiB (its offsets are Java ints).  The image is owned by the library
+ * until kvm_index_file_free; kvm_index_file_write stores it at `path` (the reference's name is
+ * "files/index-" + N + "-" + Wu). */
+typedef struct kvm_index_file kvm_index_file;
+int kvm_index_build(kvm_ctx *ctx, int32_t w, kvm_index_file **out);
+int64_t kvm_index_file_size(const kvm_index_file *f);
+const uint8_t *kvm_index_file_bytes(const kvm_index_file *f);
+#define KVM_INDEX_ROWS_BEFORE 0      /* rows (distinct keys) after step 1 */
+#define KVM_INDEX_ROWS_AFTER 1       /* rows after step 2 = lines of the file */
+#define KVM_INDEX_INTERVALS_BEFORE 2
+#define KVM_INDEX_INTERVALS_AFTER 3
+#define KVM_INDEX_STEP1_US 4         /* wall time of the three stages of the call, microseconds */
+#define KVM_INDEX_STEP2_US 5
+#define KVM_INDEX_ENCODE_US 6
+int64_t kvm_index_file_info(const kvm_index_file *f, int32_t what);
+int kvm_index_file_write(const kvm_index_file *f, const char *path);
+void kvm_index_file_free(kvm_index_file *f);
+
 /* Phase-2 time model for the phase-1 early-termination test (K/QueryEngine.java:316-327 and the same lines of the other
  * three engines): estimated T_2 in milliseconds of this library for `disjoint_windows` candidate intervals holding
  * `candidate_offsets` offsets and a query of `length` points,

@@ -34,6 +34,8 @@ static int fail(kvm_ctx *ctx, int code, const std::string &msg) {
     return code;
 }
 
+void kvm_set_error(kvm_ctx *ctx, const std::string &msg) { fail(ctx, 0, msg); }  // for the host-only translation units
+
 #define HIPCHK(ctx, call)                                                                            \
     do {                                                                                             \
         hipError_t e_ = (call);                                                                      \

@@ -11,6 +11,8 @@ way K/QueryEngine.java:368-370 does.  Phases 0/1 (index probing) are out of scop
 All arithmetic happens in libkvmatch_hip.so through the C ABI; this file only marshals.
 """
 import ctypes as C
+import os
+
 import numpy as np
 
 from . import _lib
@@ -200,6 +202,29 @@ class Phase2Context:
             self._lib.kvm_index_rows_free(h)
         return (keys, first, last, gk, go) if grouped else (keys, first, last)
 
+    def index_build(self, w, path=None):
+        """IndexBuilder.run for window length w, whole (K/IndexBuilder.java:186-347): step 1 on the GPU, step 2 (row
+        merging), IndexNode.toBytesCompact and the file layout of IndexFileOperator.writeAll on the host.  Returns
+        (bytes of files/index-{N}-{w}, info) with info = dict(rows_before, rows_after, intervals_before, intervals_after,
+        step1_ms, step2_ms, encode_ms); `path` also writes the file."""
+        import ctypes as C
+        h = C.c_void_p()
+        _lib.check(self._lib.kvm_index_build(self._h, int(w), C.byref(h)), self._h)
+        try:
+            size = int(self._lib.kvm_index_file_size(h))
+            data = C.string_at(self._lib.kvm_index_file_bytes(h), size)
+            names = ("rows_before", "rows_after", "intervals_before", "intervals_after")
+            info = {k: int(self._lib.kvm_index_file_info(h, i)) for i, k in enumerate(names)}
+            for i, k in ((4, "step1_ms"), (5, "step2_ms"), (6, "encode_ms")):
+                info[k] = self._lib.kvm_index_file_info(h, i) / 1e3
+            if path is not None:
+                rc = self._lib.kvm_index_file_write(h, os.fsencode(path))
+                if rc:
+                    raise _lib.KvMatchIOError(f"cannot write {path}")
+        finally:
+            self._lib.kvm_index_file_free(h)
+        return data, info
+
     def set_option(self, option, value):
         _lib.check(self._lib.kvm_set_option(self._h, int(option), int(value)), self._h)
 
@@ -239,6 +264,36 @@ class Phase2Context:
                            stats)
         finally:
             lib.kvm_result_free(res)
+
+
+class IndexBuilder:
+    """Mirror of K/IndexBuilder.java for the "file" storage type: `IndexBuilder(ctx, n).build_indexes(directory)` writes
+    files/index-{n}-{Wu} for the enabled window lengths (WuList with WuEnabled, :52-53 -- 25, 50, 100, 200, 400), each the
+    bytes IndexBuilder.SingleIndexBuilder.run + IndexFileOperator.writeAll produce for the series staged in `ctx`
+    (step 1 on the GPU, step 2 / codec / layout on the library's host side: kvm_index_build)."""
+    WU_LIST = (25, 50, 75, 100, 125, 150, 175, 200, 225, 250, 275, 300, 325, 350, 375, 400)
+    WU_ENABLED = (True, True, False, True, False, False, False, True, False, False, False, False, False, False, False, True)
+
+    def __init__(self, ctx, n=None):
+        self.ctx = ctx
+        self.n = int(ctx.n if n is None else n)
+        if self.n != ctx.n:
+            raise _lib.KvMatchIllegalArgument("n differs from the length of the staged series")
+
+    def build_indexes(self, directory="files"):
+        """Returns {Wu: info} (see Phase2Context.index_build); a window length longer than the series is skipped the way
+        the reference's loop logs the exception and carries on (:108-110)."""
+        os.makedirs(directory, exist_ok=True)
+        done = {}
+        for wu, enabled in zip(self.WU_LIST, self.WU_ENABLED):
+            if not enabled:
+                continue
+            try:
+                _, info = self.ctx.index_build(wu, path=os.path.join(directory, f"index-{self.n}-{wu}"))
+            except _lib.KvMatchIllegalArgument:
+                continue
+            done[wu] = info
+        return done
 
 
 class QueryStream:

@@ -1467,6 +1467,269 @@ int64_t kvo_index_rows(const double *series, int64_t n, int32_t w, double *keys,
     return cnt_rows;
 }
 
+/* ================================================================================================================
+ * Index build, the rest of IndexBuilder.run (K/IndexBuilder.java:296-347) and the index file
+ * (K/operator/file/IndexFileOperator.java:127-164, K/common/entity/IndexNode.java:51-95, K/utils/ByteUtils.java,
+ * K/utils/IndexNodeUtils.java:30-90): rows = one IndexNode per distinct key (the HashMap of :192,:270-284), step 2
+ * merges adjacent rows, the file holds the merged rows in ascending key order (TreeMap), the statistic triples and the
+ * offset table.  Everything below is int / byte work on top of kvo_index_rows.
+ * ================================================================================================================ */
+typedef struct {
+    int32_t *first, *last; /* positions: List<Pair<Integer, Integer>> */
+    int64_t size, cap;
+} kvo_node;
+
+static void node_push(kvo_node *nd, int32_t f, int32_t l) {
+    if (nd->size == nd->cap) {
+        nd->cap = nd->cap ? nd->cap * 2 : 16;
+        nd->first = (int32_t *)realloc(nd->first, (size_t)nd->cap * sizeof(int32_t));
+        nd->last = (int32_t *)realloc(nd->last, (size_t)nd->cap * sizeof(int32_t));
+    }
+    nd->first[nd->size] = f;
+    nd->last[nd->size] = l;
+    nd->size++;
+}
+
+static void node_free(kvo_node *nd) {
+    free(nd->first);
+    free(nd->last);
+    memset(nd, 0, sizeof *nd);
+}
+
+/* IndexNodeUtils.addInterval (K/utils/IndexNodeUtils.java:82-90): "diff can not exceed 255" */
+static void node_add_interval(kvo_node *nd, int32_t f, int32_t l) {
+    while (l - f >= 256) { /* IndexNode.MAXIMUM_DIFF */
+        int32_t newFirst = f + 256 - 1;
+        node_push(nd, f, newFirst);
+        f = newFirst + 1;
+    }
+    node_push(nd, f, l);
+}
+
+/* IndexNodeUtils.mergeIndexNode (K/utils/IndexNodeUtils.java:30-80) */
+static void node_merge(const kvo_node *node1, const kvo_node *node2, kvo_node *ret) {
+    int64_t index1 = 0, index2 = 0;
+    int has1 = 0, has2 = 0;
+    int32_t l1f = 0, l1s = 0, l2f = 0, l2s = 0; /* last1, last2: working copies */
+    while (index1 < node1->size && index2 < node2->size) {
+        if (!has1) { l1f = node1->first[index1]; l1s = node1->last[index1]; has1 = 1; }
+        if (!has2) { l2f = node2->first[index2]; l2s = node2->last[index2]; has2 = 1; }
+        if (l1s + 1 < l2f) {
+            node_add_interval(ret, l1f, l1s);
+            index1++;
+            has1 = 0;
+        } else if (l2s + 1 < l1f) {
+            node_add_interval(ret, l2f, l2s);
+            index2++;
+            has2 = 0;
+        } else {
+            if (l1s < l2s) {
+                if (l1f < l2f) l2f = l1f;
+                index1++;
+                has1 = 0;
+            } else {
+                if (l2f < l1f) l1f = l2f;
+                index2++;
+                has2 = 0;
+            }
+        }
+    }
+    for (int64_t i = index1; i < node1->size; i++) {
+        if (!has1) { l1f = node1->first[i]; l1s = node1->last[i]; }
+        node_add_interval(ret, l1f, l1s);
+        has1 = 0;
+    }
+    for (int64_t i = index2; i < node2->size; i++) {
+        if (!has2) { l2f = node2->first[i]; l2s = node2->last[i]; }
+        node_add_interval(ret, l2f, l2s);
+        has2 = 0;
+    }
+}
+
+static void put_be32(uint8_t *p, int32_t v) { /* Bytes.toBytes(int): big-endian */
+    uint32_t u = (uint32_t)v;
+    p[0] = (uint8_t)(u >> 24); p[1] = (uint8_t)(u >> 16); p[2] = (uint8_t)(u >> 8); p[3] = (uint8_t)u;
+}
+
+static void put_be_double(uint8_t *p, double v) { /* Bytes.toBytes(double): doubleToRawLongBits, big-endian */
+    uint64_t u;
+    memcpy(&u, &v, 8);
+    for (int b = 0; b < 8; b++) p[b] = (uint8_t)(u >> (56 - 8 * b));
+}
+
+/* IndexNode.toBytesCompact (K/common/entity/IndexNode.java:61-100); `out` has room for 8 * size bytes; returns length */
+static int64_t node_to_bytes_compact(const kvo_node *nd, uint8_t *result) {
+    int64_t index = 0, length = 0;
+    int count = 0, isPacking = 0;
+    while (index < nd->size) {
+        if (!isPacking) {
+            put_be32(result + length, nd->first[index]);
+            length += 4 + 1; /* first: 4 bytes, remain 1 byte for count */
+            int diff = nd->last[index] - nd->first[index];
+            result[length++] = (uint8_t)(int8_t)(diff - 128);
+            isPacking = 1;
+            count = 1;
+        } else {
+            int diff = nd->first[index] - nd->last[index - 1];
+            if (diff < 256 && (count - 1) / 2 + 2 < 256) {
+                result[length++] = (uint8_t)(int8_t)(diff - 128);
+                diff = nd->last[index] - nd->first[index];
+                result[length++] = (uint8_t)(int8_t)(diff - 128);
+                count += 2;
+            } else {
+                result[length - count - 1] = (uint8_t)(int8_t)((count - 1) / 2 - 128);
+                isPacking = 0;
+                continue;
+            }
+        }
+        index++;
+    }
+    if (isPacking) result[length - count - 1] = (uint8_t)(int8_t)((count - 1) / 2 - 128);
+    return length;
+}
+
+typedef struct {
+    uint64_t asc; /* Double.compareTo order as an unsigned key */
+    int64_t seq;
+} kvo_keyed;
+
+static uint64_t compare_to_bits(double v) { /* monotone in Double.compareTo: -0.0 < 0.0, NaN (canonical) above +Inf */
+    uint64_t u;
+    if (v != v) u = 0x7ff8000000000000ULL;
+    else memcpy(&u, &v, 8);
+    return (u >> 63) ? ~u : (u | 0x8000000000000000ULL);
+}
+
+static int keyed_cmp(const void *a, const void *b) {
+    const kvo_keyed *x = (const kvo_keyed *)a, *y = (const kvo_keyed *)b;
+    if (x->asc != y->asc) return x->asc < y->asc ? -1 : 1;
+    return x->seq < y->seq ? -1 : (x->seq > y->seq ? 1 : 0);
+}
+
+/* IndexBuilder.run for one window length `w` (Wu), whole: step 1 (kvo_index_rows), the rows, step 2, and the bytes
+ * IndexFileOperator.writeAll puts into files/index-{N}-{Wu}.  Returns the file length (also when > cap: then nothing is
+ * written), or KVO_ERR_ILLEGAL_ARGUMENT when there is no window at all (the Java code runs into
+ * rawStatisticInfo.get(0) on an empty list, :321).  info (optional, 4 int64): rows before step 2, rows after, intervals
+ * before, intervals after. */
+int64_t kvo_index_file(const double *series, int64_t n, int32_t w, uint8_t *out, int64_t cap, int64_t *info) {
+    int64_t pos_cap = n - w + 1;
+    if (w < 1 || w > 100000 || pos_cap < 1) return KVO_ERR_ILLEGAL_ARGUMENT;
+    double *keys = (double *)malloc((size_t)pos_cap * sizeof(double));
+    int32_t *first = (int32_t *)malloc((size_t)pos_cap * sizeof(int32_t));
+    int32_t *last = (int32_t *)malloc((size_t)pos_cap * sizeof(int32_t));
+    const int64_t cnt = kvo_index_rows(series, n, w, keys, first, last, pos_cap, NULL);
+    /* the HashMap<Double, IndexNode> of :192: one node per distinct key, intervals in the order they were appended */
+    kvo_keyed *kd = (kvo_keyed *)malloc((size_t)cnt * sizeof(kvo_keyed));
+    for (int64_t i = 0; i < cnt; i++) {
+        kd[i].asc = compare_to_bits(keys[i]);
+        kd[i].seq = i;
+    }
+    qsort(kd, (size_t)cnt, sizeof(kvo_keyed), keyed_cmp);
+    int64_t nrows = 0;
+    for (int64_t i = 0; i < cnt; i++) nrows += (i == 0 || kd[i].asc != kd[i - 1].asc);
+    kvo_node *rows = (kvo_node *)calloc((size_t)nrows, sizeof(kvo_node)); /* ascending key */
+    double *row_key = (double *)malloc((size_t)nrows * sizeof(double));
+    {
+        int64_t r = -1;
+        for (int64_t i = 0; i < cnt; i++) {
+            if (i == 0 || kd[i].asc != kd[i - 1].asc) row_key[++r] = keys[kd[i].seq];
+            node_push(&rows[r], first[kd[i].seq], last[kd[i].seq]);
+        }
+    }
+    free(kd); free(keys); free(first); free(last);
+    /* step 2 (:308-347).  rawStatisticInfo sorted by DESCENDING key (:318) = rows[nrows-1 .. 0]; StatisticInfo.append /
+     * getAverage (K/statistic/StatisticInfo.java:43-63): a double sum of the sizes over n */
+    double sum = 0;
+    for (int64_t r = 0; r < nrows; r++) sum += (double)rows[r].size;
+    const double average = sum / (double)nrows;
+    /* indexStore (TreeMap, ascending) + statisticInfo (later sorted ascending, stable, keys distinct): collect as
+     * produced (descending), reverse at the end */
+    kvo_node *store = (kvo_node *)calloc((size_t)nrows, sizeof(kvo_node));
+    double *store_key = (double *)malloc((size_t)nrows * sizeof(double));
+    int64_t nstore = 0, iv_before = cnt, iv_after = 0;
+    kvo_node lastn = rows[nrows - 1]; /* indexNodeMap.get(rawStatisticInfo.get(0).getFirst()) */
+    int last_owned = 0;               /* whether lastn is a merged node this function allocated */
+    for (int64_t i = 1; i < nrows; i++) {
+        const kvo_node *current = &rows[nrows - 1 - i];
+        int isMerged = 0;
+        if ((double)current->size < average * 1.2) { /* rawStatisticInfo.get(i).getSecond().getFirst() < average.getAverage() * 1.2 */
+            kvo_node merged = {0};
+            node_merge(&lastn, current, &merged);
+            if ((double)merged.size < (double)(lastn.size + current->size) * 0.8) {
+                if (last_owned) node_free(&lastn);
+                lastn = merged;
+                last_owned = 1;
+                isMerged = 1;
+            } else {
+                node_free(&merged);
+            }
+        }
+        if (!isMerged) {
+            store_key[nstore] = row_key[nrows - 1 - (i - 1)]; /* rawStatisticInfo.get(i - 1).getFirst() */
+            if (last_owned) {
+                store[nstore] = lastn;
+            } else { /* copy: the rows array is freed below */
+                for (int64_t t = 0; t < lastn.size; t++) node_push(&store[nstore], lastn.first[t], lastn.last[t]);
+            }
+            nstore++;
+            lastn = *current;
+            last_owned = 0;
+        }
+    }
+    store_key[nstore] = row_key[0]; /* rawStatisticInfo.get(size - 1).getFirst() */
+    if (last_owned) {
+        store[nstore] = lastn;
+    } else {
+        for (int64_t t = 0; t < lastn.size; t++) node_push(&store[nstore], lastn.first[t], lastn.last[t]);
+    }
+    nstore++;
+    for (int64_t r = 0; r < nrows; r++) node_free(&rows[r]);
+    free(rows); free(row_key);
+    /* file image: rows ascending (store[] is descending), then the triples, then the offsets */
+    int64_t body = 0;
+    for (int64_t r = 0; r < nstore; r++) {
+        body += 8 + 8 * store[r].size; /* upper bound of a line */
+        iv_after += store[r].size;
+    }
+    uint8_t *img = (uint8_t *)malloc((size_t)(body + 16 * nstore + 4 * (nstore + 2) + 64));
+    int32_t *offsets = (int32_t *)malloc((size_t)(nstore + 2) * sizeof(int32_t));
+    int64_t offset = 0, noff = 0;
+    for (int64_t r = nstore - 1; r >= 0; r--) { /* writeIndex (:142-150) */
+        offsets[noff++] = (int32_t)offset;
+        put_be_double(img + offset, store_key[r]);
+        offset += 8;
+        offset += node_to_bytes_compact(&store[r], img + offset);
+    }
+    /* writeStatisticInfo (:152-160) + ByteUtils.listTripleToByteArray: running (int) sums of #intervals and #offsets */
+    offsets[noff++] = (int32_t)offset;
+    int32_t cum_iv = 0, cum_off = 0;
+    for (int64_t r = nstore - 1; r >= 0; r--) {
+        int32_t nofs = 0;
+        for (int64_t t = 0; t < store[r].size; t++) nofs += store[r].last[t] - store[r].first[t] + 1; /* getNumOfOffsets */
+        cum_iv = (int32_t)((uint32_t)cum_iv + (uint32_t)store[r].size);
+        cum_off = (int32_t)((uint32_t)cum_off + (uint32_t)nofs);
+        put_be_double(img + offset, store_key[r]);
+        put_be32(img + offset + 8, cum_iv);
+        put_be32(img + offset + 12, cum_off);
+        offset += 16;
+    }
+    offsets[noff++] = (int32_t)offset; /* writeOffsetInfo (:162-165) */
+    for (int64_t t = 0; t < noff; t++) {
+        put_be32(img + offset, offsets[t]);
+        offset += 4;
+    }
+    if (info) {
+        info[0] = nrows;
+        info[1] = nstore;
+        info[2] = iv_before;
+        info[3] = iv_after;
+    }
+    if (offset <= cap && out) memcpy(out, img, (size_t)offset);
+    for (int64_t r = 0; r < nstore; r++) node_free(&store[r]);
+    free(store); free(store_key); free(img); free(offsets);
+    return offset;
+}
+
 /* ------------------------------------------------------------------------------------------ */
 /* Index-free full scans: the UCR-suite style executors the reference's experiments use as ground truth
  * (K/experiments/NormQueryTestGroupBySelectivity.java:115-126, NormQueryDtwTestGroupBySelectivity.java:116).

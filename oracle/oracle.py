@@ -72,6 +72,8 @@ def load():
     lib.kvo_query_stats.argtypes = [vp, i32, vp, vp]
     lib.kvo_cnsm_dtw_order.restype = C.c_int
     lib.kvo_cnsm_dtw_order.argtypes = [vp, i32, vp]
+    lib.kvo_index_file.restype = i64
+    lib.kvo_index_file.argtypes = [vp, i64, i32, vp, i64, vp]
     lib.kvo_set_lenient_sort.restype = None
     lib.kvo_set_lenient_sort.argtypes = [C.c_int]
     lib.kvo_sort_answers.restype = None
@@ -305,3 +307,17 @@ def index_rows_grouped(series, w):
     b2 = k2.view(np.uint64)
     starts = np.concatenate(([0], np.nonzero(b2[1:] != b2[:-1])[0] + 1)) if len(b2) else np.zeros(0, dtype=np.int64)
     return k2, f2, l2, k2[starts], np.concatenate((starts, [len(k2)])).astype(np.int32)
+
+
+def index_file(series, w):
+    """IndexBuilder.run for one window length, whole (K/IndexBuilder.java:186-347), as the bytes
+    IndexFileOperator.writeAll puts into files/index-{N}-{Wu}; also (rows before step 2, rows after, intervals before,
+    intervals after)."""
+    s = np.ascontiguousarray(series, dtype=np.float64)
+    info = np.zeros(4, dtype=np.int64)
+    size = load().kvo_index_file(s.ctypes.data, s.size, int(w), None, 0, info.ctypes.data)
+    if size < 0:
+        raise OracleError(int(size))
+    out = np.empty(size, dtype=np.uint8)
+    load().kvo_index_file(s.ctypes.data, s.size, int(w), out.ctypes.data, size, info.ctypes.data)
+    return out.tobytes(), info.tolist()

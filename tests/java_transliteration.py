@@ -876,3 +876,269 @@ def java_arrays_sort(a, c):
             break
     ts.merge_force_collapse()
     return a
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Index build: IndexBuilder.SingleIndexBuilder.run (K/IndexBuilder.java:186-347), IndexNodeUtils.mergeIndexNode /
+# addInterval (K/utils/IndexNodeUtils.java:30-90), IndexNode.toBytesCompact / getStatisticInfoPair
+# (K/common/entity/IndexNode.java:61-100, :145-158), MeanIntervalUtils.toRound (K/utils/MeanIntervalUtils.java:50-60),
+# ByteUtils.listTripleToByteArray / listIntToByteArray (K/utils/ByteUtils.java), IndexFileOperator.writeAll
+# (K/operator/file/IndexFileOperator.java:127-165).  Returns the bytes of files/index-{N}-{Wu}.
+import struct
+
+MAXIMUM_DIFF = 256  # IndexNode.MAXIMUM_DIFF
+
+
+def _double_key(v):
+    """what HashMap<Double, .> / Double.equals distinguish: doubleToLongBits (one NaN, 0.0 != -0.0)"""
+    return struct.pack(">d", float("nan") if v != v else v)
+
+
+def _compare_to(a, b):
+    return _java_double_compare(a, b)
+
+
+def to_round(value):
+    value *= math.pow(10, 2 - 1)
+    int_value = math.floor(value) if value == value and abs(value) != float("inf") else value
+    diff = value - int_value
+    ret = float(int_value)
+    if _java_double_compare(diff, 0.5) >= 0:
+        ret += 0.5
+    ret *= math.pow(10, -2 + 1)
+    return ret
+
+
+def _add_interval(node, position):
+    while position[1] - position[0] >= MAXIMUM_DIFF:
+        new_first = position[0] + MAXIMUM_DIFF - 1
+        node.append([position[0], new_first])
+        position[0] = new_first + 1
+    node.append(position)
+
+
+def merge_index_node(node1, node2):
+    ret = []
+    index1 = index2 = 0
+    last1 = last2 = None
+    while index1 < len(node1) and index2 < len(node2):
+        position1, position2 = node1[index1], node2[index2]
+        if last1 is None:
+            last1 = [position1[0], position1[1]]
+        if last2 is None:
+            last2 = [position2[0], position2[1]]
+        if last1[1] + 1 < last2[0]:
+            _add_interval(ret, last1)
+            index1 += 1
+            last1 = None
+        elif last2[1] + 1 < last1[0]:
+            _add_interval(ret, last2)
+            index2 += 1
+            last2 = None
+        else:
+            if last1[1] < last2[1]:
+                if last1[0] < last2[0]:
+                    last2[0] = last1[0]
+                index1 += 1
+                last1 = None
+            else:
+                if last2[0] < last1[0]:
+                    last1[0] = last2[0]
+                index2 += 1
+                last2 = None
+    for i in range(index1, len(node1)):
+        if last1 is None:
+            last1 = [node1[i][0], node1[i][1]]
+        _add_interval(ret, last1)
+        last1 = None
+    for i in range(index2, len(node2)):
+        if last2 is None:
+            last2 = [node2[i][0], node2[i][1]]
+        _add_interval(ret, last2)
+        last2 = None
+    return ret
+
+
+def _java_byte(v):
+    """(byte) of an int"""
+    return v & 0xFF
+
+
+def to_bytes_compact(positions):
+    result = bytearray(4 * len(positions) * 2)
+    index = length = count = 0
+    is_packing = False
+    while index < len(positions):
+        if not is_packing:
+            result[length: length + 4] = struct.pack(">i", positions[index][0])
+            length += 4 + 1
+            diff = positions[index][1] - positions[index][0]
+            result[length] = _java_byte(diff - 128)
+            length += 1
+            is_packing = True
+            count = 1
+        else:
+            diff = positions[index][0] - positions[index - 1][1]
+            if diff < MAXIMUM_DIFF and (count - 1) // 2 + 2 < MAXIMUM_DIFF:
+                result[length] = _java_byte(diff - 128)
+                length += 1
+                diff = positions[index][1] - positions[index][0]
+                result[length] = _java_byte(diff - 128)
+                length += 1
+                count += 2
+            else:
+                result[length - count - 1] = _java_byte((count - 1) // 2 - 128)
+                is_packing = False
+                continue
+        index += 1
+    if is_packing:
+        result[length - count - 1] = _java_byte((count - 1) // 2 - 128)
+    return bytes(result[:length])
+
+
+def parse_bytes_compact(data):
+    """IndexNode.parseBytesCompact (K/common/entity/IndexNode.java:115-133)"""
+    positions = []
+    index = 0
+
+    def sbyte(b):
+        return b - 256 if b >= 128 else b
+    while index < len(data):
+        left = struct.unpack(">i", data[index: index + 4])[0]
+        index += 4
+        count = sbyte(data[index]) + 128
+        index += 1
+        right = left + sbyte(data[index]) + 128
+        index += 1
+        positions.append((left, right))
+        for _ in range(count):
+            left = right + sbyte(data[index]) + 128
+            index += 1
+            right = left + sbyte(data[index]) + 128
+            index += 1
+            positions.append((left, right))
+    return positions
+
+
+def index_build_file(series, w, epoch=100000):
+    n = len(series)
+    it = 0
+    done = False
+    nxt = 0                         # the scanner: nextData() / getCurrentData()
+    buffer = [0.0] * epoch
+    t = [0.0] * (2 * w)
+    last_mean_round = None
+    index_node = None
+    index_node_map = {}             # HashMap<Double, IndexNode>: key bits -> (key, positions)
+    while not done:
+        if it == 0:
+            for k in range(w - 1):
+                if nxt < n:
+                    buffer[k] = series[nxt]
+                    nxt += 1
+        else:
+            for k in range(w - 1):
+                buffer[k] = buffer[epoch - w + 1 + k]
+        ep = w - 1
+        while ep < epoch:
+            if nxt < n:
+                buffer[ep] = series[nxt]
+                nxt += 1
+                ep += 1
+            else:
+                break
+        if ep <= w - 1:
+            done = True
+        else:
+            ex = ex2 = 0.0
+            for i in range(ep):
+                d = buffer[i]
+                ex += d
+                ex2 += d * d
+                t[i % w] = d
+                t[(i % w) + w] = d
+                if i >= w - 1:
+                    mean = _div(ex, w)
+                    j = (i + 1) % w
+                    loc = it * (epoch - w + 1) + i - w + 1 + 1
+                    if loc > n:
+                        done = True
+                        break
+                    cur_mean_round = to_round(mean)
+                    if last_mean_round is None or _double_key(last_mean_round) != _double_key(cur_mean_round) \
+                            or loc - index_node[-1][0] == MAXIMUM_DIFF - 1:
+                        if last_mean_round is not None:
+                            index_node_map[_double_key(last_mean_round)] = (last_mean_round, index_node)
+                        got = index_node_map.get(_double_key(cur_mean_round))
+                        index_node = got[1] if got is not None else []
+                        index_node.append([loc, loc])
+                        last_mean_round = cur_mean_round
+                    else:
+                        index_node[-1][1] = loc
+                    ex -= t[j]
+                    ex2 -= t[j] * t[j]
+            if ep < epoch:
+                done = True
+            else:
+                it += 1
+    if index_node is not None and len(index_node) > 0:
+        index_node_map[_double_key(last_mean_round)] = (last_mean_round, index_node)
+    # step 2
+    raw = []
+    total = 0.0
+    for key, node in index_node_map.values():
+        raw.append((key, len(node)))
+        total += len(node)
+    average = total / len(raw)                        # StatisticInfo.getAverage (ints sum exactly)
+    raw.sort(key=functools.cmp_to_key(lambda o1, o2: -_compare_to(o1[0], o2[0])))
+    index_store = []                                  # TreeMap<Double, IndexNode>, filled below, sorted at the end
+    statistic_info = []
+    last = index_node_map[_double_key(raw[0][0])][1]
+    for i in range(1, len(raw)):
+        current = index_node_map[_double_key(raw[i][0])][1]
+        is_merged = False
+        if raw[i][1] < average * 1.2:
+            merged = merge_index_node(last, current)
+            if len(merged) < (len(last) + len(current)) * 0.8:
+                last = merged
+                is_merged = True
+        if not is_merged:
+            key = raw[i - 1][0]
+            index_store.append((key, last))
+            statistic_info.append([key, len(last), sum(p[1] - p[0] + 1 for p in last)])
+            last = current
+    key = raw[-1][0]
+    index_store.append((key, last))
+    statistic_info.append([key, len(last), sum(p[1] - p[0] + 1 for p in last)])
+    index_store.sort(key=functools.cmp_to_key(lambda a, b: _compare_to(a[0], b[0])))
+    # IndexFileOperator.writeAll
+    out = bytearray()
+    offsets = []
+    for key, node in index_store:
+        offsets.append(len(out))
+        out += struct.pack(">d", key) + to_bytes_compact(node)
+    offsets.append(len(out))
+    statistic_info.sort(key=functools.cmp_to_key(lambda a, b: _java_double_compare(a[0], b[0])))
+    for i in range(1, len(statistic_info)):
+        statistic_info[i][1] += statistic_info[i - 1][1]
+        statistic_info[i][2] += statistic_info[i - 1][2]
+    for key, a, b in statistic_info:
+        out += struct.pack(">dii", key, a, b)
+    offsets.append(len(out))
+    for o in offsets:
+        out += struct.pack(">i", o)
+    return bytes(out), dict(rows_before=len(raw), rows_after=len(index_store))
+
+
+def read_index_file(data):
+    """IndexFileOperator.readOffsetInfo / readIndexes(all) / readStatisticInfo on an in-memory image:
+    (rows = [(key, positions)], statistic triples, offsets)."""
+    last_line_offset = struct.unpack(">i", data[-4:])[0]
+    offsets = list(struct.unpack(">%di" % ((len(data) - last_line_offset) // 4), data[last_line_offset:]))
+    rows = []
+    for i in range(len(offsets) - 2):
+        line = data[offsets[i]: offsets[i + 1]]
+        rows.append((struct.unpack(">d", line[:8])[0], parse_bytes_compact(line[8:])))
+    st = data[offsets[-2]: offsets[-1]]
+    triples = [struct.unpack(">dii", st[k: k + 16]) for k in range(0, len(st), 16)]
+    return rows, triples, offsets

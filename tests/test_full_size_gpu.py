@@ -90,3 +90,29 @@ def test_dtw_config_4(big):
     want = oracle.rsm_dtw(series, q, L, R, 0, 6.0, rho)
     got = kvmatch.QueryEngineDtw(ctx).verify((L, R), 1, q, 6.0, 0.05)
     assert same(got, want) and qoff in set(want[0].tolist())
+
+
+def test_index_build_n_1e8_equals_the_oracle(big):
+    """The whole index build for one window length over the n = 1e8 series: the file image equals the oracle's byte for
+    byte (5.5e7 step-1 intervals in 1.5e5 rows, merged by step 2, ~1e8 bytes), and its statistic block accounts for every
+    window position."""
+    import struct
+    import time
+    kvmatch, datagen, series, ctx, q, qoff, planted = big
+    w = 50
+    t0 = time.perf_counter()
+    got, info = ctx.index_build(w)
+    t_lib = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    want, winfo = oracle.index_file(series, w)
+    t_cpu = (time.perf_counter() - t0) / 2          # (oracle.index_file runs the C function twice: size, then fill)
+    assert len(got) == len(want) and got == want
+    assert [info[k] for k in ("rows_before", "rows_after", "intervals_before", "intervals_after")] == winfo
+    last_line = struct.unpack(">i", got[-4:])[0]
+    offsets = struct.unpack(">%di" % ((len(got) - last_line) // 4), got[last_line:])
+    assert len(offsets) == info["rows_after"] + 2
+    key, cum_iv, cum_off = struct.unpack(">dii", got[offsets[-1] - 16: offsets[-1]])
+    assert cum_iv == info["intervals_after"] and cum_off == N - w + 1
+    print(f"index build n=1e8 w={w}: library {t_lib:.2f} s (step 1 {info['step1_ms']:.0f} ms, step 2 {info['step2_ms']:.0f} ms, "
+          f"encode {info['encode_ms']:.0f} ms), oracle on one core {t_cpu:.1f} s, {len(got)} bytes, "
+          f"{info['rows_before']} -> {info['rows_after']} rows")
