@@ -36,6 +36,10 @@ public final class Phase2Gpu implements AutoCloseable {
     public static native long indexRowsCount(long rows);
     public static native void indexRowsGet(long rows, long from, double[] keys, int[] first, int[] last);
     public static native void indexRowsFree(long rows);
+    /** The bytes IndexBuilder.SingleIndexBuilder.run + IndexFileOperator.writeAll produce for window length w. */
+    public static native byte[] indexBuild(long ctx, int w);
+    /** kvm_set_option; option 6 (KVM_OPT_SORT_VIOLATION) = 1: answer cNSM-DTW queries on which Arrays.sort throws. */
+    public static native void setOption(long ctx, int option, long value);
     private static native long open(int device) throws IOException;
     private static native void loadSeriesFile(long ctx, String path, long n) throws IOException;
     private static native void close(long ctx);

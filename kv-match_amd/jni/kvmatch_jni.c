@@ -239,6 +239,27 @@ JNIEXPORT void JNICALL Java_cn_edu_fudan_dsm_kvmatch_gpu_Phase2Gpu_indexRowsFree
     (void)env; (void)c;
     kvm_index_rows_free((kvm_index_rows *)(intptr_t)rows);
 }
+/* IndexBuilder.SingleIndexBuilder.run + IndexFileOperator.writeAll for one window length (K/IndexBuilder.java:186-347,
+ * K/operator/file/IndexFileOperator.java:127-165): the bytes of files/index-{N}-{Wu} */
+JNIEXPORT jbyteArray JNICALL Java_cn_edu_fudan_dsm_kvmatch_gpu_Phase2Gpu_indexBuild(JNIEnv *env, jclass c, jlong h, jint w) {
+    (void)c;
+    kvm_ctx *ctx = (kvm_ctx *)(intptr_t)h;
+    kvm_index_file *f = 0;
+    int rc = kvm_index_build(ctx, w, &f);
+    if (rc) { throw_for(env, ctx, rc); return 0; }
+    const jsize size = (jsize)kvm_index_file_size(f);      /* < 2^31: kvm_index_build refuses longer images */
+    jbyteArray out = (*env)->NewByteArray(env, size);
+    if (out) (*env)->SetByteArrayRegion(env, out, 0, size, (const jbyte *)kvm_index_file_bytes(f));
+    kvm_index_file_free(f);
+    return out;
+}
+/* kvm_set_option, e.g. KVM_OPT_SORT_VIOLATION (6) */
+JNIEXPORT void JNICALL Java_cn_edu_fudan_dsm_kvmatch_gpu_Phase2Gpu_setOption(JNIEnv *env, jclass c, jlong h, jint option, jlong value) {
+    (void)c;
+    kvm_ctx *ctx = (kvm_ctx *)(intptr_t)h;
+    int rc = kvm_set_option(ctx, option, value);
+    if (rc) throw_for(env, ctx, rc);
+}
 #else
 /* no <jni.h> in this toolchain: nothing to build */
 typedef int kvm_jni_not_built;

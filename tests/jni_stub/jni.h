@@ -9,6 +9,7 @@
 typedef int32_t jint;
 typedef int64_t jlong;
 typedef double jdouble;
+typedef signed char jbyte;
 typedef uint8_t jboolean;
 typedef jint jsize;
 
@@ -20,6 +21,7 @@ typedef jobject jthrowable;
 typedef jobject jarray;
 typedef jarray jintArray;
 typedef jarray jdoubleArray;
+typedef jarray jbyteArray;
 struct _jfieldID;
 typedef struct _jfieldID *jfieldID;
 
@@ -43,9 +45,11 @@ struct JNINativeInterface_ {
     jsize (JNICALL *GetArrayLength)(JNIEnv *env, jarray array);
     jintArray (JNICALL *NewIntArray)(JNIEnv *env, jsize len);
     jdoubleArray (JNICALL *NewDoubleArray)(JNIEnv *env, jsize len);
+    jbyteArray (JNICALL *NewByteArray)(JNIEnv *env, jsize len);
     void (JNICALL *GetIntArrayRegion)(JNIEnv *env, jintArray array, jsize start, jsize l, jint *buf);
     void (JNICALL *GetDoubleArrayRegion)(JNIEnv *env, jdoubleArray array, jsize start, jsize l, jdouble *buf);
     void (JNICALL *SetIntArrayRegion)(JNIEnv *env, jintArray array, jsize start, jsize l, const jint *buf);
     void (JNICALL *SetDoubleArrayRegion)(JNIEnv *env, jdoubleArray array, jsize start, jsize l, const jdouble *buf);
+    void (JNICALL *SetByteArrayRegion)(JNIEnv *env, jbyteArray array, jsize start, jsize l, const jbyte *buf);
 };
 #endif

@@ -115,7 +115,7 @@ def test_jni_shim_type_checks_and_signatures_match_the_java_natives():
     java = open(os.path.join(root, "kv-match_amd", "java", "cn", "edu", "fudan", "dsm", "kvmatch", "gpu", "Phase2Gpu.java")).read()
     java = re.sub(r"/\*.*?\*/|//[^\n]*", "", java, flags=re.S)
     jmap = {"int": "jint", "long": "jlong", "double": "jdouble", "void": "void", "String": "jstring", "int[]": "jintArray",
-            "double[]": "jdoubleArray", "Result": "jobject"}
+            "double[]": "jdoubleArray", "byte[]": "jbyteArray", "Result": "jobject"}
     natives = {}
     for mods, ret, name, params in re.findall(r"((?:public|private|static|final|\s)*)\bnative\s+([\w\[\]]+)\s+(\w+)\s*\(([^)]*)\)", java):
         ptypes = [jmap[" ".join(p.split()[:-1]).replace(" ", "")] for p in params.split(",") if p.strip()]
