@@ -239,6 +239,13 @@ def main():
                   (2, kvmatch.QueryEngineDtw, (0.05,), dict(rho=0.05)),
                   (3, kvmatch.NormQueryEngineDtw, (0.05, 2.0, 10.0), dict(rho=0.05, alpha=2.0, beta=10.0))],
     }[wl]
+    if any(v == 3 for v, _, _, _ in plans):
+        # cNSM-DTW sorts the query the way the reference does; where that sort throws the reference
+        # cannot answer the query at all, so such a query is not a benchmark input: say so instead of failing mid-run
+        try:
+            kvmatch.cnsm_dtw_order(q)
+        except kvmatch.KvMatchIllegalArgument as e:
+            raise SystemExit(f"bench: the reference's Arrays.sort throws on this query ({e}); pick another --n / workload")
     engines = [cls(ctx) for _, cls, _, _ in plans]
     eng = engines[0]
     lib, h = ctx._lib, ctx._h

@@ -342,6 +342,8 @@ struct sorter {
                 binary_sort(lo, lo + force, lo + len);
                 len = force;
             }
+            if (stack == 64) return false;  // (cannot happen below 2^31 elements: the depth is logarithmic; Java's own
+                                            //  stack holds 49 entries and would throw ArrayIndexOutOfBoundsException)
             run_base[stack] = lo;
             run_len[stack] = len;
             stack++;

@@ -80,6 +80,20 @@ public:
         }
         kvm_index_rows_free(r);
     }
+    // IndexBuilder.SingleIndexBuilder.run + IndexFileOperator.writeAll for window length w (K/IndexBuilder.java:186-347,
+    // K/operator/file/IndexFileOperator.java:127-165): the bytes of files/index-{N}-{Wu}; `path` non-empty also writes them
+    std::vector<uint8_t> indexBuild(int32_t w, const std::string &path = std::string()) {
+        kvm_index_file *f = nullptr;
+        check(kvm_index_build(ctx_, w, &f), ctx_);
+        const uint8_t *p = kvm_index_file_bytes(f);
+        std::vector<uint8_t> image(p, p + kvm_index_file_size(f));
+        const int rc = path.empty() ? KVM_OK : kvm_index_file_write(f, path.c_str());
+        kvm_index_file_free(f);
+        if (rc) throw IOException("cannot write " + path);
+        return image;
+    }
+    void setOption(int32_t option, int64_t value) { check(kvm_set_option(ctx_, option, value), ctx_); }
+    int64_t seriesLength() const { return kvm_series_length(ctx_); }
     kvm_ctx *handle() const { return ctx_; }
 
     static void check(int rc, const kvm_ctx *ctx) {
@@ -253,6 +267,34 @@ private:
     double eps_;
     int32_t rho_;
     double alpha_, beta_;
+};
+
+// K/IndexBuilder.java for the "file" storage type: buildIndexes() writes files/index-{n}-{Wu} for the enabled window
+// lengths (WuList / WuEnabled, :52-53); a window length the series is too short for is skipped (the reference's loop logs
+// the exception and carries on, :108-110).
+class IndexBuilder {
+public:
+    IndexBuilder(Phase2Context &ctx, int64_t n) : ctx_(ctx), n_(n) {
+        if (n != ctx.seriesLength()) throw IllegalArgumentException("n differs from the length of the staged series");
+    }
+    std::vector<int> buildIndexes(const std::string &directory = "files") {
+        static const int WuList[] = {25, 50, 75, 100, 125, 150, 175, 200, 225, 250, 275, 300, 325, 350, 375, 400};
+        static const bool WuEnabled[] = {true, true, false, true, false, false, false, true, false, false, false, false, false, false, false, true};
+        std::vector<int> done;
+        for (size_t i = 0; i < sizeof WuList / sizeof WuList[0]; i++) {
+            if (!WuEnabled[i]) continue;
+            try {
+                ctx_.indexBuild(WuList[i], directory + "/index-" + std::to_string(n_) + "-" + std::to_string(WuList[i]));
+                done.push_back(WuList[i]);
+            } catch (const IllegalArgumentException &) {
+            }
+        }
+        return done;
+    }
+
+private:
+    Phase2Context &ctx_;
+    int64_t n_;
 };
 
 }  // namespace kvmatch

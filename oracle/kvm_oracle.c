@@ -880,6 +880,10 @@ static int kvo_java_timsort(kvo_index *a, int n, index_cmp c) {
             ts_binary_sort(a, lo, lo + force, lo + runLen, c);
             runLen = force;
         }
+        if (ts.stackSize == 64) { /* unreachable below 2^31 elements; Java's stack (49 entries) would overflow first */
+            rc = -1;
+            break;
+        }
         ts.runBase[ts.stackSize] = lo;
         ts.runLen[ts.stackSize] = runLen;
         ts.stackSize++;

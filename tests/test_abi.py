@@ -137,3 +137,56 @@ def test_cpp_host_mirror_compiles():
     r = subprocess.run(["g++", "-std=c++17", "-Wall", "-Werror", "-fsyntax-only", "-I", os.path.join(root, "include"),
                         os.path.join(root, "kv-match_amd", "host", "kvm_cli.cpp")], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+
+def test_index_file_host_code_on_cpu_under_sanitizers(built, tmp_path):
+    """The library's host-side index code (kvm_index_file.cpp: step 2, IndexNode.toBytesCompact, the file layout) compiled
+    with AddressSanitizer + UBSan and fed the oracle's step-1 rows instead of the GPU's (tests/harness/): the image equals
+    the oracle's kvo_index_file byte for byte, on CPU."""
+    import subprocess
+    import numpy as np
+    import oracle
+    from test_transliteration import _index_series
+    exe = tmp_path / "index_file_harness"
+    src = [os.path.join(ROOT, "tests", "harness", "index_file_harness.cpp"),
+           os.path.join(ROOT, "kv-match_amd", "csrc", "kvm_index_file.cpp")]
+    r = subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-Wall", "-Werror", "-fsanitize=address,undefined",
+                        "-fno-sanitize-recover=all", "-o", str(exe)] + src, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    rng = np.random.default_rng(17)
+    for trial in range(10):
+        n = int(rng.integers(300, 40_000)) if trial < 8 else 260_000
+        w = int(rng.choice([25, 50, 100, 200, 400]))
+        s = _index_series(rng, trial % 5, n)
+        keys, first, last, gk, go = oracle.index_rows_grouped(s, w)
+        rows = tmp_path / "rows.bin"
+        with open(rows, "wb") as f:
+            f.write(np.array([len(keys), len(gk)], dtype=np.int64).tobytes())
+            for arr, dt in ((keys, np.float64), (first, np.int32), (last, np.int32), (gk, np.float64), (go, np.int32)):
+                f.write(np.ascontiguousarray(arr, dtype=dt).tobytes())
+        out = tmp_path / "image.out"
+        r = subprocess.run([str(exe), str(rows), str(out)], capture_output=True, text=True,
+                           env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1"))
+        assert r.returncode == 0, (trial, r.stderr[-2000:])
+        want, info = oracle.index_file(s, w)
+        assert out.read_bytes() == want, (trial, n, w)
+        assert [int(x) for x in r.stdout.split()] == info
+    # no rows at all -> the IllegalArgument path (the Java code dies on rawStatisticInfo.get(0))
+    with open(rows, "wb") as f:
+        f.write(np.array([0, 0], dtype=np.int64).tobytes() + np.zeros(1, dtype=np.int32).tobytes())
+    assert subprocess.run([str(exe), str(rows), str(out)], capture_output=True).returncode == 3
+
+
+def test_timsort_restatement_is_memory_safe_under_any_comparator(tmp_path):
+    """kvm_jsort.h under AddressSanitizer + UBSan with comparators that obey nothing (tests/harness/fuzz_jsort.cpp): in a
+    JVM a broken comparator ends in an exception at worst; the C++ restatement must not touch memory out of bounds either."""
+    import subprocess
+    exe = tmp_path / "fuzz_jsort"
+    r = subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-Wall", "-Werror", "-fsanitize=address,undefined",
+                        "-fno-sanitize-recover=all", "-o", str(exe), os.path.join(ROOT, "tests", "harness", "fuzz_jsort.cpp")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr[-2000:]
+    ok, thrown = int(r.stdout.split()[1]), int(r.stdout.split()[3])
+    assert ok > 500 and thrown > 500
