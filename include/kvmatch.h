@@ -212,6 +212,15 @@ int kvm_verify_cnsm_dtw(kvm_ctx *ctx, const double *query, int32_t m, const int3
 /* `r <= 1 -> floor(r*m) else floor(r)`  (K/QueryEngineDtw.java:135-140). */
 int32_t kvm_resolve_rho(double r, int32_t m);
 
+/* sortAndMergeIntervals (K/QueryEngine.java:664-693; the same method in the other three engines): what every engine
+ * applies to phase 1's `validPositions` right before phase 2 -- sort by `left` (stable), then join every interval whose
+ * left - 1 <= the running end.  The verify entry points expect their list in this form (sorted, disjoint, non-adjacent).
+ * Host only (no GPU call).  In: k intervals in any order; out_left/out_right: room for k entries (may alias the inputs
+ * only if they are the same arrays as left/right).  Returns the number of merged intervals (k <= 1: the list as it is),
+ * or KVM_ERR_ILLEGAL_ARGUMENT.  Interval.epsilon (min over the joined intervals) is not read by phase 2 and not carried. */
+int64_t kvm_sort_and_merge_intervals(const int32_t *left, const int32_t *right, int64_t k, int32_t *out_left,
+                                     int32_t *out_right);
+
 /* The permutation cNSM-DTW sums its LB_Keogh bounds in: order[i] = index of the i-th element of tmpQ after
  * `Arrays.sort(tmpQ, (o1, o2) -> (int) (Math.abs(o2.value) - Math.abs(o1.value)))` on the z-normalised query
  * (K/NormQueryEngineDtw.java:470-484), as JDK 8's TimSort leaves it.  Host only (no GPU call); `query` is the raw

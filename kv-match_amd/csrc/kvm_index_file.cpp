@@ -282,3 +282,34 @@ extern "C" int kvm_index_file_write(const kvm_index_file *f, const char *path) {
     return (std::fclose(fp) == 0 && ok) ? KVM_OK : KVM_ERR_IO;
 }
 extern "C" void kvm_index_file_free(kvm_index_file *f) { delete f; }
+
+// ---- sortAndMergeIntervals (K/QueryEngine.java:664-693): the step between phase 1 and phase 2 -------------------------
+extern "C" int64_t kvm_sort_and_merge_intervals(const int32_t *left, const int32_t *right, int64_t k, int32_t *out_left,
+                                                int32_t *out_right) {
+    if (k < 0 || (k > 0 && (!left || !right || !out_left || !out_right))) return KVM_ERR_ILLEGAL_ARGUMENT;
+    std::vector<ival> v((size_t)k);
+    for (int64_t i = 0; i < k; i++) v[(size_t)i] = ival{left[i], right[i]};
+    if (k > 1) {
+        // intervals.sort(Comparator.comparingInt(Interval::getLeft)): List.sort is stable
+        std::stable_sort(v.begin(), v.end(), [](const ival &a, const ival &b) { return a.first < b.first; });
+        int64_t o = 0;
+        int32_t start = v[0].first, end = v[0].last;
+        for (int64_t i = 1; i < k; i++) {
+            const ival c = v[(size_t)i];
+            if ((int64_t)c.first - 1 <= end) {
+                end = std::max(c.last, end);
+            } else {
+                v[(size_t)o++] = ival{start, end};
+                start = c.first;
+                end = c.last;
+            }
+        }
+        v[(size_t)o++] = ival{start, end};
+        k = o;
+    }
+    for (int64_t i = 0; i < k; i++) {
+        out_left[i] = v[(size_t)i].first;
+        out_right[i] = v[(size_t)i].last;
+    }
+    return k;
+}

@@ -6,5 +6,5 @@ from ._lib import (KvMatchDeviceError, KvMatchIllegalArgument, KvMatchIOError, L
                    STAT_DTW_SEQUENTIAL, STAT_PASS_LB_KEOGH2, STAT_PASS_LB_KIM, STAT_RECHECKED, STAT_WINDOWS)
 from .engine import phase2_time_estimate_ms  # noqa
 from .engine import (Answers, IndexBuilder, NormQueryEngine, NormQueryEngineDtw, Phase2Context, QueryEngine, QueryEngineDtw,  # noqa
-                     QueryStream, StatisticInfo, cnsm_dtw_order, resolve_rho)
+                     QueryStream, StatisticInfo, cnsm_dtw_order, resolve_rho, sort_and_merge_intervals)
 from .ucr import UcrDtwQueryExecutor, UcrEdQueryExecutor  # noqa

@@ -32,7 +32,7 @@ SYMBOLS = [
     "kvm_index_rows_group_offsets", "kvm_index_build", "kvm_index_file_size", "kvm_index_file_bytes", "kvm_index_file_info",
     "kvm_index_file_write", "kvm_index_file_free", "kvm_phase2_time_estimate_ms",
     "kvm_verify_rsm_ed", "kvm_verify_cnsm_ed", "kvm_verify_rsm_dtw", "kvm_verify_cnsm_dtw", "kvm_resolve_rho",
-    "kvm_cnsm_dtw_order",
+    "kvm_cnsm_dtw_order", "kvm_sort_and_merge_intervals",
     "kvm_result_count", "kvm_result_candidates", "kvm_result_elapsed_ms", "kvm_result_offsets",
     "kvm_result_distances", "kvm_result_stat", "kvm_result_free",
     "kvm_set_option", "kvm_get_option", "kvm_last_kernel_ns", "kvm_verify_device", "kvm_pack_answers_device",
@@ -110,6 +110,7 @@ def load():
         "kvm_verify_cnsm_dtw": (C.c_int, [vp, vp, i32, vp, vp, i32, i32, f64, i32, f64, f64, C.POINTER(vp)]),
         "kvm_resolve_rho": (i32, [f64, i32]),
         "kvm_cnsm_dtw_order": (C.c_int, [vp, i32, vp]),
+        "kvm_sort_and_merge_intervals": (i64, [vp, vp, i64, vp, vp]),
         "kvm_result_count": (i64, [vp]),
         "kvm_result_candidates": (i64, [vp]),
         "kvm_result_elapsed_ms": (f64, [vp]),

@@ -91,6 +91,17 @@ def resolve_rho(rho, m, resolved=None):
     return int(_lib.load().kvm_resolve_rho(float(rho), int(m)))
 
 
+def sort_and_merge_intervals(valid_positions):
+    """sortAndMergeIntervals (K/QueryEngine.java:664-693): phase 1's `validPositions` in any order -> the sorted, disjoint,
+    non-adjacent (left, right) arrays the verify() methods take.  Host only."""
+    left, right = _as_intervals(valid_positions)
+    ol, orr = np.empty_like(left), np.empty_like(right)
+    k = int(_lib.load().kvm_sort_and_merge_intervals(left.ctypes.data, right.ctypes.data, left.size, ol.ctypes.data, orr.ctypes.data))
+    if k < 0:
+        _lib.check(k, None)
+    return ol[:k].copy(), orr[:k].copy()
+
+
 def cnsm_dtw_order(query):
     """The order NormQueryEngineDtw sums its LB_Keogh bounds in: the permutation JDK 8's Arrays.sort leaves under the
     comparator (int)(|o2| - |o1|) on the z-normalised query (K/NormQueryEngineDtw.java:470-484).  Host only.  Raises

@@ -1142,3 +1142,21 @@ def read_index_file(data):
     st = data[offsets[-2]: offsets[-1]]
     triples = [struct.unpack(">dii", st[k: k + 16]) for k in range(0, len(st), 16)]
     return rows, triples, offsets
+
+
+def sort_and_merge_intervals(intervals):
+    """QueryEngine.sortAndMergeIntervals (K/QueryEngine.java:664-693) on a list of (left, right, epsilon)."""
+    if len(intervals) <= 1:
+        return list(intervals)
+    intervals = sorted(intervals, key=lambda iv: iv[0])           # List.sort(comparingInt(getLeft)): stable
+    start, end, epsilon = intervals[0]
+    result = []
+    for current in intervals[1:]:
+        if current[0] - 1 <= end:
+            end = max(current[1], end)
+            epsilon = min(current[2], epsilon)
+        else:
+            result.append((start, end, epsilon))
+            start, end, epsilon = current
+    result.append((start, end, epsilon))
+    return result

@@ -190,3 +190,22 @@ def test_timsort_restatement_is_memory_safe_under_any_comparator(tmp_path):
     assert r.returncode == 0, r.stdout + r.stderr[-2000:]
     ok, thrown = int(r.stdout.split()[1]), int(r.stdout.split()[3])
     assert ok > 500 and thrown > 500
+
+
+def test_sort_and_merge_intervals_is_the_reference_step_between_the_phases(built):
+    """kvm_sort_and_merge_intervals (host only) == QueryEngine.sortAndMergeIntervals (K/QueryEngine.java:664-693)."""
+    import numpy as np
+    import kvmatch
+    import java_transliteration as J
+    rng = np.random.default_rng(8)
+    for trial in range(300):
+        k = int(rng.integers(0, 60))
+        left = rng.integers(1, 400, k)
+        right = left + rng.integers(0, 30, k)
+        want = J.sort_and_merge_intervals([(int(a), int(b), 1.0) for a, b in zip(left, right)])
+        gl, gr = kvmatch.sort_and_merge_intervals((left, right))
+        assert list(zip(gl.tolist(), gr.tolist())) == [(a, b) for a, b, _ in want], trial
+        if k > 1:     # sorted, disjoint, non-adjacent: the form phase 2 takes
+            assert np.all(gl[1:] > gr[:-1] + 1)
+    gl, gr = kvmatch.sort_and_merge_intervals((np.array([5, 1, 3]), np.array([6, 2, 3])))
+    assert gl.tolist() == [1, 5] and gr.tolist() == [3, 6]        # [1,2] and [3,3] are adjacent and joined; [5,6] stays apart
