@@ -15,13 +15,14 @@
 //            #intervals, running #offsets} (ByteUtils.listTripleToByteArray); the table of line offsets, whose last entry
 //            is its own position (IndexFileOperator.writeAll / readOffsetInfo).  Offsets are Java ints: an image of 2 GiB
 //            or more is refused.
-// The walk is sequential by nature (each decision depends on the row merged so far); the union is first COUNTED and only
-// materialised when it is accepted.
+// The walk is sequential by nature (each decision depends on the row merged so far): one pass per attempted union, read
+// straight from the grouped step-1 arrays; the lines of the file are encoded by a few host threads.
 #include <algorithm>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/kvmatch.h"
@@ -42,15 +43,30 @@ struct ival {
 
 constexpr int32_t MAXIMUM_DIFF = 256;  // IndexNode.MAXIMUM_DIFF
 
+// A row's positions: either a slice of the grouped step-1 arrays or a vector of merged intervals
+struct raw_view {
+    const int32_t *f, *l;
+    int64_t n;
+    int64_t size() const { return n; }
+    ival at(int64_t i) const { return ival{f[i], l[i]}; }
+};
+struct vec_view {
+    const ival *p;
+    int64_t n;
+    int64_t size() const { return n; }
+    ival at(int64_t i) const { return p[i]; }
+};
+
 // IndexNodeUtils.mergeIndexNode; Emit(first, last) receives every interval handed to addInterval
-template <class Emit>
-inline void merge_walk(const ival *n1, int64_t s1, const ival *n2, int64_t s2, Emit emit) {
+template <class N1, class N2, class Emit>
+inline void merge_walk(const N1 &n1, const N2 &n2, Emit emit) {
+    const int64_t s1 = n1.size(), s2 = n2.size();
     int64_t i1 = 0, i2 = 0;
     bool h1 = false, h2 = false;
     ival l1{0, 0}, l2{0, 0};
     while (i1 < s1 && i2 < s2) {
-        if (!h1) { l1 = n1[i1]; h1 = true; }
-        if (!h2) { l2 = n2[i2]; h2 = true; }
+        if (!h1) { l1 = n1.at(i1); h1 = true; }
+        if (!h2) { l2 = n2.at(i2); h2 = true; }
         if (l1.last + 1 < l2.first) {
             emit(l1.first, l1.last);
             i1++;
@@ -70,12 +86,12 @@ inline void merge_walk(const ival *n1, int64_t s1, const ival *n2, int64_t s2, E
         }
     }
     for (int64_t i = i1; i < s1; i++) {
-        if (!h1) l1 = n1[i];
+        if (!h1) l1 = n1.at(i);
         emit(l1.first, l1.last);
         h1 = false;
     }
     for (int64_t i = i2; i < s2; i++) {
-        if (!h2) l2 = n2[i];
+        if (!h2) l2 = n2.at(i);
         emit(l2.first, l2.last);
         h2 = false;
     }
@@ -165,42 +181,48 @@ extern "C" int kvm_index_build(kvm_ctx *ctx, int32_t w, kvm_index_file **out) {
     std::vector<int64_t> stored_off{0};       // row r = stored[stored_off[r], stored_off[r+1])
     std::vector<double> stored_key;
     stored.reserve((size_t)cnt);
-    std::vector<ival> last, cur, merged;
-    auto load = [&](int64_t g, std::vector<ival> &v) {
-        const int64_t b = goff[g], e = goff[g + 1];
-        v.resize((size_t)(e - b));
-        for (int64_t i = b; i < e; i++) v[(size_t)(i - b)] = ival{rf[i], rl[i]};
-    };
+    // `last` is either row g_last as step 1 left it (a view into the grouped arrays) or the union built so far (`acc`)
+    std::vector<ival> acc, merged;
+    bool last_is_raw = true;
+    int64_t g_last = 0;
+    auto raw = [&](int64_t g) { return raw_view{rf + goff[g], rl + goff[g], (int64_t)goff[g + 1] - goff[g]}; };
     auto store = [&](double key) {
-        stored.insert(stored.end(), last.begin(), last.end());
+        if (last_is_raw) {
+            const raw_view v = raw(g_last);
+            for (int64_t i = 0; i < v.n; i++) stored.push_back(v.at(i));
+        } else {
+            stored.insert(stored.end(), acc.begin(), acc.end());
+        }
         stored_off.push_back((int64_t)stored.size());
         stored_key.push_back(key);
     };
-    load(0, last);
     for (int64_t i = 1; i < G; i++) {
-        load(i, cur);
+        const raw_view cur = raw(i);
         bool is_merged = false;
-        if ((double)cur.size() < average * 1.2) {
-            int64_t msize = 0;  // merged.getPositions().size(), counted: addInterval cuts [f, l] into (l - f) / 256 + 1 pieces
-            merge_walk(last.data(), (int64_t)last.size(), cur.data(), (int64_t)cur.size(),
-                       [&](int32_t a, int32_t b) { msize += (b - a) / MAXIMUM_DIFF + 1; });
-            if ((double)msize < (double)(last.size() + cur.size()) * 0.8) {
-                merged.clear();
-                merged.reserve((size_t)msize);
-                merge_walk(last.data(), (int64_t)last.size(), cur.data(), (int64_t)cur.size(), [&](int32_t a, int32_t b) {
-                    while (b - a >= MAXIMUM_DIFF) {  // IndexNodeUtils.addInterval
-                        merged.push_back(ival{a, a + MAXIMUM_DIFF - 1});
-                        a += MAXIMUM_DIFF;
-                    }
-                    merged.push_back(ival{a, b});
-                });
-                last.swap(merged);
+        if ((double)cur.n < average * 1.2) {
+            // the union, built in one pass (IndexNodeUtils.addInterval cuts every piece to <= 256 positions) and kept
+            // only if it is short enough
+            const int64_t last_n = last_is_raw ? raw(g_last).n : (int64_t)acc.size();
+            merged.clear();
+            auto emit = [&](int32_t a, int32_t b) {
+                while (b - a >= MAXIMUM_DIFF) {
+                    merged.push_back(ival{a, a + MAXIMUM_DIFF - 1});
+                    a += MAXIMUM_DIFF;
+                }
+                merged.push_back(ival{a, b});
+            };
+            if (last_is_raw) merge_walk(raw(g_last), cur, emit);
+            else merge_walk(vec_view{acc.data(), (int64_t)acc.size()}, cur, emit);
+            if ((double)merged.size() < (double)(last_n + cur.n) * 0.8) {
+                acc.swap(merged);
+                last_is_raw = false;
                 is_merged = true;
             }
         }
         if (!is_merged) {
             store(gkey[i - 1]);
-            last.swap(cur);
+            last_is_raw = true;
+            g_last = i;
         }
     }
     store(gkey[G - 1]);
@@ -211,23 +233,62 @@ extern "C" int kvm_index_build(kvm_ctx *ctx, int32_t w, kvm_index_file **out) {
     const double t2 = now_ms();
     f->step2_ms = t2 - t1;
 
-    // ---- the file image: TreeMap order = ascending key = the finished rows backwards
+    // ---- the file image: TreeMap order = ascending key = the finished rows backwards.  The lines are independent of
+    // each other: encoded by a few host threads into per-thread buffers (contiguous ranges of lines), then laid end to end.
     std::vector<uint8_t> &img = f->image;
-    img.reserve(stored.size() * 2 + (size_t)R * 32 + 64);
     std::vector<int32_t> offsets;
     offsets.reserve((size_t)R + 2);
     bool too_long = false;
+    {
+        const int nt = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)std::thread::hardware_concurrency(), 8, R / 64 + 1}));
+        std::vector<std::vector<uint8_t>> part((size_t)nt);
+        std::vector<std::vector<int64_t>> line_len((size_t)nt);
+        // balance by intervals: line k (ascending key) is stored row R-1-k
+        std::vector<int64_t> cut((size_t)nt + 1, R);
+        cut[0] = 0;
+        {
+            const int64_t total = (int64_t)stored.size();
+            int64_t seen = 0;
+            int t = 1;
+            for (int64_t k = 0; k < R && t < nt; k++) {
+                seen += stored_off[(size_t)(R - 1 - k) + 1] - stored_off[(size_t)(R - 1 - k)];
+                if (seen >= total * t / nt) cut[(size_t)t++] = k + 1;
+            }
+        }
+        auto work = [&](int t) {
+            std::vector<uint8_t> &out = part[(size_t)t];
+            for (int64_t k = cut[(size_t)t]; k < cut[(size_t)t + 1]; k++) {
+                const int64_t r = R - 1 - k;
+                const size_t at = out.size();
+                out.resize(at + 8);
+                put_be_double(out.data() + at, stored_key[(size_t)r]);
+                encode_compact(stored.data() + stored_off[(size_t)r], stored_off[(size_t)r + 1] - stored_off[(size_t)r], out);
+                line_len[(size_t)t].push_back((int64_t)(out.size() - at));
+            }
+        };
+        std::vector<std::thread> th;
+        for (int t = 1; t < nt; t++) th.emplace_back(work, t);
+        work(0);
+        for (auto &x : th) x.join();
+        size_t total_bytes = 0;
+        for (auto &v : part) total_bytes += v.size();
+        if (total_bytes > 0x7fffffffULL) too_long = true;
+        if (!too_long) {
+            img.reserve(total_bytes + (size_t)R * 20 + 64);
+            for (int t = 0; t < nt; t++) {
+                size_t at = img.size();
+                for (int64_t len : line_len[(size_t)t]) {
+                    offsets.push_back((int32_t)at);
+                    at += (size_t)len;
+                }
+                img.insert(img.end(), part[(size_t)t].begin(), part[(size_t)t].end());
+            }
+        }
+    }
     auto mark = [&]() {
         if (img.size() > 0x7fffffffULL) too_long = true;
         offsets.push_back((int32_t)img.size());
     };
-    for (int64_t r = R - 1; r >= 0 && !too_long; r--) {
-        mark();
-        const size_t at = img.size();
-        img.resize(at + 8);
-        put_be_double(img.data() + at, stored_key[(size_t)r]);
-        encode_compact(stored.data() + stored_off[(size_t)r], stored_off[(size_t)r + 1] - stored_off[(size_t)r], img);
-    }
     mark();
     uint32_t cum_iv = 0, cum_off = 0;  // Java int sums (wrap like them)
     for (int64_t r = R - 1; r >= 0 && !too_long; r--) {

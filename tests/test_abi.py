@@ -151,7 +151,7 @@ def test_index_file_host_code_on_cpu_under_sanitizers(built, tmp_path):
     src = [os.path.join(ROOT, "tests", "harness", "index_file_harness.cpp"),
            os.path.join(ROOT, "kv-match_amd", "csrc", "kvm_index_file.cpp")]
     r = subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-Wall", "-Werror", "-fsanitize=address,undefined",
-                        "-fno-sanitize-recover=all", "-o", str(exe)] + src, capture_output=True, text=True)
+                        "-fno-sanitize-recover=all", "-pthread", "-o", str(exe)] + src, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     rng = np.random.default_rng(17)
     for trial in range(10):
