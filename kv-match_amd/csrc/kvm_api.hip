@@ -549,6 +549,7 @@ struct plan {
     int64_t n_runs = 0;         // built from them on the GPU, kvm_plan_runs_kernel); n_runs = non-empty clipped intervals
     int64_t n_tiles = 0;        // tiles (class A tiles in hybrid mode)
     int64_t n_tiles_b = 0;      // hybrid mode: class B tiles
+    int64_t n_tiles_c = 0;      // hybrid mode: class C tiles
     int64_t cnt_candidate = 0;  // sum(right-left+1) before clipping, K/QueryEngine.java:344
     int64_t windows = 0;        // windows actually evaluated
 };
@@ -557,10 +558,10 @@ struct plan {
 // kvm_plan_interval).  Written as a plain reduction so that the compiler vectorises it; the AVX2 clone is picked at
 // run time (15 675 intervals: 31 us scalar, a few us vectorised).
 struct plan_totals {
-    int64_t cnt_candidate = 0, n_tiles = 0, n_tiles_b = 0, windows = 0, nr = 0, bad_rsm = 0;
+    int64_t cnt_candidate = 0, n_tiles = 0, n_tiles_b = 0, n_tiles_c = 0, windows = 0, nr = 0, bad_rsm = 0;
 };
 #define PLAN_TOTALS_BODY                                                                                        \
-    int64_t cnt = 0, ta = 0, tb = 0, w = 0, nr = 0, bad = 0;                                                    \
+    int64_t cnt = 0, ta = 0, tb = 0, tc = 0, w = 0, nr = 0, bad = 0;                                            \
     for (int32_t p = 0; p < k; p++) {                                                                           \
         const int64_t l = left[p], r = right[p];                                                                \
         cnt += r - l + 1;                                                                                       \
@@ -571,14 +572,18 @@ struct plan_totals {
         bad |= (c64 + m - 1 < 1) ? 1 : 0;                                                                       \
         const int64_t c = c64 > 0 ? c64 : 0;                                                                    \
         const int64_t rem = c & 63;                                                                             \
-        const int64_t a_h = (c >> 6) + (rem > 32 ? 1 : 0), b_h = (rem >= 1 && rem <= 32) ? 1 : 0;               \
+        const int64_t a_h = (c >> 6) + (rem >= (int64_t)KVM_EDA_MIN ? 1 : 0);                                   \
+        const int64_t b_h = (rem > (int64_t)KVM_EDC_TILE && rem < (int64_t)KVM_EDA_MIN) ? 1 : 0;                \
+        const int64_t c_h = (rem >= 1 && (rem <= (int64_t)KVM_EDC_TILE ||                                       \
+                                          (rem > (int64_t)KVM_EDB_TILE && rem < (int64_t)KVM_EDA_MIN))) ? 1 : 0; \
         const int64_t a_u = (c + ((int64_t)1 << tile_log2) - 1) >> tile_log2;                                   \
         ta += hybrid ? a_h : a_u;                                                                               \
         tb += hybrid ? b_h : 0;                                                                                 \
+        tc += hybrid ? c_h : 0;                                                                                 \
         w += c;                                                                                                 \
         nr += c > 0 ? 1 : 0;                                                                                    \
     }                                                                                                           \
-    out.cnt_candidate = cnt; out.n_tiles = ta; out.n_tiles_b = tb; out.windows = w; out.nr = nr; out.bad_rsm = bad;
+    out.cnt_candidate = cnt; out.n_tiles = ta; out.n_tiles_b = tb; out.n_tiles_c = tc; out.windows = w; out.nr = nr; out.bad_rsm = bad;
 __attribute__((target("avx2"))) static void plan_totals_avx2(const int32_t *left, const int32_t *right, int32_t k, int64_t shift,
                                                              int64_t hi_max, int64_t m, bool hybrid, int tile_log2,
                                                              plan_totals &out) {
@@ -643,7 +648,7 @@ static int build_plan(kvm_ctx *ctx, bool cnsm, int32_t m, const int32_t *left, c
     static const bool have_avx2 = __builtin_cpu_supports("avx2");
     if (have_avx2) plan_totals_avx2(left, right, k, shift, hi_max, m, hybrid, tile_log2, tot);
     else plan_totals_generic(left, right, k, shift, hi_max, m, hybrid, tile_log2, tot);
-    const int64_t cnt_candidate = tot.cnt_candidate, n_tiles = tot.n_tiles, n_tiles_b = tot.n_tiles_b, windows = tot.windows,
+    const int64_t cnt_candidate = tot.cnt_candidate, n_tiles = tot.n_tiles, n_tiles_b = tot.n_tiles_b, n_tiles_c = tot.n_tiles_c, windows = tot.windows,
                   nr = tot.nr;
     const bool bad_rsm = tot.bad_rsm != 0;
     if (bad_rsm && !cnsm) {
@@ -665,6 +670,7 @@ static int build_plan(kvm_ctx *ctx, bool cnsm, int32_t m, const int32_t *left, c
     pl.cnt_candidate += cnt_candidate;
     pl.n_tiles += n_tiles;
     pl.n_tiles_b += n_tiles_b;
+    pl.n_tiles_c += n_tiles_c;
     pl.windows += windows;
     pl.n_runs = nr;
     return KVM_OK;
@@ -830,7 +836,7 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
     const int nchunks4 = (m + ED4_JC - 1) / ED4_JC, nchunks8 = (m + ED8_JC - 1) / ED8_JC;
     const int nchT = (m + JL_CHUNK - 1) / JL_CHUNK;  // lane-transposed copy for kvm_ed_jl.hip
     const size_t qmain = (size_t)m * 8 * (dtw ? 3 : 1) + KVM_SERIES_PAD * sizeof(double);
-    const size_t qdot0 = dtw ? 0 : ((size_t)m * 8 + KVM_SERIES_PAD * sizeof(double) + ((size_t)nchunks4 + nchunks8 + 2) * 16);
+    const size_t qdot0 = dtw ? 0 : ((size_t)m * 8 + KVM_SERIES_PAD * sizeof(double) + ((size_t)2 * nchunks4 + 1 + nchunks8 + 1) * 16);
     const bool use_qT = !dtw && ed_kernel == 4;
     const size_t qdot = dtw ? 0 : qdot0 + (use_qT ? (size_t)nchT * JL_CHUNK * 8 : 0);
     const size_t qexact_off = qmain + qdot;
@@ -864,7 +870,7 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
     // The interval list goes to the device first and the runs are built from it there (kvm_plan_runs_kernel, ~12 us)
     // while the host prepares the query block below.  Device layout: query block | left | right | runs | plan scratch.
     const size_t rbytes = (size_t)pl.n_runs * sizeof(kvm_run);
-    const size_t plan_scratch = ((size_t)(k > 0 ? k : 0) / 256 + 1) * 32;  // block totals of kvm_launch_plan_runs
+    const size_t plan_scratch = ((size_t)(k > 0 ? k : 0) / 256 + 1) * KVM_PLAN_SUMS_BYTES;  // block totals of kvm_launch_plan_runs
     const size_t rc_off = qbytes + lr_bytes + ((rbytes + 31) & ~(size_t)31) + ((plan_scratch + 31) & ~(size_t)31);
     if ((rc = ensure(ctx, ctx->b_query, rc_off + (chunks ? (size_t)pl.n_runs * sizeof(int2) : 0) + 64))) return rc;
     kvm_run *d_runs_w = (kvm_run *)((char *)ctx->b_query.p + qbytes + lr_bytes);
@@ -893,14 +899,15 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
         for (; i4 < m; i4++) s4[0] += q[i4];
         qd.q_mean = ((s4[0] + s4[1]) + (s4[2] + s4[3])) / m;
         qcen.resize(m);
-        qpref.resize((size_t)nchunks4 + 1);
+        qpref.resize((size_t)2 * nchunks4 + 1);  // ED16_JC-granular: class C uses every entry, class B every second one
         qpref8.resize((size_t)nchunks8 + 1);
-        static_assert(ED4_JC % 4 == 0 && ED8_JC % 4 == 0, "chunk boundaries fall between groups of four");
+        static_assert(ED4_JC % 4 == 0 && ED8_JC % 4 == 0 && ED16_JC % 4 == 0 && ED4_JC == 2 * ED16_JC,
+                      "chunk boundaries fall between groups of four; class B chunks are two class C chunks");
         double a1[4] = {0, 0, 0, 0}, a2[4] = {0, 0, 0, 0};
         const double qm = qd.q_mean;
         int i = 0;
         for (; i < m; i += 4) {
-            if (i % ED4_JC == 0) qpref[(size_t)(i / ED4_JC)] = make_double2((a1[0] + a1[1]) + (a1[2] + a1[3]), (a2[0] + a2[1]) + (a2[2] + a2[3]));
+            if (i % ED16_JC == 0) qpref[(size_t)(i / ED16_JC)] = make_double2((a1[0] + a1[1]) + (a1[2] + a1[3]), (a2[0] + a2[1]) + (a2[2] + a2[3]));
             if (i % ED8_JC == 0) qpref8[(size_t)(i / ED8_JC)] = make_double2((a1[0] + a1[1]) + (a1[2] + a1[3]), (a2[0] + a2[1]) + (a2[2] + a2[3]));
             const int lim = std::min(4, m - i);
             for (int u = 0; u < lim; u++) {
@@ -911,10 +918,11 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
             }
         }
         const double p1 = (a1[0] + a1[1]) + (a1[2] + a1[3]), p2 = (a2[0] + a2[1]) + (a2[2] + a2[3]);
-        qpref[(size_t)nchunks4] = make_double2(p1, p2);
+        for (size_t t = (size_t)((m + ED16_JC - 1) / ED16_JC); t <= (size_t)2 * nchunks4; t++) qpref[t] = make_double2(p1, p2);
         qpref8[(size_t)nchunks8] = make_double2(p1, p2);
     }
-    const size_t tbytes = (size_t)((retile || dtw) ? 3 * pl.n_tiles : pl.n_tiles + pl.n_tiles_b) * sizeof(kvm_tile);
+    // (device-built class lists of the ED pruner: each trimmed tile leaves at most one tile per class)
+    const size_t tbytes = (size_t)(retile ? 4 * pl.n_tiles : dtw ? 3 * pl.n_tiles : pl.n_tiles + pl.n_tiles_b + pl.n_tiles_c) * sizeof(kvm_tile);
     // (KVM_SERIES_PAD spare doubles after q: the tiled ED kernel stages whole query chunks without bounds checks)
     if ((rc = ensure(ctx, ctx->b_tiles, tbytes + 64))) return rc;
     if ((rc = ensure(ctx, ctx->b_counters, KVM_CNT_TOTAL * sizeof(unsigned long long)))) return rc;
@@ -976,6 +984,7 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
         if (hybrid)
             HIPCHK(ctx, kvm_launch_expand_tiles_hybrid(d_runs, pl.n_runs, (kvm_tile *)ctx->b_tiles.p,
                                                        (kvm_tile *)ctx->b_tiles.p + pl.n_tiles,
+                                                       (kvm_tile *)ctx->b_tiles.p + pl.n_tiles + pl.n_tiles_b,
                                                        (unsigned long long *)ctx->b_counters.p, rws.run_maxk, stream));
         else
             HIPCHK(ctx, kvm_launch_expand_tiles(d_runs, pl.n_runs, tile_max, (kvm_tile *)ctx->b_tiles.p,
@@ -988,7 +997,7 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
     qd.q_pref = dtw ? nullptr
                     : (const double2 *)((const char *)ctx->b_query.p + qmain + (size_t)m * 8 +
                                         KVM_SERIES_PAD * sizeof(double));
-    qd.q_pref8 = dtw ? nullptr : qd.q_pref + (nchunks4 + 1);
+    qd.q_pref8 = dtw ? nullptr : qd.q_pref + (2 * nchunks4 + 1);
     qd.qT = use_qT ? (const double *)((const char *)ctx->b_query.p + qmain + qdot0) : nullptr;
     qd.qu = dtw ? qd.q + m : nullptr;
     qd.ql = dtw ? qd.q + 2 * (size_t)m : nullptr;
@@ -1000,7 +1009,7 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
     ctx->last_kernel_ns = 0;
     ctx->timing_pending = false;
     KVM_TP("  H2D enqueue");
-    if (n_tiles + pl.n_tiles_b == 0) return KVM_OK;
+    if (n_tiles + pl.n_tiles_b + pl.n_tiles_c == 0) return KVM_OK;
 
     if (ctx->opt_timing) HIPCHK(ctx, hipEventRecord(ctx->ev0, stream));
     if (!dtw) {
@@ -1008,14 +1017,14 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
         if ((rc = ensure(ctx, ctx->b_cands, (size_t)pl.windows * sizeof(kvm_surv) + 64))) return rc;
         kvm_surv *surv = (kvm_surv *)ctx->b_cands.p;
         if (retile) {
-            kvm_tile *tA = (kvm_tile *)ctx->b_tiles.p + pl.n_tiles, *tB = tA + pl.n_tiles;
+            kvm_tile *tA = (kvm_tile *)ctx->b_tiles.p + pl.n_tiles, *tB = tA + pl.n_tiles, *tC = tB + pl.n_tiles;
             if (retile_rsm)
-                HIPCHK(ctx, kvm_launch_retile_rsm(ctx->d_series, qd, d_tiles, pl.n_tiles, tA, tB, counters + KVM_CNT_TILES_A,
+                HIPCHK(ctx, kvm_launch_retile_rsm(ctx->d_series, qd, d_tiles, pl.n_tiles, tA, tB, tC, counters + KVM_CNT_TILES_A,
                                                   stream));
             else
-                HIPCHK(ctx, kvm_launch_retile_cnsm(ctx->d_series, ctx->d_prefix, qd, d_tiles, pl.n_tiles, tA, tB,
+                HIPCHK(ctx, kvm_launch_retile_cnsm(ctx->d_series, ctx->d_prefix, qd, d_tiles, pl.n_tiles, tA, tB, tC,
                                                    counters + KVM_CNT_TILES_A, stream));
-            HIPCHK(ctx, kvm_launch_ed_dot(ctx->d_series, ctx->d_prefix, ctx->n, qd, tA, pl.n_tiles, tB, pl.n_tiles, surv,
+            HIPCHK(ctx, kvm_launch_ed_dot(ctx->d_series, ctx->d_prefix, ctx->n, qd, tA, pl.n_tiles, tB, pl.n_tiles, tC, pl.n_tiles, surv,
                                           pl.windows, counters, ctx->num_cu, counters + KVM_CNT_TILES_A, out.d_off, out.d_dist, out.cap,
                                           stream));
         } else if (ed_kernel == 4)
@@ -1023,7 +1032,7 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
                                          counters, ctx->num_cu, stream));
         else if (ed_kernel == 3)
             HIPCHK(ctx, kvm_launch_ed_dot(ctx->d_series, ctx->d_prefix, ctx->n, qd, d_tiles, pl.n_tiles, d_tiles + pl.n_tiles,
-                                          pl.n_tiles_b, surv, pl.windows, counters, ctx->num_cu, nullptr, out.d_off, out.d_dist,
+                                          pl.n_tiles_b, d_tiles + pl.n_tiles + pl.n_tiles_b, pl.n_tiles_c, surv, pl.windows, counters, ctx->num_cu, nullptr, out.d_off, out.d_dist,
                                           out.cap, stream));
         else if (ed_kernel == 2)
             HIPCHK(ctx, kvm_launch_ed_tiled(ctx->d_series, ctx->d_prefix, ctx->n, qd, d_tiles, n_tiles, surv,
@@ -1201,7 +1210,7 @@ static int verify_host(kvm_ctx *ctx, int variant, const double *query, int32_t m
     const int64_t spec = std::min<int64_t>(KVM_SPEC_ANSWERS, worst);
     std::vector<int32_t> off;
     std::vector<double> dist;
-    for (int pass = 0; pass < 2 && pl.n_tiles + pl.n_tiles_b > 0; pass++) {
+    for (int pass = 0; pass < 2 && pl.n_tiles + pl.n_tiles_b + pl.n_tiles_c > 0; pass++) {
         if (!ctx->h_readback)
             HIPCHK(ctx, hipHostMalloc(&ctx->h_readback, KVM_CNT_TOTAL * 8 + KVM_SPEC_ANSWERS * 12 + 64, hipHostMallocDefault));
         HIPCHK(ctx, kvm_launch_readback((const unsigned long long *)ctx->b_counters.p, out.d_off, out.d_dist, spec,
@@ -1223,8 +1232,9 @@ static int verify_host(kvm_ctx *ctx, int variant, const double *query, int32_t m
     }
     KVM_TP("sync + counters D2H");
     if (kvm_trace_on())
-        fprintf(stderr, "[kvm] tiles %lld+%lld  retiled A %llu B %llu  pruner survivors %llu\n", (long long)pl.n_tiles,
-                (long long)pl.n_tiles_b, hc[KVM_CNT_TILES_A], hc[KVM_CNT_TILES_B], hc[KVM_CNT_CANDS1]);
+        fprintf(stderr, "[kvm] tiles %lld+%lld+%lld  retiled A %llu B %llu C %llu  pruner survivors %llu\n", (long long)pl.n_tiles,
+                (long long)pl.n_tiles_b, (long long)pl.n_tiles_c, hc[KVM_CNT_TILES_A], hc[KVM_CNT_TILES_B], hc[KVM_CNT_TILES_C],
+                hc[KVM_CNT_CANDS1]);
     const int64_t cnt = (int64_t)hc[KVM_CNT_ANSWERS];
     if (cnt > worst) return fail(ctx, KVM_ERR_DEVICE, "answer buffer overflow (internal error)");
     std::unique_ptr<kvm_result> r_owner(new kvm_result());  // (released into *result at the end; freed on every error return)
@@ -1350,7 +1360,7 @@ extern "C" int kvm_verify_device(kvm_ctx *ctx, int32_t variant, const double *qu
                          dtw_ax);
     if (rc) return rc;
     if (cnt_candidate) *cnt_candidate = pl.cnt_candidate;
-    if (variant >= V_RSM_DTW && pl.n_tiles + pl.n_tiles_b > 0) {
+    if (variant >= V_RSM_DTW && pl.n_tiles + pl.n_tiles_b + pl.n_tiles_c > 0) {
         // DTW: the number of candidates that need the sequential reference-ordered path is only known on the device;
         // this one small read is the only point where a kvm_verify_device call waits for the stream
         unsigned long long n_ambig = 0;
@@ -1359,7 +1369,7 @@ extern "C" int kvm_verify_device(kvm_ctx *ctx, int32_t variant, const double *qu
         HIPCHK(ctx, hipStreamSynchronize(s));
         if (n_ambig > 0 && (rc = dtw_resolve_ambiguous(ctx, dtw_qd, dtw_ax, (int64_t)n_ambig, out, s))) return rc;
     }
-    if (pl.n_tiles + pl.n_tiles_b == 0) {
+    if (pl.n_tiles + pl.n_tiles_b + pl.n_tiles_c == 0) {
         HIPCHK(ctx, hipMemsetAsync(d_out_count, 0, sizeof(int64_t), s));
     } else {
         HIPCHK(ctx, hipMemcpyAsync(d_out_count, (unsigned long long *)ctx->b_counters.p + KVM_CNT_ANSWERS,

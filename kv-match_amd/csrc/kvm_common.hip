@@ -13,14 +13,19 @@
 // interval on one CU.)  The host sums the same per-interval rule (kvm_plan_interval) for the launch geometry only.
 #define PLAN_THREADS 256
 struct plan_sums {
-    long long nr, ta, tb, w;
+    long long nr, ta, tb, tc, w;
 };
-__device__ __forceinline__ plan_sums plan_add(plan_sums a, plan_sums b) { return plan_sums{a.nr + b.nr, a.ta + b.ta, a.tb + b.tb, a.w + b.w}; }
+static_assert(sizeof(plan_sums) == KVM_PLAN_SUMS_BYTES, "kvm_api.hip sizes the block-total scratch of kvm_launch_plan_runs with it");
+__device__ __forceinline__ plan_sums plan_add(plan_sums a, plan_sums b) {
+    return plan_sums{a.nr + b.nr, a.ta + b.ta, a.tb + b.tb, a.tc + b.tc, a.w + b.w};
+}
 __device__ __forceinline__ plan_sums plan_shfl_xor(plan_sums v, int o) {
-    return plan_sums{__shfl_xor(v.nr, o, 64), __shfl_xor(v.ta, o, 64), __shfl_xor(v.tb, o, 64), __shfl_xor(v.w, o, 64)};
+    return plan_sums{__shfl_xor(v.nr, o, 64), __shfl_xor(v.ta, o, 64), __shfl_xor(v.tb, o, 64), __shfl_xor(v.tc, o, 64),
+                     __shfl_xor(v.w, o, 64)};
 }
 __device__ __forceinline__ plan_sums plan_shfl_up(plan_sums v, int o) {
-    return plan_sums{__shfl_up(v.nr, o, 64), __shfl_up(v.ta, o, 64), __shfl_up(v.tb, o, 64), __shfl_up(v.w, o, 64)};
+    return plan_sums{__shfl_up(v.nr, o, 64), __shfl_up(v.ta, o, 64), __shfl_up(v.tb, o, 64), __shfl_up(v.tc, o, 64),
+                     __shfl_up(v.w, o, 64)};
 }
 // sum over the workgroup, result in every thread
 __device__ __forceinline__ plan_sums plan_block_sum(plan_sums v, plan_sums *wave_tot) {
@@ -34,7 +39,7 @@ __device__ __forceinline__ plan_sums plan_block_sum(plan_sums v, plan_sums *wave
     return t;
 }
 __device__ __forceinline__ plan_sums plan_item_sums(const kvm_plan_item &it) {
-    return plan_sums{it.c > 0 ? 1 : 0, (long long)it.tiles_a, (long long)it.tiles_b, (long long)it.c};
+    return plan_sums{it.c > 0 ? 1 : 0, (long long)it.tiles_a, (long long)it.tiles_b, (long long)it.tiles_c, (long long)it.c};
 }
 
 // `src_left` / `src_right` may be the pinned host staging buffer itself (zero-copy over PCIe: 8 B per interval, no copy
@@ -77,7 +82,7 @@ __global__ __launch_bounds__(PLAN_THREADS) void kvm_plan_runs_kernel(const int32
     }
     const int64_t p = (int64_t)blockIdx.x * PLAN_THREADS + tid;
     kvm_plan_item it;
-    it.lo = 1; it.c64 = 0; it.c = 0; it.tiles_a = 0; it.tiles_b = 0;
+    it.lo = 1; it.c64 = 0; it.c = 0; it.tiles_a = 0; it.tiles_b = 0; it.tiles_c = 0;
     if (p < k) it = kvm_plan_interval(left[p], right[p], shift, hi_max, hybrid != 0, tile_log2);
     const plan_sums mine = plan_item_sums(it);
     plan_sums inc = mine;  // inclusive scan inside the wave, then across the wave totals
@@ -96,6 +101,7 @@ __global__ __launch_bounds__(PLAN_THREADS) void kvm_plan_runs_kernel(const int32
         r.count = (int32_t)it.c;
         r.tile_base = off.ta + inc.ta - mine.ta;
         r.tile_base_b = it.tiles_b ? off.tb + inc.tb - mine.tb : -1;
+        r.tile_base_c = it.tiles_c ? off.tc + inc.tc - mine.tc : -1;
         r.win_base = off.w + inc.w - mine.w;
         runs[off.nr + inc.nr - mine.nr] = r;
         if (run_chunk) run_chunk[off.nr + inc.nr - mine.nr] = make_int2(chunk_lo[p], chunk_hi[p]);
@@ -184,11 +190,13 @@ hipError_t kvm_launch_bswap64(uint64_t *d, int64_t n, hipStream_t s) {
     return hipGetLastError();
 }
 
-// Hybrid ED tiling (kvm_ed_dot.hip): per run floor(count/64) full 64-candidate tiles; the remainder becomes one more
-// class-A tile if it exceeds 32 candidates, else one class-B tile (<= 32 candidates).
+// Hybrid ED tiling (kvm_ed_dot.hip): per run floor(count/64) full 64-candidate tiles; what is left goes to class A, to
+// class B and / or to class C by kvm_ed_remainder_classes (the class-B tile takes the first <= 32 candidates of the
+// remainder, the class-C tile the rest).
 __global__ __launch_bounds__(256) void kvm_expand_tiles_hybrid_kernel(const kvm_run *__restrict__ runs, int64_t n_runs,
                                                                       kvm_tile *__restrict__ tilesA,
                                                                       kvm_tile *__restrict__ tilesB,
+                                                                      kvm_tile *__restrict__ tilesC,
                                                                       unsigned long long *__restrict__ counters,
                                                                              int32_t *__restrict__ run_maxk) {
     if (blockIdx.x == 0 && threadIdx.x < KVM_CNT_TOTAL) counters[threadIdx.x] = 0;
@@ -198,7 +206,9 @@ __global__ __launch_bounds__(256) void kvm_expand_tiles_hybrid_kernel(const kvm_
     const kvm_run run = runs[r];
     if (run_maxk && lane == 0) run_maxk[r] = 0;
     const int full = run.count / 64, rem = run.count % 64;
-    const int nA = full + (rem > 32 ? 1 : 0);
+    uint32_t ra, rb, rc;
+    kvm_ed_remainder_classes((uint32_t)rem, ra, rb, rc);
+    const int nA = full + (int)ra;
     for (int t = lane; t < nA; t += 64) {
         kvm_tile tl;
         tl.start = run.start + t * 64;
@@ -207,21 +217,30 @@ __global__ __launch_bounds__(256) void kvm_expand_tiles_hybrid_kernel(const kvm_
         tl.pad = 0;
         tilesA[run.tile_base + t] = tl;
     }
-    if (lane == 0 && rem > 0 && rem <= 32) {
+    const int nb = rb ? min(rem, (int)KVM_EDB_TILE) : 0;  // candidates of the class-B tile
+    if (lane == 0 && rb) {
         kvm_tile tl;
         tl.start = run.start + full * 64;
-        tl.count = rem;
+        tl.count = nb;
         tl.run_start = run.start;
         tl.pad = 0;
         tilesB[run.tile_base_b] = tl;
     }
+    if (lane == 1 && rc) {
+        kvm_tile tl;
+        tl.start = run.start + full * 64 + nb;
+        tl.count = rem - nb;
+        tl.run_start = run.start;
+        tl.pad = 0;
+        tilesC[run.tile_base_c] = tl;
+    }
 }
 
 hipError_t kvm_launch_expand_tiles_hybrid(const kvm_run *runs, int64_t n_runs, kvm_tile *tilesA, kvm_tile *tilesB,
-                                          unsigned long long *counters, int32_t *run_maxk, hipStream_t s) {
+                                          kvm_tile *tilesC, unsigned long long *counters, int32_t *run_maxk, hipStream_t s) {
     if (n_runs <= 0) return hipSuccess;
     hipLaunchKernelGGL(kvm_expand_tiles_hybrid_kernel, dim3((unsigned)((n_runs + 3) / 4)), dim3(256), 0, s, runs, n_runs,
-                       tilesA, tilesB, counters, run_maxk);
+                       tilesA, tilesB, tilesC, counters, run_maxk);
     return hipGetLastError();
 }
 

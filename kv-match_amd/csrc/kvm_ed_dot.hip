@@ -18,8 +18,13 @@
 //   CI = 8 : 64-candidate tiles, chunk 128.  Per 2 points one ds_read_b128 of the window and one broadcast ds_read_b128
 //            of (qc[j], qc[j+1]) feed 16 FMAs: LDS at half the VALU rate -> VALU-bound.  Used for full tiles and for
 //            run remainders of more than 32 candidates.
-//   CI = 4 : 32-candidate tiles, chunk 160.  8 FMAs per 2 reads: LDS and VALU co-limited (~60 % of either), but only
-//            half the idle lanes on short remainders.  Used for remainders of <= 32 candidates.
+//   CI = 4 : class B, 32-candidate tiles, chunk 160.  8 FMAs per 2 reads; per lane-slot as fast as CI = 8 in practice, and
+//            only half the idle lanes on a short remainder.
+//   CI = 4, two tiles per row : class C, 16-candidate tiles, TWO unrelated tiles per row (lanes 0-3 / 4-7, each half of
+//            the row's LDS region staged from its own tile's position), chunk 80 -- the per-chunk work (27 loads, 27 LDS
+//            writes, ring start-up) is amortised over half as many points, so a unit of 16 such tiles takes 1.2 x a
+//            class-B unit of 8 tiles (0.318 against 0.264 ms): worth it for remainders of <= 16 candidates only
+//            (kvm_ed_remainder_classes, profiles/ed_class_cost.py).
 // Lane stride inside a row is CI*8 B; rows are displaced by 16 B against each other ((r>>1)&1 for CI=4, r&3 for CI=8) so
 // that every 16-lane group of ds_read_b128 -- which mixes lanes of four rows -- covers 16 distinct 16-B slots
 // (conflict-free; SQ_LDS_BANK_CONFLICT ~ 1 % of LDS cycles).  The loads are written with a clang ext_vector type:
@@ -38,17 +43,28 @@ typedef double ed4_d2 __attribute__((ext_vector_type(2)));
 #define EDD_ROWLEN 192                       // staged points per row per chunk (both configurations)
 #define EDD_LOADS (EDD_ROWLEN / 64)
 #define EDD_RS (EDD_ROWLEN + 32)             // row stride in doubles (x8 B = multiple of 256 B), room for the row shift
-#define EDD_WAVE_LDS (EDD_ROWS * EDD_RS + EDD_ROWLEN)
-static_assert(ED4_JC + 8 * 4 <= EDD_ROWLEN && ED8_JC + 8 * 8 <= EDD_ROWLEN, "chunk + tile must fit the staged row");
+#define EDD_SUB_OFF 112                      // class C: second tile of a row, in doubles (x8 B = 128 mod 256 B: the eight
+                                             // lanes of a row cover the same 16-B slots as with one 32-candidate tile)
+#define EDD_SUB_LEN 96                       // staged points per class-C tile per chunk
+#define EDD_TAB 32                           // class C: per-tile staging table (16 row shifts, 16 starts; padded so that a
+                                             // wave's region stays a multiple of 256 B), in doubles
+#define EDD_WAVE_LDS (EDD_ROWS * EDD_RS + EDD_ROWLEN + EDD_TAB)
+static_assert(ED16_JC + 16 <= EDD_SUB_LEN && 2 * EDD_SUB_LEN == EDD_ROWLEN && ED4_JC + 8 * 4 <= EDD_ROWLEN && ED8_JC + 8 * 8 <= EDD_ROWLEN, "chunk + tile must fit the staged (half) row");
+static_assert(EDD_SUB_OFF >= EDD_SUB_LEN && EDD_SUB_OFF + EDD_SUB_LEN + 2 <= EDD_RS && (EDD_SUB_OFF * 8) % 256 == 128, "class-B half rows");
 static_assert(4 * EDD_WAVE_LDS * 8 <= 65536 && EDD_WAVE_LDS % 2 == 0 && EDD_RS % 2 == 0 && (EDD_RS * 8) % 256 == 0, "LDS");
-static_assert(ED4_JC % 16 == 0 && ED8_JC % 16 == 0, "chunks are whole groups of 16 points (4 sub-steps of the register ring)");
+static_assert(ED4_JC % 16 == 0 && ED8_JC % 16 == 0 && ED16_JC % 16 == 0, "chunks are whole groups of 16 points (4 sub-steps of the register ring)");
 
-template <int CI>
+template <int CI, int SUB>
 struct edd_cfg {
-    static constexpr int JC = CI == 8 ? ED8_JC : ED4_JC;
-    static constexpr int TILE = 8 * CI;
+    static constexpr int JC = CI == 8 ? ED8_JC : (SUB == 2 ? ED16_JC : ED4_JC);
+    static constexpr int TILE = 8 * CI / SUB;            // candidates per tile: 64 / 32 / 16
+    static constexpr int TPU = EDD_ROWS * SUB;           // tiles per unit (= per wavefront)
+    static constexpr int QS = CI == 8 ? 1 : JC / ED16_JC;  // stride of a chunk in the q_pref array it reads
     __device__ static constexpr int row_shift(int r) { return CI == 8 ? (r & 3) * 2 : ((r >> 1) & 1) * 2; }  // doubles
 };
+#define EDD_TILES_A (EDD_ROWS)
+#define EDD_TILES_B (EDD_ROWS)
+#define EDD_TILES_C (EDD_ROWS * 2)
 
 struct edd_args {
     const double *series;
@@ -75,40 +91,52 @@ struct edd_cstat {
 // accumulators to part 0 through LDS behind one workgroup barrier, and part 0 finishes the candidates.  A unit is then
 // 1/f as long, which is what lets a few thousand units drain evenly from 2048 wave slots (see the launcher).
 // Every wave of a splitting workgroup reaches the barrier exactly once, whether or not it has work (`active`).
-template <int CI, bool NORM, bool ABANDON>
+template <int CI, int SUB, bool NORM, bool ABANDON>
 __device__ __forceinline__ void edd_body(const edd_args &A, const kvm_tile *__restrict__ tiles, int64_t n_tiles, int64_t t0,
                                          double2 *lds_wave2, const int part, const int f, const bool active) {
-    using cfg = edd_cfg<CI>;
+    using cfg = edd_cfg<CI, SUB>;
     constexpr int JC = cfg::JC;
     const int lane = threadIdx.x & 63;
-    const int row = lane >> 3, lc = lane & 7;
+    const int row = lane >> 3;
+    const int sub = SUB == 2 ? ((lane >> 2) & 1) : 0;   // which of the row's tiles this lane works on
+    const int lc = SUB == 2 ? (lane & 3) : (lane & 7);  // lane within the tile
     const kvm_query_dev &qd = A.qd;
     const int m = qd.m;
     const double eps2 = qd.eps2;
     const double *__restrict__ series = A.series;
     const double2 *__restrict__ prefix = A.prefix;
     const double *__restrict__ qc = qd.qc;
-    const double2 *__restrict__ q_pref = CI == 8 ? qd.q_pref8 : qd.q_pref;
+    const double2 *__restrict__ q_pref = CI == 8 ? qd.q_pref8 : qd.q_pref;  // (CI = 4: ED16_JC-granular, chunk stride cfg::QS)
     double *wlds = reinterpret_cast<double *>(lds_wave2);
     double *qlds = wlds + EDD_ROWS * EDD_RS;
+    double *tab_shift = qlds + EDD_ROWLEN;                                  // class C: shift / start of the unit's 16 tiles
+    int32_t *tab_start = reinterpret_cast<int32_t *>(tab_shift + 16);
     const int nchunks = (m + JC - 1) / JC;
 
-    // wave-uniform row descriptors (for staging) ...
+    // wave-uniform tile descriptors (for staging): in registers, or (class C: 16 of them) in the wave's LDS ...
     int32_t rstart[EDD_ROWS];
     double rshift[EDD_ROWS];
+    if constexpr (SUB == 1) {
 #pragma unroll
-    for (int r = 0; r < EDD_ROWS; r++) {
-        rstart[r] = (t0 + r < n_tiles) ? tiles[t0 + r].start : 1;  // empty rows stage from the head of the series
-        rshift[r] = series[rstart[r] - 1];
+        for (int r = 0; r < EDD_ROWS; r++) {
+            rstart[r] = (t0 + r < n_tiles) ? tiles[t0 + r].start : 1;  // empty rows stage from the head of the series
+            rshift[r] = series[rstart[r] - 1];
+        }
+    } else {
+        if (lane < cfg::TPU) {
+            const int32_t st = (t0 + lane < n_tiles) ? tiles[t0 + lane].start : 1;
+            tab_start[lane] = st;
+            tab_shift[lane] = series[st - 1];
+        }
     }
-    // ... and this lane's own row
+    // ... and this lane's own tile
     kvm_tile mine;
     mine.start = 1; mine.count = 0; mine.run_start = 1; mine.pad = 0;
-    if (t0 + row < n_tiles) mine = tiles[t0 + row];
+    if (t0 + row * SUB + sub < n_tiles) mine = tiles[t0 + row * SUB + sub];
     const double c_row = series[mine.start - 1];
     const int c0 = CI * lc;
     const double qbar = qd.q_mean;
-    const double2 qtot = q_pref[nchunks];
+    const double2 qtot = q_pref[nchunks * cfg::QS];
 
     // Shifted sums of points [jlo, J) of candidate a's window, re-based to the row shift; for cNSM also the window's
     // mean - c_row, sigma and sigma guard (always from the full window).
@@ -219,12 +247,35 @@ __device__ __forceinline__ void edd_body(const edd_args &A, const kvm_tile *__re
     }
 
     double stage[EDD_ROWS + 1][EDD_LOADS];
+    // class C: the 192 staged points of a row are two runs of 96, one per tile; load t of a lane falls into tile
+    // 0 (t = 0), tile 1 (t = 2) or, for t = 1, tile 0 for lanes < 32 and tile 1 above.  The series index each of a lane's
+    // 24 loads starts from is fixed for the unit: kept in registers (int32: offsets are Java ints), so that a chunk's
+    // staging costs one 64-bit add per load, as in class A.
+    auto sub_of = [&](int t) -> int { return t == 0 ? 0 : (t == 2 ? 1 : (lane >> 5)); };
+    int32_t sidx[SUB == 2 ? EDD_ROWS : 1][EDD_LOADS];
+    if constexpr (SUB == 2) {
+#pragma unroll
+        for (int r = 0; r < EDD_ROWS; r++) {
+#pragma unroll
+            for (int t = 0; t < EDD_LOADS; t++) {
+                const int sb = sub_of(t);
+                sidx[r][t] = tab_start[r * 2 + sb] - 1 + (t * 64 + lane - sb * EDD_SUB_LEN);
+            }
+        }
+    }
     auto load_chunk = [&](int j0) {
 #pragma unroll
         for (int r = 0; r < EDD_ROWS; r++) {
-            const double *src = series + ((int64_t)rstart[r] - 1 + j0);  // unguarded: series is padded (KVM_SERIES_PAD)
+            if constexpr (SUB == 1) {
+                const double *src = series + ((int64_t)rstart[r] - 1 + j0);  // unguarded: series is padded (KVM_SERIES_PAD)
 #pragma unroll
-            for (int t = 0; t < EDD_LOADS; t++) stage[r][t] = src[t * 64 + lane];  // raw: shifted when stored
+                for (int t = 0; t < EDD_LOADS; t++) stage[r][t] = src[t * 64 + lane];  // raw: shifted when stored
+            } else {
+#pragma unroll
+                for (int t = 0; t < EDD_LOADS; t++) {
+                    stage[r][t] = series[(int64_t)sidx[r][t] + j0];
+                }
+            }
         }
 #pragma unroll
         for (int t = 0; t < EDD_LOADS; t++) stage[EDD_ROWS][t] = qc[j0 + t * 64 + lane];
@@ -233,14 +284,27 @@ __device__ __forceinline__ void edd_body(const edd_args &A, const kvm_tile *__re
         // The subtraction of the row shift is the first use of the prefetched values.  Its operands pass through an
         // empty asm placed after the chunk's arithmetic, so the compiler cannot hoist the subtractions (and with them
         // the wait for the loads) above the FMA block that is there to cover the load latency.
-        double sh[EDD_ROWS];
+        if constexpr (SUB == 1) {
+            double sh[EDD_ROWS];
 #pragma unroll
-        for (int r = 0; r < EDD_ROWS; r++) sh[r] = rshift[r];
-        asm volatile("" : "+v"(sh[0]), "+v"(sh[1]), "+v"(sh[2]), "+v"(sh[3]), "+v"(sh[4]), "+v"(sh[5]), "+v"(sh[6]), "+v"(sh[7])::"memory");
+            for (int r = 0; r < EDD_ROWS; r++) sh[r] = rshift[r];
+            asm volatile("" : "+v"(sh[0]), "+v"(sh[1]), "+v"(sh[2]), "+v"(sh[3]), "+v"(sh[4]), "+v"(sh[5]), "+v"(sh[6]), "+v"(sh[7])::"memory");
 #pragma unroll
-        for (int r = 0; r < EDD_ROWS; r++) {
+            for (int r = 0; r < EDD_ROWS; r++) {
 #pragma unroll
-            for (int t = 0; t < EDD_LOADS; t++) wlds[r * EDD_RS + cfg::row_shift(r) + t * 64 + lane] = stage[r][t] - sh[r];
+                for (int t = 0; t < EDD_LOADS; t++) wlds[r * EDD_RS + cfg::row_shift(r) + t * 64 + lane] = stage[r][t] - sh[r];
+            }
+        } else {
+            asm volatile("" ::: "memory");  // (the shifts are read from LDS behind this point: same effect)
+#pragma unroll
+            for (int r = 0; r < EDD_ROWS; r++) {
+#pragma unroll
+                for (int t = 0; t < EDD_LOADS; t++) {
+                    const int sb = sub_of(t);
+                    wlds[r * EDD_RS + cfg::row_shift(r) + sb * EDD_SUB_OFF + (t * 64 + lane - sb * EDD_SUB_LEN)] =
+                        stage[r][t] - tab_shift[r * 2 + sb];
+                }
+            }
         }
 #pragma unroll
         for (int t = 0; t < EDD_LOADS; t++) qlds[t * 64 + lane] = stage[EDD_ROWS][t];
@@ -254,7 +318,8 @@ __device__ __forceinline__ void edd_body(const edd_args &A, const kvm_tile *__re
         load_chunk(ch_lo * JC);
         store_chunk();
     }
-    const ed4_d2 *X2 = reinterpret_cast<const ed4_d2 *>(lds_wave2) + (row * (EDD_RS / 2) + cfg::row_shift(row) / 2 + (CI / 2) * lc);
+    const ed4_d2 *X2 = reinterpret_cast<const ed4_d2 *>(lds_wave2) +
+                       (row * (EDD_RS / 2) + cfg::row_shift(row) / 2 + sub * (EDD_SUB_OFF / 2) + (CI / 2) * lc);
     const ed4_d2 *Q2 = reinterpret_cast<const ed4_d2 *>(lds_wave2) + EDD_ROWS * (EDD_RS / 2);
     for (int ch = ch_lo; work && ch < ch_hi; ch++) {
         const int j0 = ch * JC;
@@ -321,9 +386,9 @@ __device__ __forceinline__ void edd_body(const edd_args &A, const kvm_tile *__re
             // every 8 chunks (a split unit belongs to a short list: the launch lasts as long as its longest unit whatever
             // the others do, a wave leaves only when all its 512 candidates are dead, and each check costs more
             // than the chunk it might save).
-            if (ABANDON && (ch == ch_lo || (f == 1 && ((ch - ch_lo) & 7) == 7))) {
+            if (ABANDON && (ch == ch_lo || (f == 1 && ((ch - ch_lo) & (SUB == 2 ? 15 : 7)) == (SUB == 2 ? 15 : 7)))) {
                 const int jlo = ch_lo * JC, J = j0 + JC;
-                const double2 qa = q_pref[ch + 1], qb = q_pref[ch_lo];
+                const double2 qa = q_pref[(ch + 1) * cfg::QS], qb = q_pref[ch_lo * cfg::QS];
                 const double2 qp = make_double2(qa.x - qb.x, qa.y - qb.y);
                 // (a rolled loop: this runs once per 8 chunks, and unrolling its eight prefix-sum evaluations around
                 // the hot loop's live registers made the compiler spill)
@@ -452,13 +517,13 @@ __device__ __forceinline__ void edd_body(const edd_args &A, const kvm_tile *__re
 }
 
 // ---- tile trimming shared by the two retile kernels: a tile keeps the span of its surviving candidates (bit l of `mask` =
-// lane l's candidate survives), goes to class A (33..64) or B (1..32), and is collected in LDS; one pair of global
+// lane l's candidate survives), goes to class A, B and / or C by kvm_ed_remainder_classes, and is collected in LDS; one set of global
 // atomics per workgroup appends the collected tiles (one atomic per tile on a single address cost 0.3 ms at 24 000 tiles).
 template <int CAP>
 struct retile_out {
-    kvm_tile a[CAP], b[CAP];
-    int na, nb;
-    unsigned long long base_a, base_b;
+    kvm_tile a[CAP], b[CAP], c[CAP];  // (a trimmed tile leaves at most one tile per class)
+    int na, nb, nc;
+    unsigned long long base_a, base_b, base_c;
 };
 template <int CAP>
 __device__ __forceinline__ void retile_collect(retile_out<CAP> &o, const kvm_tile &tl, unsigned long long mask) {
@@ -469,21 +534,27 @@ __device__ __forceinline__ void retile_collect(retile_out<CAP> &o, const kvm_til
     out.count = last - first + 1;
     out.run_start = tl.run_start;
     out.pad = 0;
-    if (out.count > 32) o.a[atomicAdd(&o.na, 1)] = out;
+    // Classes as in kvm_ed_remainder_classes, except that class C is not used here: the device-built lists are what is
+    // left after a selective predicate (a few hundred tiles for 2048 wave slots), the call then lasts as long as its
+    // longest unit, and a class-C unit over the whole window takes 1.3 x a class-B unit (measured: the pruner of the
+    // bench query with early abandoning went from 97 to 128 us with the tile that holds an answer in class C).
+    if (out.count > (int)KVM_EDB_TILE) o.a[atomicAdd(&o.na, 1)] = out;
     else o.b[atomicAdd(&o.nb, 1)] = out;
 }
 // (all threads of the workgroup; list order is whatever the atomics give)
 template <int CAP>
 __device__ __forceinline__ void retile_flush(retile_out<CAP> &o, kvm_tile *__restrict__ tilesA, kvm_tile *__restrict__ tilesB,
-                                             unsigned long long *__restrict__ d_counts) {
+                                             kvm_tile *__restrict__ tilesC, unsigned long long *__restrict__ d_counts) {
     __syncthreads();
     if (threadIdx.x == 0) {
         o.base_a = o.na ? atomicAdd(&d_counts[0], (unsigned long long)o.na) : 0;
         o.base_b = o.nb ? atomicAdd(&d_counts[1], (unsigned long long)o.nb) : 0;
+        o.base_c = o.nc ? atomicAdd(&d_counts[2], (unsigned long long)o.nc) : 0;
     }
     __syncthreads();
     for (int i = threadIdx.x; i < o.na; i += blockDim.x) tilesA[o.base_a + i] = o.a[i];
     for (int i = threadIdx.x; i < o.nb; i += blockDim.x) tilesB[o.base_b + i] = o.b[i];
+    for (int i = threadIdx.x; i < o.nc; i += blockDim.x) tilesC[o.base_c + i] = o.c[i];
 }
 
 // cNSM: trim every 64-candidate tile to the span of its candidates that pass the guarded (alpha, beta) filter and sort
@@ -497,10 +568,11 @@ __global__ __launch_bounds__(256) void kvm_retile_cnsm_kernel(const double *__re
                                                               const double2 *__restrict__ prefix, kvm_query_dev qd,
                                                               const kvm_tile *__restrict__ tiles, int64_t n_tiles,
                                                               kvm_tile *__restrict__ tilesA, kvm_tile *__restrict__ tilesB,
+                                                              kvm_tile *__restrict__ tilesC,
                                                               unsigned long long *__restrict__ d_counts) {
     __shared__ retile_out<RETILE_PER_BLOCK> out;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) out.na = out.nb = 0;
+    if (threadIdx.x == 0) out.na = out.nb = out.nc = 0;
     __syncthreads();
     const int64_t t0 = (int64_t)blockIdx.x * RETILE_PER_BLOCK + wave * (RETILE_PER_BLOCK / 4);
     for (int i = 0; i < RETILE_PER_BLOCK / 4; i++) {
@@ -515,7 +587,7 @@ __global__ __launch_bounds__(256) void kvm_retile_cnsm_kernel(const double *__re
         }
         retile_collect(out, tl, __ballot(ok));
     }
-    retile_flush(out, tilesA, tilesB, d_counts);
+    retile_flush(out, tilesA, tilesB, tilesC, d_counts);
 }
 
 // RSM with the reference's early abandoning: the same trimming with the first EDR_HEAD points of the window as the
@@ -530,10 +602,11 @@ __global__ __launch_bounds__(256) void kvm_retile_cnsm_kernel(const double *__re
 __global__ __launch_bounds__(256) void kvm_retile_rsm_kernel(const double *__restrict__ series, kvm_query_dev qd,
                                                              const kvm_tile *__restrict__ tiles, int64_t n_tiles,
                                                              kvm_tile *__restrict__ tilesA, kvm_tile *__restrict__ tilesB,
+                                                             kvm_tile *__restrict__ tilesC,
                                                              unsigned long long *__restrict__ d_counts) {
     __shared__ retile_out<EDR_PER_BLOCK> out;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) out.na = out.nb = 0;
+    if (threadIdx.x == 0) out.na = out.nb = out.nc = 0;
     __syncthreads();
     const int head = qd.m < EDR_HEAD ? qd.m : EDR_HEAD;
     const double lim = qd.eps2 * (1.0 + 1e-9);  // (fused, other summation order than the reference's loop: < 1e-13 relative)
@@ -587,53 +660,66 @@ __global__ __launch_bounds__(256) void kvm_retile_rsm_kernel(const double *__res
         const bool ok = lane < tl.count && !(a0 + a1 > lim);
         retile_collect(out, tl, __ballot(ok));
     }
-    retile_flush(out, tilesA, tilesB, d_counts);
+    retile_flush(out, tilesA, tilesB, tilesC, d_counts);
 }
 
 hipError_t kvm_launch_retile_rsm(const double *series, const kvm_query_dev &qd, const kvm_tile *tiles, int64_t n_tiles,
-                                 kvm_tile *tilesA, kvm_tile *tilesB, unsigned long long *d_counts, hipStream_t s) {
+                                 kvm_tile *tilesA, kvm_tile *tilesB, kvm_tile *tilesC, unsigned long long *d_counts,
+                                 hipStream_t s) {
     if (n_tiles <= 0) return hipSuccess;
     hipLaunchKernelGGL(kvm_retile_rsm_kernel, dim3((unsigned)((n_tiles + EDR_PER_BLOCK - 1) / EDR_PER_BLOCK)), dim3(256),
-                       0, s, series, qd, tiles, n_tiles, tilesA, tilesB, d_counts);
+                       0, s, series, qd, tiles, n_tiles, tilesA, tilesB, tilesC, d_counts);
     return hipGetLastError();
 }
 
 hipError_t kvm_launch_retile_cnsm(const double *series, const double2 *prefix, const kvm_query_dev &qd, const kvm_tile *tiles,
-                                  int64_t n_tiles, kvm_tile *tilesA, kvm_tile *tilesB, unsigned long long *d_counts,
-                                  hipStream_t s) {
+                                  int64_t n_tiles, kvm_tile *tilesA, kvm_tile *tilesB, kvm_tile *tilesC,
+                                  unsigned long long *d_counts, hipStream_t s) {
     if (n_tiles <= 0) return hipSuccess;
     hipLaunchKernelGGL(kvm_retile_cnsm_kernel, dim3((unsigned)((n_tiles + RETILE_PER_BLOCK - 1) / RETILE_PER_BLOCK)), dim3(256),
-                       0, s, series, prefix, qd, tiles, n_tiles, tilesA, tilesB, d_counts);
+                       0, s, series, prefix, qd, tiles, n_tiles, tilesA, tilesB, tilesC, d_counts);
     return hipGetLastError();
 }
 
-// One launch covers both tile classes.  Workgroups [0, blocksA) run the CI=8 body on `tilesA`, the rest the CI=4 body on
-// `tilesB`; a unit = 8 tiles, shared by fA (fB) consecutive waves of a workgroup when the window is split.
+// One launch covers the three tile classes.  Workgroups [0, blocksA) run the CI=8 body on `tilesA`, the next blocksC the
+// two-tiles-per-row CI=4 body on `tilesC`, the rest the CI=4 body on `tilesB`; a unit = 8 class-A / 8 class-B / 16 class-C
+// tiles, shared by f consecutive waves of a workgroup when the window is split.
 template <bool NORM, bool ABANDON>
 __global__ __launch_bounds__(256, 2) void kvm_ed_dot_kernel(edd_args A, const kvm_tile *__restrict__ tilesA, int64_t nA,
-                                                            const kvm_tile *__restrict__ tilesB, int64_t nB, int fA, int fB,
-                                                            int64_t blocksA,
+                                                            const kvm_tile *__restrict__ tilesB, int64_t nB,
+                                                            const kvm_tile *__restrict__ tilesC, int64_t nC, int fA, int fB,
+                                                            int fC, int64_t blocksA, int64_t blocksC,
                                                             const unsigned long long *__restrict__ d_counts,
                                                             int64_t split_units) {
-    if (d_counts) {  // tile lists built on the device (kvm_retile_cnsm_kernel): the launch only knows upper bounds
+    if (d_counts) {  // tile lists built on the device (retile kernels): the launch only knows upper bounds
         nA = (int64_t)d_counts[0];
         nB = (int64_t)d_counts[1];
+        nC = (int64_t)d_counts[2];
         // the grid was sized for a 4-way split of the bounds; split only if the real lists are short
-        const int64_t uA = (nA + EDD_ROWS - 1) / EDD_ROWS, uB = (nB + EDD_ROWS - 1) / EDD_ROWS;
-        fA = fB = (uA + uB <= split_units) ? 4 : 1;
+        const int64_t uA = (nA + EDD_TILES_A - 1) / EDD_TILES_A, uB = (nB + EDD_TILES_B - 1) / EDD_TILES_B,
+                      uC = (nC + EDD_TILES_C - 1) / EDD_TILES_C;
+        fA = fB = fC = (uA + uB + uC <= split_units) ? 4 : 1;
         blocksA = (uA * fA + 3) / 4;
+        blocksC = (uC * fC + 3) / 4;
+        (void)uB;
     }
     // declared as double2 so that the window/query reads are provably 16-B aligned (ds_read_b128)
     __shared__ __attribute__((aligned(256))) double2 lds_all2[4 * EDD_WAVE_LDS / 2];
     const int wave = threadIdx.x >> 6;
     double2 *lds_wave2 = lds_all2 + wave * (EDD_WAVE_LDS / 2);
-    if ((int64_t)blockIdx.x < blocksA) {
-        const int64_t slot = (int64_t)blockIdx.x * 4 + wave, t0 = (slot / fA) * EDD_ROWS;
-        edd_body<8, NORM, ABANDON>(A, tilesA, nA, t0, lds_wave2, (int)(slot % fA), fA, t0 < nA);
+    // launch order = longest units first: class A (a unit over the whole window: 0.50 ms at m = 8192), then class C
+    // (0.35), then class B (0.26)
+    const int64_t blk = (int64_t)blockIdx.x;
+    if (blk < blocksA) {
+        const int64_t slot = blk * 4 + wave, t0 = (slot / fA) * EDD_TILES_A;
+        edd_body<8, 1, NORM, ABANDON>(A, tilesA, nA, t0, lds_wave2, (int)(slot % fA), fA, t0 < nA);
+    } else if (blk < blocksA + blocksC) {
+        const int64_t slot = (blk - blocksA) * 4 + wave, t0 = (slot / fC) * EDD_TILES_C;
+        edd_body<4, 2, NORM, ABANDON>(A, tilesC, nC, t0, lds_wave2, (int)(slot % fC), fC, t0 < nC);
     } else {
-        const int64_t slot = ((int64_t)blockIdx.x - blocksA) * 4 + wave, t0 = (slot / fB) * EDD_ROWS;
-        if (d_counts && ((int64_t)blockIdx.x - blocksA) * 4 / fB * EDD_ROWS >= nB) return;  // whole workgroup past the list
-        edd_body<4, NORM, ABANDON>(A, tilesB, nB, t0, lds_wave2, (int)(slot % fB), fB, t0 < nB);
+        const int64_t slot = (blk - blocksA - blocksC) * 4 + wave, t0 = (slot / fB) * EDD_TILES_B;
+        if (d_counts && (blk - blocksA - blocksC) * 4 / fB * EDD_TILES_B >= nB) return;  // whole workgroup past the list
+        edd_body<4, 1, NORM, ABANDON>(A, tilesB, nB, t0, lds_wave2, (int)(slot % fB), fB, t0 < nB);
     }
 }
 
@@ -664,7 +750,8 @@ static double edd_finish(double parts, double d, double g1, double t1, double g2
 // Modelled makespan (in class-A unit times) of unitsA / unitsB units split fA / fB ways on `slots` wave slots:
 // class-A parts first (list order = launch order), then class-B parts into the slots as they free up.
 static double edd_makespan(double unitsA, double unitsB, int fA, int fB, double slots) {
-    const double costB = 0.6;  // measured: a CI=4 unit takes ~0.6 of a CI=8 unit
+    const double costB = 0.53;  // measured (profiles/ed_class_cost.py): a class-B unit takes 0.53 of a class-A unit; class-C
+                                // units (0.64) are counted as 1.2 class-B units by the caller
     const double pa = unitsA * fA, da = 1.0 / fA;
     const double full = std::floor(pa / slots), rem = pa - full * slots;
     const double t1 = full * da, t2 = rem > 0 ? (full + 1) * da : t1;  // slots - rem free at t1, rem at t2
@@ -673,12 +760,15 @@ static double edd_makespan(double unitsA, double unitsB, int fA, int fB, double 
 }
 
 hipError_t kvm_launch_ed_dot(const double *series, const double2 *prefix, int64_t n, const kvm_query_dev &qd,
-                             const kvm_tile *tilesA, int64_t nA, const kvm_tile *tilesB, int64_t nB, kvm_surv *surv,
+                             const kvm_tile *tilesA, int64_t nA, const kvm_tile *tilesB, int64_t nB,
+                             const kvm_tile *tilesC, int64_t nC, kvm_surv *surv,
                              int64_t cap, unsigned long long *counters, int num_cu, const unsigned long long *d_counts,
                              int32_t *out_off, double *out_dist, int64_t out_cap, hipStream_t s) {
     (void)n;
-    if (nA + nB <= 0) return hipSuccess;
-    const int64_t unitsA = (nA + EDD_ROWS - 1) / EDD_ROWS, unitsB = (nB + EDD_ROWS - 1) / EDD_ROWS;
+    if (nA + nB + nC <= 0) return hipSuccess;
+    const int64_t unitsA = (nA + EDD_TILES_A - 1) / EDD_TILES_A, unitsB = (nB + EDD_TILES_B - 1) / EDD_TILES_B,
+                  unitsC = (nC + EDD_TILES_C - 1) / EDD_TILES_C;
+    const int64_t unitsS = unitsB + unitsC;  // the short units: one split factor for both classes
     // Window split (see edd_body): only worth it while the units are few compared with the 8 wave slots per CU, and
     // impossible with early abandon (waves leave early).  Pick the split pair with the smallest modelled makespan.
     int fA = 1, fB = 1;
@@ -689,30 +779,31 @@ hipError_t kvm_launch_ed_dot(const double *series, const double2 *prefix, int64_
         // filter leaves a few hundred units for 2048 wave slots): the grid covers a 4-way split of the bounds and the
         // kernel decides from the real counts (early abandon: only when the list cannot fill the chip anyway)
         split_units = -1;  // (bounds too large to size the grid for a split: the kernel then never splits)
-        if ((double)(unitsA + unitsB) < 16.0 * slots) {
+        if ((double)(unitsA + unitsS) < 16.0 * slots) {
             fA = fB = 4;
             split_units = qd.early_abandon ? (int64_t)(slots / 2) : (int64_t)(4 * slots);
         }
     } else if (qd.early_abandon) {
         // unit durations are unpredictable; split only when the list cannot fill the chip anyway (latency-bound)
-        if ((double)(unitsA + unitsB) * 4.0 <= slots) fA = fB = 4;
-        else if ((double)(unitsA + unitsB) * 2.0 <= slots) fA = fB = 2;
-    } else if ((double)(unitsA + unitsB) < 16.0 * slots) {
+        if ((double)(unitsA + unitsS) * 4.0 <= slots) fA = fB = 4;
+        else if ((double)(unitsA + unitsS) * 2.0 <= slots) fA = fB = 2;
+    } else if ((double)(unitsA + unitsS) < 16.0 * slots) {
         // (the model costs a few microseconds of the host's critical path: remember the last shape -- a query stream
         // over one index tends to repeat it)
-        struct memo_t { int64_t a, b; int cu, fa, fb; };
-        static thread_local memo_t memo = {-1, -1, 0, 1, 1};
-        if (memo.a == unitsA && memo.b == unitsB && memo.cu == num_cu) {
+        struct memo_t { int64_t a, b, c; int cu, fa, fb; };
+        static thread_local memo_t memo = {-1, -1, -1, 0, 1, 1};
+        const double unitsBeq = (double)unitsB + 1.2 * (double)unitsC;
+        if (memo.a == unitsA && memo.b == unitsB && memo.c == unitsC && memo.cu == num_cu) {
             fA = memo.fa;
             fB = memo.fb;
         } else {
             double best = 1e300;
             for (int a = 1; a <= 4; a *= 2)
                 for (int b = 1; b <= 4; b *= 2) {
-                    const double t = edd_makespan((double)unitsA, (double)unitsB, a, b, slots);
+                    const double t = edd_makespan((double)unitsA, unitsBeq, a, b, slots);
                     if (t < best - 1e-9) best = t, fA = a, fB = b;
                 }
-            memo = {unitsA, unitsB, num_cu, fA, fB};
+            memo = {unitsA, unitsB, unitsC, num_cu, fA, fB};
         }
     }
     if (const char *e = getenv("KVM_ED_SPLIT")) {  // experiments: "fA,fB"
@@ -720,16 +811,26 @@ hipError_t kvm_launch_ed_dot(const double *series, const double2 *prefix, int64_
         if (sscanf(e, "%d,%d", &a, &b) == 2 && (a == 1 || a == 2 || a == 4) && (b == 1 || b == 2 || b == 4))
             fA = a, fB = b;
         if (getenv("KVM_TRACE"))
-            fprintf(stderr, "[kvm] ed_dot unitsA %lld unitsB %lld split %d,%d model %.3f (1,1: %.3f)\n", (long long)unitsA,
-                    (long long)unitsB, fA, fB, edd_makespan((double)unitsA, (double)unitsB, fA, fB, slots),
-                    edd_makespan((double)unitsA, (double)unitsB, 1, 1, slots));
+            fprintf(stderr, "[kvm] ed_dot unitsA %lld unitsB %lld unitsC %lld split %d,%d\n", (long long)unitsA, (long long)unitsB,
+                    (long long)unitsC, fA, fB);
     }
-    const int64_t blocksA = (unitsA * fA + 3) / 4, blocksB = (unitsB * fB + 3) / 4;
-    dim3 grid((unsigned)(blocksA + blocksB)), block(256);
+    const int fC = fB;
+    int64_t blocksA = (unitsA * fA + 3) / 4, blocksB = (unitsB * fB + 3) / 4, blocksC = (unitsC * fC + 3) / 4;
+    if (d_counts) {
+        // device-built lists: nA = nB = nC = the number of tiles that were trimmed, and every trimmed tile lands in exactly
+        // one class, so the three lists together hold at most nA tiles = nA / 8 (+ one partly filled unit per class)
+        // units.  The kernel lays the classes out from the real counts; the grid only has to cover that total (workgroups
+        // that find nothing return at once, but each of them still has to be given its 63 KB of LDS first).
+        static_assert(KVM_EDA_MIN == KVM_EDB_TILE + 1u, "a trimmed tile must fall into exactly one class for this bound");
+        const int64_t units_total = (nA + EDD_TILES_A - 1) / EDD_TILES_A + 3;
+        blocksA = (units_total * fA + 3) / 4 + 3;
+        blocksB = blocksC = 0;
+    }
+    dim3 grid((unsigned)(blocksA + blocksB + blocksC)), block(256);
     edd_args A{series, prefix, qd, surv, cap, counters, out_off, out_dist, out_cap};
 #define LAUNCH(NORM, AB) \
-    hipLaunchKernelGGL((kvm_ed_dot_kernel<NORM, AB>), grid, block, 0, s, A, tilesA, nA, tilesB, nB, fA, fB, blocksA, d_counts, \
-                       split_units)
+    hipLaunchKernelGGL((kvm_ed_dot_kernel<NORM, AB>), grid, block, 0, s, A, tilesA, nA, tilesB, nB, tilesC, nC, fA, fB, fC, blocksA, \
+                       blocksC, d_counts, split_units)
     if (qd.normalised) {
         if (qd.early_abandon) LAUNCH(true, true); else LAUNCH(true, false);
     } else {

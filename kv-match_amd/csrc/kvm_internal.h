@@ -27,7 +27,8 @@ struct kvm_run {
     int32_t start;      // first window start offset (1-based)
     int32_t count;      // number of consecutive offsets
     int64_t tile_base;  // index of the run's first tile in the tile list (class A list in hybrid mode)
-    int64_t tile_base_b;  // hybrid ED tiling only: index of the run's class-B tile (its <= 32-candidate remainder), or -1
+    int64_t tile_base_b;  // hybrid ED tiling only: index of the run's class-B tile (the first <= 32 of its remainder), or -1
+    int64_t tile_base_c;  // ... of its class-C tile (the last <= 16 of its remainder), or -1
     int64_t win_base;   // ordinal of the run's first window among all windows of the query (exclusive prefix of counts)
 };
 
@@ -123,18 +124,39 @@ struct kvm_plan_item {
     uint32_t c;        // windows (0: clipped away)
     uint32_t tiles_a;  // tiles (class A tiles in hybrid mode)
     uint32_t tiles_b;  // hybrid mode: 1 if the run has a class-B remainder tile
+    uint32_t tiles_c;  // hybrid mode: 1 if the run has a class-C remainder tile
 };
+// Tile classes of the correlation-form ED pruner (kvm_ed_dot.hip): class A = up to 64 consecutive candidates (one row of
+// 8 lanes x 8 candidates), class B = up to 32 (8 lanes x 4), class C = up to 16 (half a row: 4 lanes x 4; a row holds two
+// unrelated class-C tiles).  What is left of a run after its full 64-candidate tiles (rem = count mod 64) becomes
+//     rem >= KVM_EDA_MIN (33): one more class-A tile      17 .. 32: one class-B tile      1 .. 16: one class-C tile
+// (measured, profiles/ed_class_cost.py: per lane-slot classes A and B cost the same, class C 1.2 x as much because its
+// chunks are half as long -- a win below 17 candidates only; a partly filled class-A tile runs faster than a full one,
+// so cutting 33..48 into a class-B and a class-C tile buys nothing, which KVM_EDA_MIN = 49 would do).  The same rule cuts
+// the trimmed tiles of the device-built lists (retile kernels).
+#define KVM_PLAN_SUMS_BYTES 40  // sizeof(plan_sums) of kvm_common.hip: per-block totals of kvm_launch_plan_runs
+#define KVM_EDB_TILE 32u
+#define KVM_EDC_TILE 16u
+#define KVM_EDA_MIN 33u
 #ifdef __HIPCC__
 __host__ __device__
 #endif
-static inline void kvm_plan_tiles(uint32_t c, bool hybrid, int tile_log2, uint32_t &tiles_a, uint32_t &tiles_b) {
-    if (hybrid) {  // correlation-form ED pruner: 64-candidate tiles + <= 32-candidate remainders (kvm_ed_dot.hip)
-        const uint32_t rem = c & 63u;
-        tiles_a = (c >> 6) + (rem > 32u ? 1u : 0u);
-        tiles_b = (rem - 1u) < 32u ? 1u : 0u;
+static inline void kvm_ed_remainder_classes(uint32_t rem, uint32_t &a, uint32_t &b, uint32_t &c) {
+    a = rem >= KVM_EDA_MIN ? 1u : 0u;
+    b = (rem > KVM_EDC_TILE && rem < KVM_EDA_MIN) ? 1u : 0u;
+    c = (rem >= 1u && (rem <= KVM_EDC_TILE || (rem > KVM_EDB_TILE && rem < KVM_EDA_MIN))) ? 1u : 0u;
+}
+#ifdef __HIPCC__
+__host__ __device__
+#endif
+static inline void kvm_plan_tiles(uint32_t c, bool hybrid, int tile_log2, uint32_t &tiles_a, uint32_t &tiles_b, uint32_t &tiles_c) {
+    if (hybrid) {
+        uint32_t a1;
+        kvm_ed_remainder_classes(c & 63u, a1, tiles_b, tiles_c);
+        tiles_a = (c >> 6) + a1;
     } else {
         tiles_a = (c + (1u << tile_log2) - 1u) >> tile_log2;
-        tiles_b = 0u;
+        tiles_b = tiles_c = 0u;
     }
 }
 #ifdef __HIPCC__
@@ -149,7 +171,7 @@ static inline kvm_plan_item kvm_plan_interval(int64_t l, int64_t r, int64_t shif
     it.lo = lo;
     it.c64 = c64;
     it.c = c64 > 0 ? (uint32_t)c64 : 0u;
-    kvm_plan_tiles(it.c, hybrid, tile_log2, it.tiles_a, it.tiles_b);
+    kvm_plan_tiles(it.c, hybrid, tile_log2, it.tiles_a, it.tiles_b, it.tiles_c);
     return it;
 }
 // `chunk_lo` / `chunk_hi` (optional, per interval; may be pinned host memory): the data range [lo, hi] (1-based points) of
@@ -164,9 +186,9 @@ hipError_t kvm_launch_set_u64(unsigned long long *a, unsigned long long va, unsi
                               hipStream_t s);
 hipError_t kvm_launch_expand_tiles(const kvm_run *runs, int64_t n_runs, int32_t tile_max, kvm_tile *tiles,
                                    unsigned long long *counters, int32_t *run_maxk, hipStream_t s);
-// hybrid ED tiling: class A = 64-candidate tiles (full tiles and remainders > 32), class B = remainders <= 32
+// hybrid ED tiling: classes A / B / C of kvm_ed_remainder_classes
 hipError_t kvm_launch_expand_tiles_hybrid(const kvm_run *runs, int64_t n_runs, kvm_tile *tilesA, kvm_tile *tilesB,
-                                          unsigned long long *counters, int32_t *run_maxk, hipStream_t s);
+                                          kvm_tile *tilesC, unsigned long long *counters, int32_t *run_maxk, hipStream_t s);
 hipError_t kvm_launch_prefix(const double *x, double2 *prefix, int64_t n, hipStream_t s);
 // counters + the first `spec` answers, stored straight into device-mapped pinned host memory:
 // [KVM_CNT_TOTAL x u64 | spec x int32 | spec x f64]
@@ -193,7 +215,8 @@ struct kvm_query_dev {
     // correlation-form pruner (kvm_ed_dot.hip): statistics of the device query q[] (raw for RSM, zQ for cNSM)
     double q_mean;          // mean of q
     const double *qc;       // q - q_mean, device, m entries (+ KVM_SERIES_PAD spare)
-    const double2 *q_pref;  // q_pref[t] = { sum_{j < t*ED4_JC} (q_j - q_mean), sum_{j < t*ED4_JC} (q_j - q_mean)^2 }, t = 0..nchunks
+    const double2 *q_pref;  // q_pref[t] = { sum_{j < t*ED16_JC} (q_j - q_mean), sum_{j < t*ED16_JC} (q_j - q_mean)^2 }, t = 0 .. 2*ceil(m/ED4_JC)
+                            // (class C chunks; a class B chunk is two of them; entries past m hold the totals)
     const double2 *q_pref8; // the same at ED8_JC granularity
     const double *qT;       // qc zero-padded to whole JL_CHUNKs, lane-transposed for kvm_ed_jl.hip (see there)
 };
@@ -210,19 +233,22 @@ hipError_t kvm_launch_ed_tiled(const double *series, const double2 *prefix, int6
 hipError_t kvm_launch_ed_jl(const double *series, const double2 *prefix, int64_t n, const kvm_query_dev &qd,
                             const kvm_tile *tiles, int64_t n_tiles, kvm_surv *surv, int64_t cap,
                             unsigned long long *counters, int num_cu, hipStream_t s);
-#define ED4_JC 160  // chunk lengths of the correlation-form pruner (also the granularity of kvm_query_dev::q_pref / q_pref8):
-#define ED8_JC 128  // 4 candidates per lane / 8 candidates per lane
+#define ED4_JC 160  // chunk lengths of the correlation-form pruner (also the granularity of kvm_query_dev::q_pref / q_pref8 /
+#define ED8_JC 128  // q_pref16): class B (4 candidates per lane), class A (8 per lane), class C (4 per lane, two 16-candidate
+#define ED16_JC 80  // tiles per row)
 hipError_t kvm_launch_ed_dot(const double *series, const double2 *prefix, int64_t n, const kvm_query_dev &qd,
-                             const kvm_tile *tilesA, int64_t nA, const kvm_tile *tilesB, int64_t nB, kvm_surv *surv,
+                             const kvm_tile *tilesA, int64_t nA, const kvm_tile *tilesB, int64_t nB,
+                             const kvm_tile *tilesC, int64_t nC, kvm_surv *surv,
                              int64_t cap, unsigned long long *counters, int num_cu, const unsigned long long *d_counts,
                              int32_t *out_off, double *out_dist, int64_t out_cap, hipStream_t s);
 // cNSM: 64-candidate tiles -> trimmed class-A / class-B tile lists of the candidates passing the guarded (alpha, beta)
-// filter; the list lengths go to d_counts[0..1] (kvm_launch_ed_dot then takes nA, nB as upper bounds)
+// filter; the list lengths go to d_counts[0..2] (kvm_launch_ed_dot then takes nA, nB, nC as upper bounds)
 hipError_t kvm_launch_retile_rsm(const double *series, const kvm_query_dev &qd, const kvm_tile *tiles, int64_t n_tiles,
-                                 kvm_tile *tilesA, kvm_tile *tilesB, unsigned long long *d_counts, hipStream_t s);
+                                 kvm_tile *tilesA, kvm_tile *tilesB, kvm_tile *tilesC, unsigned long long *d_counts,
+                                 hipStream_t s);
 hipError_t kvm_launch_retile_cnsm(const double *series, const double2 *prefix, const kvm_query_dev &qd, const kvm_tile *tiles,
-                                  int64_t n_tiles, kvm_tile *tilesA, kvm_tile *tilesB, unsigned long long *d_counts,
-                                  hipStream_t s);
+                                  int64_t n_tiles, kvm_tile *tilesA, kvm_tile *tilesB, kvm_tile *tilesC,
+                                  unsigned long long *d_counts, hipStream_t s);
 // Exact final pass (kvm_exact.hip)
 hipError_t kvm_launch_exact_ed(const double *series, const kvm_query_dev &qd, const double *q_exact,
                                const int32_t *order, const kvm_surv *surv, const unsigned long long *d_n_surv,
@@ -299,7 +325,8 @@ hipError_t kvm_launch_dtw_dp(const double *series, int64_t n, const kvm_query_de
 #define KVM_CNT_REPLAY_RUNS 11        // runs queued for the running-sum replay
 #define KVM_CNT_TILES_A 12            // cNSM-ED: trimmed tile lists built on the device (kvm_retile_cnsm_kernel)
 #define KVM_CNT_TILES_B 13
-#define KVM_CNT_AMBIG 14              // DTW: candidates handed to the sequential reference-ordered path
+#define KVM_CNT_TILES_C 14
+#define KVM_CNT_AMBIG 15              // DTW: candidates handed to the sequential reference-ordered path
 #define KVM_CNT_TOTAL 16
 
 // kvm_index.hip: index build step 1 on the device
