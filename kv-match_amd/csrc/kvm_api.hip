@@ -921,8 +921,7 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
         for (size_t t = (size_t)((m + ED16_JC - 1) / ED16_JC); t <= (size_t)2 * nchunks4; t++) qpref[t] = make_double2(p1, p2);
         qpref8[(size_t)nchunks8] = make_double2(p1, p2);
     }
-    // (device-built class lists of the ED pruner: each trimmed tile leaves at most one tile per class)
-    const size_t tbytes = (size_t)(retile ? 4 * pl.n_tiles : dtw ? 3 * pl.n_tiles : pl.n_tiles + pl.n_tiles_b + pl.n_tiles_c) * sizeof(kvm_tile);
+    const size_t tbytes = (size_t)((retile || dtw) ? 3 * pl.n_tiles : pl.n_tiles + pl.n_tiles_b + pl.n_tiles_c) * sizeof(kvm_tile);
     // (KVM_SERIES_PAD spare doubles after q: the tiled ED kernel stages whole query chunks without bounds checks)
     if ((rc = ensure(ctx, ctx->b_tiles, tbytes + 64))) return rc;
     if ((rc = ensure(ctx, ctx->b_counters, KVM_CNT_TOTAL * sizeof(unsigned long long)))) return rc;
@@ -1017,14 +1016,14 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
         if ((rc = ensure(ctx, ctx->b_cands, (size_t)pl.windows * sizeof(kvm_surv) + 64))) return rc;
         kvm_surv *surv = (kvm_surv *)ctx->b_cands.p;
         if (retile) {
-            kvm_tile *tA = (kvm_tile *)ctx->b_tiles.p + pl.n_tiles, *tB = tA + pl.n_tiles, *tC = tB + pl.n_tiles;
+            kvm_tile *tA = (kvm_tile *)ctx->b_tiles.p + pl.n_tiles, *tB = tA + pl.n_tiles;
             if (retile_rsm)
-                HIPCHK(ctx, kvm_launch_retile_rsm(ctx->d_series, qd, d_tiles, pl.n_tiles, tA, tB, tC, counters + KVM_CNT_TILES_A,
+                HIPCHK(ctx, kvm_launch_retile_rsm(ctx->d_series, qd, d_tiles, pl.n_tiles, tA, tB, counters + KVM_CNT_TILES_A,
                                                   stream));
             else
-                HIPCHK(ctx, kvm_launch_retile_cnsm(ctx->d_series, ctx->d_prefix, qd, d_tiles, pl.n_tiles, tA, tB, tC,
+                HIPCHK(ctx, kvm_launch_retile_cnsm(ctx->d_series, ctx->d_prefix, qd, d_tiles, pl.n_tiles, tA, tB,
                                                    counters + KVM_CNT_TILES_A, stream));
-            HIPCHK(ctx, kvm_launch_ed_dot(ctx->d_series, ctx->d_prefix, ctx->n, qd, tA, pl.n_tiles, tB, pl.n_tiles, tC, pl.n_tiles, surv,
+            HIPCHK(ctx, kvm_launch_ed_dot(ctx->d_series, ctx->d_prefix, ctx->n, qd, tA, pl.n_tiles, tB, pl.n_tiles, tB, 0, surv,
                                           pl.windows, counters, ctx->num_cu, counters + KVM_CNT_TILES_A, out.d_off, out.d_dist, out.cap,
                                           stream));
         } else if (ed_kernel == 4)

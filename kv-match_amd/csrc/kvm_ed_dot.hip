@@ -22,8 +22,8 @@
 //            only half the idle lanes on a short remainder.
 //   CI = 4, two tiles per row : class C, 16-candidate tiles, TWO unrelated tiles per row (lanes 0-3 / 4-7, each half of
 //            the row's LDS region staged from its own tile's position), chunk 80 -- the per-chunk work (27 loads, 27 LDS
-//            writes, ring start-up) is amortised over half as many points, so a unit of 16 such tiles takes 1.2 x a
-//            class-B unit of 8 tiles (0.318 against 0.264 ms): worth it for remainders of <= 16 candidates only
+//            writes, ring start-up) is amortised over half as many points, so a unit of 16 such tiles takes 1.3 x a
+//            class-B unit of 8 tiles (0.35 against 0.26 ms): worth it for remainders of <= 16 candidates only
 //            (kvm_ed_remainder_classes, profiles/ed_class_cost.py).
 // Lane stride inside a row is CI*8 B; rows are displaced by 16 B against each other ((r>>1)&1 for CI=4, r&3 for CI=8) so
 // that every 16-lane group of ds_read_b128 -- which mixes lanes of four rows -- covers 16 distinct 16-B slots
@@ -50,7 +50,7 @@ typedef double ed4_d2 __attribute__((ext_vector_type(2)));
                                              // wave's region stays a multiple of 256 B), in doubles
 #define EDD_WAVE_LDS (EDD_ROWS * EDD_RS + EDD_ROWLEN + EDD_TAB)
 static_assert(ED16_JC + 16 <= EDD_SUB_LEN && 2 * EDD_SUB_LEN == EDD_ROWLEN && ED4_JC + 8 * 4 <= EDD_ROWLEN && ED8_JC + 8 * 8 <= EDD_ROWLEN, "chunk + tile must fit the staged (half) row");
-static_assert(EDD_SUB_OFF >= EDD_SUB_LEN && EDD_SUB_OFF + EDD_SUB_LEN + 2 <= EDD_RS && (EDD_SUB_OFF * 8) % 256 == 128, "class-B half rows");
+static_assert(EDD_SUB_OFF >= EDD_SUB_LEN && EDD_SUB_OFF + EDD_SUB_LEN + 2 <= EDD_RS && (EDD_SUB_OFF * 8) % 256 == 128, "class-C half rows");
 static_assert(4 * EDD_WAVE_LDS * 8 <= 65536 && EDD_WAVE_LDS % 2 == 0 && EDD_RS % 2 == 0 && (EDD_RS * 8) % 256 == 0, "LDS");
 static_assert(ED4_JC % 16 == 0 && ED8_JC % 16 == 0 && ED16_JC % 16 == 0, "chunks are whole groups of 16 points (4 sub-steps of the register ring)");
 
@@ -517,13 +517,13 @@ __device__ __forceinline__ void edd_body(const edd_args &A, const kvm_tile *__re
 }
 
 // ---- tile trimming shared by the two retile kernels: a tile keeps the span of its surviving candidates (bit l of `mask` =
-// lane l's candidate survives), goes to class A, B and / or C by kvm_ed_remainder_classes, and is collected in LDS; one set of global
+// lane l's candidate survives), goes to class A (33..64) or B (1..32), and is collected in LDS; one pair of global
 // atomics per workgroup appends the collected tiles (one atomic per tile on a single address cost 0.3 ms at 24 000 tiles).
 template <int CAP>
 struct retile_out {
-    kvm_tile a[CAP], b[CAP], c[CAP];  // (a trimmed tile leaves at most one tile per class)
-    int na, nb, nc;
-    unsigned long long base_a, base_b, base_c;
+    kvm_tile a[CAP], b[CAP];
+    int na, nb;
+    unsigned long long base_a, base_b;
 };
 template <int CAP>
 __device__ __forceinline__ void retile_collect(retile_out<CAP> &o, const kvm_tile &tl, unsigned long long mask) {
@@ -544,17 +544,15 @@ __device__ __forceinline__ void retile_collect(retile_out<CAP> &o, const kvm_til
 // (all threads of the workgroup; list order is whatever the atomics give)
 template <int CAP>
 __device__ __forceinline__ void retile_flush(retile_out<CAP> &o, kvm_tile *__restrict__ tilesA, kvm_tile *__restrict__ tilesB,
-                                             kvm_tile *__restrict__ tilesC, unsigned long long *__restrict__ d_counts) {
+                                             unsigned long long *__restrict__ d_counts) {
     __syncthreads();
     if (threadIdx.x == 0) {
         o.base_a = o.na ? atomicAdd(&d_counts[0], (unsigned long long)o.na) : 0;
         o.base_b = o.nb ? atomicAdd(&d_counts[1], (unsigned long long)o.nb) : 0;
-        o.base_c = o.nc ? atomicAdd(&d_counts[2], (unsigned long long)o.nc) : 0;
     }
     __syncthreads();
     for (int i = threadIdx.x; i < o.na; i += blockDim.x) tilesA[o.base_a + i] = o.a[i];
     for (int i = threadIdx.x; i < o.nb; i += blockDim.x) tilesB[o.base_b + i] = o.b[i];
-    for (int i = threadIdx.x; i < o.nc; i += blockDim.x) tilesC[o.base_c + i] = o.c[i];
 }
 
 // cNSM: trim every 64-candidate tile to the span of its candidates that pass the guarded (alpha, beta) filter and sort
@@ -568,11 +566,10 @@ __global__ __launch_bounds__(256) void kvm_retile_cnsm_kernel(const double *__re
                                                               const double2 *__restrict__ prefix, kvm_query_dev qd,
                                                               const kvm_tile *__restrict__ tiles, int64_t n_tiles,
                                                               kvm_tile *__restrict__ tilesA, kvm_tile *__restrict__ tilesB,
-                                                              kvm_tile *__restrict__ tilesC,
                                                               unsigned long long *__restrict__ d_counts) {
     __shared__ retile_out<RETILE_PER_BLOCK> out;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) out.na = out.nb = out.nc = 0;
+    if (threadIdx.x == 0) out.na = out.nb = 0;
     __syncthreads();
     const int64_t t0 = (int64_t)blockIdx.x * RETILE_PER_BLOCK + wave * (RETILE_PER_BLOCK / 4);
     for (int i = 0; i < RETILE_PER_BLOCK / 4; i++) {
@@ -587,7 +584,7 @@ __global__ __launch_bounds__(256) void kvm_retile_cnsm_kernel(const double *__re
         }
         retile_collect(out, tl, __ballot(ok));
     }
-    retile_flush(out, tilesA, tilesB, tilesC, d_counts);
+    retile_flush(out, tilesA, tilesB, d_counts);
 }
 
 // RSM with the reference's early abandoning: the same trimming with the first EDR_HEAD points of the window as the
@@ -602,11 +599,10 @@ __global__ __launch_bounds__(256) void kvm_retile_cnsm_kernel(const double *__re
 __global__ __launch_bounds__(256) void kvm_retile_rsm_kernel(const double *__restrict__ series, kvm_query_dev qd,
                                                              const kvm_tile *__restrict__ tiles, int64_t n_tiles,
                                                              kvm_tile *__restrict__ tilesA, kvm_tile *__restrict__ tilesB,
-                                                             kvm_tile *__restrict__ tilesC,
                                                              unsigned long long *__restrict__ d_counts) {
     __shared__ retile_out<EDR_PER_BLOCK> out;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) out.na = out.nb = out.nc = 0;
+    if (threadIdx.x == 0) out.na = out.nb = 0;
     __syncthreads();
     const int head = qd.m < EDR_HEAD ? qd.m : EDR_HEAD;
     const double lim = qd.eps2 * (1.0 + 1e-9);  // (fused, other summation order than the reference's loop: < 1e-13 relative)
@@ -660,24 +656,23 @@ __global__ __launch_bounds__(256) void kvm_retile_rsm_kernel(const double *__res
         const bool ok = lane < tl.count && !(a0 + a1 > lim);
         retile_collect(out, tl, __ballot(ok));
     }
-    retile_flush(out, tilesA, tilesB, tilesC, d_counts);
+    retile_flush(out, tilesA, tilesB, d_counts);
 }
 
 hipError_t kvm_launch_retile_rsm(const double *series, const kvm_query_dev &qd, const kvm_tile *tiles, int64_t n_tiles,
-                                 kvm_tile *tilesA, kvm_tile *tilesB, kvm_tile *tilesC, unsigned long long *d_counts,
-                                 hipStream_t s) {
+                                 kvm_tile *tilesA, kvm_tile *tilesB, unsigned long long *d_counts, hipStream_t s) {
     if (n_tiles <= 0) return hipSuccess;
     hipLaunchKernelGGL(kvm_retile_rsm_kernel, dim3((unsigned)((n_tiles + EDR_PER_BLOCK - 1) / EDR_PER_BLOCK)), dim3(256),
-                       0, s, series, qd, tiles, n_tiles, tilesA, tilesB, tilesC, d_counts);
+                       0, s, series, qd, tiles, n_tiles, tilesA, tilesB, d_counts);
     return hipGetLastError();
 }
 
 hipError_t kvm_launch_retile_cnsm(const double *series, const double2 *prefix, const kvm_query_dev &qd, const kvm_tile *tiles,
-                                  int64_t n_tiles, kvm_tile *tilesA, kvm_tile *tilesB, kvm_tile *tilesC,
-                                  unsigned long long *d_counts, hipStream_t s) {
+                                  int64_t n_tiles, kvm_tile *tilesA, kvm_tile *tilesB, unsigned long long *d_counts,
+                                  hipStream_t s) {
     if (n_tiles <= 0) return hipSuccess;
     hipLaunchKernelGGL(kvm_retile_cnsm_kernel, dim3((unsigned)((n_tiles + RETILE_PER_BLOCK - 1) / RETILE_PER_BLOCK)), dim3(256),
-                       0, s, series, prefix, qd, tiles, n_tiles, tilesA, tilesB, tilesC, d_counts);
+                       0, s, series, prefix, qd, tiles, n_tiles, tilesA, tilesB, d_counts);
     return hipGetLastError();
 }
 
@@ -817,11 +812,10 @@ hipError_t kvm_launch_ed_dot(const double *series, const double2 *prefix, int64_
     const int fC = fB;
     int64_t blocksA = (unitsA * fA + 3) / 4, blocksB = (unitsB * fB + 3) / 4, blocksC = (unitsC * fC + 3) / 4;
     if (d_counts) {
-        // device-built lists: nA = nB = nC = the number of tiles that were trimmed, and every trimmed tile lands in exactly
-        // one class, so the three lists together hold at most nA tiles = nA / 8 (+ one partly filled unit per class)
-        // units.  The kernel lays the classes out from the real counts; the grid only has to cover that total (workgroups
+        // device-built lists (classes A and B only): nA = nB = the number of tiles that were trimmed, and every trimmed
+        // tile lands in exactly one class, so the lists together hold at most nA tiles = nA / 8 (+ one partly filled
+        // unit per class) units.  The kernel lays the classes out from the real counts; the grid only has to cover that total (workgroups
         // that find nothing return at once, but each of them still has to be given its 63 KB of LDS first).
-        static_assert(KVM_EDA_MIN == KVM_EDB_TILE + 1u, "a trimmed tile must fall into exactly one class for this bound");
         const int64_t units_total = (nA + EDD_TILES_A - 1) / EDD_TILES_A + 3;
         blocksA = (units_total * fA + 3) / 4 + 3;
         blocksB = blocksC = 0;

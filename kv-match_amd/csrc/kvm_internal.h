@@ -132,8 +132,8 @@ struct kvm_plan_item {
 //     rem >= KVM_EDA_MIN (33): one more class-A tile      17 .. 32: one class-B tile      1 .. 16: one class-C tile
 // (measured, profiles/ed_class_cost.py: per lane-slot classes A and B cost the same, class C 1.2 x as much because its
 // chunks are half as long -- a win below 17 candidates only; a partly filled class-A tile runs faster than a full one,
-// so cutting 33..48 into a class-B and a class-C tile buys nothing, which KVM_EDA_MIN = 49 would do).  The same rule cuts
-// the trimmed tiles of the device-built lists (retile kernels).
+// so cutting 33..48 into a class-B and a class-C tile buys nothing, which KVM_EDA_MIN = 49 would do).  The device-built
+// lists of the retile kernels use classes A and B only (they are latency-bound: see retile_collect).
 #define KVM_PLAN_SUMS_BYTES 40  // sizeof(plan_sums) of kvm_common.hip: per-block totals of kvm_launch_plan_runs
 #define KVM_EDB_TILE 32u
 #define KVM_EDC_TILE 16u
@@ -242,13 +242,12 @@ hipError_t kvm_launch_ed_dot(const double *series, const double2 *prefix, int64_
                              int64_t cap, unsigned long long *counters, int num_cu, const unsigned long long *d_counts,
                              int32_t *out_off, double *out_dist, int64_t out_cap, hipStream_t s);
 // cNSM: 64-candidate tiles -> trimmed class-A / class-B tile lists of the candidates passing the guarded (alpha, beta)
-// filter; the list lengths go to d_counts[0..2] (kvm_launch_ed_dot then takes nA, nB, nC as upper bounds)
+// filter; the list lengths go to d_counts[0..1] (kvm_launch_ed_dot then takes nA, nB as upper bounds; no class C here)
 hipError_t kvm_launch_retile_rsm(const double *series, const kvm_query_dev &qd, const kvm_tile *tiles, int64_t n_tiles,
-                                 kvm_tile *tilesA, kvm_tile *tilesB, kvm_tile *tilesC, unsigned long long *d_counts,
-                                 hipStream_t s);
+                                 kvm_tile *tilesA, kvm_tile *tilesB, unsigned long long *d_counts, hipStream_t s);
 hipError_t kvm_launch_retile_cnsm(const double *series, const double2 *prefix, const kvm_query_dev &qd, const kvm_tile *tiles,
-                                  int64_t n_tiles, kvm_tile *tilesA, kvm_tile *tilesB, kvm_tile *tilesC,
-                                  unsigned long long *d_counts, hipStream_t s);
+                                  int64_t n_tiles, kvm_tile *tilesA, kvm_tile *tilesB, unsigned long long *d_counts,
+                                  hipStream_t s);
 // Exact final pass (kvm_exact.hip)
 hipError_t kvm_launch_exact_ed(const double *series, const kvm_query_dev &qd, const double *q_exact,
                                const int32_t *order, const kvm_surv *surv, const unsigned long long *d_n_surv,
