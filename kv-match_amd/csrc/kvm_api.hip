@@ -858,6 +858,19 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
     }
     rc = build_plan(ctx, cnsm, m, left, right, k, shift, tile_max, hybrid, pl);
     if (rc) return rc;
+    // Class-C tiles (two <= 16-candidate remainders per row, kvm_ed_dot.hip) fill the lanes better but a class-C unit
+    // takes 1.3 x as long as a class-B unit: worth it when the list needs more than one round of the chip's wave slots
+    // (throughput), not when the call lasts as long as its longest unit (latency).  Decided here, from the totals; the
+    // device-side plan follows the same rule (kvm_plan_tiles: hybrid = 2 with class C, 1 without).
+    int hybrid_mode = 0;
+    if (hybrid) {
+        const int64_t units = (pl.n_tiles + 7) / 8 + (pl.n_tiles_b + 7) / 8 + (pl.n_tiles_c + 15) / 16;
+        hybrid_mode = units > (int64_t)ctx->num_cu * 8 ? 2 : 1;
+        if (hybrid_mode == 1) {
+            pl.n_tiles_b += pl.n_tiles_c;
+            pl.n_tiles_c = 0;
+        }
+    }
     if (out.own) {  // capacity: every evaluated window may be an answer
         if ((rc = ensure(ctx, ctx->b_out_off, (size_t)pl.windows * 4 + 64))) return rc;
         if ((rc = ensure(ctx, ctx->b_out_dist, (size_t)pl.windows * 8 + 64))) return rc;
@@ -881,7 +894,7 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
         // (the first plan kernel reads the interval list straight from the pinned staging buffer and leaves the device copy)
         HIPCHK(ctx, kvm_launch_plan_runs(pl.left, pl.right, (int32_t *)((char *)ctx->b_query.p + qbytes),
                                          (int32_t *)((char *)ctx->b_query.p + qbytes + lr_half), k, shift,
-                                         ctx->n - m + 1, hybrid, tile_log2, d_runs_w,
+                                         ctx->n - m + 1, hybrid_mode, tile_log2, d_runs_w,
                                          (char *)ctx->b_query.p + qbytes + lr_bytes + ((rbytes + 31) & ~(size_t)31), stream,
                                          pl.chunk_lo, pl.chunk_hi, d_run_chunk));
     }
@@ -981,7 +994,7 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
     const kvm_run *d_runs = d_runs_w;
     if (rbytes) {
         if (hybrid)
-            HIPCHK(ctx, kvm_launch_expand_tiles_hybrid(d_runs, pl.n_runs, (kvm_tile *)ctx->b_tiles.p,
+            HIPCHK(ctx, kvm_launch_expand_tiles_hybrid(d_runs, pl.n_runs, hybrid_mode, (kvm_tile *)ctx->b_tiles.p,
                                                        (kvm_tile *)ctx->b_tiles.p + pl.n_tiles,
                                                        (kvm_tile *)ctx->b_tiles.p + pl.n_tiles + pl.n_tiles_b,
                                                        (unsigned long long *)ctx->b_counters.p, rws.run_maxk, stream));

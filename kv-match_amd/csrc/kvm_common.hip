@@ -57,7 +57,7 @@ __global__ __launch_bounds__(PLAN_THREADS) void kvm_plan_totals_kernel(const int
         const int32_t l = src_left[p], r = src_right[p];
         left[p] = l;
         right[p] = r;
-        mine = plan_item_sums(kvm_plan_interval(l, r, shift, hi_max, hybrid != 0, tile_log2));
+        mine = plan_item_sums(kvm_plan_interval(l, r, shift, hi_max, hybrid, tile_log2));
     }
     const plan_sums t = plan_block_sum(mine, wave_tot);
     if (threadIdx.x == 0) block_tot[blockIdx.x] = t;
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(PLAN_THREADS) void kvm_plan_runs_kernel(const int32
     const int64_t p = (int64_t)blockIdx.x * PLAN_THREADS + tid;
     kvm_plan_item it;
     it.lo = 1; it.c64 = 0; it.c = 0; it.tiles_a = 0; it.tiles_b = 0; it.tiles_c = 0;
-    if (p < k) it = kvm_plan_interval(left[p], right[p], shift, hi_max, hybrid != 0, tile_log2);
+    if (p < k) it = kvm_plan_interval(left[p], right[p], shift, hi_max, hybrid, tile_log2);
     const plan_sums mine = plan_item_sums(it);
     plan_sums inc = mine;  // inclusive scan inside the wave, then across the wave totals
 #pragma unroll
@@ -139,17 +139,17 @@ __global__ __launch_bounds__(1024) void kvm_plan_scan_kernel(plan_sums *__restri
 
 // `scratch`: 32 B per 256 intervals (block totals)
 hipError_t kvm_launch_plan_runs(const int32_t *src_left, const int32_t *src_right, int32_t *left, int32_t *right, int32_t k,
-                                int32_t shift, int64_t hi_max, bool hybrid, int tile_log2, kvm_run *runs, void *scratch,
+                                int32_t shift, int64_t hi_max, int hybrid, int tile_log2, kvm_run *runs, void *scratch,
                                 hipStream_t s, const int32_t *chunk_lo, const int32_t *chunk_hi, int2 *run_chunk) {
     if (k <= 0) return hipSuccess;
     const int64_t blocks = ((int64_t)k + PLAN_THREADS - 1) / PLAN_THREADS;
     plan_sums *bt = reinterpret_cast<plan_sums *>(scratch);
     hipLaunchKernelGGL(kvm_plan_totals_kernel, dim3((unsigned)blocks), dim3(PLAN_THREADS), 0, s, src_left, src_right, left, right,
-                       k, shift, hi_max, hybrid ? 1 : 0, tile_log2, bt);
+                       k, shift, hi_max, hybrid, tile_log2, bt);
     const int scanned = blocks > PLAN_SCAN_ABOVE;
     if (scanned) hipLaunchKernelGGL(kvm_plan_scan_kernel, dim3(1), dim3(1024), 0, s, bt, blocks);
     hipLaunchKernelGGL(kvm_plan_runs_kernel, dim3((unsigned)blocks), dim3(PLAN_THREADS), 0, s, left, right, k, shift, hi_max,
-                       hybrid ? 1 : 0, tile_log2, bt, scanned, runs, chunk_lo, chunk_hi, run_chunk);
+                       hybrid, tile_log2, bt, scanned, runs, chunk_lo, chunk_hi, run_chunk);
     return hipGetLastError();
 }
 
@@ -194,7 +194,7 @@ hipError_t kvm_launch_bswap64(uint64_t *d, int64_t n, hipStream_t s) {
 // class B and / or to class C by kvm_ed_remainder_classes (the class-B tile takes the first <= 32 candidates of the
 // remainder, the class-C tile the rest).
 __global__ __launch_bounds__(256) void kvm_expand_tiles_hybrid_kernel(const kvm_run *__restrict__ runs, int64_t n_runs,
-                                                                      kvm_tile *__restrict__ tilesA,
+                                                                      int hybrid, kvm_tile *__restrict__ tilesA,
                                                                       kvm_tile *__restrict__ tilesB,
                                                                       kvm_tile *__restrict__ tilesC,
                                                                       unsigned long long *__restrict__ counters,
@@ -208,6 +208,10 @@ __global__ __launch_bounds__(256) void kvm_expand_tiles_hybrid_kernel(const kvm_
     const int full = run.count / 64, rem = run.count % 64;
     uint32_t ra, rb, rc;
     kvm_ed_remainder_classes((uint32_t)rem, ra, rb, rc);
+    if (hybrid == 1) {  // no class C for this list (kvm_plan_tiles): a remainder of <= 16 is a class-B tile
+        rb += rc;
+        rc = 0;
+    }
     const int nA = full + (int)ra;
     for (int t = lane; t < nA; t += 64) {
         kvm_tile tl;
@@ -236,11 +240,11 @@ __global__ __launch_bounds__(256) void kvm_expand_tiles_hybrid_kernel(const kvm_
     }
 }
 
-hipError_t kvm_launch_expand_tiles_hybrid(const kvm_run *runs, int64_t n_runs, kvm_tile *tilesA, kvm_tile *tilesB,
+hipError_t kvm_launch_expand_tiles_hybrid(const kvm_run *runs, int64_t n_runs, int hybrid, kvm_tile *tilesA, kvm_tile *tilesB,
                                           kvm_tile *tilesC, unsigned long long *counters, int32_t *run_maxk, hipStream_t s) {
     if (n_runs <= 0) return hipSuccess;
     hipLaunchKernelGGL(kvm_expand_tiles_hybrid_kernel, dim3((unsigned)((n_runs + 3) / 4)), dim3(256), 0, s, runs, n_runs,
-                       tilesA, tilesB, tilesC, counters, run_maxk);
+                       hybrid, tilesA, tilesB, tilesC, counters, run_maxk);
     return hipGetLastError();
 }
 

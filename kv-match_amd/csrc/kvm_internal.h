@@ -149,11 +149,16 @@ static inline void kvm_ed_remainder_classes(uint32_t rem, uint32_t &a, uint32_t 
 #ifdef __HIPCC__
 __host__ __device__
 #endif
-static inline void kvm_plan_tiles(uint32_t c, bool hybrid, int tile_log2, uint32_t &tiles_a, uint32_t &tiles_b, uint32_t &tiles_c) {
+// `hybrid`: 0 = uniform tiles of 2^tile_log2, 1 = classes A / B (a remainder of <= 16 goes to class B too), 2 = A / B / C
+static inline void kvm_plan_tiles(uint32_t c, int hybrid, int tile_log2, uint32_t &tiles_a, uint32_t &tiles_b, uint32_t &tiles_c) {
     if (hybrid) {
         uint32_t a1;
         kvm_ed_remainder_classes(c & 63u, a1, tiles_b, tiles_c);
         tiles_a = (c >> 6) + a1;
+        if (hybrid == 1) {
+            tiles_b += tiles_c;
+            tiles_c = 0u;
+        }
     } else {
         tiles_a = (c + (1u << tile_log2) - 1u) >> tile_log2;
         tiles_b = tiles_c = 0u;
@@ -162,7 +167,7 @@ static inline void kvm_plan_tiles(uint32_t c, bool hybrid, int tile_log2, uint32
 #ifdef __HIPCC__
 __host__ __device__
 #endif
-static inline kvm_plan_item kvm_plan_interval(int64_t l, int64_t r, int64_t shift, int64_t hi_max, bool hybrid, int tile_log2) {
+static inline kvm_plan_item kvm_plan_interval(int64_t l, int64_t r, int64_t shift, int64_t hi_max, int hybrid, int tile_log2) {
     kvm_plan_item it;
     int64_t lo = l - shift, hi = r - shift;
     lo = lo < 1 ? 1 : lo;
@@ -178,7 +183,7 @@ static inline kvm_plan_item kvm_plan_interval(int64_t l, int64_t r, int64_t shif
 // the chunk the reference fetches for that interval (cNSM engines: greedy-merged chunks, K/NormQueryEngineDtw.java:492-520);
 // copied per non-empty run into `run_chunk` -- where the reference's data envelope is clipped (DTW only).
 hipError_t kvm_launch_plan_runs(const int32_t *src_left, const int32_t *src_right, int32_t *left, int32_t *right, int32_t k,
-                                int32_t shift, int64_t hi_max, bool hybrid, int tile_log2, kvm_run *runs, void *scratch,
+                                int32_t shift, int64_t hi_max, int hybrid, int tile_log2, kvm_run *runs, void *scratch,
                                 hipStream_t s, const int32_t *chunk_lo = nullptr, const int32_t *chunk_hi = nullptr,
                                 int2 *run_chunk = nullptr);
 hipError_t kvm_launch_upload(void *dst, const void *src_pinned, size_t bytes, hipStream_t s);
@@ -187,7 +192,7 @@ hipError_t kvm_launch_set_u64(unsigned long long *a, unsigned long long va, unsi
 hipError_t kvm_launch_expand_tiles(const kvm_run *runs, int64_t n_runs, int32_t tile_max, kvm_tile *tiles,
                                    unsigned long long *counters, int32_t *run_maxk, hipStream_t s);
 // hybrid ED tiling: classes A / B / C of kvm_ed_remainder_classes
-hipError_t kvm_launch_expand_tiles_hybrid(const kvm_run *runs, int64_t n_runs, kvm_tile *tilesA, kvm_tile *tilesB,
+hipError_t kvm_launch_expand_tiles_hybrid(const kvm_run *runs, int64_t n_runs, int hybrid, kvm_tile *tilesA, kvm_tile *tilesB,
                                           kvm_tile *tilesC, unsigned long long *counters, int32_t *run_maxk, hipStream_t s);
 hipError_t kvm_launch_prefix(const double *x, double2 *prefix, int64_t n, hipStream_t s);
 // counters + the first `spec` answers, stored straight into device-mapped pinned host memory:

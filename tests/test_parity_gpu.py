@@ -1032,3 +1032,44 @@ def test_ed_pruner_tile_classes_every_remainder_length(world):
     finally:
         ctx.set_option(kvmatch.OPT_EARLY_ABANDON, 1)
         ctx.load_series(series)
+
+
+def test_ed_pruner_class_c_on_a_long_list_of_short_runs(built):
+    """Class-C tiles (remainders of 1..16 candidates, two per row) are only used when the list needs more than one round of
+    the chip's wave slots (kvm_api.hip: hybrid_mode): 90 000 runs of 1..48 candidates, early abandoning off -> several
+    thousand units of each class, with planted copies of the query inside tiles of every class; bit for bit against
+    the oracle, and the same answers with early abandoning on (device-built lists, classes A and B only)."""
+    import kvmatch
+    from kvmatch import datagen
+    n, m = 3_000_000, 300
+    s = datagen.gen_series(n, seed=99)
+    rng = np.random.default_rng(99)
+    q = s[1_000_000:1_000_000 + m].copy()
+    L, R, pos = [], [], 1
+    while pos + 48 + m < n:
+        ln = int(rng.integers(1, 49))
+        L.append(pos)
+        R.append(pos + ln - 1)
+        pos += ln + int(rng.integers(2, 13))
+    L, R = np.array(L, dtype=np.int32), np.array(R, dtype=np.int32)
+    assert len(L) > 80_000
+    planted = []
+    for i in rng.choice(len(L), 300, replace=False):
+        off = int(rng.integers(L[i], R[i] + 1))
+        if planted and min(abs(off - p) for p in planted) < 2 * m:
+            continue
+        s[off - 1: off - 1 + m] = q + rng.normal(size=m) * 0.01
+        planted.append(off)
+    lens = (R - L + 1)
+    assert (lens <= 16).sum() > 20_000 and ((lens > 16) & (lens <= 32)).sum() > 20_000 and (lens > 32).sum() > 20_000
+    with kvmatch.Phase2Context(0) as ctx:
+        ctx.load_series(s)
+        want = oracle.rsm_ed(s, q, L, R, 0, 2.0)
+        for ab in (0, 1):
+            ctx.set_option(kvmatch.OPT_EARLY_ABANDON, ab)
+            got = kvmatch.QueryEngine(ctx).verify((L, R), 1, q, 2.0)
+            compare(got, want, tag=f"long list of short runs ab={ab}")
+        assert set(planted) <= set(got.offsets.tolist()) and len(planted) > 100
+        ctx.set_option(kvmatch.OPT_EARLY_ABANDON, 0)
+        got = kvmatch.QueryEngine(ctx).verify((L, R), 1, q, 30.0)       # many survivors of the pruner in every class
+        compare(got, oracle.rsm_ed(s, q, L, R, 0, 30.0), tag="long list, wide eps")
