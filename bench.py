@@ -147,6 +147,11 @@ def roofline_block(wl, plans, k_ns, stage_stats, m):
             "hbm_algorithmic_gbs": algo_bytes / ks / 1e9 if ks > 0 else 0.0,
             "hbm_measured_gbs": (traffic / ks / 1e9) if (traffic and ks > 0) else None,
             "hbm_peak_gbs": HBM_PEAK_GBS,
+            "fp64_fma_sustained_tflops": 56.8,
+            "fp64_fma_sustained_source": "profiles/micro/mfma_f64_rate.hip (profiles/r02_mfma_f64_rate.log): a register-only "
+                                         "v_fma_f64 loop at 4 waves/SIMD sustains 56.8 TFLOP/s on this part (54.5 at the 2 "
+                                         "waves/SIMD this kernel runs at; v_mfma_f64_16x16x4 46.6) -- NOT measured by this run; "
+                                         "`peak` stays the vendor figure",
             "note": "bound = fp64 vector pipe: 63 of every 64 algorithmic bytes are served from LDS (tile reuse), so the "
                     "algorithmic-byte rate exceeds the HBM peak by construction; hbm_measured_gbs is the real HBM rate"}
 
