@@ -39,6 +39,10 @@
 
 typedef double ed4_d2 __attribute__((ext_vector_type(2)));
 
+#ifndef EDD_PD
+#define EDD_PD 1  // sub-steps between an LDS read of the hot loop and its first use (1 or 3)
+#endif
+
 #define EDD_ROWS 8
 #define EDD_ROWLEN 192                       // staged points per row per chunk (both configurations)
 #define EDD_LOADS (EDD_ROWLEN / 64)
@@ -327,39 +331,41 @@ __device__ __forceinline__ void edd_body(const edd_args &A, const kvm_tile *__re
         if (more) load_chunk(j0 + JC);
         const int jlim = min(JC, m - j0);
         if (jlim == JC) {
-            // Window registers: a ring of 8 pairs, R[p % 8] = (X[c0 + 2p], X[c0 + 2p + 1]).  Sub-step G (4 points) reads
-            // pairs 2G .. 2G + CI/2 + 1 and, before its arithmetic, issues the LDS reads of the two pairs and the two
-            // query pairs that sub-step G + 1 adds -- into the ring slots that died one sub-step earlier.  Four
-            // sub-steps advance the ring by exactly 8 pairs, so every register index below is a compile-time constant
-            // (no rotation moves), and every LDS read has a sub-step of FMAs (32 / 16 of them) to land.
+            // Window registers: a ring of RING pairs, R[p % RING] = (X[c0 + 2p], X[c0 + 2p + 1]).  Sub-step G (4 points)
+            // reads pairs 2G .. 2G + CI/2 + 1 and, before its arithmetic, issues the LDS reads of the two window pairs and
+            // the two query pairs that sub-step G + PD will add -- into ring slots that died PD sub-steps earlier.  RING/2
+            // sub-steps advance the ring by exactly RING pairs, so every register index below is a compile-time constant
+            // (no rotation moves), and every LDS read has PD sub-steps of FMAs (32 / 16 each) to land.
             constexpr int NP = CI / 2 + 2;
-            ed4_d2 R[8], QA[2], QB[2];
+            constexpr int PD = SUB == 2 ? 1 : EDD_PD;   // (class C: 20 sub-steps per chunk, not a multiple of 8)
+            constexpr int RING = PD == 1 ? 8 : 16, U = RING / 2, NQ = PD + 1;
+            static_assert(NP + 2 * PD <= RING && (JC / 4) % U == 0 && U % NQ == 0, "static ring / query-buffer indices");
+            ed4_d2 R[RING], Q[NQ][2];
 #pragma unroll
-            for (int j = 0; j < NP; j++) R[j] = X2[j];
-            QA[0] = Q2[0];
-            QA[1] = Q2[1];
-            for (int body = 0; body < JC / 16; body++) {
+            for (int j = 0; j < NP + 2 * (PD - 1); j++) R[j] = X2[j];
 #pragma unroll
-                for (int g = 0; g < 4; g++) {
-                    const int G = body * 4 + g;
-                    R[(2 * g + NP) % 8] = X2[2 * G + NP];  // (the last sub-step of a chunk reads past it: staged, unused)
-                    R[(2 * g + NP + 1) % 8] = X2[2 * G + NP + 1];
-                    if (g & 1) {
-                        QA[0] = Q2[2 * G + 2];
-                        QA[1] = Q2[2 * G + 3];
-                    } else {
-                        QB[0] = Q2[2 * G + 2];
-                        QB[1] = Q2[2 * G + 3];
-                    }
+            for (int d = 0; d < PD; d++) {
+                Q[d][0] = Q2[2 * d];
+                Q[d][1] = Q2[2 * d + 1];
+            }
+            for (int body = 0; body < JC / 4 / U; body++) {
+#pragma unroll
+                for (int g = 0; g < U; g++) {
+                    const int G = body * U + g;
+                    constexpr int AH = NP + 2 * (PD - 1);  // first pair sub-step G loads, relative to 2G
+                    R[(2 * g + AH) % RING] = X2[2 * G + AH];  // (the last sub-steps of a chunk read past it: staged, unused)
+                    R[(2 * g + AH + 1) % RING] = X2[2 * G + AH + 1];
+                    Q[(g + PD) % NQ][0] = Q2[2 * (G + PD)];
+                    Q[(g + PD) % NQ][1] = Q2[2 * (G + PD) + 1];
                     // fence: the reads above stay above it (memory clobber), the FMAs below it (accumulator operands)
                     if constexpr (CI == 8)
                         asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]),
                                      "+v"(acc[6]), "+v"(acc[7])::"memory");
                     else
                         asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3])::"memory");
-                    const ed4_d2 q0 = (g & 1) ? QB[0] : QA[0], q1 = (g & 1) ? QB[1] : QA[1];
+                    const ed4_d2 q0 = Q[g % NQ][0], q1 = Q[g % NQ][1];
                     // w[k] = X[c0 + 4G + k], k < CI + 4
-#define EDD_W(k) (((k) & 1) ? R[(2 * g + (k) / 2) % 8].y : R[(2 * g + (k) / 2) % 8].x)
+#define EDD_W(k) (((k) & 1) ? R[(2 * g + (k) / 2) % RING].y : R[(2 * g + (k) / 2) % RING].x)
 #pragma unroll
                     for (int a = 0; a < CI; a++) acc[a] = __builtin_fma(EDD_W(a), q0.x, acc[a]);
 #pragma unroll
