@@ -54,3 +54,30 @@ def test_sharded_verifier_two_ranks_one_device(built, tmp_path):
             w_off, w_dist, w_st = want[int(z["variant"])]
             assert np.array_equal(z["offs"], w_off) and np.array_equal(z["dists"], w_dist), (i, rank)
             assert int(z["cnt"]) == w_st["cnt_candidate"]
+
+
+def test_bench_launched_path_two_ranks_rehearsal(built):
+    """bench.py as the driver launches it for N > 1 (torch.distributed.run, one process per rank, ShardedStream with the
+    calling thread issuing the all-gathers, max-over-ranks timing, rank 0 printing the one JSON line) -- rehearsed with two
+    ranks on this box's single GPU over gloo (KVM_BENCH_REHEARSAL: RCCL refuses two ranks on one device).  Checks the
+    plumbing and the line, not a number."""
+    import json
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, KVM_BENCH_REHEARSAL="gloo")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    for workload, extra in (("rsm_ed", []), ("mixed", ["--queries-per-step", "4"])):
+        cp = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                             "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                             "--gpus", "2", "--steps", "2", "--warmup", "1", "--candidates", "30000",   # (the launcher's own
+                             # parser takes `--n` for an abbreviation of its options: the series stays at the default 1e8)
+                             "--extras", "0", "--cpu-baseline", "0", "--workload", workload] + extra,
+                            env=env, capture_output=True, text=True, timeout=900)
+        assert cp.returncode == 0, cp.stdout[-2000:] + cp.stderr[-4000:]
+        lines = [l for l in cp.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, cp.stdout[-2000:]                       # rank 0 alone prints, and prints one line
+        d = json.loads(lines[0])
+        assert d["n_gpus"] == 2 and d["rccl_ranks"] == 0 and "rehearsal" in d and d["scaling"] == "weak"
+        assert d["value"] > 0 and d["steps"] == 2 and d["config"]["queries_in_flight"] >= 1
+        assert "x2" in d["config"]["parallelism"] and d["config"]["answers"] >= 1   # the merged answers of both shards
