@@ -190,6 +190,14 @@ double kvm_phase2_time_estimate_ms(int32_t variant, int64_t disjoint_windows, in
 
 /* ---- phase 2: the four verification entry points ------------------------------------------------ */
 
+/* The interval list.  left[i] / right[i] are `validPositions` as the engines hold them right before phase 2: the output
+ * of sortAndMergeIntervals (sorted by left, disjoint, non-adjacent; kvm_sort_and_merge_intervals produces that form).
+ * Lists with adjacent, overlapping, nested, repeated or empty (right < left) intervals are processed the way the Java
+ * loops process them -- every interval scanned on its own, an offset covered twice answered twice, cntCandidate summing
+ * right - left + 1 as it stands.  A list NOT sorted by left: the RSM engines treat intervals independently and return
+ * the same (offset, distance) pairs as for the sorted list; the cNSM engines index their merged chunks with
+ * `left - begin`, which is an exception in Java, and return KVM_ERR_ILLEGAL_ARGUMENT here. */
+
 /* RSM-ED.  Replaces K/QueryEngine.java:338-363 (+ sort :373). */
 int kvm_verify_rsm_ed(kvm_ctx *ctx, const double *query, int32_t m, const int32_t *left, const int32_t *right,
                       int32_t k, int32_t shift, double epsilon, kvm_result **result);

@@ -600,6 +600,33 @@ static void plan_totals_generic(const int32_t *left, const int32_t *right, int32
 static int build_plan(kvm_ctx *ctx, bool cnsm, int32_t m, const int32_t *left, const int32_t *right, int32_t k,
                       int32_t shift, int32_t tile_max, bool hybrid, plan &pl) {
     const int64_t n = ctx->n;
+    // The engines hand phase 2 the list sortAndMergeIntervals leaves (K/QueryEngine.java:664-693): sorted by `left`.
+    // Lists with overlapping, adjacent, nested, repeated or empty intervals go through like in the Java loops (every
+    // interval is scanned on its own); a list that is NOT sorted by `left` is different: the device side looks a
+    // candidate's run up by its start (kvm_find_run).  RSM engines treat intervals independently, so such a list is
+    // sorted here (stable, by `left`) -- the same (offset, distance) pairs come out.  The cNSM engines merge consecutive
+    // intervals into one fetched chunk and index it with `left - begin`: out of order that is an
+    // IndexOutOfBoundsException or the range check of readTimeSeries in Java, depending on the list; refused here.
+    std::vector<int32_t> sorted_l, sorted_r;
+    {
+        bool ascending = true;
+        for (int32_t p = 1; p < k; p++) ascending &= left[p] >= left[p - 1];
+        if (!ascending) {
+            if (cnsm)
+                return fail(ctx, KVM_ERR_ILLEGAL_ARGUMENT, "interval list not sorted by left (sortAndMergeIntervals, K/QueryEngine.java:664-693)");
+            std::vector<int32_t> idx((size_t)k);
+            for (int32_t p = 0; p < k; p++) idx[(size_t)p] = p;
+            std::stable_sort(idx.begin(), idx.end(), [left](int32_t a, int32_t b) { return left[a] < left[b]; });
+            sorted_l.resize((size_t)k);
+            sorted_r.resize((size_t)k);
+            for (int32_t p = 0; p < k; p++) {
+                sorted_l[(size_t)p] = left[idx[(size_t)p]];
+                sorted_r[(size_t)p] = right[idx[(size_t)p]];
+            }
+            left = sorted_l.data();
+            right = sorted_r.data();
+        }
+    }
     // RSM engines fetch per interval: readTimeSeries(begin, end-begin+1) throws when the clipped range is empty
     // (K/QueryEngine.java:346-352; K/operator/file/TimeSeriesFileOperator.java:55-57).  end - begin + 1 == (clipped window
     // count) + m - 1, so the totals loop below notices an offender (and then words the message from the first one).

@@ -282,6 +282,11 @@ def _query_stats(query):
 
 def _chunks(left, right, last_segment, query_length, n):
     """The greedy chunk merge shared by both cNSM engines: yields (beginIdx, endIdx, begin, end)."""
+    # GUARD (not in the Java code; the oracle and the library have the same one): a list that is not sorted by left ends
+    # in readTimeSeries' range check or in an IndexOutOfBoundsException in Java, depending on the list -- and Python's
+    # negative indices would silently wrap.  The engines only ever pass sortAndMergeIntervals' output.
+    if any(left[p] < left[p - 1] for p in range(1, len(left))):
+        raise IllegalArgumentException("interval list not sorted by left")
     idx = 0
     size = len(left)
     while idx < size:

@@ -1073,3 +1073,61 @@ def test_ed_pruner_class_c_on_a_long_list_of_short_runs(built):
         ctx.set_option(kvmatch.OPT_EARLY_ABANDON, 0)
         got = kvmatch.QueryEngine(ctx).verify((L, R), 1, q, 30.0)       # many survivors of the pruner in every class
         compare(got, oracle.rsm_ed(s, q, L, R, 0, 30.0), tag="long list, wide eps")
+
+
+def test_interval_lists_not_in_the_form_sort_and_merge_leaves(world):
+    """The engines hand phase 2 the list sortAndMergeIntervals leaves (sorted, disjoint, non-adjacent).  Anything else a
+    caller might pass: adjacent, overlapping, nested, repeated and reversed (empty) intervals go through like in the Java
+    loops -- every interval scanned on its own, an offset covered twice answered twice -- bit for bit with the oracle; a
+    list not sorted by `left` gives the same answers as its sorted form for the RSM engines (intervals are independent
+    there) and IllegalArgument for the cNSM engines on both sides (their chunk indexing breaks in Java)."""
+    kvmatch, datagen, series, ctx = world
+
+    def compare(got, want, tag):     # (an offset may occur twice, with distances that differ in their last bits: no dict)
+        assert np.array_equal(got.offsets, want[0]) and np.array_equal(got.distances, want[1]), tag
+        assert got.cnt_candidate == want[2]["cnt_candidate"], tag
+
+    m = 200
+    s = series.copy()
+    q = s[50_000:50_000 + m].copy()
+    for p in (20_000, 120_000, 200_000):
+        s[p - 1:p - 1 + m] = q + np.random.default_rng(p).normal(size=m) * 0.01
+    ctx.load_series(s)
+    lists = {
+        "adjacent": ([100, 200, 300, 19_990, 20_001], [199, 299, 399, 20_000, 20_050]),
+        "overlapping": ([100, 150, 19_990, 19_995], [200, 400, 20_010, 20_020]),
+        "nested": ([100, 150, 160, 19_900, 19_990], [1000, 200, 170, 20_100, 20_010]),
+        "reversed": ([500, 19_990], [400, 20_010]),
+        "repeated": ([19_990, 19_990, 19_990], [20_010, 20_010, 20_010]),
+    }
+    try:
+        for name, (L, R) in lists.items():
+            L, R = np.array(L, dtype=np.int32), np.array(R, dtype=np.int32)
+            compare(kvmatch.QueryEngine(ctx).verify((L, R), 1, q, 3.0), oracle.rsm_ed(s, q, L, R, 0, 3.0), tag=name + " rsm_ed")
+            compare(kvmatch.NormQueryEngine(ctx).verify((L, R), 1, q, 1.0, 1.5, 3.0), oracle.cnsm_ed(s, q, L, R, 0, 1.0, 1.5, 3.0),
+                    tag=name + " cnsm_ed")
+            compare(kvmatch.QueryEngineDtw(ctx).verify((L, R), 1, q, 3.0, 10), oracle.rsm_dtw(s, q, L, R, 0, 3.0, 10), tag=name + " rsm_dtw")
+            compare(kvmatch.NormQueryEngineDtw(ctx).verify((L, R), 1, q, 1.0, 10, 1.5, 3.0),
+                    oracle.cnsm_dtw(s, q, L, R, 0, 1.0, 10, 1.5, 3.0), tag=name + " cnsm_dtw")
+        # not sorted by left
+        L = np.array([120_000, 100, 19_990, 50_000, 199_990], dtype=np.int32)
+        R = np.array([120_100, 400, 20_010, 50_040, 200_020], dtype=np.int32)
+        order = np.argsort(L, kind="stable")
+        Ls, Rs = L[order], R[order]
+        for eng, ofn, args in ((kvmatch.QueryEngine, oracle.rsm_ed, (3.0,)), (kvmatch.QueryEngineDtw, oracle.rsm_dtw, (3.0, 10))):
+            got = eng(ctx).verify((L, R), 1, q, *args)
+            want = ofn(s, q, Ls, Rs, 0, *args)                     # the sorted form of the list
+            compare(got, want, tag="unsorted " + eng.__name__)
+            assert {20_000, 50_001, 120_000, 200_000} <= set(got.offsets.tolist())
+            raw = ofn(s, q, L, R, 0, *args)                        # the Java loops on the list as given: the same pairs
+            assert sorted(zip(raw[0].tolist(), raw[1].tolist())) == sorted(zip(got.offsets.tolist(), got.distances.tolist()))
+        for call, ocall in ((lambda: kvmatch.NormQueryEngine(ctx).verify((L, R), 1, q, 1.0, 1.5, 3.0),
+                             lambda: oracle.cnsm_ed(s, q, L, R, 0, 1.0, 1.5, 3.0)),
+                            (lambda: kvmatch.NormQueryEngineDtw(ctx).verify((L, R), 1, q, 1.0, 10, 1.5, 3.0),
+                             lambda: oracle.cnsm_dtw(s, q, L, R, 0, 1.0, 10, 1.5, 3.0))):
+            with pytest.raises(kvmatch.KvMatchIllegalArgument):
+                call()
+            with pytest.raises(oracle.OracleError):
+                ocall()
+    finally:
+        ctx.load_series(series)
