@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Random malformed interval lists (overlaps, nesting, repeats, empties, out-of-range ends, shifts, optionally unsorted)
+through all four engines, library vs oracle.  `fuzz_lists.py [cases] [seed]`."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "kv-match_amd")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import numpy as np, kvmatch, oracle
+from kvmatch import datagen
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+n = 60_000
+s = datagen.gen_series(n, seed=21)
+oracle.set_lenient_sort(True)
+bad = exc = total = 0
+with kvmatch.Phase2Context(0) as ctx:
+    ctx.load_series(s); ctx.set_option(kvmatch.OPT_SORT_VIOLATION, 1)
+    for case in range(cases):
+        m = int(rng.choice([25, 64, 200, 700]))
+        qoff = int(rng.integers(1, n - m))
+        q = s[qoff - 1:qoff - 1 + m].copy()
+        k = int(rng.integers(0, 12))
+        centres = rng.integers(-50, n + 50, k)
+        if rng.random() < 0.7 and k:
+            centres[rng.integers(0, k)] = qoff            # usually cover the self match
+        L = centres - rng.integers(0, 40, k)
+        R = centres + rng.integers(-5, 60, k)              # some right < left
+        if rng.random() < 0.75:
+            o = np.argsort(L, kind="stable"); L, R = L[o], R[o]
+        L, R = L.astype(np.int32), R.astype(np.int32)
+        ls = int(rng.choice([1, 1, 2, 3]))
+        shift = (ls - 1) * 25
+        eps = float(rng.choice([0.0, 0.5, 3.0, 50.0])); rho = int(rng.choice([0, 3, m // 10])); a = float(rng.choice([1.0, 1.5, 1e9])); b = float(rng.choice([0.0, 2.0, 1e9]))
+        for vname, lib, orc in (
+            ("rsm_ed", lambda: kvmatch.QueryEngine(ctx).verify((L, R), ls, q, eps), lambda: oracle.rsm_ed(s, q, L, R, shift, eps)),
+            ("cnsm_ed", lambda: kvmatch.NormQueryEngine(ctx).verify((L, R), ls, q, eps, a, b), lambda: oracle.cnsm_ed(s, q, L, R, shift, eps, a, b)),
+            ("rsm_dtw", lambda: kvmatch.QueryEngineDtw(ctx).verify((L, R), ls, q, eps, rho), lambda: oracle.rsm_dtw(s, q, L, R, shift, eps, rho)),
+            ("cnsm_dtw", lambda: kvmatch.NormQueryEngineDtw(ctx).verify((L, R), ls, q, eps, rho, a, b, resolved=True), lambda: oracle.cnsm_dtw(s, q, L, R, shift, eps, rho, a, b))):
+            total += 1
+            try:
+                r = lib(); ares = sorted(zip(r.distances.tolist(), r.offsets.tolist())), r.cnt_candidate
+            except kvmatch.KvMatchIllegalArgument as e:
+                ares = "EXC"
+            try:
+                o = orc(); ores = sorted(zip(o[1].tolist(), o[0].tolist())), o[2]["cnt_candidate"]
+            except oracle.OracleError:
+                ores = "EXC"
+            if ares == "EXC" or ores == "EXC":
+                exc += 1
+            if ares != ores:
+                bad += 1
+                print(f"DIFFER case {case} {vname} m={m} ls={ls} eps={eps} rho={rho} a={a} b={b} L={L.tolist()} R={R.tolist()}\n   lib {str(ares)[:160]}\n   orc {str(ores)[:160]}", flush=True)
+print("engine calls", total, "with an exception on either side", exc, "differences", bad)
+sys.exit(1 if bad else 0)
