@@ -4,6 +4,7 @@
 // K/NormQueryEngineDtw.java (K/ = src/main/java/cn/edu/fudan/dsm/kvmatch/).  Phases 0/1 stay in the Java host.
 #pragma once
 #include <cstdint>
+#include <limits>
 #include <stdexcept>
 #include <algorithm>
 #include <string>
@@ -226,10 +227,19 @@ public:
         if (M < 1 || N_ < M || N_ > kvm_series_length(c_.handle())) throw IllegalArgumentException("N outside [M, series length]");
         std::vector<int32_t> l, r;
         detail::segments(1, last, segment_ > 0 ? segment_ : last, l, r);
+        // distance() of the executor abandons on `sum < bsf` (U/UcrEdQueryExecutor.java:93): with Epsilon^2 == 0 it never
+        // adds a term and every window that passes the (Alpha, Beta) test is reported at distance 0 (kvmatch/ucr.py)
+        const bool zero = eps_ * eps_ == 0.0;
         kvm_result *res = nullptr;
         Phase2Context::check(kvm_verify_cnsm_ed(c_.handle(), q_.data(), (int32_t)M, l.data(), r.data(), (int32_t)l.size(), 0,
-                                                eps_, alpha_, beta_, &res), c_.handle());
-        return detail::collect(res);
+                                                zero ? std::numeric_limits<double>::infinity() : eps_, alpha_, beta_, &res),
+                             c_.handle());
+        Answers a = detail::collect(res);
+        if (zero) {
+            std::sort(a.answers.begin(), a.answers.end(), [](const Answer &x, const Answer &y) { return x.first < y.first; });
+            for (auto &p : a.answers) p.second = 0.0;
+        }
+        return a;
     }
 private:
     Phase2Context &c_;

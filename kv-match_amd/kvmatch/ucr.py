@@ -47,7 +47,10 @@ class _Executor:
 
 class UcrEdQueryExecutor(_Executor):
     """U/UcrEdQueryExecutor.java.  ``run()`` returns the number of answers (:174); ``answers`` holds them sorted by
-    distance, 1-based offsets (:161).  ``segment=None`` replays the reference's single running-sum chain."""
+    distance, 1-based offsets (:161).  ``segment=None`` replays the reference's single running-sum chain.
+    The executor's distance() stops on ``sum < bsf`` where the engines' loops stop on ``dist <= bsf``: the difference is
+    reproduced for Epsilon^2 == 0 (see run()); a partial sum that lands EXACTLY on Epsilon^2 before the last term -- which
+    the executor would report at distance Epsilon -- is not."""
 
     def __init__(self, ctx, N, M, queryData, Epsilon, Alpha, Beta, segment=None):
         super().__init__(ctx, N, M, queryData, Epsilon, Alpha, Beta)
@@ -58,6 +61,16 @@ class UcrEdQueryExecutor(_Executor):
     def run(self):
         last = self.N - self.M + 1
         lr = segments(1, last, last if self.segment is None else self.segment)
+        if self.Epsilon * self.Epsilon == 0.0:
+            # The executor's own distance() abandons on `sum < bsf` (U/UcrEdQueryExecutor.java:93) and accepts on
+            # `dist <= bsf` (:165): with bsf = Epsilon * Epsilon == 0 the loop never runs, dist stays 0, and EVERY window
+            # that passes the (Alpha, Beta) test is reported at distance 0 -- the engines, whose loop condition is
+            # `dist <= bsf` (K/NormQueryEngine.java:513), compute the first term instead.  Reproduced here: the windows
+            # that pass the filter (they all are answers for an infinite threshold), in scan order, at distance 0.
+            a = NormQueryEngine(self.ctx).verify(lr, 1, self.queryData, float("inf"), self.Alpha, self.Beta)
+            offs = np.sort(a.offsets)
+            self.answers = Answers(offs, np.zeros(offs.size), a.cnt_candidate, a.elapsed_ms, a.stats)
+            return len(self.answers)
         self.answers = NormQueryEngine(self.ctx).verify(lr, 1, self.queryData, self.Epsilon, self.Alpha, self.Beta)
         return len(self.answers)
 

@@ -1131,3 +1131,30 @@ def test_interval_lists_not_in_the_form_sort_and_merge_leaves(world):
                 ocall()
     finally:
         ctx.load_series(series)
+
+
+def test_ucr_ed_executor_at_epsilon_zero(world):
+    """U/UcrEdQueryExecutor.java's distance() abandons on `sum < bsf` (:93) where the engines' loops run on `dist <= bsf`: at
+    Epsilon^2 == 0 it never adds a term, so the executor reports EVERY window that passes the (Alpha, Beta) test at
+    distance 0.  The oracle restates that; the mirrors reproduce it (kvmatch/ucr.py)."""
+    kvmatch, datagen, series, ctx = world
+    n, m = 30_000, 60
+    s = series[:n].copy()
+    q = s[5_000:5_000 + m].copy()
+    ctx.load_series(s)
+    try:
+        for eps, alpha, beta in ((0.0, 1.3, 1.5), (1e-200, 1e9, 1e9), (0.0, 1.0, 0.0)):
+            e = kvmatch.UcrEdQueryExecutor(ctx, n, m, q, eps, alpha, beta)
+            cnt = e.run()
+            off, dist, st = oracle.ucr_ed(s, q, eps, alpha, beta)
+            assert cnt == len(off) and np.array_equal(e.answers.offsets, off) and np.array_equal(e.answers.distances, dist)
+            assert np.all(dist == 0.0) and (alpha == 1.0 or 5_001 in off.tolist())   # (alpha = 1, beta = 0: the running sums
+            #                                   of the scan need not reproduce the query's own statistics to the last bit)
+        assert len(oracle.ucr_ed(s, q, 0.0, 1e9, 1e9)[0]) == n - m + 1         # (the artefact: every window)
+        # the engine on the same windows computes the first term and keeps the true zero-distance matches only
+        L, R = np.array([1], dtype=np.int32), np.array([n - m + 1], dtype=np.int32)
+        eng = kvmatch.NormQueryEngine(ctx).verify((L, R), 1, q, 0.0, 1e9, 1e9)
+        compare(eng, oracle.cnsm_ed(s, q, L, R, 0, 0.0, 1e9, 1e9), tag="engine at eps 0")
+        assert len(eng) < 10
+    finally:
+        ctx.load_series(series)
