@@ -602,10 +602,10 @@ static int build_plan(kvm_ctx *ctx, bool cnsm, int32_t m, const int32_t *left, c
     const int64_t n = ctx->n;
     // The engines hand phase 2 the list sortAndMergeIntervals leaves (K/QueryEngine.java:664-693): sorted by `left`.
     // Lists with overlapping, adjacent, nested, repeated or empty intervals go through like in the Java loops (every
-    // interval is scanned on its own); a list that is NOT sorted by `left` is different: the device side looks a
-    // candidate's run up by its start (kvm_find_run).  RSM engines treat intervals independently, so such a list is
-    // sorted here (stable, by `left`) -- the same (offset, distance) pairs come out.  The cNSM engines merge consecutive
-    // intervals into one fetched chunk and index it with `left - begin`: out of order that is an
+    // interval is scanned on its own: a candidate's records carry the INDEX of its run, two runs may well start at the
+    // same offset).  A list that is NOT sorted by `left`: the RSM engines treat intervals independently, so it is sorted
+    // here (stable, by `left`) -- the same (offset, distance) pairs come out, in the tie order of the sorted list.  The cNSM
+    // engines merge consecutive intervals into one fetched chunk and index it with `left - begin`: out of order that is an
     // IndexOutOfBoundsException or the range check of readTimeSeries in Java, depending on the list; refused here.
     std::vector<int32_t> sorted_l, sorted_r;
     {

@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256) void kvm_expand_tiles_hybrid_kernel(const kvm_
         tl.start = run.start + t * 64;
         tl.count = min(64, run.count - t * 64);
         tl.run_start = run.start;
-        tl.pad = 0;
+        tl.run = (int32_t)r;
         tilesA[run.tile_base + t] = tl;
     }
     const int nb = rb ? min(rem, (int)KVM_EDB_TILE) : 0;  // candidates of the class-B tile
@@ -227,7 +227,7 @@ __global__ __launch_bounds__(256) void kvm_expand_tiles_hybrid_kernel(const kvm_
         tl.start = run.start + full * 64;
         tl.count = nb;
         tl.run_start = run.start;
-        tl.pad = 0;
+        tl.run = (int32_t)r;
         tilesB[run.tile_base_b] = tl;
     }
     if (lane == 1 && rc) {
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256) void kvm_expand_tiles_hybrid_kernel(const kvm_
         tl.start = run.start + full * 64 + nb;
         tl.count = rem - nb;
         tl.run_start = run.start;
-        tl.pad = 0;
+        tl.run = (int32_t)r;
         tilesC[run.tile_base_c] = tl;
     }
 }
@@ -333,7 +333,7 @@ __global__ __launch_bounds__(256) void kvm_expand_tiles_kernel(const kvm_run *__
         tl.start = run.start + t * tile_max;
         tl.count = min(tile_max, run.count - t * tile_max);
         tl.run_start = run.start;
-        tl.pad = 0;
+        tl.run = (int32_t)r;
         tiles[run.tile_base + t] = tl;
     }
 }

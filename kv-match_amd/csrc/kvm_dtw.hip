@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void kvm_dtw_filter_kernel(const double *__res
         const unsigned long long below = bk & ((1ULL << lane) - 1ULL);
         kvm_cand c;
         c.start = start;
-        c.run_start = tile.run_start;
+        c.run = tile.run;
         c.mean = mean;
         c.std = std;
         c.lim = lim;
@@ -270,7 +270,7 @@ __device__ int dp_prologue(const double *__restrict__ series, const kvm_query_de
     // eps^2 == 0: the loops `lb < bsf` do not even start and row 0 of the DP already "reaches" bsf -- sequential path
     if (!(0.0 < Elo)) return DP_AMBIG;
     // ---- the data envelope at the ends of the fetched chunk ----
-    dref_chunk(ax, m, c.run_start, pl.cbeg, pl.cend);
+    dref_chunk(ax, m, c.run, pl.cbeg, pl.cend);
     pl.sb = max(pl.cbeg, pl.cend - 2 * r + 1);
     dp_build_patch(series, r, pl, c.start, m, lane, patch);
     // ---- lbKeoghCumulative and lbKeoghDataCumulative: terms in the reference's order, inclusive scans = its partial sums

@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) void kvm_dtw_screen_kernel(const double *__res
     if (keep) {
         kvm_cand c;
         c.start = tile.start + lane;
-        c.run_start = tile.run_start;
+        c.run = tile.run;
         c.mean = mean;
         c.std = sd;
         c.lim = lim;
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(256) void kvm_retile_dtw_kernel(const double *__res
             const int first = __ffsll((long long)mk) - 1, last = 63 - __clzll((long long)mk);
             kvm_tile o;
             o.run_start = tl.run_start;
-            o.pad = 0;
+            o.run = tl.run;
             o.start = tl.start + first;
             o.count = last - first + 1;
             outs[atomicAdd(&n_out, 1)] = o;

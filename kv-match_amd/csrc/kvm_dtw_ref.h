@@ -64,8 +64,8 @@ __device__ __forceinline__ double dref_term_d(double qv, double U, double L, dou
 // (lowerUpperLemire over the fetched chunk, K/QueryEngineDtw.java:397-399, K/NormQueryEngineDtw.java:522-524) is clipped.
 // RSM engines fetch per interval: begin = the run's first window, end = its last window's last point
 // (K/QueryEngineDtw.java:387-394); cNSM engines fetch merged chunks, whose bounds the host computed per run.
-__device__ __forceinline__ void dref_chunk(const kvm_dtw_aux &ax, int m, int32_t run_start, int32_t &cbeg, int32_t &cend) {
-    const int64_t r = kvm_find_run(ax.runs, ax.n_runs, run_start);
+__device__ __forceinline__ void dref_chunk(const kvm_dtw_aux &ax, int m, int32_t run, int32_t &cbeg, int32_t &cend) {
+    const int64_t r = run;
     if (ax.run_chunk) {
         const int2 c = ax.run_chunk[r];
         cbeg = c.x;

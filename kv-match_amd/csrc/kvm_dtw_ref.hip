@@ -64,7 +64,7 @@ __global__ __launch_bounds__(64) void kvm_dtw_ref_chains_kernel(const double *__
     }
     if (pass) {
         int32_t cbeg, cend;
-        dref_chunk(ax, m, c.run_start, cbeg, cend);
+        dref_chunk(ax, m, c.run, cbeg, cend);
         for (int k = 0; k < m; k++) cb2[k] = 0.0;
         for (int i = 0; i < m && lbK2 < bsf; i++) {                            // K/utils/DtwUtils.java:242
             const int o = ax.order[i];

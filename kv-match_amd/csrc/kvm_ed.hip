@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void kvm_ed_wave_kernel(const double *__restri
         const double total = kvm_wave_sum(acc);
         if (!(total > lim) && lane == 0) {  // (NaN total: a NaN / Inf point in the window -- the exact pass rejects it)
             unsigned long long idx = atomicAdd(&counters[KVM_CNT_CANDS1], 1ULL);
-            if ((int64_t)idx < cap) surv[idx] = kvm_surv{start, tile.run_start};
+            if ((int64_t)idx < cap) surv[idx] = kvm_surv{start, tile.run};
         }
     }
     if (NORM && lane == 0 && passed) atomicAdd(&counters[KVM_CNT_PASS_FILTER], (unsigned long long)passed);

@@ -135,7 +135,7 @@ __device__ __forceinline__ void edd_body(const edd_args &A, const kvm_tile *__re
     }
     // ... and this lane's own tile
     kvm_tile mine;
-    mine.start = 1; mine.count = 0; mine.run_start = 1; mine.pad = 0;
+    mine.start = 1; mine.count = 0; mine.run_start = 1; mine.run = 0;
     if (t0 + row * SUB + sub < n_tiles) mine = tiles[t0 + row * SUB + sub];
     const double c_row = series[mine.start - 1];
     const int c0 = CI * lc;
@@ -517,7 +517,7 @@ __device__ __forceinline__ void edd_body(const edd_args &A, const kvm_tile *__re
     for (int a = 0; a < CI; a++) {
         if ((keepm >> a) & 1u) {
             unsigned long long idx = atomicAdd(&A.counters[KVM_CNT_CANDS1], 1ULL);
-            if ((int64_t)idx < A.cap) A.surv[idx] = kvm_surv{mine.start + c0 + a, mine.run_start};
+            if ((int64_t)idx < A.cap) A.surv[idx] = kvm_surv{mine.start + c0 + a, mine.run};
         }
     }
 }
@@ -539,7 +539,7 @@ __device__ __forceinline__ void retile_collect(retile_out<CAP> &o, const kvm_til
     out.start = tl.start + first;
     out.count = last - first + 1;
     out.run_start = tl.run_start;
-    out.pad = 0;
+    out.run = tl.run;
     // Classes as in kvm_ed_remainder_classes, except that class C is not used here: the device-built lists are what is
     // left after a selective predicate (a few hundred tiles for 2048 wave slots), the call then lasts as long as its
     // longest unit, and a class-C unit over the whole window takes 1.3 x a class-B unit (measured: the pruner of the

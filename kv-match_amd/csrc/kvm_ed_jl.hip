@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256, 2) void kvm_ed_jl_kernel(jl_args A) {
     kvm_tile cur = tiles[u0];
     cur.start = __builtin_amdgcn_readfirstlane(cur.start);
     cur.count = __builtin_amdgcn_readfirstlane(cur.count);
-    cur.run_start = __builtin_amdgcn_readfirstlane(cur.run_start);
+    cur.run = __builtin_amdgcn_readfirstlane(cur.run);
     jl_d2 qs[8];
     load_x(series + ((int64_t)cur.start - 1));
 #pragma unroll
@@ -240,11 +240,11 @@ __global__ __launch_bounds__(256, 2) void kvm_ed_jl_kernel(jl_args A) {
         }
         if (keep) {
             const unsigned long long idx = atomicAdd(&A.counters[KVM_CNT_CANDS1], 1ULL);
-            if ((int64_t)idx < A.cap) A.surv[idx] = kvm_surv{cur.start + mycand, cur.run_start};
+            if ((int64_t)idx < A.cap) A.surv[idx] = kvm_surv{cur.start + mycand, cur.run};
         }
         cur.start = __builtin_amdgcn_readfirstlane(nxt_v.start);
         cur.count = __builtin_amdgcn_readfirstlane(nxt_v.count);
-        cur.run_start = __builtin_amdgcn_readfirstlane(nxt_v.run_start);
+        cur.run = __builtin_amdgcn_readfirstlane(nxt_v.run);
         c_cur = c_nxt;
     }
 }

@@ -58,11 +58,11 @@ __global__ __launch_bounds__(256, 3) void kvm_ed_tiled_kernel(const double *__re
             const kvm_tile t = tiles[t0 + r];
             rstart[r] = t.start;
             rcount[r] = t.count;
-            rrun[r] = t.run_start;
+            rrun[r] = t.run;
         } else {
             rstart[r] = 1;  // empty row: stage from the head of the series (always readable), results discarded
             rcount[r] = 0;
-            rrun[r] = 1;
+            rrun[r] = 0;
         }
     }
     // static selects (a runtime-indexed register array would be demoted to scratch)

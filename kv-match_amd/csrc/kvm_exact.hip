@@ -72,8 +72,8 @@ __global__ __launch_bounds__(256) void kvm_replay_mark_kernel(const REC *__restr
          i += (unsigned long long)gridDim.x * blockDim.x) {
         const REC rec = recs[i];
         if (rec.start < 0) continue;
-        const int64_t r = kvm_find_run(ws.runs, ws.n_runs, rec.run_start);
-        const int32_t k = rec.start - rec.run_start;
+        const int64_t r = rec.run;
+        const int32_t k = rec.start - ws.runs[r].start;
         if (atomicMax(&ws.run_maxk[r], k + 1) == 0)  // first mark of this run: queue it for the replay
             ws.run_list[atomicAdd(ws.run_list_n, 1ULL)] = (int32_t)r;
     }
@@ -219,8 +219,8 @@ __global__ __launch_bounds__(EX_THREADS) void kvm_exact_ed_kernel(const double *
                 start = sv.start;
                 if (NORM) {
                     // the reference's running sums of this window (replayed per run by kvm_replay_runs_kernel)
-                    const int64_t r = kvm_find_run(ws.runs, ws.n_runs, sv.run_start);
-                    const int64_t wi = ws.runs[r].win_base + (sv.start - sv.run_start);
+                    const kvm_run rn = ws.runs[sv.run];
+                    const int64_t wi = rn.win_base + (sv.start - rn.start);
                     mean = ws.stats[wi] / m;                                     // K/NormQueryEngine.java:507
                     std = sqrt(ws.stats[ws.stats_plane + wi] / m - mean * mean);  // :508
                     if (!kvm_cnsm_filter(mean, std, qd.meanQ, qd.stdQ, qd.alpha, qd.beta)) active = 0;
@@ -341,8 +341,8 @@ __global__ __launch_bounds__(256) void kvm_exact_stats_apply_kernel(kvm_query_de
     for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (unsigned long long)gridDim.x * blockDim.x) {
         kvm_cand c = cands[i];
-        const int64_t r = kvm_find_run(ws.runs, ws.n_runs, c.run_start);
-        const int64_t wi = ws.runs[r].win_base + (c.start - c.run_start);  // ex, ex2 of the replay
+        const kvm_run rn = ws.runs[c.run];
+        const int64_t wi = rn.win_base + (c.start - rn.start);  // ex, ex2 of the replay
         const double mean = ws.stats[wi] / qd.m;                                      // K/NormQueryEngineDtw.java:550
         const double std = sqrt(ws.stats[ws.stats_plane + wi] / qd.m - mean * mean);  // :551
         c.mean = mean;

@@ -49,19 +49,20 @@ struct kvm_tile {
     int32_t start;      // first window start offset of the tile (1-based)
     int32_t count;      // consecutive offsets in the tile
     int32_t run_start;  // first window start offset of the tile's whole run (where the reference's running sums restart)
-    int32_t pad;
+    int32_t run;        // index of that run in the query's run list (lists with repeated `left` values hold several runs
+                        // with the same start: the start alone does not identify the run)
 };
 
 // Survivor of a fast ED kernel, to be decided by the exact pass (kvm_exact.hip).
 struct kvm_surv {
     int32_t start;
-    int32_t run_start;
+    int32_t run;  // index of its run in the run list
 };
 
 // Survivor record flowing between the cascade kernels.
 struct kvm_cand {
     int32_t start;      // window start offset (1-based); negated once the exact (alpha, beta) test rejects it
-    int32_t run_start;  // first window start offset of its run
+    int32_t run;        // index of its run in the run list
     double mean;
     double std;
     double lim;         // cNSM: pruning limit of the lower bounds for THIS candidate (eps^2 + its guard band, stage 1)
@@ -543,15 +544,6 @@ __device__ __forceinline__ double kvm_eps2_slack(double eps2, int32_t m, double 
     return eps2 * 1e-9 + factor * (g * sqrt((double)m * eps2) + g * g * m);
 }
 
-// index of the run that starts at window offset `run_start` (runs are sorted by start and disjoint)
-__device__ __forceinline__ int64_t kvm_find_run(const kvm_run *__restrict__ runs, int64_t n_runs, int32_t run_start) {
-    int64_t lo = 0, hi = n_runs - 1;
-    while (lo < hi) {
-        const int64_t mid = (lo + hi) >> 1;
-        if (runs[mid].start < run_start) lo = mid + 1; else hi = mid;
-    }
-    return lo;
-}
 
 // Wave-uniform values as SCALARS.  A value every lane agrees on must also look uniform to the compiler, or it lowers the
 // branches that depend on it as divergent control flow -- and a loop with a cross-lane operation (ds_bpermute, DPP) at

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Random malformed interval lists (overlaps, nesting, repeats, empties, out-of-range ends, shifts, optionally unsorted)
-through all four engines, library vs oracle.  `fuzz_lists.py [cases] [seed]`."""
+through all four engines, library vs oracle.  `fuzz_lists.py [cases] [seed] [kmax]`."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "kv-match_amd")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -8,6 +8,7 @@ import numpy as np, kvmatch, oracle
 from kvmatch import datagen
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+kmax = int(sys.argv[3]) if len(sys.argv) > 3 else 12
 n = 60_000
 s = datagen.gen_series(n, seed=21)
 oracle.set_lenient_sort(True)
@@ -18,7 +19,7 @@ with kvmatch.Phase2Context(0) as ctx:
         m = int(rng.choice([25, 64, 200, 700]))
         qoff = int(rng.integers(1, n - m))
         q = s[qoff - 1:qoff - 1 + m].copy()
-        k = int(rng.integers(0, 12))
+        k = int(rng.integers(0, kmax))
         centres = rng.integers(-50, n + 50, k)
         if rng.random() < 0.7 and k:
             centres[rng.integers(0, k)] = qoff            # usually cover the self match
@@ -48,6 +49,15 @@ with kvmatch.Phase2Context(0) as ctx:
                 exc += 1
             if ares != ores:
                 bad += 1
-                print(f"DIFFER case {case} {vname} m={m} ls={ls} eps={eps} rho={rho} a={a} b={b} L={L.tolist()} R={R.tolist()}\n   lib {str(ares)[:160]}\n   orc {str(ores)[:160]}", flush=True)
+                from collections import Counter
+                if ares != "EXC" and ores != "EXC":
+                    ca, co = Counter(ares[0]), Counter(ores[0])
+                    only_lib, only_orc = list((ca - co).elements())[:6], list((co - ca).elements())[:6]
+                    detail = f"answers {len(ares[0])} vs {len(ores[0])} cnt {ares[1]} vs {ores[1]}; only lib {only_lib}; only oracle {only_orc}"
+                else:
+                    detail = f"lib {str(ares)[:80]} orc {str(ores)[:80]}"
+                print(f"DIFFER case {case} {vname} m={m} ls={ls} eps={eps} rho={rho} a={a} b={b} k={k} sorted={bool(np.all(np.diff(L) >= 0))}: {detail}", flush=True)
+                if os.environ.get("FUZZ_DUMP"):
+                    np.savez(os.path.join(ROOT, "gpurun_out", f"fuzz_case_{case}_{vname}.npz"), L=L, R=R, q=q, m=m, ls=ls, eps=eps, rho=rho, a=a, b=b)
 print("engine calls", total, "with an exception on either side", exc, "differences", bad)
 sys.exit(1 if bad else 0)

@@ -11,6 +11,7 @@ run python -u profiles/edge_sizes.py
 run python -u profiles/edge_clip.py
 run python -u profiles/stress_ed.py 200
 run python -u profiles/fuzz_lists.py 600 3
+run python -u profiles/fuzz_lists.py 150 9 1500
 run python -u profiles/messy_lists.py
 run python -u profiles/exotic_params.py
 run python -u profiles/fuzz_index.py 64 2

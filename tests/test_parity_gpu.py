@@ -1099,6 +1099,10 @@ def test_interval_lists_not_in_the_form_sort_and_merge_leaves(world):
         "nested": ([100, 150, 160, 19_900, 19_990], [1000, 200, 170, 20_100, 20_010]),
         "reversed": ([500, 19_990], [400, 20_010]),
         "repeated": ([19_990, 19_990, 19_990], [20_010, 20_010, 20_010]),
+        # two runs that START at the same offset but end differently: a candidate's records carry the index of its run, not
+        # the run's start (looking the run up by its start took the wrong one: RSM-DTW clipped the data envelope of
+        # LB_Keogh at the wrong end and lost answers near eps -- found by profiles/fuzz_lists.py with long lists)
+        "same_left": ([100, 100, 19_960, 19_960, 19_960], [120, 400, 19_965, 20_100, 20_003]),
     }
     try:
         for name, (L, R) in lists.items():
