@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Random malformed interval lists (overlaps, nesting, repeats, empties, out-of-range ends, shifts, optionally unsorted)
-through all four engines, library vs oracle.  `fuzz_lists.py [cases] [seed] [kmax]`."""
+through all four engines, library vs oracle.  `fuzz_lists.py [cases] [seed] [kmax] [wide]`."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "kv-match_amd")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -9,14 +9,24 @@ from kvmatch import datagen
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 kmax = int(sys.argv[3]) if len(sys.argv) > 3 else 12
+wide = len(sys.argv) > 4 and sys.argv[4] == "wide"   # long queries and wide bands (both DP kernels), short lists
 n = 60_000
 s = datagen.gen_series(n, seed=21)
 oracle.set_lenient_sort(True)
 bad = exc = total = 0
 with kvmatch.Phase2Context(0) as ctx:
     ctx.load_series(s); ctx.set_option(kvmatch.OPT_SORT_VIOLATION, 1)
+    hostile = len(sys.argv) > 4 and sys.argv[4] == "hostile"   # integer / piecewise-constant / NaN-sprinkled / huge-level series
     for case in range(cases):
-        m = int(rng.choice([25, 64, 200, 700]))
+        if hostile and case % 10 == 0:
+            kind = (case // 10) % 5
+            if kind == 0: s = rng.integers(-3, 4, n).astype(np.float64)
+            elif kind == 1: s = np.repeat(rng.normal(size=n // 50 + 1), 50)[:n].copy()
+            elif kind == 2: s = datagen.gen_series(n, seed=case + 1); s[rng.integers(0, n, 40)] = np.nan; s[rng.integers(0, n, 10)] = np.inf
+            elif kind == 3: s = 1e7 + np.cumsum(rng.normal(size=n))
+            else: s = rng.integers(-9, 10, n) * 0.5
+            ctx.load_series(s)
+        m = int(rng.choice([700, 1600, 2500])) if wide else int(rng.choice([25, 64, 200, 700]))
         qoff = int(rng.integers(1, n - m))
         q = s[qoff - 1:qoff - 1 + m].copy()
         k = int(rng.integers(0, kmax))
@@ -30,7 +40,7 @@ with kvmatch.Phase2Context(0) as ctx:
         L, R = L.astype(np.int32), R.astype(np.int32)
         ls = int(rng.choice([1, 1, 2, 3]))
         shift = (ls - 1) * 25
-        eps = float(rng.choice([0.0, 0.5, 3.0, 50.0])); rho = int(rng.choice([0, 3, m // 10])); a = float(rng.choice([1.0, 1.5, 1e9])); b = float(rng.choice([0.0, 2.0, 1e9]))
+        eps = float(rng.choice([0.0, 0.5, 3.0, 50.0])) if not hostile else float(rng.choice([0.0, 1.0, 2.0, np.sqrt(m), 8.0])); rho = int(rng.choice([m // 10, m // 3, m // 2, m, 3 * m])) if wide else int(rng.choice([0, 3, m // 10])); a = float(rng.choice([1.0, 1.5, 1e9])); b = float(rng.choice([0.0, 2.0, 1e9]))
         for vname, lib, orc in (
             ("rsm_ed", lambda: kvmatch.QueryEngine(ctx).verify((L, R), ls, q, eps), lambda: oracle.rsm_ed(s, q, L, R, shift, eps)),
             ("cnsm_ed", lambda: kvmatch.NormQueryEngine(ctx).verify((L, R), ls, q, eps, a, b), lambda: oracle.cnsm_ed(s, q, L, R, shift, eps, a, b)),

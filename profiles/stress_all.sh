@@ -12,6 +12,8 @@ run python -u profiles/edge_clip.py
 run python -u profiles/stress_ed.py 200
 run python -u profiles/fuzz_lists.py 600 3
 run python -u profiles/fuzz_lists.py 150 9 1500
+run python -u profiles/fuzz_lists.py 60 21 8 wide
+run python -u profiles/fuzz_lists.py 300 31 30 hostile
 run python -u profiles/messy_lists.py
 run python -u profiles/exotic_params.py
 run python -u profiles/fuzz_index.py 64 2
