@@ -114,8 +114,10 @@ static void free_series(kvm_ctx *ctx) {
     if (ctx->own_series && ctx->d_series) hipFree(ctx->d_series);
     ctx->d_series = nullptr;
     if (ctx->own_series && ctx->d_prefix) hipFree(ctx->d_prefix);  // (a shared series belongs to its owner context)
+    if (ctx->own_series && ctx->d_blockmax) hipFree(ctx->d_blockmax);
     ctx->own_series = false;
     ctx->d_prefix = nullptr;
+    ctx->d_blockmax = nullptr;
     if (ctx->d_env_u) hipFree(ctx->d_env_u);
     if (ctx->d_env_l) hipFree(ctx->d_env_l);
     ctx->d_env_u = ctx->d_env_l = nullptr;
@@ -196,6 +198,9 @@ static int finish_load_steps(kvm_ctx *ctx) {
     // prefix sums for per-window mean/std (replaces the running ex/ex2 of K/NormQueryEngine.java:497-509)
     HIPCHK(ctx, hipMalloc((void **)&ctx->d_prefix, (size_t)ctx->n * sizeof(double2)));
     HIPCHK(ctx, kvm_launch_prefix(ctx->d_series, ctx->d_prefix, ctx->n, ctx->stream));
+    // largest x^2 per prefix block: what the reference's running sums may still carry the residue of (kvm_hist_*)
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_blockmax, (size_t)((ctx->n >> KVM_PS_BLOCK_LOG2) + 1) * sizeof(double)));
+    HIPCHK(ctx, kvm_launch_blockmax(ctx->d_series, ctx->n, ctx->d_blockmax, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return KVM_OK;
 }
@@ -294,6 +299,7 @@ extern "C" int kvm_share_series(kvm_ctx *ctx, const kvm_ctx *owner) {
     free_series(ctx);
     ctx->d_series = owner->d_series;  // values and prefix sums are read-only after staging
     ctx->d_prefix = owner->d_prefix;
+    ctx->d_blockmax = owner->d_blockmax;
     ctx->own_series = false;
     ctx->n = owner->n;
     return KVM_OK;
@@ -912,9 +918,12 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
     const size_t rbytes = (size_t)pl.n_runs * sizeof(kvm_run);
     const size_t plan_scratch = ((size_t)(k > 0 ? k : 0) / 256 + 1) * KVM_PLAN_SUMS_BYTES;  // block totals of kvm_launch_plan_runs
     const size_t rc_off = qbytes + lr_bytes + ((rbytes + 31) & ~(size_t)31) + ((plan_scratch + 31) & ~(size_t)31);
-    if ((rc = ensure(ctx, ctx->b_query, rc_off + (chunks ? (size_t)pl.n_runs * sizeof(int2) : 0) + 64))) return rc;
+    const size_t hist_off = (rc_off + (chunks ? (size_t)pl.n_runs * sizeof(int2) : 0) + 15) & ~(size_t)15;  // cNSM: run_hist
+    if ((rc = ensure(ctx, ctx->b_query, hist_off + (cnsm ? (size_t)pl.n_runs * sizeof(double) : 0) + 64))) return rc;
     kvm_run *d_runs_w = (kvm_run *)((char *)ctx->b_query.p + qbytes + lr_bytes);
     int2 *d_run_chunk = chunks ? (int2 *)((char *)ctx->b_query.p + rc_off) : nullptr;
+    double *d_run_hist = cnsm ? (double *)((char *)ctx->b_query.p + hist_off) : nullptr;
+    qd.run_hist = d_run_hist;
     if (rbytes) {
         int tile_log2 = 0;
         while ((1 << tile_log2) < tile_max) tile_log2++;
@@ -1026,8 +1035,10 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
                                                        (kvm_tile *)ctx->b_tiles.p + pl.n_tiles + pl.n_tiles_b,
                                                        (unsigned long long *)ctx->b_counters.p, rws.run_maxk, stream));
         else
+            // (cNSM: also what the reference's running sums of each interval pass over -- guard of the pruners, kvm_hist_*)
             HIPCHK(ctx, kvm_launch_expand_tiles(d_runs, pl.n_runs, tile_max, (kvm_tile *)ctx->b_tiles.p,
-                                                (unsigned long long *)ctx->b_counters.p, rws.run_maxk, stream));
+                                                (unsigned long long *)ctx->b_counters.p, rws.run_maxk, stream,
+                                                ctx->d_blockmax, d_run_hist, m, ctx->n));
     } else {
         HIPCHK(ctx, hipMemsetAsync(ctx->b_counters.p, 0, KVM_CNT_TOTAL * sizeof(unsigned long long), stream));
     }

@@ -320,7 +320,9 @@ hipError_t kvm_launch_pack_answers(const int32_t *off, const double *dist, const
 __global__ __launch_bounds__(256) void kvm_expand_tiles_kernel(const kvm_run *__restrict__ runs, int64_t n_runs,
                                                                int32_t tile_max, kvm_tile *__restrict__ tiles,
                                                                unsigned long long *__restrict__ counters,
-                                                               int32_t *__restrict__ run_maxk) {
+                                                               int32_t *__restrict__ run_maxk,
+                                                               const double *__restrict__ blockmax, double *__restrict__ run_hist,
+                                                               int32_t m, int64_t n) {
     if (blockIdx.x == 0 && threadIdx.x < KVM_CNT_TOTAL) counters[threadIdx.x] = 0;  // (saves a fill launch per call)
     const int lane = threadIdx.x & 63;
     const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -336,13 +338,34 @@ __global__ __launch_bounds__(256) void kvm_expand_tiles_kernel(const kvm_run *__
         tl.run = (int32_t)r;
         tiles[run.tile_base + t] = tl;
     }
+    if (run_hist) {
+        // cNSM: the largest block maximum among the prefix blocks the run's data range [start, start + count + m - 2]
+        // (1-based points) touches -- what the reference's running sums of that interval pass over, rounded up to whole
+        // blocks (kvm_hist_*).  An ordinary run touches one or two blocks, the run of a full scan thousands.
+        const int64_t lo = ((int64_t)run.start - 1) >> KVM_PS_BLOCK_LOG2;
+        int64_t last = (int64_t)run.start - 1 + run.count + m - 2;
+        if (last > n - 1) last = n - 1;
+        const int64_t hi = last >> KVM_PS_BLOCK_LOG2;
+        double mx = 0.0;
+        for (int64_t b = lo + lane; b <= hi; b += 64) {
+            const double t = blockmax[b];
+            mx = (mx != mx || t != t) ? __builtin_nan("") : fmax(mx, t);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const double t = __shfl_xor(mx, o, 64);
+            mx = (mx != mx || t != t) ? __builtin_nan("") : fmax(mx, t);
+        }
+        if (lane == 0) run_hist[r] = mx;
+    }
 }
 
 hipError_t kvm_launch_expand_tiles(const kvm_run *runs, int64_t n_runs, int32_t tile_max, kvm_tile *tiles,
-                                   unsigned long long *counters, int32_t *run_maxk, hipStream_t s) {
+                                   unsigned long long *counters, int32_t *run_maxk, hipStream_t s, const double *blockmax,
+                                   double *run_hist, int32_t m, int64_t n) {
     if (n_runs <= 0) return hipSuccess;
     hipLaunchKernelGGL(kvm_expand_tiles_kernel, dim3((unsigned)((n_runs + 3) / 4)), dim3(256), 0, s, runs, n_runs,
-                       tile_max, tiles, counters, run_maxk);
+                       tile_max, tiles, counters, run_maxk, blockmax, run_hist, m, n);
     return hipGetLastError();
 }
 
@@ -419,6 +442,37 @@ __global__ __launch_bounds__(256) void kvm_prefix_kernel(const double *__restric
     }
 }
 
+// max x^2 of every prefix block; NaN if the block holds a NaN (fmax would drop it).  One workgroup per block.
+__global__ __launch_bounds__(256) void kvm_blockmax_kernel(const double *__restrict__ x, int64_t n, double *__restrict__ out) {
+    __shared__ double red[4];
+    const int64_t b0 = (int64_t)blockIdx.x << KVM_PS_BLOCK_LOG2;
+    double mx = 0.0;
+    bool nan = false;
+    for (int64_t i = b0 + threadIdx.x; i < b0 + KVM_PS_BLOCK && i < n; i += 256) {
+        const double v = x[i];
+        nan |= v != v;
+        mx = fmax(mx, v * v);
+    }
+    if (nan) mx = __builtin_nan("");
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double t = __shfl_xor(mx, o, 64);
+        mx = (mx != mx || t != t) ? __builtin_nan("") : fmax(mx, t);
+    }
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double r = red[0];
+        for (int w = 1; w < 4; w++) r = (r != r || red[w] != red[w]) ? __builtin_nan("") : fmax(r, red[w]);
+        out[blockIdx.x] = r;
+    }
+}
+hipError_t kvm_launch_blockmax(const double *x, int64_t n, double *blockmax, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    const int64_t blocks = (n + KVM_PS_BLOCK - 1) >> KVM_PS_BLOCK_LOG2;
+    hipLaunchKernelGGL(kvm_blockmax_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, n, blockmax);
+    return hipGetLastError();
+}
 hipError_t kvm_launch_prefix(const double *x, double2 *prefix, int64_t n, hipStream_t s) {
     if (n <= 0) return hipSuccess;
     int64_t blocks = (n + KVM_PS_BLOCK - 1) >> KVM_PS_BLOCK_LOG2;

@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256) void kvm_dtw_filter_kernel(const double *__res
     double lim = qd.eps2 * (1.0 + 1e-9);  // pruning threshold of the lower bounds: eps^2 plus the guard band
     if (alive) {
         if (NORM) {
-            const kvm_stat_guard sg = kvm_window_mean_std_g(prefix, series, (int64_t)start - 1, m, mean, std);
+            const kvm_stat_guard sg = kvm_window_mean_std_g(prefix, series, (int64_t)start - 1, m, mean, std, kvm_run_hist_of(qd, tile.run));
             pass_filter = kvm_cnsm_filter_guarded(mean, std, qd.meanQ, qd.stdQ, qd.alpha, qd.beta, sg);
             lim = qd.eps2 + kvm_eps2_slack(qd.eps2, m, sg.g, 16.0);
             if (!(std == std) || !(std > 0.0) || kvm_guard_degenerate(sg.g)) { std = __builtin_nan(""); lim = __builtin_huge_val(); }  // exact pass decides

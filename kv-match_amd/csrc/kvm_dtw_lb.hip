@@ -23,14 +23,14 @@ __device__ __forceinline__ double lb4_dsq(double a, double b) { return (a - b) *
 // inside the band, NaN) is kept for the exact stage.
 template <bool NORM>
 __device__ __forceinline__ void lb4_prefilter(const double *__restrict__ series, const double2 *__restrict__ prefix,
-                                              const kvm_query_dev &qd, int64_t w0, bool &pass_filter, bool &pass_kim,
-                                              double &mean, double &sd, double &inv, double &nmi, double &lim) {
+                                              const kvm_query_dev &qd, int64_t w0, int32_t run, bool &pass_filter,
+                                              bool &pass_kim, double &mean, double &sd, double &inv, double &nmi, double &lim) {
     const int m = qd.m;
     mean = 0.0; sd = 1.0; inv = 1.0; nmi = 0.0;
     lim = qd.eps2 * (1.0 + 1e-9);
     pass_filter = true;
     if (NORM) {
-        const kvm_stat_guard sg = kvm_window_mean_std_g(prefix, series, w0, m, mean, sd);
+        const kvm_stat_guard sg = kvm_window_mean_std_g(prefix, series, w0, m, mean, sd, kvm_run_hist_of(qd, run));
         pass_filter = kvm_cnsm_filter_guarded(mean, sd, qd.meanQ, qd.stdQ, qd.alpha, qd.beta, sg);
         lim = qd.eps2 + kvm_eps2_slack(qd.eps2, m, sg.g, 16.0);
         if (!(sd == sd) || !(sd > 0.0) || kvm_guard_degenerate(sg.g)) {  // degenerate sigma: no bound, the exact pass decides
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) void kvm_dtw_screen_kernel(const double *__res
     bool pf = false, pk = false;
     double mean = 0.0, sd = 1.0, inv = 1.0, nmi = 0.0, lim = qd.eps2 * (1.0 + 1e-9);
     const int64_t w0 = (int64_t)tile.start - 1 + (lane < tile.count ? lane : 0);
-    if (lane < tile.count) lb4_prefilter<NORM>(series, prefix, qd, w0, pf, pk, mean, sd, inv, nmi, lim);
+    if (lane < tile.count) lb4_prefilter<NORM>(series, prefix, qd, w0, tile.run, pf, pk, mean, sd, inv, nmi, lim);
     if (!d_n_tiles) {  // (with device-built tiles the retile kernel has counted every candidate)
         const unsigned long long bf = __ballot(pf), bk = __ballot(pk);
         if (lane == 0) {
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256) void kvm_retile_dtw_kernel(const double *__res
         bool pf = false, pk = false;
         if (lane < tl.count) {
             double mean, sd, inv, nmi, lim;
-            lb4_prefilter<NORM>(series, prefix, qd, (int64_t)tl.start - 1 + lane, pf, pk, mean, sd, inv, nmi, lim);
+            lb4_prefilter<NORM>(series, prefix, qd, (int64_t)tl.start - 1 + lane, tl.run, pf, pk, mean, sd, inv, nmi, lim);
         }
         const unsigned long long mf = __ballot(pf), mk = __ballot(pk);
         cf += (unsigned)__popcll(mf);

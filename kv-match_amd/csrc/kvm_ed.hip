@@ -32,7 +32,7 @@ __global__ __launch_bounds__(256) void kvm_ed_wave_kernel(const double *__restri
         double mean = 0.0, inv = 1.0, lim = eps2 * (1.0 + 1e-9);  // pruning threshold = eps^2 + guard band
         if (NORM) {
             double std;
-            const kvm_stat_guard sg = kvm_window_mean_std_g(prefix, series, (int64_t)start - 1, m, mean, std);
+            const kvm_stat_guard sg = kvm_window_mean_std_g(prefix, series, (int64_t)start - 1, m, mean, std, kvm_run_hist_of(qd, tile.run));
             if (!kvm_cnsm_filter_guarded(mean, std, qd.meanQ, qd.stdQ, qd.alpha, qd.beta, sg)) continue;  // wave-uniform
             passed++;
             inv = 1.0 / std;

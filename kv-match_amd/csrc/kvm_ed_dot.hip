@@ -138,6 +138,7 @@ __device__ __forceinline__ void edd_body(const edd_args &A, const kvm_tile *__re
     mine.start = 1; mine.count = 0; mine.run_start = 1; mine.run = 0;
     if (t0 + row * SUB + sub < n_tiles) mine = tiles[t0 + row * SUB + sub];
     const double c_row = series[mine.start - 1];
+    const double hist = NORM ? kvm_run_hist_of(qd, mine.run) : 0.0;  // residue the reference's running sums may carry (kvm_hist_*)
     const int c0 = CI * lc;
     const double qbar = qd.q_mean;
     const double2 qtot = q_pref[nchunks * cfg::QS];
@@ -170,8 +171,8 @@ __device__ __forceinline__ void edd_body(const edd_args &A, const kvm_tile *__re
             st.mc = S1 / m;
             const double var = S2 / m - st.mc * st.mc, mean = c_row + st.mc;
             st.sg = sqrt(var);
-            st.gd.mean_err = E1 / m;
-            const double var_err = E2 / m + 2.0 * fabs(st.mc) * st.gd.mean_err;
+            st.gd.mean_err = E1 / m + kvm_hist_mean(hist);
+            const double var_err = E2 / m + 2.0 * fabs(st.mc) * st.gd.mean_err + kvm_hist_var(hist);
             st.gd.g = kvm_sigma_guard(mean, st.sg, var_err / (2.0 * var) + st.gd.mean_err / st.sg);
             st.gd.std_hi = sqrt(fmax(var, 0.0) + var_err + 1e-8 * (mean * mean + fabs(var)));
             if (!full) {
@@ -585,7 +586,7 @@ __global__ __launch_bounds__(256) void kvm_retile_cnsm_kernel(const double *__re
         bool ok = false;
         if (lane < tl.count) {
             double mean, sd;
-            const kvm_stat_guard sg = kvm_window_mean_std_g(prefix, series, (int64_t)tl.start - 1 + lane, qd.m, mean, sd);
+            const kvm_stat_guard sg = kvm_window_mean_std_g(prefix, series, (int64_t)tl.start - 1 + lane, qd.m, mean, sd, kvm_run_hist_of(qd, tl.run));
             ok = kvm_cnsm_filter_guarded(mean, sd, qd.meanQ, qd.stdQ, qd.alpha, qd.beta, sg);
         }
         retile_collect(out, tl, __ballot(ok));

@@ -76,13 +76,13 @@ __global__ __launch_bounds__(256, 3) void kvm_ed_tiled_kernel(const double *__re
     double lim0 = eps2 * (1.0 + 1e-9), lim1 = lim0;
     if (NORM) {
         if (v0) {
-            const kvm_stat_guard sg = kvm_window_mean_std_g(prefix, series, (int64_t)my_start - 1 + c0, m, mean0, sd0);
+            const kvm_stat_guard sg = kvm_window_mean_std_g(prefix, series, (int64_t)my_start - 1 + c0, m, mean0, sd0, kvm_run_hist_of(qd, my_run));
             v0 = kvm_cnsm_filter_guarded(mean0, sd0, qd.meanQ, qd.stdQ, qd.alpha, qd.beta, sg);
             lim0 = (eps2 + kvm_eps2_slack(eps2, m, sg.g, 4.0)) * (sd0 * sd0);
             if (!(sd0 == sd0) || !(sd0 > 0.0) || kvm_guard_degenerate(sg.g)) { mean0 = 0.0; sd0 = 0.0; lim0 = __builtin_huge_val(); }  // exact pass decides
         }
         if (v1) {
-            const kvm_stat_guard sg = kvm_window_mean_std_g(prefix, series, (int64_t)my_start + c0, m, mean1, sd1);
+            const kvm_stat_guard sg = kvm_window_mean_std_g(prefix, series, (int64_t)my_start + c0, m, mean1, sd1, kvm_run_hist_of(qd, my_run));
             v1 = kvm_cnsm_filter_guarded(mean1, sd1, qd.meanQ, qd.stdQ, qd.alpha, qd.beta, sg);
             lim1 = (eps2 + kvm_eps2_slack(eps2, m, sg.g, 4.0)) * (sd1 * sd1);
             if (!(sd1 == sd1) || !(sd1 > 0.0) || kvm_guard_degenerate(sg.g)) { mean1 = 0.0; sd1 = 0.0; lim1 = __builtin_huge_val(); }

@@ -83,6 +83,7 @@ struct kvm_ctx {
     double *d_series = nullptr;
     bool own_series = false;
     double2 *d_prefix = nullptr;  // n entries {sum x, sum x^2}, block-restarted
+    double *d_blockmax = nullptr; // max x^2 of every prefix block (NaN if the block holds one): kvm_run_hist
     // cached data envelope for LB_Keogh2 (per rho)
     double *d_env_u = nullptr, *d_env_l = nullptr;
     int32_t env_rho = -1;
@@ -190,12 +191,16 @@ hipError_t kvm_launch_plan_runs(const int32_t *src_left, const int32_t *src_righ
 hipError_t kvm_launch_upload(void *dst, const void *src_pinned, size_t bytes, hipStream_t s);
 hipError_t kvm_launch_set_u64(unsigned long long *a, unsigned long long va, unsigned long long *b, unsigned long long vb,
                               hipStream_t s);
+// (run_hist != nullptr, cNSM: also the per-run maximum of the block maxima `blockmax` over the run's data range)
 hipError_t kvm_launch_expand_tiles(const kvm_run *runs, int64_t n_runs, int32_t tile_max, kvm_tile *tiles,
-                                   unsigned long long *counters, int32_t *run_maxk, hipStream_t s);
+                                   unsigned long long *counters, int32_t *run_maxk, hipStream_t s,
+                                   const double *blockmax = nullptr, double *run_hist = nullptr, int32_t m = 0, int64_t n = 0);
 // hybrid ED tiling: classes A / B / C of kvm_ed_remainder_classes
 hipError_t kvm_launch_expand_tiles_hybrid(const kvm_run *runs, int64_t n_runs, int hybrid, kvm_tile *tilesA, kvm_tile *tilesB,
                                           kvm_tile *tilesC, unsigned long long *counters, int32_t *run_maxk, hipStream_t s);
 hipError_t kvm_launch_prefix(const double *x, double2 *prefix, int64_t n, hipStream_t s);
+// max x^2 per prefix block (at load)
+hipError_t kvm_launch_blockmax(const double *x, int64_t n, double *blockmax, hipStream_t s);
 // counters + the first `spec` answers, stored straight into device-mapped pinned host memory:
 // [KVM_CNT_TOTAL x u64 | spec x int32 | spec x f64]
 #define KVM_SPEC_ANSWERS 4096
@@ -225,6 +230,8 @@ struct kvm_query_dev {
                             // (class C chunks; a class B chunk is two of them; entries past m hold the totals)
     const double2 *q_pref8; // the same at ED8_JC granularity
     const double *qT;       // qc zero-padded to whole JL_CHUNKs, lane-transposed for kvm_ed_jl.hip (see there)
+    const double *run_hist; // cNSM: per run, the largest x^2 among the points the reference's running sums of that run pass
+                            // over (to the granularity of the prefix blocks; NaN with a NaN among them) -- see kvm_hist_*
 };
 
 // ED pruners: survivors (decision quantity within the guard band of eps^2, filter within its guard band) are appended
@@ -408,6 +415,14 @@ __device__ __forceinline__ void kvm_window_shifted_sums(const double2 *__restric
 struct kvm_sum_err {
     double e1, e2;
 };
+// The reference's running sums (ex += d, ex2 += d * d, later -= the same) keep the rounding residue of everything that
+// ever passed through them since the interval began: a value of magnitude X leaves about u X^2 sqrt(m) in ex2 and
+// u X sqrt(m) in ex for the rest of the run, whatever the windows look like by then.  With `hist` = the largest x^2 the
+// run has seen, the reference's variance is uncertain by kvm_hist_var(hist) and its mean by kvm_hist_mean(hist) on top of
+// everything else.  On ordinary data (hist ~ level^2) both vanish next to the other guard terms; after a spike 1e6 x the
+// local sigma they decide (found by the adversarial sweep, seed 23: a 1e-158-scaled series with O(1) planted values).
+__device__ __forceinline__ double kvm_hist_var(double hist) { return 1e-14 * hist; }
+__device__ __forceinline__ double kvm_hist_mean(double hist) { return 1e-14 * sqrt(hist); }
 __device__ __forceinline__ kvm_sum_err kvm_prefix_err(double pm) {
     kvm_sum_err r;
     r.e1 = 2e-11 * sqrt(pm);
@@ -506,26 +521,30 @@ __device__ __forceinline__ bool kvm_guard_degenerate(double g) { return !(g < KV
 struct kvm_stat_guard {
     double g, mean_err, std_hi;
 };
-__device__ __forceinline__ kvm_stat_guard kvm_make_stat_guard(double c, double s1, double s2, int32_t m, double pm) {
+__device__ __forceinline__ kvm_stat_guard kvm_make_stat_guard(double c, double s1, double s2, int32_t m, double pm,
+                                                              double hist = 0.0) {
     kvm_stat_guard r;
     const double ms = s1 / m, var = s2 / m - ms * ms, mean = c + ms;
     const kvm_sum_err e = kvm_prefix_err(pm);
-    r.mean_err = e.e1 / m;
-    const double var_err = e.e2 / m + 2.0 * fabs(ms) * r.mean_err;
+    r.mean_err = e.e1 / m + kvm_hist_mean(hist);
+    const double var_err = e.e2 / m + 2.0 * fabs(ms) * r.mean_err + kvm_hist_var(hist);
     r.g = kvm_sigma_guard(mean, sqrt(var), var_err / (2.0 * var) + r.mean_err / sqrt(var));
     r.std_hi = sqrt(fmax(var, 0.0) + var_err + 1e-8 * (mean * mean + fabs(var)));
     return r;
 }
 // mean / std / guard in one go (prefix-magnitude share included)
 __device__ __forceinline__ kvm_stat_guard kvm_window_mean_std_g(const double2 *__restrict__ P, const double *__restrict__ x,
-                                                                int64_t s, int32_t m, double &mean, double &std) {
+                                                                int64_t s, int32_t m, double &mean, double &std,
+                                                                double hist = 0.0) {
     double s1, s2, c, pm;
     kvm_window_shifted_sums(P, x, s, m, s1, s2, c, &pm);
     const double ms = s1 / m;
     mean = c + ms;
     std = sqrt(s2 / m - ms * ms);
-    return kvm_make_stat_guard(c, s1, s2, m, pm);
+    return kvm_make_stat_guard(c, s1, s2, m, pm, hist);
 }
+// `hist` of a tile's run (0 for the RSM engines: no running sums there)
+__device__ __forceinline__ double kvm_run_hist_of(const kvm_query_dev &qd, int32_t run) { return qd.run_hist ? qd.run_hist[run] : 0.0; }
 // (alpha, beta) test widened by the guard.  With a degenerate guard (NaN sigma, variance rounded below zero, prefix sums
 // too coarse for this window) only the one thing that is still certain is tested: a sigma that cannot reach the lower
 // limit; everything else is left to the exact pass.

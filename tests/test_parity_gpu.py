@@ -1162,3 +1162,33 @@ def test_ucr_ed_executor_at_epsilon_zero(world):
         assert len(eng) < 10
     finally:
         ctx.load_series(series)
+
+
+def test_residue_of_a_spike_in_the_references_running_sums(built):
+    """The reference's running sums (ex += d, ex2 += d * d, later -= the same, K/NormQueryEngine.java:497-524) keep the
+    rounding residue of everything that passed through them since the interval began: after a burst of 1e9-scale values --
+    or O(1) values in a 1e-158-scaled series -- the mean and sigma of every later window of that interval are noise, and
+    so are the answers; the oracle reproduces them, and so must the library (its pruners know the true sigma: the guard
+    has to widen by what the run has seen, kvm_hist_*).  Found by the adversarial sweep, seed 23."""
+    import kvmatch
+    rng = np.random.default_rng(2323)
+    n, m = 60_000, 256
+    L, R = np.array([1], dtype=np.int32), np.array([n - m + 1], dtype=np.int32)       # one interval: one chain of sums
+    with kvmatch.Phase2Context(0) as ctx:
+        for scale, burst in ((1.0, 1e9), (1e-158, 1.0), (1.0, 1e5), (1e3, 1e12)):
+            s = np.cumsum(rng.uniform(-1, 1, n)) * scale
+            s[20_000:20_010] = burst * rng.uniform(0.5, 1.5, 10)
+            q = s[40_000:40_000 + m].copy()
+            ctx.load_series(s)
+            for eps in (float(np.sqrt(m)), 8.0, 1.0):
+                for ab in (1, 0):
+                    ctx.set_option(kvmatch.OPT_EARLY_ABANDON, ab)
+                    compare(kvmatch.NormQueryEngine(ctx).verify((L, R), 1, q, eps, 1e9, 1e9), oracle.cnsm_ed(s, q, L, R, 0, eps, 1e9, 1e9),
+                            tag=f"spike ed scale={scale} burst={burst} eps={eps} ab={ab}")
+                compare(kvmatch.NormQueryEngine(ctx).verify((L, R), 1, q, eps, 1.5, 3.0 * scale), oracle.cnsm_ed(s, q, L, R, 0, eps, 1.5, 3.0 * scale),
+                        tag=f"spike ed filter scale={scale} burst={burst} eps={eps}")
+            ctx.set_option(kvmatch.OPT_EARLY_ABANDON, 1)
+            Ld, Rd = np.array([19_000], dtype=np.int32), np.array([23_000], dtype=np.int32)   # (DTW on a shorter interval)
+            for eps in (8.0, 2.0):
+                compare(kvmatch.NormQueryEngineDtw(ctx).verify((Ld, Rd), 1, q, eps, 12, 1e9, 1e9), oracle.cnsm_dtw(s, q, Ld, Rd, 0, eps, 12, 1e9, 1e9),
+                        tag=f"spike dtw scale={scale} burst={burst} eps={eps}")
