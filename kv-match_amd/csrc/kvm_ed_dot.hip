@@ -171,8 +171,8 @@ __device__ __forceinline__ void edd_body(const edd_args &A, const kvm_tile *__re
             st.mc = S1 / m;
             const double var = S2 / m - st.mc * st.mc, mean = c_row + st.mc;
             st.sg = sqrt(var);
-            st.gd.mean_err = E1 / m + kvm_hist_mean(hist);
-            const double var_err = E2 / m + 2.0 * fabs(st.mc) * st.gd.mean_err + kvm_hist_var(hist);
+            st.gd.mean_err = E1 / m + kvm_hist_mean(hist, m);
+            const double var_err = E2 / m + 2.0 * fabs(st.mc) * st.gd.mean_err + kvm_hist_var(hist, m);
             st.gd.g = kvm_sigma_guard(mean, st.sg, var_err / (2.0 * var) + st.gd.mean_err / st.sg);
             st.gd.std_hi = sqrt(fmax(var, 0.0) + var_err + 1e-8 * (mean * mean + fabs(var)));
             if (!full) {

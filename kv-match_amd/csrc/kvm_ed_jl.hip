@@ -213,8 +213,8 @@ __global__ __launch_bounds__(256, 2) void kvm_ed_jl_kernel(jl_args A) {
                 const double var = S2 / m - mc * mc, sg = sqrt(var), mean = c_cur + mc;
                 kvm_stat_guard gd;
                 const double hist = kvm_run_hist_of(qd, cur.run);
-                gd.mean_err = E1 / m + kvm_hist_mean(hist);
-                const double var_err = E2 / m + 2.0 * fabs(mc) * gd.mean_err + kvm_hist_var(hist);
+                gd.mean_err = E1 / m + kvm_hist_mean(hist, m);
+                const double var_err = E2 / m + 2.0 * fabs(mc) * gd.mean_err + kvm_hist_var(hist, m);
                 gd.g = kvm_sigma_guard(mean, sg, var_err / (2.0 * var) + gd.mean_err / sg);
                 gd.std_hi = sqrt(fmax(var, 0.0) + var_err + 1e-8 * (mean * mean + fabs(var)));
                 passed = kvm_cnsm_filter_guarded(mean, sg, qd.meanQ, qd.stdQ, qd.alpha, qd.beta, gd);

@@ -416,13 +416,14 @@ struct kvm_sum_err {
     double e1, e2;
 };
 // The reference's running sums (ex += d, ex2 += d * d, later -= the same) keep the rounding residue of everything that
-// ever passed through them since the interval began: a value of magnitude X leaves about u X^2 sqrt(m) in ex2 and
-// u X sqrt(m) in ex for the rest of the run, whatever the windows look like by then.  With `hist` = the largest x^2 the
-// run has seen, the reference's variance is uncertain by kvm_hist_var(hist) and its mean by kvm_hist_mean(hist) on top of
-// everything else.  On ordinary data (hist ~ level^2) both vanish next to the other guard terms; after a spike 1e6 x the
-// local sigma they decide (found by the adversarial sweep, seed 23: a 1e-158-scaled series with O(1) planted values).
-__device__ __forceinline__ double kvm_hist_var(double hist) { return 1e-14 * hist; }
-__device__ __forceinline__ double kvm_hist_mean(double hist) { return 1e-14 * sqrt(hist); }
+// ever passed through them since the interval began.  While values of magnitude X fill the window, ex2 is about m X^2 and
+// each of the ~2m additions and subtractions that carry them in and out rounds by up to u m X^2: up to 2 m^2 u X^2 stays
+// in ex2 -- 2 m u X^2 in the variance ex2 / m -- for the rest of the run, whatever the windows look like by then; the
+// mean keeps up to 2 m u X.  With `hist` = the largest x^2 the run has seen (u = 1.1e-16, margin 2):
+__device__ __forceinline__ double kvm_hist_var(double hist, int32_t m) { return 4e-16 * m * hist; }
+__device__ __forceinline__ double kvm_hist_mean(double hist, int32_t m) { return 4e-16 * m * sqrt(hist); }
+// On ordinary data (hist ~ level^2) this is of the size of the level term of kvm_sigma_guard; after a burst 1e6 x the
+// local sigma it decides (found by the adversarial sweep, seed 23: a 1e-158-scaled series with O(1) planted windows).
 __device__ __forceinline__ kvm_sum_err kvm_prefix_err(double pm) {
     kvm_sum_err r;
     r.e1 = 2e-11 * sqrt(pm);
@@ -526,8 +527,8 @@ __device__ __forceinline__ kvm_stat_guard kvm_make_stat_guard(double c, double s
     kvm_stat_guard r;
     const double ms = s1 / m, var = s2 / m - ms * ms, mean = c + ms;
     const kvm_sum_err e = kvm_prefix_err(pm);
-    r.mean_err = e.e1 / m + kvm_hist_mean(hist);
-    const double var_err = e.e2 / m + 2.0 * fabs(ms) * r.mean_err + kvm_hist_var(hist);
+    r.mean_err = e.e1 / m + kvm_hist_mean(hist, m);
+    const double var_err = e.e2 / m + 2.0 * fabs(ms) * r.mean_err + kvm_hist_var(hist, m);
     r.g = kvm_sigma_guard(mean, sqrt(var), var_err / (2.0 * var) + r.mean_err / sqrt(var));
     r.std_hi = sqrt(fmax(var, 0.0) + var_err + 1e-8 * (mean * mean + fabs(var)));
     return r;
