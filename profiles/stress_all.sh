@@ -19,3 +19,4 @@ run python -u profiles/exotic_params.py
 run python -u profiles/fuzz_index.py 64 2
 run python -u profiles/fuzz_ucr.py 45 4
 run python -u profiles/fuzz_lifecycle.py 400 5
+run python -u profiles/fuzz_spikes.py 150 3
