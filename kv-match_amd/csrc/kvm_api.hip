@@ -613,7 +613,7 @@ static int build_plan(kvm_ctx *ctx, bool cnsm, int32_t m, const int32_t *left, c
     // here (stable, by `left`) -- the same (offset, distance) pairs come out, in the tie order of the sorted list.  The cNSM
     // engines merge consecutive intervals into one fetched chunk and index it with `left - begin`: out of order that is an
     // IndexOutOfBoundsException or the range check of readTimeSeries in Java, depending on the list; refused here.
-    std::vector<int32_t> sorted_l, sorted_r;
+    std::vector<int32_t> sorted_l, sorted_r, clipped_r;
     {
         bool ascending = true;
         for (int32_t p = 1; p < k; p++) ascending &= left[p] >= left[p - 1];
@@ -671,7 +671,25 @@ static int build_plan(kvm_ctx *ctx, bool cnsm, int32_t m, const int32_t *left, c
                     pl.chunk_lo[p] = (int32_t)begin;
                     pl.chunk_hi[p] = (int32_t)end;
                 }
+            // An interval is scanned inside its chunk only: `if (end1 > data.size() - 1) end1 = data.size() - 1`
+            // (K/NormQueryEngine.java:494, K/NormQueryEngineDtw.java:536).  The chunk ends where its LAST interval ends, so
+            // in a list with overlapping or nested intervals an earlier, longer interval loses the windows that reach past
+            // it (found by profiles/fuzz_lists.py); with disjoint sorted intervals the clip never bites.
+            for (int32_t p = beginIdx; p <= endIdx; p++) {
+                const int64_t last_start = end - m + 1 + shift;  // in the coordinates of `right`
+                if ((int64_t)right[p] > last_start) {
+                    if (clipped_r.empty()) clipped_r.assign(right, right + k);
+                    clipped_r[(size_t)p] = (int32_t)std::max<int64_t>(last_start, (int64_t)left[p] - 1);
+                }
+            }
         }
+    }
+    // (cntCandidate is counted from the list as given, K/NormQueryEngine.java:485; the plan from the clipped one)
+    int64_t cnt_given = 0;
+    const int32_t *right_plan = right;
+    if (!clipped_r.empty()) {
+        for (int32_t p = 0; p < k; p++) cnt_given += (int64_t)right[p] - left[p] + 1;
+        right_plan = clipped_r.data();
     }
     // totals only (launch geometry, buffer sizes): the per-run prefix sums are formed on the device from the same rule
     const int64_t hi_max = n - m + 1;
@@ -679,9 +697,9 @@ static int build_plan(kvm_ctx *ctx, bool cnsm, int32_t m, const int32_t *left, c
     while ((1 << tile_log2) < tile_max) tile_log2++;
     plan_totals tot;
     static const bool have_avx2 = __builtin_cpu_supports("avx2");
-    if (have_avx2) plan_totals_avx2(left, right, k, shift, hi_max, m, hybrid, tile_log2, tot);
-    else plan_totals_generic(left, right, k, shift, hi_max, m, hybrid, tile_log2, tot);
-    const int64_t cnt_candidate = tot.cnt_candidate, n_tiles = tot.n_tiles, n_tiles_b = tot.n_tiles_b, n_tiles_c = tot.n_tiles_c, windows = tot.windows,
+    if (have_avx2) plan_totals_avx2(left, right_plan, k, shift, hi_max, m, hybrid, tile_log2, tot);
+    else plan_totals_generic(left, right_plan, k, shift, hi_max, m, hybrid, tile_log2, tot);
+    const int64_t cnt_candidate = clipped_r.empty() ? tot.cnt_candidate : cnt_given, n_tiles = tot.n_tiles, n_tiles_b = tot.n_tiles_b, n_tiles_c = tot.n_tiles_c, windows = tot.windows,
                   nr = tot.nr;
     const bool bad_rsm = tot.bad_rsm != 0;
     if (bad_rsm && !cnsm) {
@@ -698,7 +716,7 @@ static int build_plan(kvm_ctx *ctx, bool cnsm, int32_t m, const int32_t *left, c
     }
     if (k > 0) {
         std::memcpy(pl.left, left, (size_t)k * 4);
-        std::memcpy(pl.right, right, (size_t)k * 4);
+        std::memcpy(pl.right, right_plan, (size_t)k * 4);
     }
     pl.cnt_candidate += cnt_candidate;
     pl.n_tiles += n_tiles;

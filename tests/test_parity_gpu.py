@@ -1113,6 +1113,15 @@ def test_interval_lists_not_in_the_form_sort_and_merge_leaves(world):
             compare(kvmatch.QueryEngineDtw(ctx).verify((L, R), 1, q, 3.0, 10), oracle.rsm_dtw(s, q, L, R, 0, 3.0, 10), tag=name + " rsm_dtw")
             compare(kvmatch.NormQueryEngineDtw(ctx).verify((L, R), 1, q, 1.0, 10, 1.5, 3.0),
                     oracle.cnsm_dtw(s, q, L, R, 0, 1.0, 10, 1.5, 3.0), tag=name + " cnsm_dtw")
+            # every window an answer: shows WHICH windows are scanned.  The cNSM engines scan an interval inside its merged
+            # chunk only, and the chunk ends where its LAST interval ends (K/NormQueryEngine.java:494): in "nested" and
+            # "same_left" an earlier, longer interval loses the windows that reach past it (profiles/fuzz_lists.py found the
+            # library scanning them)
+            compare(kvmatch.NormQueryEngine(ctx).verify((L, R), 1, q, 1e3, 1e9, 1e9), oracle.cnsm_ed(s, q, L, R, 0, 1e3, 1e9, 1e9),
+                    tag=name + " cnsm_ed, every window")
+            compare(kvmatch.NormQueryEngineDtw(ctx).verify((L, R), 1, q, 1e3, 10, 1e9, 1e9),
+                    oracle.cnsm_dtw(s, q, L, R, 0, 1e3, 10, 1e9, 1e9), tag=name + " cnsm_dtw, every window")
+            compare(kvmatch.QueryEngine(ctx).verify((L, R), 1, q, 1e6), oracle.rsm_ed(s, q, L, R, 0, 1e6), tag=name + " rsm_ed, every window")
         # not sorted by left
         L = np.array([120_000, 100, 19_990, 50_000, 199_990], dtype=np.int32)
         R = np.array([120_100, 400, 20_010, 50_040, 200_020], dtype=np.int32)
