@@ -20,3 +20,4 @@ run python -u profiles/fuzz_index.py 64 2
 run python -u profiles/fuzz_ucr.py 45 4
 run python -u profiles/fuzz_lifecycle.py 400 5
 run python -u profiles/fuzz_spikes.py 150 3
+run python -u profiles/fuzz_knife.py 60 7 12
