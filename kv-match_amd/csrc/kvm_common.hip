@@ -19,6 +19,9 @@ static_assert(sizeof(plan_sums) == KVM_PLAN_SUMS_BYTES, "kvm_api.hip sizes the b
 __device__ __forceinline__ plan_sums plan_add(plan_sums a, plan_sums b) {
     return plan_sums{a.nr + b.nr, a.ta + b.ta, a.tb + b.tb, a.tc + b.tc, a.w + b.w};
 }
+__device__ __forceinline__ plan_sums plan_sub(plan_sums a, plan_sums b) {
+    return plan_sums{a.nr - b.nr, a.ta - b.ta, a.tb - b.tb, a.tc - b.tc, a.w - b.w};
+}
 __device__ __forceinline__ plan_sums plan_shfl_xor(plan_sums v, int o) {
     return plan_sums{__shfl_xor(v.nr, o, 64), __shfl_xor(v.ta, o, 64), __shfl_xor(v.tb, o, 64), __shfl_xor(v.tc, o, 64),
                      __shfl_xor(v.w, o, 64)};
@@ -52,7 +55,7 @@ __global__ __launch_bounds__(PLAN_THREADS) void kvm_plan_totals_kernel(const int
                                                                       int tile_log2, plan_sums *__restrict__ block_tot) {
     __shared__ plan_sums wave_tot[PLAN_THREADS / 64];
     const int64_t p = (int64_t)blockIdx.x * PLAN_THREADS + threadIdx.x;
-    plan_sums mine{0, 0, 0, 0};
+    plan_sums mine{0, 0, 0, 0, 0};
     if (p < k) {
         const int32_t l = src_left[p], r = src_right[p];
         left[p] = l;
@@ -73,7 +76,7 @@ __global__ __launch_bounds__(PLAN_THREADS) void kvm_plan_runs_kernel(const int32
     __shared__ plan_sums wave_tot[PLAN_THREADS / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // totals of the blocks before this one: summed here (few blocks), or already scanned by kvm_plan_scan_kernel
-    plan_sums before{0, 0, 0, 0};
+    plan_sums before{0, 0, 0, 0, 0};
     if (scanned) {
         before = block_tot[blockIdx.x];
     } else {
@@ -117,7 +120,7 @@ __global__ __launch_bounds__(1024) void kvm_plan_scan_kernel(plan_sums *__restri
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t per = (blocks + 1023) / 1024;
     const int64_t b0 = min(blocks, (int64_t)tid * per), b1 = min(blocks, b0 + per);
-    plan_sums mine{0, 0, 0, 0};
+    plan_sums mine{0, 0, 0, 0, 0};
     for (int64_t b = b0; b < b1; b++) mine = plan_add(mine, block_tot[b]);
     plan_sums inc = mine;
 #pragma unroll
@@ -127,9 +130,9 @@ __global__ __launch_bounds__(1024) void kvm_plan_scan_kernel(plan_sums *__restri
     }
     if (lane == 63) wave_tot[wave] = inc;
     __syncthreads();
-    plan_sums run{0, 0, 0, 0};
+    plan_sums run{0, 0, 0, 0, 0};
     for (int w = 0; w < wave; w++) run = plan_add(run, wave_tot[w]);
-    run = plan_add(run, plan_sums{inc.nr - mine.nr, inc.ta - mine.ta, inc.tb - mine.tb, inc.w - mine.w});
+    run = plan_add(run, plan_sub(inc, mine));  // exclusive inside the wave
     for (int64_t b = b0; b < b1; b++) {
         const plan_sums t = block_tot[b];
         block_tot[b] = run;
@@ -137,7 +140,7 @@ __global__ __launch_bounds__(1024) void kvm_plan_scan_kernel(plan_sums *__restri
     }
 }
 
-// `scratch`: 32 B per 256 intervals (block totals)
+// `scratch`: KVM_PLAN_SUMS_BYTES per 256 intervals (block totals)
 hipError_t kvm_launch_plan_runs(const int32_t *src_left, const int32_t *src_right, int32_t *left, int32_t *right, int32_t k,
                                 int32_t shift, int64_t hi_max, int hybrid, int tile_log2, kvm_run *runs, void *scratch,
                                 hipStream_t s, const int32_t *chunk_lo, const int32_t *chunk_hi, int2 *run_chunk) {
