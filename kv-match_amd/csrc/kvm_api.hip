@@ -910,13 +910,14 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
     rc = build_plan(ctx, cnsm, m, left, right, k, shift, tile_max, hybrid, pl);
     if (rc) return rc;
     // Class-C tiles (two <= 16-candidate remainders per row, kvm_ed_dot.hip) fill the lanes better but a class-C unit
-    // takes 1.3 x as long as a class-B unit: worth it when the list needs more than one round of the chip's wave slots
-    // (throughput), not when the call lasts as long as its longest unit (latency).  Decided here, from the totals; the
-    // device-side plan follows the same rule (kvm_plan_tiles: hybrid = 2 with class C, 1 without).
+    // lasts 1.3 x as long as a class-B unit: always worth it when the list needs more than one round of the chip's wave
+    // slots (throughput); below that the launcher's model of the launch decides (kvm_ed_dot_choose_classes).  Decided
+    // here, from the totals; the device-side plan follows the same rule (kvm_plan_tiles: hybrid = 2 with class C, 1 without).
     int hybrid_mode = 0;
     if (hybrid) {
-        const int64_t units = (pl.n_tiles + 7) / 8 + (pl.n_tiles_b + 7) / 8 + (pl.n_tiles_c + 15) / 16;
-        hybrid_mode = units > (int64_t)ctx->num_cu * 8 ? 2 : 1;
+        hybrid_mode = kvm_ed_dot_choose_classes(m, pl.n_tiles, pl.n_tiles_b, pl.n_tiles_c, ctx->num_cu);
+        if (const char *e = getenv("KVM_ED_HYBRID"))  // experiments: force the tiling (1 = classes A / B, 2 = A / B / C)
+            if (e[0] == '1' || e[0] == '2') hybrid_mode = e[0] - '0';
         if (hybrid_mode == 1) {
             pl.n_tiles_b += pl.n_tiles_c;
             pl.n_tiles_c = 0;
