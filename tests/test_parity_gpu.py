@@ -1075,27 +1075,35 @@ def test_ed_pruner_class_c_on_a_long_list_of_short_runs(built):
         compare(got, oracle.rsm_ed(s, q, L, R, 0, 30.0), tag="long list, wide eps")
 
 
+def _long_list_of_short_runs(k, m, seed):
+    from kvmatch import datagen
+    rng = np.random.default_rng(seed)
+    lens = rng.integers(1, 21, k)
+    gaps = rng.integers(2, 9, k)
+    L = (1 + np.cumsum(lens + gaps) - lens - gaps).astype(np.int64) + 1
+    R = L + lens - 1
+    n = int(R[-1]) + 4 * m
+    s = datagen.gen_series(n, seed=seed)
+    q = s[n // 3: n // 3 + m].copy()
+    L, R = L.astype(np.int32), R.astype(np.int32)
+    for i in rng.choice(len(L), 200, replace=False):                      # answers in every part of the list
+        off = int(rng.integers(L[i], R[i] + 1))
+        noise = rng.normal(size=m) * 0.01 * min(1.0, float(np.std(q)))
+        s[off - 1: off - 1 + m] = 1.5 * q + 0.3 + noise if i % 2 else q + noise
+    return s, q, L, R
+
+
 def test_lists_of_more_than_262144_intervals(built):
     """Above 1024 blocks of 256 intervals the device-side plan scans its block totals in a kernel of its own
     (kvm_plan_scan_kernel).  That kernel once built its in-wave exclusive prefix from a four-field initialiser of the
     five-field sums (class-C tiles were added in round 2): class-C tile bases and window bases of every such list were
     wrong -- a memory fault in the tile expansion.  330 000 runs of 1..20 candidates through all four engines (early
-    abandoning off and on), bit for bit against the oracle."""
+    abandoning off and on), bit for bit against the oracle; on a series of zeros (eps = 0) millions of DTW candidates take
+    the sequential tie path, in several batches of its 1-GiB slot buffer (dtw_resolve_ambiguous)."""
     import kvmatch
-    from kvmatch import datagen
-    n, m = 5_400_000, 64
-    s = datagen.gen_series(n, seed=5)
-    rng = np.random.default_rng(5)
-    q = s[2_000_000:2_000_000 + m].copy()
-    lens = rng.integers(1, 21, 330_000)
-    gaps = rng.integers(2, 9, 330_000)
-    L = (1 + np.cumsum(lens + gaps) - lens - gaps).astype(np.int64) + 1
-    R = L + lens - 1
-    assert R[-1] + m < n and len(L) > 262_144 + 256
-    L, R = L.astype(np.int32), R.astype(np.int32)
-    for i in rng.choice(len(L), 200, replace=False):                      # answers in every part of the list
-        off = int(rng.integers(L[i], R[i] + 1))
-        s[off - 1: off - 1 + m] = 1.5 * q + 0.3 + rng.normal(size=m) * 0.01 if i % 2 else q + rng.normal(size=m) * 0.01
+    m = 64
+    s, q, L, R = _long_list_of_short_runs(330_000, m, 5)
+    assert len(L) > 262_144 + 256
     with kvmatch.Phase2Context(0) as ctx:
         ctx.load_series(s)
         ctx.set_option(kvmatch.OPT_SORT_VIOLATION, 1)
@@ -1110,10 +1118,40 @@ def test_lists_of_more_than_262144_intervals(built):
         ctx.set_option(kvmatch.OPT_EARLY_ABANDON, 0)
         got = kvmatch.QueryEngine(ctx).verify((L, R), 1, q, 6.0)           # many pruner survivors in every class
         compare(got, oracle.rsm_ed(s, q, L, R, 0, 6.0), tag="330k intervals rsm_ed wide")
-        got = kvmatch.QueryEngineDtw(ctx).verify((L, R), 1, q, 1.0, 3)
-        compare(got, oracle.rsm_dtw(s, q, L, R, 0, 1.0, 3), tag="330k intervals rsm_dtw")
-        got = kvmatch.NormQueryEngineDtw(ctx).verify((L, R), 1, q, 1.0, 3, 2.0, 1.0, resolved=True)
-        compare(got, oracle.cnsm_dtw(s, q, L, R, 0, 1.0, 3, 2.0, 1.0), tag="330k intervals cnsm_dtw")
+        for eps in (1.0, 0.0):
+            got = kvmatch.QueryEngineDtw(ctx).verify((L, R), 1, q, eps, 3)
+            compare(got, oracle.rsm_dtw(s, q, L, R, 0, eps, 3), tag=f"330k intervals rsm_dtw eps={eps}")
+            got = kvmatch.NormQueryEngineDtw(ctx).verify((L, R), 1, q, eps, 3, 2.0, 1.0, resolved=True)
+            compare(got, oracle.cnsm_dtw(s, q, L, R, 0, eps, 3, 2.0, 1.0), tag=f"330k intervals cnsm_dtw eps={eps}")
+        # a series of zeros with a one in a hundred, query of zeros, eps = 0: nearly every candidate's bounds land exactly
+        # on the threshold -> millions of candidates through the sequential tie path, in several batches
+        rng = np.random.default_rng(7)
+        z = (rng.random(len(s)) < 0.01).astype(np.float64)
+        ctx.load_series(z)
+        got = kvmatch.QueryEngineDtw(ctx).verify((L, R), 1, np.zeros(m), 0.0, 3)
+        compare(got, oracle.rsm_dtw(z, np.zeros(m), L, R, 0, 0.0, 3), tag="330k intervals rsm_dtw ties")
+        assert got.stats[kvmatch.STAT_DTW_SEQUENTIAL] > (1 << 30) // (2 * m * 8) and len(got.offsets) > 1_000_000
+
+
+def test_lists_of_more_than_16_rounds_of_wave_slots(built):
+    """From 16 units per wave slot on (32 768 units on this part) the pruner's launcher stops modelling window splits and
+    the device-built lists are launched on a grid that never splits: 800 000 runs of 1..20 candidates are ~ 47 000 units.
+    Both ED engines, early abandoning off and on."""
+    import kvmatch
+    m = 64
+    s, q, L, R = _long_list_of_short_runs(800_000, m, 6)
+    lens = R.astype(np.int64) - L + 1
+    assert (lens <= 16).sum() // 16 + (lens > 16).sum() // 8 > 16 * 2048 + 4096
+    with kvmatch.Phase2Context(0) as ctx:
+        ctx.load_series(s)
+        for ab in (0, 1):
+            ctx.set_option(kvmatch.OPT_EARLY_ABANDON, ab)
+            got = kvmatch.QueryEngine(ctx).verify((L, R), 1, q, 1.0)
+            compare(got, oracle.rsm_ed(s, q, L, R, 0, 1.0), tag=f"800k intervals rsm_ed ab={ab}")
+            assert len(got.offsets) >= 90
+            got = kvmatch.NormQueryEngine(ctx).verify((L, R), 1, q, 1.0, 2.0, 1.0)
+            compare(got, oracle.cnsm_ed(s, q, L, R, 0, 1.0, 2.0, 1.0), tag=f"800k intervals cnsm_ed ab={ab}")
+            assert len(got.offsets) >= 10
 
 
 def test_interval_lists_not_in_the_form_sort_and_merge_leaves(world):
