@@ -27,6 +27,7 @@ def around(x):
 
 with kvmatch.Phase2Context(0) as ctx:
     ctx.set_option(kvmatch.OPT_SORT_VIOLATION, 1)
+    if os.environ.get("FUZZ_ABANDON") == "0": ctx.set_option(kvmatch.OPT_EARLY_ABANDON, 0)   # host-planned tile classes A / B / C + window splits
     for case in range(cases):
         kind = int(rng.integers(0, 5))
         if kind == 0: s = datagen.gen_series(n, seed=1000 * seed + case)

@@ -16,6 +16,7 @@ oracle.set_lenient_sort(True)
 bad = exc = total = 0
 with kvmatch.Phase2Context(0) as ctx:
     ctx.load_series(s); ctx.set_option(kvmatch.OPT_SORT_VIOLATION, 1)
+    if os.environ.get("FUZZ_ABANDON") == "0": ctx.set_option(kvmatch.OPT_EARLY_ABANDON, 0)   # host-planned tile classes A / B / C + window splits
     hostile = len(sys.argv) > 4 and sys.argv[4] == "hostile"   # integer / piecewise-constant / NaN-sprinkled / huge-level series
     for case in range(cases):
         if hostile and case % 10 == 0:
