@@ -841,6 +841,7 @@ hipError_t kvm_launch_ed_dot(const double *series, const double2 *prefix, int64_
         if ((double)(unitsA + unitsS) < 16.0 * slots) {
             fA = fB = 4;
             split_units = qd.early_abandon ? (int64_t)(slots / 2) : (int64_t)(4 * slots);
+            if (const char *e = getenv("KVM_ED_SPLIT_UNITS")) split_units = atoll(e);  // experiments
         }
     } else if (qd.early_abandon) {
         // unit durations are unpredictable; split only when the list cannot fill the chip anyway (latency-bound)
