@@ -840,7 +840,10 @@ hipError_t kvm_launch_ed_dot(const double *series, const double2 *prefix, int64_
         split_units = -1;  // (bounds too large to size the grid for a split: the kernel then never splits)
         if ((double)(unitsA + unitsS) < 16.0 * slots) {
             fA = fB = 4;
-            split_units = qd.early_abandon ? (int64_t)(slots / 2) : (int64_t)(4 * slots);
+            // (profiles/ed_norm_split_sweep.py: a four-way split pays up to one unit per wave slot for long windows and up to
+            // half of that for short ones, whose parts are mostly prologue; it was 4 x slots until late in round 2, which
+            // cost up to 1.57 x at m = 1024)
+            split_units = (qd.early_abandon || qd.m < 4096) ? (int64_t)(slots / 2) : (int64_t)slots;
             if (const char *e = getenv("KVM_ED_SPLIT_UNITS")) split_units = atoll(e);  // experiments
         }
     } else if (qd.early_abandon) {
