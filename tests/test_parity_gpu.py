@@ -2,6 +2,8 @@
 inputs.  Bar (north_star): identical answer offsets and #answers, distances within 1e-6 relative.  What is asserted
 is stronger: cntCandidate identical, answer list identical in content AND order, distances BIT-identical for all four
 variants (kvm_exact.hip replays the reference's running sums and sequential additions for every survivor)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -1248,6 +1250,33 @@ def test_ucr_ed_executor_at_epsilon_zero(world):
         eng = kvmatch.NormQueryEngine(ctx).verify((L, R), 1, q, 0.0, 1e9, 1e9)
         compare(eng, oracle.cnsm_ed(s, q, L, R, 0, 0.0, 1e9, 1e9), tag="engine at eps 0")
         assert len(eng) < 10
+    finally:
+        ctx.load_series(series)
+
+
+def test_ucr_ed_partial_sum_tie_is_the_known_difference(world):
+    """U/UcrEdQueryExecutor.java's distance() loop runs `while sum < bsf`: a partial sum (in its |zQ|-sorted order) that lands
+    EXACTLY on eps^2 ends the loop and the window is reported at distance eps, whatever its real distance.  Found by
+    profiles/fuzz_ucr.py (seed 261) on integer-valued data: offset 35265, real distance 10.28, reported at eps = 2.  The
+    oracle restates that; the executor mirrors do NOT: they answer with the windows whose full sum is <= eps^2.
+    This test pins both halves: the oracle's fifth answer and the library's four."""
+    kvmatch, datagen, series, ctx = world
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "ucr_ed_partial_sum_tie.npz"))
+    s, q = g["s"].astype(np.float64), g["q"].astype(np.float64)
+    eps, alpha, beta = float(g["eps"]), float(g["alpha"]), float(g["beta"])
+    off, dist, st = oracle.ucr_ed(s, q, eps, alpha, beta)
+    assert np.array_equal(off, g["oracle_off"]) and np.array_equal(dist, g["oracle_dist"])
+    tie = [int(o) for o, d in zip(off, dist) if d == eps]
+    assert tie == [35265]
+    w = s[tie[0] - 1: tie[0] - 1 + len(q)]
+    real = np.sqrt(np.sum(((w - w.mean()) / w.std() - (q - q.mean()) / q.std()) ** 2))
+    assert real > 5 * eps                                                   # nowhere near a match
+    ctx.load_series(s)
+    try:
+        e = kvmatch.UcrEdQueryExecutor(ctx, len(s), len(q), q, eps, alpha, beta)
+        e.run()
+        keep = [i for i, o in enumerate(off.tolist()) if o not in tie]
+        assert np.array_equal(e.answers.offsets, off[keep]) and np.array_equal(e.answers.distances, dist[keep])
     finally:
         ctx.load_series(series)
 
