@@ -5,6 +5,7 @@ from oracle/kvm_oracle.c), statement for statement, to lower the risk that the C
     cnsm_ed   K/NormQueryEngine.java:192-198 (query statistics), :437-526, sort
     rsm_dtw   K/QueryEngineDtw.java:352-449, sort
     cnsm_dtw  K/NormQueryEngineDtw.java:205-211, :460-601, sort
+    ucr_ed    K/experiments/ucr/UcrEdQueryExecutor.java:85-175;  ucr_dtw  K/experiments/ucr/UcrDtwQueryExecutor.java:84-315
     DtwUtils  K/utils/DtwUtils.java:24-337, CircularArray K/common/CircularArray.java:21-110,
     readTimeSeries range check K/operator/file/TimeSeriesFileOperator.java:55-57
 
@@ -487,6 +488,168 @@ def cnsm_dtw(series, query, left, right, last_segment, epsilon, rho, alpha, beta
                     ex -= T[j]
                     ex2 -= T[j] * T[j]
     return _sorted_answers(answers), cnt_candidate
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The index-free full-scan executors of the reference's experiments (U/ = K/experiments/ucr/), written from the Java text
+# like the engines above.  The scanner (an iterator over TimeSeriesNodes) is restated as a pass over the first N points:
+# nextData() (U/UcrEdQueryExecutor.java:57-79) counts `++cnt <= N` only inside a node, so N is a loose upper limit; the
+# callers pass N = the length of the data.
+UCR_EPOCH = 100000              # U/UcrDtwQueryExecutor.java:97
+
+
+def ucr_ed(series, query, epsilon, alpha, beta):
+    """U/UcrEdQueryExecutor.java:96-175.  One pair of running sums over the whole scan; 1-based answer offsets
+    (`i - M + 2`, :161).  distance() (:85-92) loops `while sum < bsf`: a partial sum that lands exactly on bsf ends it."""
+    M = len(query)
+    ex = ex2 = 0.0
+    Q = [0.0] * M
+    for i in range(M):
+        d = query[i]
+        ex += d
+        ex2 += d * d
+        Q[i] = d
+    mean_q = ex / M
+    std_q = ex2 / M
+    v = std_q - mean_q * mean_q
+    std_q = math.sqrt(v) if v >= 0 else float("nan")
+    for i in range(M):
+        Q[i] = _div(Q[i] - mean_q, std_q)
+    q_tmp = [(Q[i], i) for i in range(M)]
+    # Arrays.sort with Double.compare(|o2|, |o1|): a consistent comparator, so the stable sort's result is determined by it
+    q_tmp = sorted(q_tmp, key=functools.cmp_to_key(lambda o1, o2: _java_double_compare(abs(o2[0]), abs(o1[0]))))
+    order = [0] * M
+    for i in range(M):
+        Q[i] = q_tmp[i][0]
+        order[i] = q_tmp[i][1]
+    t = [0.0] * (2 * M)
+    bsf = epsilon * epsilon
+    ex = ex2 = 0.0
+    answers = []
+    i = 0
+    for d in series:
+        ex += d
+        ex2 += d * d
+        t[i % M] = d
+        t[(i % M) + M] = d
+        if i >= M - 1:
+            j = (i + 1) % M
+            mean = ex / M
+            std = ex2 / M
+            v = std - mean * mean
+            std = math.sqrt(v) if v >= 0 else float("nan")
+            if abs(mean - mean_q) <= beta and _div(std, std_q) <= alpha and _div(std, std_q) >= _div(1.0, alpha):
+                total = 0.0                                  # distance(), :85-92
+                k = 0
+                while k < M and total < bsf:
+                    x = _div(t[order[k] + j] - mean, std)
+                    total += (x - Q[k]) * (x - Q[k])
+                    k += 1
+                if total <= epsilon * epsilon:
+                    answers.append((i - M + 2, math.sqrt(total)))
+            ex -= t[j]
+            ex2 -= t[j] * t[j]
+        i += 1
+    return _sorted_answers(answers)
+
+
+def ucr_dtw(series, query, epsilon, rho, alpha, beta):
+    """U/UcrDtwQueryExecutor.java:84-315.  The data in buffers of EPOCH points that overlap by M - 1 (:175-203); running
+    sums restart per buffer (:215-216); the data envelope is built over the buffer (:210); cb1 / cb2 are allocated once and
+    never cleared between windows (:157-161 -- the engines allocate fresh ones); 0-BASED answer offsets (:283); the query
+    is sorted with the contract-breaking comparator (int)(|o2| - |o1|) (:139-142) like NormQueryEngineDtw."""
+    M = len(query)
+    ex = ex2 = 0.0
+    q = [0.0] * M
+    for i in range(M):
+        d = query[i]
+        ex += d
+        ex2 += d * d
+        q[i] = d
+    mean_q = ex / M
+    std_q = ex2 / M
+    v = std_q - mean_q * mean_q
+    std_q = math.sqrt(v) if v >= 0 else float("nan")
+    for i in range(M):
+        q[i] = _div(q[i] - mean_q, std_q)
+    l, u = [0.0] * M, [0.0] * M
+    lower_upper_lemire(q, M, rho, l, u)
+    q_tmp = [(q[i], i) for i in range(M)]
+    try:
+        java_arrays_sort(q_tmp, lambda o1, o2: _java_int(abs(o2[0]) - abs(o1[0])))
+    except ComparisonContractViolation as e:
+        raise IllegalArgumentException(str(e))
+    order = [o for _, o in q_tmp]
+    qo = [q[o] for o in order]
+    uo = [u[o] for o in order]
+    lo = [l[o] for o in order]
+    cb, cb1, cb2 = [0.0] * M, [0.0] * M, [0.0] * M
+    t = [0.0] * (2 * M)
+    tz = [0.0] * M
+    buffer = [0.0] * UCR_EPOCH
+    u_buff, l_buff = [0.0] * UCR_EPOCH, [0.0] * UCR_EPOCH
+    source = iter(series)
+    bsf = epsilon * epsilon
+    answers = []
+    done = False
+    it = 0
+    while not done:
+        if it == 0:
+            for k in range(M - 1):
+                d = next(source, None)
+                if d is not None:                          # (EOFException: do nothing)
+                    buffer[k] = d
+        else:
+            for k in range(M - 1):
+                buffer[k] = buffer[UCR_EPOCH - M + 1 + k]
+        ep = M - 1
+        while ep < UCR_EPOCH:
+            d = next(source, None)
+            if d is None:
+                break
+            buffer[ep] = d
+            ep += 1
+        if ep <= M - 1:
+            done = True
+        else:
+            lower_upper_lemire(buffer, ep, rho, l_buff, u_buff)
+            ex = ex2 = 0.0
+            for i in range(ep):
+                d = buffer[i]
+                ex += d
+                ex2 += d * d
+                t[i % M] = d
+                t[(i % M) + M] = d
+                if i >= M - 1:
+                    mean = ex / M
+                    std = ex2 / M
+                    v = std - mean * mean
+                    std = math.sqrt(v) if v >= 0 else float("nan")
+                    j = (i + 1) % M
+                    I = i - (M - 1)
+                    if abs(mean - mean_q) <= beta and _div(std, std_q) <= alpha and _div(std, std_q) >= _div(1.0, alpha):
+                        lb_kim = lb_kim_hierarchy(t, q, j, M, mean, std, bsf)
+                        if lb_kim <= bsf:
+                            lb_k = lb_keogh_cumulative(order, t, uo, lo, cb1, j, M, mean, std, bsf)
+                            if lb_k <= bsf:
+                                for k in range(M):
+                                    tz[k] = _div(t[k + j] - mean, std)
+                                lb_k2 = lb_keogh_data_cumulative(order, qo, cb2, I, l_buff, u_buff, M, mean, std, bsf)
+                                if lb_k2 <= bsf:
+                                    src = cb1 if lb_k > lb_k2 else cb2
+                                    cb[M - 1] = src[M - 1]
+                                    for k in range(M - 2, -1, -1):
+                                        cb[k] = cb[k + 1] + src[k]
+                                    dist = dtw(tz, q, cb, M, rho, bsf)
+                                    if dist <= bsf:
+                                        answers.append((it * (UCR_EPOCH - M + 1) + i - M + 1, math.sqrt(dist)))
+                    ex -= t[j]
+                    ex2 -= t[j] * t[j]
+            if ep < UCR_EPOCH:
+                done = True
+            else:
+                it += 1
+    return _sorted_answers(answers)
 
 
 # ---------------------------------------------------------------------------------------------------------------
