@@ -306,7 +306,7 @@ def test_ucr_ed_executor_reports_a_partial_sum_that_lands_on_epsilon_squared(bui
     sum that lands exactly on eps^2 ends the loop and the window is an answer at distance eps.  A natural instance (integer
     data, found by profiles/fuzz_ucr.py seed 261): offset 35265 is reported at distance 2 = eps, its real distance is 10.28."""
     import os
-    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "ucr_ed_partial_sum_tie.npz"))
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "ucr", "ucr_ed_partial_sum_tie.npz"))
     s, q = g["s"].astype(np.float64), g["q"].astype(np.float64)
     off, dist, st = oracle.ucr_ed(s, q, float(g["eps"]), float(g["alpha"]), float(g["beta"]))
     assert np.array_equal(off, g["oracle_off"]) and np.array_equal(dist, g["oracle_dist"])

@@ -1261,7 +1261,7 @@ def test_ucr_ed_partial_sum_tie_is_the_known_difference(world):
     oracle restates that; the executor mirrors do NOT: they answer with the windows whose full sum is <= eps^2.
     This test pins both halves: the oracle's fifth answer and the library's four."""
     kvmatch, datagen, series, ctx = world
-    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "ucr_ed_partial_sum_tie.npz"))
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "ucr", "ucr_ed_partial_sum_tie.npz"))
     s, q = g["s"].astype(np.float64), g["q"].astype(np.float64)
     eps, alpha, beta = float(g["eps"]), float(g["alpha"]), float(g["beta"])
     off, dist, st = oracle.ucr_ed(s, q, eps, alpha, beta)
