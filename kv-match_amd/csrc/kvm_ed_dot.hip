@@ -31,6 +31,7 @@
 // hipcc scalarises HIP's double2 and re-pairs it as ds_read2_b64, whose 8-B banking rules conflict 4-way here.
 #include "kvm_internal.h"
 #include "kvm_seqadd.h"
+#include "kvm_ed_launch_model.h"
 
 #include <algorithm>
 #include <cmath>
@@ -725,97 +726,10 @@ __global__ __launch_bounds__(256, 2) void kvm_ed_dot_kernel(edd_args A, const kv
     }
 }
 
-// ---- the launcher's model of a launch: which window split (fA for class A, fB for classes B and C) ends first -----------
-// Fitted to profiles/ed_split_sweep.py (81 list shapes x 9 split pairs, m = 512 .. 8192, 10^5 .. 4 10^6 candidates, mean
-// run 8 .. 400; profiles/r02_ed_split_sweep_{a,b}.log): rms error 7 %, the pair it picks is 2 % (geometric mean; worst
-// 14 %) slower than the best measured pair, where the round-based model it replaces lost 9-14 % (worst 40 %).
-//  * a part (one wave's share of a unit) costs  a + b ceil(chunks / f)  microseconds on a full chip -- the per-part
-//    prologue (statistics, staging tables, first chunk) is what makes splitting short windows expensive;
-//  * parts start in launch order (A, C, B) on `slots` wave slots;
-//  * every resident wave advances at a speed that depends on how full the chip is (two waves on a SIMD share its fp64
-//    pipe; below one wave per SIMD the clock is higher as well): piecewise linear in the fraction of occupied slots.
-// The makespan is then a short event simulation over cohorts of identical parts (a few dozen events).
-static double edd_speed(double x) {
-    static const double kx[6] = {1.0, 0.75, 0.55, 0.5, 0.25, 0.0}, kv[6] = {1.0, 1.073, 1.094, 1.664, 1.765, 2.187};
-    if (x >= 1.0) return 1.0;
-    for (int i = 1; i < 6; i++)
-        if (x >= kx[i]) return kv[i - 1] + (kv[i] - kv[i - 1]) * (kx[i - 1] - x) / (kx[i - 1] - kx[i]);
-    return kv[5];
-}
-static double edd_makespan(const double cnt_in[3], const double w[3], double slots) {
-    constexpr int CAP = 48;
-    double cnt[3] = {cnt_in[0], cnt_in[1], cnt_in[2]};
-    double a_cnt[CAP], a_rem[CAP];
-    int na = 0, qi = 0;
-    double free_slots = slots, t = 0.0;
-    for (int guard = 0; guard < 100000; guard++) {
-        while (free_slots > 0 && qi < 3) {
-            if (cnt[qi] <= 0) { qi++; continue; }
-            const double take = std::min(free_slots, cnt[qi]);
-            if (na == CAP) {  // (never seen: cohorts retire as fast as they start) -- finish with the fluid bound
-                double work = 0;
-                for (int i = 0; i < na; i++) work += a_cnt[i] * a_rem[i];
-                for (int c = qi; c < 3; c++) work += cnt[c] * w[c];
-                return t + work / slots;
-            }
-            a_cnt[na] = take, a_rem[na] = w[qi], na++;
-            free_slots -= take, cnt[qi] -= take;
-        }
-        if (na == 0) return t;
-        double n = 0, rem = 1e300;
-        for (int i = 0; i < na; i++) n += a_cnt[i], rem = std::min(rem, a_rem[i]);
-        t += rem / edd_speed(n / slots);
-        int k = 0;
-        for (int i = 0; i < na; i++) {
-            a_rem[i] -= rem;
-            if (a_rem[i] <= 1e-9) free_slots += a_cnt[i];
-            else a_cnt[k] = a_cnt[i], a_rem[k] = a_rem[i], k++;
-        }
-        na = k;
-    }
-    return t;
-}
-// modelled duration (microseconds, without the launch's constant) of unitsA / unitsB / unitsC units split fA / fB ways
-static double edd_model(int m, double unitsA, double unitsB, double unitsC, int fA, int fB, double slots) {
-    auto chunks = [](int mm, int jc, int f) { return std::ceil(std::ceil((double)mm / jc) / f); };
-    const double w[3] = {9.222 + 5.105 * chunks(m, ED8_JC, fA), 7.968 + 2.879 * chunks(m, ED16_JC, fB),
-                         5.979 + 4.543 * chunks(m, ED4_JC, fB)};                      // launch order: A, C, B
-    auto parts = [](double units, int f) { return 4.0 * std::ceil(units * f / 4.0); };  // whole workgroups of 4 waves
-    const double cnt[3] = {parts(unitsA, fA), parts(unitsC, fB), parts(unitsB, fB)};
-    return edd_makespan(cnt, w, slots);
-}
-
-// smallest modelled duration over the nine split pairs
-static double edd_best_split(int m, double unitsA, double unitsB, double unitsC, double slots, int &fA, int &fB) {
-    double best = 1e300;
-    fA = fB = 1;
-    for (int a = 1; a <= 4; a *= 2)
-        for (int b = 1; b <= 4; b *= 2) {
-            const double t = edd_model(m, unitsA, unitsB, unitsC, a, b, slots);
-            if (t < best * (1.0 - 1e-3)) best = t, fA = a, fB = b;   // (near ties: the coarser split)
-        }
-    return best;
-}
-
-// Tiling of a host-planned list: 2 = classes A / B / C, 1 = remainders of <= 16 candidates in class-B tiles as well.  Class
-// C fills the lanes better (a remainder of <= 16 takes 19 us of a wave at m = 8192 instead of 30) but its units last
-// longer: on a list that does not fill the wave slots once the model decides (profiles/ed_hybrid_sweep.py: with the
-// model's splits class C is 1.0-1.5 x faster on lists of short runs and within +-2 % elsewhere, 4 shapes of 90 lose 5-10 %).
+// The launcher's model of a launch (window splits, tile classes): kvm_ed_launch_model.h (host-only, unit-tested on the CPU).
+static_assert(EDM_TILES_A == EDD_TILES_A && EDM_TILES_B == EDD_TILES_B && EDM_TILES_C == EDD_TILES_C, "model and kernel agree on the unit sizes");
 int kvm_ed_dot_choose_classes(int m, int64_t tilesA, int64_t tilesB, int64_t tilesC, int num_cu) {
-    const double slots = (double)num_cu * 8;
-    const int64_t uA = (tilesA + EDD_TILES_A - 1) / EDD_TILES_A, uB = (tilesB + EDD_TILES_B - 1) / EDD_TILES_B,
-                  uC = (tilesC + EDD_TILES_C - 1) / EDD_TILES_C, uBC = (tilesB + tilesC + EDD_TILES_B - 1) / EDD_TILES_B;
-    if (tilesC <= 0) return 1;
-    if ((double)(uA + uB + uC) > slots) return 2;  // throughput-bound: fewer, fuller tiles
-    struct memo_t { int64_t a, b, c; int cu, m, mode; };
-    static thread_local memo_t memo = {-1, -1, -1, 0, 0, 1};
-    if (memo.a == tilesA && memo.b == tilesB && memo.c == tilesC && memo.cu == num_cu && memo.m == m) return memo.mode;
-    int fa, fb;
-    const double t1 = edd_best_split(m, (double)uA, (double)uBC, 0.0, slots, fa, fb);
-    const double t2 = edd_best_split(m, (double)uA, (double)uB, (double)uC, slots, fa, fb);
-    const int mode = t2 <= t1 * 1.02 ? 2 : 1;
-    memo = {tilesA, tilesB, tilesC, num_cu, m, mode};
-    return mode;
+    return edd_choose_classes(m, tilesA, tilesB, tilesC, num_cu);
 }
 
 hipError_t kvm_launch_ed_dot(const double *series, const double2 *prefix, int64_t n, const kvm_query_dev &qd,

@@ -192,6 +192,21 @@ def test_timsort_restatement_is_memory_safe_under_any_comparator(tmp_path):
     assert ok > 500 and thrown > 500
 
 
+def test_ed_launch_model_on_the_cpu(tmp_path):
+    """The ED pruner launcher's model of a launch (kvm_ed_launch_model.h: window splits, tile classes) is host-only code on
+    every query's critical path: compiled alone with g++ -Wall -Wextra -Werror under ASan + UBSan and checked against the
+    choices the sweeps on the MI355X measured as best (profiles/r02_ed_split_sweep_*.log), for monotonicity, for
+    degenerate inputs (no units, millions of units, no wave slots) and for its cost per decision."""
+    import subprocess
+    exe = tmp_path / "launch_model_harness"
+    r = subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-fsanitize=address,undefined",
+                        "-fno-sanitize-recover=all", "-I", os.path.join(ROOT, "kv-match_amd", "csrc"), "-o", str(exe),
+                        os.path.join(ROOT, "tests", "harness", "launch_model_harness.cpp")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0 and "FAIL" not in r.stdout and r.stdout.count("ok  ") >= 13, r.stdout + r.stderr[-2000:]
+
+
 def test_sort_and_merge_intervals_is_the_reference_step_between_the_phases(built):
     """kvm_sort_and_merge_intervals (host only) == QueryEngine.sortAndMergeIntervals (K/QueryEngine.java:664-693)."""
     import numpy as np
