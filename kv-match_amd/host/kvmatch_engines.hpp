@@ -229,6 +229,8 @@ public:
         detail::segments(1, last, segment_ > 0 ? segment_ : last, l, r);
         // distance() of the executor abandons on `sum < bsf` (U/UcrEdQueryExecutor.java:93): with Epsilon^2 == 0 it never
         // adds a term and every window that passes the (Alpha, Beta) test is reported at distance 0 (kvmatch/ucr.py)
+        // (NOT reproduced: a partial sum that lands exactly on Epsilon^2 before the last term, which the executor reports
+        // at distance Epsilon -- a known difference of the executor mirrors)
         const bool zero = eps_ * eps_ == 0.0;
         kvm_result *res = nullptr;
         Phase2Context::check(kvm_verify_cnsm_ed(c_.handle(), q_.data(), (int32_t)M, l.data(), r.data(), (int32_t)l.size(), 0,

@@ -50,7 +50,8 @@ class UcrEdQueryExecutor(_Executor):
     distance, 1-based offsets (:161).  ``segment=None`` replays the reference's single running-sum chain.
     The executor's distance() stops on ``sum < bsf`` where the engines' loops stop on ``dist <= bsf``: the difference is
     reproduced for Epsilon^2 == 0 (see run()); a partial sum that lands EXACTLY on Epsilon^2 before the last term -- which
-    the executor would report at distance Epsilon -- is not."""
+    the executor would report at distance Epsilon -- is not (a known difference; rare, but integer-valued data
+    produces it: tests/golden/ucr/ucr_ed_partial_sum_tie.npz, test_ucr_ed_partial_sum_tie_is_the_known_difference)."""
 
     def __init__(self, ctx, N, M, queryData, Epsilon, Alpha, Beta, segment=None):
         super().__init__(ctx, N, M, queryData, Epsilon, Alpha, Beta)
