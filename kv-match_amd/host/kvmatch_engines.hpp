@@ -253,6 +253,8 @@ private:
 
 // run(): answers sorted by distance, 0-BASED offsets as the reference reports them (UcrDtwQueryExecutor.java:283);
 // EPOCH = 100000 buffers (:97) == intervals of EPOCH - M + 1 offsets.  Rho is the band half-width in points.
+// Known difference: the executor never clears cb1 / cb2 between windows (:157-161); at an exact LB_Keogh tie it
+// can reject a window that the engines -- and this mirror -- report at distance Epsilon.
 class UcrDtwQueryExecutor {
 public:
     static constexpr int64_t EPOCH = 100000;

@@ -78,7 +78,9 @@ class UcrEdQueryExecutor(_Executor):
 
 class UcrDtwQueryExecutor(_Executor):
     """U/UcrDtwQueryExecutor.java.  ``run()`` returns the number of answers (:314); ``answers`` holds them sorted by
-    distance, 0-BASED offsets (:283)."""
+    distance, 0-BASED offsets (:283).  Known difference: the executor never clears cb1 / cb2 between windows
+    (:157-161), so at an exact LB_Keogh tie it can reject a window the engines -- and this mirror -- report at distance
+    Epsilon (tests/golden/ucr/ucr_dtw_stale_cb_tie.npz)."""
 
     def __init__(self, ctx, N, M, queryData, Epsilon, Rho, Alpha, Beta):
         super().__init__(ctx, N, M, queryData, Epsilon, Alpha, Beta)

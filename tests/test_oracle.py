@@ -311,3 +311,27 @@ def test_ucr_ed_executor_reports_a_partial_sum_that_lands_on_epsilon_squared(bui
     off, dist, st = oracle.ucr_ed(s, q, float(g["eps"]), float(g["alpha"]), float(g["beta"]))
     assert np.array_equal(off, g["oracle_off"]) and np.array_equal(dist, g["oracle_dist"])
     assert off.tolist()[-1] == 35265 and dist.tolist()[-1] == float(g["eps"]) and dist.tolist()[:-1] == [0.0] * 4
+
+
+def test_ucr_dtw_executor_reads_stale_cb_entries_at_exact_ties(built):
+    """U/UcrDtwQueryExecutor.java allocates cb1 / cb2 once (:157-161) and never clears them; the LB_Keogh loops stop at the
+    first partial sum >= bsf and leave the rest of the array as the PREVIOUS window left it.  When that partial sum lands
+    exactly on bsf the window goes on to the DP with those stale entries in its cb[], whose row test then returns a value
+    above bsf -- where NormQueryEngineDtw, with fresh (zero) arrays, returns exactly bsf and reports the window at distance
+    eps.  A natural instance on integer-valued data (found by a CPU fuzz of the two restatements, round 2): the executor
+    reports 8 windows, the engine on the same offsets 14; the 6 extra ones are all at distance eps.  Both the oracle and
+    the independent transliteration agree on the executor's 8."""
+    import os
+    import java_transliteration as J
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "ucr", "ucr_dtw_stale_cb_tie.npz"))
+    s, q = g["s"].astype(np.float64), g["q"].astype(np.float64)
+    eps, rho, alpha, beta = float(g["eps"]), int(g["rho"]), float(g["alpha"]), float(g["beta"])
+    uo, ud, _ = oracle.ucr_dtw(s, q, eps, rho, alpha, beta)
+    assert np.array_equal(uo, g["executor_off"]) and np.array_equal(ud, g["executor_dist"]) and len(uo) == 8
+    py = J.ucr_dtw(s.tolist(), q.tolist(), eps, rho, alpha, beta)
+    assert [a[0] for a in py] == uo.tolist() and np.array_equal(np.array([a[1] for a in py]), ud)
+    n, m = len(s), len(q)
+    eo, ed, _ = oracle.cnsm_dtw(s, q, np.array([1], dtype=np.int32), np.array([n - m + 1], dtype=np.int32), 0, eps, rho, alpha, beta)
+    assert np.array_equal(eo - 1, g["engine_off"]) and np.array_equal(ed, g["engine_dist"]) and len(eo) == 14
+    executor, engine = set(zip(uo.tolist(), ud.tolist())), set(zip((eo - 1).tolist(), ed.tolist()))
+    assert executor < engine and all(d == eps for _, d in engine - executor)

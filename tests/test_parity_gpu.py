@@ -1281,6 +1281,28 @@ def test_ucr_ed_partial_sum_tie_is_the_known_difference(world):
         ctx.load_series(series)
 
 
+def test_ucr_dtw_stale_cb_tie_is_the_known_difference(world):
+    """U/UcrDtwQueryExecutor.java never clears cb1 / cb2 between windows; at an exact LB_Keogh tie the DP then reads what the
+    previous window left there and rejects windows the engines (fresh arrays) report at distance eps
+    (tests/test_oracle.py::test_ucr_dtw_executor_reads_stale_cb_entries_at_exact_ties).  The executor mirror runs the
+    engine's semantics: on this instance it answers with the engine's 14 windows, not the executor's 8 -- the 6
+    extra ones all at distance eps.  This test pins that documented difference."""
+    kvmatch, datagen, series, ctx = world
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "ucr", "ucr_dtw_stale_cb_tie.npz"))
+    s, q = g["s"].astype(np.float64), g["q"].astype(np.float64)
+    eps, rho, alpha, beta = float(g["eps"]), int(g["rho"]), float(g["alpha"]), float(g["beta"])
+    ctx.load_series(s)
+    try:
+        d = kvmatch.UcrDtwQueryExecutor(ctx, len(s), len(q), q, eps, rho, alpha, beta)
+        assert d.run() == 14
+        assert np.array_equal(d.answers.offsets, g["engine_off"]) and np.array_equal(d.answers.distances, g["engine_dist"])
+        uo, ud, _ = oracle.ucr_dtw(s, q, eps, rho, alpha, beta)
+        extra = set(zip(d.answers.offsets.tolist(), d.answers.distances.tolist())) - set(zip(uo.tolist(), ud.tolist()))
+        assert len(uo) == 8 and len(extra) == 6 and all(dist == eps for _, dist in extra)
+    finally:
+        ctx.load_series(series)
+
+
 def test_residue_of_a_spike_in_the_references_running_sums(built):
     """The reference's running sums (ex += d, ex2 += d * d, later -= the same, K/NormQueryEngine.java:497-524) keep the
     rounding residue of everything that passed through them since the interval began: after a burst of 1e9-scale values --
