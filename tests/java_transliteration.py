@@ -26,6 +26,11 @@ WU0 = 25                        # WuList[0]
 MAX_SCAN_DATA_LENGTH = 40000    # NormQueryEngine.MAX_SCAN_DATA_LENGTH / NormQueryEngineDtw
 
 
+class ArrayIndexOutOfBoundsException(Exception):
+    """java.lang.ArrayIndexOutOfBoundsException: the reference does not catch it -- query() ends with it.  Raised where Python's
+    negative indices would silently wrap (DtwUtils.lowerUpperLemire on an array no longer than the band: `u[i - r - 1]`)."""
+
+
 class IllegalArgumentException(Exception):
     pass
 
@@ -122,6 +127,8 @@ def lower_upper_lemire(t, length, r, l, u):
         elif i == 2 * r + 1 + dl.front():
             dl.pop_front()
     for i in range(length, length + r + 1):
+        if i - r - 1 < 0:       # (Python would wrap a negative index; Java throws -- whenever length <= r)
+            raise ArrayIndexOutOfBoundsException(str(i - r - 1))
         u[i - r - 1] = t[du.front()]
         l[i - r - 1] = t[dl.front()]
         if i - du.front() >= 2 * r + 1:
