@@ -212,7 +212,9 @@ int kvm_verify_cnsm_ed(kvm_ctx *ctx, const double *query, int32_t m, const int32
                        int32_t k, int32_t shift, double epsilon, double alpha, double beta, kvm_result **result);
 
 /* RSM-DTW.  Replaces K/QueryEngineDtw.java:349-452.  `rho` is the resolved Sakoe-Chiba half-width
- * (see kvm_resolve_rho). */
+ * (see kvm_resolve_rho).  rho >= m, and an interval whose fetched data is no longer than rho points (one that starts beyond
+ * offset n - m + 1), are inputs on which the reference ends in ArrayIndexOutOfBoundsException (DtwUtils.lowerUpperLemire
+ * stores to u[i - r - 1] with a negative index); these entry points compute the natural extension instead of failing. */
 int kvm_verify_rsm_dtw(kvm_ctx *ctx, const double *query, int32_t m, const int32_t *left, const int32_t *right,
                        int32_t k, int32_t shift, double epsilon, int32_t rho, kvm_result **result);
 
