@@ -1075,7 +1075,9 @@ def _compare_to(a, b):
 
 def to_round(value):
     value *= math.pow(10, 2 - 1)
-    int_value = math.floor(value) if value == value and abs(value) != float("inf") else value
+    # Math.floor returns a double: floor(-0.0) is -0.0 (Python's math.floor returns the int 0 and loses the sign), NaN and
+    # the infinities come back unchanged
+    int_value = float(math.floor(value)) if value == value and abs(value) != float("inf") and value != 0.0 else value
     diff = value - int_value
     ret = float(int_value)
     if _java_double_compare(diff, 0.5) >= 0:
@@ -1195,7 +1197,12 @@ def parse_bytes_compact(data):
     return positions
 
 
-def index_build_file(series, w, epoch=100000):
+def index_build_file(series, w, epoch=100000, canonical_nan_key=True):
+    """IndexBuilder.run + the index file image.  `canonical_nan_key`: Java keeps ONE NaN row (Double.equals) and writes the raw
+    bits (HBase Bytes.toBytes(double) = doubleToRawLongBits) of the first NaN key it met -- the hardware's default NaN when
+    it comes out of inf - inf (sign bit set on x86, clear on AArch64): not a function of the Java text.  The oracle and the
+    library write the canonical 0x7ff8000000000000; True does the same here, False keeps what this
+    machine's arithmetic produced."""
     n = len(series)
     it = 0
     done = False
@@ -1240,10 +1247,13 @@ def index_build_file(series, w, epoch=100000):
                         done = True
                         break
                     cur_mean_round = to_round(mean)
+                    if canonical_nan_key and cur_mean_round != cur_mean_round:
+                        cur_mean_round = float("nan")       # 0x7ff8000000000000
                     if last_mean_round is None or _double_key(last_mean_round) != _double_key(cur_mean_round) \
                             or loc - index_node[-1][0] == MAXIMUM_DIFF - 1:
-                        if last_mean_round is not None:
-                            index_node_map[_double_key(last_mean_round)] = (last_mean_round, index_node)
+                        if last_mean_round is not None:      # HashMap.put: an equal key that is already there stays
+                            kk = _double_key(last_mean_round)
+                            index_node_map[kk] = (index_node_map[kk][0] if kk in index_node_map else last_mean_round, index_node)
                         got = index_node_map.get(_double_key(cur_mean_round))
                         index_node = got[1] if got is not None else []
                         index_node.append([loc, loc])
@@ -1257,7 +1267,8 @@ def index_build_file(series, w, epoch=100000):
             else:
                 it += 1
     if index_node is not None and len(index_node) > 0:
-        index_node_map[_double_key(last_mean_round)] = (last_mean_round, index_node)
+        kk = _double_key(last_mean_round)
+        index_node_map[kk] = (index_node_map[kk][0] if kk in index_node_map else last_mean_round, index_node)
     # step 2
     raw = []
     total = 0.0
