@@ -212,6 +212,15 @@ def test_to_round_known_values(built):
         got = oracle.to_round(v)
         assert got == want or (math.isnan(got) and math.isnan(want)), (v, got, want)
     assert math.isnan(oracle.to_round(float("nan")))
+    # The only worked examples the reference itself holds for this path: the Javadoc of toRound (K/utils/MeanIntervalUtils.java:
+    # 44-46, written for d = 0.5: 1.9 -> 1.5, 1.4 -> 1.0, 1.5 -> 1.5, -1.9 -> -2.0, -1.4 -> -1.5, -1.5 -> -1.5), at the
+    # precision the code runs with (posOfD = 2, d = 0.05: the same numbers a decade down), for the oracle and the transliteration
+    import java_transliteration as J
+    for v, want in [(0.19, 0.15), (0.14, 0.10), (0.15, 0.15), (-0.19, -0.20), (-0.14, -0.15), (-0.15, -0.15)]:
+        for got in (oracle.to_round(v), J.to_round(v)):
+            assert abs(got - want) < 1e-15, (v, got, want)
+        assert oracle.to_round(v) == J.to_round(v)
+    assert math.copysign(1.0, oracle.to_round(-0.0)) == -1.0 and oracle.to_round(-1e-320) == J.to_round(-1e-320) == -0.05
 
 
 def test_index_rows_restatement_vs_python_loop(built):
