@@ -71,6 +71,8 @@ extern "C" {
 #define KVM_ERR_DEVICE (-5)        /* HIP runtime failure (also -> IOException in the shim) */
 #define KVM_ERR_NO_SERIES (-6)     /* verify called before a series was loaded */
 #define KVM_ERR_UNSUPPORTED (-7)   /* parameter outside what the kernels are built for */
+#define KVM_ERR_INDEX_OUT_OF_BOUNDS (-8) /* the reference ends in ArrayIndexOutOfBoundsException on this input
+                                            (KVM_OPT_STRICT_BOUNDS; the shim throws the same) */
 
 typedef struct kvm_ctx kvm_ctx;
 typedef struct kvm_result kvm_result;
@@ -285,6 +287,22 @@ void kvm_result_free(kvm_result *r);
                                     message for exactly those queries; 1: answer them anyway (lower bounds summed in
                                     index order -- the answers are those of any successful order except at exact
                                     ties with eps^2). */
+#define KVM_OPT_UCR_LOOPS 7      /* 0 (default): the engines' loops.  1: the loops of the reference's index-free executors
+                                    where they differ (set only by their mirrors, kvmatch.UcrEdQueryExecutor /
+                                    UcrDtwQueryExecutor; the candidate list must then be the executor's scan -- consecutive
+                                    intervals in offset order).  kvm_verify_cnsm_ed: UcrEdQueryExecutor.distance() runs
+                                    `for (...; i < m && sum < bsf; ...)` (experiments/ucr/UcrEdQueryExecutor.java:91-98), so a
+                                    partial sum exactly on eps^2 ends it and the window is an answer at distance sqrt(eps^2);
+                                    with eps^2 == 0 every window passing (Alpha, Beta) is an answer at distance 0.
+                                    kvm_verify_cnsm_dtw: UcrDtwQueryExecutor never clears cb1 / cb2 between windows
+                                    (experiments/ucr/UcrDtwQueryExecutor.java:157-161): a window whose LB_Keogh loop stops
+                                    exactly on eps^2 runs its DP with what earlier windows left in the rest of the array. */
+#define KVM_OPT_STRICT_BOUNDS 8  /* 1 (default): the DTW entry points fail where the reference dies in
+                                    DtwUtils.lowerUpperLemire (K/utils/DtwUtils.java:81-90: `u[i - r - 1]` with an array no
+                                    longer than the band): rho >= m (the query envelope), or an interval whose fetched data
+                                    holds <= rho points (a stub beyond the last window offset) -> KVM_ERR_INDEX_OUT_OF_BOUNDS,
+                                    which the JNI shim throws as ArrayIndexOutOfBoundsException.  0: compute the envelope's
+                                    natural extension (window clipped at the array's ends) and answer. */
 int kvm_set_option(kvm_ctx *ctx, int32_t option, int64_t value);
 int64_t kvm_get_option(const kvm_ctx *ctx, int32_t option);
 /* Device time (ns, HIP events on the launch stream) of the verification kernels of the most recent

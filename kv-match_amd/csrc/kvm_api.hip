@@ -159,6 +159,8 @@ extern "C" int kvm_set_option(kvm_ctx *ctx, int32_t option, int64_t value) {
         case KVM_OPT_TIMING: ctx->opt_timing = value ? 1 : 0; return KVM_OK;
         case KVM_OPT_DP_KERNEL: ctx->opt_dp_kernel = value == 1 ? 1 : 0; return KVM_OK;
         case KVM_OPT_SORT_VIOLATION: ctx->opt_sort_violation = value ? 1 : 0; return KVM_OK;
+        case KVM_OPT_UCR_LOOPS: ctx->opt_ucr_loops = value ? 1 : 0; return KVM_OK;
+        case KVM_OPT_STRICT_BOUNDS: ctx->opt_strict_bounds = value ? 1 : 0; return KVM_OK;
     }
     return fail(ctx, KVM_ERR_ILLEGAL_ARGUMENT, "unknown option");
 }
@@ -188,6 +190,8 @@ extern "C" int64_t kvm_get_option(const kvm_ctx *ctx, int32_t option) {
         case KVM_OPT_TIMING: return ctx->opt_timing;
         case KVM_OPT_DP_KERNEL: return ctx->opt_dp_kernel;
         case KVM_OPT_SORT_VIOLATION: return ctx->opt_sort_violation;
+        case KVM_OPT_UCR_LOOPS: return ctx->opt_ucr_loops;
+        case KVM_OPT_STRICT_BOUNDS: return ctx->opt_strict_bounds;
     }
     return KVM_ERR_ILLEGAL_ARGUMENT;
 }
@@ -1154,8 +1158,24 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
         const double *q_exact = cnsm ? (const double *)((const char *)ctx->b_query.p + qexact_off) : qd.q;
         const int32_t *d_order =
             cnsm ? (const int32_t *)((const char *)ctx->b_query.p + qexact_off + (size_t)m * 8) : nullptr;
+        // KVM_OPT_UCR_LOOPS (executor mirrors only): UcrEdQueryExecutor's `sum < bsf` loop -- the windows whose ordered partial
+        // sums may land exactly on eps^2 go through the literal loop behind the survivors (kvm_ucr.hip)
+        kvm_surv *ties = nullptr;
+        if (cnsm && ctx->opt_ucr_loops) {
+            if ((rc = ensure(ctx, ctx->b_cands2, (size_t)pl.windows * sizeof(kvm_surv) + 64))) return rc;
+            ties = (kvm_surv *)ctx->b_cands2.p;
+            if (retile) {
+                const kvm_tile *tA = (const kvm_tile *)ctx->b_tiles.p + pl.n_tiles, *tB = tA + pl.n_tiles;
+                HIPCHK(ctx, kvm_launch_ucr_ed_screen(ctx->d_series, ctx->d_prefix, qd, q_exact, d_order, tA, pl.n_tiles, tB, pl.n_tiles,
+                                                     counters + KVM_CNT_TILES_A, ties, pl.windows, counters, ctx->num_cu, stream));
+            } else {
+                HIPCHK(ctx, kvm_launch_ucr_ed_screen(ctx->d_series, ctx->d_prefix, qd, q_exact, d_order, d_tiles, n_tiles, nullptr, 0,
+                                                     nullptr, ties, pl.windows, counters, ctx->num_cu, stream));
+            }
+        }
         HIPCHK(ctx, kvm_launch_exact_ed(ctx->d_series, qd, q_exact, d_order, surv, counters + KVM_CNT_CANDS1, pl.windows,
-                                        rws, out.d_off, out.d_dist, out.cap, counters, ctx->num_cu, stream));
+                                        rws, out.d_off, out.d_dist, out.cap, counters, ctx->num_cu, stream, ties,
+                                        counters + KVM_CNT_UCR_TIES, ties ? pl.windows : 0));
     } else {
         const int use_lb = (int)ctx->opt_lb_cascade;
         if ((rc = ensure(ctx, ctx->b_cands, (size_t)pl.windows * sizeof(kvm_cand) + 64))) return rc;

@@ -311,17 +311,26 @@ __global__ __launch_bounds__(EX_THREADS) void kvm_exact_ed_kernel(const double *
 hipError_t kvm_launch_exact_ed(const double *series, const kvm_query_dev &qd, const double *q_exact,
                                const int32_t *order, const kvm_surv *surv, const unsigned long long *d_n_surv,
                                int64_t max_surv, const kvm_replay_ws &ws, int32_t *out_off, double *out_dist,
-                               int64_t cap, unsigned long long *counters, int num_cu, hipStream_t s) {
+                               int64_t cap, unsigned long long *counters, int num_cu, hipStream_t s, const kvm_surv *ties,
+                               const unsigned long long *d_n_ties, int64_t max_ties) {
     if (max_surv <= 0) return hipSuccess;
     // 2-3 workgroups resident per CU (176 / 138 VGPRs), EX_GROUP survivors per workgroup at a time
     int64_t blocks = std::min<int64_t>((max_surv + EX_GROUP - 1) / EX_GROUP, (int64_t)num_cu * (qd.normalised ? 2 : 3));
     if (qd.normalised) {
         hipLaunchKernelGGL((kvm_replay_mark_kernel<kvm_surv>), dim3((unsigned)std::min<int64_t>((max_surv + 255) / 256, 1024)),
                            dim3(256), 0, s, surv, d_n_surv, ws);
+        if (ties)  // (their runs join the same replay)
+            hipLaunchKernelGGL((kvm_replay_mark_kernel<kvm_surv>), dim3((unsigned)std::min<int64_t>((max_ties + 255) / 256, 1024)),
+                               dim3(256), 0, s, ties, d_n_ties, ws);
         hipError_t e = ex_replay(series, qd.m, ws, s);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL((kvm_exact_ed_kernel<true>), dim3((unsigned)blocks), dim3(EX_THREADS), 0, s, series, qd,
                            q_exact, order, surv, d_n_surv, ws, out_off, out_dist, cap, counters);
+        if (ties) {
+            e = kvm_launch_ucr_ed_ties(series, qd, q_exact, order, ties, d_n_ties, max_ties, ws, out_off, out_dist, cap, counters,
+                                       num_cu, s);
+            if (e != hipSuccess) return e;
+        }
     } else {
         hipLaunchKernelGGL((kvm_exact_ed_kernel<false>), dim3((unsigned)blocks), dim3(EX_THREADS), 0, s, series, qd,
                            q_exact, order, surv, d_n_surv, ws, out_off, out_dist, cap, counters);

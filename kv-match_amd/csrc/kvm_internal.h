@@ -97,7 +97,7 @@ struct kvm_ctx {
     void *h_readback = nullptr;  // pinned, device-mapped: the readback kernel stores counters + first answers here
     size_t h_pinned_cap = 0;
     int64_t opt_early_abandon = 1, opt_lb_cascade = 1, opt_ed_kernel = 0, opt_timing = 0, opt_dp_kernel = 0,
-            opt_sort_violation = 0;
+            opt_sort_violation = 0, opt_ucr_loops = 0, opt_strict_bounds = 1;
     int num_cu = 256;
     int64_t last_kernel_ns = 0;
     bool timing_pending = false;  // ev0/ev1 recorded, elapsed time not read yet (read lazily: no mid-pipeline sync)
@@ -264,10 +264,22 @@ hipError_t kvm_launch_retile_cnsm(const double *series, const double2 *prefix, c
                                   int64_t n_tiles, kvm_tile *tilesA, kvm_tile *tilesB, unsigned long long *d_counts,
                                   hipStream_t s);
 // Exact final pass (kvm_exact.hip)
+// (`ties`, cNSM with KVM_OPT_UCR_LOOPS: the windows kvm_launch_ucr_ed_screen handed to the executor's literal loop -- replayed
+// and evaluated behind the survivors, kvm_ucr.hip)
 hipError_t kvm_launch_exact_ed(const double *series, const kvm_query_dev &qd, const double *q_exact,
                                const int32_t *order, const kvm_surv *surv, const unsigned long long *d_n_surv,
                                int64_t max_surv, const kvm_replay_ws &ws, int32_t *out_off, double *out_dist,
-                               int64_t cap, unsigned long long *counters, int num_cu, hipStream_t s);
+                               int64_t cap, unsigned long long *counters, int num_cu, hipStream_t s,
+                               const kvm_surv *ties = nullptr, const unsigned long long *d_n_ties = nullptr, int64_t max_ties = 0);
+// kvm_ucr.hip: the executors' loop semantics (KVM_OPT_UCR_LOOPS)
+hipError_t kvm_launch_ucr_ed_screen(const double *series, const double2 *prefix, const kvm_query_dev &qd, const double *zqs,
+                                    const int32_t *order, const kvm_tile *tilesA, int64_t nA, const kvm_tile *tilesB, int64_t nB,
+                                    const unsigned long long *d_counts, kvm_surv *ties, int64_t cap, unsigned long long *counters,
+                                    int num_cu, hipStream_t s);
+hipError_t kvm_launch_ucr_ed_ties(const double *series, const kvm_query_dev &qd, const double *zqs, const int32_t *order,
+                                  const kvm_surv *ties, const unsigned long long *d_n, int64_t max_ties, const kvm_replay_ws &ws,
+                                  int32_t *out_off, double *out_dist, int64_t cap, unsigned long long *counters, int num_cu,
+                                  hipStream_t s);
 hipError_t kvm_launch_exact_stats(const double *series, const kvm_query_dev &qd, kvm_cand *cands,
                                   const unsigned long long *d_n, int64_t max_n, const kvm_replay_ws &ws,
                                   unsigned long long *counters, int num_cu, hipStream_t s);
@@ -324,7 +336,7 @@ hipError_t kvm_launch_dtw_dp(const double *series, int64_t n, const kvm_query_de
                              int64_t cap, unsigned long long *counters, int num_cu, int force_lds, hipStream_t s,
                              hipEvent_t ev_dp_start = nullptr);  // recorded between the prologue kernel and the DP
 
-// counters layout (unsigned long long[16])
+// counters layout (unsigned long long[KVM_CNT_TOTAL])
 #define KVM_CNT_ANSWERS 0
 #define KVM_CNT_WINDOWS 1
 #define KVM_CNT_PASS_FILTER 2
@@ -341,7 +353,8 @@ hipError_t kvm_launch_dtw_dp(const double *series, int64_t n, const kvm_query_de
 #define KVM_CNT_TILES_B 13
 #define KVM_CNT_TILES_C 14
 #define KVM_CNT_AMBIG 15              // DTW: candidates handed to the sequential reference-ordered path
-#define KVM_CNT_TOTAL 16
+#define KVM_CNT_UCR_TIES 16           // KVM_OPT_UCR_LOOPS, cNSM-ED: windows handed to the executor's literal distance() loop
+#define KVM_CNT_TOTAL 20
 
 // kvm_index.hip: index build step 1 on the device
 struct kvm_index_dev {

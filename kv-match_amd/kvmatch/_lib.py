@@ -17,10 +17,12 @@ KVM_ERR_IO = -3
 KVM_ERR_DEVICE = -5
 KVM_ERR_NO_SERIES = -6
 KVM_ERR_UNSUPPORTED = -7
+KVM_ERR_INDEX_OUT_OF_BOUNDS = -8
 
 STAT_WINDOWS, STAT_PASS_FILTER, STAT_PASS_LB_KIM, STAT_PASS_LB_KEOGH, STAT_PASS_LB_KEOGH2, STAT_KERNEL_NS, \
     STAT_RECHECKED, STAT_DTW_SEQUENTIAL = range(8)
-OPT_EARLY_ABANDON, OPT_LB_CASCADE, OPT_ED_KERNEL, OPT_TIMING, OPT_DP_KERNEL, OPT_SORT_VIOLATION = 1, 2, 3, 4, 5, 6
+OPT_EARLY_ABANDON, OPT_LB_CASCADE, OPT_ED_KERNEL, OPT_TIMING, OPT_DP_KERNEL, OPT_SORT_VIOLATION, OPT_UCR_LOOPS, \
+    OPT_STRICT_BOUNDS = 1, 2, 3, 4, 5, 6, 7, 8
 
 # every symbol include/kvmatch.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
@@ -50,6 +52,12 @@ class KvMatchIOError(IOError):
 
 class KvMatchIllegalArgument(ValueError):
     """-> java.lang.IllegalArgumentException (K/operator/file/TimeSeriesFileOperator.java:55-57)."""
+
+
+class KvMatchIndexOutOfBounds(IndexError):
+    """-> java.lang.ArrayIndexOutOfBoundsException: where the reference's DtwUtils.lowerUpperLemire indexes below its
+    arrays (K/utils/DtwUtils.java:81-90; rho >= m, or an interval whose fetched data holds <= rho points).  Raised with
+    OPT_STRICT_BOUNDS = 1 (default)."""
 
 
 _lib = None
@@ -146,4 +154,6 @@ def check(rc, ctx=None):
         raise KvMatchIllegalArgument(msg)
     if rc == KVM_ERR_IO:
         raise KvMatchIOError(msg)
+    if rc == KVM_ERR_INDEX_OUT_OF_BOUNDS:
+        raise KvMatchIndexOutOfBounds(msg)
     raise KvMatchDeviceError(f"[{rc}] {msg}")

@@ -33,6 +33,22 @@ def segments(first, last, length):
     return left.astype(np.int32), right.astype(np.int32)
 
 
+class _ucr_loops:
+    """KVM_OPT_UCR_LOOPS for the duration of one executor run (the option belongs to the context: the engines that share it
+    keep the engines' loops)."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+
+    def __enter__(self):
+        self.old = self.ctx.get_option(_lib.OPT_UCR_LOOPS)
+        self.ctx.set_option(_lib.OPT_UCR_LOOPS, 1)
+
+    def __exit__(self, *exc):
+        self.ctx.set_option(_lib.OPT_UCR_LOOPS, self.old)
+        return False
+
+
 class _Executor:
     def __init__(self, ctx, N, M, queryData, Epsilon, Alpha, Beta):
         self.ctx, self.N, self.M = ctx, int(N), int(M)
@@ -48,10 +64,10 @@ class _Executor:
 class UcrEdQueryExecutor(_Executor):
     """U/UcrEdQueryExecutor.java.  ``run()`` returns the number of answers (:174); ``answers`` holds them sorted by
     distance, 1-based offsets (:161).  ``segment=None`` replays the reference's single running-sum chain.
-    The executor's distance() stops on ``sum < bsf`` where the engines' loops stop on ``dist <= bsf``: the difference is
-    reproduced for Epsilon^2 == 0 (see run()); a partial sum that lands EXACTLY on Epsilon^2 before the last term -- which
-    the executor would report at distance Epsilon -- is not (a known difference; rare, but integer-valued data
-    produces it: tests/golden/ucr/ucr_ed_partial_sum_tie.npz, test_ucr_ed_partial_sum_tie_is_the_known_difference)."""
+    The executor's distance() stops on ``sum < bsf`` (:93) where the engines' loops stop on ``dist <= bsf``
+    (K/NormQueryEngine.java:513): a partial sum that lands EXACTLY on Epsilon^2 before the last term is reported at
+    distance Epsilon, and with Epsilon^2 == 0 every window that passes the (Alpha, Beta) test is reported at distance 0.
+    Both are reproduced on the GPU (KVM_OPT_UCR_LOOPS, kvm_ucr.hip)."""
 
     def __init__(self, ctx, N, M, queryData, Epsilon, Alpha, Beta, segment=None):
         super().__init__(ctx, N, M, queryData, Epsilon, Alpha, Beta)
@@ -62,25 +78,16 @@ class UcrEdQueryExecutor(_Executor):
     def run(self):
         last = self.N - self.M + 1
         lr = segments(1, last, last if self.segment is None else self.segment)
-        if self.Epsilon * self.Epsilon == 0.0:
-            # The executor's own distance() abandons on `sum < bsf` (U/UcrEdQueryExecutor.java:93) and accepts on
-            # `dist <= bsf` (:165): with bsf = Epsilon * Epsilon == 0 the loop never runs, dist stays 0, and EVERY window
-            # that passes the (Alpha, Beta) test is reported at distance 0 -- the engines, whose loop condition is
-            # `dist <= bsf` (K/NormQueryEngine.java:513), compute the first term instead.  Reproduced here: the windows
-            # that pass the filter (they all are answers for an infinite threshold), in scan order, at distance 0.
-            a = NormQueryEngine(self.ctx).verify(lr, 1, self.queryData, float("inf"), self.Alpha, self.Beta)
-            offs = np.sort(a.offsets)
-            self.answers = Answers(offs, np.zeros(offs.size), a.cnt_candidate, a.elapsed_ms, a.stats)
-            return len(self.answers)
-        self.answers = NormQueryEngine(self.ctx).verify(lr, 1, self.queryData, self.Epsilon, self.Alpha, self.Beta)
+        with _ucr_loops(self.ctx):
+            self.answers = NormQueryEngine(self.ctx).verify(lr, 1, self.queryData, self.Epsilon, self.Alpha, self.Beta)
         return len(self.answers)
 
 
 class UcrDtwQueryExecutor(_Executor):
     """U/UcrDtwQueryExecutor.java.  ``run()`` returns the number of answers (:314); ``answers`` holds them sorted by
-    distance, 0-BASED offsets (:283).  Known difference: the executor never clears cb1 / cb2 between windows
-    (:157-161), so at an exact LB_Keogh tie it can reject a window the engines -- and this mirror -- report at distance
-    Epsilon (tests/golden/ucr/ucr_dtw_stale_cb_tie.npz)."""
+    distance, 0-BASED offsets (:283).  The executor never clears cb1 / cb2 between windows (:157-161): at an exact LB_Keogh
+    tie its DP reads what earlier windows left in the rest of the array and can reject a window the engines report at
+    distance Epsilon.  Reproduced on the GPU (KVM_OPT_UCR_LOOPS, kvm_ucr.hip)."""
 
     def __init__(self, ctx, N, M, queryData, Epsilon, Rho, Alpha, Beta):
         super().__init__(ctx, N, M, queryData, Epsilon, Alpha, Beta)
@@ -90,7 +97,8 @@ class UcrDtwQueryExecutor(_Executor):
 
     def run(self):
         lr = segments(1, self.N - self.M + 1, EPOCH - self.M + 1)
-        a = NormQueryEngineDtw(self.ctx).verify(lr, 1, self.queryData, self.Epsilon, self.Rho, self.Alpha, self.Beta,
-                                                resolved=True)
+        with _ucr_loops(self.ctx):
+            a = NormQueryEngineDtw(self.ctx).verify(lr, 1, self.queryData, self.Epsilon, self.Rho, self.Alpha, self.Beta,
+                                                    resolved=True)
         self.answers = Answers(a.offsets - 1, a.distances, a.cnt_candidate, a.elapsed_ms, a.stats)
         return len(self.answers)

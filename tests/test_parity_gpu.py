@@ -1254,12 +1254,12 @@ def test_ucr_ed_executor_at_epsilon_zero(world):
         ctx.load_series(series)
 
 
-def test_ucr_ed_partial_sum_tie_is_the_known_difference(world):
+def test_ucr_ed_partial_sum_tie(world):
     """U/UcrEdQueryExecutor.java's distance() loop runs `while sum < bsf`: a partial sum (in its |zQ|-sorted order) that lands
     EXACTLY on eps^2 ends the loop and the window is reported at distance eps, whatever its real distance.  Found by
     profiles/fuzz_ucr.py (seed 261) on integer-valued data: offset 35265, real distance 10.28, reported at eps = 2.  The
-    oracle restates that; the executor mirrors do NOT: they answer with the windows whose full sum is <= eps^2.
-    This test pins both halves: the oracle's fifth answer and the library's four."""
+    oracle restates that and, since round 3, the executor mirror reproduces it (KVM_OPT_UCR_LOOPS, kvm_ucr.hip): plain
+    equality -- while the ENGINE on the same windows keeps answering with the windows whose full sum is <= eps^2."""
     kvmatch, datagen, series, ctx = world
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", "ucr", "ucr_ed_partial_sum_tie.npz"))
     s, q = g["s"].astype(np.float64), g["q"].astype(np.float64)
@@ -1273,10 +1273,17 @@ def test_ucr_ed_partial_sum_tie_is_the_known_difference(world):
     assert real > 5 * eps                                                   # nowhere near a match
     ctx.load_series(s)
     try:
-        e = kvmatch.UcrEdQueryExecutor(ctx, len(s), len(q), q, eps, alpha, beta)
-        e.run()
-        keep = [i for i, o in enumerate(off.tolist()) if o not in tie]
-        assert np.array_equal(e.answers.offsets, off[keep]) and np.array_equal(e.answers.distances, dist[keep])
+        for ab in (1, 0):
+            ctx.set_option(kvmatch.OPT_EARLY_ABANDON, ab)
+            e = kvmatch.UcrEdQueryExecutor(ctx, len(s), len(q), q, eps, alpha, beta)
+            assert e.run() == len(off)
+            assert np.array_equal(e.answers.offsets, off) and np.array_equal(e.answers.distances, dist)
+            assert ctx.get_option(kvmatch.OPT_UCR_LOOPS) == 0               # the option does not outlive the run
+            # the engine's own loop (`dist <= bsf`) on the same single interval: without the tie window
+            L, R = np.array([1], dtype=np.int32), np.array([len(s) - len(q) + 1], dtype=np.int32)
+            compare(kvmatch.NormQueryEngine(ctx).verify((L, R), 1, q, eps, alpha, beta), oracle.cnsm_ed(s, q, L, R, 0, eps, alpha, beta),
+                    tag=f"engine on the tie instance ab={ab}")
+        ctx.set_option(kvmatch.OPT_EARLY_ABANDON, 1)
     finally:
         ctx.load_series(series)
 
