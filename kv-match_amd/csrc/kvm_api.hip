@@ -131,7 +131,8 @@ extern "C" int kvm_close(kvm_ctx *ctx) {
     hipStreamSynchronize(ctx->stream);
     free_series(ctx);
     kvm_dev_buf *bufs[] = {&ctx->b_query, &ctx->b_tiles, &ctx->b_out_off, &ctx->b_out_dist, &ctx->b_counters,
-                           &ctx->b_cands, &ctx->b_cands2, &ctx->b_aux,   &ctx->b_aux2,    &ctx->b_scratch, &ctx->b_plans};
+                           &ctx->b_cands, &ctx->b_cands2, &ctx->b_aux,   &ctx->b_aux2,    &ctx->b_scratch, &ctx->b_plans,
+                           &ctx->b_ucr};
     for (kvm_dev_buf *b : bufs)
         if (b->p) hipFree(b->p);
     if (ctx->h_pinned) hipHostFree(ctx->h_pinned);
@@ -761,6 +762,11 @@ struct verify_out {
     double *d_dist;
     int64_t cap;
     bool own;  // true: answers go to the context's own buffers, sized by run_variant once the plan knows #windows
+    // cNSM-DTW with KVM_OPT_UCR_LOOPS: what the sequential tie path needs to reconstruct the executor's never-cleared cb1 / cb2
+    kvm_replay_ws rws = {};
+    const kvm_tile *tiles = nullptr;
+    int64_t n_tiles = 0, windows = 0;
+    bool ucr_tables_ready = false;
 };
 
 enum { V_RSM_ED = 0, V_CNSM_ED = 1, V_RSM_DTW = 2, V_CNSM_DTW = 3 };
@@ -1226,6 +1232,13 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
                                       ctx->opt_timing ? ctx->ev0 : nullptr));  // (timing: the DP kernel alone)
         KVM_DBG_SYNC(ctx, stream, "dtw_dp");
         dtw_qd = qd;
+        if (cnsm && ctx->opt_ucr_loops) {
+            out.rws = rws;
+            out.tiles = d_tiles;
+            out.n_tiles = n_tiles;
+            out.windows = pl.windows;
+            out.ucr_tables_ready = false;
+        }
     }
     HIPCHK(ctx, hipEventRecord(ctx->ev_staged, stream));  // every copy out of h_pinned has been enqueued before this point
     ctx->staged_pending = true;
@@ -1258,9 +1271,26 @@ static int dtw_resolve_ambiguous(kvm_ctx *ctx, const kvm_query_dev &qd, const kv
     if (kvm_trace_on())
         fprintf(stderr, "[kvm] dtw sequential path: %lld candidates, m %d rho %d, batches of %lld\n", (long long)n_ambig, qd.m,
                 qd.rho, (long long)batch);
+    // KVM_OPT_UCR_LOOPS (UcrDtwQueryExecutor's never-cleared cb1 / cb2, kvm_ucr.hip): exit depths of every window of the scan
+    // once per query, then per candidate the terms earlier windows left behind
+    const bool stale = out.tiles != nullptr;
+    int32_t *depth1 = nullptr, *depth2 = nullptr, *tmax1 = nullptr, *tmax2 = nullptr;
+    if (stale) {
+        if ((rc = ensure(ctx, ctx->b_ucr, ((size_t)2 * out.windows + 2 * out.n_tiles) * sizeof(int32_t) + 64))) return rc;
+        depth1 = (int32_t *)ctx->b_ucr.p;
+        depth2 = depth1 + out.windows;
+        tmax1 = depth2 + out.windows;
+        tmax2 = tmax1 + out.n_tiles;
+    }
     for (int64_t off = 0; off < n_ambig; off += batch) {
         const int64_t nb = std::min(batch, n_ambig - off);
-        HIPCHK(ctx, kvm_launch_dtw_ref_chains(ctx->d_series, qd, ax, cands + off, nb, slots, stream));
+        if (stale) {
+            HIPCHK(ctx, kvm_launch_ucr_dtw_stale(ctx->d_series, qd, ax, out.tiles, out.n_tiles, out.rws, depth1, depth2, tmax1, tmax2,
+                                                 cands + off, nb, slots, out.ucr_tables_ready, stream));
+            out.ucr_tables_ready = true;
+            KVM_DBG_SYNC(ctx, stream, "ucr_dtw_stale");
+        }
+        HIPCHK(ctx, kvm_launch_dtw_ref_chains(ctx->d_series, qd, ax, cands + off, nb, slots, stream, stale));
         KVM_DBG_SYNC(ctx, stream, "dtw_ref_chains");
         HIPCHK(ctx, kvm_launch_set_u64(counters + KVM_CNT_CANDS2, (unsigned long long)nb, counters + KVM_CNT_QUEUE, 0ULL, stream));
         HIPCHK(ctx, kvm_launch_dtw_dp(ctx->d_series, ctx->n, qd, ax2, cands + off, counters + KVM_CNT_CANDS2, nb, nullptr,
@@ -1464,6 +1494,11 @@ extern "C" int kvm_verify_device(kvm_ctx *ctx, int32_t variant, const double *qu
         HIPCHK(ctx, hipMemcpyAsync(d_out_count, (unsigned long long *)ctx->b_counters.p + KVM_CNT_ANSWERS,
                                    sizeof(int64_t), hipMemcpyDeviceToDevice, s));
     }
+    // Everything this call has enqueued behind run_variant's own record -- the sequential tie path's kernels, the copy of the
+    // answer count out of the counters -- still reads the context's scratch: the next call (possibly on another stream) must
+    // wait for all of it before it reuses the buffers.
+    HIPCHK(ctx, hipEventRecord(ctx->ev_staged, s));
+    ctx->staged_pending = true;
     return KVM_OK;
 }
 

@@ -37,7 +37,7 @@ __device__ __forceinline__ void ref_env_at(const double *__restrict__ series, co
 
 __global__ __launch_bounds__(64) void kvm_dtw_ref_chains_kernel(const double *__restrict__ series, kvm_query_dev qd,
                                                                 kvm_dtw_aux ax, kvm_cand *__restrict__ cands, int64_t n,
-                                                                double *__restrict__ slots) {
+                                                                double *__restrict__ slots, int keep_slots) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n) return;
     kvm_cand c = cands[idx];
@@ -53,7 +53,8 @@ __global__ __launch_bounds__(64) void kvm_dtw_ref_chains_kernel(const double *__
     }
     double lbK = 0, lbK2 = 0;
     if (pass) {
-        for (int k = 0; k < m; k++) cb1[k] = 0.0;                              // new double[queryLength]
+        if (!keep_slots)
+            for (int k = 0; k < m; k++) cb1[k] = 0.0;                          // new double[queryLength]
         for (int i = 0; i < m && lbK < bsf; i++) {                             // K/utils/DtwUtils.java:210
             const int o = ax.order[i];
             const double d = dref_term_q((x[o] - mean) / std, ax.uo[i], ax.lo[i]);
@@ -65,7 +66,8 @@ __global__ __launch_bounds__(64) void kvm_dtw_ref_chains_kernel(const double *__
     if (pass) {
         int32_t cbeg, cend;
         dref_chunk(ax, m, c.run, cbeg, cend);
-        for (int k = 0; k < m; k++) cb2[k] = 0.0;
+        if (!keep_slots)
+            for (int k = 0; k < m; k++) cb2[k] = 0.0;
         for (int i = 0; i < m && lbK2 < bsf; i++) {                            // K/utils/DtwUtils.java:242
             const int o = ax.order[i];
             double U, L;
@@ -87,9 +89,9 @@ __global__ __launch_bounds__(64) void kvm_dtw_ref_chains_kernel(const double *__
 }
 
 hipError_t kvm_launch_dtw_ref_chains(const double *series, const kvm_query_dev &qd, const kvm_dtw_aux &ax, kvm_cand *cands,
-                                     int64_t n, double *slots, hipStream_t s) {
+                                     int64_t n, double *slots, hipStream_t s, bool keep_slots) {
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(kvm_dtw_ref_chains_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, series, qd, ax, cands, n,
-                       slots);
+                       slots, keep_slots ? 1 : 0);
     return hipGetLastError();
 }

@@ -182,6 +182,10 @@ static hipError_t ex_replay(const double *series, int m, const kvm_replay_ws &ws
     return hipGetLastError();
 }
 
+hipError_t kvm_launch_replay_runs(const double *series, int m, const kvm_replay_ws &ws, hipStream_t s) {
+    return ex_replay(series, m, ws, s);
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Exact ED.  q_exact: RSM = the raw query; cNSM = zQ permuted by `order` (|zQ| descending, stable).
 // A workgroup evaluates EX_GROUP survivors at a time: waves 1-3 produce the distance terms of all of them one chunk

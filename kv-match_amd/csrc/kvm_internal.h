@@ -90,7 +90,7 @@ struct kvm_ctx {
     hipEvent_t ev_env = nullptr;     // recorded behind the envelope build
     hipStream_t env_stream = nullptr;  // the stream it was built on
     // grow-only scratch
-    kvm_dev_buf b_query, b_tiles, b_out_off, b_out_dist, b_counters, b_cands, b_cands2, b_aux, b_aux2, b_scratch, b_plans;
+    kvm_dev_buf b_query, b_tiles, b_out_off, b_out_dist, b_counters, b_cands, b_cands2, b_aux, b_aux2, b_scratch, b_plans, b_ucr;
     void *h_pinned = nullptr;
     void *h_readback2 = nullptr;  // pinned: answers beyond the first KVM_SPEC_ANSWERS (grow-only)
     size_t h_readback2_cap = 0;
@@ -276,6 +276,8 @@ hipError_t kvm_launch_ucr_ed_screen(const double *series, const double2 *prefix,
                                     const int32_t *order, const kvm_tile *tilesA, int64_t nA, const kvm_tile *tilesB, int64_t nB,
                                     const unsigned long long *d_counts, kvm_surv *ties, int64_t cap, unsigned long long *counters,
                                     int num_cu, hipStream_t s);
+// replay of the runs queued in ws.run_list (kvm_exact.hip)
+hipError_t kvm_launch_replay_runs(const double *series, int m, const kvm_replay_ws &ws, hipStream_t s);
 hipError_t kvm_launch_ucr_ed_ties(const double *series, const kvm_query_dev &qd, const double *zqs, const int32_t *order,
                                   const kvm_surv *ties, const unsigned long long *d_n, int64_t max_ties, const kvm_replay_ws &ws,
                                   int32_t *out_off, double *out_dist, int64_t cap, unsigned long long *counters, int num_cu,
@@ -319,8 +321,17 @@ hipError_t kvm_launch_dtw_screen(const double *series, const double2 *prefix, co
 // sequential reference-ordered evaluation of the ambiguous candidates: LB_Kim, both LB_Keogh loops with their exits,
 // the choice of the larger bound and its suffix sums (K/NormQueryEngineDtw.java:555-587); rejected candidates get
 // start = -start, the others their cb[] in slots[2m * index + (lim != 0 ? m : 0)]
+// (keep_slots: the cb1 / cb2 slots already hold what the arrays hold when the loops start -- KVM_OPT_UCR_LOOPS -- instead of
+// being zeroed like the engines' fresh arrays)
 hipError_t kvm_launch_dtw_ref_chains(const double *series, const kvm_query_dev &qd, const kvm_dtw_aux &ax, kvm_cand *cands,
-                                     int64_t n, double *slots, hipStream_t s);
+                                     int64_t n, double *slots, hipStream_t s, bool keep_slots = false);
+// cNSM-DTW with KVM_OPT_UCR_LOOPS: slots[2m per candidate] <- what the executor's never-cleared cb1 / cb2 hold when the
+// candidate's loops start (kvm_launch_dtw_ref_chains then runs with keep_slots).  depth1/2: [windows], tmax1/2: [n_tiles]
+// scratch, filled on the first call of a query (`tables_ready` = false).
+hipError_t kvm_launch_ucr_dtw_stale(const double *series, const kvm_query_dev &qd, const kvm_dtw_aux &ax, const kvm_tile *tiles,
+                                    int64_t n_tiles, const kvm_replay_ws &ws, int32_t *depth1, int32_t *depth2, int32_t *tmax1,
+                                    int32_t *tmax2, const kvm_cand *cands, int64_t n, double *slots, bool tables_ready,
+                                    hipStream_t s);
 hipError_t kvm_launch_dtw_filter(const double *series, const double2 *prefix, int64_t n, const kvm_query_dev &qd,
                                  const kvm_tile *tiles, int64_t n_tiles, int32_t use_lb, kvm_cand *out,
                                  unsigned long long *counters, hipStream_t s);

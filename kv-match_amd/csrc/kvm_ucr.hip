@@ -192,3 +192,195 @@ hipError_t kvm_launch_ucr_ed_ties(const double *series, const kvm_query_dev &qd,
                        out_dist, cap, counters);
     return hipGetLastError();
 }
+
+// ---- 2. UcrDtwQueryExecutor: what earlier windows left in cb1 / cb2 ---------------------------------------------------------
+// upper / lower envelope of the fetched chunk at 1-based point p (as ref_env_at of kvm_dtw_ref.hip: a pure selection)
+__device__ __forceinline__ void ucr_env_at(const double *__restrict__ series, const kvm_dtw_aux &ax, int r, int32_t cbeg,
+                                           int32_t cend, int32_t p, double &U, double &L) {
+    if (p - r >= cbeg && p + r <= cend) {
+        U = ax.env_u[p - 1];
+        L = ax.env_l[p - 1];
+        return;
+    }
+    const int32_t a = max(cbeg, p - r), b = min(cend, p + r);
+    double mx = series[a - 1], mn = mx;
+    for (int32_t t = a + 1; t <= b; t++) {
+        const double v = series[t - 1];
+        mx = (v > mx) ? v : mx;
+        mn = (v < mn) ? v : mn;
+    }
+    U = mx;
+    L = mn;
+}
+
+// every run of the query queued for a full replay of its running sums (the depth kernel needs the reference's own mean /
+// std of EVERY window)
+__global__ __launch_bounds__(256) void kvm_ucr_mark_all_kernel(kvm_replay_ws ws) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < ws.n_runs) {
+        ws.run_maxk[r] = ws.runs[r].count;
+        ws.run_list[r] = (int32_t)r;
+    }
+    if (r == 0) *ws.run_list_n = (unsigned long long)ws.n_runs;
+}
+
+// One lane per window, in the reference's arithmetic (U/UcrDtwQueryExecutor.java:227-262): depth1 = iterations of
+// lbKeoghCumulative (0: not reached), depth2 = iterations of lbKeoghDataCumulative; tmax1 / tmax2 = their maxima per tile.
+__global__ __launch_bounds__(256) void kvm_ucr_dtw_depth_kernel(const double *__restrict__ series, kvm_query_dev qd, kvm_dtw_aux ax,
+                                                                const kvm_tile *__restrict__ tiles, int64_t n_tiles,
+                                                                kvm_replay_ws ws, int32_t *__restrict__ depth1,
+                                                                int32_t *__restrict__ depth2, int32_t *__restrict__ tmax1,
+                                                                int32_t *__restrict__ tmax2) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t t = (int64_t)blockIdx.x * 4 + wave;
+    if (t >= n_tiles) return;
+    const kvm_tile tile = tiles[t];
+    const int m = qd.m, r = qd.rho;
+    const double bsf = qd.eps2;
+    int d1 = 0, d2 = 0;
+    if (lane < tile.count) {
+        const kvm_run rn = ws.runs[tile.run];
+        const int32_t start = tile.start + lane;
+        const int64_t wi = rn.win_base + (start - rn.start);
+        const double mean = ws.stats[wi] / m;                                       // :227
+        const double std = sqrt(ws.stats[ws.stats_plane + wi] / m - mean * mean);   // :228-229
+        const double *__restrict__ x = series + (start - 1);
+        if (kvm_cnsm_filter(mean, std, qd.meanQ, qd.stdQ, qd.alpha, qd.beta)) {     // :236
+            bool pass = true;
+            if (m >= 6) pass = dref_kim(x, qd.q, m, mean, std, bsf) <= bsf;          // :239-241
+            if (pass) {
+                double lb = 0;
+                int i = 0;
+                for (; i < m && lb < bsf; i++) lb += dref_term_q((x[ax.order[i]] - mean) / std, ax.uo[i], ax.lo[i]);  // :244
+                d1 = i;
+                if (lb <= bsf) {                                                    // :245
+                    int32_t cbeg, cend;
+                    dref_chunk(ax, m, tile.run, cbeg, cend);
+                    double lb2 = 0;
+                    for (i = 0; i < m && lb2 < bsf; i++) {                          // :255
+                        double U, L;
+                        ucr_env_at(series, ax, r, cbeg, cend, start + ax.order[i], U, L);
+                        lb2 += dref_term_d(ax.qo[i], U, L, mean, std);
+                    }
+                    d2 = i;
+                }
+            }
+        }
+        depth1[wi] = d1;
+        depth2[wi] = d2;
+    }
+    int m1 = d1, m2 = d2;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        m1 = max(m1, __shfl_xor(m1, o, 64));
+        m2 = max(m2, __shfl_xor(m2, o, 64));
+    }
+    if (lane == 0) {
+        tmax1[t] = m1;
+        tmax2[t] = m2;
+    }
+}
+
+// One wavefront per candidate of the sequential tie path: the content the executor's cb1 / cb2 have when this window's loops
+// start, for the positions its own loops will not overwrite.  Walks back over the earlier windows in scan order (= the order
+// of the tile list): the nearest one whose loop got past depth C wrote the entries of depths [C, its depth), then C rises.
+__global__ __launch_bounds__(64) void kvm_ucr_dtw_stale_kernel(const double *__restrict__ series, kvm_query_dev qd, kvm_dtw_aux ax,
+                                                               const kvm_tile *__restrict__ tiles, kvm_replay_ws ws,
+                                                               const int32_t *__restrict__ depth1,
+                                                               const int32_t *__restrict__ depth2,
+                                                               const int32_t *__restrict__ tmax1,
+                                                               const int32_t *__restrict__ tmax2,
+                                                               const kvm_cand *__restrict__ cands, int64_t n,
+                                                               double *__restrict__ slots) {
+    const int64_t idx = blockIdx.x;
+    if (idx >= n) return;
+    const int lane = threadIdx.x;
+    const int m = qd.m, r = qd.rho;
+    const kvm_cand c = cands[idx];
+    double *__restrict__ cb1 = slots + (size_t)idx * 2 * m, *__restrict__ cb2 = cb1 + m;
+    for (int k = lane; k < 2 * m; k += 64) cb1[k] = 0.0;   // `new double[M]`, U/UcrDtwQueryExecutor.java:157-161
+    if (c.start < 0) return;
+    const kvm_run rc = ws.runs[c.run];
+    const int64_t tw = rc.tile_base + (c.start - rc.start) / 64;  // (the DTW plan cuts runs into tiles of 64)
+    const int lw = (c.start - rc.start) % 64;
+    const int64_t wic = rc.win_base + (c.start - rc.start);
+    for (int which = 0; which < 2; which++) {
+        const int32_t *__restrict__ depth = which ? depth2 : depth1, *__restrict__ tmax = which ? tmax2 : tmax1;
+        double *__restrict__ cb = which ? cb2 : cb1;
+        int C = depth[wic];  // the candidate's own loop overwrites the entries below its own depth
+        int64_t t = tw;
+        int limit = lw;      // lanes < limit of tile t are earlier windows
+        while (C < m && t >= 0) {
+            const kvm_tile tile = tiles[t];
+            const kvm_run rn = ws.runs[tile.run];
+            const bool have = lane < min(limit, tile.count);
+            const int32_t start = tile.start + lane;
+            const int64_t wi = rn.win_base + (start - rn.start);
+            const int d = have ? depth[wi] : 0;
+            // a record: deeper than everything between it and the candidate (and than C)
+            int sfx = d;  // inclusive maximum over lanes >= mine
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int v = __shfl_down(sfx, o, 64);
+                if (lane + o < 64) sfx = max(sfx, v);
+            }
+            const int above = __shfl_down(sfx, 1, 64);  // exclusive: lanes > mine
+            const int nearer = lane < 63 ? above : 0;
+            unsigned long long rec = __ballot(d > max(C, nearer));
+            while (rec && C < m) {
+                const int L = 63 - __clzll((long long)rec);  // nearest record first (wave-uniform)
+                rec &= ~(1ULL << L);
+                const int dL = __shfl(d, L, 64);
+                if (dL <= C) continue;
+                const int32_t sL = tile.start + L;
+                const int64_t wL = rn.win_base + (sL - rn.start);
+                const double mean = ws.stats[wL] / m;
+                const double std = sqrt(ws.stats[ws.stats_plane + wL] / m - mean * mean);
+                const double *__restrict__ x = series + (sL - 1);
+                int32_t cbeg = 0, cend = 0;
+                if (which) dref_chunk(ax, m, tile.run, cbeg, cend);
+                for (int i = C + lane; i < dL; i += 64) {
+                    const int o = ax.order[i];
+                    double term;
+                    if (!which) {
+                        term = dref_term_q((x[o] - mean) / std, ax.uo[i], ax.lo[i]);
+                    } else {
+                        double U, Lo;
+                        ucr_env_at(series, ax, r, cbeg, cend, sL + o, U, Lo);
+                        term = dref_term_d(ax.qo[i], U, Lo, mean, std);
+                    }
+                    cb[o] = term;
+                }
+                C = dL;
+            }
+            if (C >= m) break;
+            // the nearest earlier tile that holds a deeper window
+            limit = 64;
+            int64_t tn = -1;
+            for (int64_t base = t - 1; base >= 0 && tn < 0; base -= 64) {
+                const int64_t tj = base - lane;
+                const bool hit = tj >= 0 && tmax[tj] > C;
+                const unsigned long long b = __ballot(hit);
+                if (b) tn = base - (__ffsll((long long)b) - 1);
+            }
+            t = tn;
+        }
+    }
+}
+
+hipError_t kvm_launch_ucr_dtw_stale(const double *series, const kvm_query_dev &qd, const kvm_dtw_aux &ax, const kvm_tile *tiles,
+                                    int64_t n_tiles, const kvm_replay_ws &ws, int32_t *depth1, int32_t *depth2, int32_t *tmax1,
+                                    int32_t *tmax2, const kvm_cand *cands, int64_t n, double *slots, bool tables_ready,
+                                    hipStream_t s) {
+    if (n <= 0 || n_tiles <= 0) return hipSuccess;
+    if (!tables_ready) {
+        hipLaunchKernelGGL(kvm_ucr_mark_all_kernel, dim3((unsigned)((ws.n_runs + 255) / 256)), dim3(256), 0, s, ws);
+        hipError_t e = kvm_launch_replay_runs(series, qd.m, ws, s);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kvm_ucr_dtw_depth_kernel, dim3((unsigned)((n_tiles + 3) / 4)), dim3(256), 0, s, series, qd, ax, tiles,
+                           n_tiles, ws, depth1, depth2, tmax1, tmax2);
+    }
+    hipLaunchKernelGGL(kvm_ucr_dtw_stale_kernel, dim3((unsigned)n), dim3(64), 0, s, series, qd, ax, tiles, ws, depth1, depth2, tmax1,
+                       tmax2, cands, n, slots);
+    return hipGetLastError();
+}

@@ -1288,24 +1288,30 @@ def test_ucr_ed_partial_sum_tie(world):
         ctx.load_series(series)
 
 
-def test_ucr_dtw_stale_cb_tie_is_the_known_difference(world):
-    """U/UcrDtwQueryExecutor.java never clears cb1 / cb2 between windows; at an exact LB_Keogh tie the DP then reads what the
-    previous window left there and rejects windows the engines (fresh arrays) report at distance eps
-    (tests/test_oracle.py::test_ucr_dtw_executor_reads_stale_cb_entries_at_exact_ties).  The executor mirror runs the
-    engine's semantics: on this instance it answers with the engine's 14 windows, not the executor's 8 -- the 6
-    extra ones all at distance eps.  This test pins that documented difference."""
+def test_ucr_dtw_stale_cb_tie(world):
+    """U/UcrDtwQueryExecutor.java never clears cb1 / cb2 between windows; at an exact LB_Keogh tie the DP then reads what
+    earlier windows left there and rejects windows the engines (fresh arrays) report at distance eps
+    (tests/test_oracle.py::test_ucr_dtw_executor_reads_stale_cb_entries_at_exact_ties).  Since round 3 the executor mirror
+    reproduces that (KVM_OPT_UCR_LOOPS, kvm_ucr.hip): on this instance the executor's 8 windows, plain equality with the
+    oracle's restatement -- while the ENGINE on the executor's segments keeps its 14 (the 6 extra ones all at distance eps)."""
     kvmatch, datagen, series, ctx = world
+    from kvmatch import ucr
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", "ucr", "ucr_dtw_stale_cb_tie.npz"))
     s, q = g["s"].astype(np.float64), g["q"].astype(np.float64)
     eps, rho, alpha, beta = float(g["eps"]), int(g["rho"]), float(g["alpha"]), float(g["beta"])
     ctx.load_series(s)
     try:
-        d = kvmatch.UcrDtwQueryExecutor(ctx, len(s), len(q), q, eps, rho, alpha, beta)
-        assert d.run() == 14
-        assert np.array_equal(d.answers.offsets, g["engine_off"]) and np.array_equal(d.answers.distances, g["engine_dist"])
         uo, ud, _ = oracle.ucr_dtw(s, q, eps, rho, alpha, beta)
-        extra = set(zip(d.answers.offsets.tolist(), d.answers.distances.tolist())) - set(zip(uo.tolist(), ud.tolist()))
-        assert len(uo) == 8 and len(extra) == 6 and all(dist == eps for _, dist in extra)
+        assert len(uo) == 8
+        d = kvmatch.UcrDtwQueryExecutor(ctx, len(s), len(q), q, eps, rho, alpha, beta)
+        assert d.run() == 8
+        assert np.array_equal(d.answers.offsets, uo) and np.array_equal(d.answers.distances, ud)
+        assert d.answers.stats[kvmatch.STAT_DTW_SEQUENTIAL] > 0 and ctx.get_option(kvmatch.OPT_UCR_LOOPS) == 0
+        L, R = ucr.segments(1, len(s) - len(q) + 1, ucr.EPOCH - len(q) + 1)
+        eng = kvmatch.NormQueryEngineDtw(ctx).verify((L, R), 1, q, eps, rho, alpha, beta, resolved=True)
+        assert np.array_equal(eng.offsets - 1, g["engine_off"]) and np.array_equal(eng.distances, g["engine_dist"]) and len(eng) == 14
+        extra = set(zip((eng.offsets - 1).tolist(), eng.distances.tolist())) - set(zip(uo.tolist(), ud.tolist()))
+        assert len(extra) == 6 and all(dist == eps for _, dist in extra)
     finally:
         ctx.load_series(series)
 
