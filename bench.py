@@ -13,14 +13,19 @@ The headline runs with early abandoning OFF, i.e. every candidate is evaluated o
 only mode whose work is data-independent (with abandoning on, random candidates die after ~12 points and the
 number measures launch overhead; it is reported separately as value_early_abandon).
 
-A step is a STREAM of `--queries-per-step` such passes (default: 100 for the ED workloads, 10 for cNSM-DTW, 8 for the
+A step is a STREAM of `--queries-per-step` such passes (default: 300 for the ED workloads, 30 for cNSM-DTW, 40 for the
 mixed stream), so that the timed region of the default run is seconds, not milliseconds; `value` = candidates
-verified per second over the stream, `ms_per_query` = one pass.
+verified per second over the stream, `ms_per_query` = one pass.  The stream is NOT one query repeated: NQ = 10 queries
+drawn at seeded offsets of the series ("10 offsets per setting"), each with two noisy copies planted, cycle
+through the step, and query j runs over interval list j mod 4 of four differently seeded phase-1-shaped lists.  Every
+workload the run times is checked against the CPU oracle (`parity_vs_oracle`, per workload); the CPU baseline runs
+BEFORE the timed region (rank 0, N = 1).
 
 Multi-GPU: one process per GPU.  `python bench.py --gpus N` (N > 1) without a launcher starts
 `python -m torch.distributed.run --nproc-per-node N` on itself as a child process BEFORE any GPU call and relays its
 output; it never silently runs on one rank.  `--scaling weak` (default): every rank verifies its own shard of 1e6
-candidates of a world*1e6 list (series replicated); `--scaling strong`: the 1e6-candidate list is split over the ranks.
+candidates of a world*1e6 list (series replicated); `--scaling strong`: the 1e6-candidate list is split over the ranks;
+`--scaling both`: the weak run is the line's `value`, the strong run of the same launch is reported beside it (`strong`).
 Either way ONE all-gather (RCCL) of the surviving (offset, distance) pairs per query.
 """
 import argparse
@@ -63,8 +68,11 @@ def parse():
                     help="phase-2 passes (queries of the stream) per step; 0 = per-workload default")
     ap.add_argument("--in-flight", type=int, default=4,
                     help="queries in flight per GPU (contexts over one resident series, one host thread each)")
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
-                    help="weak: --candidates per GPU; strong: --candidates in total, split over the GPUs")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong", "both"],
+                    help="weak: --candidates per GPU; strong: --candidates in total, split over the GPUs; both: weak is the "
+                         "headline, the strong run of the same launch is reported in `strong`")
+    ap.add_argument("--queries", type=int, default=10, help="distinct queries cycling through a step (seeded offsets)")
+    ap.add_argument("--lists", type=int, default=4, help="distinct interval lists (query j runs over list j mod this)")
     ap.add_argument("--workload", default="rsm_ed", choices=["rsm_ed", "cnsm_ed", "cnsm_dtw", "mixed"],
                     help="rsm_ed = BASELINE configs[1] (headline); cnsm_ed = configs[2]; cnsm_dtw = configs[3] "
                          "(m=4096, rho=5%%); mixed = configs[4]-style stream alternating all four variants")
@@ -156,12 +164,31 @@ def roofline_block(wl, plans, k_ns, stage_stats, m):
                     "algorithmic-byte rate exceeds the HBM peak by construction; hbm_measured_gbs is the real HBM rate"}
 
 
+def visible_gpus():
+    """GPU agents of the KFD topology (nodes with SIMDs), narrowed by ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES when set; None
+    when sysfs does not tell (the ranks then fail by themselves if a device is missing)."""
+    try:
+        base = "/sys/class/kfd/kfd/topology/nodes"
+        cnt = 0
+        for node in os.listdir(base):
+            with open(os.path.join(base, node, "properties")) as f:
+                props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+            cnt += int(props.get("simd_count", "0")) > 0
+        for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+            v = os.environ.get(var)
+            if v is not None and v.strip() != "":
+                cnt = min(cnt, len([x for x in v.split(",") if x.strip() != ""]))
+        return cnt
+    except Exception:
+        return None
+
+
 def self_launch(n_gpus):
     """`python bench.py --gpus N` without a launcher: start one rank per GPU through torch.distributed.run as a CHILD
     process (this process has made no GPU call: an exec or a fork after HIP initialisation is not allowed on the pool)
     and relay its output and exit code."""
-    have = torch.cuda.device_count()  # (counting devices does not initialise the GPU)
-    if have < n_gpus:
+    have = visible_gpus()  # (the KFD topology in sysfs: no HIP / HSA call in this process)
+    if have is not None and have < n_gpus:
         print(f"bench.py: --gpus {n_gpus} but only {have} GPU(s) are visible; refusing to run fewer ranks", file=sys.stderr)
         return 2
     with socket.socket() as s:
@@ -217,32 +244,57 @@ def main():
             raise SystemExit(f"--gpus {a.gpus} but the RCCL group has {rccl_ranks} ranks")
     n, m = a.n, a.m
     wl = a.workload
-    qps = a.queries_per_step if a.queries_per_step > 0 else {"rsm_ed": 100, "cnsm_ed": 100, "cnsm_dtw": 10, "mixed": 8}[wl]
-    # weak scaling: the list grows with the world (fixed work per GPU); strong: the list is fixed and split
-    total_list = a.candidates * world if a.scaling == "weak" else a.candidates
+    qps = a.queries_per_step if a.queries_per_step > 0 else {"rsm_ed": 300, "cnsm_ed": 300, "cnsm_dtw": 30, "mixed": 40}[wl]
+    NQ, NL = max(1, a.queries), max(1, a.lists)
+    if wl == "cnsm_dtw":
+        m = 4096
 
-    # ---- inputs: every rank builds the same series (replicated), deterministic from the seed ------------
+    # ---- inputs: every rank builds the same series (replicated), deterministic from the seeds ------------
+    # NQ queries at seeded offsets, two noisy copies of each planted (non-trivial answers); positions on a grid of 4m-point
+    # cells, so that no planted copy overwrites another query.  NL interval lists (different seeds), each covering every query
+    # offset and every copy; query j runs over list j mod NL.
     t0 = time.perf_counter()
     series = datagen.gen_series(n)
-    qoff = n // 3 + 17
-    planted = [n // 7, n // 2 + 1000, n - 3 * m]
-    q = datagen.plant_copies(series, qoff, m, planted, [1.0, 1.0, 1.0], [0.0, 0.02, -0.03], 0.01)
-    left, right = datagen.gen_intervals(n, m, total_list, 64.0, must_cover=[qoff] + planted, seed=1)
-    my_l, my_r = distributed.split_intervals(left, right, world, rank)
-    my_cands = int((my_r.astype(np.int64) - my_l + 1).sum())
+    rng = np.random.default_rng(0x51EED + m)
+    cells = rng.choice(max(3 * NQ + 2, n // (4 * m) - 2), size=3 * NQ, replace=False) + 1
+    pos = [int(c) * 4 * m + 1 for c in cells]
+    qoffs, queries, must = [], [], []
+    for j in range(NQ):
+        qo, planted = pos[3 * j], [pos[3 * j + 1], pos[3 * j + 2]]
+        if wl == "cnsm_dtw":
+            # cNSM-DTW sorts the query the way the reference does (JDK TimSort under its truncating comparator, DESIGN.md
+            # section 2); where that sort throws the reference cannot answer the query at all, so such a slice is not a
+            # benchmark input: move on to the next cell that holds a query the reference can run
+            for step_ in range(64):
+                try:
+                    kvmatch.cnsm_dtw_order(series[qo - 1: qo - 1 + m])
+                    break
+                except kvmatch.KvMatchIllegalArgument:
+                    qo += 4 * m * (3 * NQ + 1)
+                    if qo + 4 * m > n:
+                        qo = pos[3 * j] // 2 + 1
+            queries.append(series[qo - 1: qo - 1 + m].copy())
+            must += [qo]
+        else:
+            queries.append(datagen.plant_copies(series, qo, m, planted, [1.0, 1.0], [0.02, -0.03], 0.01, seed=100 + j))
+            must += [qo] + planted
+        qoffs.append(qo)
+    must = sorted(set(must))
+
+    def make_lists(total):
+        ls = [datagen.gen_intervals(n, m, total, 64.0, must_cover=must, seed=1 + i) for i in range(NL)]
+        return ls, [distributed.split_intervals(l, r, world, rank) for l, r in ls]
+
+    scalings = ["weak", "strong"] if a.scaling == "both" else [a.scaling]
+    full_lists, shards = make_lists(a.candidates * world if scalings[0] == "weak" else a.candidates)
+    my_cands_l = [int((r.astype(np.int64) - l + 1).sum()) for l, r in shards]
+    my_cands = my_cands_l[0]
     ctx = kvmatch.Phase2Context(local_rank)
     ctx.load_series(series)
     ctx.set_option(kvmatch.OPT_ED_KERNEL, a.ed_kernel)  # (HIP-event timing of the kernels: only in the exclusive pass below --
     #                                                       the event records cost ~0.1 ms of stream time per query)
     setup_s = time.perf_counter() - t0
 
-    # per-workload query parameters (BASELINE.json configs)
-    if wl == "cnsm_dtw":
-        m = 4096
-        q = series[qoff - 1: qoff - 1 + m].copy()
-        left, right = datagen.gen_intervals(n, m, total_list, 64.0, must_cover=[qoff], seed=2)
-        my_l, my_r = distributed.split_intervals(left, right, world, rank)
-        my_cands = int((my_r.astype(np.int64) - my_l + 1).sum())
     # (variant id of kvm_verify_device, engine class, positional args after epsilon, keyword args for ShardedVerifier)
     plans = {
         "rsm_ed": [(0, kvmatch.QueryEngine, (), {})],
@@ -253,16 +305,57 @@ def main():
                   (2, kvmatch.QueryEngineDtw, (0.05,), dict(rho=0.05)),
                   (3, kvmatch.NormQueryEngineDtw, (0.05, 2.0, 10.0), dict(rho=0.05, alpha=2.0, beta=10.0))],
     }[wl]
-    if any(v == 3 for v, _, _, _ in plans):
-        # cNSM-DTW sorts the query the way the reference does; where that sort throws the reference
-        # cannot answer the query at all, so such a query is not a benchmark input: say so instead of failing mid-run
-        try:
-            kvmatch.cnsm_dtw_order(q)
-        except kvmatch.KvMatchIllegalArgument as e:
-            raise SystemExit(f"bench: the reference's Arrays.sort throws on this query ({e}); pick another --n / workload")
+    if wl == "mixed":  # (the cNSM-DTW leg of the mixed stream: queries on which the reference's sort throws are answered in
+        ctx.set_option(kvmatch.OPT_SORT_VIOLATION, 1)  # index order -- the planted ED queries are not chosen for that sort)
     engines = [cls(ctx) for _, cls, _, _ in plans]
     eng = engines[0]
     lib, h = ctx._lib, ctx._h
+    out = {}
+
+    # ---- CPU baseline FIRST (rank 0, N = 1): the oracle (a C port of the reference loops) ----------------
+    # (before the GPU's timed region, so that the GPU is busy for the rest of the run; bounded: one query single-threaded,
+    # the same query on all host cores in a child process -- no GPU context there)
+    oracle = None
+    if rank == 0 and world == 1 and (a.cpu_baseline or a.extras):
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import oracle  # test infrastructure: used here only as the timed CPU baseline / checker
+    if rank == 0 and world == 1 and a.cpu_baseline and wl == "rsm_ed":
+        l0, r0 = shards[0]
+        t1 = time.perf_counter()
+        o_off, o_dist, o_st = oracle.rsm_ed(series, queries[0], l0, r0, 0, a.epsilon, no_abandon=True)
+        cpu_s = time.perf_counter() - t1
+        t1 = time.perf_counter()
+        oracle.rsm_ed(series, queries[0], l0, r0, 0, a.epsilon, no_abandon=False)
+        cpu_ab_s = time.perf_counter() - t1
+        # the reference's own Java loop could only be timed with a JDK on this box (and the Maven artefacts its sources
+        # import): probe instead of assuming
+        java, javac = shutil.which("java"), shutil.which("javac")
+        out["cpu_baseline"] = {
+            "value": o_st["windows"] / cpu_s, "unit": "candidates/s", "cores": 1, "kind": "port",
+            "jdk_probe": {"java": java, "javac": javac},
+            "sample": f"all {o_st['windows']} candidates of query 0 over list 0 of the N=1 workload, early abandon off (same work "
+                      f"per query as `value`), single thread; C restatement of K/QueryEngine.java:338-363 "
+                      f"({'a JDK is present but the reference needs un-vendored Maven artefacts' if java else 'no JDK on this box: java/javac not on PATH'}; "
+                      f"the port avoids Java boxing, so it flatters the CPU side)",
+            "value_early_abandon": o_st["windows"] / cpu_ab_s,
+            "seconds": cpu_s,
+        }
+        # the same loop on all host cores: a child process (no GPU context there) forks one worker per core
+        try:
+            ncores = min(os.cpu_count() or 1, 64)
+            np.savez(os.path.join(ROOT, "gpurun_out", "_bench_cpu_in.npz") if os.path.isdir(os.path.join(ROOT, "gpurun_out"))
+                     else "/tmp/_bench_cpu_in.npz", q=queries[0], left=l0, right=r0)
+            cp = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline.py"), "rsm_ed", str(n), str(a.epsilon),
+                                 str(ncores), os.path.join(ROOT, "gpurun_out", "_bench_cpu_in.npz")
+                                 if os.path.isdir(os.path.join(ROOT, "gpurun_out")) else "/tmp/_bench_cpu_in.npz"],
+                                capture_output=True, text=True, timeout=300)
+            allc = json.loads(cp.stdout.strip().splitlines()[-1])
+            out["cpu_baseline"]["all_cores"] = {"cores": allc["cores"], "value": allc["no_abandon"]["candidates_per_s"],
+                                                "value_early_abandon": allc["early_abandon"]["candidates_per_s"],
+                                                "note": "same port, interval shards over forked worker processes"}
+        except Exception as e:
+            out["cpu_baseline"]["all_cores"] = {"error": repr(e)}
+
     step_no = [0]
     last = {}
     F = max(1, a.in_flight)
@@ -272,58 +365,67 @@ def main():
     # launched ranks: device-resident shard verification (kvm_verify_device) through ShardedStream, whose calling thread
     # alone issues the RCCL all-gathers, in query order.
     qstream = None if use_dist else kvmatch.QueryStream(ctx, F)
-    sstream = distributed.ShardedStream(ctx, plans[0][0], my_cands, in_flight=F) if use_dist else None
+    sstream = distributed.ShardedStream(ctx, plans[0][0], max(my_cands_l), in_flight=F) if use_dist else None
     eng_cache = {}
 
-    def host_job(i):
+    def host_job(i, j):
         def job(c):
             e = eng_cache.get((id(c), i))
             if e is None:
                 e = eng_cache[(id(c), i)] = plans[i][1](c)
-            ans = e.verify((my_l, my_r), 1, q, a.epsilon, *plans[i][2])
-            return i, ans.offsets, ans.distances
+            l_, r_ = shards[j % NL]
+            ans = e.verify((l_, r_), 1, queries[j], a.epsilon, *plans[i][2])
+            return i, j, ans.offsets, ans.distances
         return job
 
     def step():
-        idx = [(step_no[0] + j) % len(plans) for j in range(qps)]  # "mixed": the stream cycles through the four variants
+        # the stream cycles through the NQ queries (and, "mixed", through the four variants); query j runs over list j mod NL
+        ids = [((step_no[0] + t) % len(plans), (step_no[0] + t) % NQ) for t in range(qps)]
         step_no[0] += qps
         if use_dist:
-            res = sstream.run([dict(valid_positions=(my_l, my_r), last_segment=1, query_data=q, epsilon=a.epsilon,
-                                    variant=plans[i][0], **plans[i][3]) for i in idx])
-            last["offs"], last["dists"] = res[-1]
+            res = sstream.run([dict(valid_positions=shards[j % NL], last_segment=1, query_data=queries[j], epsilon=a.epsilon,
+                                    variant=plans[i][0], **plans[i][3]) for i, j in ids])
+            last["res"] = [(i, j, o, d) for (i, j), (o, d) in zip(ids, res)][-NQ * len(plans):]
         else:
-            res = qstream.run([host_job(i) for i in idx])
-            last["offs"], last["dists"] = res[-1][1], res[-1][2]
+            res = qstream.run([host_job(i, j) for i, j in ids])
+            last["res"] = res[-NQ * len(plans):]
 
     def set_option(opt, val):
         (sstream if use_dist else qstream).set_option(opt, val)
 
+    def sum_cands(ids_count):
+        """candidates verified by `ids_count` consecutive queries of the stream starting at query 0 (whole job)"""
+        per_q = np.array([my_cands_l[j % NL] for j in range(NQ)], dtype=np.int64)
+        tot = int(per_q.sum()) * (ids_count // NQ) + int(per_q[: ids_count % NQ].sum())
+        if world > 1:
+            t = torch.tensor([tot], dtype=torch.int64, device="cuda")
+            dist.all_reduce(t)
+            tot = int(t.item())
+        return tot
+
     # ---- headline: early abandon off ---------------------------------------------------------------------
     set_option(kvmatch.OPT_EARLY_ABANDON, 0)
     # first calls allocate scratch (and build the rho envelope for DTW); through the host API on this rank's shard, which
-    # also returns the per-stage counters the roofline block needs (the sharded path returns answers only), and -- one
-    # query at a time -- the EXCLUSIVE duration of the dominant kernel (HIP events on its own stream): with several
-    # queries in flight the kernels of different contexts overlap and their event-to-event times are no longer their own.
+    # also returns the per-stage counters the roofline block needs (the sharded path returns answers only)
     stage_stats = {}
-    for i, (v, _, pos, _) in enumerate(plans):
-        r_ = engines[i].verify((my_l, my_r), 1, q, a.epsilon, *pos)
+    for i, (v, _, pos_, _) in enumerate(plans):
+        r_ = engines[i].verify(shards[0], 1, queries[0], a.epsilon, *pos_)
         stage_stats[v] = list(r_.stats)
     step()
     step_no[0] = 0
     dt = timed_steps(step, a.steps, a.warmup, world)
-    total_cands = my_cands
-    if world > 1:
-        t = torch.tensor([my_cands], dtype=torch.int64, device="cuda")
-        dist.all_reduce(t)
-        total_cands = int(t.item())
-    value = total_cands * a.steps * qps / dt
-    head_offs, head_dists = last["offs"].copy(), last["dists"].copy()
-    # (right after the timed region, clocks still up: the dominant kernel's own duration, one query in flight)
+    step_no[0] = 0
+    value = sum_cands(a.steps * qps) / dt
+    head = {(i, j): (o.copy(), d.copy()) for i, j, o, d in last["res"]}
+    # (right after the timed region, clocks still up: the dominant kernel's own duration, ONE query in flight, HIP events on
+    # its own stream -- with several queries in flight the kernels of different contexts overlap and an event-to-event time is
+    # not a kernel's own.  Averaged over the NQ queries and their lists.)
     excl_ns = []
     ctx.set_option(kvmatch.OPT_TIMING, 1)
-    for i, (v, _, pos, _) in enumerate(plans):
-        for rep in range(12):
-            engines[i].verify((my_l, my_r), 1, q, a.epsilon, *pos)
+    for i, (v, _, pos_, _) in enumerate(plans):
+        for rep in range(2 + max(10, NQ)):
+            j = rep % NQ
+            engines[i].verify(shards[j % NL], 1, queries[j], a.epsilon, *pos_)
             if rep >= 2:
                 excl_ns.append((i, int(lib.kvm_last_kernel_ns(h))))
     ctx.set_option(kvmatch.OPT_TIMING, 0)
@@ -333,10 +435,26 @@ def main():
     step_no[0] = 0
     n_ab = max(2, a.steps // 4)
     dt_ab = timed_steps(step, n_ab, 1, world)
-    value_ab = total_cands * n_ab * qps / dt_ab
-    ab_match = bool(np.array_equal(head_offs, last["offs"])) if (len(plans) == 1 or qps % len(plans) == 0) else None
+    value_ab = sum_cands(n_ab * qps) / dt_ab
+    ab = {(i, j): (o, d) for i, j, o, d in last["res"]}
+    ab_match = bool(all(k in ab and np.array_equal(ab[k][0], head[k][0]) and np.array_equal(ab[k][1], head[k][1]) for k in head))
 
-    out = {
+    # ---- --scaling both: the strong-scaling run of the same launch (the --candidates list split over the ranks) ----------
+    strong = None
+    if len(scalings) == 2:
+        set_option(kvmatch.OPT_EARLY_ABANDON, 0)
+        weak_state = (full_lists, shards, my_cands_l)
+        full_lists, shards = make_lists(a.candidates)
+        my_cands_l = [int((r.astype(np.int64) - l + 1).sum()) for l, r in shards]
+        step_no[0] = 0
+        dt_s = timed_steps(step, a.steps, a.warmup, world)
+        strong = {"value": sum_cands(a.steps * qps) / dt_s, "ms_per_step": dt_s / a.steps * 1e3,
+                  "ms_per_query": dt_s / (a.steps * qps) * 1e3, "candidates_per_query_per_gpu": my_cands_l[0],
+                  "note": "the same launch, --candidates in total split over the ranks (early abandon off)"}
+        full_lists, shards, my_cands_l = weak_state
+        set_option(kvmatch.OPT_EARLY_ABANDON, 1)
+
+    out.update({
         "metric": {"rsm_ed": "candidate subsequences verified/sec (RSM-ED, n=1e8, m=8192)",
                    "cnsm_ed": "candidate subsequences verified/sec (cNSM-ED, n=1e8, m=8192)",
                    "cnsm_dtw": "candidate subsequences verified/sec (cNSM-DTW, n=1e8, m=4096, rho=5%)",
@@ -351,33 +469,56 @@ def main():
         "ms_per_step": dt / a.steps * 1e3,
         "ms_per_query": dt / (a.steps * qps) * 1e3,
         "higher_is_better": True,
-        "scaling": a.scaling,
+        "scaling": scalings[0],
+        **({"strong": strong} if strong else {}),
         "vs_baseline": None,
         "dtype": "f64",
-        "data": "synthetic (seeded restatement of K/DataGenerator.java; query + 3 noisy copies planted)",
+        "data": f"synthetic (seeded restatement of K/DataGenerator.java; {NQ} queries at seeded offsets, 2 noisy copies of each planted)",
         "config": {"workload": {"rsm_ed": "RSM-ED phase 2 (BASELINE configs[1])",
                                 "cnsm_ed": "cNSM-ED phase 2, alpha=2 beta=10 (BASELINE configs[2])",
                                 "cnsm_dtw": "cNSM-DTW phase 2, rho=5%, alpha=2 beta=10 (BASELINE configs[3])",
                                 "mixed": "mixed ED+DTW query stream (BASELINE configs[4] style)"}[wl], "n": n, "m": m,
-                   "queries_per_step": qps, "queries_in_flight": F, "candidates_per_query_per_gpu": my_cands,
-                   "candidates_per_gpu": my_cands, "intervals_per_gpu": int(len(my_l)), "epsilon": a.epsilon,
+                   "queries_per_step": qps, "queries_in_flight": F, "distinct_queries": NQ, "distinct_interval_lists": NL,
+                   "candidates_per_query_per_gpu": my_cands,
+                   "candidates_per_gpu": my_cands, "intervals_per_gpu": int(len(shards[0][0])), "epsilon": a.epsilon,
                    "early_abandon": False, "parallelism": f"candidate shards x{world}, series replicated",
-                   "answers": int(len(head_offs)), "ed_kernel": a.ed_kernel},
+                   "answers": int(sum(len(o) for (i, j), (o, d) in head.items() if i == 0) / max(1, sum(1 for (i, j) in head if i == 0))),
+                   "answers_per_query": [int(len(head[k][0])) for k in sorted(head)][:NQ], "ed_kernel": a.ed_kernel},
         "value_early_abandon": value_ab,
         "early_abandon_same_answers": ab_match,
         "setup_s": setup_s,
-    }
+    })
     out["roofline"] = roofline_block(wl, plans, excl_ns, stage_stats, m)
     out["roofline"]["kernel_ms_note"] = ("HIP events around the kernel on its own stream, measured in this run right after the "
-                                         "timed region with ONE query in flight: the kernel's own duration (what rocprofv3 "
+                                         f"timed region with ONE query in flight, averaged over the {NQ} queries and their "
+                                         "lists: the kernel's own duration (what rocprofv3 "
                                          f"--kernel-trace shows per launch).  In the timed region the kernels of {F} contexts "
                                          "overlap, so an event-to-event time there is not a kernel's own; the events are off "
                                          "there (they cost ~0.1 ms of stream time per query)")
+
+    # ---- parity of the timed workload against the oracle (rank 0, N = 1): EVERY query of the stream ----------------------
+    parity = {}
+    if rank == 0 and world == 1 and oracle is not None and a.cpu_baseline:
+        def same_answers(got_off, got_dist, o_off, o_dist):
+            if sorted(o_off.tolist()) != sorted(got_off.tolist()):
+                return False
+            od = dict(zip(o_off.tolist(), o_dist.tolist()))
+            return all(abs(d - od[o]) <= max(1e-6 * max(d, od[o]), 1e-9) for o, d in zip(got_off.tolist(), got_dist.tolist()))
+        if wl in ("rsm_ed", "cnsm_ed"):
+            ok = True
+            for (i, j), (g_off, g_dist) in head.items():
+                l_, r_ = shards[j % NL]
+                o = (oracle.rsm_ed(series, queries[j], l_, r_, 0, a.epsilon) if wl == "rsm_ed"
+                     else oracle.cnsm_ed(series, queries[j], l_, r_, 0, a.epsilon, 2.0, 10.0))
+                ok = ok and same_answers(g_off, g_dist, o[0], o[1])
+            parity[wl] = bool(ok and len(head) == NQ)
 
     # ---- extras (N=1): the other variants on the same staged series ---------------------------------------
     if rank == 0 and world == 1 and a.extras and wl == "rsm_ed":
         ex = {}
         try:
+            q, my_l, my_r = queries[0], shards[0][0], shards[0][1]
+            qoff = qoffs[0]
             ctx.set_option(kvmatch.OPT_EARLY_ABANDON, 0)
             neng = kvmatch.NormQueryEngine(ctx)
             f = lambda: neng.verify((my_l, my_r), 1, q, a.epsilon, 2.0, 1e9)  # noqa: E731 (filter passes all)
@@ -388,6 +529,18 @@ def main():
             ex["cnsm_ed_no_abandon_candidates_per_s"] = my_cands * 5 / (time.perf_counter() - t1)
             ex["cnsm_ed_pass_filter"] = r_.stats[kvmatch.STAT_PASS_FILTER]
             ctx.set_option(kvmatch.OPT_EARLY_ABANDON, 1)
+            # cNSM-ED, BASELINE configs[2] (alpha = 2, beta = 10), the NQ queries over their lists, reference's early abandoning
+            ce = [neng.verify(shards[j % NL], 1, queries[j], a.epsilon, 2.0, 10.0) for j in range(NQ)]
+            t1 = time.perf_counter()
+            for j in range(NQ):
+                neng.verify(shards[j % NL], 1, queries[j], a.epsilon, 2.0, 10.0)
+            ex["cnsm_ed_candidates_per_s_one_in_flight"] = sum(my_cands_l[j % NL] for j in range(NQ)) / (time.perf_counter() - t1)
+            if oracle is not None and a.cpu_baseline:
+                ok = True
+                for j in range(NQ):
+                    o = oracle.cnsm_ed(series, queries[j], shards[j % NL][0], shards[j % NL][1], 0, a.epsilon, 2.0, 10.0)
+                    ok = ok and np.array_equal(ce[j].offsets, o[0]) and np.array_equal(ce[j].distances, o[1])
+                parity["cnsm_ed"] = bool(ok)
             # cNSM-DTW, BASELINE configs[3]: m=4096, rho=5%
             m2 = 4096
             q2 = series[qoff - 1: qoff - 1 + m2].copy()
@@ -395,13 +548,50 @@ def main():
             deng = kvmatch.NormQueryEngineDtw(ctx)
             g = lambda: deng.verify((l2, r2), 1, q2, 10.0, 0.05, 2.0, 10.0)  # noqa: E731
             g()
+            ctx.set_option(kvmatch.OPT_TIMING, 1)
             t1 = time.perf_counter()
             reps = 3
+            dp_ns = []
             for _ in range(reps):
                 r_ = g()
+                dp_ns.append(int(lib.kvm_last_kernel_ns(h)))
+            ctx.set_option(kvmatch.OPT_TIMING, 0)
             ex["cnsm_dtw_m4096_candidates_per_s"] = r_.cnt_candidate * reps / (time.perf_counter() - t1)
             ex["cnsm_dtw_stats"] = {"windows": r_.stats[0], "pass_filter": r_.stats[1], "pass_kim": r_.stats[2],
                                     "pass_keogh": r_.stats[3], "dp": r_.stats[4], "answers": len(r_)}
+            # roofline of the DTW workload's dominant kernel, the banded DP (K/utils/DtwUtils.java:269-337): 5 non-fusable fp64
+            # operations per cell against the vector pipe's issue rate without FMA; cells of a FULL DP per candidate that
+            # reaches it (an upper bound of the executed cells: the reference's early abandoning is on in this workload)
+            rho2 = int(lib.kvm_resolve_rho(0.05, m2))
+            cells2 = m2 * (2 * rho2 + 1) - rho2 * (rho2 + 1)
+            ks2 = float(np.mean(dp_ns)) * 1e-9
+            if ks2 > 0:
+                ach2 = r_.stats[4] * cells2 * 5.0 / ks2 / 1e12
+                out["roofline_dtw"] = {"bound": "fp64_valu", "achieved": ach2, "peak": FP64_VALU_PEAK_TOPS_NOFMA, "unit": "TFLOP/s",
+                                       "frac": ach2 / FP64_VALU_PEAK_TOPS_NOFMA, "traffic": None,
+                                       "kernel": "kvm_dtw_dp_reg_kernel<4,0> (banded DP with the reference's row test)",
+                                       "kernel_ms": ks2 * 1e3, "dp_candidates_per_launch": r_.stats[4], "cells_per_candidate": cells2,
+                                       "cells_per_s": r_.stats[4] * cells2 / ks2,
+                                       "workload": "cNSM-DTW m=4096 rho=204, 1e6 candidates, eps=10 alpha=2 beta=10 (BASELINE configs[3])",
+                                       "note": "achieved counts the cells of a full DP for every candidate that reaches the DP kernel; "
+                                               "with the reference's early abandoning (on here) rejected candidates stop earlier, so "
+                                               "the executed cells are fewer and `achieved` is an upper bound of the executed rate; "
+                                               "peak = vector fp64 issue rate without FMA (78.6 / 2)"}
+            if oracle is not None and a.cpu_baseline:
+                # the oracle's cNSM-DTW on all host cores (a child process; whole intervals dealt round-robin to the workers)
+                try:
+                    tmp = os.path.join(ROOT, "gpurun_out") if os.path.isdir(os.path.join(ROOT, "gpurun_out")) else "/tmp"
+                    fin, fout = os.path.join(tmp, "_bench_dtw_in.npz"), os.path.join(tmp, "_bench_dtw_out.npz")
+                    np.savez(fin, q=q2, left=l2, right=r2)
+                    cp = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline.py"), "cnsm_dtw_answers", str(n),
+                                         "10.0", str(min(os.cpu_count() or 1, 64)), fin, fout, str(rho2), "2.0", "10.0"],
+                                        capture_output=True, text=True, timeout=600)
+                    z = np.load(fout)
+                    parity["cnsm_dtw"] = bool(np.array_equal(z["off"], r_.offsets) and np.array_equal(z["dist"], r_.distances))
+                    ex["cnsm_dtw_oracle_seconds_all_cores"] = float(z["seconds"])
+                except Exception as e:
+                    parity["cnsm_dtw"] = None
+                    ex["cnsm_dtw_parity_error"] = repr(e)
             # DP kernel alone: cascade off on a small slice => every filter-passing window runs the full DP
             ctx.set_option(kvmatch.OPT_LB_CASCADE, 0)
             ctx.set_option(kvmatch.OPT_EARLY_ABANDON, 0)
@@ -413,12 +603,16 @@ def main():
             t1 = time.perf_counter()
             r_ = g3()
             dtp = time.perf_counter() - t1
-            rho = 204
-            cells = m2 * (2 * rho + 1) - rho * (rho + 1)
             ex["dtw_dp_full_candidates_per_s"] = r_.stats[0] / dtp
-            ex["dtw_dp_cells_per_s"] = r_.stats[0] * cells / dtp
+            ex["dtw_dp_cells_per_s"] = r_.stats[0] * cells2 / dtp
             ex["dtw_dp_kernel_ms"] = lib.kvm_last_kernel_ns(h) * 1e-6
-            ex["dtw_dp_kernel_cells_per_s"] = r_.stats[0] * cells / (lib.kvm_last_kernel_ns(h) * 1e-9) if lib.kvm_last_kernel_ns(h) else None
+            kns = lib.kvm_last_kernel_ns(h)
+            ex["dtw_dp_kernel_cells_per_s"] = r_.stats[0] * cells2 / (kns * 1e-9) if kns else None
+            if kns:
+                out.setdefault("roofline_dtw", {})["full_dp"] = {
+                    "achieved": r_.stats[0] * cells2 * 5.0 / (kns * 1e-9) / 1e12, "frac": r_.stats[0] * cells2 * 5.0 / (kns * 1e-9) / 1e12 / FP64_VALU_PEAK_TOPS_NOFMA,
+                    "kernel_ms": kns * 1e-6, "dp_candidates_per_launch": r_.stats[0],
+                    "note": "cascade and early abandoning off on a slice of the list: every candidate runs ALL its cells (executed = algorithmic)"}
             ctx.set_option(kvmatch.OPT_TIMING, 0)
             ctx.set_option(kvmatch.OPT_LB_CASCADE, 1)
             ctx.set_option(kvmatch.OPT_EARLY_ABANDON, 1)
@@ -454,48 +648,8 @@ def main():
         except Exception as e:  # extras must never take the headline down
             ex["error"] = repr(e)
         out["extras"] = ex
-
-    # ---- CPU baseline: the oracle (a C port of the reference loops), rank 0, N=1 only --------------------
-    # (after the extras: its all-cores leg leaves the host busy for a while, which the sync-heavy DTW cascade feels)
-    if rank == 0 and world == 1 and a.cpu_baseline and wl == "rsm_ed":
-        sys.path.insert(0, os.path.join(ROOT, "oracle"))
-        import oracle  # test infrastructure: used here only as the timed CPU baseline / checker
-        t1 = time.perf_counter()
-        o_off, o_dist, o_st = oracle.rsm_ed(series, q, my_l, my_r, 0, a.epsilon, no_abandon=True)
-        cpu_s = time.perf_counter() - t1
-        t1 = time.perf_counter()
-        oracle.rsm_ed(series, q, my_l, my_r, 0, a.epsilon, no_abandon=False)
-        cpu_ab_s = time.perf_counter() - t1
-        # the reference's own Java loop could only be timed with a JDK on this box (and the Maven artefacts its sources
-        # import): probe instead of assuming
-        java, javac = shutil.which("java"), shutil.which("javac")
-        out["cpu_baseline"] = {
-            "value": o_st["windows"] / cpu_s, "unit": "candidates/s", "cores": 1, "kind": "port",
-            "jdk_probe": {"java": java, "javac": javac},
-            "sample": f"all {o_st['windows']} candidates of one query of the N=1 workload, early abandon off (same work "
-                      f"per query as `value`), single thread; C restatement of K/QueryEngine.java:338-363 "
-                      f"({'a JDK is present but the reference needs un-vendored Maven artefacts' if java else 'no JDK on this box: java/javac not on PATH'}; "
-                      f"the port avoids Java boxing, so it flatters the CPU side)",
-            "value_early_abandon": o_st["windows"] / cpu_ab_s,
-            "seconds": cpu_s,
-        }
-        # the same loop on all host cores: a child process (no GPU context there) forks one worker per core
-        try:
-            ncores = min(os.cpu_count() or 1, 64)
-            cp = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline.py"), str(n), str(m),
-                                 str(a.candidates), str(a.epsilon), str(ncores)], capture_output=True, text=True,
-                                timeout=300)
-            allc = json.loads(cp.stdout.strip().splitlines()[-1])
-            out["cpu_baseline"]["all_cores"] = {"cores": allc["cores"], "value": allc["no_abandon"]["candidates_per_s"],
-                                                "value_early_abandon": allc["early_abandon"]["candidates_per_s"],
-                                                "note": "same port, interval shards over forked worker processes"}
-        except Exception as e:
-            out["cpu_baseline"]["all_cores"] = {"error": repr(e)}
-        same = sorted(o_off.tolist()) == sorted(head_offs.tolist())
-        od = dict(zip(o_off.tolist(), o_dist.tolist()))
-        close = same and all(abs(d - od[o]) <= max(1e-6 * max(d, od[o]), 1e-9)
-                             for o, d in zip(head_offs.tolist(), head_dists.tolist()))
-        out["parity_vs_oracle"] = bool(same and close)
+    if parity:
+        out["parity_vs_oracle"] = parity
 
     (sstream if use_dist else qstream).close()
     ctx.close()

@@ -608,8 +608,12 @@ static void plan_totals_generic(const int32_t *left, const int32_t *right, int32
 
 // Window start offsets of interval [left,right]: max(1,left-shift) .. min(right-shift, n-m+1)
 // (K/QueryEngine.java:346-354: begin/end clipping, loop `i + length - 1 < data.size()`).
+// `rho_strict` >= 0 (DTW engines with KVM_OPT_STRICT_BOUNDS): a fetched range of <= rho_strict points ends the reference in
+// ArrayIndexOutOfBoundsException (lowerUpperLemire over the fetched data, K/QueryEngineDtw.java:399,
+// K/NormQueryEngineDtw.java:524 -> K/utils/DtwUtils.java:81-90) -- right after the readTimeSeries that could have thrown
+// IllegalArgumentException for the same range, interval by interval (chunk by chunk) in list order.
 static int build_plan(kvm_ctx *ctx, bool cnsm, int32_t m, const int32_t *left, const int32_t *right, int32_t k,
-                      int32_t shift, int32_t tile_max, bool hybrid, plan &pl) {
+                      int32_t shift, int32_t tile_max, bool hybrid, plan &pl, int32_t rho_strict = -1) {
     const int64_t n = ctx->n;
     // The engines hand phase 2 the list sortAndMergeIntervals leaves (K/QueryEngine.java:664-693): sorted by `left`.
     // Lists with overlapping, adjacent, nested, repeated or empty intervals go through like in the Java loops (every
@@ -619,6 +623,7 @@ static int build_plan(kvm_ctx *ctx, bool cnsm, int32_t m, const int32_t *left, c
     // engines merge consecutive intervals into one fetched chunk and index it with `left - begin`: out of order that is an
     // IndexOutOfBoundsException or the range check of readTimeSeries in Java, depending on the list; refused here.
     std::vector<int32_t> sorted_l, sorted_r, clipped_r;
+    const int32_t *const left_given = left, *const right_given = right;  // (which interval throws first: the list as given)
     {
         bool ascending = true;
         for (int32_t p = 1; p < k; p++) ascending &= left[p] >= left[p - 1];
@@ -671,6 +676,11 @@ static int build_plan(kvm_ctx *ctx, bool cnsm, int32_t m, const int32_t *left, c
                 snprintf(msg, sizeof msg, "left: %lld, length: %lld", (long long)begin, (long long)(end - begin + 1));
                 return fail(ctx, KVM_ERR_ILLEGAL_ARGUMENT, msg);
             }
+            if (rho_strict >= 0 && end - begin + 1 <= rho_strict) {
+                char msg[32];
+                snprintf(msg, sizeof msg, "%lld", (long long)(end - begin + 1 - rho_strict - 1));  // (JDK 8 words it as the index)
+                return fail(ctx, KVM_ERR_INDEX_OUT_OF_BOUNDS, msg);
+            }
             if (pl.chunk_lo)  // the data envelope of the DTW cascade is built per fetched chunk (K/NormQueryEngineDtw.java:522-524)
                 for (int32_t p = beginIdx; p <= endIdx; p++) {
                     pl.chunk_lo[p] = (int32_t)begin;
@@ -707,15 +717,21 @@ static int build_plan(kvm_ctx *ctx, bool cnsm, int32_t m, const int32_t *left, c
     const int64_t cnt_candidate = clipped_r.empty() ? tot.cnt_candidate : cnt_given, n_tiles = tot.n_tiles, n_tiles_b = tot.n_tiles_b, n_tiles_c = tot.n_tiles_c, windows = tot.windows,
                   nr = tot.nr;
     const bool bad_rsm = tot.bad_rsm != 0;
-    if (bad_rsm && !cnsm) {
+    // (a stub of <= rho < m points holds no window: windows < list length is the cheap sign that one may exist)
+    if ((bad_rsm || (rho_strict >= 0 && nr < k)) && !cnsm) {
         for (int32_t p = 0; p < k; p++) {
-            int64_t begin = (int64_t)left[p] - shift, end = (int64_t)right[p] - shift + m - 1;
+            int64_t begin = (int64_t)left_given[p] - shift, end = (int64_t)right_given[p] - shift + m - 1;
             if (begin < 1) begin = 1;
             if (end > n) end = n;
             if (end - begin + 1 < 1) {
                 char msg[96];
                 snprintf(msg, sizeof msg, "left: %lld, length: %lld", (long long)begin, (long long)(end - begin + 1));
                 return fail(ctx, KVM_ERR_ILLEGAL_ARGUMENT, msg);
+            }
+            if (rho_strict >= 0 && end - begin + 1 <= rho_strict) {
+                char msg[32];
+                snprintf(msg, sizeof msg, "%lld", (long long)(end - begin + 1 - rho_strict - 1));
+                return fail(ctx, KVM_ERR_INDEX_OUT_OF_BOUNDS, msg);
             }
         }
     }
@@ -850,6 +866,14 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
         qd.stdQ = std::sqrt(ex2 / m - qd.meanQ * qd.meanQ);
         for (int i = 0; i < m; i++) q[i] = (query[i] - qd.meanQ) / qd.stdQ;
     }
+    // DtwUtils.lowerUpperLemire(Q, length, rho, l, u) (K/QueryEngineDtw.java:362, K/NormQueryEngineDtw.java:469) stores
+    // `u[i - r - 1]` from i = len on (K/utils/DtwUtils.java:81-90): with rho >= m that is ArrayIndexOutOfBoundsException
+    // before anything has been read -- and before the sort below.  KVM_OPT_STRICT_BOUNDS = 0 computes the natural extension.
+    if (dtw && ctx->opt_strict_bounds && m <= rho) {
+        char msg[32];
+        snprintf(msg, sizeof msg, "%d", (int)(m - rho - 1));
+        return fail(ctx, KVM_ERR_INDEX_OUT_OF_BOUNDS, msg);
+    }
     if (dtw) query_envelope(q, rho, qu, ql);
     // The reference's summation order of the LB_Keogh loops.  RSM-DTW: the reorder is commented out, order = identity
     // (K/QueryEngineDtw.java:364-383).  cNSM-DTW: Arrays.sort with the comparator (int)(|o2| - |o1|)
@@ -917,7 +941,7 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
         pl.chunk_lo = (int32_t *)(hp + qbytes + 2 * lr_half);
         pl.chunk_hi = (int32_t *)(hp + qbytes + 3 * lr_half);
     }
-    rc = build_plan(ctx, cnsm, m, left, right, k, shift, tile_max, hybrid, pl);
+    rc = build_plan(ctx, cnsm, m, left, right, k, shift, tile_max, hybrid, pl, (dtw && ctx->opt_strict_bounds) ? rho : -1);
     if (rc) return rc;
     // Class-C tiles (two <= 16-candidate remainders per row, kvm_ed_dot.hip) fill the lanes better but a class-C unit
     // lasts 1.3 x as long as a class-B unit: always worth it when the list needs more than one round of the chip's wave

@@ -19,6 +19,8 @@ namespace kvmatch {
 struct IllegalArgumentException : std::invalid_argument { using std::invalid_argument::invalid_argument; };
 // java.io.IOException (what query() declares, K/QueryEngine.java:155); device failures map here too
 struct IOException : std::runtime_error { using std::runtime_error::runtime_error; };
+// java.lang.ArrayIndexOutOfBoundsException: where DtwUtils.lowerUpperLemire indexes below its arrays (K/utils/DtwUtils.java:81-90)
+struct ArrayIndexOutOfBoundsException : std::out_of_range { using std::out_of_range::out_of_range; };
 
 struct Interval { int32_t left, right; };              // K/common/Interval.java:23-35 (epsilon is not read by phase 2)
 using Answer = std::pair<int32_t, double>;             // Pair<Integer, Double>, K/QueryEngine.java:341
@@ -101,6 +103,7 @@ public:
         if (rc == KVM_OK) return;
         std::string msg = kvm_last_error(ctx);
         if (rc == KVM_ERR_ILLEGAL_ARGUMENT) throw IllegalArgumentException(msg);
+        if (rc == KVM_ERR_INDEX_OUT_OF_BOUNDS) throw ArrayIndexOutOfBoundsException(msg);  // (KVM_OPT_STRICT_BOUNDS)
         throw IOException("[" + std::to_string(rc) + "] " + msg);
     }
 
@@ -207,6 +210,13 @@ private:
 // Index-free full scans (experiments/ucr/UcrEdQueryExecutor.java, UcrDtwQueryExecutor.java): the same phase-2 path on a
 // candidate list that covers the series; see kvmatch/ucr.py for how the cut of the list reproduces each executor.
 namespace detail {
+// KVM_OPT_UCR_LOOPS for the duration of one executor run (the engines on the same context keep the engines' loops)
+struct UcrLoops {
+    explicit UcrLoops(Phase2Context &c) : c_(c), old_(kvm_get_option(c.handle(), KVM_OPT_UCR_LOOPS)) { c_.setOption(KVM_OPT_UCR_LOOPS, 1); }
+    ~UcrLoops() { kvm_set_option(c_.handle(), KVM_OPT_UCR_LOOPS, old_); }
+    Phase2Context &c_;
+    int64_t old_;
+};
 inline void segments(int64_t first, int64_t last, int64_t length, std::vector<int32_t> &l, std::vector<int32_t> &r) {
     for (int64_t f = first; f <= last; f += length) {
         l.push_back((int32_t)f);
@@ -227,20 +237,15 @@ public:
         if (M < 1 || N_ < M || N_ > kvm_series_length(c_.handle())) throw IllegalArgumentException("N outside [M, series length]");
         std::vector<int32_t> l, r;
         detail::segments(1, last, segment_ > 0 ? segment_ : last, l, r);
-        // distance() of the executor abandons on `sum < bsf` (U/UcrEdQueryExecutor.java:93): with Epsilon^2 == 0 it never
-        // adds a term and every window that passes the (Alpha, Beta) test is reported at distance 0 (kvmatch/ucr.py)
-        // (NOT reproduced: a partial sum that lands exactly on Epsilon^2 before the last term, which the executor reports
-        // at distance Epsilon -- a known difference of the executor mirrors)
-        const bool zero = eps_ * eps_ == 0.0;
+        // distance() of the executor abandons on `sum < bsf` (U/UcrEdQueryExecutor.java:93) where the engines' loops run on
+        // `dist <= bsf`: a partial sum exactly on Epsilon^2 is an answer at distance Epsilon, and with Epsilon^2 == 0 every window
+        // that passes the (Alpha, Beta) test is one at distance 0 -- reproduced by the library behind KVM_OPT_UCR_LOOPS
+        detail::UcrLoops guard(c_);
         kvm_result *res = nullptr;
-        Phase2Context::check(kvm_verify_cnsm_ed(c_.handle(), q_.data(), (int32_t)M, l.data(), r.data(), (int32_t)l.size(), 0,
-                                                zero ? std::numeric_limits<double>::infinity() : eps_, alpha_, beta_, &res),
+        Phase2Context::check(kvm_verify_cnsm_ed(c_.handle(), q_.data(), (int32_t)M, l.data(), r.data(), (int32_t)l.size(), 0, eps_,
+                                                alpha_, beta_, &res),
                              c_.handle());
         Answers a = detail::collect(res);
-        if (zero) {
-            std::sort(a.answers.begin(), a.answers.end(), [](const Answer &x, const Answer &y) { return x.first < y.first; });
-            for (auto &p : a.answers) p.second = 0.0;
-        }
         return a;
     }
 private:
@@ -253,8 +258,8 @@ private:
 
 // run(): answers sorted by distance, 0-BASED offsets as the reference reports them (UcrDtwQueryExecutor.java:283);
 // EPOCH = 100000 buffers (:97) == intervals of EPOCH - M + 1 offsets.  Rho is the band half-width in points.
-// Known difference: the executor never clears cb1 / cb2 between windows (:157-161); at an exact LB_Keogh tie it
-// can reject a window that the engines -- and this mirror -- report at distance Epsilon.
+// The executor never clears cb1 / cb2 between windows (:157-161): at an exact LB_Keogh tie its DP reads what earlier windows
+// left there and can reject a window the engines report at distance Epsilon -- reproduced behind KVM_OPT_UCR_LOOPS.
 class UcrDtwQueryExecutor {
 public:
     static constexpr int64_t EPOCH = 100000;
@@ -267,6 +272,7 @@ public:
             throw IllegalArgumentException("N outside [M, series length] or M > EPOCH");
         std::vector<int32_t> l, r;
         detail::segments(1, N_ - M + 1, EPOCH - M + 1, l, r);
+        detail::UcrLoops guard(c_);
         kvm_result *res = nullptr;
         Phase2Context::check(kvm_verify_cnsm_dtw(c_.handle(), q_.data(), (int32_t)M, l.data(), r.data(), (int32_t)l.size(), 0,
                                                  eps_, rho_, alpha_, beta_, &res), c_.handle());

@@ -20,10 +20,13 @@
 
 static void throw_for(JNIEnv *env, kvm_ctx *ctx, int rc) {
     const char *msg = kvm_last_error(ctx);
-    /* range/parameter errors -> IllegalArgumentException (K/operator/file/TimeSeriesFileOperator.java:55-57);
-     * everything else -> IOException (what query() declares, K/QueryEngine.java:155) */
-    jclass cls = (*env)->FindClass(env, rc == KVM_ERR_ILLEGAL_ARGUMENT ? "java/lang/IllegalArgumentException"
-                                                                     : "java/io/IOException");
+    /* range/parameter errors -> IllegalArgumentException (K/operator/file/TimeSeriesFileOperator.java:55-57); where the
+     * reference's DtwUtils.lowerUpperLemire indexes below its arrays (K/utils/DtwUtils.java:81-90; KVM_OPT_STRICT_BOUNDS) ->
+     * ArrayIndexOutOfBoundsException with the index as its message, as JDK 8 words it; everything else -> IOException
+     * (what query() declares, K/QueryEngine.java:155) */
+    jclass cls = (*env)->FindClass(env, rc == KVM_ERR_ILLEGAL_ARGUMENT      ? "java/lang/IllegalArgumentException"
+                                        : rc == KVM_ERR_INDEX_OUT_OF_BOUNDS ? "java/lang/ArrayIndexOutOfBoundsException"
+                                                                            : "java/io/IOException");
     (*env)->ThrowNew(env, cls, msg ? msg : "kvmatch error");
 }
 

@@ -122,6 +122,11 @@ def sharded_verify(engine, valid_positions, last_segment, query_data, *params, g
     return offs, dists, int(cnt.item())
 
 
+class ShardFailed(RuntimeError):
+    """Another rank raised while verifying its shard of a query (every rank learns it from the exchange and raises: nobody is
+    left waiting in a collective)."""
+
+
 class ShardedVerifier:
     """Device-resident sharded verification: kernels write survivors straight into torch tensors on this rank's GPU
     (kvm_verify_device, launched on torch's current stream), the survivors are packed on the device and exchanged
@@ -178,7 +183,17 @@ class ShardedVerifier:
     def verify(self, valid_positions, last_segment, query_data, epsilon, rho=0, alpha=1.0, beta=0.0, resolved=None):
         import torch
         import torch.distributed as dist
-        self.launch(valid_positions, last_segment, query_data, epsilon, rho, alpha, beta, resolved)
+        # A shard-dependent error (a range error of THIS rank's intervals, an unsorted shard, out of memory) must not leave the
+        # other ranks waiting in the all-gather: the failing rank still takes part, with a count of -1 in its block, and
+        # every rank raises once the exchange is through.
+        local_err = None
+        try:
+            self.launch(valid_positions, last_segment, query_data, epsilon, rho, alpha, beta, resolved)
+        except Exception as e:  # noqa: BLE001
+            if self.world == 1:
+                raise
+            local_err = e
+            self.packed[0, 0] = -1.0
         k = self.pack_cap
         if self.world > 1:
             dist.all_gather_into_tensor(self.gathered, self.packed, group=self.group)
@@ -188,6 +203,10 @@ class ShardedVerifier:
         torch.cuda.current_stream(self.dev).synchronize()
         host = self.host.numpy().reshape(self.world, k + 1, 2)
         counts = host[:, 0, 0].astype(np.int64)
+        if local_err is not None:
+            raise local_err
+        if counts.min() < 0:
+            raise ShardFailed(f"rank(s) {np.nonzero(counts < 0)[0].tolist()} failed on their shard of this query")
         if counts.max() <= k:
             offs = np.concatenate([host[w, 1:1 + counts[w], 0] for w in range(self.world)]).astype(np.int32)
             dists = np.concatenate([host[w, 1:1 + counts[w], 1] for w in range(self.world)])
@@ -227,7 +246,7 @@ class ShardedStream:
             if i:
                 from . import _lib
                 for opt in (_lib.OPT_EARLY_ABANDON, _lib.OPT_LB_CASCADE, _lib.OPT_ED_KERNEL, _lib.OPT_TIMING, _lib.OPT_DP_KERNEL,
-                            _lib.OPT_SORT_VIOLATION):
+                            _lib.OPT_SORT_VIOLATION, _lib.OPT_UCR_LOOPS, _lib.OPT_STRICT_BOUNDS):
                     c.set_option(opt, ctx.get_option(opt))
             v = ShardedVerifier(c, variant, max_candidates, group=group, pack_cap=pack_cap)
             self.slots.append(dict(ctx=c, v=v, stream=torch.cuda.Stream(device=self.dev), ready=torch.cuda.Event()))
@@ -254,22 +273,35 @@ class ShardedStream:
         consumed = [threading.Event() for _ in range(nq)]
         err = []
         cnts = [0] * nq
+        stop = threading.Event()   # set by the calling thread once the stream has ended (early) on every rank
 
         def slot_thread(si):
             s = self.slots[si]
             try:
+                failed = False
                 for qi in range(si, nq, ns):
                     if qi - ns >= 0:
                         consumed[qi - ns].wait()      # the slot's buffers are free again
-                    if err:
+                    if stop.is_set():
                         return
                     with torch.cuda.stream(s["stream"]):
-                        s["v"].launch(**queries[qi])  # verify + pack on the slot's stream, no synchronisation
+                        if not failed:
+                            try:
+                                s["v"].launch(**queries[qi])  # verify + pack on the slot's stream, no synchronisation
+                            except Exception as e:  # noqa: BLE001
+                                # a shard-dependent error: the other ranks are (or will be) in this query's all-gather -- take
+                                # part in it with a count of -1, so that every rank ends the stream at this query and raises
+                                if self.world == 1:
+                                    raise
+                                err.append((qi, e))
+                                failed = True
+                        if failed:
+                            s["v"].packed[0, 0] = -1.0
                         s["ready"].record(s["stream"])
                     cnts[qi] = s["v"].cnt_candidate
                     produced[qi].set()
             except BaseException as e:  # noqa: BLE001
-                err.append(e)
+                err.append((-1, e))
                 for ev in produced:
                     ev.set()
 
@@ -281,7 +313,7 @@ class ShardedStream:
         try:
             for qi in range(nq):
                 produced[qi].wait()
-                if err:
+                if err and (self.world == 1 or any(q < 0 for q, _ in err)):
                     break
                 si = qi % ns
                 s = self.slots[si]
@@ -295,6 +327,11 @@ class ShardedStream:
                     self.comm_stream.synchronize()
                     host = self.host[si].numpy().reshape(self.world, k + 1, 2)
                     counts = host[:, 0, 0].astype(np.int64)
+                    if counts.min() < 0:   # some rank failed on its shard of this query: every rank sees it here and stops
+                        if not any(q == qi for q, _ in err):
+                            err.append((qi, ShardFailed(f"rank(s) {np.nonzero(counts < 0)[0].tolist()} failed on their shard of "
+                                                        f"query {qi}")))
+                        break
                     if counts.max() <= k:
                         offs = np.concatenate([host[w, 1:1 + counts[w], 0] for w in range(self.world)]).astype(np.int32)
                         dists = np.concatenate([host[w, 1:1 + counts[w], 1] for w in range(self.world)])
@@ -306,12 +343,13 @@ class ShardedStream:
                                    else sort_answers(vo.cpu().numpy(), vd.cpu().numpy()))
                 consumed[qi].set()
         finally:
+            stop.set()
             for ev in consumed:
                 ev.set()
             for t in threads:
                 t.join()
         if err:
-            raise err[0]
+            raise sorted(err, key=lambda qe: (qe[0] < 0, qe[0]))[0][1]   # the earliest query's error (this rank's own if it has one)
         self.cnt_candidate = cnts
         return out
 

@@ -32,6 +32,8 @@
 #define KVO_ERR_ILLEGAL_ARGUMENT (-2) /* IllegalArgumentException, K/operator/file/TimeSeriesFileOperator.java:55-57 */
 #define KVO_ERR_IO (-3)               /* IOException */
 #define KVO_ERR_CAPACITY (-4)         /* caller's answer buffer too small (no reference counterpart) */
+#define KVO_ERR_INDEX_OUT_OF_BOUNDS (-8) /* ArrayIndexOutOfBoundsException: DtwUtils.lowerUpperLemire with len <= r,
+                                            K/utils/DtwUtils.java:81-90 (kvo_set_strict_bounds) */
 
 #define KVO_MAX_SCAN_DATA_LENGTH 40000 /* K/NormQueryEngine.java:60, K/NormQueryEngineDtw.java:61 */
 #define KVO_ROW_LENGTH 1000            /* K/common/entity/TimeSeriesNode.java:30 */
@@ -236,7 +238,20 @@ static int imin(int a, int b) { return (a < b) ? a : b; }               /* :30-3
 
 /* lowerUpperLemire, array and List<Double> overloads are the same algorithm
  * (K/utils/DtwUtils.java:50-91 and :93-134). */
+/* `u[i - r - 1]` of the closing loop (:81-90) starts at i = len: with len <= r the index is negative and Java throws
+ * ArrayIndexOutOfBoundsException -- the engines never catch it, the query dies.  Strict (default): the callers below return
+ * KVO_ERR_INDEX_OUT_OF_BOUNDS at that point.  Not strict: the stores outside the arrays are skipped ("natural extension":
+ * a window clipped at the ends of the array) and the query goes on. */
+static int kvo_strict_bounds = 1;
+static int kvo_oob = 0;
+void kvo_set_strict_bounds(int on) { kvo_strict_bounds = on ? 1 : 0; }
+static int kvo_take_oob(void) { int v = kvo_oob; kvo_oob = 0; return v; }
+
 void kvo_lower_upper_lemire(const double *t, int len, int r, double *l, double *u) {
+    if (kvo_strict_bounds && len <= r) {
+        kvo_oob = 1;
+        return;
+    }
     circ du, dl;
     circ_init(&du, 2 * r + 2);
     circ_init(&dl, 2 * r + 2);
@@ -269,8 +284,7 @@ void kvo_lower_upper_lemire(const double *t, int len, int r, double *l, double *
         }
     }
     for (int i = len; i < len + r + 1; i++) {
-        /* Java would throw ArrayIndexOutOfBounds for i-r-1 < 0 (len <= r); callers never do that
-         * with len >= 25 > ... well, they can when rho >= len; guard to stay memory-safe. */
+        /* (not strict only: Java throws ArrayIndexOutOfBounds for i - r - 1 < 0, i.e. len <= r) */
         if (i - r - 1 >= 0) {
             u[i - r - 1] = t[circ_front(&du)];
             l[i - r - 1] = t[circ_front(&dl)];
@@ -1066,6 +1080,10 @@ int64_t kvo_query_rsm_dtw(const double *series, int n, const double *queryData, 
     double *u = (double *)malloc((size_t)length * sizeof(double));
     double *l = (double *)malloc((size_t)length * sizeof(double));
     kvo_lower_upper_lemire(Q, length, rho, l, u);
+    if (kvo_take_oob()) { /* K/QueryEngineDtw.java:362 dies in lowerUpperLemire: rho >= length */
+        free(Q); free(u); free(l);
+        return KVO_ERR_INDEX_OUT_OF_BOUNDS;
+    }
     /* the reorder sort is commented out in the reference (:369-372): order = identity */
     int *order = (int *)malloc((size_t)length * sizeof(int));
     double *qo = (double *)malloc((size_t)length * sizeof(double));
@@ -1101,6 +1119,11 @@ int64_t kvo_query_rsm_dtw(const double *series, int n, const double *queryData, 
         double *uBuff = (double *)malloc((size_t)dataSize * sizeof(double));
         double *lBuff = (double *)malloc((size_t)dataSize * sizeof(double));
         kvo_lower_upper_lemire(data, dataSize, rho, lBuff, uBuff);
+        if (kvo_take_oob()) { /* K/QueryEngineDtw.java:399: a fetched stub no longer than the band */
+            free(uBuff); free(lBuff);
+            rc = KVO_ERR_INDEX_OUT_OF_BOUNDS;
+            break;
+        }
 
         for (int i = 0; i < dataSize; i++) {
             double d = data[i];
@@ -1191,6 +1214,10 @@ int64_t kvo_query_cnsm_dtw(const double *series, int n, const double *queryData,
     double *u = (double *)malloc((size_t)queryLength * sizeof(double));
     double *l = (double *)malloc((size_t)queryLength * sizeof(double));
     kvo_lower_upper_lemire(zQ, queryLength, rho, l, u);
+    if (kvo_take_oob()) { /* K/NormQueryEngineDtw.java:469, before the sort */
+        free(zQ); free(u); free(l);
+        return KVO_ERR_INDEX_OUT_OF_BOUNDS;
+    }
     kvo_index *tmpQ = (kvo_index *)malloc((size_t)queryLength * sizeof(kvo_index));
     for (int i = 0; i < queryLength; i++) {
         tmpQ[i].value = zQ[i];
@@ -1258,6 +1285,11 @@ int64_t kvo_query_cnsm_dtw(const double *series, int n, const double *queryData,
         double *uBuff = (double *)malloc((size_t)dataSize * sizeof(double));
         double *lBuff = (double *)malloc((size_t)dataSize * sizeof(double));
         kvo_lower_upper_lemire(data, dataSize, rho, lBuff, uBuff);
+        if (kvo_take_oob()) { /* K/NormQueryEngineDtw.java:524 */
+            free(uBuff); free(lBuff);
+            rc = KVO_ERR_INDEX_OUT_OF_BOUNDS;
+            break;
+        }
 
         for (int idx1 = beginIdx; idx1 <= endIdx; idx1++) {
             cntCandidate += right[idx1] - left[idx1] + 1;
@@ -1862,6 +1894,11 @@ int64_t kvo_ucr_dtw(const double *series, int n, const double *queryData, int M,
     stdQ = sqrt(stdQ - meanQ * meanQ);
     for (int i = 0; i < M; i++) q[i] = (q[i] - meanQ) / stdQ;
     kvo_lower_upper_lemire(q, M, Rho, l, u); /* :134 */
+    if (kvo_take_oob()) { /* Rho >= M: ArrayIndexOutOfBoundsException */
+        free(q); free(qo); free(uo); free(lo); free(order); free(Q_tmp); free(u); free(l);
+        free(cb); free(cb1); free(cb2); free(t); free(tz); free(buffer); free(u_buff); free(l_buff);
+        return KVO_ERR_INDEX_OUT_OF_BOUNDS;
+    }
     for (int i = 0; i < M; i++) {
         Q_tmp[i].value = q[i];
         Q_tmp[i].index = i;

@@ -76,6 +76,8 @@ def load():
     lib.kvo_index_file.argtypes = [vp, i64, i32, vp, i64, vp]
     lib.kvo_set_lenient_sort.restype = None
     lib.kvo_set_lenient_sort.argtypes = [C.c_int]
+    lib.kvo_set_strict_bounds.restype = None
+    lib.kvo_set_strict_bounds.argtypes = [C.c_int]
     lib.kvo_sort_answers.restype = None
     lib.kvo_sort_answers.argtypes = [vp, vp, i64]
     _lib = lib
@@ -84,7 +86,8 @@ def load():
 
 class OracleError(Exception):
     def __init__(self, code):
-        super().__init__({-2: "IllegalArgumentException", -3: "IOException", -4: "capacity"}.get(code, str(code)))
+        super().__init__({-2: "IllegalArgumentException", -3: "IOException", -4: "capacity",
+                          -8: "ArrayIndexOutOfBoundsException"}.get(code, str(code)))
         self.code = code
 
 
@@ -149,6 +152,21 @@ def set_lenient_sort(on):
 
 
 _lenient = False
+
+
+def set_strict_bounds(on):
+    """Default True = the reference: DtwUtils.lowerUpperLemire over an array no longer than the band (rho >= m, or a fetched
+    stub of <= rho points) ends the query in ArrayIndexOutOfBoundsException -> OracleError(-8).  False (TEST SWITCH, the
+    counterpart of the library's OPT_STRICT_BOUNDS = 0): the out-of-array stores are skipped and the query goes on.
+    Returns the previous setting."""
+    global _strict
+    prev = _strict
+    load().kvo_set_strict_bounds(1 if on else 0)
+    _strict = bool(on)
+    return prev
+
+
+_strict = True
 
 
 def cnsm_dtw_order(zq):

@@ -52,6 +52,30 @@ def main():
         for i, (offs, dists) in enumerate(res):
             np.savez(os.path.join(out_dir, f"stream{i}_r{rank}.npz"), offs=offs, dists=dists, cnt=int(cnts[i].item()),
                      variant=queries[i]["variant"])
+        # one bad shard: rank 1's list ends in an interval beyond the series (readTimeSeries' IllegalArgument, for that rank
+        # only).  Nobody may be left waiting in the all-gather: the failing rank takes part with a count of -1, rank 1 raises
+        # its own error, rank 0 raises ShardFailed -- from ShardedVerifier.verify and, at the same query, from ShardedStream.run.
+        lb, rb = (l, r) if rank == 0 else (np.append(l, n + 10).astype(np.int32), np.append(r, n + 20).astype(np.int32))
+        outcome = []
+        v = D.ShardedVerifier(ctx, 0, cands + 64)
+        try:
+            v.verify((lb, rb), 1, q, **args[0])
+            outcome.append("no error")
+        except Exception as e:  # noqa: BLE001
+            outcome.append(type(e).__name__)
+        queries = [dict(valid_positions=(l, r), last_segment=1, query_data=q, variant=0, **args[0]),
+                   dict(valid_positions=(lb, rb), last_segment=1, query_data=q, variant=0, **args[0]),
+                   dict(valid_positions=(l, r), last_segment=1, query_data=q, variant=1, **args[1]),
+                   dict(valid_positions=(l, r), last_segment=1, query_data=q, variant=0, **args[0])]
+        try:
+            ss.run(queries)
+            outcome.append("no error")
+        except Exception as e:  # noqa: BLE001
+            outcome.append(type(e).__name__)
+        res = ss.run(queries[:1] + queries[2:])       # and the stream is usable afterwards
+        outcome.append(len(res))
+        with open(os.path.join(out_dir, f"bad_shard_r{rank}.txt"), "w") as f:
+            f.write(repr(outcome))
         ss.close()
     dist.barrier()
     dist.destroy_process_group()

@@ -56,6 +56,11 @@ def test_sharded_verifier_two_ranks_one_device(built, tmp_path):
             assert int(z["cnt"]) == w_st["cnt_candidate"]
 
 
+    # a shard-dependent error ends the query on EVERY rank (the job above would have hung in the all-gather otherwise)
+    assert (tmp_path / "bad_shard_r0.txt").read_text() == repr(["ShardFailed", "ShardFailed", 3])
+    assert (tmp_path / "bad_shard_r1.txt").read_text() == repr(["KvMatchIllegalArgument", "KvMatchIllegalArgument", 3])
+
+
 def test_bench_launched_path_two_ranks_rehearsal(built):
     """bench.py as the driver launches it for N > 1 (torch.distributed.run, one process per rank, ShardedStream with the
     calling thread issuing the all-gathers, max-over-ranks timing, rank 0 printing the one JSON line) -- rehearsed with two

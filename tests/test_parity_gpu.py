@@ -81,10 +81,85 @@ def test_cnsm_ed(world, m, eps, alpha, beta):
 def test_rsm_dtw(world, m, eps, rho):
     kvmatch = world[0]
     s, q, L, R = planted(world, m)
-    got = kvmatch.QueryEngineDtw(world[3]).verify((L, R), 1, q, eps, rho)
-    want = oracle.rsm_dtw(s, q, L, R, 0, eps, oracle.resolve_rho(rho, m))
+    loose = oracle.resolve_rho(rho, m) >= m
+    if loose:
+        # the reference dies in lowerUpperLemire over the query (`u[i - r - 1]`, K/utils/DtwUtils.java:81-90): so do both sides by
+        # default; the band's natural extension is behind OPT_STRICT_BOUNDS = 0 / oracle.set_strict_bounds(False)
+        with pytest.raises(kvmatch.KvMatchIndexOutOfBounds, match=str(m - oracle.resolve_rho(rho, m) - 1)):
+            kvmatch.QueryEngineDtw(world[3]).verify((L, R), 1, q, eps, rho)
+        with pytest.raises(oracle.OracleError) as ei:
+            oracle.rsm_dtw(s, q, L, R, 0, eps, oracle.resolve_rho(rho, m))
+        assert ei.value.code == -8
+        world[3].set_option(kvmatch.OPT_STRICT_BOUNDS, 0)
+        oracle.set_strict_bounds(False)
+    try:
+        got = kvmatch.QueryEngineDtw(world[3]).verify((L, R), 1, q, eps, rho)
+        want = oracle.rsm_dtw(s, q, L, R, 0, eps, oracle.resolve_rho(rho, m))
+    finally:
+        world[3].set_option(kvmatch.OPT_STRICT_BOUNDS, 1)
+        oracle.set_strict_bounds(True)
     compare(got, want, exact=True, tag=f"rsm_dtw m={m} rho={rho}")
     assert 123_456 in got.offsets.tolist()
+
+
+def test_dtw_engines_die_where_the_reference_does(world):
+    """DtwUtils.lowerUpperLemire stores `u[i - r - 1]` from i = len on (K/utils/DtwUtils.java:81-90): over an array of
+    len <= r points that is ArrayIndexOutOfBoundsException, uncaught, and query() dies -- for the query envelope when
+    rho >= m (K/QueryEngineDtw.java:362, K/NormQueryEngineDtw.java:469: before the sort, before anything is read), for the
+    data envelope when a fetched range holds <= rho points (:399 / :524: a stub beyond the last window offset), right behind
+    the readTimeSeries that throws IllegalArgumentException for an EMPTY range -- whichever interval offends first decides.
+    KVM_OPT_STRICT_BOUNDS (default 1) mirrors that; 0 computes the envelope's natural extension, as rounds 1-2 did."""
+    kvmatch, datagen, series, ctx = world
+    n, m, rho = len(series), 100, 30
+    s = series
+    ctx.load_series(s)
+    q = s[5_000:5_000 + m].copy()
+    eds = (("rsm", lambda iv, r: kvmatch.QueryEngineDtw(ctx).verify(iv, 1, q, 3.0, r, resolved=True),
+            lambda iv, r: oracle.rsm_dtw(s, q, iv[0], iv[1], 0, 3.0, r)),
+           ("cnsm", lambda iv, r: kvmatch.NormQueryEngineDtw(ctx).verify(iv, 1, q, 3.0, r, 1.5, 5.0, resolved=True),
+            lambda iv, r: oracle.cnsm_dtw(s, q, iv[0], iv[1], 0, 3.0, r, 1.5, 5.0)))
+    arr = lambda *v: np.array(v, dtype=np.int32)
+    good = (arr(4_990), arr(5_010))
+    stub_oob = (arr(4_990, n - 20), arr(5_010, n - 15))     # second interval fetches [n-20, n]: 21 points <= rho
+    stub_ok = (arr(4_990, n - 60), arr(5_010, n - 55))      # 61 points: longer than the band, shorter than m -> no window, no error
+    empty_first = (arr(4_990, n + 5, n - 20), arr(5_010, n + 9, n - 15))   # an empty range comes first: IllegalArgument wins
+    oob_first = (arr(4_990, n - 20, n + 5), arr(5_010, n - 15, n + 9))
+    for name, lib, orc in eds:
+        # rho >= m
+        for r in (m, m + 7, 3 * m):
+            with pytest.raises(kvmatch.KvMatchIndexOutOfBounds, match=f"^{m - r - 1}$"):
+                lib(good, r)
+            with pytest.raises(oracle.OracleError) as ei:
+                orc(good, r)
+            assert ei.value.code == -8, name
+        compare(lib(good, m - 1), orc(good, m - 1), tag=f"{name} rho = m - 1")
+        # stubs
+        with pytest.raises(kvmatch.KvMatchIndexOutOfBounds, match="^-10$"):
+            lib(stub_oob, rho)
+        with pytest.raises(oracle.OracleError) as ei:
+            orc(stub_oob, rho)
+        assert ei.value.code == -8, name
+        compare(lib(stub_ok, rho), orc(stub_ok, rho), tag=f"{name} stub longer than the band")
+        if name == "rsm":   # (the cNSM engines merge the three intervals into one chunk: no empty read there)
+            with pytest.raises(kvmatch.KvMatchIllegalArgument):
+                lib(empty_first, rho)
+            with pytest.raises(oracle.OracleError) as ei:
+                orc(empty_first, rho)
+            assert ei.value.code == -2
+            with pytest.raises(kvmatch.KvMatchIndexOutOfBounds):
+                lib(oob_first, rho)
+            with pytest.raises(oracle.OracleError) as ei:
+                orc(oob_first, rho)
+            assert ei.value.code == -8
+        # the natural extension behind the switch: same answers on both sides
+        ctx.set_option(kvmatch.OPT_STRICT_BOUNDS, 0)
+        oracle.set_strict_bounds(False)
+        try:
+            compare(lib(good, 3 * m), orc(good, 3 * m), tag=f"{name} rho = 3 m, not strict")
+            compare(lib(stub_oob, rho), orc(stub_oob, rho), tag=f"{name} stub, not strict")
+        finally:
+            ctx.set_option(kvmatch.OPT_STRICT_BOUNDS, 1)
+            oracle.set_strict_bounds(True)
 
 
 @pytest.mark.parametrize("m,eps,rho,alpha,beta", [(128, 3.0, 6, 1.5, 2.0), (512, 6.0, 0.05, 1.3, 1.5),
@@ -418,6 +493,52 @@ def test_device_resident_verifier_matches_host_api(world):
             assert np.array_equal(offs, host[variant].offsets), variant
             assert np.array_equal(dists, host[variant].distances), variant
             assert v.cnt_candidate == host[variant].cnt_candidate
+
+
+def test_verify_device_alternating_streams_on_integer_data(world):
+    """kvm_verify_device returns without synchronising; for the DTW engines the sequential tie path (integer-valued data,
+    eps^2 an achievable value: routinely taken) enqueues its kernels and the copy of the answer count AFTER run_variant's own
+    record of ev_staged.  The next call on the same context waits on that event only -- so it has to be re-recorded behind
+    everything the call enqueued, or a call on ANOTHER stream may reuse the scratch while the tie path still reads it
+    (advisor, round 2).  Two streams alternate on one context; every answer list must equal the host path's."""
+    import torch
+    kvmatch = world[0]
+    from kvmatch import distributed as D
+    ctx = world[3]
+    rng = np.random.default_rng(4711)
+    n, m = 120_000, 64
+    s = rng.integers(-3, 4, n).astype(np.float64)
+    q = s[60_000:60_000 + m].copy()
+    for p in (20_000, 90_000):
+        s[p - 1:p - 1 + m] = q
+    ctx.load_series(s)
+    try:
+        L, R = np.array([1], dtype=np.int32), np.array([n - m + 1], dtype=np.int32)
+        cands = n - m + 1
+        dev = torch.device(f"cuda:{ctx.device}")
+        jobs = [(2, dict(epsilon=3.0, rho=4)), (3, dict(epsilon=2.0, rho=4, alpha=1.5, beta=1.0)),
+                (2, dict(epsilon=0.0, rho=2)), (3, dict(epsilon=3.0, rho=6, alpha=2.0, beta=2.0))]
+        want = [kvmatch.QueryEngineDtw(ctx).verify((L, R), 1, q, 3.0, 4), kvmatch.NormQueryEngineDtw(ctx).verify((L, R), 1, q, 2.0, 4, 1.5, 1.0),
+                kvmatch.QueryEngineDtw(ctx).verify((L, R), 1, q, 0.0, 2), kvmatch.NormQueryEngineDtw(ctx).verify((L, R), 1, q, 3.0, 6, 2.0, 2.0)]
+        assert sum(w.stats[kvmatch.STAT_DTW_SEQUENTIAL] for w in want) > 0     # the tie path is what this is about
+        streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+        verifiers = {}
+        for rep in range(3):
+            launched = []
+            for i, (variant, kw) in enumerate(jobs):
+                st = streams[(i + rep) % 2]
+                with torch.cuda.stream(st):
+                    v = verifiers.setdefault((i, (i + rep) % 2), D.ShardedVerifier(ctx, variant, cands))
+                    v.launch((L, R), 1, q, kw["epsilon"], kw.get("rho", 0), kw.get("alpha", 1.0), kw.get("beta", 0.0), None)
+                    launched.append((v, st))             # (no synchronisation between the calls)
+            for st in streams:
+                st.synchronize()
+            for i, (v, st) in enumerate(launched):
+                cnt = int(v.count.item())
+                offs, dists = D.sort_answers(v.out_off[:cnt].cpu().numpy(), v.out_dist[:cnt].cpu().numpy())
+                assert np.array_equal(offs, want[i].offsets) and np.array_equal(dists, want[i].distances), (rep, i)
+    finally:
+        ctx.load_series(world[2])
 
 
 def test_verify_device_on_a_foreign_stream_with_a_fresh_rho(world):
@@ -869,7 +990,7 @@ def test_randomised_sweep_all_variants(world):
     compared bit for bit with the oracle."""
     kvmatch, datagen, series, ctx = world
     rng = np.random.default_rng(20260101)
-    cases = 0
+    cases = died = 0
     for trial in range(60):
         n = int(rng.integers(3_000, 60_000))
         kind = trial % 4
@@ -908,12 +1029,27 @@ def test_randomised_sweep_all_variants(world):
                 oracle.cnsm_ed(s, q, L2, R2, shift, eps, alpha, beta), tag="cnsm_ed " + tag)
         # (a float rho goes through the prompt rule, an int is points: alternate the two spellings)
         rho_arg = float(rho) if trial % 2 else int(rho_resolved)
+        if rho_resolved >= m:
+            # (rho = 1 typed at the reference's prompt is "100 % of the length": lowerUpperLemire then indexes below its arrays and
+            # the query dies, K/utils/DtwUtils.java:81-90 -- on both sides here)
+            for f in (lambda: kvmatch.QueryEngineDtw(ctx).verify((L2, R2), last_segment, q, eps, rho_arg),
+                      lambda: kvmatch.NormQueryEngineDtw(ctx).verify((L2, R2), last_segment, q, eps, rho_arg, alpha, beta)):
+                with pytest.raises(kvmatch.KvMatchIndexOutOfBounds):
+                    f()
+            for f in (lambda: oracle.rsm_dtw(s, q, L2, R2, shift, eps, rho_resolved),
+                      lambda: oracle.cnsm_dtw(s, q, L2, R2, shift, eps, rho_resolved, alpha, beta)):
+                with pytest.raises(oracle.OracleError) as ei:
+                    f()
+                assert ei.value.code == -8
+            died += 1
+            cases += 4
+            continue
         compare(kvmatch.QueryEngineDtw(ctx).verify((L2, R2), last_segment, q, eps, rho_arg),
                 oracle.rsm_dtw(s, q, L2, R2, shift, eps, rho_resolved), tag="rsm_dtw " + tag)
         compare(kvmatch.NormQueryEngineDtw(ctx).verify((L2, R2), last_segment, q, eps, rho_arg, alpha, beta),
                 oracle.cnsm_dtw(s, q, L2, R2, shift, eps, rho_resolved, alpha, beta), tag="cnsm_dtw " + tag)
         cases += 4
-    assert cases == 240
+    assert cases == 240 and died >= 1     # (some trial has rho = 1.0 -> the whole length)
 
 
 @pytest.mark.parametrize("m,rho", [(3000, 1100), (9000, 2000)])
