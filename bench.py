@@ -99,39 +99,38 @@ def timed_steps(fn, steps, warmup, world):
     return dt
 
 
-def roofline_block(wl, plans, k_ns, stage_stats, m):
+def roofline_block(wl, plans, launches, m):
     """Roofline of the workload's dominant kernel.  None of these kernels is HBM-bound (a tile of 64 consecutive candidates
     needs m+63 points, not 64*m: 63 of every 64 algorithmic bytes are served from LDS): the binding roof is the fp64
     vector pipe, so `bound` says so; the HBM view (8*m algorithmic bytes per candidate) is kept as secondary
-    fields.  `achieved` = algorithmic operations of one launch / the kernel's average HIP-event duration in this run."""
+    fields.  `achieved` = algorithmic operations of the measured launches / their summed HIP-event durations in this run
+    (`launches`: one record per exclusive launch -- plan index, kernel ns, the call's stage counters)."""
     variants = [v for v, _, _, _ in plans]
     dtw_i = [i for i, v in enumerate(variants) if v == 3] or [i for i, v in enumerate(variants) if v == 2]
     if dtw_i:
         # DTW: the banded DP (K/utils/DtwUtils.java:269-337), 5 non-fusable fp64 operations per cell
         i = dtw_i[0]
-        v = variants[i]
-        ns = [t for j, t in k_ns if j == i and t > 0]
-        ks = float(np.mean(ns)) * 1e-9 if ns else 0.0
+        ls = [x for x in launches if x["plan"] == i and x["ns"] > 0]
+        ks = float(np.sum([x["ns"] for x in ls])) * 1e-9
         rho = int(kvmatch._lib.load().kvm_resolve_rho(0.05, m))
         cells = m * (2 * rho + 1) - rho * (rho + 1)
-        dps = stage_stats[v][kvmatch.STAT_PASS_LB_KEOGH2]
+        dps = int(np.sum([x["stats"][kvmatch.STAT_PASS_LB_KEOGH2] for x in ls]))
         ops = dps * cells * 5.0
         ach = ops / ks / 1e12 if ks > 0 else 0.0
         return {"bound": "fp64_valu", "achieved": ach, "peak": FP64_VALU_PEAK_TOPS_NOFMA, "unit": "TFLOP/s",
                 "frac": ach / FP64_VALU_PEAK_TOPS_NOFMA, "traffic": None,
                 "kernel": "kvm_dtw_dp_reg_kernel (banded DP, early abandon off: every candidate that reaches it runs all cells)",
-                "kernel_ms": ks * 1e3, "dp_candidates_per_launch": dps, "cells_per_candidate": cells,
+                "kernel_ms": ks * 1e3 / max(1, len(ls)), "launches_measured": len(ls),
+                "dp_candidates_per_launch": dps / max(1, len(ls)), "cells_per_candidate": cells,
                 "cells_per_s": dps * cells / ks if ks > 0 else 0.0,
                 "note": "peak = vector fp64 issue rate without FMA (78.6 TFLOP/s / 2); HBM traffic of the DP is negligible "
                         "(8*m bytes per candidate), see profiles/ for the LDS / occupancy counters"}
-    i = 0
     v = variants[0]
-    ns = [t for j, t in k_ns if j == i and t > 0]
-    ks = float(np.mean(ns)) * 1e-9 if ns else 0.0
-    st = stage_stats[v]
-    windows = st[kvmatch.STAT_WINDOWS]
+    ls = [x for x in launches if x["plan"] == 0 and x["ns"] > 0]
+    ks = float(np.sum([x["ns"] for x in ls])) * 1e-9
+    nl = max(1, len(ls))
     # cNSM-ED: only the candidates passing the (alpha, beta) filter reach the O(m) pruner (K/NormQueryEngine.java:511)
-    evaluated = st[kvmatch.STAT_PASS_FILTER] if v == 1 else windows
+    evaluated = float(np.sum([x["stats"][kvmatch.STAT_PASS_FILTER] if v == 1 else x["stats"][kvmatch.STAT_WINDOWS] for x in ls]))
     fma_flops = evaluated * m * 2.0  # the correlation-form pruner executes ONE fma per (candidate, point)
     ach = fma_flops / ks / 1e12 if ks > 0 else 0.0
     algo_bytes = evaluated * 8.0 * m  # SURVEY 8d: 8*m algorithmic bytes per candidate
@@ -148,12 +147,12 @@ def roofline_block(wl, plans, k_ns, stage_stats, m):
             "traffic_source": (tsrc + " -- NOT measured by this run (gpurun refuses --pmc together with tracing)") if tsrc else None,
             "kernel": "kvm_ed_dot_kernel (ED pruning pass incl. the in-place exact evaluation of its survivors" +
                       ("; cNSM: + the (alpha, beta) retile before it)" if v == 1 else ")"),
-            "kernel_ms": ks * 1e3, "candidates_evaluated_per_launch": evaluated,
+            "kernel_ms": ks * 1e3 / nl, "launches_measured": len(ls), "candidates_evaluated_per_launch": evaluated / nl,
             "executed_fma_tflops": ach,
             "reference_arithmetic_tflops": evaluated * m * 3.0 / ks / 1e12 if ks > 0 else 0.0,  # sub, mul, add per term
-            "algorithmic_bytes_per_launch": algo_bytes,
+            "algorithmic_bytes_per_launch": algo_bytes / nl,
             "hbm_algorithmic_gbs": algo_bytes / ks / 1e9 if ks > 0 else 0.0,
-            "hbm_measured_gbs": (traffic / ks / 1e9) if (traffic and ks > 0) else None,
+            "hbm_measured_gbs": (traffic * nl / ks / 1e9) if (traffic and ks > 0) else None,
             "hbm_peak_gbs": HBM_PEAK_GBS,
             "fp64_fma_sustained_tflops": 56.8,
             "fp64_fma_sustained_source": "profiles/micro/mfma_f64_rate.hip (profiles/r02_mfma_f64_rate.log): a register-only "
@@ -169,6 +168,8 @@ def visible_gpus():
     when sysfs does not tell (the ranks then fail by themselves if a device is missing)."""
     try:
         base = "/sys/class/kfd/kfd/topology/nodes"
+        if not os.path.isdir("/sys/class/kfd"):
+            return 0  # no KFD driver at all: no AMD GPU on this box
         cnt = 0
         for node in os.listdir(base):
             with open(os.path.join(base, node, "properties")) as f:
@@ -280,6 +281,10 @@ def main():
             must += [qo] + planted
         qoffs.append(qo)
     must = sorted(set(must))
+    # (the planted windows, for the CPU legs that rebuild the series in a child process)
+    patch_pos = [p_ for j in range(NQ) for p_ in (pos[3 * j + 1], pos[3 * j + 2])] if wl != "cnsm_dtw" else []
+    patch_val = np.stack([series[p_ - 1: p_ - 1 + m] for p_ in patch_pos]) if patch_pos else np.empty((0, m))
+    tmpdir = os.path.join(ROOT, "gpurun_out") if os.path.isdir(os.path.join(ROOT, "gpurun_out")) else "/tmp"
 
     def make_lists(total):
         ls = [datagen.gen_intervals(n, m, total, 64.0, must_cover=must, seed=1 + i) for i in range(NL)]
@@ -343,12 +348,10 @@ def main():
         # the same loop on all host cores: a child process (no GPU context there) forks one worker per core
         try:
             ncores = min(os.cpu_count() or 1, 64)
-            np.savez(os.path.join(ROOT, "gpurun_out", "_bench_cpu_in.npz") if os.path.isdir(os.path.join(ROOT, "gpurun_out"))
-                     else "/tmp/_bench_cpu_in.npz", q=queries[0], left=l0, right=r0)
+            fin = os.path.join(tmpdir, "_bench_cpu_in.npz")
+            np.savez(fin, q=queries[0], left=l0, right=r0, patch_pos=np.array(patch_pos, dtype=np.int64), patch_val=patch_val)
             cp = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline.py"), "rsm_ed", str(n), str(a.epsilon),
-                                 str(ncores), os.path.join(ROOT, "gpurun_out", "_bench_cpu_in.npz")
-                                 if os.path.isdir(os.path.join(ROOT, "gpurun_out")) else "/tmp/_bench_cpu_in.npz"],
-                                capture_output=True, text=True, timeout=300)
+                                 str(ncores), fin], capture_output=True, text=True, timeout=300)
             allc = json.loads(cp.stdout.strip().splitlines()[-1])
             out["cpu_baseline"]["all_cores"] = {"cores": allc["cores"], "value": allc["no_abandon"]["candidates_per_s"],
                                                 "value_early_abandon": allc["early_abandon"]["candidates_per_s"],
@@ -406,11 +409,9 @@ def main():
     # ---- headline: early abandon off ---------------------------------------------------------------------
     set_option(kvmatch.OPT_EARLY_ABANDON, 0)
     # first calls allocate scratch (and build the rho envelope for DTW); through the host API on this rank's shard, which
-    # also returns the per-stage counters the roofline block needs (the sharded path returns answers only)
-    stage_stats = {}
+    # (further down) also returns the per-stage counters the roofline block needs (the sharded path returns answers only)
     for i, (v, _, pos_, _) in enumerate(plans):
-        r_ = engines[i].verify(shards[0], 1, queries[0], a.epsilon, *pos_)
-        stage_stats[v] = list(r_.stats)
+        engines[i].verify(shards[0], 1, queries[0], a.epsilon, *pos_)
     step()
     step_no[0] = 0
     dt = timed_steps(step, a.steps, a.warmup, world)
@@ -425,9 +426,9 @@ def main():
     for i, (v, _, pos_, _) in enumerate(plans):
         for rep in range(2 + max(10, NQ)):
             j = rep % NQ
-            engines[i].verify(shards[j % NL], 1, queries[j], a.epsilon, *pos_)
+            r_ = engines[i].verify(shards[j % NL], 1, queries[j], a.epsilon, *pos_)
             if rep >= 2:
-                excl_ns.append((i, int(lib.kvm_last_kernel_ns(h))))
+                excl_ns.append({"plan": i, "ns": int(lib.kvm_last_kernel_ns(h)), "stats": list(r_.stats)})
     ctx.set_option(kvmatch.OPT_TIMING, 0)
 
     # ---- same workload with the reference's early abandoning on (reported, not the headline) -------------
@@ -488,7 +489,7 @@ def main():
         "early_abandon_same_answers": ab_match,
         "setup_s": setup_s,
     })
-    out["roofline"] = roofline_block(wl, plans, excl_ns, stage_stats, m)
+    out["roofline"] = roofline_block(wl, plans, excl_ns, m)
     out["roofline"]["kernel_ms_note"] = ("HIP events around the kernel on its own stream, measured in this run right after the "
                                          f"timed region with ONE query in flight, averaged over the {NQ} queries and their "
                                          "lists: the kernel's own duration (what rocprofv3 "
@@ -542,7 +543,10 @@ def main():
                     ok = ok and np.array_equal(ce[j].offsets, o[0]) and np.array_equal(ce[j].distances, o[1])
                 parity["cnsm_ed"] = bool(ok)
             # cNSM-DTW, BASELINE configs[3]: m=4096, rho=5%
+            # (the query of rounds 1-2, a slice at n/3 of a random-walk stretch with thousands of near neighbours in this list: the
+            # DP kernel gets ~1.4e4 candidates per launch, i.e. it is measured throughput-bound, not as a handful of lone DPs)
             m2 = 4096
+            qoff = n // 3 + 17
             q2 = series[qoff - 1: qoff - 1 + m2].copy()
             l2, r2 = datagen.gen_intervals(n, m2, a.candidates, 64.0, must_cover=[qoff], seed=2)
             deng = kvmatch.NormQueryEngineDtw(ctx)
@@ -580,9 +584,8 @@ def main():
             if oracle is not None and a.cpu_baseline:
                 # the oracle's cNSM-DTW on all host cores (a child process; whole intervals dealt round-robin to the workers)
                 try:
-                    tmp = os.path.join(ROOT, "gpurun_out") if os.path.isdir(os.path.join(ROOT, "gpurun_out")) else "/tmp"
-                    fin, fout = os.path.join(tmp, "_bench_dtw_in.npz"), os.path.join(tmp, "_bench_dtw_out.npz")
-                    np.savez(fin, q=q2, left=l2, right=r2)
+                    fin, fout = os.path.join(tmpdir, "_bench_dtw_in.npz"), os.path.join(tmpdir, "_bench_dtw_out.npz")
+                    np.savez(fin, q=q2, left=l2, right=r2, patch_pos=np.array(patch_pos, dtype=np.int64), patch_val=patch_val)
                     cp = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline.py"), "cnsm_dtw_answers", str(n),
                                          "10.0", str(min(os.cpu_count() or 1, 64)), fin, fout, str(rho2), "2.0", "10.0"],
                                         capture_output=True, text=True, timeout=600)

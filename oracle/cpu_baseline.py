@@ -1,7 +1,16 @@
 #!/usr/bin/env python3
-"""CPU baseline on all host cores: the oracle's RSM-ED loop (a C port of K/QueryEngine.java:338-363) over the bench
-workload, interval shards spread over `workers` forked processes.  Run as a CHILD process by bench.py (this process
-never touches the GPU).  TEST/MEASUREMENT INFRASTRUCTURE ONLY -- lives under oracle/.  Prints one JSON line."""
+"""CPU legs of bench.py on all host cores, run as a CHILD process (this process never touches the GPU): the oracle's loops
+(C ports of the reference's phase-2 blocks) over inputs bench.py hands over in an .npz file, interval shards spread over
+forked worker processes.  TEST / MEASUREMENT INFRASTRUCTURE ONLY -- lives under oracle/.
+
+  cpu_baseline.py rsm_ed <n> <eps> <workers> <in.npz>
+      times K/QueryEngine.java:338-363 (early abandon off, then on) over `left` / `right` of in.npz; prints one JSON line
+  cpu_baseline.py cnsm_dtw_answers <n> <eps> <workers> <in.npz> <out.npz> <rho> <alpha> <beta>
+      the answers of K/NormQueryEngineDtw.java:457-603 for the checker (`parity_vs_oracle` of the cNSM-DTW workload): whole
+      intervals dealt round-robin to the workers (running sums restart per interval, so no value depends on the deal; the
+      fetched chunks -- hence the clipping of the data envelope of LB_Keogh -- do, which can only matter at an exact tie
+      of a lower bound with eps^2), merged and sorted like the reference sorts them; writes off / dist / seconds to out.npz
+"""
 import json
 import multiprocessing as mp
 import os
@@ -16,33 +25,61 @@ import numpy as np  # noqa: E402
 _G = {}
 
 
-def _work(args):
+def _work_ed(args):
     import oracle
     lo, hi, no_abandon = args
     off, dist, st = oracle.rsm_ed(_G["series"], _G["q"], _G["L"][lo:hi], _G["R"][lo:hi], 0, _G["eps"], no_abandon=no_abandon)
     return st["windows"], len(off)
 
 
+def _work_dtw(w):
+    import oracle
+    L, R = _G["L"][w::_G["workers"]], _G["R"][w::_G["workers"]]
+    if len(L) == 0:
+        return np.empty(0, np.int32), np.empty(0, np.float64)
+    off, dist, st = oracle.cnsm_dtw(_G["series"], _G["q"], L, R, 0, _G["eps"], _G["rho"], _G["alpha"], _G["beta"])
+    return off, dist
+
+
 def main():
-    n, m, cands, eps, workers = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), float(sys.argv[4]), int(sys.argv[5])
+    mode, n, eps, workers, fin = sys.argv[1], int(sys.argv[2]), float(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
     from kvmatch import datagen  # host-side generators only (no HIP call is made in this process)
+    z = np.load(fin)
     series = datagen.gen_series(n)
-    qoff = n // 3 + 17
-    planted = [n // 7, n // 2 + 1000, n - 3 * m]
-    q = datagen.plant_copies(series, qoff, m, planted, [1.0, 1.0, 1.0], [0.0, 0.02, -0.03], 0.01)
-    L, R = datagen.gen_intervals(n, m, cands, 64.0, must_cover=[qoff] + planted, seed=1)
-    _G.update(series=series, q=q, L=L, R=R, eps=eps)
-    k = len(L)
-    bounds = [(k * i // workers, k * (i + 1) // workers) for i in range(workers)]
-    out = {"cores": workers}
-    with mp.get_context("fork").Pool(workers) as pool:
-        pool.map(_work, [(0, 1, 1)] * workers)  # warm the workers (library load)
-        for name, flag in (("no_abandon", 1), ("early_abandon", 0)):
-            t = time.perf_counter()
-            res = pool.map(_work, [(lo, hi, flag) for lo, hi in bounds])
-            dt = time.perf_counter() - t
-            out[name] = {"candidates_per_s": sum(r[0] for r in res) / dt, "seconds": dt, "answers": sum(r[1] for r in res)}
-    print(json.dumps(out))
+    q, L, R = z["q"], z["left"], z["right"]
+    m = len(q)
+    # bench.py plants copies of its queries into the series it stages; the slices this leg reads must be the staged ones:
+    # the planted windows are handed over with the inputs
+    if "patch_pos" in z:
+        for p, w in zip(z["patch_pos"].tolist(), z["patch_val"]):
+            series[p - 1: p - 1 + len(w)] = w
+    _G.update(series=series, q=q, L=L, R=R, eps=eps, workers=workers)
+    if mode == "rsm_ed":
+        k = len(L)
+        bounds = [(k * i // workers, k * (i + 1) // workers) for i in range(workers)]
+        out = {"cores": workers}
+        with mp.get_context("fork").Pool(workers) as pool:
+            pool.map(_work_ed, [(0, 1, 1)] * workers)  # warm the workers (library load)
+            for name, flag in (("no_abandon", 1), ("early_abandon", 0)):
+                t = time.perf_counter()
+                res = pool.map(_work_ed, [(lo, hi, flag) for lo, hi in bounds])
+                dt = time.perf_counter() - t
+                out[name] = {"candidates_per_s": sum(r[0] for r in res) / dt, "seconds": dt, "answers": sum(r[1] for r in res)}
+        print(json.dumps(out))
+    elif mode == "cnsm_dtw_answers":
+        fout, rho, alpha, beta = sys.argv[6], int(sys.argv[7]), float(sys.argv[8]), float(sys.argv[9])
+        _G.update(rho=rho, alpha=alpha, beta=beta)
+        t = time.perf_counter()
+        with mp.get_context("fork").Pool(workers) as pool:
+            res = pool.map(_work_dtw, list(range(workers)))
+        dt = time.perf_counter() - t
+        off = np.concatenate([r[0] for r in res]).astype(np.int32)
+        dist = np.concatenate([r[1] for r in res]).astype(np.float64)
+        order = np.lexsort((off, dist))  # stable sort by distance of an offset-ascending list (K/QueryEngine.java:373)
+        np.savez(fout, off=off[order], dist=dist[order], seconds=dt)
+        print(json.dumps({"cores": workers, "seconds": dt, "answers": int(len(off))}))
+    else:
+        raise SystemExit(f"unknown mode {mode}")
 
 
 if __name__ == "__main__":

@@ -12,7 +12,8 @@ for p in (ROOT, os.path.join(ROOT, "kv-match_amd"), os.path.join(ROOT, "oracle")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
-    config.addinivalue_line("markers", "strict_sort: run with the reference's behaviour where NormQueryEngineDtw's sort throws")
+    config.addinivalue_line("markers", "lenient_sort: answer cNSM-DTW queries on which the reference's Arrays.sort throws (index order, both sides)")
+    config.addinivalue_line("markers", "strict_sort: (kept for readability) the test is about the reference's default, which every unmarked test runs")
 
 
 @pytest.fixture(scope="session")
@@ -25,12 +26,12 @@ def built():
 
 @pytest.fixture(autouse=True)
 def lenient_sort(request):
-    """NormQueryEngineDtw's Arrays.sort throws on a good part of the noisy synthetic queries the GPU tests use (DESIGN.md
-    section 2); the reference's query() dies there, and by default so do the oracle and the library.  What the GPU parity
-    tests are after is the verification arithmetic, so they run with the switch that carries on in index order -- on BOTH
-    sides (oracle.set_lenient_sort / OPT_SORT_VIOLATION on every context a test opens).  Tests marked `strict_sort` keep
-    the reference's behaviour: they are the ones that check the throw itself."""
-    if "gpu" not in request.keywords or request.node.get_closest_marker("strict_sort"):
+    """The GPU suite runs the reference's DEFAULT behaviour: where NormQueryEngineDtw's Arrays.sort throws (its comparator
+    breaks the contract) the query dies -- in the oracle and in the library.  Queries of cNSM-DTW tests are
+    therefore chosen so that JDK 8's TimSort comes through (`sortable_query` below).  Only tests marked `lenient_sort` -- the
+    ones that are ABOUT such queries, or that draw random queries by the hundred -- flip the switch that carries on in
+    index order, on BOTH sides (oracle.set_lenient_sort / OPT_SORT_VIOLATION on every context the test opens)."""
+    if "gpu" not in request.keywords or not request.node.get_closest_marker("lenient_sort"):
         yield
         return
     import kvmatch
@@ -54,6 +55,23 @@ def lenient_sort(request):
         oracle.set_lenient_sort(prev)
         for c in shared:
             c.set_option(kvmatch.OPT_SORT_VIOLATION, 0)
+
+
+def sortable_query(series, m, start, step=997, tries=400):
+    """First offset >= `start` (walking in steps) whose length-m slice the reference CAN run as a cNSM-DTW query: JDK 8's
+    TimSort under the truncating comparator of K/NormQueryEngineDtw.java:475-478 does not throw on it
+    (kvm_cnsm_dtw_order returns OK).  Returns the 1-based offset."""
+    import kvmatch
+    qo = int(start)
+    for _ in range(tries):
+        if qo + m - 1 > len(series):
+            qo = max(1, qo % (len(series) - m))
+        try:
+            kvmatch.cnsm_dtw_order(series[qo - 1: qo - 1 + m])
+            return qo
+        except kvmatch.KvMatchIllegalArgument:
+            qo += step
+    raise AssertionError("no sortable query found")
 
 
 @pytest.fixture(scope="session")

@@ -90,6 +90,27 @@ def test_dtw_config_4(big):
     want = oracle.rsm_dtw(series, q, L, R, 0, 6.0, rho)
     got = kvmatch.QueryEngineDtw(ctx).verify((L, R), 1, q, 6.0, 0.05)
     assert same(got, want) and qoff in set(want[0].tolist())
+    # The query above is a smooth slice: JDK 8's TimSort leaves it in index order.  A query on which the reference's sort
+    # comes through with a NON-identity permutation exercises order[] -- the summation order of both LB_Keogh loops
+    # (K/NormQueryEngineDtw.java:475-490) -- at BASELINE size: the first such slice of the series, found by asking the library's
+    # restatement of the sort (which the oracle's must agree with, or the two sides below would not match).
+    q2off = None
+    for cand in range(1000, N - m, 7919):
+        try:
+            order = kvmatch.cnsm_dtw_order(series[cand - 1: cand - 1 + m])
+        except kvmatch.KvMatchIllegalArgument:
+            continue                                   # (the reference cannot run this one at all)
+        moved = int((order != np.arange(m)).sum())
+        if 0 < moved < m:                              # (not a plain reversal either)
+            q2off = cand
+            break
+    assert q2off is not None
+    q2 = series[q2off - 1: q2off - 1 + m].copy()
+    L2, R2 = datagen.gen_intervals(N, m, 100_000, 64.0, must_cover=[q2off], seed=5)
+    for eps in (3.0, 12.0):
+        want = oracle.cnsm_dtw(series, q2, L2, R2, 0, eps, rho, 2.0, 10.0)
+        got = kvmatch.NormQueryEngineDtw(ctx).verify((L2, R2), 1, q2, eps, 0.05, 2.0, 10.0)
+        assert same(got, want) and got.cnt_candidate == want[2]["cnt_candidate"] and q2off in set(want[0].tolist()), (eps, moved)
 
 
 @pytest.mark.parametrize("w", [25, 50, 400])
