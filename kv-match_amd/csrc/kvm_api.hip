@@ -115,6 +115,8 @@ static void free_series(kvm_ctx *ctx) {
     ctx->d_series = nullptr;
     if (ctx->own_series && ctx->d_prefix) hipFree(ctx->d_prefix);  // (a shared series belongs to its owner context)
     if (ctx->own_series && ctx->d_blockmax) hipFree(ctx->d_blockmax);
+    if (ctx->own_series && ctx->d_series_sh) hipFree(ctx->d_series_sh);
+    ctx->d_series_sh = nullptr;
     ctx->own_series = false;
     ctx->d_prefix = nullptr;
     ctx->d_blockmax = nullptr;
@@ -206,6 +208,10 @@ static int finish_load_steps(kvm_ctx *ctx) {
     // largest x^2 per prefix block: what the reference's running sums may still carry the residue of (kvm_hist_*)
     HIPCHK(ctx, hipMalloc((void **)&ctx->d_blockmax, (size_t)((ctx->n >> KVM_PS_BLOCK_LOG2) + 1) * sizeof(double)));
     HIPCHK(ctx, kvm_launch_blockmax(ctx->d_series, ctx->n, ctx->d_blockmax, ctx->stream));
+    // the series once more, every point minus the first point of its prefix block: the lane-granular ED pruner stages it
+    // by LDS-DMA (no register, no VALU between HBM and LDS: kvm_ed_g.hip), 8 B per point
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_series_sh, (size_t)(ctx->n + KVM_SERIES_PAD) * sizeof(double)));
+    HIPCHK(ctx, kvm_launch_shift_series(ctx->d_series, ctx->n, ctx->d_series_sh, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return KVM_OK;
 }
@@ -305,6 +311,7 @@ extern "C" int kvm_share_series(kvm_ctx *ctx, const kvm_ctx *owner) {
     ctx->d_series = owner->d_series;  // values and prefix sums are read-only after staging
     ctx->d_prefix = owner->d_prefix;
     ctx->d_blockmax = owner->d_blockmax;
+    ctx->d_series_sh = owner->d_series_sh;
     ctx->own_series = false;
     ctx->n = owner->n;
     return KVM_OK;
@@ -913,15 +920,26 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
     // RSM-ED with early abandoning: the same, trimmed by the head of the window (kvm_retile_rsm_kernel)
     const bool retile_rsm = !cnsm && !dtw && ed_kernel == 3 && ctx->opt_early_abandon;
     const bool retile = (cnsm && !dtw && ed_kernel == 3) || retile_rsm;
-    const int32_t tile_max = (!dtw && ed_kernel == 4) ? 16 : retile ? KVM_TILE_MAX
+    // host-planned list for the correlation-form pruner (RSM-ED, every point evaluated): lane-granular tiles of 8 candidates
+    // (kvm_ed_g.hip) by default; KVM_ED_GEN=0 in the environment: the class A / B / C tiling of round 2 (kvm_ed_dot.hip)
+    static const bool env_gen = [] {
+        const char *e = getenv("KVM_ED_GEN");
+        return !(e && e[0] == '0');
+    }();
+    const bool gen = !dtw && ed_kernel == 3 && !retile && env_gen;
+    const int32_t tile_max = gen ? 8 : (!dtw && ed_kernel == 4) ? 16 : retile ? KVM_TILE_MAX
                              : (!dtw && ed_kernel >= 2) ? KVM_TILE_TILED : KVM_TILE_MAX;
-    const bool hybrid = !dtw && ed_kernel == 3 && !retile;
+    const bool hybrid = !dtw && ed_kernel == 3 && !retile && !gen;
     // query block: q | (qu | ql for DTW) | pad || (qc | pad | q_pref | q_pref8 | qT for ED) || (zQ sorted | order: cNSM-ED
     // exact pass); the runs follow it in the pinned staging buffer, where build_plan writes them directly
     const int nchunks4 = (m + ED4_JC - 1) / ED4_JC, nchunks8 = (m + ED8_JC - 1) / ED8_JC;
     const int nchT = (m + JL_CHUNK - 1) / JL_CHUNK;  // lane-transposed copy for kvm_ed_jl.hip
     const size_t qmain = (size_t)m * 8 * (dtw ? 3 : 1) + KVM_SERIES_PAD * sizeof(double);
-    const size_t qdot0 = dtw ? 0 : ((size_t)m * 8 + KVM_SERIES_PAD * sizeof(double) + ((size_t)2 * nchunks4 + 1 + nchunks8 + 1) * 16);
+    // (... | qc_pre: m + 1 running sums of qc, padded to a multiple of 16 B | q_pref16: the chunk sums at 16-point granularity)
+    const int n16 = (m + 15) / 16;
+    const size_t qpre_bytes = (((size_t)m + 1) * 8 + 15) / 16 * 16, qp16_bytes = ((size_t)n16 + 2) * 16;
+    const size_t qdot_old = (size_t)m * 8 + KVM_SERIES_PAD * sizeof(double) + ((size_t)2 * nchunks4 + 1 + nchunks8 + 1) * 16;
+    const size_t qdot0 = dtw ? 0 : qdot_old + qpre_bytes + qp16_bytes;
     const bool use_qT = !dtw && ed_kernel == 4;
     const size_t qdot = dtw ? 0 : qdot0 + (use_qT ? (size_t)nchT * JL_CHUNK * 8 : 0);
     const size_t qexact_off = qmain + qdot;
@@ -989,8 +1007,8 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
     }
 
     // correlation-form ED pruner: centred query and its chunk-granular prefix sums
-    std::vector<double> qcen;
-    std::vector<double2> qpref, qpref8;
+    std::vector<double> qcen, qcpre;
+    std::vector<double2> qpref, qpref8, qpref16;
     if (!dtw) {
         // (pruner-side quantities, guard-banded: the summation order is free, so four interleaved partial sums keep the
         // adders busy -- the plain sequential loops cost ~20 us of the host's critical path at m = 8192)
@@ -1019,6 +1037,20 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
                 a2[u] += c * c;
             }
         }
+        // lane-granular pruner (kvm_ed_g.hip): running sums of qc per point and its chunk sums per 16 points
+        qcpre.resize((size_t)m + 1);
+        qpref16.resize((size_t)n16 + 2);
+        {
+            double r1 = 0, r2 = 0;
+            for (int j = 0; j < m; j++) {
+                if (j % 16 == 0) qpref16[(size_t)(j / 16)] = make_double2(r1, r2);
+                qcpre[(size_t)j] = r1;
+                r1 += qcen[(size_t)j];
+                r2 += qcen[(size_t)j] * qcen[(size_t)j];
+            }
+            qcpre[(size_t)m] = r1;
+            for (size_t t = (size_t)((m + 15) / 16); t < qpref16.size(); t++) qpref16[t] = make_double2(r1, r2);
+        }
         const double p1 = (a1[0] + a1[1]) + (a1[2] + a1[3]), p2 = (a2[0] + a2[1]) + (a2[2] + a2[3]);
         for (size_t t = (size_t)((m + ED16_JC - 1) / ED16_JC); t <= (size_t)2 * nchunks4; t++) qpref[t] = make_double2(p1, p2);
         qpref8[(size_t)nchunks8] = make_double2(p1, p2);
@@ -1036,6 +1068,8 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
         std::memcpy(hp + qmain + (size_t)m * 8 + KVM_SERIES_PAD * sizeof(double), qpref.data(), qpref.size() * 16);
         std::memcpy(hp + qmain + (size_t)m * 8 + KVM_SERIES_PAD * sizeof(double) + qpref.size() * 16, qpref8.data(),
                     qpref8.size() * 16);
+        std::memcpy(hp + qmain + qdot_old, qcpre.data(), qcpre.size() * 8);
+        std::memcpy(hp + qmain + qdot_old + qpre_bytes, qpref16.data(), qpref16.size() * 16);
         if (use_qT) {
             // qT[chunk][i][lane] = the pair (qc[chunk*1024 + 16*lane + 2i], qc[... + 2i + 1]); zero past m
             double *qT = (double *)(hp + qmain + qdot0);
@@ -1101,6 +1135,8 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
                     : (const double2 *)((const char *)ctx->b_query.p + qmain + (size_t)m * 8 +
                                         KVM_SERIES_PAD * sizeof(double));
     qd.q_pref8 = dtw ? nullptr : qd.q_pref + (2 * nchunks4 + 1);
+    qd.qc_pre = dtw ? nullptr : (const double *)((const char *)ctx->b_query.p + qmain + qdot_old);
+    qd.q_pref16 = dtw ? nullptr : (const double2 *)((const char *)ctx->b_query.p + qmain + qdot_old + qpre_bytes);
     qd.qT = use_qT ? (const double *)((const char *)ctx->b_query.p + qmain + qdot0) : nullptr;
     qd.qu = dtw ? qd.q + m : nullptr;
     qd.ql = dtw ? qd.q + 2 * (size_t)m : nullptr;
@@ -1133,6 +1169,11 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
         } else if (ed_kernel == 4)
             HIPCHK(ctx, kvm_launch_ed_jl(ctx->d_series, ctx->d_prefix, ctx->n, qd, d_tiles, n_tiles, surv, pl.windows,
                                          counters, ctx->num_cu, stream));
+        else if (gen) {
+            if ((rc = ensure(ctx, ctx->b_aux, kvm_ed_g_scratch_bytes(n_tiles, ctx->num_cu)))) return rc;
+            HIPCHK(ctx, kvm_launch_ed_g(ctx->d_series, ctx->d_series_sh, ctx->d_prefix, qd, d_tiles, n_tiles, surv, pl.windows, counters,
+                                        ctx->num_cu, out.d_off, out.d_dist, out.cap, ctx->b_aux.p, stream));
+        }
         else if (ed_kernel == 3)
             HIPCHK(ctx, kvm_launch_ed_dot(ctx->d_series, ctx->d_prefix, ctx->n, qd, d_tiles, pl.n_tiles, d_tiles + pl.n_tiles,
                                           pl.n_tiles_b, d_tiles + pl.n_tiles + pl.n_tiles_b, pl.n_tiles_c, surv, pl.windows, counters, ctx->num_cu, nullptr, out.d_off, out.d_dist,

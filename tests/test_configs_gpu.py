@@ -15,6 +15,7 @@ import numpy as np
 import pytest
 
 import oracle
+from conftest import sortable_query
 
 pytestmark = pytest.mark.gpu
 
@@ -29,7 +30,7 @@ def test_config_0_file_data_1000000_every_offset(built, tmp_path):
     from kvmatch import datagen
     n, m, eps = 1_000_000, 1024, 10.0
     s = datagen.gen_series(n, seed=20241003)
-    qoff = 123_456
+    qoff = sortable_query(s, m, 123_456)     # (a query the reference can run through all four engines)
     planted = [400_000, 777_777, n - m + 1]
     q = datagen.plant_copies(s, qoff, m, planted, [1.0, 1.0, 1.0], [0.0, 0.05, -0.02], 0.01)
     path = tmp_path / f"data-{n}"

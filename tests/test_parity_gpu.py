@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 import oracle
-from conftest import rel_close
+from conftest import sortable_query,  rel_close
 
 pytestmark = pytest.mark.gpu
 
@@ -44,8 +44,11 @@ def compare(got, want, exact=True, tag="", abs_floor=1e-9):
 
 
 def planted(world, m, qoff=123_456, seed=11):
+    """Series with the query (the slice at `planted.qoff`: the first offset from `qoff` on that the reference can run as a
+    cNSM-DTW query too -- its Arrays.sort does not throw on it, conftest.sortable_query) and three noisy copies."""
     kvmatch, datagen, series, ctx = world
     s = series.copy()
+    qoff = planted.qoff = sortable_query(s, m, qoff)
     q = datagen.plant_copies(s, qoff, m, [40_000, 200_000, 250_000], [1.0, 1.2, 0.8], [0.0, 0.5, -1.0], 0.02,
                              seed=seed)
     ctx.load_series(s)
@@ -59,7 +62,7 @@ def test_rsm_ed(world, m, eps):
     s, q, L, R = planted(world, m)
     got = kvmatch.QueryEngine(world[3]).verify((L, R), 1, q, eps)
     compare(got, oracle.rsm_ed(s, q, L, R, 0, eps), tag=f"rsm_ed m={m}")
-    assert got.offsets[0] == 123_456 and got.distances[0] == 0.0  # self-match, README.md:73
+    assert got.offsets[0] == planted.qoff and got.distances[0] == 0.0  # self-match, README.md:73
     assert len(got) >= 2
 
 
@@ -71,7 +74,7 @@ def test_cnsm_ed(world, m, eps, alpha, beta):
     want = oracle.cnsm_ed(s, q, L, R, 0, eps, alpha, beta)
     compare(got, want, tag=f"cnsm_ed m={m}")
     assert got.stats[1] == want[2]["pass_filter"]
-    assert 123_456 in got.offsets.tolist() and len(got) >= 2
+    assert planted.qoff in got.offsets.tolist() and len(got) >= 2
 
 
 # rho picks the DP kernel form: register band with V = 1 (rho <= 63), 2, 4, 8 (<= 511) cells per lane, LDS form above
@@ -99,7 +102,7 @@ def test_rsm_dtw(world, m, eps, rho):
         world[3].set_option(kvmatch.OPT_STRICT_BOUNDS, 1)
         oracle.set_strict_bounds(True)
     compare(got, want, exact=True, tag=f"rsm_dtw m={m} rho={rho}")
-    assert 123_456 in got.offsets.tolist()
+    assert planted.qoff in got.offsets.tolist()
 
 
 def test_dtw_engines_die_where_the_reference_does(world):
@@ -171,7 +174,7 @@ def test_cnsm_dtw(world, m, eps, rho, alpha, beta):
     want = oracle.cnsm_dtw(s, q, L, R, 0, eps, oracle.resolve_rho(rho, m), alpha, beta)
     compare(got, want, tag=f"cnsm_dtw m={m}")
     assert got.stats[1] == want[2]["pass_filter"]
-    assert 123_456 in got.offsets.tolist() and len(got) >= 2
+    assert planted.qoff in got.offsets.tolist() and len(got) >= 2
 
 
 @pytest.mark.parametrize("rho", [0, 1, 7, 64, 204, 1500, 5000])
@@ -284,7 +287,8 @@ def test_shift_clipping_empty_and_errors(world):
     s = series[:20_000].copy()
     ctx.load_series(s)
     m = 100
-    q = s[:m].copy()
+    qo = sortable_query(s, m, 1, step=7)
+    q = s[qo - 1:qo - 1 + m].copy()
     left = np.array([10, 5000, 19_950], dtype=np.int32)
     right = np.array([60, 5100, 20_040], dtype=np.int32)
     for last_segment in (1, 3):
@@ -679,7 +683,7 @@ def test_degenerate_windows_constant_segments(world):
     s = series[:30_000].copy()
     s[10_000:12_000] = 3.25      # constant: variance exactly 0 -> std 0 (or NaN) -> never passes the filter
     m = 256
-    qoff = 20_000
+    qoff = sortable_query(s, m, 20_000)
     q = s[qoff - 1: qoff - 1 + m].copy()
     ctx.load_series(s)
     L = np.array([9_900, qoff - 5], dtype=np.int32)
@@ -705,7 +709,7 @@ def test_query_lengths_all_variants(world, m):
     """m below one lane group, around the 160-point chunk, and beyond one prefix-sum block (16384)."""
     kvmatch, datagen, series, ctx = world
     s = series[:120_000].copy()
-    qoff = 50_000
+    qoff = sortable_query(s, m, 50_000, step=211) if m >= 2 else 50_000
     q = datagen.plant_copies(s, qoff, m, [10_000, 90_000], [1.0, 1.0], [0.01, -0.01], 0.01, seed=m)
     ctx.load_series(s)
     L, R = datagen.gen_intervals(len(s), m, 3_000, 12.0, must_cover=[qoff, 10_000, 90_000], seed=m)
@@ -870,7 +874,7 @@ def test_ucr_full_scan_executors(world):
     from kvmatch.ucr import segments, EPOCH
     n, m = 230_000, 256
     s = series[:n].copy()
-    q = datagen.plant_copies(s, 20_000, m, [99_400, 99_900, 150_000, 229_000], [1.0, 1.0, 1.3, 0.7], [0.0, 0.0, 0.4, -0.5], 0.03)
+    q = datagen.plant_copies(s, sortable_query(s, m, 20_000), m, [99_400, 99_900, 150_000, 229_000], [1.0, 1.0, 1.3, 0.7], [0.0, 0.0, 0.4, -0.5], 0.03)
     ctx.load_series(s)
     eps, alpha, beta, rho = 2.5, 1.5, 1.0, 12
     ex = kvmatch.UcrEdQueryExecutor(ctx, n, m, q, eps, alpha, beta)
@@ -906,7 +910,7 @@ def test_long_queries_and_wide_bands(world):
     n = 120_000
     s = series[:n].copy()
     for m, rho in ((3_000, 600), (20_000, 1_000), (40_000, 520)):
-        qoff = 31_337
+        qoff = sortable_query(s, m, 31_337 if m < 30_000 else 20_011, step=101)   # (its window ends in front of the copy at 70 001)
         q = datagen.plant_copies(s, qoff, m, [70_001], [1.05], [0.2], 0.01, seed=m)
         ctx.load_series(s)
         L = np.array([qoff - 2, 50_000, 70_000], dtype=np.int32)
@@ -985,6 +989,8 @@ def test_cpp_host_mirror_cli(world):
     c2.close()
 
 
+@pytest.mark.lenient_sort   # (60 random queries, noise included: on a good part of them the reference's sort throws, and which
+#                             ones is the subject of test_cnsm_dtw_sort_violation_...; here the switch carries on, on both sides)
 def test_randomised_sweep_all_variants(world):
     """Seeded random sweep over series shape, query length, thresholds and interval layouts: 240 verifications, each
     compared bit for bit with the oracle."""
@@ -1057,9 +1063,10 @@ def test_wide_bands_envelope_paths(world, m, rho):
     """rho > 1024 (1024-point envelope tiles with > 64 KiB of LDS) and the LDS form of the DP (rho > 511)."""
     kvmatch, datagen, series, ctx = world
     s = series[:60_000].copy()
-    q = datagen.plant_copies(s, 20_000, m, [40_000], [1.0], [0.0], 0.02, seed=2)
+    qoff = sortable_query(s, m, 20_000, step=53)
+    q = datagen.plant_copies(s, qoff, m, [40_000], [1.0], [0.0], 0.02, seed=2)
     ctx.load_series(s)
-    L, R = datagen.gen_intervals(len(s), m, 300, 8.0, must_cover=[20_000, 40_000], seed=3)
+    L, R = datagen.gen_intervals(len(s), m, 300, 8.0, must_cover=[qoff, 40_000], seed=3)
     eps = 0.08 * np.sqrt(m)
     compare(kvmatch.QueryEngineDtw(ctx).verify((L, R), 1, q, eps, rho), oracle.rsm_dtw(s, q, L, R, 0, eps, rho),
             tag=f"wide band rsm {rho}")
@@ -1222,7 +1229,8 @@ def _long_list_of_short_runs(k, m, seed):
     R = L + lens - 1
     n = int(R[-1]) + 4 * m
     s = datagen.gen_series(n, seed=seed)
-    q = s[n // 3: n // 3 + m].copy()
+    qo = sortable_query(s, m, n // 3 + 1)
+    q = s[qo - 1: qo - 1 + m].copy()
     L, R = L.astype(np.int32), R.astype(np.int32)
     for i in rng.choice(len(L), 200, replace=False):                      # answers in every part of the list
         off = int(rng.integers(L[i], R[i] + 1))
@@ -1292,6 +1300,8 @@ def test_lists_of_more_than_16_rounds_of_wave_slots(built):
             assert len(got.offsets) >= 10
 
 
+@pytest.mark.lenient_sort   # (the lists below are built around the query's own offset 50 001, a slice on which the reference's sort
+#                             throws: this test is about malformed LISTS, so the switch carries on in index order on both sides)
 def test_interval_lists_not_in_the_form_sort_and_merge_leaves(world):
     """The engines hand phase 2 the list sortAndMergeIntervals leaves (sorted, disjoint, non-adjacent).  Anything else a
     caller might pass: adjacent, overlapping, nested, repeated and reversed (empty) intervals go through like in the Java
