@@ -208,10 +208,12 @@ static int finish_load_steps(kvm_ctx *ctx) {
     // largest x^2 per prefix block: what the reference's running sums may still carry the residue of (kvm_hist_*)
     HIPCHK(ctx, hipMalloc((void **)&ctx->d_blockmax, (size_t)((ctx->n >> KVM_PS_BLOCK_LOG2) + 1) * sizeof(double)));
     HIPCHK(ctx, kvm_launch_blockmax(ctx->d_series, ctx->n, ctx->d_blockmax, ctx->stream));
-    // the series once more, every point minus the first point of its prefix block: the lane-granular ED pruner stages it
-    // by LDS-DMA (no register, no VALU between HBM and LDS: kvm_ed_g.hip), 8 B per point
-    HIPCHK(ctx, hipMalloc((void **)&ctx->d_series_sh, (size_t)(ctx->n + KVM_SERIES_PAD) * sizeof(double)));
-    HIPCHK(ctx, kvm_launch_shift_series(ctx->d_series, ctx->n, ctx->d_series_sh, ctx->stream));
+    if (const char *e = getenv("KVM_ED_GEN")) {
+        if (e[0] == '1') {  // (the block-centred copy the lane-granular pruner stages from: with the series, so that sharing contexts see it)
+            HIPCHK(ctx, hipMalloc((void **)&ctx->d_series_sh, (size_t)(ctx->n + KVM_SERIES_PAD) * sizeof(double)));
+            HIPCHK(ctx, kvm_launch_shift_series(ctx->d_series, ctx->n, ctx->d_series_sh, ctx->stream));
+        }
+    }
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return KVM_OK;
 }
@@ -920,11 +922,13 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
     // RSM-ED with early abandoning: the same, trimmed by the head of the window (kvm_retile_rsm_kernel)
     const bool retile_rsm = !cnsm && !dtw && ed_kernel == 3 && ctx->opt_early_abandon;
     const bool retile = (cnsm && !dtw && ed_kernel == 3) || retile_rsm;
-    // host-planned list for the correlation-form pruner (RSM-ED, every point evaluated): lane-granular tiles of 8 candidates
-    // (kvm_ed_g.hip) by default; KVM_ED_GEN=0 in the environment: the class A / B / C tiling of round 2 (kvm_ed_dot.hip)
+    // host-planned list for the correlation-form pruner (RSM-ED, every point evaluated): the class A / B / C tiling
+    // (kvm_ed_dot.hip); KVM_ED_GEN=1 in the environment: lane-granular tiles of 8 candidates staged by LDS-DMA (kvm_ed_g.hip,
+    // round 3: +5-8 % with four queries in flight, 15-20 % SLOWER as a single launch -- its LDS-DMA volume per point is twice the
+    // register staging's and the CU's DMA path, not the FMA pipe, sets its pace: not the default)
     static const bool env_gen = [] {
         const char *e = getenv("KVM_ED_GEN");
-        return !(e && e[0] == '0');
+        return e && e[0] == '1';
     }();
     const bool gen = !dtw && ed_kernel == 3 && !retile && env_gen;
     const int32_t tile_max = gen ? 8 : (!dtw && ed_kernel == 4) ? 16 : retile ? KVM_TILE_MAX
@@ -1170,6 +1174,13 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
             HIPCHK(ctx, kvm_launch_ed_jl(ctx->d_series, ctx->d_prefix, ctx->n, qd, d_tiles, n_tiles, surv, pl.windows,
                                          counters, ctx->num_cu, stream));
         else if (gen) {
+            // the series once more, every point minus the first point of its prefix block: the source of the LDS-DMA staging (no
+            // register, no VALU between HBM and LDS), 8 B per point; built on first use
+            if (!ctx->d_series_sh) {
+                if (!ctx->own_series) return fail(ctx, KVM_ERR_UNSUPPORTED, "KVM_ED_GEN=1 on a context that shares another one's series: run one query on the owner first");
+                HIPCHK(ctx, hipMalloc((void **)&ctx->d_series_sh, (size_t)(ctx->n + KVM_SERIES_PAD) * sizeof(double)));
+                HIPCHK(ctx, kvm_launch_shift_series(ctx->d_series, ctx->n, ctx->d_series_sh, stream));
+            }
             if ((rc = ensure(ctx, ctx->b_aux, kvm_ed_g_scratch_bytes(n_tiles, ctx->num_cu)))) return rc;
             HIPCHK(ctx, kvm_launch_ed_g(ctx->d_series, ctx->d_series_sh, ctx->d_prefix, qd, d_tiles, n_tiles, surv, pl.windows, counters,
                                         ctx->num_cu, out.d_off, out.d_dist, out.cap, ctx->b_aux.p, stream));

@@ -37,15 +37,22 @@ typedef double edg_d2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(1))) const void edg_gptr;
 typedef __attribute__((address_space(3))) void edg_lptr;
 
-#define EDG_WAVE_LDS 2368                                   // doubles per wavefront (18.5 KB): two workgroups of 4 waves per CU with room to spare
-#define EDG_TMAX 17                                         // LDS-DMA instructions (1 KiB = 128 doubles each) for the window regions
+// EDG_DB = 1: ONE wavefront per SIMD with 40 KB of LDS and two images -- the LDS-DMA of chunk t+1 is issued before chunk t is
+// computed and has the whole chunk to land (a chunk's image is re-fetched from L2 / HBM every 80-128 points: with one image
+// the wait for it is a quarter of the chunk loop, in-kernel stamps); EDG_DB = 0: two wavefronts per SIMD, one image each.
+#ifndef EDG_DB
+#define EDG_DB 0
+#endif
+#define EDG_TMAX (EDG_DB ? 18 : 17)                         // LDS-DMA instructions (1 KiB = 128 doubles each) for the window regions
 #define EDG_BUDGET (EDG_TMAX * 128)                         // doubles for the window regions: whole DMA pieces, so that the last
                                                             // instruction of an image cannot write into the query region
 #define EDG_QLEN 160                                        // query region: a chunk (<= 128 points) + the loop's read-ahead (a
                                                             // 1-KiB piece + a 256-B piece)
-static_assert(EDG_BUDGET + EDG_QLEN + 16 <= EDG_WAVE_LDS, "window regions + query region + slack for the ring's read-ahead");
+#define EDG_NBUF (EDG_DB ? 2 : 1)
+#define EDG_WAVE_LDS (EDG_NBUF * (EDG_BUDGET + EDG_QLEN) + 32)  // doubles per wavefront: 38.6 KB / 18.5 KB
+#define EDG_WPS (EDG_DB ? 1 : 2)                            // wavefronts per SIMD = workgroups per CU
 #define EDG_INLINE_MAX 4
-static_assert(EDG_BUDGET % 2 == 0 && EDG_WAVE_LDS % 2 == 0 && 4 * EDG_WAVE_LDS * 8 <= 81920, "LDS layout");
+static_assert(EDG_BUDGET % 32 == 0 && EDG_WAVE_LDS % 32 == 0 && 4 * EDG_WAVE_LDS * 8 * EDG_WPS <= 163840, "LDS layout");
 
 struct edg_args {
     const double *series, *series_sh;
@@ -65,6 +72,8 @@ struct edg_args {
     // per unit, built once by kvm_ed_g_plan_kernel: the LDS-DMA source offsets [unit][t][lane], every lane's read position in the
     // LDS image (16-B slots), chunk length and number of DMA instructions
     const int32_t *tab_soff, *tab_x2;
+    const int32_t *tab_pf;    // [unit][2][lane] series offsets (points, relative to a chunk's j0) of the 128-B lines the NEXT chunk's image
+                              // brings in for the first time (-1: none): touched one chunk ahead, so that the LDS-DMA hits the L2
     const int2 *tab_meta;
     unsigned long long *phase_t;  // experiments (KVM_EDG_DBG & 2): summed 100-MHz ticks of [0] table loads [1] chunk loops [2] hand-over
                                   // + decision [3] queue pops + unit search [4] passes [5] whole wavefronts
@@ -140,7 +149,6 @@ __device__ __forceinline__ void edg_pass(const edg_args &A, const kvm_tile *__re
     const double *__restrict__ series = A.series;
     const double *__restrict__ qc = qd.qc;
     double *wlds = reinterpret_cast<double *>(lds_wave2);
-    double *qlds = wlds + EDG_BUDGET;
     const unsigned lds_base = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)(edg_lptr *)wlds);  // LDS byte address
 
     // ---- the unit's staging table (kvm_ed_g_plan_kernel) -------------------------------------------------------------------
@@ -151,12 +159,14 @@ __device__ __forceinline__ void edg_pass(const edg_args &A, const kvm_tile *__re
     {
         const int32_t *__restrict__ ts = A.tab_soff + ((size_t)unit * EDG_TMAX) * 64 + lane;
 #pragma unroll
-        for (int t = 0; t < EDG_TMAX; t++) soff[t] = t < T ? ts[t * 64] : 0;
+        for (int t = 0; t < EDG_TMAX; t++) soff[t] = ts[t * 64];   // (unconditional: one load latency for the lot)
     }
     const int x2_off = A.tab_x2[unit * 64 + lane];
+    const int32_t pf0 = A.tab_pf[(unit * 2 + 0) * 64 + lane], pf1 = A.tab_pf[(unit * 2 + 1) * 64 + lane];
 
-    const edg_d2 *X2 = reinterpret_cast<const edg_d2 *>(lds_wave2) + x2_off;
-    const edg_d2 *Q2 = reinterpret_cast<const edg_d2 *>(lds_wave2) + (EDG_BUDGET / 2);
+    // LDS of the wavefront: image 0 | image 1 | query chunk 0 | query chunk 1   (EDG_DB = 0: image | query chunk)
+    const edg_d2 *X2b = reinterpret_cast<const edg_d2 *>(lds_wave2) + x2_off;
+    const edg_d2 *Q2b = reinterpret_cast<const edg_d2 *>(lds_wave2) + (EDG_NBUF * EDG_BUDGET / 2);
 
     // ---- chunks of JC points from 16 r_lo to min(m, 16 r_hi) ----------------------------------------------------------------
     double acc[8];
@@ -164,19 +174,54 @@ __device__ __forceinline__ void edg_pass(const edg_args &A, const kvm_tile *__re
     for (int a = 0; a < 8; a++) acc[a] = 0.0;
     const int j_end = min(m, 16 * r_hi);
     const unsigned long long ts1 = A.phase_t ? wall_clock64() : 0;
-    for (int j0 = 16 * r_lo; j0 < j_end; j0 += JC) {
-        // LDS-DMA: the unit's image (T x 1 KiB) and the query chunk; nothing of the previous chunk is still being read (its
-        // last FMAs have consumed every ds_read)
+    // issue the LDS-DMA of the chunk that starts at j0 into image `buf`: the unit's image (T x 1 KiB) and the query chunk
+    auto dma_chunk = [&](int j0, int buf) {
         const double *__restrict__ src = A.series_sh + j0;
-        if (!(A.dbg & 1) || j0 == 16 * r_lo) {
+        const unsigned img = lds_base + (unsigned)buf * (EDG_BUDGET * 8u), qb = lds_base + (EDG_NBUF * EDG_BUDGET + buf * EDG_QLEN) * 8u;
 #pragma unroll
         for (int t = 0; t < EDG_TMAX; t++)
-            if (t < T) edg_dma16(src + soff[t], lds_base + 1024u * t);
-        edg_dma16(qc + j0 + 2 * lane, lds_base + EDG_BUDGET * 8u);
+            if (t < T) edg_dma16(src + soff[t], img + 1024u * t);
+        edg_dma16(qc + j0 + 2 * lane, qb);
         if (JC > 112)  // (the read-ahead beyond 128 points: 64 lanes x 4 B = 32 doubles)
-            edg_dma4(reinterpret_cast<const float *>(qc + j0 + 128) + lane, lds_base + (EDG_BUDGET + 128) * 8u);
+            edg_dma4(reinterpret_cast<const float *>(qc + j0 + 128) + lane, qb + 128 * 8u);
+    };
+    const int n_dma = T + 1 + (JC > 112 ? 1 : 0);  // instructions per chunk (the counted wait below leaves the NEXT chunk's in flight)
+    if (EDG_DB && 16 * r_lo < j_end) dma_chunk(16 * r_lo, 0);
+    int buf = 0;
+    unsigned pf_sink0 = 0, pf_sink1 = 0;
+    for (int j0 = 16 * r_lo; j0 < j_end; j0 += JC, buf ^= (EDG_NBUF - 1)) {
+        if (EDG_DB) {
+            // the next chunk's image goes into the other buffer (last read a chunk ago) while this one is computed
+            if (j0 + JC < j_end) {
+                dma_chunk(j0 + JC, buf ^ 1);
+                switch (n_dma) {   // s_waitcnt takes an immediate: this chunk's image has landed, the next one's may still be on its way
+#define EDG_WAIT(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+                    EDG_WAIT(2) EDG_WAIT(3) EDG_WAIT(4) EDG_WAIT(5) EDG_WAIT(6) EDG_WAIT(7) EDG_WAIT(8) EDG_WAIT(9) EDG_WAIT(10) EDG_WAIT(11)
+                    EDG_WAIT(12) EDG_WAIT(13) EDG_WAIT(14) EDG_WAIT(15) EDG_WAIT(16) EDG_WAIT(17) EDG_WAIT(18) EDG_WAIT(19) EDG_WAIT(20)
+#undef EDG_WAIT
+                    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+        } else {
+            // one image: nothing of the previous chunk is still being read (its last FMAs have consumed every ds_read)
+            if (!(A.dbg & 1) || j0 == 16 * r_lo) dma_chunk(j0, 0);
+            if (!(A.dbg & 4)) {
+                // two plain loads per lane pull the lines the next chunk's image adds into the L2 (results unused; issued AFTER
+                // the DMA, so the counted wait below leaves them in flight)
+                // (the two sink registers stay live -- "+v", loop-carried -- until the wait behind the loop: a load still in
+                // flight must not find its destination handed to something else)
+                const double *__restrict__ nx = A.series_sh + j0;
+                asm volatile("global_load_dword %0, %1, off" : "+v"(pf_sink0) : "v"(nx + (pf0 < 0 ? 0 : pf0)) : "memory");
+                asm volatile("global_load_dword %0, %1, off" : "+v"(pf_sink1) : "v"(nx + (pf1 < 0 ? 0 : pf1)) : "memory");
+                asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const edg_d2 *X2 = X2b + buf * (EDG_BUDGET / 2), *Q2 = Q2b + buf * (EDG_QLEN / 2);
+        double *qlds = wlds + EDG_NBUF * EDG_BUDGET + buf * EDG_QLEN;
         const int jlim = min(JC, j_end - j0);
         const int bodies = jlim >> 4;
         if (bodies > 0) {
@@ -223,6 +268,7 @@ __device__ __forceinline__ void edg_pass(const edg_args &A, const kvm_tile *__re
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (read-ahead of the ring: retired before the next chunk's DMA)
     }
 
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf_sink0), "+v"(pf_sink1)::"memory");  // (the last prefetches have landed: sinks released)
     const unsigned long long ts2 = A.phase_t ? wall_clock64() : 0;
     struct edg_stamp {  // (records the pass's phases on every way out)
         const edg_args &A; unsigned long long t0, t1, t2; int lane;
@@ -344,7 +390,7 @@ __device__ __forceinline__ void edg_pass(const edg_args &A, const kvm_tile *__re
     }
 }
 
-__global__ __launch_bounds__(256, 2) void kvm_ed_g_kernel(edg_args A, const kvm_tile *__restrict__ tiles, int64_t n_tiles) {
+__global__ __launch_bounds__(256, EDG_WPS) void kvm_ed_g_kernel(edg_args A, const kvm_tile *__restrict__ tiles, int64_t n_tiles) {
     __shared__ __attribute__((aligned(256))) double2 lds_all2[4 * EDG_WAVE_LDS / 2];
     // (the wave index must LOOK uniform to the compiler: everything the chunk loop's control depends on derives from it, and a
     // "divergent" loop gets exec-mask control flow, loop counters in VGPRs and lgkmcnt(0) waits in the hot loop)
@@ -395,7 +441,8 @@ __global__ __launch_bounds__(256, 2) void kvm_ed_g_kernel(edg_args A, const kvm_
 // of LDS-DMA source offsets and every lane's read position -- and its cost.
 __global__ __launch_bounds__(256) void kvm_ed_g_plan_kernel(const kvm_tile *__restrict__ tiles, int64_t n_tiles, int64_t units, int m,
                                                             int chunk_cost, int64_t *__restrict__ cost, int32_t *__restrict__ tab_soff,
-                                                            int32_t *__restrict__ tab_x2, int2 *__restrict__ tab_meta) {
+                                                            int32_t *__restrict__ tab_x2, int2 *__restrict__ tab_meta,
+                                                            int32_t *__restrict__ tab_pf) {
     const int lane = threadIdx.x & 63;
     const int64_t unit = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (unit >= units) return;
@@ -411,6 +458,8 @@ __global__ __launch_bounds__(256) void kvm_ed_g_plan_kernel(const kvm_tile *__re
             cost[unit] = 1;
             tab_meta[unit] = make_int2(16, 0);
         }
+        tab_pf[(unit * 2 + 0) * 64 + lane] = -1;
+        tab_pf[(unit * 2 + 1) * 64 + lane] = -1;
         return;
     }
     const int my_head = valid ? 63 - __clzll((long long)(heads & ((2ULL << lane) - 1ULL))) : 0;
@@ -422,6 +471,8 @@ __global__ __launch_bounds__(256) void kvm_ed_g_plan_kernel(const kvm_tile *__re
 #pragma unroll
     for (int t = 0; t < EDG_TMAX; t++) soff[t] = 0;
     int cur = 0, my_base = 0;
+    int32_t pf[2] = {-1, -1};
+    int pf_next = 0;   // entries handed out so far (entry e belongs to lane e & 63, slot e >> 6)
     for (unsigned long long hb = heads; hb;) {
         const int h = __ffsll((long long)hb) - 1;
         hb &= hb - 1;
@@ -443,8 +494,17 @@ __global__ __launch_bounds__(256) void kvm_ed_g_plan_kernel(const kvm_tile *__re
             }
         }
         cur = base + size;
+        // the lines this segment's image gains with the next chunk: points [8 k + 8 + JC, 8 k + 8 + 2 JC) behind its start
+        const int nl = (JC >> 4) + 1;
+        for (int i = 0; i < nl; i++) {
+            const int e = pf_next + i;
+            if (e < 128 && (e & 63) == lane) pf[e >> 6] = gstart + 8 * k + 8 + JC + 16 * i;
+        }
+        pf_next += nl;
     }
     const int T = (cur + 63) >> 6;
+    tab_pf[(unit * 2 + 0) * 64 + lane] = pf[0];
+    tab_pf[(unit * 2 + 1) * 64 + lane] = pf[1];
     int32_t *__restrict__ ts = tab_soff + ((size_t)unit * EDG_TMAX) * 64 + lane;
 #pragma unroll
     for (int t = 0; t < EDG_TMAX; t++) ts[t * 64] = soff[t];
@@ -485,14 +545,14 @@ __global__ __launch_bounds__(1024) void kvm_ed_g_scan_kernel(int64_t *__restrict
 
 // scratch of the launch: partial accumulators of (units + pieces) passes | cost prefix sums | arrival counters + queue head |
 // per-unit tables
-#define EDG_PIECES_PER_WAVE 6
+#define EDG_PIECES_PER_WAVE 2
 static int64_t edg_pieces(int64_t nw) {
     int64_t k = EDG_PIECES_PER_WAVE;
     if (const char *e = getenv("KVM_EDG_PIECES")) k = std::max<int64_t>(1, atoll(e));  // experiments
     return nw * k;
 }
 struct edg_layout {
-    size_t parts, unit_off, arrived, tab_meta, tab_x2, tab_soff, total;
+    size_t parts, unit_off, arrived, tab_meta, tab_x2, tab_pf, tab_soff, total;
 };
 static edg_layout edg_scratch_layout(int64_t units, int64_t pieces) {
     edg_layout L;
@@ -502,13 +562,14 @@ static edg_layout edg_scratch_layout(int64_t units, int64_t pieces) {
     L.arrived = o;   o += ((size_t)(units + 2) * sizeof(unsigned) + 15) / 16 * 16;
     L.tab_meta = o;  o += (size_t)units * sizeof(int2);
     L.tab_x2 = o;    o += (size_t)units * 64 * sizeof(int32_t);
+    L.tab_pf = o;    o += (size_t)units * 2 * 64 * sizeof(int32_t);
     L.tab_soff = o;  o += (size_t)units * EDG_TMAX * 64 * sizeof(int32_t);
     L.total = o + 256;
     return L;
 }
 size_t kvm_ed_g_scratch_bytes(int64_t n_tiles8, int num_cu) {
     const int64_t units = (n_tiles8 + 63) / 64;
-    return edg_scratch_layout(units, edg_pieces((int64_t)num_cu * 8)).total;
+    return edg_scratch_layout(units, edg_pieces((int64_t)num_cu * 4 * EDG_WPS)).total;
 }
 
 hipError_t kvm_launch_ed_g(const double *series, const double *series_sh, const double2 *prefix, const kvm_query_dev &qd,
@@ -519,7 +580,7 @@ hipError_t kvm_launch_ed_g(const double *series, const double *series_sh, const 
     const int gpu = (qd.m + 15) / 16;
     const int64_t total = units * gpu;
     // one wavefront per wave slot of the chip; short lists: at least 32 groups (512 points of 512 candidates) per piece
-    const int64_t slots = (int64_t)num_cu * 8;
+    const int64_t slots = (int64_t)num_cu * 4 * EDG_WPS;
     const int64_t pieces = std::max<int64_t>(1, std::min<int64_t>(edg_pieces(slots), total / 32));
     const int64_t nw = std::min<int64_t>(slots, pieces);
     const edg_layout L = edg_scratch_layout(units, edg_pieces(slots));
@@ -535,6 +596,7 @@ hipError_t kvm_launch_ed_g(const double *series, const double *series_sh, const 
     A.tab_meta = (const int2 *)(base + L.tab_meta);
     A.tab_x2 = (const int32_t *)(base + L.tab_x2);
     A.tab_soff = (const int32_t *)(base + L.tab_soff);
+    A.tab_pf = (const int32_t *)(base + L.tab_pf);
     A.units = units; A.groups_per_unit = gpu; A.n_waves = (int)nw; A.n_pieces = pieces;
     A.dbg = getenv("KVM_EDG_DBG") ? atoi(getenv("KVM_EDG_DBG")) : 0;
     static unsigned long long *d_phase = nullptr;
@@ -546,7 +608,7 @@ hipError_t kvm_launch_ed_g(const double *series, const double *series_sh, const 
     }
     hipLaunchKernelGGL(kvm_ed_g_plan_kernel, dim3((unsigned)((units + 3) / 4)), dim3(256), 0, s, tiles8, n_tiles8, units, (int)qd.m,
                        getenv("KVM_EDG_CHUNK_COST") ? atoi(getenv("KVM_EDG_CHUNK_COST")) : EDG_CHUNK_COST, unit_off,
-                       (int32_t *)(base + L.tab_soff), (int32_t *)(base + L.tab_x2), (int2 *)(base + L.tab_meta));
+                       (int32_t *)(base + L.tab_soff), (int32_t *)(base + L.tab_x2), (int2 *)(base + L.tab_meta), (int32_t *)(base + L.tab_pf));
     hipLaunchKernelGGL(kvm_ed_g_scan_kernel, dim3(1), dim3(1024), 0, s, unit_off, units, A.arrived, A.next_piece);
     if (getenv("KVM_TRACE"))
         fprintf(stderr, "[kvm] ed_g m %d tiles8 %lld units %lld waves %lld pieces %lld\n", (int)qd.m, (long long)n_tiles8, (long long)units,
