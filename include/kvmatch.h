@@ -187,12 +187,25 @@ void kvm_index_file_free(kvm_index_file *f);
 /* Phase-2 time model for the phase-1 early-termination test (K/QueryEngine.java:316-327 and the same lines of the other
  * three engines): estimated T_2 in milliseconds of this library for `disjoint_windows` candidate intervals holding
  * `candidate_offsets` offsets and a query of `length` points,
- *     T_2 = C + A * disjoint_windows + B * (candidate_offsets / 1e5) * length,
- * i.e. the reference's own formula (PHASE_2_TIME_ESTIMATE_COEFFICIENT_A/B/INTERCEPT, K/QueryEngine.java:55-57) with
- * the constants re-fitted on an MI355X (profiles/fit_cost_model.py -> profiles/r01_phase2_cost_model.json; the Java
- * constants are 4.07 / 0.27 for RSM-ED and 9.72 / 0.0107 for the others, five to six orders of magnitude larger).
+ *     T_2 = C + A * disjoint_windows + (B * length + E) * (candidate_offsets / 1e5) + D * (length | length^2 / 1e3),
+ * i.e. the reference's own formula (PHASE_2_TIME_ESTIMATE_COEFFICIENT_A/B/INTERCEPT, K/QueryEngine.java:55-57) plus the
+ * terms a GPU call adds: C, its launch chain; D, the one unit of work that holds an answer and walks the whole window
+ * (`length` points for the ED engines, one banded DP ~ length^2 for the DTW engines); E, the part of a candidate's cost
+ * that does not grow with the query.  Constants fitted on an MI355X by
+ * profiles/fit_cost_model.py -> profiles/r03_phase2_cost_model.json and compiled in from kv-match_amd/csrc/kvm_cost_model.inc
+ * (the Java constants are A = 4.07 / B = 0.27 for RSM-ED and 9.72 / 0.0107 for the others: five to six orders of magnitude
+ * larger); tests/test_full_size_gpu.py::test_phase2_time_model_against_measured_calls holds the estimate to measured calls.
  * `variant`: 0 rsm_ed, 1 cnsm_ed, 2 rsm_dtw, 3 cnsm_dtw.  Pure function; < 0 for an unknown variant. */
 double kvm_phase2_time_estimate_ms(int32_t variant, int64_t disjoint_windows, int64_t candidate_offsets, int32_t length);
+/* The early-termination test itself, deterministic (K/QueryEngine.java:316-327: `if (i >= 5 && totalTimeUsageEstimated >
+ * lastTotalTimeUsageEstimated) break; lastTotalTimeUsageEstimated = totalTimeUsageEstimated;`).  The reference adds the
+ * WALL-CLOCK time of phase 1 so far to its phase-2 estimate, so `lastSegment` -- and with it the candidate list -- differs
+ * from run to run; here the caller passes its phase-1 cost so far from a model of its own (`phase1_ms_so_far`: index rows
+ * scanned times a constant, say), the phase-2 term is kvm_phase2_time_estimate_ms.  `segment_index` is the loop's `i`,
+ * `*last_total_ms` the carried `lastTotalTimeUsageEstimated` (start it at 0, as the reference does).  Returns 1 = stop (the
+ * Java `break`), 0 = go on (and `*last_total_ms` is updated), < 0 for bad arguments. */
+int32_t kvm_phase1_should_stop(int32_t variant, int32_t segment_index, double phase1_ms_so_far, int64_t disjoint_windows,
+                               int64_t candidate_offsets, int32_t length, double *last_total_ms);
 
 /* ---- phase 2: the four verification entry points ------------------------------------------------ */
 

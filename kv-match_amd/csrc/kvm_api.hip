@@ -493,19 +493,34 @@ extern "C" void kvm_index_rows_free(kvm_index_rows *r) {
 // The reference's phase-2 time model T_2 = A * #intervals + B * (#offsets / 1e5) * m (K/QueryEngine.java:55-57,316-327) with
 // the terms this path adds: C, the launch chain of a call, and D, the one unit of work that holds an answer (a query drawn
 // from the series always has its self match) and walks the whole window -- m points for the ED engines, one banded DP of
-// m macro-steps x O(m) cells (rho = 5 percent of m) for the DTW engines.  Constants of profiles/r02_phase2_cost_model.json
-// (non-negative least squares on relative residuals, 27-48 (intervals, offsets, m) points per variant on n = 1e8, early
-// abandon on, selective queries, one MI355X): {C [ms], A [ms per interval], B [ms per 1e5 offset-points], D}.
+// m macro-steps x O(m) cells (rho = 5 percent of m) for the DTW engines -- and E, the part of a candidate's cost that does not
+// grow with m.  The constants are generated: profiles/fit_cost_model.py writes kvm_cost_model.inc next to
+// profiles/r03_phase2_cost_model.json (non-negative least squares on relative residuals, 27-48 (intervals, offsets, m) points
+// per variant on n = 1e8, early abandon on, selective queries, one MI355X): {C [ms], A [ms per interval], B [ms per 1e5
+// offset-points], D, E [ms per 1e5 offsets]}; tests/test_full_size_gpu.py holds the estimate to measured calls.
 extern "C" double kvm_phase2_time_estimate_ms(int32_t variant, int64_t disjoint_windows, int64_t candidate_offsets, int32_t length) {
-    static const double K[4][4] = {{0.07796, 1.95e-06, 2.329e-07, 1.229e-05},   // rsm_ed
-                                   {0.1131, 2.113e-06, 5.408e-07, 1.779e-05},   // cnsm_ed
-                                   {0.3406, 2.52e-06, 1.571e-05, 4.804e-05},   // rsm_dtw
-                                   {0.3946, 2.649e-06, 3.748e-05, 4.889e-05}};  // cnsm_dtw
+    static const double K[4][5] = {
+#include "kvm_cost_model.inc"
+    };
     if (variant < 0 || variant > 3) return -1.0;
     const double m = (double)length;
     const double floor_units = variant >= 2 ? m * m / 1e3 : m;
-    return K[variant][0] + K[variant][1] * (double)disjoint_windows + K[variant][2] * ((double)candidate_offsets / 1e5) * m +
-           K[variant][3] * floor_units;
+    return K[variant][0] + K[variant][1] * (double)disjoint_windows +
+           (K[variant][2] * m + K[variant][4]) * ((double)candidate_offsets / 1e5) + K[variant][3] * floor_units;
+}
+
+// The phase-1 early-termination test of the four engines (K/QueryEngine.java:316-327: `i >= 5 && totalTimeUsageEstimated >
+// lastTotalTimeUsageEstimated`), deterministic: the caller supplies its phase-1 cost so far from a model of its own (index rows
+// scanned x a constant, say) instead of reading the wall clock, the phase-2 term is the estimate above.
+extern "C" int32_t kvm_phase1_should_stop(int32_t variant, int32_t segment_index, double phase1_ms_so_far, int64_t disjoint_windows,
+                                          int64_t candidate_offsets, int32_t length, double *last_total_ms) {
+    if (!last_total_ms) return -1;
+    const double est = kvm_phase2_time_estimate_ms(variant, disjoint_windows, candidate_offsets, length);
+    if (est < 0) return -1;
+    const double total = phase1_ms_so_far + est;
+    if (segment_index >= 5 && total > *last_total_ms) return 1;   // (`break`: lastTotalTimeUsageEstimated is not updated, :321-324)
+    *last_total_ms = total;                                        // :325
+    return 0;
 }
 
 extern "C" int32_t kvm_resolve_rho(double r, int32_t m) {

@@ -4,6 +4,8 @@ import ctypes
 import os
 import re
 
+import numpy as np
+
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -79,6 +81,37 @@ def test_phase2_time_estimate_is_the_reference_formula(built):
         d1, d2 = f(v, 0, 0, 4096) - f(v, 0, 0, 2048), f(v, 0, 0, 8192) - f(v, 0, 0, 4096)
         assert d1 > 0 and abs(d2 / d1 - (2.0 if v < 2 else 4.0)) < 1e-9
     assert f(7, 1, 1, 1) < 0
+
+
+def test_phase1_should_stop_is_the_reference_loop_test(built):
+    """kvm_phase1_should_stop against a transliteration of K/QueryEngine.java:316-327 driven by the same numbers: never
+    before i = 5, then at the first i whose estimated total exceeds the carried one, which is not updated by the stop."""
+    import kvmatch
+    rng = np.random.default_rng(5)
+    for trial in range(200):
+        v = int(rng.integers(0, 4))
+        m = int(rng.choice([256, 1024, 4096]))
+        t1 = np.cumsum(rng.uniform(0.0, 0.05, 16))
+        wins = np.sort(rng.integers(1, 50_000, 16))[::-1]
+        offs = np.sort(rng.integers(1, 5_000_000, 16))[::-1]
+        last_ref, stop_ref = 0.0, None
+        for i in range(16):
+            total = t1[i] + kvmatch.phase2_time_estimate_ms(v, int(wins[i]), int(offs[i]), m)
+            if i >= 5 and total > last_ref:
+                stop_ref = i
+                break
+            last_ref = total
+        last, stop = 0.0, None
+        for i in range(16):
+            s, new = kvmatch.phase1_should_stop(v, i, float(t1[i]), int(wins[i]), int(offs[i]), m, last)
+            if s:
+                assert new == last
+                stop = i
+                break
+            last = new
+        assert stop == stop_ref and last == last_ref
+    with pytest.raises(ValueError):
+        kvmatch.phase1_should_stop(9, 0, 0.0, 1, 1, 1, 0.0)
 
 
 def test_java_adapter_natives_match_the_jni_shim():
