@@ -319,6 +319,35 @@ __device__ int dp_prologue(const double *__restrict__ series, const kvm_query_de
                 carry2 = kvm_readlane_f64(S, 63);
             }
         }
+        // A candidate that is still in both loops after the first round (the 256 largest |q|, where the loops of a candidate
+        // that is going to be dropped nearly always stop) most likely runs them to the end.  Every term is >= 0, so the
+        // partial sums never decrease: if the TOTALS stay below eps^2 (1 - tau), no partial sum reached eps^2 and both loops
+        // ran to the end -- and a total needs no ordered scan, just one accumulator per lane and one wave reduction.  The
+        // rest of the terms are summed that way (any order is within tau of the reference's, see kvm_dtw_aux::tau); only if
+        // a total does reach the threshold do the scanned rounds go on from here to find where.  (Round 3: the scans were
+        // two thirds of the prologue of a surviving candidate, 0.15 ms at m = 4096.)
+        if (base == 0 && !amb1 && !amb2 && m > 256) {
+            double s1 = 0.0, s2 = 0.0;
+            for (int b2 = 256; b2 < m; b2 += 256) {
+#pragma unroll
+                for (int h = 0; h < 4; h++) {
+                    const int i = b2 + 64 * h + lane, ic = min(i, m - 1);
+                    const int o = ax.order[ic];
+                    const double t1 = dp_term_q(x[o], mean, inv_sd, ax.uo[ic], ax.lo[ic]);
+                    double U, L;
+                    dp_env_at(ax, patch, r, pl, c.start + o, U, L);
+                    const double t2 = dp_term_d(ax.qo[ic], U, L, mean, inv_sd);
+                    s1 += i < m ? t1 : 0.0;
+                    s2 += i < m ? t2 : 0.0;
+                }
+            }
+            const double T1 = carry1 + kvm_wave_sum(s1), T2 = carry2 + kvm_wave_sum(s2);
+            if (T1 < Elo && T2 < Elo) {
+                carry1 = T1;
+                carry2 = T2;
+                break;
+            }
+        }
     }
     if (amb1 || amb2) return DP_AMBIG;
     const double S1 = carry1, S2 = carry2;  // (< eps^2 (1 - tau): both loops ran to the end, cb1[] and cb2[] are complete)
@@ -596,10 +625,14 @@ __device__ __forceinline__ double dp_from_right(double v, double fill) {  // lan
     return __hiloint2double(hi, lo);
 }
 
-// LDS window buffers of the register-form DP.  The data/query values a lane needs advance by one index per macro-step,
-// so they are kept in LINEAR buffers (index i at position i - low): a lane's read address is base + 8*step and the
-// V steps of an unrolled block use immediate offsets.  A buffer holds the 64*V values behind the front plus
-// DP_EPOCH chunks of 64 new values; after DP_EPOCH chunks the live tail is slid back to the front.
+// LDS window buffers of the register-form DP.  The data/query values a lane needs advance by one index per macro-step:
+// a block of V macro-steps reads the V values [j V, (j + 1) V) of each window, j = j0 -+ lane, and j0 advances by one per
+// block.  A buffer holds the 64*V values behind the front plus DP_EPOCH chunks of 64 new values; after DP_EPOCH chunks
+// the live tail is slid back to the front.  Layout (round 3): a lane's V values are fetched with V/2 ds_read_b128, and for
+// those to be free of bank conflicts consecutive lanes must hit consecutive 16-byte slots -- so the PAIRS (2h, 2h+1) of
+// every group of V go to sub-buffer h, group j at doubles [2j, 2j+2) of it: lanes j0 -+ lane then read one contiguous
+// kilobyte per instruction.  (The linear layout of rounds 1-2 read with a lane stride of 8V bytes: 57 % of the LDS cycles
+// of the kernel were bank conflicts.)  Values are fetched one block AHEAD of their use into a second register set.
 #ifndef DP_EPOCH
 #define DP_EPOCH 4
 #endif
@@ -609,22 +642,68 @@ __device__ __forceinline__ double dp_from_right(double v, double fill) {  // lan
 template <int V>
 struct dp_buf {
     static constexpr int LIVE = 64 * V;                  // values behind the front that lanes still read
-    static constexpr int LIN = LIVE + 64 * DP_EPOCH;     // doubles per buffer (V=4: 768 = 6 KiB)
+    static constexpr int LIN = LIVE + 64 * DP_EPOCH;     // doubles per buffer (V=4: 512 = 4 KiB)
+    static constexpr int NSUB = V >= 2 ? V / 2 : 1;
+    static constexpr int SUB = LIN / NSUB;               // doubles per sub-buffer
+    __device__ static __forceinline__ int phys(int p) {  // where linear position p >= 0 lives
+        if constexpr (V <= 2) return p;
+        else return ((p % V) >> 1) * SUB + (p / V) * 2 + (p & 1);
+    }
+    // the V values of a group: `at` = address of the group's first pair in sub-buffer 0 (group j of a buffer: buf + GROUP * j
+    // doubles), `ahead` groups further on (an immediate offset)
+    static constexpr int GROUP = V == 1 ? 1 : 2;
+    __device__ static __forceinline__ void load(const double *at, int ahead, double (&out)[V]) {
+        if constexpr (V == 1) {
+            out[0] = at[ahead];
+        } else {
+#pragma unroll
+            for (int h = 0; h < V / 2; h++) {
+                const double2 t = *reinterpret_cast<const double2 *>(at + h * SUB + 2 * ahead);
+                out[2 * h] = t.x;
+                out[2 * h + 1] = t.y;
+            }
+        }
+    }
 };
 
-template <int V, int CSTAR, bool ABANDON>
-__global__ __launch_bounds__(256) void kvm_dtw_dp_reg_kernel(const double *__restrict__ series, kvm_query_dev qd,
-                                                             kvm_dtw_aux ax, const kvm_cand *__restrict__ in,
-                                                             const dp_plan *__restrict__ plans,
-                                                             const unsigned long long *__restrict__ d_n_in,
-                                                             int32_t *__restrict__ out_off,
-                                                             double *__restrict__ out_dist, int64_t cap,
-                                                             unsigned long long *__restrict__ counters) {
-    constexpr int LIN = dp_buf<V>::LIN, LIVE = dp_buf<V>::LIVE;
+__device__ __forceinline__ unsigned dp_u32_from_left(unsigned v, unsigned fill) {
+    return (unsigned)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x138 /*wave_shr:1*/, 0xf, 0xf, false);
+}
+__device__ __forceinline__ unsigned dp_umin3(unsigned a, unsigned b, unsigned c) {  // one v_min3_u32
+    unsigned r;
+    asm("v_min3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+// Row test of the first run (EXACT = false), whose row minima are carried as the HIGH WORDS of the cells only: every cell
+// is a sum of squares, >= +0, so the order of two cells is the order of their bit patterns, and the minimum of the high
+// words is the high word of the minimum -- one v_min3_u32 per slot and macro-step instead of two v_min_f64, one DPP move
+// per hand-over instead of two.  The true minimum rv of a row lies in [rv_lo, rv_up] = high word with the low word all
+// zeros / all ones (a relative width of 2^-20), and fl(rv + cb) is monotone in rv: a row is certainly below eps^2 when even
+// rv_up + cb is (less the tolerance of the approximate cb), the first row that is not rejects the candidate when even
+// rv_lo + cb is above, and is ambiguous otherwise -- the second run (EXACT) carries the minima in full.
+__device__ __forceinline__ int dp_row_test_hi(bool valid, unsigned hi, double cbv, double E, double tol) {
+    const double lo = __hiloint2double((int)hi, 0) + cbv, up = __hiloint2double((int)hi, -1) + cbv;
+    const unsigned long long bal = __ballot(valid && !(up < E - tol));
+    if (!bal) return 0;
+    const double Bf = kvm_readlane_f64(lo, __ffsll((long long)bal) - 1);
+    return (Bf > E + tol) ? 1 : 2;
+}
+
+template <int V, int CSTAR, bool ABANDON, bool EXACT>
+__device__ __forceinline__ void dp_reg_sweep(const double *__restrict__ series, const kvm_query_dev &qd, const kvm_dtw_aux &ax,
+                                             const kvm_cand *__restrict__ in, const dp_plan *__restrict__ plans,
+                                             const unsigned long long *__restrict__ d_n_in, int32_t *__restrict__ out_off,
+                                             double *__restrict__ out_dist, int64_t cap,
+                                             unsigned long long *__restrict__ counters) {
+    using BUF = dp_buf<V>;
+    constexpr int LIN = BUF::LIN, LIVE = BUF::LIVE, NBLK = 64 / V;
     constexpr int WAVE_LDS = 2 * LIN + 64 * V + 64;  // buffer A, buffer B, result scratch, finished row minima
-    __shared__ double lds_all[4 * WAVE_LDS];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ __attribute__((aligned(16))) double lds_all[4 * WAVE_LDS];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     double *bufA = lds_all + wave * WAVE_LDS, *bufB = bufA + LIN, *scratch = bufB + LIN, *bufR = scratch + 64 * V;
+    unsigned *bufR32 = reinterpret_cast<unsigned *>(bufR);
+    char *lds_raw = reinterpret_cast<char *>(lds_all);
     const int m = qd.m, r = qd.rho;
     const double eps2 = qd.eps2;
     const double *__restrict__ Bq = qd.q;
@@ -633,8 +712,8 @@ __global__ __launch_bounds__(256) void kvm_dtw_dp_reg_kernel(const double *__res
     const int pV = lane * V;
     const bool edge_lane = lane == r / V;  // the band-edge cell O[r] is cell CSTAR (= r % V) of this lane
     const int kfin = (r & 1) ? ((r - 1) >> 1) : (r >> 1);  // index of cell (m-1, m-1) (k = r) in O (r odd) / E (r even)
-    const bool exact = ax.cb_exact != nullptr;
     const double tol = 4.0 * ax.tau * eps2;
+    const unsigned INF_HI = (unsigned)__double2hiint(DTW_INF);
     double *__restrict__ patch = ax.patch + (size_t)(blockIdx.x * 4 + wave) * 8 * (size_t)r;
 
     // (one pop per iteration, at most n_in successful pops in the whole grid: the bound is a guard, every wave leaves)
@@ -649,47 +728,49 @@ __global__ __launch_bounds__(256) void kvm_dtw_dp_reg_kernel(const double *__res
         const double mean = cand.mean, sd = cand.std;
         dp_plan pl;
         pl.which = 0; pl.total = 0.0; pl.pad = 0.0; pl.cbeg = pl.cend = pl.sb = 0;
-        if (!exact) {
+        if (!EXACT) {
             pl = plans[idx];
             if (pl.which < 0) continue;  // dropped by the prologue, or queued for the sequential path
             if (pl.which == 1) dp_build_patch(series, r, pl, cand.start, m, lane, patch);
         }
         if (lane == 0) atomicAdd(&counters[KVM_CNT_PASS_KEOGH2], 1ULL);
-        const double *__restrict__ cb_src = exact ? ax.cb_exact + (size_t)idx * 2 * m + (cand.lim != 0.0 ? m : 0) : nullptr;
+        const double *__restrict__ cb_src = EXACT ? ax.cb_exact + (size_t)idx * 2 * m + (cand.lim != 0.0 ? m : 0) : nullptr;
         // prefix of the cb terms below the first index the row test needs (cb[I0 + 1]: chunk Ic covers cb[Ic+1 .. Ic+64])
         double pref = 0.0;
-        if (!exact) {
+        if (!EXACT) {
             for (int base = 0; base <= I0; base += 64) {
                 const int k = base + lane;
                 pref += kvm_wave_sum((k <= I0 && k < m) ? dp_cb_term(x, qd, ax, patch, pl, cand.start, mean, sd, k) : 0.0);
             }
         }
-        // buffer position p holds A[lowA + p] / B[lowB + p]
+        // linear position p of a buffer holds A[lowA + p] / B[lowB + p] (stored at BUF::phys(p))
         int lowA = I0 - LIVE, lowB = I0 - r;
         // zT[k] = (T[k+j] - mean) / std (K/NormQueryEngineDtw.java:564-567); RSM: (x - 0) / 1 == x exactly
         auto fillA = [&](int pos, int cnt) {
             for (int t = lane; t < cnt; t += 64) {
                 const int i = lowA + pos + t;
-                bufA[pos + t] = (i >= 0 && i < m) ? (x[i] - mean) / sd : DTW_POS_BIG;
+                bufA[BUF::phys(pos + t)] = (i >= 0 && i < m) ? (x[i] - mean) / sd : DTW_POS_BIG;
             }
         };
         auto fillB = [&](int pos, int cnt) {
             for (int t = lane; t < cnt; t += 64) {
                 const int j = lowB + pos + t;
-                bufB[pos + t] = (j >= 0 && j < m) ? Bq[j] : DTW_NEG_BIG;
+                bufB[BUF::phys(pos + t)] = (j >= 0 && j < m) ? Bq[j] : DTW_NEG_BIG;
             }
         };
         fillA(0, LIVE + 64);
         fillB(0, LIVE + 64);
 
-        double E[V], O[V], a[V], b[V], R[V];
+        double E[V], O[V], a[V], b[V], R[EXACT ? V : 1];
+        unsigned Rh[EXACT ? 1 : V];
 #pragma unroll
         for (int c = 0; c < V; c++) {
             E[c] = DTW_INF;
             O[c] = DTW_INF;
-            R[c] = DTW_INF;
-            a[c] = c >= 1 ? bufA[I0 - pV - c - lowA] : 0.0;
-            b[c] = bufB[I0 - r + pV + c - lowB];
+            if constexpr (EXACT) R[c] = DTW_INF;
+            else Rh[c] = INF_HI;
+            a[c] = c >= 1 ? bufA[BUF::phys(I0 - pV - c - lowA)] : 0.0;
+            b[c] = bufB[BUF::phys(I0 - r + pV + c - lowB)];
         }
         // seed of cell (0,0): k = r
         if ((r & 1) == 0) {
@@ -701,11 +782,12 @@ __global__ __launch_bounds__(256) void kvm_dtw_dp_reg_kernel(const double *__res
             for (int c = 0; c < V; c++)
                 if (pV + c == ((r - 1) >> 1)) O[c] = 0.0;
         }
-        // read pointers: macro-step I reads A[I - pV] and B[I - r + pV + V]
-        const double *pA = bufA + (I0 - pV - lowA);
-        const double *pB = bufB + (I0 - r + pV + V - lowB);
+        // read groups: the block of macro-steps I .. I+V-1 reads A[I - pV ..] and B[I - r + pV + V ..], i.e. group
+        // ja = (I - pV - lowA) / V of buffer A and jb = (I - r + pV + V - lowB) / V of buffer B (both exact: multiples of V)
+        const double *ja = bufA + BUF::GROUP * ((LIVE - pV) / V), *jb = bufB + BUF::GROUP * (lane + 1);
         // halos: lane 0 (left) / lane 63 (right) never receive from a neighbour, so they keep this initial INF for ever
         double halo_l = DTW_INF, halo_r = DTW_INF, r_in = DTW_INF;
+        unsigned rh_in = INF_HI;
         const double edge_pen = edge_lane ? DTW_INF : 0.0;
         bool done = false;
         double result = DTW_INF;
@@ -713,66 +795,115 @@ __global__ __launch_bounds__(256) void kvm_dtw_dp_reg_kernel(const double *__res
         double value = 0.0;
         int chunk = 0;
 
-        for (int Ic = I0; Ic <= Ilast && !done; Ic += 64) {
-            double *pR = bufR;
-#pragma unroll 1
-            for (int blk = 0; blk < 64 / V && !done; blk++) {
+        // one block of V macro-steps, from macro-step Ib, with the window values (an, bn) fetched for it; CHECKED: the block
+        // that holds macro-step Ilast (cell (m-1, m-1) is read out of it)
+        auto block = [&](auto checked, const double(&an)[V], const double(&bn)[V], const int Ib, const unsigned pr) {
+            constexpr bool CHECKED = decltype(checked)::value;
 #pragma unroll
-                for (int s = 0; s < V; s++) {
-                    const int I = Ic + blk * V + s;
-                    const double a_new = pA[s], b_new = pB[s];
-                    // the row that left this lane's last slot moves on to the next lane; lane 0 starts a new row: it
-                    // never receives, so its r_in keeps the INF it was initialised with (no constant to re-materialise)
-                    r_in = dp_from_left(R[(V - s) % V], r_in);
-                    // ---- E-update (diagonal 2I - r) ----
-                    halo_l = dp_from_left(O[V - 1], halo_l);
+            for (int s = 0; s < V; s++) {
+                const int I = Ib + s;
+                // the row that left this lane's last slot moves on to the next lane; lane 0 starts a new row: it
+                // never receives, so its r_in keeps the INF it was initialised with (no constant to re-materialise)
+                if constexpr (EXACT) r_in = dp_from_left(R[(V - s) % V], r_in);
+                else rh_in = dp_u32_from_left(Rh[(V - s) % V], rh_in);
+                // ---- E-update (diagonal 2I - r) ----
+                halo_l = dp_from_left(O[V - 1], halo_l);
 #pragma unroll
-                    for (int c = V - 1; c >= 0; c--) {
-                        if (c == 0) a[(V - s) % V] = a_new;  // slot of cell 0 at step s
-                        const double av = a[((c - s) % V + V) % V], bv = b[(c + s) % V];
-                        const double dd = (av - bv) * (av - bv);
-                        const double yy = c > 0 ? O[c - 1] : halo_l;
-                        E[c] = dp_min(dp_min(O[c], yy), E[c]) + dd;
-                    }
-                    if ((r & 1) == 0 && I == Ilast) {  // r even: cell (m-1, m-1) is E[r/2] of this update
+                for (int c = V - 1; c >= 0; c--) {
+                    if (c == 0) a[(V - s) % V] = an[s];  // slot of cell 0 at step s
+                    const double av = a[((c - s) % V + V) % V], bv = b[(c + s) % V];
+                    const double dd = (av - bv) * (av - bv);
+                    const double yy = c > 0 ? O[c - 1] : halo_l;
+                    E[c] = dp_min(dp_min(O[c], yy), E[c]) + dd;
+                }
+                if (CHECKED && (r & 1) == 0 && I == Ilast) {  // r even: cell (m-1, m-1) is E[r/2] of this update
 #pragma unroll
-                        for (int c = 0; c < V; c++) scratch[pV + c] = E[c];
-                        result = scratch[kfin];
-                        done = true;
-                    }
-                    // ---- O-update (diagonal 2I - r + 1) ----
-                    halo_r = dp_from_right(E[0], halo_r);
-                    b[s % V] = b_new;  // slot (V + s) % V: query value of O cell V-1, E cell V-1 of the next step
+                    for (int c = 0; c < V; c++) scratch[pV + c] = E[c];
+                    result = scratch[kfin];
+                    done = true;
+                }
+                // ---- O-update (diagonal 2I - r + 1) ----
+                halo_r = dp_from_right(E[0], halo_r);
+                b[s % V] = bn[s];  // slot (V + s) % V: query value of O cell V-1, E cell V-1 of the next step
 #pragma unroll
-                    for (int c = 0; c < V; c++) {
-                        const double av = a[((c - s) % V + V) % V], bv = b[(c + 1 + s) % V];
-                        const double dd = (av - bv) * (av - bv);
-                        const double xx = c < V - 1 ? E[c + 1] : halo_r;
-                        O[c] = dp_min(dp_min(xx, E[c]), O[c]) + dd;
-                    }
-                    if ((r & 1) == 1 && I == Ilast) {
+                for (int c = 0; c < V; c++) {
+                    const double av = a[((c - s) % V + V) % V], bv = b[(c + 1 + s) % V];
+                    const double dd = (av - bv) * (av - bv);
+                    const double xx = c < V - 1 ? E[c + 1] : halo_r;
+                    O[c] = dp_min(dp_min(xx, E[c]), O[c]) + dd;
+                }
+                if (CHECKED && (r & 1) == 1 && I == Ilast) {
 #pragma unroll
-                        for (int c = 0; c < V; c++) scratch[pV + c] = O[c];
-                        result = scratch[kfin];
-                        done = true;
-                    }
-                    // band edge k = 2r+1: O[r] must read as INF (>= 1e20: `edge_pen` is 1e20 in that lane, 0 elsewhere)
-                    O[CSTAR] += edge_pen;
-                    // ---- row minima (slot 0 takes over the row handed in from the left) ----
+                    for (int c = 0; c < V; c++) scratch[pV + c] = O[c];
+                    result = scratch[kfin];
+                    done = true;
+                }
+                // band edge k = 2r+1: O[r] must read as INF (>= 1e20: `edge_pen` is 1e20 in that lane, 0 elsewhere)
+                O[CSTAR] += edge_pen;
+                // ---- row minima (slot 0 takes over the row handed in from the left) ----
+                if constexpr (EXACT) {
 #pragma unroll
                     for (int c = 0; c < V; c++)
                         R[((c - s) % V + V) % V] = dp_min(dp_min(c == 0 ? r_in : R[((c - s) % V + V) % V], E[c]), O[c]);
-                    if (edge_lane) pR[s] = R[((CSTAR - s) % V + V) % V];  // row I - r is complete
+                    if (edge_lane) *reinterpret_cast<double *>(lds_raw + pr + 8 * s) = R[((CSTAR - s) % V + V) % V];  // row I - r is complete
+                } else {
+#pragma unroll
+                    for (int c = 0; c < V; c++)
+                        Rh[((c - s) % V + V) % V] = dp_umin3(c == 0 ? rh_in : Rh[((c - s) % V + V) % V],
+                                                             (unsigned)__double2hiint(E[c]), (unsigned)__double2hiint(O[c]));
+                    if (edge_lane) *reinterpret_cast<unsigned *>(lds_raw + pr + 4 * s) = Rh[((CSTAR - s) % V + V) % V];
                 }
-                pA += V;
-                pB += V;
-                pR += V;
+            }
+        };
+
+        for (int Ic = I0; Ic <= Ilast && !done; Ic += 64) {
+            // blocks of this chunk that lie wholly before macro-step Ilast run unchecked; the one holding Ilast, if it is in
+            // this chunk, is the last block of the candidate
+            const int nb = min(NBLK, (Ilast - Ic) / V);
+            // Register sets of window values: the block in flight computes from set u while the next block's values land in
+            // set u+1 -- and the values of the block before it, which the slots a[] / b[] still hold, stay where they were
+            // fetched (set u-1): three sets in rotation, no copies.  (V = 8 has no registers to spare: one set, fetched
+            // at the top of its block.)
+            constexpr int NSETS = V <= 4 ? 3 : 1;
+            double as[NSETS][V], bs[NSETS][V];
+            BUF::load(ja, 0, as[0]);   // (the first block of a chunk waits for its values: they were filled a moment ago)
+            BUF::load(jb, 0, bs[0]);
+            int blk = 0;
+            // byte offset of the strip of finished row minima, in a VGPR of its own (a uniform address would be re-materialised
+            // from an SGPR in front of every masked store)
+            unsigned pr = (unsigned)((char *)bufR - lds_raw);
+            asm volatile("" : "+v"(pr));
+            constexpr unsigned PR_STEP = V * (EXACT ? 8 : 4);
+            bool more = blk < nb;
+#pragma unroll 1
+            while (more) {
+#pragma unroll
+                for (int u = 0; u < NSETS; u++) {
+                    if (more) {
+                        if constexpr (NSETS > 1) {
+                            BUF::load(ja, 1, as[(u + 1) % NSETS]);   // (the group after the chunk's last is fetched and
+                            BUF::load(jb, 1, bs[(u + 1) % NSETS]);   //  dropped: it lies inside this wave's LDS region)
+                        } else if (blk > 0) {
+                            BUF::load(ja, 0, as[0]);
+                            BUF::load(jb, 0, bs[0]);
+                        }
+                        block(std::false_type{}, as[u], bs[u], Ic + blk * V, pr);
+                        blk++; ja += BUF::GROUP; jb += BUF::GROUP; pr += PR_STEP;
+                        more = blk < nb;
+                    }
+                }
+            }
+            if (nb < NBLK) {
+                BUF::load(ja, 0, as[0]);
+                BUF::load(jb, 0, bs[0]);
+                block(std::true_type{}, as[0], bs[0], Ic + nb * V, pr);
+                ja += BUF::GROUP; jb += BUF::GROUP;
             }
             // ---- row test of the rows finished in macro-steps Ic .. Ic+63 (lane t: row Ic + t - r) ----
             if (decision == 0) {
                 const int I = Ic + lane, k = I + 1;  // needs cb[I + 1]
                 double cbv, term = 0.0;
-                if (exact) {
+                if (EXACT) {
                     cbv = (k < m) ? cb_src[k] : 0.0;
                 } else {
                     term = (k < m) ? dp_cb_term(x, qd, ax, patch, pl, cand.start, mean, sd, k) : 0.0;
@@ -780,7 +911,9 @@ __global__ __launch_bounds__(256) void kvm_dtw_dp_reg_kernel(const double *__res
                     cbv = pl.total - (pref + (inc - term));
                     pref += kvm_readlane_f64(inc, 63);
                 }
-                const int t = dp_row_test(I >= r && I <= m - 2, bufR[lane], cbv, eps2, tol, exact, value);
+                const bool valid = I >= r && I <= m - 2;
+                const int t = EXACT ? dp_row_test(valid, bufR[lane], cbv, eps2, tol, true, value)
+                                    : dp_row_test_hi(valid, bufR32[lane], cbv, eps2, tol);
                 if (t) {
                     decision = t;
                     if (ABANDON) break;
@@ -793,18 +926,18 @@ __global__ __launch_bounds__(256) void kvm_dtw_dp_reg_kernel(const double *__res
                 double ta[V], tb[V];
 #pragma unroll
                 for (int c = 0; c < V; c++) {
-                    ta[c] = bufA[64 * DP_EPOCH + lane + 64 * c];
-                    tb[c] = bufB[64 * DP_EPOCH + lane + 64 * c];
+                    ta[c] = bufA[BUF::phys(64 * DP_EPOCH + lane + 64 * c)];
+                    tb[c] = bufB[BUF::phys(64 * DP_EPOCH + lane + 64 * c)];
                 }
 #pragma unroll
                 for (int c = 0; c < V; c++) {
-                    bufA[lane + 64 * c] = ta[c];
-                    bufB[lane + 64 * c] = tb[c];
+                    bufA[BUF::phys(lane + 64 * c)] = ta[c];
+                    bufB[BUF::phys(lane + 64 * c)] = tb[c];
                 }
                 lowA += 64 * DP_EPOCH;
                 lowB += 64 * DP_EPOCH;
-                pA -= 64 * DP_EPOCH;
-                pB -= 64 * DP_EPOCH;
+                ja -= BUF::GROUP * (64 * DP_EPOCH / V);
+                jb -= BUF::GROUP * (64 * DP_EPOCH / V);
                 chunk = 0;
             }
             // the 64 values the next chunk adds at the front of each window
@@ -827,20 +960,52 @@ __global__ __launch_bounds__(256) void kvm_dtw_dp_reg_kernel(const double *__res
     }
 }
 
+// The kernels.  V <= 4 (rho <= 255): held to 168 VGPRs, three waves per SIMD -- the workgroup's LDS (42 KiB at V = 4)
+// allows three workgroups per CU, and the third wave fills the issue slots the other two leave at s_nop / s_waitcnt
+// (3.87 -> 4.16e12 cells/s on 16 384 full DPs, profiles/r03_ab_dtw.log).  V = 8 needs 224 VGPRs: two waves.
+template <int V, int CSTAR, bool ABANDON, bool EXACT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void kvm_dtw_dp_reg_kernel(
+    const double *__restrict__ series, kvm_query_dev qd, kvm_dtw_aux ax, const kvm_cand *__restrict__ in,
+    const dp_plan *__restrict__ plans, const unsigned long long *__restrict__ d_n_in, int32_t *__restrict__ out_off,
+    double *__restrict__ out_dist, int64_t cap, unsigned long long *__restrict__ counters) {
+    dp_reg_sweep<V, CSTAR, ABANDON, EXACT>(series, qd, ax, in, plans, d_n_in, out_off, out_dist, cap, counters);
+}
+template <int V, int CSTAR, bool ABANDON, bool EXACT>
+__global__ __launch_bounds__(256) void kvm_dtw_dp_reg_wide_kernel(
+    const double *__restrict__ series, kvm_query_dev qd, kvm_dtw_aux ax, const kvm_cand *__restrict__ in,
+    const dp_plan *__restrict__ plans, const unsigned long long *__restrict__ d_n_in, int32_t *__restrict__ out_off,
+    double *__restrict__ out_dist, int64_t cap, unsigned long long *__restrict__ counters) {
+    dp_reg_sweep<V, CSTAR, ABANDON, EXACT>(series, qd, ax, in, plans, d_n_in, out_off, out_dist, cap, counters);
+}
+
 template <int V, int CSTAR>
 static hipError_t launch_dp_reg_c(const double *series, const kvm_query_dev &qd, const kvm_dtw_aux &ax, const kvm_cand *in,
                                   const dp_plan *plans, const unsigned long long *d_n_in, int64_t max_in, int32_t *out_off, double *out_dist,
                                   int64_t cap, unsigned long long *counters, int num_cu, hipStream_t s) {
-    // waves per SIMD = DP_BLOCKS_PER_CU (bounded by LDS: 4 waves x (2*LIN + 64V + 64) doubles per workgroup)
+    // resident workgroups per CU = waves per SIMD: bounded by the LDS (4 waves x (2*LIN + 64V + 64) doubles per workgroup)
+    // and by the registers (three waves for V <= 4, two for V = 8, see the kernels)
     const int lds_limit = (int)((160 * 1024) / (4 * (2 * dp_buf<V>::LIN + 64 * V + 64) * sizeof(double)));
-    int64_t blocks = (int64_t)num_cu * (DP_BLOCKS_PER_CU < lds_limit ? DP_BLOCKS_PER_CU : lds_limit);
+    const int reg_limit = V <= 4 ? 3 : 2;
+    int64_t blocks = (int64_t)num_cu * (reg_limit < lds_limit ? reg_limit : lds_limit);
     if (blocks > (max_in + 3) / 4) blocks = (max_in + 3) / 4;
-    if (qd.early_abandon)
-        hipLaunchKernelGGL((kvm_dtw_dp_reg_kernel<V, CSTAR, true>), dim3((unsigned)blocks), dim3(256), 0, s, series, qd,
-                           ax, in, plans, d_n_in, out_off, out_dist, cap, counters);
-    else
-        hipLaunchKernelGGL((kvm_dtw_dp_reg_kernel<V, CSTAR, false>), dim3((unsigned)blocks), dim3(256), 0, s, series, qd,
-                           ax, in, plans, d_n_in, out_off, out_dist, cap, counters);
+#define KVM_DP_LAUNCH(AB, EX)                                                                                               \
+    do {                                                                                                                     \
+        if constexpr (V <= 4)                                                                                                \
+            hipLaunchKernelGGL((kvm_dtw_dp_reg_kernel<V, CSTAR, AB, EX>), dim3((unsigned)blocks), dim3(256), 0, s, series,   \
+                               qd, ax, in, plans, d_n_in, out_off, out_dist, cap, counters);                                 \
+        else                                                                                                                 \
+            hipLaunchKernelGGL((kvm_dtw_dp_reg_wide_kernel<V, CSTAR, AB, EX>), dim3((unsigned)blocks), dim3(256), 0, s,      \
+                               series, qd, ax, in, plans, d_n_in, out_off, out_dist, cap, counters);                         \
+    } while (0)
+    const bool exact = ax.cb_exact != nullptr;  // the second run, on the sequential path's candidates: exact cb[], full minima
+    if (qd.early_abandon) {
+        if (exact) KVM_DP_LAUNCH(true, true);
+        else KVM_DP_LAUNCH(true, false);
+    } else {
+        if (exact) KVM_DP_LAUNCH(false, true);
+        else KVM_DP_LAUNCH(false, false);
+    }
+#undef KVM_DP_LAUNCH
     return hipGetLastError();
 }
 

@@ -6,7 +6,7 @@ n, m = 10_000_000, 4096
 series = datagen.gen_series(n, seed=4242)
 qoff = n // 3 + 5
 q = series[qoff-1:qoff-1+m].copy()
-L, R = datagen.gen_intervals(n, m, 16384, 64.0, must_cover=[qoff], seed=3)
+L, R = datagen.gen_intervals(n, m, 16383, 64.0, must_cover=[qoff], seed=3)  # 16 384 DPs = 8 full rounds of the 2 048 waves in flight
 ctx = kvmatch.Phase2Context(0); ctx.load_series(series)
 ctx.set_option(kvmatch.OPT_EARLY_ABANDON, 0); ctx.set_option(kvmatch.OPT_LB_CASCADE, 0); ctx.set_option(kvmatch.OPT_TIMING, 1)
 eng = kvmatch.QueryEngineDtw(ctx)
