@@ -29,7 +29,8 @@
  * (ii) a thread_local memo of the ED pruner's launch-shape model.  Nothing else is shared.
  *
  * Environment (read once per process; all optional, none changes an answer):
- *   KVM_ED_KERNEL=1..4   default ED pruning kernel where KVM_OPT_ED_KERNEL is 0 (auto)
+ *   KVM_ED_KERNEL=1|3|4  default ED pruning kernel where KVM_OPT_ED_KERNEL is 0 (auto)
+ *   KVM_ED_GEN=1         the same as KVM_ED_KERNEL=4 (lane-granular tiles staged by LDS-DMA, experimental)
  *   KVM_TRACE=1          per-stage host timings of every call on stderr
  *   KVM_DEBUG_SYNC=1     DTW calls wait for the stream after every stage and name it on stderr
  *   KVM_LIB=<path>       (Python binding only) load another build of this library
@@ -286,9 +287,11 @@ void kvm_result_free(kvm_result *r);
                                     reference does; 0: evaluate every candidate over all m points */
 #define KVM_OPT_LB_CASCADE 2     /* 1 (default): LB_Kim / LB_Keogh screens in front of the exact DTW stage; 0: every
                                     filter-passing candidate goes to the exact stage.  Same answers either way. */
-#define KVM_OPT_ED_KERNEL 3      /* ED pruning kernel: 0 auto (default = 3), 1 wave-per-candidate, 2 LDS-tiled
-                                    direct form, 3 LDS-tiled correlation form, 4 correlation form with the lanes
-                                    along the window (experimental).  All return identical answers. */
+#define KVM_OPT_ED_KERNEL 3      /* ED pruning kernel: 0 auto (default = 3), 1 wave-per-candidate (the cross-check of
+                                    the tests), 3 LDS-tiled correlation form, 4 correlation form on lane-granular
+                                    tiles staged by LDS-DMA (experimental; RSM-ED with every point evaluated, 3
+                                    otherwise).  All return identical answers.  (2 and round 2's 4 were removed in
+                                    round 3 and are refused.) */
 #define KVM_OPT_TIMING 4         /* 1: record HIP-event kernel times into KVM_STAT_KERNEL_NS */
 #define KVM_OPT_DP_KERNEL 5      /* 0 auto (default: register-resident band when rho <= 511), 1 generic LDS form */
 #define KVM_OPT_SORT_VIOLATION 6 /* cNSM-DTW only.  NormQueryEngineDtw sorts its query with a comparator that breaks

@@ -156,7 +156,8 @@ extern "C" int kvm_set_option(kvm_ctx *ctx, int32_t option, int64_t value) {
         case KVM_OPT_EARLY_ABANDON: ctx->opt_early_abandon = value ? 1 : 0; return KVM_OK;
         case KVM_OPT_LB_CASCADE: ctx->opt_lb_cascade = value ? 1 : 0; return KVM_OK;
         case KVM_OPT_ED_KERNEL:
-            if (value < 0 || value > 4) return fail(ctx, KVM_ERR_ILLEGAL_ARGUMENT, "KVM_OPT_ED_KERNEL in {0,1,2,3,4}");
+            if (value != 0 && value != 1 && value != 3 && value != 4)
+                return fail(ctx, KVM_ERR_ILLEGAL_ARGUMENT, "KVM_OPT_ED_KERNEL in {0,1,3,4}");
             ctx->opt_ed_kernel = value;
             return KVM_OK;
         case KVM_OPT_TIMING: ctx->opt_timing = value ? 1 : 0; return KVM_OK;
@@ -922,14 +923,17 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
         HIPCHK(ctx, hipEventSynchronize(ctx->ev_staged));
         ctx->staged_pending = false;
     }
-    // ED pruning kernel: 1 = wave-per-candidate, 2 = LDS-tiled direct form, 3 = LDS-tiled correlation form,
-    // 4 = correlation form with the lanes along the window; 0 = auto (KVM_ED_KERNEL in the environment overrides auto)
+    // ED pruning kernel: 1 = wave-per-candidate (the cross-check), 3 = LDS-tiled correlation form, 4 = correlation form on
+    // lane-granular tiles staged by LDS-DMA (RSM-ED with every point evaluated; otherwise 3); 0 = auto (KVM_ED_KERNEL in the
+    // environment overrides auto).  (2, the direct LDS-tiled form, and round 2's 4, lanes along the window, were removed in
+    // round 3: one cross-check pruner is enough.)
     static const int env_ed_kernel = [] {
         const char *e = getenv("KVM_ED_KERNEL");
         const int v = e ? atoi(e) : 0;
-        return (v >= 1 && v <= 4) ? v : 0;
+        return (v == 1 || v == 3 || v == 4) ? v : 0;
     }();
-    const int ed_kernel = ctx->opt_ed_kernel != 0 ? (int)ctx->opt_ed_kernel : (env_ed_kernel ? env_ed_kernel : 3);
+    const int ed_kernel_opt = ctx->opt_ed_kernel != 0 ? (int)ctx->opt_ed_kernel : (env_ed_kernel ? env_ed_kernel : 3);
+    const int ed_kernel = ed_kernel_opt == 4 ? 3 : ed_kernel_opt;
     auto tp_ = std::chrono::steady_clock::now();
     // 32-candidate tiles for the LDS-tiled kernels (ED pruners, fused DTW lower-bound stage), 64 otherwise
     // (DTW cascade: 64-candidate tiles first, trimmed and cut to <= 32 on the device by kvm_retile_dtw_kernel)
@@ -945,22 +949,19 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
         const char *e = getenv("KVM_ED_GEN");
         return e && e[0] == '1';
     }();
-    const bool gen = !dtw && ed_kernel == 3 && !retile && env_gen;
-    const int32_t tile_max = gen ? 8 : (!dtw && ed_kernel == 4) ? 16 : retile ? KVM_TILE_MAX
-                             : (!dtw && ed_kernel >= 2) ? KVM_TILE_TILED : KVM_TILE_MAX;
+    const bool gen = !dtw && ed_kernel == 3 && !retile && (env_gen || ed_kernel_opt == 4);
+    const int32_t tile_max = gen ? 8 : retile ? KVM_TILE_MAX : (!dtw && ed_kernel == 3) ? KVM_TILE_TILED : KVM_TILE_MAX;
     const bool hybrid = !dtw && ed_kernel == 3 && !retile && !gen;
     // query block: q | (qu | ql for DTW) | pad || (qc | pad | q_pref | q_pref8 | qT for ED) || (zQ sorted | order: cNSM-ED
     // exact pass); the runs follow it in the pinned staging buffer, where build_plan writes them directly
     const int nchunks4 = (m + ED4_JC - 1) / ED4_JC, nchunks8 = (m + ED8_JC - 1) / ED8_JC;
-    const int nchT = (m + JL_CHUNK - 1) / JL_CHUNK;  // lane-transposed copy for kvm_ed_jl.hip
     const size_t qmain = (size_t)m * 8 * (dtw ? 3 : 1) + KVM_SERIES_PAD * sizeof(double);
     // (... | qc_pre: m + 1 running sums of qc, padded to a multiple of 16 B | q_pref16: the chunk sums at 16-point granularity)
     const int n16 = (m + 15) / 16;
     const size_t qpre_bytes = (((size_t)m + 1) * 8 + 15) / 16 * 16, qp16_bytes = ((size_t)n16 + 2) * 16;
     const size_t qdot_old = (size_t)m * 8 + KVM_SERIES_PAD * sizeof(double) + ((size_t)2 * nchunks4 + 1 + nchunks8 + 1) * 16;
     const size_t qdot0 = dtw ? 0 : qdot_old + qpre_bytes + qp16_bytes;
-    const bool use_qT = !dtw && ed_kernel == 4;
-    const size_t qdot = dtw ? 0 : qdot0 + (use_qT ? (size_t)nchT * JL_CHUNK * 8 : 0);
+    const size_t qdot = qdot0;
     const size_t qexact_off = qmain + qdot;
     // DTW: the reference's summation order of the LB_Keogh loops and the query / its envelope in that order
     // (uo | lo | qo | order) behind the main block
@@ -1089,15 +1090,6 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
                     qpref8.size() * 16);
         std::memcpy(hp + qmain + qdot_old, qcpre.data(), qcpre.size() * 8);
         std::memcpy(hp + qmain + qdot_old + qpre_bytes, qpref16.data(), qpref16.size() * 16);
-        if (use_qT) {
-            // qT[chunk][i][lane] = the pair (qc[chunk*1024 + 16*lane + 2i], qc[... + 2i + 1]); zero past m
-            double *qT = (double *)(hp + qmain + qdot0);
-            std::memset(qT + (size_t)(nchT - 1) * JL_CHUNK, 0, JL_CHUNK * sizeof(double));
-            for (int i = 0; i < m; i++) {
-                const int ch = i / JL_CHUNK, r = i % JL_CHUNK, ln = r / 16, pi = (r % 16) / 2;
-                qT[(size_t)ch * JL_CHUNK + ((size_t)pi * 64 + ln) * 2 + (r & 1)] = qcen[i];
-            }
-        }
     }
     const size_t qfirst = (cnsm && !dtw) ? qexact_off : qbytes;  // the exact-pass block is staged later (see below)
     if (dtw) {
@@ -1156,7 +1148,6 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
     qd.q_pref8 = dtw ? nullptr : qd.q_pref + (2 * nchunks4 + 1);
     qd.qc_pre = dtw ? nullptr : (const double *)((const char *)ctx->b_query.p + qmain + qdot_old);
     qd.q_pref16 = dtw ? nullptr : (const double2 *)((const char *)ctx->b_query.p + qmain + qdot_old + qpre_bytes);
-    qd.qT = use_qT ? (const double *)((const char *)ctx->b_query.p + qmain + qdot0) : nullptr;
     qd.qu = dtw ? qd.q + m : nullptr;
     qd.ql = dtw ? qd.q + 2 * (size_t)m : nullptr;
     unsigned long long *counters = (unsigned long long *)ctx->b_counters.p;
@@ -1185,10 +1176,7 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
             HIPCHK(ctx, kvm_launch_ed_dot(ctx->d_series, ctx->d_prefix, ctx->n, qd, tA, pl.n_tiles, tB, pl.n_tiles, tB, 0, surv,
                                           pl.windows, counters, ctx->num_cu, counters + KVM_CNT_TILES_A, out.d_off, out.d_dist, out.cap,
                                           stream));
-        } else if (ed_kernel == 4)
-            HIPCHK(ctx, kvm_launch_ed_jl(ctx->d_series, ctx->d_prefix, ctx->n, qd, d_tiles, n_tiles, surv, pl.windows,
-                                         counters, ctx->num_cu, stream));
-        else if (gen) {
+        } else if (gen) {
             // the series once more, every point minus the first point of its prefix block: the source of the LDS-DMA staging (no
             // register, no VALU between HBM and LDS), 8 B per point; built on first use
             if (!ctx->d_series_sh) {
@@ -1204,9 +1192,6 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
             HIPCHK(ctx, kvm_launch_ed_dot(ctx->d_series, ctx->d_prefix, ctx->n, qd, d_tiles, pl.n_tiles, d_tiles + pl.n_tiles,
                                           pl.n_tiles_b, d_tiles + pl.n_tiles + pl.n_tiles_b, pl.n_tiles_c, surv, pl.windows, counters, ctx->num_cu, nullptr, out.d_off, out.d_dist,
                                           out.cap, stream));
-        else if (ed_kernel == 2)
-            HIPCHK(ctx, kvm_launch_ed_tiled(ctx->d_series, ctx->d_prefix, ctx->n, qd, d_tiles, n_tiles, surv,
-                                            pl.windows, counters, stream));
         else
             HIPCHK(ctx, kvm_launch_ed_wave(ctx->d_series, ctx->d_prefix, ctx->n, qd, d_tiles, n_tiles, surv,
                                            pl.windows, counters, stream));

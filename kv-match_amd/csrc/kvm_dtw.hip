@@ -256,6 +256,9 @@ __device__ __forceinline__ double dp_cb_term(const double *__restrict__ x, const
     return dp_term_d(qd.q[k], U, L, mean, inv);
 }
 
+#ifndef DP_SUM_MODE
+#define DP_SUM_MODE 1
+#endif
 // The cascade in front of the DP for one candidate (K/NormQueryEngineDtw.java:555-587), wave-cooperative.
 __device__ int dp_prologue(const double *__restrict__ series, const kvm_query_dev &qd, const kvm_dtw_aux &ax,
                            const kvm_cand &c, int lane, double *__restrict__ patch, dp_plan &pl) {
@@ -326,7 +329,7 @@ __device__ int dp_prologue(const double *__restrict__ series, const kvm_query_de
         // rest of the terms are summed that way (any order is within tau of the reference's, see kvm_dtw_aux::tau); only if
         // a total does reach the threshold do the scanned rounds go on from here to find where.  (Round 3: the scans were
         // two thirds of the prologue of a surviving candidate, 0.15 ms at m = 4096.)
-        if (base == 0 && !amb1 && !amb2 && m > 256) {
+        if (DP_SUM_MODE && base == 0 && !amb1 && !amb2 && m > 256) {
             double s1 = 0.0, s2 = 0.0;
             for (int b2 = 256; b2 < m; b2 += 256) {
 #pragma unroll
@@ -690,6 +693,12 @@ __device__ __forceinline__ int dp_row_test_hi(bool valid, unsigned hi, double cb
     return (Bf > E + tol) ? 1 : 2;
 }
 
+// A candidate is swept with its row minima on high words first; if the first row that may reach eps^2 cannot be told from
+// a high word (about one candidate in a thousand: the bound of successive rows creeps up on eps^2, so the first row past it
+// is often within 2^-20 of it), the same wave sweeps it again at once with the minima in full -- in the kernel, so that the
+// second sweep hides among the other waves' work instead of adding a launch of lone DPs behind the first.  What is then
+// still within the tolerance of the approximate cb[] goes to the sequential path (ax.ambig).  EXACT: the run on the
+// sequential path's candidates -- exact cb[] (ax.cb_exact), minima in full, the reference's own comparison.
 template <int V, int CSTAR, bool ABANDON, bool EXACT>
 __device__ __forceinline__ void dp_reg_sweep(const double *__restrict__ series, const kvm_query_dev &qd, const kvm_dtw_aux &ax,
                                              const kvm_cand *__restrict__ in, const dp_plan *__restrict__ plans,
@@ -736,13 +745,19 @@ __device__ __forceinline__ void dp_reg_sweep(const double *__restrict__ series, 
         if (lane == 0) atomicAdd(&counters[KVM_CNT_PASS_KEOGH2], 1ULL);
         const double *__restrict__ cb_src = EXACT ? ax.cb_exact + (size_t)idx * 2 * m + (cand.lim != 0.0 ? m : 0) : nullptr;
         // prefix of the cb terms below the first index the row test needs (cb[I0 + 1]: chunk Ic covers cb[Ic+1 .. Ic+64])
-        double pref = 0.0;
+        double pref0 = 0.0;
         if (!EXACT) {
             for (int base = 0; base <= I0; base += 64) {
                 const int k = base + lane;
-                pref += kvm_wave_sum((k <= I0 && k < m) ? dp_cb_term(x, qd, ax, patch, pl, cand.start, mean, sd, k) : 0.0);
+                pref0 += kvm_wave_sum((k <= I0 && k < m) ? dp_cb_term(x, qd, ax, patch, pl, cand.start, mean, sd, k) : 0.0);
             }
         }
+        double result = DTW_INF, value = 0.0;
+        // one sweep of the candidate; full_tag: row minima as doubles (true) or as high words (false).  Returns the decision:
+        // 0 none (`result` = cell (m-1, m-1)), 1 reject, 2 cannot tell, 3 the reference returns `value` at a row (EXACT)
+        auto one = [&](auto full_tag) -> int {
+        constexpr bool FULLMIN = decltype(full_tag)::value;
+        double pref = pref0;
         // linear position p of a buffer holds A[lowA + p] / B[lowB + p] (stored at BUF::phys(p))
         int lowA = I0 - LIVE, lowB = I0 - r;
         // zT[k] = (T[k+j] - mean) / std (K/NormQueryEngineDtw.java:564-567); RSM: (x - 0) / 1 == x exactly
@@ -761,13 +776,13 @@ __device__ __forceinline__ void dp_reg_sweep(const double *__restrict__ series, 
         fillA(0, LIVE + 64);
         fillB(0, LIVE + 64);
 
-        double E[V], O[V], a[V], b[V], R[EXACT ? V : 1];
-        unsigned Rh[EXACT ? 1 : V];
+        double E[V], O[V], a[V], b[V], R[FULLMIN ? V : 1];
+        unsigned Rh[FULLMIN ? 1 : V];
 #pragma unroll
         for (int c = 0; c < V; c++) {
             E[c] = DTW_INF;
             O[c] = DTW_INF;
-            if constexpr (EXACT) R[c] = DTW_INF;
+            if constexpr (FULLMIN) R[c] = DTW_INF;
             else Rh[c] = INF_HI;
             a[c] = c >= 1 ? bufA[BUF::phys(I0 - pV - c - lowA)] : 0.0;
             b[c] = bufB[BUF::phys(I0 - r + pV + c - lowB)];
@@ -790,9 +805,7 @@ __device__ __forceinline__ void dp_reg_sweep(const double *__restrict__ series, 
         unsigned rh_in = INF_HI;
         const double edge_pen = edge_lane ? DTW_INF : 0.0;
         bool done = false;
-        double result = DTW_INF;
         int decision = 0;  // 0 none yet, 1 reject, 2 ambiguous, 3 the reference returns `value` at a row
-        double value = 0.0;
         int chunk = 0;
 
         // one block of V macro-steps, from macro-step Ib, with the window values (an, bn) fetched for it; CHECKED: the block
@@ -804,7 +817,7 @@ __device__ __forceinline__ void dp_reg_sweep(const double *__restrict__ series, 
                 const int I = Ib + s;
                 // the row that left this lane's last slot moves on to the next lane; lane 0 starts a new row: it
                 // never receives, so its r_in keeps the INF it was initialised with (no constant to re-materialise)
-                if constexpr (EXACT) r_in = dp_from_left(R[(V - s) % V], r_in);
+                if constexpr (FULLMIN) r_in = dp_from_left(R[(V - s) % V], r_in);
                 else rh_in = dp_u32_from_left(Rh[(V - s) % V], rh_in);
                 // ---- E-update (diagonal 2I - r) ----
                 halo_l = dp_from_left(O[V - 1], halo_l);
@@ -841,7 +854,7 @@ __device__ __forceinline__ void dp_reg_sweep(const double *__restrict__ series, 
                 // band edge k = 2r+1: O[r] must read as INF (>= 1e20: `edge_pen` is 1e20 in that lane, 0 elsewhere)
                 O[CSTAR] += edge_pen;
                 // ---- row minima (slot 0 takes over the row handed in from the left) ----
-                if constexpr (EXACT) {
+                if constexpr (FULLMIN) {
 #pragma unroll
                     for (int c = 0; c < V; c++)
                         R[((c - s) % V + V) % V] = dp_min(dp_min(c == 0 ? r_in : R[((c - s) % V + V) % V], E[c]), O[c]);
@@ -873,7 +886,7 @@ __device__ __forceinline__ void dp_reg_sweep(const double *__restrict__ series, 
             // from an SGPR in front of every masked store)
             unsigned pr = (unsigned)((char *)bufR - lds_raw);
             asm volatile("" : "+v"(pr));
-            constexpr unsigned PR_STEP = V * (EXACT ? 8 : 4);
+            constexpr unsigned PR_STEP = V * (FULLMIN ? 8 : 4);
             bool more = blk < nb;
 #pragma unroll 1
             while (more) {
@@ -912,8 +925,8 @@ __device__ __forceinline__ void dp_reg_sweep(const double *__restrict__ series, 
                     pref += kvm_readlane_f64(inc, 63);
                 }
                 const bool valid = I >= r && I <= m - 2;
-                const int t = EXACT ? dp_row_test(valid, bufR[lane], cbv, eps2, tol, true, value)
-                                    : dp_row_test_hi(valid, bufR32[lane], cbv, eps2, tol);
+                const int t = FULLMIN ? dp_row_test(valid, bufR[lane], cbv, eps2, tol, EXACT, value)
+                                      : dp_row_test_hi(valid, bufR32[lane], cbv, eps2, tol);
                 if (t) {
                     decision = t;
                     if (ABANDON) break;
@@ -943,6 +956,18 @@ __device__ __forceinline__ void dp_reg_sweep(const double *__restrict__ series, 
             // the 64 values the next chunk adds at the front of each window
             fillA(LIVE + 64 * chunk, 64);
             fillB(LIVE + 64 * chunk, 64);
+        }
+        return decision;
+        };
+        int decision;
+        if constexpr (EXACT) {
+            decision = one(std::true_type{});
+        } else {
+            decision = one(std::false_type{});
+            if (decision == 2) {
+                if (lane == 0) atomicAdd(&counters[KVM_CNT_DP_RERUN], 1ULL);
+                decision = one(std::true_type{});
+            }
         }
         if (decision == 2) {
             dp_emit_ambig(ax, counters, cand, lane);
@@ -997,7 +1022,7 @@ static hipError_t launch_dp_reg_c(const double *series, const kvm_query_dev &qd,
             hipLaunchKernelGGL((kvm_dtw_dp_reg_wide_kernel<V, CSTAR, AB, EX>), dim3((unsigned)blocks), dim3(256), 0, s,      \
                                series, qd, ax, in, plans, d_n_in, out_off, out_dist, cap, counters);                         \
     } while (0)
-    const bool exact = ax.cb_exact != nullptr;  // the second run, on the sequential path's candidates: exact cb[], full minima
+    const bool exact = ax.cb_exact != nullptr;  // the run on the sequential path's candidates: exact cb[], the reference's comparison
     if (qd.early_abandon) {
         if (exact) KVM_DP_LAUNCH(true, true);
         else KVM_DP_LAUNCH(true, false);

@@ -1,12 +1,10 @@
 // kvm_ed.hip -- Euclidean verification kernels (RSM-ED, cNSM-ED) for gfx950.
 //
 // Replaces the inner loops of K/QueryEngine.java:354-362 and K/NormQueryEngine.java:497-521.
-// fp64 throughout.  Two kernels:
-//   * kvm_ed_wave_kernel : one wavefront per candidate window, coalesced 8 B/lane loads of the window
-//     straight from HBM/L2, per-lane partial sums, 64-lane butterfly reduction.  Bound: HBM (isolated
-//     candidates, 8*m B each) or L2 (overlapping candidates of one interval).
-//   * kvm_ed_tiled_kernel: see kvm_ed_tiled.hip -- LDS-tiled, every staged point reused by all
-//     candidates of the tile.
+// fp64 throughout.  kvm_ed_wave_kernel: one wavefront per candidate window, coalesced 8 B/lane loads of the window
+// straight from HBM/L2, per-lane partial sums, 64-lane butterfly reduction.  Bound: HBM (isolated candidates, 8*m B each)
+// or L2 (overlapping candidates of one interval).  Not the default (kvm_ed_dot.hip is): kept as the independent
+// cross-check the tests run every ED case through (KVM_OPT_ED_KERNEL = 1).
 // The decision quantity is dist^2 <= eps^2 exactly as the reference writes it (epsilon*epsilon).
 #include "kvm_internal.h"
 

@@ -231,7 +231,6 @@ struct kvm_query_dev {
     const double2 *q_pref;  // q_pref[t] = { sum_{j < t*ED16_JC} (q_j - q_mean), sum_{j < t*ED16_JC} (q_j - q_mean)^2 }, t = 0 .. 2*ceil(m/ED4_JC)
                             // (class C chunks; a class B chunk is two of them; entries past m hold the totals)
     const double2 *q_pref8; // the same at ED8_JC granularity
-    const double *qT;       // qc zero-padded to whole JL_CHUNKs, lane-transposed for kvm_ed_jl.hip (see there)
     const double *qc_pre;   // [m + 1] qc_pre[k] = sum_{j < k} qc[j] (kvm_ed_g.hip: re-basing a window that crosses a prefix block)
     const double2 *q_pref16; // as q_pref at 16-point granularity: t = 0 .. ceil(m / 16) (kvm_ed_g.hip: chunk lengths vary per unit)
     const double *run_hist; // cNSM: per run, the largest x^2 among the points the reference's running sums of that run pass
@@ -239,17 +238,10 @@ struct kvm_query_dev {
 };
 
 // ED pruners: survivors (decision quantity within the guard band of eps^2, filter within its guard band) are appended
-// to `surv` (count in counters[KVM_CNT_CANDS1]); the exact pass decides.  Wave-per-candidate and LDS-tiled forms.
+// to `surv` (count in counters[KVM_CNT_CANDS1]); the exact pass decides.  Wave-per-candidate form (the cross-check).
 hipError_t kvm_launch_ed_wave(const double *series, const double2 *prefix, int64_t n, const kvm_query_dev &qd,
                               const kvm_tile *tiles, int64_t n_tiles, kvm_surv *surv, int64_t cap,
                               unsigned long long *counters, hipStream_t s);
-hipError_t kvm_launch_ed_tiled(const double *series, const double2 *prefix, int64_t n, const kvm_query_dev &qd,
-                               const kvm_tile *tiles, int64_t n_tiles, kvm_surv *surv, int64_t cap,
-                               unsigned long long *counters, hipStream_t s);
-#define JL_CHUNK 1024  // window points per chunk of the lanes-along-the-window ED pruner
-hipError_t kvm_launch_ed_jl(const double *series, const double2 *prefix, int64_t n, const kvm_query_dev &qd,
-                            const kvm_tile *tiles, int64_t n_tiles, kvm_surv *surv, int64_t cap,
-                            unsigned long long *counters, int num_cu, hipStream_t s);
 #define ED4_JC 160  // chunk lengths of the correlation-form pruner (also the granularity of kvm_query_dev::q_pref / q_pref8 /
 #define ED8_JC 128  // q_pref16): class B (4 candidates per lane), class A (8 per lane), class C (4 per lane, two 16-candidate
 #define ED16_JC 80  // tiles per row)
@@ -377,6 +369,7 @@ hipError_t kvm_launch_dtw_dp(const double *series, int64_t n, const kvm_query_de
 #define KVM_CNT_TILES_C 14
 #define KVM_CNT_AMBIG 15              // DTW: candidates handed to the sequential reference-ordered path
 #define KVM_CNT_UCR_TIES 16           // KVM_OPT_UCR_LOOPS, cNSM-ED: windows handed to the executor's literal distance() loop
+#define KVM_CNT_DP_RERUN 17           // DTW: candidates swept a second time with their row minima in full (see dp_reg_sweep)
 #define KVM_CNT_TOTAL 20
 
 // kvm_index.hip: index build step 1 on the device
