@@ -265,6 +265,21 @@ __device__ int dp_prologue(const double *__restrict__ series, const kvm_query_de
     const int m = qd.m, r = qd.rho;
     const double E = qd.eps2, mean = c.mean, sd = c.std;
     const double *__restrict__ x = series + (c.start - 1);
+#ifdef DP_STAMPS
+    const unsigned long long ts0 = wall_clock64();
+    unsigned long long tsv[4] = {0, 0, 0, 0};
+    int tsn = 0;
+#define DP_STAMP(tag)                                                                                    \
+    do {                                                                                                 \
+        if (tsn < 4) tsv[tsn++] = wall_clock64() - ts0;                                                  \
+        if (tsn == 4 && lane == 0 && blockIdx.x == 0 && (threadIdx.x >> 6) == 0) {                       \
+            printf("stamps kim+chunk %llu patch %llu round %llu totals %llu\n", tsv[0], tsv[1], tsv[2], tsv[3]); \
+            tsn = 5;                                                                                     \
+        }                                                                                                \
+    } while (0)
+#else
+#define DP_STAMP(tag)
+#endif
     if (m >= 6) {  // (below that the reference's bound indexes outside the window; every entry point requires m >= 25)
         const double kim = dref_kim(x, qd.q, m, mean, sd, E);
         if (!(kim <= E)) return DP_REJECT;  // :556
@@ -275,7 +290,9 @@ __device__ int dp_prologue(const double *__restrict__ series, const kvm_query_de
     // ---- the data envelope at the ends of the fetched chunk ----
     dref_chunk(ax, m, c.run, pl.cbeg, pl.cend);
     pl.sb = max(pl.cbeg, pl.cend - 2 * r + 1);
+    DP_STAMP("kim+chunk");
     dp_build_patch(series, r, pl, c.start, m, lane, patch);
+    DP_STAMP("patch");
     // ---- lbKeoghCumulative and lbKeoghDataCumulative: terms in the reference's order, inclusive scans = its partial sums
     // up to rounding.  The two loops are independent of each other (each fills its own cb array from scratch), so they are
     // scanned in the same rounds -- four 64-term chunks of each per round, loads and divisions issued together: a round is
@@ -299,6 +316,17 @@ __device__ int dp_prologue(const double *__restrict__ series, const kvm_query_de
             const double t2 = dp_term_d(ax.qo[ic], U, L, mean, inv_sd);
             d1[h] = i < m ? t1 : 0.0;
             d2[h] = i < m ? t2 : 0.0;
+        }
+        // Past the first round (a candidate whose totals reach eps^2: one of its loops stops somewhere): a round whose own
+        // total leaves both running sums below eps^2 (1 - tau) holds no stop -- the partial sums never decrease -- and is
+        // passed over with two wave reductions instead of eight ordered scans; only the round of the stop is scanned.
+        if (base > 0) {
+            const double r1 = kvm_wave_sum((d1[0] + d1[1]) + (d1[2] + d1[3])), r2 = kvm_wave_sum((d2[0] + d2[1]) + (d2[2] + d2[3]));
+            if ((amb1 || carry1 + r1 < Elo) && (amb2 || carry2 + r2 < Elo)) {
+                if (!amb1) carry1 += r1;
+                if (!amb2) carry2 += r2;
+                continue;
+            }
         }
 #pragma unroll
         for (int h = 0; h < 4; h++) {
@@ -325,26 +353,52 @@ __device__ int dp_prologue(const double *__restrict__ series, const kvm_query_de
         // A candidate that is still in both loops after the first round (the 256 largest |q|, where the loops of a candidate
         // that is going to be dropped nearly always stop) most likely runs them to the end.  Every term is >= 0, so the
         // partial sums never decrease: if the TOTALS stay below eps^2 (1 - tau), no partial sum reached eps^2 and both loops
-        // ran to the end -- and a total needs no ordered scan, just one accumulator per lane and one wave reduction.  The
-        // rest of the terms are summed that way (any order is within tau of the reference's, see kvm_dtw_aux::tau); only if
-        // a total does reach the threshold do the scanned rounds go on from here to find where.  (Round 3: the scans were
-        // two thirds of the prologue of a surviving candidate, 0.15 ms at m = 4096.)
+        // ran to the end -- and a total needs neither the reference's order nor a scan: all m terms of each bound are summed
+        // in NATURAL order, one accumulator per lane and one wave reduction (any order is within tau of the reference's, see
+        // kvm_dtw_aux::tau).  Natural order makes every load of the pass coalesced; the ordered rounds gather x[order[i]] and
+        // the envelope at order[i], one 64-B sector per 8-B value, and with a few thousand candidates in flight the prologue
+        // ran at the L2's transaction rate (0.35 - 0.55 ms per call, round 2).  Only if a total does reach the threshold do
+        // the ordered, scanned rounds go on from here to find where.
+        DP_STAMP("round");
         if (DP_SUM_MODE && base == 0 && !amb1 && !amb2 && m > 256) {
             double s1 = 0.0, s2 = 0.0;
-            for (int b2 = 256; b2 < m; b2 += 256) {
+            // (a window whose data envelope lies wholly inside the fetched chunk -- nearly all of them -- reads the whole-series
+            // envelope without a test per point: four terms of each bound per lane and pass, all their loads in flight together)
+            const bool interior = c.start - r >= pl.cbeg && c.start + m - 1 + r <= pl.cend;
+            if (interior) {
+                const double *__restrict__ eu = ax.env_u + (c.start - 1), *__restrict__ el = ax.env_l + (c.start - 1);
+                for (int b2 = 0; b2 < m; b2 += 256) {
+                    double xv[4], uq[4], lq[4], qv[4], ud[4], ld[4];
 #pragma unroll
-                for (int h = 0; h < 4; h++) {
-                    const int i = b2 + 64 * h + lane, ic = min(i, m - 1);
-                    const int o = ax.order[ic];
-                    const double t1 = dp_term_q(x[o], mean, inv_sd, ax.uo[ic], ax.lo[ic]);
-                    double U, L;
-                    dp_env_at(ax, patch, r, pl, c.start + o, U, L);
-                    const double t2 = dp_term_d(ax.qo[ic], U, L, mean, inv_sd);
-                    s1 += i < m ? t1 : 0.0;
-                    s2 += i < m ? t2 : 0.0;
+                    for (int h = 0; h < 4; h++) {
+                        const int ic = min(b2 + 64 * h + lane, m - 1);
+                        xv[h] = x[ic]; uq[h] = qd.qu[ic]; lq[h] = qd.ql[ic]; qv[h] = qd.q[ic]; ud[h] = eu[ic]; ld[h] = el[ic];
+                    }
+#pragma unroll
+                    for (int h = 0; h < 4; h++) {
+                        const bool in = b2 + 64 * h + lane < m;
+                        const double t1 = dp_term_q(xv[h], mean, inv_sd, uq[h], lq[h]);
+                        const double t2 = dp_term_d(qv[h], ud[h], ld[h], mean, inv_sd);
+                        s1 += in ? t1 : 0.0;
+                        s2 += in ? t2 : 0.0;
+                    }
+                }
+            } else {
+                for (int b2 = 0; b2 < m; b2 += 256) {
+#pragma unroll
+                    for (int h = 0; h < 4; h++) {
+                        const int i = b2 + 64 * h + lane, ic = min(i, m - 1);
+                        const double t1 = dp_term_q(x[ic], mean, inv_sd, qd.qu[ic], qd.ql[ic]);
+                        double U, L;
+                        dp_env_at(ax, patch, r, pl, c.start + ic, U, L);
+                        const double t2 = dp_term_d(qd.q[ic], U, L, mean, inv_sd);
+                        s1 += i < m ? t1 : 0.0;
+                        s2 += i < m ? t2 : 0.0;
+                    }
                 }
             }
-            const double T1 = carry1 + kvm_wave_sum(s1), T2 = carry2 + kvm_wave_sum(s2);
+            const double T1 = kvm_wave_sum(s1), T2 = kvm_wave_sum(s2);
+            DP_STAMP("totals");
             if (T1 < Elo && T2 < Elo) {
                 carry1 = T1;
                 carry2 = T2;
