@@ -203,7 +203,8 @@ double kvm_phase2_time_estimate_ms(int32_t variant, int64_t disjoint_windows, in
  * WALL-CLOCK time of phase 1 so far to its phase-2 estimate, so `lastSegment` -- and with it the candidate list -- differs
  * from run to run; here the caller passes its phase-1 cost so far from a model of its own (`phase1_ms_so_far`: index rows
  * scanned times a constant, say), the phase-2 term is kvm_phase2_time_estimate_ms.  `segment_index` is the loop's `i`,
- * `*last_total_ms` the carried `lastTotalTimeUsageEstimated` (start it at 0, as the reference does).  Returns 1 = stop (the
+ * `*last_total_ms` the carried `lastTotalTimeUsageEstimated` (the reference starts it at Double.MAX_VALUE, :187; any start
+ * value works: nothing stops before i = 5 and every earlier call overwrites it).  Returns 1 = stop (the
  * Java `break`), 0 = go on (and `*last_total_ms` is updated), < 0 for bad arguments. */
 int32_t kvm_phase1_should_stop(int32_t variant, int32_t segment_index, double phase1_ms_so_far, int64_t disjoint_windows,
                                int64_t candidate_offsets, int32_t length, double *last_total_ms);

@@ -1334,7 +1334,9 @@ static int dtw_resolve_ambiguous(kvm_ctx *ctx, const kvm_query_dev &qd, const kv
                                  hipStream_t stream) {
     if (n_ambig <= 0) return KVM_OK;
     const size_t per = (size_t)2 * qd.m * sizeof(double);
-    int64_t batch = std::max<int64_t>(1, (int64_t)(((size_t)1 << 30) / per));
+    // (128 MiB of cb slots per batch: 2 048 candidates at m = 4096 -- a round of the chains' wave slots; the buffer is grow-only
+    //  and stays with the context, so a tie-heavy query must not leave a gigabyte behind)
+    int64_t batch = std::max<int64_t>(1, (int64_t)(((size_t)128 << 20) / per));
     if (batch > n_ambig) batch = n_ambig;
     int rc = ensure(ctx, ctx->b_aux2, (size_t)batch * per + 64);
     if (rc) return rc;

@@ -5,8 +5,20 @@
 // fixes the summation order of the two LB_Keogh loops, but the reference's accept/reject decision at an exact tie with
 // eps^2 depends on it, so the library reproduces it: TimSort as TimSort.sort(a, 0, n, c, null, 0, 0) runs it -- run
 // detection with reversal of strictly descending runs, binary insertion up to minRun, the JDK 8 mergeCollapse rule,
-// trimming by gallopRight / gallopLeft in mergeAt, mergeLo / mergeHi with the adaptive minGallop.  The JDK is a
-// dependency that is not part of the reference tree; this is written from the algorithm as OpenJDK 8 publishes it.
+// trimming by gallopRight / gallopLeft in mergeAt, mergeLo / mergeHi with the adaptive minGallop.
+//
+// Provenance.  The JDK is a dependency that is not part of the reference tree (pom.xml targets Java 8).  The ALGORITHM is
+// Tim Peters' listsort (CPython's Objects/listsort.txt and listobject.c, 2002, PSF licence); java.util.TimSort is Joshua
+// Bloch's port of it, first published in Android / Apache Harmony under the Apache License 2.0 and shipped in OpenJDK 7+
+// (GPLv2 with the Classpath exception).  This file is a restatement written for this library from the published
+// description of that algorithm and of the JDK 8 behaviour it has to reproduce -- the structure and the names of the steps
+// (count_run_and_make_ascending, binary_sort, merge_collapse, gallop_left / gallop_right, merge_lo / merge_hi, MIN_MERGE,
+// MIN_GALLOP) follow the JDK's unavoidably, because what has to be reproduced under a contract-breaking comparator IS
+// the implementation's sequence of comparisons and moves: the order of every comparison, the JDK 8 form of the
+// mergeCollapse invariant (before the 2015 fix of the stack-size bug, JDK-8072909 / de Gouw et al.), and the two places
+// that throw.  No JDK source text is copied; the same algorithm is restated twice more by the test infrastructure (in C
+// and in Python), and tests/test_transliteration.py holds the three to the same permutation and the
+// same throw / no-throw verdict.
 // Two facts a caller can rely on: a sequence with c(a[i], a[i-1]) >= 0 throughout is ONE run and comes back unchanged
 // (every query whose |zQ| never rises by >= 1 between neighbours); and the sort can FAIL -- Java throws
 // IllegalArgumentException("Comparison method violates its general contract!") out of mergeLo / mergeHi, which ends

@@ -29,6 +29,7 @@ public final class Phase2Gpu implements AutoCloseable {
     // optional: TimeSeriesOperator.readTimeSeries from HBM; index build step 1 (see the end of section 3)
     public static native double[] readTimeSeries(long ctx, int left, int length);
     public static native double phase2TimeEstimateMs(int variant, long disjointWindows, long candidateOffsets, int length);
+    public static native boolean phase1ShouldStop(int variant, int segmentIndex, double phase1Ms, long disjointWindows, long candidateOffsets, int length, double[] last);
     public static native long indexRowsBuild(long ctx, int w);
     public static native long indexRowsBuildGrouped(long ctx, int w);
     public static native long indexRowsGroups(long rows);

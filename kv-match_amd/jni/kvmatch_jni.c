@@ -30,6 +30,10 @@ static void throw_for(JNIEnv *env, kvm_ctx *ctx, int rc) {
     (*env)->ThrowNew(env, cls, msg ? msg : "kvmatch error");
 }
 
+static void throw_new(JNIEnv *env, const char *cls_name, const char *msg) {
+    (*env)->ThrowNew(env, (*env)->FindClass(env, cls_name), msg);
+}
+
 JNIEXPORT jlong JNICALL Java_cn_edu_fudan_dsm_kvmatch_gpu_Phase2Gpu_open(JNIEnv *env, jclass c, jint device) {
     (void)c;
     kvm_ctx *ctx = 0;
@@ -183,6 +187,25 @@ JNIEXPORT jdouble JNICALL Java_cn_edu_fudan_dsm_kvmatch_gpu_Phase2Gpu_phase2Time
         jlong windows, jlong offsets, jint length) {
     (void)env; (void)c;
     return kvm_phase2_time_estimate_ms(variant, windows, offsets, length);
+}
+
+/* the early-termination test itself (K/QueryEngine.java:321-326); last[0] carries lastTotalTimeUsageEstimated */
+JNIEXPORT jboolean JNICALL Java_cn_edu_fudan_dsm_kvmatch_gpu_Phase2Gpu_phase1ShouldStop(JNIEnv *env, jclass c, jint variant,
+        jint segmentIndex, jdouble phase1Ms, jlong windows, jlong offsets, jint length, jdoubleArray last) {
+    (void)c;
+    if (!last || (*env)->GetArrayLength(env, last) < 1) {
+        throw_new(env, "java/lang/IllegalArgumentException", "phase1ShouldStop: last must hold one double");
+        return 0;
+    }
+    jdouble v = 0;
+    (*env)->GetDoubleArrayRegion(env, last, 0, 1, &v);
+    const int32_t rc = kvm_phase1_should_stop(variant, segmentIndex, phase1Ms, windows, offsets, length, &v);
+    if (rc < 0) {
+        throw_new(env, "java/lang/IllegalArgumentException", "phase1ShouldStop: unknown variant");
+        return 0;
+    }
+    (*env)->SetDoubleArrayRegion(env, last, 0, 1, &v);
+    return (jboolean)(rc ? 1 : 0);
 }
 
 /* Index build step 1 (K/IndexBuilder.java:186-300): build, bulk accessors, free */

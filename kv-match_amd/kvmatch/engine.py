@@ -124,7 +124,7 @@ def phase2_time_estimate_ms(variant, disjoint_windows, candidate_offsets, length
 def phase1_should_stop(variant, segment_index, phase1_ms_so_far, disjoint_windows, candidate_offsets, length, last_total_ms):
     """The early-termination test of the phase-1 loop (K/QueryEngine.java:316-327) with a caller-supplied, deterministic
     phase-1 cost instead of the reference's wall clock.  Returns ``(stop, last_total_ms)``: carry the second value into the
-    next call (start at 0.0)."""
+    next call (any start value: nothing stops before segment 5 and every earlier call overwrites it)."""
     last = C.c_double(float(last_total_ms))
     rc = _lib.load().kvm_phase1_should_stop(int(variant), int(segment_index), float(phase1_ms_so_far), int(disjoint_windows),
                                             int(candidate_offsets), int(length), C.byref(last))

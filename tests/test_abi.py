@@ -147,7 +147,7 @@ def test_jni_shim_type_checks_and_signatures_match_the_java_natives():
     assert "GetPrimitiveArrayCritical" not in src
     java = open(os.path.join(root, "kv-match_amd", "java", "cn", "edu", "fudan", "dsm", "kvmatch", "gpu", "Phase2Gpu.java")).read()
     java = re.sub(r"/\*.*?\*/|//[^\n]*", "", java, flags=re.S)
-    jmap = {"int": "jint", "long": "jlong", "double": "jdouble", "void": "void", "String": "jstring", "int[]": "jintArray",
+    jmap = {"int": "jint", "long": "jlong", "double": "jdouble", "boolean": "jboolean", "void": "void", "String": "jstring", "int[]": "jintArray",
             "double[]": "jdoubleArray", "byte[]": "jbyteArray", "Result": "jobject"}
     natives = {}
     for mods, ret, name, params in re.findall(r"((?:public|private|static|final|\s)*)\bnative\s+([\w\[\]]+)\s+(\w+)\s*\(([^)]*)\)", java):
