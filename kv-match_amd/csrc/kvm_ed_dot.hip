@@ -43,6 +43,18 @@ typedef double ed4_d2 __attribute__((ext_vector_type(2)));
 #ifndef EDD_PD
 #define EDD_PD 1  // sub-steps between an LDS read of the hot loop and its first use (1 or 3)
 #endif
+// Class A (64-candidate tiles) stages its rows as a STREAM (round 3): a row of the wave's LDS is a ring of 128 points with an
+// 80-point lookahead region behind it; every 16 window points each lane fetches ONE 16-byte piece (two points of its own
+// row, four blocks ahead) and writes it where the ring has just gone dead -- 8 global loads and 13 LDS writes per 128 points
+// instead of 27 + 27 per chunk (a chunk re-staged the 64 points it shares with its neighbour and restarted the register
+// ring).  The arithmetic is unchanged: the same products accumulate in the same order.
+#ifndef EDD_RING
+#define EDD_RING 1
+#endif
+#define EDD_RING_LEN 128                     // points of the ring (= ED8_JC: one chunk is one revolution, all addresses static)
+#define EDD_RING_AHEAD 80                    // lookahead region [128, 208): the start of the next revolution (>= 64 + 8 window points)
+#define EDD_RING_D 4                         // blocks a global load is issued ahead of its LDS write
+typedef double ed4_d2u __attribute__((ext_vector_type(2), aligned(8)));
 
 #define EDD_ROWS 8
 #define EDD_ROWLEN 192                       // staged points per row per chunk (both configurations)
@@ -58,6 +70,8 @@ static_assert(ED16_JC + 16 <= EDD_SUB_LEN && 2 * EDD_SUB_LEN == EDD_ROWLEN && ED
 static_assert(EDD_SUB_OFF >= EDD_SUB_LEN && EDD_SUB_OFF + EDD_SUB_LEN + 2 <= EDD_RS && (EDD_SUB_OFF * 8) % 256 == 128, "class-C half rows");
 static_assert(4 * EDD_WAVE_LDS * 8 <= 65536 && EDD_WAVE_LDS % 2 == 0 && EDD_RS % 2 == 0 && (EDD_RS * 8) % 256 == 0, "LDS");
 static_assert(ED4_JC % 16 == 0 && ED8_JC % 16 == 0 && ED16_JC % 16 == 0, "chunks are whole groups of 16 points (4 sub-steps of the register ring)");
+static_assert(EDD_RING_LEN == ED8_JC && EDD_RING_LEN + EDD_RING_AHEAD + 6 <= EDD_RS && EDD_RING_LEN + 16 <= EDD_ROWLEN && EDD_RING_AHEAD >= 72 + 8,
+              "ring + lookahead fit a row; the query ring + its lookahead fit the query region");
 
 template <int CI, int SUB>
 struct edd_cfg {
@@ -320,9 +334,46 @@ __device__ __forceinline__ void edd_body(const edd_args &A, const kvm_tile *__re
 #pragma unroll
     for (int a = 0; a < CI; a++) acc[a] = 0.0;
     const int ch_lo = nchunks * part / f, ch_hi = nchunks * (part + 1) / f;
+    constexpr bool RINGED = EDD_RING && CI == 8 && SUB == 1;
+    // ---- stream staging (class A): lane = 8 row + piece stages points 2 piece, 2 piece + 1 of every 16-point block of its row
+    const double *gsrc = series + ((int64_t)mine.start - 1 + 2 * lc);               // + point index of the block
+    double *wdst = wlds + row * EDD_RS + cfg::row_shift(row) + 2 * lc;               // + position in the row
+    ed4_d2 st[EDD_RING_D], qst[2];
+    auto ring_ld = [&](int j) -> ed4_d2 {   // block at window point j (unguarded: the series is padded, KVM_SERIES_PAD)
+        const ed4_d2u v = *reinterpret_cast<const ed4_d2u *>(gsrc + j);
+        return ed4_d2{v.x, v.y};
+    };
+    auto ring_wr = [&](ed4_d2 v, int pos, bool ring, bool ahead) {
+        v.x -= c_row;
+        v.y -= c_row;
+        if (ring) *reinterpret_cast<ed4_d2 *>(wdst + pos) = v;
+        if (ahead) *reinterpret_cast<ed4_d2 *>(wdst + EDD_RING_LEN + pos) = v;
+    };
+    auto ring_ldq = [&](int j) -> ed4_d2 {  // 64 query values from point j: lanes 0..31, two each (qc is padded like the series)
+        const ed4_d2u v = *reinterpret_cast<const ed4_d2u *>(qc + j + 2 * (lane & 31));
+        return ed4_d2{v.x, v.y};
+    };
+    auto ring_wrq = [&](ed4_d2 v, int pos, bool ahead) {   // ahead: the first 16 also behind the ring (the next revolution's start)
+        if (lane < 32) *reinterpret_cast<ed4_d2 *>(qlds + pos + 2 * lane) = v;
+        if (ahead && lane < 8) *reinterpret_cast<ed4_d2 *>(qlds + EDD_RING_LEN + 2 * lane) = v;
+    };
     if (work && ch_lo < ch_hi) {
-        load_chunk(ch_lo * JC);
-        store_chunk();
+        if constexpr (RINGED) {
+            const int jb = ch_lo * JC;
+            ed4_d2 p6[6];
+#pragma unroll
+            for (int b = 0; b < 6; b++) p6[b] = ring_ld(jb + 16 * b);
+            const ed4_d2 q0v = ring_ldq(jb);
+#pragma unroll
+            for (int b = 0; b < EDD_RING_D; b++) st[b] = ring_ld(jb + 16 * (6 + b));
+            qst[0] = ring_ldq(jb + 64);
+#pragma unroll
+            for (int b = 0; b < 6; b++) ring_wr(p6[b], 16 * b, true, false);
+            ring_wrq(q0v, 0, false);
+        } else {
+            load_chunk(ch_lo * JC);
+            store_chunk();
+        }
     }
     const ed4_d2 *X2 = reinterpret_cast<const ed4_d2 *>(lds_wave2) +
                        (row * (EDD_RS / 2) + cfg::row_shift(row) / 2 + sub * (EDD_SUB_OFF / 2) + (CI / 2) * lc);
@@ -330,9 +381,83 @@ __device__ __forceinline__ void edd_body(const edd_args &A, const kvm_tile *__re
     for (int ch = ch_lo; work && ch < ch_hi; ch++) {
         const int j0 = ch * JC;
         const bool more = ch + 1 < ch_hi;
-        if (more) load_chunk(j0 + JC);
+        if (!RINGED && more) load_chunk(j0 + JC);
         const int jlim = min(JC, m - j0);
-        if (jlim == JC) {
+        if (RINGED && jlim == JC) {
+            if constexpr (RINGED) {
+                // One revolution of the ring = one chunk of 128 points = 8 blocks of 16 points = 32 sub-steps, all unrolled:
+                // every LDS address and every register index is a compile-time constant.  At the start the rows hold the
+                // points [j0, j0 + 96); block B's turn writes points [j0 + 16 (B + 6), + 16) -- fetched four blocks ago --
+                // where the ring went dead two blocks ago (and, for the blocks that start the next revolution, behind the
+                // ring as well, where this revolution's last sub-steps read them), then fetches the block four further on.
+                constexpr int NP = CI / 2 + 2, PD = 1, RING = 8, U = RING / 2, NQ = PD + 1;
+                constexpr int AH = NP + 2 * (PD - 1);
+                ed4_d2 R[RING], Q[NQ][2];
+#pragma unroll
+                for (int j = 0; j < AH; j++) R[j] = X2[j];
+                Q[0][0] = Q2[0];
+                Q[0][1] = Q2[1];
+#pragma unroll
+                for (int B = 0; B < 8; B++) {
+                    {
+                        const int wb = (B + 6) & 7;   // ring block the write goes to
+                        ring_wr(st[B % EDD_RING_D], 16 * wb, true, 16 * wb < EDD_RING_AHEAD);
+                        st[B % EDD_RING_D] = ring_ld(j0 + 16 * (B + 6 + EDD_RING_D));
+                        if (B == 1) {   // the second half of this revolution's query values; fetch the next revolution's first half
+                            ring_wrq(qst[0], 64, false);
+                            qst[1] = ring_ldq(j0 + 128);
+                        }
+                        if (B == 5) {   // the next revolution's first half (its first 16 values are read by this revolution's end)
+                            ring_wrq(qst[1], 0, true);
+                            qst[0] = ring_ldq(j0 + 192);
+                        }
+                    }
+#pragma unroll
+                    for (int g = 0; g < U; g++) {
+                        const int G = B * U + g;
+                        R[(2 * g + AH) % RING] = X2[2 * G + AH];
+                        R[(2 * g + AH + 1) % RING] = X2[2 * G + AH + 1];
+                        Q[(g + PD) % NQ][0] = Q2[2 * (G + PD)];
+                        Q[(g + PD) % NQ][1] = Q2[2 * (G + PD) + 1];
+                        asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]),
+                                     "+v"(acc[6]), "+v"(acc[7])::"memory");
+                        const ed4_d2 q0 = Q[g % NQ][0], q1 = Q[g % NQ][1];
+#define EDD_W(k) (((k) & 1) ? R[(2 * g + (k) / 2) % RING].y : R[(2 * g + (k) / 2) % RING].x)
+#pragma unroll
+                        for (int a = 0; a < CI; a++) acc[a] = __builtin_fma(EDD_W(a), q0.x, acc[a]);
+#pragma unroll
+                        for (int a = 0; a < CI; a++) acc[a] = __builtin_fma(EDD_W(a + 1), q0.y, acc[a]);
+#pragma unroll
+                        for (int a = 0; a < CI; a++) acc[a] = __builtin_fma(EDD_W(a + 2), q1.x, acc[a]);
+#pragma unroll
+                        for (int a = 0; a < CI; a++) acc[a] = __builtin_fma(EDD_W(a + 3), q1.y, acc[a]);
+#undef EDD_W
+                    }
+                }
+            }
+        } else if (RINGED) {
+            if constexpr (RINGED) {
+                // the last, partial chunk of the window: the rows hold [j0, j0 + 96); the points up to j0 + jlim + 72 go BEHIND
+                // each other in the lookahead region, so that the row is linear from the ring's start (nothing of this chunk
+                // may be overwritten), and the query values [j0 + 64, j0 + 128) arrive in place
+                const ed4_d2 e10 = ring_ld(j0 + 160), e11 = ring_ld(j0 + 176), e12 = ring_ld(j0 + 192);
+                ring_wr(st[0], 96, true, false);
+                ring_wr(st[1], 112, true, false);
+                ring_wr(st[2], 0, false, true);
+                ring_wr(st[3], 16, false, true);
+                ring_wr(e10, 32, false, true);
+                ring_wr(e11, 48, false, true);
+                ring_wr(e12, 64, false, true);
+                ring_wrq(qst[0], 64, false);
+                asm volatile("" ::: "memory");
+                const double *X = reinterpret_cast<const double *>(X2);
+                for (int jj = 0; jj < jlim; jj++) {
+                    const double qv = qlds[jj];
+#pragma unroll
+                    for (int a = 0; a < CI; a++) acc[a] = __builtin_fma(X[jj + a], qv, acc[a]);
+                }
+            }
+        } else if (jlim == JC) {
             // Window registers: a ring of RING pairs, R[p % RING] = (X[c0 + 2p], X[c0 + 2p + 1]).  Sub-step G (4 points)
             // reads pairs 2G .. 2G + CI/2 + 1 and, before its arithmetic, issues the LDS reads of the two window pairs and
             // the two query pairs that sub-step G + PD will add -- into ring slots that died PD sub-steps earlier.  RING/2
@@ -440,7 +565,7 @@ __device__ __forceinline__ void edd_body(const edd_args &A, const kvm_tile *__re
                     break;  // split unit: the other parts wait at the barrier below
                 }
             }
-            store_chunk();
+            if (!RINGED) store_chunk();
         }
     }
     if (f > 1) {
