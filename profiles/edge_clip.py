@@ -16,8 +16,10 @@ def run(fn):
         return ("ok", fn())
     except (kvmatch.KvMatchIllegalArgument,) as e:
         return ("illegal", None)
+    except kvmatch.KvMatchIndexOutOfBounds as e:   # (round 3: where the reference ends in ArrayIndexOutOfBounds)
+        return ("oob", None)
     except oracle.OracleError as e:
-        return ("illegal" if e.code == -2 else f"oracle{e.code}", None)
+        return ({-2: "illegal", -8: "oob"}.get(e.code, f"oracle{e.code}"), None)
 for case in range(int(sys.argv[1]) if len(sys.argv) > 1 else 300):
     n = int(rng.integers(2_000, 60_000)); s = base[int(rng.integers(0, 200_000)):][:n].copy()
     m = int(rng.choice([25, 50, 128, 700, 1500])); m = min(m, n)

@@ -14,6 +14,7 @@ def same(tag, a, o):
 base = datagen.gen_series(400_000, seed=9)
 ctx = kvmatch.Phase2Context(0)
 ctx.set_option(kvmatch.OPT_SORT_VIOLATION, 1); oracle.set_lenient_sort(True)  # compare the arithmetic also where the reference's sort throws
+ctx.set_option(kvmatch.OPT_STRICT_BOUNDS, 0); oracle.set_strict_bounds(False)   # ... and where it ends in ArrayIndexOutOfBounds (rho >= m below)
 s = base[:50_000].copy(); ctx.load_series(s)
 rng = np.random.default_rng(3)
 cnt = 0
@@ -35,6 +36,7 @@ print("tiny m:", cnt, "verifications, bad", bad, flush=True)
 def worker(tid, out):
     c = kvmatch.Phase2Context(0)
     c.set_option(kvmatch.OPT_SORT_VIOLATION, 1); oracle.set_lenient_sort(True)  # compare the arithmetic also where the reference's sort throws
+    c.set_option(kvmatch.OPT_STRICT_BOUNDS, 0)
     ss = base[tid * 100_000: tid * 100_000 + 150_000].copy()
     c.load_series(ss)
     r = np.random.default_rng(tid)

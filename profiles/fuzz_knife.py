@@ -82,7 +82,7 @@ with kvmatch.Phase2Context(0) as ctx:
                 total += 1
                 try:
                     r = lib(e, a, b); ares = (sorted(zip(r.distances.tolist(), r.offsets.tolist())), r.cnt_candidate)
-                except kvmatch.KvMatchIllegalArgument:
+                except (kvmatch.KvMatchIllegalArgument, kvmatch.KvMatchIndexOutOfBounds):
                     ares = "EXC"
                 try:
                     oo = orc(e, a, b); ores = (sorted(zip(oo[1].tolist(), oo[0].tolist())), oo[2]["cnt_candidate"])

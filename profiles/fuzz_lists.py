@@ -51,17 +51,19 @@ with kvmatch.Phase2Context(0) as ctx:
             try:
                 r = lib(); ares = sorted(zip(r.distances.tolist(), r.offsets.tolist())), r.cnt_candidate
             except kvmatch.KvMatchIllegalArgument as e:
-                ares = "EXC"
+                ares = "EXC illegal argument"
+            except kvmatch.KvMatchIndexOutOfBounds as e:   # (round 3: where the reference ends in ArrayIndexOutOfBounds)
+                ares = "EXC index out of bounds"
             try:
                 o = orc(); ores = sorted(zip(o[1].tolist(), o[0].tolist())), o[2]["cnt_candidate"]
-            except oracle.OracleError:
-                ores = "EXC"
-            if ares == "EXC" or ores == "EXC":
+            except oracle.OracleError as e:
+                ores = {-2: "EXC illegal argument", -8: "EXC index out of bounds"}.get(e.code, f"EXC {e.code}")
+            if isinstance(ares, str) or isinstance(ores, str):
                 exc += 1
             if ares != ores:
                 bad += 1
                 from collections import Counter
-                if ares != "EXC" and ores != "EXC":
+                if not isinstance(ares, str) and not isinstance(ores, str):
                     ca, co = Counter(ares[0]), Counter(ores[0])
                     only_lib, only_orc = list((ca - co).elements())[:6], list((co - ca).elements())[:6]
                     detail = f"answers {len(ares[0])} vs {len(ores[0])} cnt {ares[1]} vs {ores[1]}; only lib {only_lib}; only oracle {only_orc}"
