@@ -1191,12 +1191,6 @@ int64_t kvo_query_cnsm_dtw(const double *series, int n, const double *queryData,
                            const int32_t *left, const int32_t *right, int k, int shift, double epsilon, int rho,
                            double alpha, double beta, int32_t *out_off, double *out_dist, int64_t cap,
                            int64_t *stats) {
-    /* GUARD (not in the Java code): the chunk loop below indexes the fetched chunk with `left - begin`.  The engines only
-     * ever pass the list sortAndMergeIntervals leaves (sorted by left, K/QueryEngine.java:664-693); on a list that is not
-     * sorted by left Java ends in the range check of readTimeSeries or in an IndexOutOfBoundsException, depending on the
-     * list, and C would read outside the chunk.  Reported as the IllegalArgument case (the library does the same). */
-    for (int p = 1; p < k; p++)
-        if (left[p] < left[p - 1]) return KVO_ERR_ILLEGAL_ARGUMENT;
     kvo_answers answers = {out_off, out_dist, cap, 0, 0};
     int64_t cntCandidate = 0, windows = 0, passed = 0, pKim = 0, pK1 = 0, pK2 = 0, cells = 0;
 
@@ -1233,6 +1227,17 @@ int64_t kvo_query_cnsm_dtw(const double *series, int n, const double *queryData,
             tmpQ[i].index = i;
         }
     }
+    /* GUARD (not in the Java code): the chunk loop below indexes the fetched chunk with `left - begin`.  The engines only
+     * ever pass the list sortAndMergeIntervals leaves (sorted by left, K/QueryEngine.java:664-693); on a list that is not
+     * sorted by left Java ends in the range check of readTimeSeries or in an IndexOutOfBoundsException, depending on the
+     * list, and C would read outside the chunk.  Reported as the IllegalArgument case (the library does the same) -- HERE,
+     * where Java first touches the list: behind the query envelope (:469) and the sort (:475), whose own exceptions come
+     * first (round 3: profiles/fuzz_lists.py `wide` found the guard in front of them). */
+    for (int p = 1; p < k; p++)
+        if (left[p] < left[p - 1]) {
+            free(zQ); free(u); free(l); free(tmpQ);
+            return KVO_ERR_ILLEGAL_ARGUMENT;
+        }
     int *order = (int *)malloc((size_t)queryLength * sizeof(int));
     double *qo = (double *)malloc((size_t)queryLength * sizeof(double));
     double *uo = (double *)malloc((size_t)queryLength * sizeof(double));

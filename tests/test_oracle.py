@@ -344,3 +344,33 @@ def test_ucr_dtw_executor_reads_stale_cb_entries_at_exact_ties(built):
     assert np.array_equal(eo - 1, g["engine_off"]) and np.array_equal(ed, g["engine_dist"]) and len(eo) == 14
     executor, engine = set(zip(uo.tolist(), ud.tolist())), set(zip((eo - 1).tolist(), ed.tolist()))
     assert executor < engine and all(d == eps for _, d in engine - executor)
+
+
+def test_cnsm_dtw_exceptions_come_in_the_reference_order(built):
+    """K/NormQueryEngineDtw.java: the query envelope (:469, ArrayIndexOutOfBounds when rho >= m) and the sort (:475, may
+    throw IllegalArgument) come before the interval list is touched; the oracle's guard for lists not sorted by left (not in
+    the Java code) stands where Java first reads the list, behind both."""
+    import oracle
+    from kvmatch import datagen
+    s = datagen.gen_series(20_000, seed=3)
+    m = 100
+    q = s[5_000:5_000 + m].copy()
+    unsorted = (np.array([5_100, 4_990], np.int32), np.array([5_120, 5_010], np.int32))
+    with pytest.raises(oracle.OracleError) as ei:
+        oracle.cnsm_dtw(s, q, unsorted[0], unsorted[1], 0, 3.0, m + 7, 1.5, 5.0)
+    assert ei.value.code == -8
+    with pytest.raises(oracle.OracleError) as ei:
+        oracle.cnsm_dtw(s, q, unsorted[0], unsorted[1], 0, 3.0, 10, 1.5, 5.0)
+    assert ei.value.code == -2
+    rng = np.random.default_rng(1)
+    for _ in range(200):          # a query on which JDK 8's TimSort throws: IllegalArgument either way, before the list matters
+        qn = rng.standard_normal(m)
+        try:
+            oracle.cnsm_dtw_order((qn - qn.mean()) / qn.std())
+        except oracle.OracleError:
+            break
+    else:
+        pytest.skip("no throwing query found")
+    with pytest.raises(oracle.OracleError) as ei:
+        oracle.cnsm_dtw(s, qn, unsorted[0], unsorted[1], 0, 3.0, 10, 1.5, 5.0)
+    assert ei.value.code == -2

@@ -136,6 +136,14 @@ def test_dtw_engines_die_where_the_reference_does(world):
                 orc(good, r)
             assert ei.value.code == -8, name
         compare(lib(good, m - 1), orc(good, m - 1), tag=f"{name} rho = m - 1")
+        # ... and that comes before the list is looked at: an unsorted list (refused as such by the cNSM entry points, sorted
+        # by the RSM ones) does not change the exception (round 3: the oracle's guard stood in front of the envelope)
+        unsorted = (arr(5_100, 4_990), arr(5_120, 5_010))
+        with pytest.raises(kvmatch.KvMatchIndexOutOfBounds):
+            lib(unsorted, m + 7)
+        with pytest.raises(oracle.OracleError) as ei:
+            orc(unsorted, m + 7)
+        assert ei.value.code == -8, name
         # stubs
         with pytest.raises(kvmatch.KvMatchIndexOutOfBounds, match="^-10$"):
             lib(stub_oob, rho)
