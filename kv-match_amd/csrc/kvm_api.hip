@@ -867,7 +867,10 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
     if (!(epsilon >= 0)) return fail(ctx, KVM_ERR_ILLEGAL_ARGUMENT, "epsilon must be >= 0");
     const bool cnsm = variant == V_CNSM_ED || variant == V_CNSM_DTW;
     const bool dtw = variant == V_RSM_DTW || variant == V_CNSM_DTW;
-    if (cnsm && !(alpha > 0)) return fail(ctx, KVM_ERR_ILLEGAL_ARGUMENT, "alpha must be > 0");
+    // (the REPLs refuse `alpha <= 0.0` (K/NormQueryEngine.java:139-142); a NaN passes that test, and in the engine neither
+    //  `std / stdQ <= alpha` nor `>= 1 / alpha` holds for it (:511): no answers -- the guarded filters keep every candidate
+    //  (a NaN compares false) and the exact (alpha, beta) test, which is the reference's own, drops them all)
+    if (cnsm && alpha <= 0) return fail(ctx, KVM_ERR_ILLEGAL_ARGUMENT, "alpha must be > 0");
     if (dtw && rho < 0) return fail(ctx, KVM_ERR_ILLEGAL_ARGUMENT, "rho must be >= 0");
     // ---- query-side constants (host, sequential, exactly the reference's arithmetic) ----
     std::vector<double> q(query, query + m), qu, ql;

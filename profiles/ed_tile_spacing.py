@@ -13,12 +13,14 @@ q = s[n // 3: n // 3 + m].copy()
 ctx = kvmatch.Phase2Context(0); ctx.load_series(s)
 ctx.set_option(kvmatch.OPT_EARLY_ABANDON, 0); ctx.set_option(kvmatch.OPT_TIMING, 1)
 eng = kvmatch.QueryEngine(ctx)
-for spacing in (66, 80, 128, 256, 512, 1024, 2048, 4096, 6390):
+WARM = 3000
+for spacing in [int(x) for x in os.environ.get("SPACINGS", "66,80,128,256,512,1024,2048,4096,6390").split(",")]:
     starts = 1 + np.arange(runs, dtype=np.int64) * spacing
     left = starts.astype(np.int32); right = (starts + L - 1).astype(np.int32)
-    for _ in range(3): r = eng.verify((left, right), 1, q, 10.0)
+    for _ in range(WARM): r = eng.verify((left, right), 1, q, 10.0)   # (the first configuration also brings the clocks up: ~1 s of load)
+    WARM = 5
     ks = []
-    for _ in range(8):
+    for _ in range(20):
         r = eng.verify((left, right), 1, q, 10.0); ks.append(r.stats[kvmatch.STAT_KERNEL_NS] / 1e6)
     k = float(np.median(ks))
     print(f"runs of {L} every {spacing:5d} points ({spacing * 8:6d} B; footprint {(runs * spacing + m) * 8 / 1e6:7.1f} MB): kernel {k:.4f} ms  {2 * m * runs * L / k / 1e9:.1f} TFLOP/s", flush=True)

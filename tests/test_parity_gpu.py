@@ -105,6 +105,21 @@ def test_rsm_dtw(world, m, eps, rho):
     assert planted.qoff in got.offsets.tolist()
 
 
+def test_nan_alpha_is_answered_like_the_engines_answer_it(world):
+    """The REPLs refuse `alpha <= 0.0` (K/NormQueryEngine.java:139-142) -- a NaN passes that test, and in the engine neither
+    `std / stdQ <= alpha` nor `>= 1 / alpha` holds for it: no answers, cntCandidate as ever (rounds 1-2 refused it)."""
+    kvmatch, datagen, series, ctx = world
+    m = 128
+    qoff = sortable_query(series, m, 40_000)
+    q = series[qoff - 1: qoff - 1 + m].copy()
+    L, R = datagen.gen_intervals(len(series), m, 5_000, 20.0, must_cover=[qoff], seed=9)
+    nan = float("nan")
+    compare(kvmatch.NormQueryEngine(ctx).verify((L, R), 1, q, 3.0, nan, 2.0), oracle.cnsm_ed(series, q, L, R, 0, 3.0, nan, 2.0), tag="nan alpha ed")
+    compare(kvmatch.NormQueryEngineDtw(ctx).verify((L, R), 1, q, 3.0, 6, nan, 2.0), oracle.cnsm_dtw(series, q, L, R, 0, 3.0, 6, nan, 2.0), tag="nan alpha dtw")
+    with pytest.raises(kvmatch.KvMatchIllegalArgument):
+        kvmatch.NormQueryEngine(ctx).verify((L, R), 1, q, 3.0, 0.0, 2.0)
+
+
 def test_dtw_engines_die_where_the_reference_does(world):
     """DtwUtils.lowerUpperLemire stores `u[i - r - 1]` from i = len on (K/utils/DtwUtils.java:81-90): over an array of
     len <= r points that is ArrayIndexOutOfBoundsException, uncaught, and query() dies -- for the query envelope when
