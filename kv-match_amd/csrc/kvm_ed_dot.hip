@@ -51,6 +51,9 @@ typedef double ed4_d2 __attribute__((ext_vector_type(2)));
 #ifndef EDD_RING
 #define EDD_RING 1
 #endif
+#ifndef EDD_RING_B
+#define EDD_RING_B EDD_RING                  // class B (32-candidate tiles) too
+#endif
 #define EDD_RING_LEN 128                     // points of the ring (= ED8_JC: one chunk is one revolution, all addresses static)
 #define EDD_RING_AHEAD 80                    // lookahead region [128, 208): the start of the next revolution (>= 64 + 8 window points)
 #define EDD_RING_D 4                         // blocks a global load is issued ahead of its LDS write
@@ -75,10 +78,12 @@ static_assert(EDD_RING_LEN == ED8_JC && EDD_RING_LEN + EDD_RING_AHEAD + 6 <= EDD
 
 template <int CI, int SUB>
 struct edd_cfg {
-    static constexpr int JC = CI == 8 ? ED8_JC : (SUB == 2 ? ED16_JC : ED4_JC);
+    // (class B: 128 like class A when its rows are staged as a stream -- one revolution of the ring --, 160 in the chunked form)
+    static constexpr int JC = CI == 8 ? ED8_JC : (SUB == 2 ? ED16_JC : (EDD_RING_B ? ED8_JC : ED4_JC));
+    static constexpr bool PREF8 = CI == 8 || (SUB == 1 && EDD_RING_B);   // chunk prefix sums of the query at ED8_JC granularity
     static constexpr int TILE = 8 * CI / SUB;            // candidates per tile: 64 / 32 / 16
     static constexpr int TPU = EDD_ROWS * SUB;           // tiles per unit (= per wavefront)
-    static constexpr int QS = CI == 8 ? 1 : JC / ED16_JC;  // stride of a chunk in the q_pref array it reads
+    static constexpr int QS = PREF8 ? 1 : JC / ED16_JC;  // stride of a chunk in the q_pref array it reads
     __device__ static constexpr int row_shift(int r) { return CI == 8 ? (r & 3) * 2 : ((r >> 1) & 1) * 2; }  // doubles
 };
 #define EDD_TILES_A (EDD_ROWS)
@@ -125,7 +130,7 @@ __device__ __forceinline__ void edd_body(const edd_args &A, const kvm_tile *__re
     const double *__restrict__ series = A.series;
     const double2 *__restrict__ prefix = A.prefix;
     const double *__restrict__ qc = qd.qc;
-    const double2 *__restrict__ q_pref = CI == 8 ? qd.q_pref8 : qd.q_pref;  // (CI = 4: ED16_JC-granular, chunk stride cfg::QS)
+    const double2 *__restrict__ q_pref = cfg::PREF8 ? qd.q_pref8 : qd.q_pref;  // (else ED16_JC-granular, chunk stride cfg::QS)
     double *wlds = reinterpret_cast<double *>(lds_wave2);
     double *qlds = wlds + EDD_ROWS * EDD_RS;
     double *tab_shift = qlds + EDD_ROWLEN;                                  // class C: shift / start of the unit's 16 tiles
@@ -334,7 +339,7 @@ __device__ __forceinline__ void edd_body(const edd_args &A, const kvm_tile *__re
 #pragma unroll
     for (int a = 0; a < CI; a++) acc[a] = 0.0;
     const int ch_lo = nchunks * part / f, ch_hi = nchunks * (part + 1) / f;
-    constexpr bool RINGED = EDD_RING && CI == 8 && SUB == 1;
+    constexpr bool RINGED = SUB == 1 && (CI == 8 ? EDD_RING : EDD_RING_B);
     // ---- stream staging (class A): lane = 8 row + piece stages points 2 piece, 2 piece + 1 of every 16-point block of its row
     const double *gsrc = series + ((int64_t)mine.start - 1 + 2 * lc);               // + point index of the block
     double *wdst = wlds + row * EDD_RS + cfg::row_shift(row) + 2 * lc;               // + position in the row
@@ -419,8 +424,11 @@ __device__ __forceinline__ void edd_body(const edd_args &A, const kvm_tile *__re
                         R[(2 * g + AH + 1) % RING] = X2[2 * G + AH + 1];
                         Q[(g + PD) % NQ][0] = Q2[2 * (G + PD)];
                         Q[(g + PD) % NQ][1] = Q2[2 * (G + PD) + 1];
-                        asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]),
-                                     "+v"(acc[6]), "+v"(acc[7])::"memory");
+                        if constexpr (CI == 8)
+                            asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]),
+                                         "+v"(acc[6]), "+v"(acc[7])::"memory");
+                        else
+                            asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3])::"memory");
                         const ed4_d2 q0 = Q[g % NQ][0], q1 = Q[g % NQ][1];
 #define EDD_W(k) (((k) & 1) ? R[(2 * g + (k) / 2) % RING].y : R[(2 * g + (k) / 2) % RING].x)
 #pragma unroll
