@@ -54,6 +54,11 @@ typedef double ed4_d2 __attribute__((ext_vector_type(2)));
 #ifndef EDD_RING_B
 #define EDD_RING_B EDD_RING                  // class B (32-candidate tiles) too
 #endif
+#ifndef EDD_RING_C
+#define EDD_RING_C EDD_RING                  // class C (two 16-candidate tiles per row): two rings of 64 points per row
+#endif
+#define EDD_RINGC_LEN 64                     // class C: ring of a half row (half a chunk: two revolutions per chunk)
+#define EDD_RINGC_AHEAD 32                   // ... and its lookahead region (>= 16 + 8 window points)
 #define EDD_RING_LEN 128                     // points of the ring (= ED8_JC: one chunk is one revolution, all addresses static)
 #define EDD_RING_AHEAD 80                    // lookahead region [128, 208): the start of the next revolution (>= 64 + 8 window points)
 #define EDD_RING_D 4                         // blocks a global load is issued ahead of its LDS write
@@ -73,14 +78,15 @@ static_assert(ED16_JC + 16 <= EDD_SUB_LEN && 2 * EDD_SUB_LEN == EDD_ROWLEN && ED
 static_assert(EDD_SUB_OFF >= EDD_SUB_LEN && EDD_SUB_OFF + EDD_SUB_LEN + 2 <= EDD_RS && (EDD_SUB_OFF * 8) % 256 == 128, "class-C half rows");
 static_assert(4 * EDD_WAVE_LDS * 8 <= 65536 && EDD_WAVE_LDS % 2 == 0 && EDD_RS % 2 == 0 && (EDD_RS * 8) % 256 == 0, "LDS");
 static_assert(ED4_JC % 16 == 0 && ED8_JC % 16 == 0 && ED16_JC % 16 == 0, "chunks are whole groups of 16 points (4 sub-steps of the register ring)");
+static_assert(EDD_RINGC_LEN + EDD_RINGC_AHEAD <= EDD_SUB_LEN && 2 * EDD_RINGC_LEN == ED8_JC && EDD_RINGC_AHEAD >= 24 + 8, "class C: ring + lookahead fit a half row");
 static_assert(EDD_RING_LEN == ED8_JC && EDD_RING_LEN + EDD_RING_AHEAD + 6 <= EDD_RS && EDD_RING_LEN + 16 <= EDD_ROWLEN && EDD_RING_AHEAD >= 72 + 8,
               "ring + lookahead fit a row; the query ring + its lookahead fit the query region");
 
 template <int CI, int SUB>
 struct edd_cfg {
     // (class B: 128 like class A when its rows are staged as a stream -- one revolution of the ring --, 160 in the chunked form)
-    static constexpr int JC = CI == 8 ? ED8_JC : (SUB == 2 ? ED16_JC : (EDD_RING_B ? ED8_JC : ED4_JC));
-    static constexpr bool PREF8 = CI == 8 || (SUB == 1 && EDD_RING_B);   // chunk prefix sums of the query at ED8_JC granularity
+    static constexpr int JC = CI == 8 ? ED8_JC : (SUB == 2 ? (EDD_RING_C ? ED8_JC : ED16_JC) : (EDD_RING_B ? ED8_JC : ED4_JC));
+    static constexpr bool PREF8 = JC == ED8_JC;   // chunk prefix sums of the query at ED8_JC granularity
     static constexpr int TILE = 8 * CI / SUB;            // candidates per tile: 64 / 32 / 16
     static constexpr int TPU = EDD_ROWS * SUB;           // tiles per unit (= per wavefront)
     static constexpr int QS = PREF8 ? 1 : JC / ED16_JC;  // stride of a chunk in the q_pref array it reads
@@ -362,8 +368,52 @@ __device__ __forceinline__ void edd_body(const edd_args &A, const kvm_tile *__re
         if (lane < 32) *reinterpret_cast<ed4_d2 *>(qlds + pos + 2 * lane) = v;
         if (ahead && lane < 8) *reinterpret_cast<ed4_d2 *>(qlds + EDD_RING_LEN + 2 * lane) = v;
     };
+    // ---- stream staging, class C: lane = 8 row + piece stages points 2 piece, 2 piece + 1 of every 16-point block of BOTH tiles
+    // of its row (two streams per row, a ring of 64 points + 32 of lookahead each, in the half rows of the chunked form)
+    constexpr bool RINGC = SUB == 2 && EDD_RING_C;
+    const double *gsrcC[2] = {series, series};
+    double *wdstC[2] = {wlds, wlds};
+    double shC[2] = {0.0, 0.0};
+    ed4_d2 stc[2][4];
+    if constexpr (RINGC) {
+        asm volatile("" ::: "memory");   // (the unit's tile table was written by lanes 0..15 above)
+#pragma unroll
+        for (int sb = 0; sb < 2; sb++) {
+            gsrcC[sb] = series + ((int64_t)tab_start[row * 2 + sb] - 1 + 2 * (lane & 7));
+            shC[sb] = tab_shift[row * 2 + sb];
+            wdstC[sb] = wlds + row * EDD_RS + cfg::row_shift(row) + sb * EDD_SUB_OFF + 2 * (lane & 7);
+        }
+    }
+    auto ringc_ld = [&](int sb, int j) -> ed4_d2 {
+        const ed4_d2u v = *reinterpret_cast<const ed4_d2u *>(gsrcC[sb] + j);
+        return ed4_d2{v.x, v.y};
+    };
+    auto ringc_wr = [&](int sb, ed4_d2 v, int pos, bool ring, bool ahead) {
+        v.x -= shC[sb];
+        v.y -= shC[sb];
+        if (ring) *reinterpret_cast<ed4_d2 *>(wdstC[sb] + pos) = v;
+        if (ahead) *reinterpret_cast<ed4_d2 *>(wdstC[sb] + EDD_RINGC_LEN + pos) = v;
+    };
     if (work && ch_lo < ch_hi) {
-        if constexpr (RINGED) {
+        if constexpr (RINGC) {
+            const int jb = ch_lo * JC;
+            ed4_d2 p3[2][3];
+#pragma unroll
+            for (int sb = 0; sb < 2; sb++)
+#pragma unroll
+                for (int b = 0; b < 3; b++) p3[sb][b] = ringc_ld(sb, jb + 16 * b);
+            const ed4_d2 q0v = ring_ldq(jb);
+#pragma unroll
+            for (int sb = 0; sb < 2; sb++)
+#pragma unroll
+                for (int b = 0; b < 4; b++) stc[sb][b] = ringc_ld(sb, jb + 16 * (3 + b));
+            qst[0] = ring_ldq(jb + 64);
+#pragma unroll
+            for (int sb = 0; sb < 2; sb++)
+#pragma unroll
+                for (int b = 0; b < 3; b++) ringc_wr(sb, p3[sb][b], 16 * b, true, false);
+            ring_wrq(q0v, 0, false);
+        } else if constexpr (RINGED) {
             const int jb = ch_lo * JC;
             ed4_d2 p6[6];
 #pragma unroll
@@ -386,9 +436,80 @@ __device__ __forceinline__ void edd_body(const edd_args &A, const kvm_tile *__re
     for (int ch = ch_lo; work && ch < ch_hi; ch++) {
         const int j0 = ch * JC;
         const bool more = ch + 1 < ch_hi;
-        if (!RINGED && more) load_chunk(j0 + JC);
+        if (!RINGED && !RINGC && more) load_chunk(j0 + JC);
         const int jlim = min(JC, m - j0);
-        if (RINGED && jlim == JC) {
+        if (RINGC) {
+            if constexpr (RINGC) {
+                // One chunk of 128 points = two revolutions of the half rows' rings = 8 blocks of 16 points; at the start the
+                // half rows hold [j0, j0 + 48).  Block B's turn writes points [j0 + 16 (B + 3), + 16) of both tiles -- fetched four
+                // blocks ago -- where the ring went dead a block ago (the first two blocks of a revolution also behind the ring),
+                // then fetches the blocks four further on.  A block runs only if it lies wholly inside the window (the last
+                // chunk of a window may be partial); what is left of a partial block is added point by point.
+                constexpr int NP = CI / 2 + 2, PD = 1, RING = 8, U = RING / 2, NQ = PD + 1;
+                constexpr int AH = NP + 2 * (PD - 1);
+                ed4_d2 R[RING], Q[NQ][2];
+#pragma unroll
+                for (int j = 0; j < AH; j++) R[j] = X2[j];
+                Q[0][0] = Q2[0];
+                Q[0][1] = Q2[1];
+                int done_blocks = 0;
+                // (GUARDED = the last, partial chunk: a test per block; a full chunk runs its eight blocks as one basic block)
+                auto blocks = [&](auto guarded_tag) {
+                constexpr bool GUARDED = decltype(guarded_tag)::value;
+#pragma unroll
+                for (int B = 0; B < 8; B++) {
+                    if (!GUARDED || 16 * (B + 1) <= jlim) {   // (wave-uniform)
+                        done_blocks = B + 1;
+                        const int wb = (B + 3) & 3;
+#pragma unroll
+                        for (int sb = 0; sb < 2; sb++) {
+                            ringc_wr(sb, stc[sb][B % 4], 16 * wb, true, 16 * wb < EDD_RINGC_AHEAD);
+                            stc[sb][B % 4] = ringc_ld(sb, j0 + 16 * (B + 3 + 4));
+                        }
+                        if (B == 1) {
+                            ring_wrq(qst[0], 64, false);
+                            qst[1] = ring_ldq(j0 + 128);
+                        }
+                        if (B == 5) {
+                            ring_wrq(qst[1], 0, true);
+                            qst[0] = ring_ldq(j0 + 192);
+                        }
+#pragma unroll
+                        for (int g = 0; g < U; g++) {
+                            const int G = B * U + g, Gx = G & 15;   // (the window rings go round twice per chunk)
+                            R[(2 * g + AH) % RING] = X2[2 * Gx + AH];
+                            R[(2 * g + AH + 1) % RING] = X2[2 * Gx + AH + 1];
+                            Q[(g + PD) % NQ][0] = Q2[2 * (G + PD)];
+                            Q[(g + PD) % NQ][1] = Q2[2 * (G + PD) + 1];
+                            asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3])::"memory");
+                            const ed4_d2 q0 = Q[g % NQ][0], q1 = Q[g % NQ][1];
+#define EDD_W(k) (((k) & 1) ? R[(2 * g + (k) / 2) % RING].y : R[(2 * g + (k) / 2) % RING].x)
+#pragma unroll
+                            for (int a = 0; a < CI; a++) acc[a] = __builtin_fma(EDD_W(a), q0.x, acc[a]);
+#pragma unroll
+                            for (int a = 0; a < CI; a++) acc[a] = __builtin_fma(EDD_W(a + 1), q0.y, acc[a]);
+#pragma unroll
+                            for (int a = 0; a < CI; a++) acc[a] = __builtin_fma(EDD_W(a + 2), q1.x, acc[a]);
+#pragma unroll
+                            for (int a = 0; a < CI; a++) acc[a] = __builtin_fma(EDD_W(a + 3), q1.y, acc[a]);
+#undef EDD_W
+                        }
+                    }
+                }
+                };
+                if (jlim == JC) blocks(std::false_type{});
+                else blocks(std::true_type{});
+                if (16 * done_blocks < jlim) {   // the rest of a partial block: the blocks it reads are in place (B + 2 at most)
+                    asm volatile("" ::: "memory");
+                    const double *X = reinterpret_cast<const double *>(X2) + 16 * (done_blocks & 3);
+                    for (int jj = 16 * done_blocks; jj < jlim; jj++) {
+                        const double qv = qlds[jj];
+#pragma unroll
+                        for (int a = 0; a < CI; a++) acc[a] = __builtin_fma(X[jj - 16 * done_blocks + a], qv, acc[a]);
+                    }
+                }
+            }
+        } else if (RINGED && jlim == JC) {
             if constexpr (RINGED) {
                 // One revolution of the ring = one chunk of 128 points = 8 blocks of 16 points = 32 sub-steps, all unrolled:
                 // every LDS address and every register index is a compile-time constant.  At the start the rows hold the
@@ -527,7 +648,8 @@ __device__ __forceinline__ void edd_body(const edd_args &A, const kvm_tile *__re
             // every 8 chunks (a split unit belongs to a short list: the launch lasts as long as its longest unit whatever
             // the others do, a wave leaves only when all its 512 candidates are dead, and each check costs more
             // than the chunk it might save).
-            if (ABANDON && (ch == ch_lo || (f == 1 && ((ch - ch_lo) & (SUB == 2 ? 15 : 7)) == (SUB == 2 ? 15 : 7)))) {
+            constexpr int EVERY = JC >= ED8_JC ? 7 : 15;   // (chunks between two tests of an unsplit unit: ~1024 points)
+            if (ABANDON && (ch == ch_lo || (f == 1 && ((ch - ch_lo) & EVERY) == EVERY))) {
                 const int jlo = ch_lo * JC, J = j0 + JC;
                 const double2 qa = q_pref[(ch + 1) * cfg::QS], qb = q_pref[ch_lo * cfg::QS];
                 const double2 qp = make_double2(qa.x - qb.x, qa.y - qb.y);
@@ -573,7 +695,7 @@ __device__ __forceinline__ void edd_body(const edd_args &A, const kvm_tile *__re
                     break;  // split unit: the other parts wait at the barrier below
                 }
             }
-            if (!RINGED) store_chunk();
+            if (!RINGED && !RINGC) store_chunk();
         }
     }
     if (f > 1) {
