@@ -14,9 +14,9 @@
 //        candidate.  On continuous data the band is empty.
 //      kvm_ucr_ed_tie_kernel    : one wavefront per tie candidate, the executor's loop literally -- replayed mean / std
 //        (the executor's single chain of running sums = the cNSM replay of its run), true division, terms added one by one
-//        by lane 0 -- and, where it stops on `sum == bsf`, a look at the remaining terms: if one of them is not zero the
-//        engine's loop goes past eps^2 and does NOT report the window, so it is appended here at sqrt(bsf); if all are zero
-//        the engine reports the same window at the same distance itself.
+//        by lane 0 -- and, where it stops on `sum == bsf`, the ENGINE's sum is carried on over the remaining terms: if it
+//        ends above eps^2 the engine does not report the window, so it is appended here at sqrt(bsf); if it stays on eps^2
+//        (terms too small to move the sum) the engine reports the same window at the same distance itself.
 //
 // 2. UcrDtwQueryExecutor allocates cb1 / cb2 once (U/UcrDtwQueryExecutor.java:157-161) and never clears them, while the
 //    engines allocate fresh arrays per window (K/NormQueryEngineDtw.java:559,571).  lbKeoghCumulative /
