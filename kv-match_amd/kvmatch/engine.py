@@ -68,7 +68,14 @@ def _as_intervals(valid_positions):
             return np.ascontiguousarray(left), np.ascontiguousarray(right)
         left, right = (np.asarray(x, dtype=np.int64) for x in (left, right))
     else:
-        arr = np.asarray(valid_positions, dtype=np.int64).reshape(-1, 2)
+        arr = np.asarray(valid_positions, dtype=np.int64)
+        if arr.size == 0:
+            arr = arr.reshape(0, 2)
+        if arr.ndim != 2 or arr.shape[1] != 2:
+            # (a tuple of two plain lists (left[], right[]) of k != 2 entries ends here instead of being re-read, silently,
+            #  as k pairs in the wrong order: that form needs numpy arrays)
+            raise _lib.KvMatchIllegalArgument("valid_positions: a sequence of (left, right) pairs, a (k, 2) array, or a 2-tuple "
+                                              "of one-dimensional numpy arrays (left[], right[])")
         left, right = arr[:, 0], arr[:, 1]
     if left.shape != right.shape:
         raise _lib.KvMatchIllegalArgument("left/right length mismatch")

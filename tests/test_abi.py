@@ -257,3 +257,25 @@ def test_sort_and_merge_intervals_is_the_reference_step_between_the_phases(built
             assert np.all(gl[1:] > gr[:-1] + 1)
     gl, gr = kvmatch.sort_and_merge_intervals((np.array([5, 1, 3]), np.array([6, 2, 3])))
     assert gl.tolist() == [1, 5] and gr.tolist() == [3, 6]        # [1,2] and [3,3] are adjacent and joined; [5,6] stays apart
+
+
+def test_interval_argument_forms_cannot_be_misread(built):
+    """kvmatch.engine._as_intervals: pairs, a (k, 2) array and a 2-tuple of numpy arrays are the three accepted forms; a tuple
+    of two plain LISTS of k != 2 entries -- which rounds 1-2 read as (left[], right[]) -- is refused instead of being re-read
+    as k pairs in the wrong order; a tuple of two pairs is two intervals (documented in INTEGRATION.md section 6)."""
+    import kvmatch
+    from kvmatch.engine import _as_intervals
+    l, r = _as_intervals([(1, 5), (10, 20), (30, 40)])
+    assert l.tolist() == [1, 10, 30] and r.tolist() == [5, 20, 40] and l.dtype == np.int32
+    l, r = _as_intervals(np.array([[1, 5], [10, 20]]))
+    assert l.tolist() == [1, 10] and r.tolist() == [5, 20]
+    l, r = _as_intervals((np.array([1, 10, 30]), np.array([5, 20, 40])))
+    assert l.tolist() == [1, 10, 30] and r.tolist() == [5, 20, 40]
+    l, r = _as_intervals(((1, 5), (10, 20)))
+    assert l.tolist() == [1, 10] and r.tolist() == [5, 20]
+    l, r = _as_intervals([])
+    assert l.size == 0 and r.size == 0
+    with pytest.raises(kvmatch.KvMatchIllegalArgument):
+        _as_intervals(([1, 10, 30], [5, 20, 40]))
+    with pytest.raises(kvmatch.KvMatchIllegalArgument):
+        _as_intervals([1, 5, 10, 20])
