@@ -304,12 +304,23 @@ __device__ int dp_prologue(const double *__restrict__ series, const kvm_query_de
     double carry1 = 0.0, carry2 = 0.0;
     bool amb1 = false, amb2 = false;  // the loop has stopped at a partial within rounding of eps^2
     const double inv_sd = 1.0 / sd;
+    // (the positions of a round's terms are fetched one round ahead: a round is then ONE exposed memory latency -- the gathers
+    // they address -- instead of two)
+    int onext[4];
+#pragma unroll
+    for (int h = 0; h < 4; h++) onext[h] = ax.order[min(64 * h + lane, m - 1)];
     for (int base = 0; base < m && !(amb1 && amb2); base += 256) {
         double d1[4], d2[4];
+        int ocur[4];
+#pragma unroll
+        for (int h = 0; h < 4; h++) {
+            ocur[h] = onext[h];
+            onext[h] = ax.order[min(base + 256 + 64 * h + lane, m - 1)];
+        }
 #pragma unroll
         for (int h = 0; h < 4; h++) {
             const int i = base + 64 * h + lane, ic = min(i, m - 1);
-            const int o = ax.order[ic];
+            const int o = ocur[h];
             const double t1 = dp_term_q(x[o], mean, inv_sd, ax.uo[ic], ax.lo[ic]);
             double U, L;
             dp_env_at(ax, patch, r, pl, c.start + o, U, L);
@@ -321,7 +332,13 @@ __device__ int dp_prologue(const double *__restrict__ series, const kvm_query_de
         // total leaves both running sums below eps^2 (1 - tau) holds no stop -- the partial sums never decrease -- and is
         // passed over with two wave reductions instead of eight ordered scans; only the round of the stop is scanned.
         if (base > 0) {
-            const double r1 = kvm_wave_sum((d1[0] + d1[1]) + (d1[2] + d1[3])), r2 = kvm_wave_sum((d2[0] + d2[1]) + (d2[2] + d2[3]));
+            double r1 = (d1[0] + d1[1]) + (d1[2] + d1[3]), r2 = (d2[0] + d2[1]) + (d2[2] + d2[3]);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {   // (both reductions in the same butterfly steps: their shuffles overlap)
+                const double p1 = __shfl_xor(r1, o, 64), p2 = __shfl_xor(r2, o, 64);
+                r1 += p1;
+                r2 += p2;
+            }
             if ((amb1 || carry1 + r1 < Elo) && (amb2 || carry2 + r2 < Elo)) {
                 if (!amb1) carry1 += r1;
                 if (!amb2) carry2 += r2;
