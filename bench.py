@@ -345,6 +345,29 @@ def main():
             "value_early_abandon": o_st["windows"] / cpu_ab_s,
             "seconds": cpu_s,
         }
+        # where a JDK exists: oracle/java/Phase2LoopsBaseline.java, a minimal transcription of the same loop over boxed
+        # List<Double> (what the reference pays for), on a bounded sample -- the first fifth of the list, every point evaluated
+        if java and javac:
+            try:
+                jdir = os.path.join(tmpdir, "_bench_java")
+                os.makedirs(jdir, exist_ok=True)
+                kj = max(1, len(l0) // 5)
+                series.astype(">f8").tofile(os.path.join(jdir, "data.bin"))
+                np.stack([l0[:kj], r0[:kj]], axis=1).astype("<i4").tofile(os.path.join(jdir, "intervals.bin"))
+                subprocess.run([javac, "-d", jdir, os.path.join(ROOT, "oracle", "java", "Phase2LoopsBaseline.java")], check=True,
+                               capture_output=True, text=True, timeout=120)
+                cpj = subprocess.run([java, "-cp", jdir, "Phase2LoopsBaseline", os.path.join(jdir, "data.bin"), str(n),
+                                      os.path.join(jdir, "intervals.bin"), str(qoffs[0]), str(m), repr(float(a.epsilon)), "0"],
+                                     capture_output=True, text=True, timeout=600)
+                tok = cpj.stdout.split()
+                jw, js = int(tok[tok.index("windows") + 1]), float(tok[tok.index("seconds") + 1])
+                out["cpu_baseline"]["java_transcription"] = {
+                    "value": jw / js, "unit": "candidates/s", "cores": 1, "seconds": js, "answers": int(tok[tok.index("answers") + 1]),
+                    "sample": f"the first {kj} intervals of list 0 ({jw} candidates), early abandon off; oracle/java/Phase2LoopsBaseline.java: "
+                              "a transcription of the loop over List<Double>, NOT the reference's engine (which needs its Maven artefacts)"}
+                os.remove(os.path.join(jdir, "data.bin"))
+            except Exception as e:  # noqa: BLE001
+                out["cpu_baseline"]["java_transcription"] = {"error": repr(e)}
         # the same loop on all host cores: a child process (no GPU context there) forks one worker per core
         try:
             ncores = min(os.cpu_count() or 1, 64)
