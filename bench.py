@@ -66,7 +66,7 @@ def parse():
     ap.add_argument("--ed-kernel", type=int, default=0)
     ap.add_argument("--queries-per-step", type=int, default=0,
                     help="phase-2 passes (queries of the stream) per step; 0 = per-workload default")
-    ap.add_argument("--in-flight", type=int, default=4,
+    ap.add_argument("--in-flight", type=int, default=5,
                     help="queries in flight per GPU (contexts over one resident series, one host thread each)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong", "both"],
                     help="weak: --candidates per GPU; strong: --candidates in total, split over the GPUs; both: weak is the "
