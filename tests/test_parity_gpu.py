@@ -340,6 +340,10 @@ def test_shift_clipping_empty_and_errors(world):
 def test_knobs_do_not_change_answers(world):
     kvmatch = world[0]
     ctx = world[3]
+    for removed in (2, 5, -1):   # (2: the direct LDS-tiled pruner, removed in round 3)
+        with pytest.raises(kvmatch.KvMatchIllegalArgument):
+            ctx.set_option(kvmatch.OPT_ED_KERNEL, removed)
+    assert ctx.get_option(kvmatch.OPT_ED_KERNEL) == 0 and ctx.get_option(kvmatch.OPT_STRICT_BOUNDS) == 1 and ctx.get_option(kvmatch.OPT_UCR_LOOPS) == 0
     s, q, L, R = planted(world, 256)
     base_ed = kvmatch.QueryEngine(ctx).verify((L, R), 1, q, 5.0)
     base_dtw = kvmatch.NormQueryEngineDtw(ctx).verify((L, R), 1, q, 4.0, 12, 1.5, 2.0)
