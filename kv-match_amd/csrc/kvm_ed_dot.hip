@@ -59,6 +59,20 @@ typedef double ed4_d2 __attribute__((ext_vector_type(2)));
 #endif
 #define EDD_RINGC_LEN 64                     // class C: ring of a half row (half a chunk: two revolutions per chunk)
 #define EDD_RINGC_AHEAD 32                   // ... and its lookahead region (>= 16 + 8 window points)
+// Stream-staged classes A and B take their query values from a REGISTER by DPP row broadcast instead of two broadcast LDS reads
+// per sub-step: one ds_read_b64 per lane and 16 points puts q[j + (lane & 15)] into a VGPR pair, and v_fmac_f64_dpp
+// row_newbcast:K (the only DPP form the DP ALU has, gfx90a+) feeds lane K's value of every 16-lane row to the FMA.  Halves the
+// hot loop's LDS reads (class B, 4 candidates per lane, is LDS-bound).  The same operation: acc = fma(w, q, acc).
+#ifndef EDD_QDPP
+#define EDD_QDPP 1
+#endif
+#define EDD_BC_CASE(K) case K: asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:" #K " row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(q16), "v"(w)); break;
+__device__ __forceinline__ void edd_fmac_bc(double &acc, double q16, double w, int k) {  // k: a constant after unrolling
+    switch (k) {
+        EDD_BC_CASE(0) EDD_BC_CASE(1) EDD_BC_CASE(2) EDD_BC_CASE(3) EDD_BC_CASE(4) EDD_BC_CASE(5) EDD_BC_CASE(6) EDD_BC_CASE(7)
+        EDD_BC_CASE(8) EDD_BC_CASE(9) EDD_BC_CASE(10) EDD_BC_CASE(11) EDD_BC_CASE(12) EDD_BC_CASE(13) EDD_BC_CASE(14) EDD_BC_CASE(15)
+    }
+}
 #define EDD_RING_LEN 128                     // points of the ring (= ED8_JC: one chunk is one revolution, all addresses static)
 #define EDD_RING_AHEAD 80                    // lookahead region [128, 208): the start of the next revolution (>= 64 + 8 window points)
 #define EDD_RING_D 4                         // blocks a global load is issued ahead of its LDS write
@@ -521,8 +535,14 @@ __device__ __forceinline__ void edd_body(const edd_args &A, const kvm_tile *__re
                 ed4_d2 R[RING], Q[NQ][2];
 #pragma unroll
                 for (int j = 0; j < AH; j++) R[j] = X2[j];
-                Q[0][0] = Q2[0];
-                Q[0][1] = Q2[1];
+                const double *q16p = qlds + (lane & 15);
+                double qq[2];
+                if constexpr (EDD_QDPP) {
+                    qq[0] = q16p[0];
+                } else {
+                    Q[0][0] = Q2[0];
+                    Q[0][1] = Q2[1];
+                }
 #pragma unroll
                 for (int B = 0; B < 8; B++) {
                     {
@@ -538,28 +558,41 @@ __device__ __forceinline__ void edd_body(const edd_args &A, const kvm_tile *__re
                             qst[0] = ring_ldq(j0 + 192);
                         }
                     }
+                    // (the 16 query values of the NEXT block, one per lane of a 16-lane row; the last block's come from the
+                    // lookahead behind the query ring, written three blocks ago)
+                    if constexpr (EDD_QDPP) qq[(B + 1) & 1] = q16p[16 * (B + 1)];
 #pragma unroll
                     for (int g = 0; g < U; g++) {
                         const int G = B * U + g;
                         R[(2 * g + AH) % RING] = X2[2 * G + AH];
                         R[(2 * g + AH + 1) % RING] = X2[2 * G + AH + 1];
-                        Q[(g + PD) % NQ][0] = Q2[2 * (G + PD)];
-                        Q[(g + PD) % NQ][1] = Q2[2 * (G + PD) + 1];
+                        if constexpr (!EDD_QDPP) {
+                            Q[(g + PD) % NQ][0] = Q2[2 * (G + PD)];
+                            Q[(g + PD) % NQ][1] = Q2[2 * (G + PD) + 1];
+                        }
                         if constexpr (CI == 8)
                             asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]),
                                          "+v"(acc[6]), "+v"(acc[7])::"memory");
                         else
                             asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3])::"memory");
-                        const ed4_d2 q0 = Q[g % NQ][0], q1 = Q[g % NQ][1];
 #define EDD_W(k) (((k) & 1) ? R[(2 * g + (k) / 2) % RING].y : R[(2 * g + (k) / 2) % RING].x)
+                        if constexpr (EDD_QDPP) {
+                            const double qv = qq[B & 1];
 #pragma unroll
-                        for (int a = 0; a < CI; a++) acc[a] = __builtin_fma(EDD_W(a), q0.x, acc[a]);
+                            for (int k = 0; k < 4; k++)
 #pragma unroll
-                        for (int a = 0; a < CI; a++) acc[a] = __builtin_fma(EDD_W(a + 1), q0.y, acc[a]);
+                                for (int a = 0; a < CI; a++) edd_fmac_bc(acc[a], qv, EDD_W(a + k), 4 * g + k);
+                        } else {
+                            const ed4_d2 q0 = Q[g % NQ][0], q1 = Q[g % NQ][1];
 #pragma unroll
-                        for (int a = 0; a < CI; a++) acc[a] = __builtin_fma(EDD_W(a + 2), q1.x, acc[a]);
+                            for (int a = 0; a < CI; a++) acc[a] = __builtin_fma(EDD_W(a), q0.x, acc[a]);
 #pragma unroll
-                        for (int a = 0; a < CI; a++) acc[a] = __builtin_fma(EDD_W(a + 3), q1.y, acc[a]);
+                            for (int a = 0; a < CI; a++) acc[a] = __builtin_fma(EDD_W(a + 1), q0.y, acc[a]);
+#pragma unroll
+                            for (int a = 0; a < CI; a++) acc[a] = __builtin_fma(EDD_W(a + 2), q1.x, acc[a]);
+#pragma unroll
+                            for (int a = 0; a < CI; a++) acc[a] = __builtin_fma(EDD_W(a + 3), q1.y, acc[a]);
+                        }
 #undef EDD_W
                     }
                 }
