@@ -227,7 +227,8 @@ __device__ __forceinline__ void edd_body(const edd_args &A, const kvm_tile *__re
         st.e2J = E2;
         return st;
     };
-    // RSM only: `stats` of the range [jlo, J) of candidate a from loads issued earlier (kvm_issue_window_sums)
+    // `stats` of the range [jlo, J) of candidate a from loads issued earlier (kvm_issue_window_sums): RSM any range, cNSM the
+    // whole window only (jlo = 0, J = m) -- the same arithmetic in the same order as `stats`
     auto stats_from = [&](const kvm_raw_sums &raw, int a, int jlo, int J) -> edd_cstat {
         edd_cstat st;
         double s1, s2, cb, pm;
@@ -242,8 +243,27 @@ __device__ __forceinline__ void edd_body(const edd_args &A, const kvm_tile *__re
         st.e2J = e.e2 + 2.0 * fabs(dc) * e.e1 + 1e-15 * (fabs(s2) + 2.0 * fabs(dc * s1) + len0 * (dc * dc));
         st.mc = 0.0; st.sg = 1.0;
         st.gd.g = 0.0; st.gd.mean_err = 0.0; st.gd.std_hi = 0.0;
+        if (NORM) {
+            st.mc = st.s1J / m;
+            const double var = st.s2J / m - st.mc * st.mc, mean = c_row + st.mc;
+            st.sg = sqrt(var);
+            st.gd.mean_err = st.e1J / m + kvm_hist_mean(hist, m);
+            const double var_err = st.e2J / m + 2.0 * fabs(st.mc) * st.gd.mean_err + kvm_hist_var(hist, m);
+            st.gd.g = kvm_sigma_guard(mean, st.sg, var_err / (2.0 * var) + st.gd.mean_err / st.sg);
+            st.gd.std_hi = sqrt(fmax(var, 0.0) + var_err + 1e-8 * (mean * mean + fabs(var)));
+        }
         return st;
     };
+    // the whole-window sums of this lane's CI candidates, all loads in flight together (one memory latency instead of two
+    // per candidate: this runs once per part before the first chunk (cNSM) and once per unit behind the last)
+    auto issue_full = [&](kvm_raw_sums (&raw)[4], int a0) {   // (four at a time: 64 registers of loads in flight)
+#pragma unroll
+        for (int a = 0; a < 4; a++) {
+            const int64_t w0 = (int64_t)mine.start - 1 + ((c0 + a0 + a < mine.count) ? c0 + a0 + a : 0);
+            raw[a] = kvm_issue_window_sums(prefix, series, w0, m);
+        }
+    };
+    static_assert(CI % 4 == 0, "candidates per lane come in fours");
     // correlation-form distance over a range of J points (st, acc and the query sums qp all taken over that range) and
     // its guard band
     auto dist_form = [&](const edd_cstat &st, double acc, int J, const double2 qp, double &slack) -> double {
@@ -273,10 +293,14 @@ __device__ __forceinline__ void edd_body(const edd_args &A, const kvm_tile *__re
     unsigned vm = 0, fm = 0;
 #pragma unroll
     for (int a = 0; a < CI; a++) {
+        kvm_raw_sums raw0[4];
+        if constexpr (NORM) {
+            if (a % 4 == 0) issue_full(raw0, a);
+        }
         if (c0 + a < mine.count) {
             bool ok = true;
-            if (NORM) {
-                const edd_cstat st = stats(a, 0, m);
+            if constexpr (NORM) {
+                const edd_cstat st = stats_from(raw0[a % 4], a, 0, m);
                 ok = kvm_cnsm_filter_guarded(c_row + st.mc, st.sg, qd.meanQ, qd.stdQ, qd.alpha, qd.beta, st.gd);
                 if (ok && (!(st.sg == st.sg) || !(st.sg > 0.0) || kvm_guard_degenerate(st.gd.g))) fm |= 1u << a;  // exact pass decides
             }
@@ -749,13 +773,15 @@ __device__ __forceinline__ void edd_body(const edd_args &A, const kvm_tile *__re
         return;
     }
     unsigned keepm = 0;
+    kvm_raw_sums rawf[4];
 #pragma unroll
     for (int a = 0; a < CI; a++) {
+        if (a % 4 == 0) issue_full(rawf, a);
         if ((vm >> a) & 1u) {
             bool keep = (fm >> a) & 1u;
             if (!keep) {
                 double slack;
-                const edd_cstat st = stats(a, 0, m);
+                const edd_cstat st = stats_from(rawf[a % 4], a, 0, m);
                 keep = !(dist_form(st, acc[a], m, qtot, slack) > eps2 + slack);  // (NaN: a poisoned prefix block -> keep)
             }
             if (keep) keepm |= 1u << a;

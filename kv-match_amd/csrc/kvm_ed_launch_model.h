@@ -16,8 +16,10 @@
 
 // ---- the launcher's model of a launch: which window split (fA for class A, fB for classes B and C) ends first -----------
 // Fitted to profiles/ed_split_sweep.py (81 list shapes x 9 split pairs, m = 512 .. 8192, 10^5 .. 4 10^6 candidates, mean
-// run 8 .. 400; profiles/r02_ed_split_sweep_{a,b}.log): rms error 7 %, the pair it picks is 2 % (geometric mean; worst
-// 14 %) slower than the best measured pair, where the round-based model it replaces lost 9-14 % (worst 40 %).
+// run 8 .. 400), by profiles/fit_ed_launch_model.py.  Round 2's fit (profiles/r02_ed_split_sweep_{a,b}.log): rms error 7 %.
+// Refitted late in round 3 (profiles/r03_split_sweep_{a,b}.log) -- every class now works in chunks of 128 points and a part's
+// constant fell from 6-9 to 4-6 us (the whole-window sums of a lane's candidates are loaded together): rms 8.5 %, the pair it
+// picks is 3.4 % (geometric mean; worst 20 %) behind the best measured pair, 4.3 % (worst 31 %) with round 2's constants.
 //  * a part (one wave's share of a unit) costs  a + b ceil(chunks / f)  microseconds on a full chip -- the per-part
 //    prologue (statistics, staging tables, first chunk) is what makes splitting short windows expensive;
 //  * parts start in launch order (A, C, B) on `slots` wave slots;
@@ -25,7 +27,7 @@
 //    pipe; below one wave per SIMD the clock is higher as well): piecewise linear in the fraction of occupied slots.
 // The makespan is then a short event simulation over cohorts of identical parts (a few dozen events).
 static inline double edd_speed(double x) {
-    static const double kx[6] = {1.0, 0.75, 0.55, 0.5, 0.25, 0.0}, kv[6] = {1.0, 1.073, 1.094, 1.664, 1.765, 2.187};
+    static const double kx[6] = {1.0, 0.75, 0.55, 0.5, 0.25, 0.0}, kv[6] = {1.0, 1.093, 1.149, 1.687, 1.695, 2.240};
     if (x >= 1.0) return 1.0;
     for (int i = 1; i < 6; i++)
         if (x >= kx[i]) return kv[i - 1] + (kv[i] - kv[i - 1]) * (kx[i - 1] - x) / (kx[i - 1] - kx[i]);
@@ -67,8 +69,8 @@ static inline double edd_makespan(const double cnt_in[3], const double w[3], dou
 // modelled duration (microseconds, without the launch's constant) of unitsA / unitsB / unitsC units split fA / fB ways
 static inline double edd_model(int m, double unitsA, double unitsB, double unitsC, int fA, int fB, double slots) {
     auto chunks = [](int mm, int jc, int f) { return std::ceil(std::ceil((double)mm / jc) / f); };
-    const double w[3] = {9.222 + 5.105 * chunks(m, ED8_JC, fA), 7.968 + 2.879 * chunks(m, ED16_JC, fB),
-                         5.979 + 4.543 * chunks(m, ED4_JC, fB)};                      // launch order: A, C, B
+    const double w[3] = {5.188 + 4.535 * chunks(m, ED8_JC, fA), 6.360 + 3.899 * chunks(m, ED8_JC, fB),
+                         3.951 + 3.719 * chunks(m, ED8_JC, fB)};                      // launch order: A, C, B
     auto parts = [](double units, int f) { return 4.0 * std::ceil(units * f / 4.0); };  // whole workgroups of 4 waves
     const double cnt[3] = {parts(unitsA, fA), parts(unitsC, fB), parts(unitsB, fB)};
     return edd_makespan(cnt, w, slots);

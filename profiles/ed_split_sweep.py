@@ -21,6 +21,9 @@ if len(sys.argv) > 1: shapes = shapes[::int(sys.argv[1])]
 for m, c, ml in shapes:
     q = s[n // 3: n // 3 + m].copy()
     left, right = datagen.gen_intervals(n, m, c, ml, seed=int(ml) + c % 97)
+    if os.environ.get("SWEEP_UNITS"):   # one traced call: the launcher prints the unit counts of the three classes (stderr)
+        sys.stdout.flush(); os.environ.pop("KVM_ED_SPLIT", None); os.environ["KVM_TRACE"] = "1"
+        eng.verify((left, right), 1, q, 10.0); os.environ.pop("KVM_TRACE")
     row = []
     for sp in splits:
         if sp == "auto": os.environ.pop("KVM_ED_SPLIT", None)
