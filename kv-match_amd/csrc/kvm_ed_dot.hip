@@ -488,8 +488,14 @@ __device__ __forceinline__ void edd_body(const edd_args &A, const kvm_tile *__re
                 ed4_d2 R[RING], Q[NQ][2];
 #pragma unroll
                 for (int j = 0; j < AH; j++) R[j] = X2[j];
-                Q[0][0] = Q2[0];
-                Q[0][1] = Q2[1];
+                const double *q16p = qlds + (lane & 15);   // (query values by DPP row broadcast, as in classes A and B)
+                double qq[2];
+                if constexpr (EDD_QDPP) {
+                    qq[0] = q16p[0];
+                } else {
+                    Q[0][0] = Q2[0];
+                    Q[0][1] = Q2[1];
+                }
                 int done_blocks = 0;
                 // (GUARDED = the last, partial chunk: a test per block; a full chunk runs its eight blocks as one basic block)
                 auto blocks = [&](auto guarded_tag) {
@@ -512,24 +518,37 @@ __device__ __forceinline__ void edd_body(const edd_args &A, const kvm_tile *__re
                             ring_wrq(qst[1], 0, true);
                             qst[0] = ring_ldq(j0 + 192);
                         }
+                        // (the 16 query values of the NEXT block; a guarded block's successor may lie past the window: its
+                        // values are staged -- the query is padded -- and never used)
+                        if constexpr (EDD_QDPP) qq[(B + 1) & 1] = q16p[16 * (B + 1)];
 #pragma unroll
                         for (int g = 0; g < U; g++) {
                             const int G = B * U + g, Gx = G & 15;   // (the window rings go round twice per chunk)
                             R[(2 * g + AH) % RING] = X2[2 * Gx + AH];
                             R[(2 * g + AH + 1) % RING] = X2[2 * Gx + AH + 1];
-                            Q[(g + PD) % NQ][0] = Q2[2 * (G + PD)];
-                            Q[(g + PD) % NQ][1] = Q2[2 * (G + PD) + 1];
+                            if constexpr (!EDD_QDPP) {
+                                Q[(g + PD) % NQ][0] = Q2[2 * (G + PD)];
+                                Q[(g + PD) % NQ][1] = Q2[2 * (G + PD) + 1];
+                            }
                             asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3])::"memory");
-                            const ed4_d2 q0 = Q[g % NQ][0], q1 = Q[g % NQ][1];
 #define EDD_W(k) (((k) & 1) ? R[(2 * g + (k) / 2) % RING].y : R[(2 * g + (k) / 2) % RING].x)
+                            if constexpr (EDD_QDPP) {
+                                const double qv = qq[B & 1];
 #pragma unroll
-                            for (int a = 0; a < CI; a++) acc[a] = __builtin_fma(EDD_W(a), q0.x, acc[a]);
+                                for (int k = 0; k < 4; k++)
 #pragma unroll
-                            for (int a = 0; a < CI; a++) acc[a] = __builtin_fma(EDD_W(a + 1), q0.y, acc[a]);
+                                    for (int a = 0; a < CI; a++) edd_fmac_bc(acc[a], qv, EDD_W(a + k), 4 * g + k);
+                            } else {
+                                const ed4_d2 q0 = Q[g % NQ][0], q1 = Q[g % NQ][1];
 #pragma unroll
-                            for (int a = 0; a < CI; a++) acc[a] = __builtin_fma(EDD_W(a + 2), q1.x, acc[a]);
+                                for (int a = 0; a < CI; a++) acc[a] = __builtin_fma(EDD_W(a), q0.x, acc[a]);
 #pragma unroll
-                            for (int a = 0; a < CI; a++) acc[a] = __builtin_fma(EDD_W(a + 3), q1.y, acc[a]);
+                                for (int a = 0; a < CI; a++) acc[a] = __builtin_fma(EDD_W(a + 1), q0.y, acc[a]);
+#pragma unroll
+                                for (int a = 0; a < CI; a++) acc[a] = __builtin_fma(EDD_W(a + 2), q1.x, acc[a]);
+#pragma unroll
+                                for (int a = 0; a < CI; a++) acc[a] = __builtin_fma(EDD_W(a + 3), q1.y, acc[a]);
+                            }
 #undef EDD_W
                         }
                     }
