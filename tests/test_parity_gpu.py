@@ -1206,6 +1206,41 @@ def test_ed_pruner_tile_classes_every_remainder_length(world):
         ctx.load_series(series)
 
 
+def test_ed_pruner_every_window_split_and_awkward_window_lengths(world):
+    """The launcher shares a unit between 1, 2 or 4 waves (each takes a range of 128-point chunks, part 0 finishes the
+    candidates): every split pair forced through KVM_ED_SPLIT, window lengths that leave 1..127 points for the last chunk, fewer
+    chunks than parts (m = 200 split four ways: two parts have no chunk), runs of all three tile classes with a planted copy
+    each; RSM-ED with every point evaluated (the device-built lists of cNSM-ED and of early abandoning split by themselves),
+    bit for bit against the oracle."""
+    kvmatch, datagen, series, ctx = world
+    rng = np.random.default_rng(321)
+    lengths = [1, 7, 16, 17, 31, 32, 33, 50, 64, 65, 100, 128, 129, 200, 16, 16, 5, 9]
+    try:
+        ctx.set_option(kvmatch.OPT_EARLY_ABANDON, 0)
+        for m in (200, 257, 1000, 1111, 2049):
+            s = series.copy()
+            q = s[5000:5000 + m].copy()
+            L, R, pos = [], [], 12_000
+            for i, ln in enumerate(lengths):
+                L.append(pos)
+                R.append(pos + ln - 1)
+                off = (pos, pos + ln - 1, pos + ln // 2)[i % 3]
+                s[off - 1: off - 1 + m] = q + rng.normal(size=m) * 0.01
+                pos += ln + m + int(rng.integers(2, 40))
+            assert pos + m < len(s)
+            L, R = np.array(L, dtype=np.int32), np.array(R, dtype=np.int32)
+            ctx.load_series(s)
+            want = oracle.rsm_ed(s, q, L, R, 0, 2.0)
+            assert len(want[0]) >= len(lengths)
+            for sp in ("1,1", "1,2", "1,4", "2,1", "2,2", "2,4", "4,1", "4,2", "4,4"):
+                os.environ["KVM_ED_SPLIT"] = sp
+                compare(kvmatch.QueryEngine(ctx).verify((L, R), 1, q, 2.0), want, tag=f"split {sp} m={m}")
+    finally:
+        os.environ.pop("KVM_ED_SPLIT", None)
+        ctx.set_option(kvmatch.OPT_EARLY_ABANDON, 1)
+        ctx.load_series(series)
+
+
 def test_ed_pruner_class_c_on_a_long_list_of_short_runs(built):
     """Class-C tiles (remainders of 1..16 candidates, two per row) are only used when the list needs more than one round of
     the chip's wave slots (kvm_api.hip: hybrid_mode): 90 000 runs of 1..48 candidates, early abandoning off -> several
