@@ -989,6 +989,12 @@ __global__ __launch_bounds__(256) void kvm_retile_rsm_kernel(const double *__res
                 a0 = __builtin_fma(d0, d0, a0);
                 a1 = __builtin_fma(d1, d1, a1);
             }
+            // every candidate of the tile is dead already (the sums only grow: terms >= 0, round to nearest is monotone):
+            // on a random list that is the case after the first block, and the tile costs one block instead of eight
+            if (!__any(lane < tl.count && !(a0 + a1 > lim))) {
+                j = head;
+                break;
+            }
         }
         for (; j < head; j++) {
             const double d0 = xw[lane + j] - qs[j];
