@@ -6,7 +6,9 @@ import os, sys, re, collections
 if len(sys.argv) > 1:
     acc = collections.defaultdict(list); sect = None
     for line in open(sys.argv[1]):
-        if line.startswith("== "): sect = line.strip(); continue
+        if line.startswith("== "):
+            sect = None if line.strip().endswith(" end") else line.strip()
+            continue
         m = re.match(r"\[kvm\] (.+?)\s+([0-9.]+) us", line)
         if m and sect: acc[(sect, m.group(1).strip())].append(float(m.group(2)))
     last = None
