@@ -295,5 +295,13 @@ int main(int argc, char **argv) {
         run<16, 2, 0, 1>("CI 16 q scalar  x LDS  staged", wps);
         run<16, 1, 1, 0>("CI 16 q none    x none unstaged (bare, 16 acc)", wps);
     }
+    // occupancy: with chunks of 64 points a workgroup's LDS is 46 KB and three fit a CU (the library's 63 KB allow two)
+    for (int wps : {1, 2, 3}) {
+        run<8, 3, 0, 0, 64>("CI 8  q DPP     x LDS  unstaged  JC 64", wps);
+        run<8, 3, 0, 1, 64>("CI 8  q DPP     x LDS  staged    JC 64", wps);
+        run<8, 1, 0, 0, 64>("CI 8  q none    x LDS  unstaged  JC 64", wps);
+        run<8, 1, 1, 0, 64>("CI 8  q none    x none unstaged  JC 64 (bare)", wps);
+        run<4, 3, 0, 0, 64>("CI 4  q DPP     x LDS  unstaged  JC 64", wps);
+    }
     return 0;
 }
