@@ -1127,20 +1127,22 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
     // the query block (the tile list -- 16 B per tile -- is expanded from the runs on the GPU, by the kernel that also
     // zeroes the counters; for cNSM-ED the exact-pass block is filled in and copied further down, in stream order, before
     // its only reader -- the exact pass -- is launched)
-    HIPCHK(ctx, kvm_launch_upload(ctx->b_query.p, hp, qfirst, stream));
+    // (the upload rides on the expansion launch: one launch less per call -- a latency-bound call is a chain of launches)
     const kvm_run *d_runs = d_runs_w;
     if (rbytes) {
         if (hybrid)
             HIPCHK(ctx, kvm_launch_expand_tiles_hybrid(d_runs, pl.n_runs, hybrid_mode, (kvm_tile *)ctx->b_tiles.p,
                                                        (kvm_tile *)ctx->b_tiles.p + pl.n_tiles,
                                                        (kvm_tile *)ctx->b_tiles.p + pl.n_tiles + pl.n_tiles_b,
-                                                       (unsigned long long *)ctx->b_counters.p, rws.run_maxk, stream));
+                                                       (unsigned long long *)ctx->b_counters.p, rws.run_maxk, stream,
+                                                       ctx->b_query.p, hp, qfirst));
         else
             // (cNSM: also what the reference's running sums of each interval pass over -- guard of the pruners, kvm_hist_*)
             HIPCHK(ctx, kvm_launch_expand_tiles(d_runs, pl.n_runs, tile_max, (kvm_tile *)ctx->b_tiles.p,
                                                 (unsigned long long *)ctx->b_counters.p, rws.run_maxk, stream,
-                                                ctx->d_blockmax, d_run_hist, m, ctx->n));
+                                                ctx->d_blockmax, d_run_hist, m, ctx->n, ctx->b_query.p, hp, qfirst));
     } else {
+        HIPCHK(ctx, kvm_launch_upload(ctx->b_query.p, hp, qfirst, stream));
         HIPCHK(ctx, hipMemsetAsync(ctx->b_counters.p, 0, KVM_CNT_TOTAL * sizeof(unsigned long long), stream));
     }
     qd.q = (const double *)ctx->b_query.p;

@@ -212,8 +212,11 @@ __global__ __launch_bounds__(256) void kvm_expand_tiles_hybrid_kernel(const kvm_
                                                                       kvm_tile *__restrict__ tilesB,
                                                                       kvm_tile *__restrict__ tilesC,
                                                                       unsigned long long *__restrict__ counters,
-                                                                             int32_t *__restrict__ run_maxk) {
+                                                                      int32_t *__restrict__ run_maxk,
+                                                                      unsigned long long *__restrict__ up_dst,
+                                                                      const unsigned long long *__restrict__ up_src, int64_t up_n8) {
     if (blockIdx.x == 0 && threadIdx.x < KVM_CNT_TOTAL) counters[threadIdx.x] = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < up_n8; i += (int64_t)gridDim.x * blockDim.x) up_dst[i] = up_src[i];  // (the call's query block: see kvm_expand_tiles_kernel)
     const int lane = threadIdx.x & 63;
     const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= n_runs) return;
@@ -255,10 +258,12 @@ __global__ __launch_bounds__(256) void kvm_expand_tiles_hybrid_kernel(const kvm_
 }
 
 hipError_t kvm_launch_expand_tiles_hybrid(const kvm_run *runs, int64_t n_runs, int hybrid, kvm_tile *tilesA, kvm_tile *tilesB,
-                                          kvm_tile *tilesC, unsigned long long *counters, int32_t *run_maxk, hipStream_t s) {
-    if (n_runs <= 0) return hipSuccess;
+                                          kvm_tile *tilesC, unsigned long long *counters, int32_t *run_maxk, hipStream_t s,
+                                          void *up_dst, const void *up_src_pinned, size_t up_bytes) {
+    if (n_runs <= 0) return up_bytes ? kvm_launch_upload(up_dst, up_src_pinned, up_bytes, s) : hipSuccess;
     hipLaunchKernelGGL(kvm_expand_tiles_hybrid_kernel, dim3((unsigned)((n_runs + 3) / 4)), dim3(256), 0, s, runs, n_runs,
-                       hybrid, tilesA, tilesB, tilesC, counters, run_maxk);
+                       hybrid, tilesA, tilesB, tilesC, counters, run_maxk, (unsigned long long *)up_dst,
+                       (const unsigned long long *)up_src_pinned, (int64_t)((up_bytes + 7) / 8));
     return hipGetLastError();
 }
 
@@ -336,8 +341,12 @@ __global__ __launch_bounds__(256) void kvm_expand_tiles_kernel(const kvm_run *__
                                                                unsigned long long *__restrict__ counters,
                                                                int32_t *__restrict__ run_maxk,
                                                                const double *__restrict__ blockmax, double *__restrict__ run_hist,
-                                                               int32_t m, int64_t n) {
+                                                               int32_t m, int64_t n, unsigned long long *__restrict__ up_dst,
+                                                               const unsigned long long *__restrict__ up_src, int64_t up_n8) {
     if (blockIdx.x == 0 && threadIdx.x < KVM_CNT_TOTAL) counters[threadIdx.x] = 0;  // (saves a fill launch per call)
+    // ... and the upload launch: the call's query block comes over from the pinned staging buffer here (kvm_upload_kernel's
+    // loop; nothing between the plan kernels and this one reads it)
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < up_n8; i += (int64_t)gridDim.x * blockDim.x) up_dst[i] = up_src[i];
     const int lane = threadIdx.x & 63;
     const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= n_runs) return;
@@ -376,10 +385,11 @@ __global__ __launch_bounds__(256) void kvm_expand_tiles_kernel(const kvm_run *__
 
 hipError_t kvm_launch_expand_tiles(const kvm_run *runs, int64_t n_runs, int32_t tile_max, kvm_tile *tiles,
                                    unsigned long long *counters, int32_t *run_maxk, hipStream_t s, const double *blockmax,
-                                   double *run_hist, int32_t m, int64_t n) {
-    if (n_runs <= 0) return hipSuccess;
+                                   double *run_hist, int32_t m, int64_t n, void *up_dst, const void *up_src_pinned, size_t up_bytes) {
+    if (n_runs <= 0) return up_bytes ? kvm_launch_upload(up_dst, up_src_pinned, up_bytes, s) : hipSuccess;
     hipLaunchKernelGGL(kvm_expand_tiles_kernel, dim3((unsigned)((n_runs + 3) / 4)), dim3(256), 0, s, runs, n_runs,
-                       tile_max, tiles, counters, run_maxk, blockmax, run_hist, m, n);
+                       tile_max, tiles, counters, run_maxk, blockmax, run_hist, m, n, (unsigned long long *)up_dst,
+                       (const unsigned long long *)up_src_pinned, (int64_t)((up_bytes + 7) / 8));
     return hipGetLastError();
 }
 

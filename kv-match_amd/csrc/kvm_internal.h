@@ -194,12 +194,15 @@ hipError_t kvm_launch_upload(void *dst, const void *src_pinned, size_t bytes, hi
 hipError_t kvm_launch_set_u64(unsigned long long *a, unsigned long long va, unsigned long long *b, unsigned long long vb,
                               hipStream_t s);
 // (run_hist != nullptr, cNSM: also the per-run maximum of the block maxima `blockmax` over the run's data range)
+// (`up_*`: optionally the call's query block, copied from the pinned staging buffer by the same launch)
 hipError_t kvm_launch_expand_tiles(const kvm_run *runs, int64_t n_runs, int32_t tile_max, kvm_tile *tiles,
                                    unsigned long long *counters, int32_t *run_maxk, hipStream_t s,
-                                   const double *blockmax = nullptr, double *run_hist = nullptr, int32_t m = 0, int64_t n = 0);
+                                   const double *blockmax = nullptr, double *run_hist = nullptr, int32_t m = 0, int64_t n = 0,
+                                   void *up_dst = nullptr, const void *up_src_pinned = nullptr, size_t up_bytes = 0);
 // hybrid ED tiling: classes A / B / C of kvm_ed_remainder_classes
 hipError_t kvm_launch_expand_tiles_hybrid(const kvm_run *runs, int64_t n_runs, int hybrid, kvm_tile *tilesA, kvm_tile *tilesB,
-                                          kvm_tile *tilesC, unsigned long long *counters, int32_t *run_maxk, hipStream_t s);
+                                          kvm_tile *tilesC, unsigned long long *counters, int32_t *run_maxk, hipStream_t s,
+                                          void *up_dst = nullptr, const void *up_src_pinned = nullptr, size_t up_bytes = 0);
 hipError_t kvm_launch_prefix(const double *x, double2 *prefix, int64_t n, hipStream_t s);
 // max x^2 per prefix block (at load)
 hipError_t kvm_launch_blockmax(const double *x, int64_t n, double *blockmax, hipStream_t s);
