@@ -1,6 +1,6 @@
 #!/bin/bash
-# same-box A/B of build variants (profiles/variants/*.so) on the bench list WITH the reference's early abandoning: the stream's
-# rate with every point evaluated and with abandoning, one and five queries in flight (steps 24: the abandoning leg runs steps/4)
+# same-box A/B of build variants (profiles/variants/*.so) on the bench list: the stream's rate with every point evaluated and
+# with the reference's early abandoning, one and five queries in flight
 cd "$(dirname "$0")/.."
 line() { python -c "
 import json,sys
