@@ -1165,7 +1165,9 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
     KVM_TP("  H2D enqueue");
     if (n_tiles + pl.n_tiles_b + pl.n_tiles_c == 0) return KVM_OK;
 
-    if (ctx->opt_timing) HIPCHK(ctx, hipEventRecord(ctx->ev0, stream));
+    // (the default ED pruner on a host-planned list stamps its own begin and end: kvm_launch_ed_dot)
+    const bool self_timed = ctx->opt_timing && !dtw && !retile && !gen && ed_kernel == 3;
+    if (ctx->opt_timing && !self_timed) HIPCHK(ctx, hipEventRecord(ctx->ev0, stream));
     if (!dtw) {
         // pruning pass (fast kernels, guard band) -> survivors -> exact pass in the reference's operation order
         if ((rc = ensure(ctx, ctx->b_cands, (size_t)pl.windows * sizeof(kvm_surv) + 64))) return rc;
@@ -1196,11 +1198,11 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
         else if (ed_kernel == 3)
             HIPCHK(ctx, kvm_launch_ed_dot(ctx->d_series, ctx->d_prefix, ctx->n, qd, d_tiles, pl.n_tiles, d_tiles + pl.n_tiles,
                                           pl.n_tiles_b, d_tiles + pl.n_tiles + pl.n_tiles_b, pl.n_tiles_c, surv, pl.windows, counters, ctx->num_cu, nullptr, out.d_off, out.d_dist,
-                                          out.cap, stream));
+                                          out.cap, stream, self_timed ? ctx->ev0 : nullptr, self_timed ? ctx->ev1 : nullptr));
         else
             HIPCHK(ctx, kvm_launch_ed_wave(ctx->d_series, ctx->d_prefix, ctx->n, qd, d_tiles, n_tiles, surv,
                                            pl.windows, counters, stream));
-        if (ctx->opt_timing) HIPCHK(ctx, hipEventRecord(ctx->ev1, stream));
+        if (ctx->opt_timing && !self_timed) HIPCHK(ctx, hipEventRecord(ctx->ev1, stream));
         if (cnsm) {
             // cNSM-ED exact pass: the reference sums over the |zQ|-descending permutation (stable sort with
             // Double.compare(|o2|, |o1|), K/NormQueryEngine.java:443-452).  Computed here, while the pruning kernel runs.

@@ -32,6 +32,7 @@
 #include "kvm_internal.h"
 #include "kvm_seqadd.h"
 #include "kvm_ed_launch_model.h"
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <cmath>
@@ -1075,7 +1076,8 @@ hipError_t kvm_launch_ed_dot(const double *series, const double2 *prefix, int64_
                              const kvm_tile *tilesA, int64_t nA, const kvm_tile *tilesB, int64_t nB,
                              const kvm_tile *tilesC, int64_t nC, kvm_surv *surv,
                              int64_t cap, unsigned long long *counters, int num_cu, const unsigned long long *d_counts,
-                             int32_t *out_off, double *out_dist, int64_t out_cap, hipStream_t s) {
+                             int32_t *out_off, double *out_dist, int64_t out_cap, hipStream_t s, hipEvent_t ev_start,
+                             hipEvent_t ev_stop) {
     (void)n;
     if (nA + nB + nC <= 0) return hipSuccess;
     const int64_t unitsA = (nA + EDD_TILES_A - 1) / EDD_TILES_A, unitsB = (nB + EDD_TILES_B - 1) / EDD_TILES_B,
@@ -1137,9 +1139,17 @@ hipError_t kvm_launch_ed_dot(const double *series, const double2 *prefix, int64_
     }
     dim3 grid((unsigned)(blocksA + blocksB + blocksC)), block(256);
     edd_args A{series, prefix, qd, surv, cap, counters, out_off, out_dist, out_cap};
-#define LAUNCH(NORM, AB) \
-    hipLaunchKernelGGL((kvm_ed_dot_kernel<NORM, AB>), grid, block, 0, s, A, tilesA, nA, tilesB, nB, tilesC, nC, fA, fB, fC, blocksA, \
-                       blocksC, d_counts, split_units)
+    // (ev_start / ev_stop: the kernel's own begin and end -- hipExtLaunchKernelGGL stamps the dispatch itself, so the time between
+    // them holds neither the launch's dispatch latency nor a host that enqueues later than the GPU gets there)
+#define LAUNCH(NORM, AB)                                                                                                          \
+    do {                                                                                                                          \
+        if (ev_start && ev_stop)                                                                                                  \
+            hipExtLaunchKernelGGL((kvm_ed_dot_kernel<NORM, AB>), grid, block, 0, s, ev_start, ev_stop, 0, A, tilesA, nA, tilesB,  \
+                                  nB, tilesC, nC, fA, fB, fC, blocksA, blocksC, d_counts, split_units);                          \
+        else                                                                                                                      \
+            hipLaunchKernelGGL((kvm_ed_dot_kernel<NORM, AB>), grid, block, 0, s, A, tilesA, nA, tilesB, nB, tilesC, nC, fA, fB,   \
+                               fC, blocksA, blocksC, d_counts, split_units);                                                      \
+    } while (0)
     if (qd.normalised) {
         if (qd.early_abandon) LAUNCH(true, true); else LAUNCH(true, false);
     } else {

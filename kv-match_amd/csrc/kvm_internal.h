@@ -254,7 +254,7 @@ hipError_t kvm_launch_ed_dot(const double *series, const double2 *prefix, int64_
                              const kvm_tile *tilesA, int64_t nA, const kvm_tile *tilesB, int64_t nB,
                              const kvm_tile *tilesC, int64_t nC, kvm_surv *surv,
                              int64_t cap, unsigned long long *counters, int num_cu, const unsigned long long *d_counts,
-                             int32_t *out_off, double *out_dist, int64_t out_cap, hipStream_t s);
+                             int32_t *out_off, double *out_dist, int64_t out_cap, hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 // Lane-granular form of the same pruner (kvm_ed_g.hip; RSM, every point evaluated): `tiles8` = the list cut into tiles of 8
 // consecutive candidates (one lane each), 64 of them per wavefront whatever runs they come from; window chunks staged by
 // LDS-DMA from `series_sh` (kvm_ctx::d_series_sh)
