@@ -516,7 +516,7 @@ def main():
     out["roofline"]["kernel_ms_note"] = ("HIP events on the kernel's own stream (RSM-ED every point: the start / stop stamps of the "
                                          "dispatch itself, hipExtLaunchKernelGGL), measured in this run right after the "
                                          f"timed region with ONE query in flight, averaged over the {NQ} queries and their "
-                                         "lists: the kernel's own duration on the chip the stream has heated (what rocprofv3 "
+                                         "lists: the kernel's own duration (what rocprofv3 "
                                          f"--kernel-trace shows per launch).  In the timed region the kernels of {F} contexts "
                                          "overlap, so an event-to-event time there is not a kernel's own; the events are off "
                                          "there (they cost ~0.1 ms of stream time per query)")
