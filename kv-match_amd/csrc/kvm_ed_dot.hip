@@ -901,9 +901,10 @@ __device__ __forceinline__ void retile_flush(retile_out<CAP> &o, kvm_tile *__res
 // the trimmed tiles into the two classes of the pruner (33..64 -> A, 1..32 -> B); tiles without a passing candidate
 // disappear.  The filter is selective in practice and its survivors are contiguous stretches of a run (mean and sigma
 // move slowly with the offset), so the pruner's O(m) work shrinks by about the selectivity.  One wavefront per tile,
-// one lane per candidate; 64 tiles per workgroup are collected in LDS and appended with one pair of global atomics
-// (one atomic per tile on a single address cost 0.3 ms at 24 000 tiles); list order is whatever the atomics give.
-#define RETILE_PER_BLOCK 64  // tiles per workgroup: 4 waves x 16 tiles; one pair of global atomics per workgroup
+// one lane per candidate; 32 tiles per workgroup are collected in LDS and appended with one pair of global atomics
+// (one atomic per tile on a single address cost 0.3 ms at 24 000 tiles; 16 tiles per workgroup are as fast on a selective
+// filter and pay twice the atomics on a list everything passes); list order is whatever the atomics give.
+#define RETILE_PER_BLOCK 32  // tiles per workgroup: 4 waves x 8 tiles (two batches of four); one pair of global atomics per workgroup
 __global__ __launch_bounds__(256) void kvm_retile_cnsm_kernel(const double *__restrict__ series,
                                                               const double2 *__restrict__ prefix, kvm_query_dev qd,
                                                               const kvm_tile *__restrict__ tiles, int64_t n_tiles,
@@ -914,17 +915,37 @@ __global__ __launch_bounds__(256) void kvm_retile_cnsm_kernel(const double *__re
     if (threadIdx.x == 0) out.na = out.nb = 0;
     __syncthreads();
     const int64_t t0 = (int64_t)blockIdx.x * RETILE_PER_BLOCK + wave * (RETILE_PER_BLOCK / 4);
-    for (int i = 0; i < RETILE_PER_BLOCK / 4; i++) {
-        const int64_t t = t0 + i;
-        if (t >= n_tiles) break;  // wave-uniform
-        const kvm_tile tl = tiles[t];
-        bool ok = false;
-        if (lane < tl.count) {
-            double mean, sd;
-            const kvm_stat_guard sg = kvm_window_mean_std_g(prefix, series, (int64_t)tl.start - 1 + lane, qd.m, mean, sd, kvm_run_hist_of(qd, tl.run));
-            ok = kvm_cnsm_filter_guarded(mean, sd, qd.meanQ, qd.stdQ, qd.alpha, qd.beta, sg);
+    // Four tiles at a time: their descriptors together, then the raw prefix operands of the four windows of every lane
+    // (kvm_issue_window_sums: unconditional loads from addresses valid for every lane), then the four decisions -- three memory
+    // latencies per four tiles.  One tile after the other, each behind its own descriptor load, was three latencies per TILE on
+    // one wave per SIMD: 31-41 us for the bench list, whatever the arithmetic behind them (profiles/retile_probe.py).
+    constexpr int RB = 4;
+    for (int i0 = 0; i0 < RETILE_PER_BLOCK / 4; i0 += RB) {
+        if (t0 + i0 >= n_tiles) break;  // wave-uniform
+        kvm_tile tls[RB];
+        kvm_raw_sums raw[RB];
+        double hist[RB];
+#pragma unroll
+        for (int u = 0; u < RB; u++) tls[u] = tiles[t0 + i0 + u < n_tiles ? t0 + i0 + u : n_tiles - 1];
+#pragma unroll
+        for (int u = 0; u < RB; u++) {
+            raw[u] = kvm_issue_window_sums(prefix, series, (int64_t)tls[u].start - 1 + (lane < tls[u].count ? lane : 0), qd.m);
+            hist[u] = kvm_run_hist_of(qd, tls[u].run);
         }
-        retile_collect(out, tl, __ballot(ok));
+#pragma unroll
+        for (int u = 0; u < RB; u++) {
+            if (t0 + i0 + u >= n_tiles) break;  // wave-uniform
+            const kvm_tile tl = tls[u];
+            bool ok = false;
+            if (lane < tl.count) {
+                double s1, s2, c, pm;   // = kvm_window_mean_std_g, from the operands loaded above (same arithmetic, same order)
+                kvm_finish_window_sums(raw[u], prefix, series, (int64_t)tl.start - 1 + lane, qd.m, s1, s2, c, &pm);
+                const double ms = s1 / qd.m, mean = c + ms, sd = sqrt(s2 / qd.m - ms * ms);
+                const kvm_stat_guard sg = kvm_make_stat_guard(c, s1, s2, qd.m, pm, hist[u]);
+                ok = kvm_cnsm_filter_guarded(mean, sd, qd.meanQ, qd.stdQ, qd.alpha, qd.beta, sg);
+            }
+            retile_collect(out, tl, __ballot(ok));
+        }
     }
     retile_flush(out, tilesA, tilesB, d_counts);
 }
