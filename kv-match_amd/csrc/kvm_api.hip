@@ -161,7 +161,7 @@ extern "C" int kvm_set_option(kvm_ctx *ctx, int32_t option, int64_t value) {
             ctx->opt_ed_kernel = value;
             return KVM_OK;
         case KVM_OPT_TIMING: ctx->opt_timing = value ? 1 : 0; return KVM_OK;
-        case KVM_OPT_DP_KERNEL: ctx->opt_dp_kernel = value == 1 ? 1 : 0; return KVM_OK;
+        case KVM_OPT_DP_KERNEL: ctx->opt_dp_kernel = (value >= 0 && value <= 3) ? value : 0; return KVM_OK;
         case KVM_OPT_SORT_VIOLATION: ctx->opt_sort_violation = value ? 1 : 0; return KVM_OK;
         case KVM_OPT_UCR_LOOPS: ctx->opt_ucr_loops = value ? 1 : 0; return KVM_OK;
         case KVM_OPT_STRICT_BOUNDS: ctx->opt_strict_bounds = value ? 1 : 0; return KVM_OK;
@@ -1311,7 +1311,7 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
         KVM_DBG_SYNC(ctx, stream, "exact_stats");
         if ((rc = ensure(ctx, ctx->b_plans, kvm_dtw_plan_bytes(pl.windows) + 64))) return rc;
         HIPCHK(ctx, kvm_launch_dtw_dp(ctx->d_series, ctx->n, qd, ax, c1, dp_n, pl.windows, ctx->b_plans.p, out.d_off, out.d_dist,
-                                      out.cap, counters, ctx->num_cu, ctx->opt_dp_kernel == 1 ? 1 : 0, stream,
+                                      out.cap, counters, ctx->num_cu, (int)ctx->opt_dp_kernel, stream,
                                       ctx->opt_timing ? ctx->ev0 : nullptr));  // (timing: the DP kernel alone)
         KVM_DBG_SYNC(ctx, stream, "dtw_dp");
         dtw_qd = qd;
@@ -1379,7 +1379,7 @@ static int dtw_resolve_ambiguous(kvm_ctx *ctx, const kvm_query_dev &qd, const kv
         KVM_DBG_SYNC(ctx, stream, "dtw_ref_chains");
         HIPCHK(ctx, kvm_launch_set_u64(counters + KVM_CNT_CANDS2, (unsigned long long)nb, counters + KVM_CNT_QUEUE, 0ULL, stream));
         HIPCHK(ctx, kvm_launch_dtw_dp(ctx->d_series, ctx->n, qd, ax2, cands + off, counters + KVM_CNT_CANDS2, nb, nullptr,
-                                      out.d_off, out.d_dist, out.cap, counters, ctx->num_cu, ctx->opt_dp_kernel == 1 ? 1 : 0,
+                                      out.d_off, out.d_dist, out.cap, counters, ctx->num_cu, (int)ctx->opt_dp_kernel,
                                       stream));
         KVM_DBG_SYNC(ctx, stream, "dtw_dp (exact cb)");
     }

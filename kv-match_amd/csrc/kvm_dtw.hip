@@ -16,11 +16,8 @@
 // Whatever lands within rounding of eps^2 in a wave-parallel sum is "ambiguous" and goes to the sequential path
 // (kvm_dtw_ref.hip), which returns exact cb[] arrays for a second run of the same DP that compares without tolerance.
 // With KVM_OPT_LB_CASCADE=0 the screens are skipped and this stage sees every filter-passing candidate: same answers.
-#include "kvm_dtw_ref.h"
+#include "kvm_dtw_dp.h"
 
-#define DTW_INF 1e20  // K/utils/DtwUtils.java:24
-
-__device__ __forceinline__ double dsq(double a, double b) { return (a - b) * (a - b); }
 
 // ---------------------------------------------------------------------------------------------------
 // Stage 1: one lane per candidate window; one wavefront per tile (<= 64 consecutive candidates).
@@ -123,138 +120,6 @@ hipError_t kvm_launch_dtw_filter(const double *series, const double2 *prefix, in
     return hipGetLastError();
 }
 
-// ---------------------------------------------------------------------------------------------------
-// Shared by both DP forms: wave-cooperative pieces of the exact decision (all 64 lanes of the wavefront take part).
-enum { DP_REJECT = 0, DP_RUN = 1, DP_AMBIG = 2 };
-
-__device__ __forceinline__ double dp_scan_add(double v, int lane) {  // inclusive, in lane order
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const double t = __shfl_up(v, o, 64);
-        if (lane >= o) v += t;
-    }
-    return v;
-}
-__device__ __forceinline__ double dp_sel_max(double a, double b) { return (b > a) ? b : a; }  // pure selections, as the
-__device__ __forceinline__ double dp_sel_min(double a, double b) { return (b < a) ? b : a; }  // envelope is (:50-91)
-__device__ __forceinline__ void dp_scan_maxmin(double &mx, double &mn, int lane) {  // inclusive running max / min
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const double tx = __shfl_up(mx, o, 64), tn = __shfl_up(mn, o, 64);
-        if (lane >= o) {
-            mx = dp_sel_max(mx, tx);
-            mn = dp_sel_min(mn, tn);
-        }
-    }
-}
-
-// What the prologue (kvm_dtw_prep_kernel) hands to the sweep, one record per candidate: which bound's terms form cb[]
-// (0: query envelope, 1: data envelope; < 0: the candidate does not reach the DP), their total, and the geometry of the
-// clipped data envelope.
-struct dp_plan {
-    int32_t which;
-    int32_t cbeg, cend, sb;  // fetched chunk [cbeg, cend] (1-based points); sb = first point of the suffix patch
-    double total;
-    double pad;
-};
-static_assert(sizeof(dp_plan) == 32, "one 32-byte record per candidate");
-#define DP_PLAN_REJECT (-1)
-#define DP_PLAN_AMBIG (-2)
-
-// Upper / lower data envelope at 1-based point p as the reference builds it over the fetched chunk:
-// max / min of data[max(cbeg, p-r) .. min(cend, p+r)].  Interior points come from the whole-series envelope; within r of a
-// chunk end from the wave's patch: running max/min from cbeg (PM) and towards cend (SM), 2r entries each.
-__device__ __forceinline__ void dp_env_at(const kvm_dtw_aux &ax, const double *__restrict__ patch, int r, const dp_plan &pl,
-                                          int32_t p, double &U, double &L) {
-    if (p - r < pl.cbeg) {
-        const int t = min(pl.cend, p + r) - pl.cbeg;
-        U = patch[t];
-        L = patch[2 * r + t];
-    } else if (p + r > pl.cend) {
-        const int t = p - r - pl.sb;
-        U = patch[4 * r + t];
-        L = patch[6 * r + t];
-    } else {
-        U = ax.env_u[p - 1];
-        L = ax.env_l[p - 1];
-    }
-}
-
-// The wave's envelope patch for one candidate: running max / min of the data from cbeg upwards (entries [0, 2r) max,
-// [2r, 4r) min) and from cend downwards (entries [4r, 6r) / [6r, 8r), indexed from sb), computed only when the candidate's
-// window comes within r of that end of the chunk.  2r points each: a handful of wave scans.
-__device__ __forceinline__ void dp_build_patch(const double *__restrict__ series, int r, const dp_plan &pl, int32_t start, int m,
-                                               int lane, double *__restrict__ patch) {
-    const int32_t s1 = start, e1 = start + m - 1;
-    if (!(r > 0 && (s1 - r < pl.cbeg || e1 + r > pl.cend))) return;
-    if (s1 - r < pl.cbeg) {
-        const int32_t last = min(pl.cend, pl.cbeg + 2 * r - 1);
-        double cx = -__builtin_huge_val(), cn = __builtin_huge_val();
-        for (int32_t base = pl.cbeg; base <= last; base += 64) {
-            const int32_t t = base + lane;
-            const double v = series[min(t, last) - 1];
-            double mx = v, mn = v;  // (lanes past `last` repeat the last point: no effect on a running max / min)
-            dp_scan_maxmin(mx, mn, lane);
-            mx = dp_sel_max(cx, mx);
-            mn = dp_sel_min(cn, mn);
-            if (t <= last) {
-                patch[t - pl.cbeg] = mx;
-                patch[2 * r + (t - pl.cbeg)] = mn;
-            }
-            cx = kvm_readlane_f64(mx, 63);
-            cn = kvm_readlane_f64(mn, 63);
-        }
-    }
-    if (e1 + r > pl.cend) {
-        double cx = -__builtin_huge_val(), cn = __builtin_huge_val();
-        for (int32_t base = pl.cend; base >= pl.sb; base -= 64) {
-            const int32_t t = base - lane;
-            const double v = series[max(t, pl.sb) - 1];
-            double mx = v, mn = v;
-            dp_scan_maxmin(mx, mn, lane);
-            mx = dp_sel_max(cx, mx);
-            mn = dp_sel_min(cn, mn);
-            if (t >= pl.sb) {
-                patch[4 * r + (t - pl.sb)] = mx;
-                patch[6 * r + (t - pl.sb)] = mn;
-            }
-            cx = kvm_readlane_f64(mx, 63);
-            cn = kvm_readlane_f64(mn, 63);
-        }
-    }
-    // the patch is read back by other lanes of this wavefront, through the CU's own L1: a WORKGROUP-scope fence (wait for
-    // the stores; no cache action is needed inside a CU) -- an agent-scope __threadfence() writes the L2 back and cost
-    // ~0.15 ms per candidate here
-    __threadfence_block();
-}
-
-// The terms of the wave-parallel sums are formed with ONE reciprocal per candidate instead of a division per term: the
-// sums are only compared within the tolerance tau, which carries the difference (a normalised value off by <= 3 ulp moves
-// a term (w - e)^2 by <= 6u sqrt(term) |w|; |w| <= sqrt(m) wherever a term is non-zero, so a whole sum moves by
-// <= 6u m sqrt(sum): the 1e-15 m / sqrt(eps^2) in kvm_dtw_aux::tau).  The divisions were 45 % of the prologue's
-// instructions.  Bit-exact terms are only needed where additions are replayed one by one (kvm_dtw_ref.hip) and in the DP
-// cells (fillA keeps its true division).
-__device__ __forceinline__ double dp_term_q(double x, double mean, double inv, double u, double l) {
-    return dref_term_q((x - mean) * inv, u, l);
-}
-__device__ __forceinline__ double dp_term_d(double qv, double U, double L, double mean, double inv) {
-    const double uu = (U - mean) * inv, ll = (L - mean) * inv;
-    double d = 0;
-    if (qv > uu) d = dref_dsq(qv, uu);
-    else if (qv < ll) d = dref_dsq(qv, ll);
-    return d;
-}
-
-// term k (natural window position) of the bound chosen for cb[]: cb1[k] / cb2[k] of K/NormQueryEngineDtw.java:559-575
-__device__ __forceinline__ double dp_cb_term(const double *__restrict__ x, const kvm_query_dev &qd, const kvm_dtw_aux &ax,
-                                             const double *__restrict__ patch, const dp_plan &pl, int32_t start, double mean,
-                                             double sd, int k) {
-    const double inv = 1.0 / sd;
-    if (pl.which == 0) return dp_term_q(x[k], mean, inv, qd.qu[k], qd.ql[k]);
-    double U, L;
-    dp_env_at(ax, patch, qd.rho, pl, start + k, U, L);
-    return dp_term_d(qd.q[k], U, L, mean, inv);
-}
 
 #ifndef DP_SUM_MODE
 #define DP_SUM_MODE 1
@@ -438,26 +303,6 @@ __device__ int dp_prologue(const double *__restrict__ series, const kvm_query_de
     return DP_RUN;
 }
 
-// Row test over the macro-steps (register form) / rows (generic form) of one chunk: lane t holds the minimum `rv` of a
-// completed row i and tests `min_cost + cb[i + r + 1] >= bsf` (K/utils/DtwUtils.java:324-326), valid iff i + r < m - 1.
-//   approximate cb (cbv = total - prefix, off by <= 2 tau total <= 2 tau eps^2): a value within `tol` of eps^2 is ambiguous;
-//   exact cb (second run, arrays from kvm_dtw_ref.hip): the reference's comparison itself.
-// Returns 0: no row of the chunk reaches eps^2; 1: the first that does is certainly above (reject); 2: ambiguous;
-// 3: exact mode, first row >= eps^2, its value in `value` (an answer iff <= eps^2, i.e. == eps^2).
-__device__ __forceinline__ int dp_row_test(bool valid, double rv, double cbv, double E, double tol, bool exact, double &value) {
-    const double B = rv + cbv;
-    const unsigned long long bal = __ballot(valid && (exact ? (B >= E) : !(B < E - tol)));
-    if (!bal) return 0;
-    const double Bf = kvm_readlane_f64(B, __ffsll((long long)bal) - 1);
-    value = Bf;
-    if (exact) return 3;
-    return (Bf > E + tol) ? 1 : 2;
-}
-
-__device__ __forceinline__ void dp_emit_ambig(const kvm_dtw_aux &ax, unsigned long long *__restrict__ counters,
-                                              const kvm_cand &c, int lane) {
-    if (lane == 0) ax.ambig[atomicAdd(&counters[KVM_CNT_AMBIG], 1ULL)] = c;
-}
 
 // The prologue as its own kernel (one wavefront per candidate, grid-stride): it writes one dp_plan per candidate and
 // queues the ambiguous ones.  Kept out of the DP kernels so that their register allocation is the sweep's alone (with the
@@ -465,7 +310,7 @@ __device__ __forceinline__ void dp_emit_ambig(const kvm_dtw_aux &ax, unsigned lo
 __global__ __launch_bounds__(256) void kvm_dtw_prep_kernel(const double *__restrict__ series, kvm_query_dev qd, kvm_dtw_aux ax,
                                                            const kvm_cand *__restrict__ in,
                                                            const unsigned long long *__restrict__ d_n_in,
-                                                           dp_plan *__restrict__ plans,
+                                                           dp_plan *__restrict__ plans, unsigned *__restrict__ list,
                                                            unsigned long long *__restrict__ counters) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned long long n_in = *d_n_in;
@@ -483,7 +328,11 @@ __global__ __launch_bounds__(256) void kvm_dtw_prep_kernel(const double *__restr
                 dp_emit_ambig(ax, counters, c, lane);
             }
         }
-        if (lane == 0) plans[idx] = pl;
+        if (lane == 0) {
+            plans[idx] = pl;
+            // the DP kernels take their work from a compact list: every pop is a candidate that runs
+            if (pl.which >= 0) list[atomicAdd(&counters[KVM_CNT_DP_LIST], 1ULL)] = (unsigned)idx;
+        }
     }
 }
 
@@ -677,27 +526,6 @@ __global__ __launch_bounds__(64) void kvm_dtw_dp_lds_kernel(const double *__rest
 // macro-steps the wavefront tests the 64 finished rows in parallel (dp_row_test) -- in row order, so the first row
 // whose bound reaches eps^2 is the reference's.  The cb[] values the test needs are formed right there: total - prefix
 // of the chosen bound's terms, one term per lane and chunk.
-#define DTW_POS_BIG 1e10
-#define DTW_NEG_BIG (-1e10)
-
-__device__ __forceinline__ double dp_min(double a, double b) {
-    // one v_min_f64; fmin() would add a canonicalising v_max_f64 per operand in IEEE mode
-    double r;
-    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-__device__ __forceinline__ double dp_from_left(double v, double fill) {   // lane i <- lane i-1; lane 0 <- fill
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(__double2loint(fill), lo, 0x138 /*wave_shr:1*/, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(__double2hiint(fill), hi, 0x138, 0xf, 0xf, false);
-    return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double dp_from_right(double v, double fill) {  // lane i <- lane i+1; lane 63 <- fill
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(__double2loint(fill), lo, 0x130 /*wave_shl:1*/, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(__double2hiint(fill), hi, 0x130, 0xf, 0xf, false);
-    return __hiloint2double(hi, lo);
-}
 
 // LDS window buffers of the register-form DP.  The data/query values a lane needs advance by one index per macro-step:
 // a block of V macro-steps reads the V values [j V, (j + 1) V) of each window, j = j0 -+ lane, and j0 advances by one per
@@ -740,29 +568,6 @@ struct dp_buf {
     }
 };
 
-__device__ __forceinline__ unsigned dp_u32_from_left(unsigned v, unsigned fill) {
-    return (unsigned)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x138 /*wave_shr:1*/, 0xf, 0xf, false);
-}
-__device__ __forceinline__ unsigned dp_umin3(unsigned a, unsigned b, unsigned c) {  // one v_min3_u32
-    unsigned r;
-    asm("v_min3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
-
-// Row test of the first run (EXACT = false), whose row minima are carried as the HIGH WORDS of the cells only: every cell
-// is a sum of squares, >= +0, so the order of two cells is the order of their bit patterns, and the minimum of the high
-// words is the high word of the minimum -- one v_min3_u32 per slot and macro-step instead of two v_min_f64, one DPP move
-// per hand-over instead of two.  The true minimum rv of a row lies in [rv_lo, rv_up] = high word with the low word all
-// zeros / all ones (a relative width of 2^-20), and fl(rv + cb) is monotone in rv: a row is certainly below eps^2 when even
-// rv_up + cb is (less the tolerance of the approximate cb), the first row that is not rejects the candidate when even
-// rv_lo + cb is above, and is ambiguous otherwise -- the second run (EXACT) carries the minima in full.
-__device__ __forceinline__ int dp_row_test_hi(bool valid, unsigned hi, double cbv, double E, double tol) {
-    const double lo = __hiloint2double((int)hi, 0) + cbv, up = __hiloint2double((int)hi, -1) + cbv;
-    const unsigned long long bal = __ballot(valid && !(up < E - tol));
-    if (!bal) return 0;
-    const double Bf = kvm_readlane_f64(lo, __ffsll((long long)bal) - 1);
-    return (Bf > E + tol) ? 1 : 2;
-}
 
 // A candidate is swept with its row minima on high words first; if the first row that may reach eps^2 cannot be told from
 // a high word (about one candidate in a thousand: the bound of successive rows creeps up on eps^2, so the first row past it
@@ -775,7 +580,8 @@ __device__ __forceinline__ void dp_reg_sweep(const double *__restrict__ series, 
                                              const kvm_cand *__restrict__ in, const dp_plan *__restrict__ plans,
                                              const unsigned long long *__restrict__ d_n_in, int32_t *__restrict__ out_off,
                                              double *__restrict__ out_dist, int64_t cap,
-                                             unsigned long long *__restrict__ counters) {
+                                             unsigned long long *__restrict__ counters, const unsigned *__restrict__ list,
+                                             int share_mode, int num_cu) {
     using BUF = dp_buf<V>;
     constexpr int LIN = BUF::LIN, LIVE = BUF::LIVE, NBLK = 64 / V;
     constexpr int WAVE_LDS = 2 * LIN + 64 * V + 64;  // buffer A, buffer B, result scratch, finished row minima
@@ -787,7 +593,10 @@ __device__ __forceinline__ void dp_reg_sweep(const double *__restrict__ series, 
     const int m = qd.m, r = qd.rho;
     const double eps2 = qd.eps2;
     const double *__restrict__ Bq = qd.q;
-    const unsigned long long n_in = *d_n_in;
+    // first sweep: the entries of the prologue's compact list behind the packed kernel's share; EXACT: the whole of `in`
+    const unsigned long long n_list = EXACT ? 0ULL : counters[KVM_CNT_DP_LIST];
+    const unsigned long long first = EXACT ? 0ULL : dp_pack_share(n_list, num_cu, share_mode, r);
+    const unsigned long long n_in = EXACT ? *d_n_in : n_list - first;
     const int I0 = r >> 1, Ilast = m - 1 + I0;
     const int pV = lane * V;
     const bool edge_lane = lane == r / V;  // the band-edge cell O[r] is cell CSTAR (= r % V) of this lane
@@ -799,9 +608,10 @@ __device__ __forceinline__ void dp_reg_sweep(const double *__restrict__ series, 
     // (one pop per iteration, at most n_in successful pops in the whole grid: the bound is a guard, every wave leaves)
     for (unsigned long long pops = 0; pops <= n_in; pops++) {
         unsigned long long popped = 0;
-        if (lane == 0) popped = atomicAdd(&counters[KVM_CNT_QUEUE], 1ULL);
-        const unsigned long long idx = kvm_uniform_u64(popped);  // (a scalar: see kvm_uniform_u64)
-        if (idx >= n_in) break;
+        if (lane == 0) popped = atomicAdd(&counters[EXACT ? KVM_CNT_QUEUE : KVM_CNT_QUEUE2], 1ULL);
+        const unsigned long long pos = kvm_uniform_u64(popped);  // (a scalar: see kvm_uniform_u64)
+        if (pos >= n_in) break;
+        const unsigned long long idx = EXACT ? pos : (unsigned long long)list[first + pos];
         const kvm_cand cand = in[idx];
         if (cand.start < 0) continue;  // rejected by the exact (alpha, beta) test / by the sequential path
         const double *__restrict__ x = series + (cand.start - 1);
@@ -1063,21 +873,24 @@ template <int V, int CSTAR, bool ABANDON, bool EXACT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void kvm_dtw_dp_reg_kernel(
     const double *__restrict__ series, kvm_query_dev qd, kvm_dtw_aux ax, const kvm_cand *__restrict__ in,
     const dp_plan *__restrict__ plans, const unsigned long long *__restrict__ d_n_in, int32_t *__restrict__ out_off,
-    double *__restrict__ out_dist, int64_t cap, unsigned long long *__restrict__ counters) {
-    dp_reg_sweep<V, CSTAR, ABANDON, EXACT>(series, qd, ax, in, plans, d_n_in, out_off, out_dist, cap, counters);
+    double *__restrict__ out_dist, int64_t cap, unsigned long long *__restrict__ counters, const unsigned *__restrict__ list,
+    int share_mode, int num_cu) {
+    dp_reg_sweep<V, CSTAR, ABANDON, EXACT>(series, qd, ax, in, plans, d_n_in, out_off, out_dist, cap, counters, list, share_mode, num_cu);
 }
 template <int V, int CSTAR, bool ABANDON, bool EXACT>
 __global__ __launch_bounds__(256) void kvm_dtw_dp_reg_wide_kernel(
     const double *__restrict__ series, kvm_query_dev qd, kvm_dtw_aux ax, const kvm_cand *__restrict__ in,
     const dp_plan *__restrict__ plans, const unsigned long long *__restrict__ d_n_in, int32_t *__restrict__ out_off,
-    double *__restrict__ out_dist, int64_t cap, unsigned long long *__restrict__ counters) {
-    dp_reg_sweep<V, CSTAR, ABANDON, EXACT>(series, qd, ax, in, plans, d_n_in, out_off, out_dist, cap, counters);
+    double *__restrict__ out_dist, int64_t cap, unsigned long long *__restrict__ counters, const unsigned *__restrict__ list,
+    int share_mode, int num_cu) {
+    dp_reg_sweep<V, CSTAR, ABANDON, EXACT>(series, qd, ax, in, plans, d_n_in, out_off, out_dist, cap, counters, list, share_mode, num_cu);
 }
 
 template <int V, int CSTAR>
 static hipError_t launch_dp_reg_c(const double *series, const kvm_query_dev &qd, const kvm_dtw_aux &ax, const kvm_cand *in,
                                   const dp_plan *plans, const unsigned long long *d_n_in, int64_t max_in, int32_t *out_off, double *out_dist,
-                                  int64_t cap, unsigned long long *counters, int num_cu, hipStream_t s) {
+                                  int64_t cap, unsigned long long *counters, int num_cu, const unsigned *list, int share_mode,
+                                  hipStream_t s) {
     // resident workgroups per CU = waves per SIMD: bounded by the LDS (4 waves x (2*LIN + 64V + 64) doubles per workgroup)
     // and by the registers (three waves for V <= 4, two for V = 8, see the kernels)
     const int lds_limit = (int)((160 * 1024) / (4 * (2 * dp_buf<V>::LIN + 64 * V + 64) * sizeof(double)));
@@ -1088,10 +901,10 @@ static hipError_t launch_dp_reg_c(const double *series, const kvm_query_dev &qd,
     do {                                                                                                                     \
         if constexpr (V <= 4)                                                                                                \
             hipLaunchKernelGGL((kvm_dtw_dp_reg_kernel<V, CSTAR, AB, EX>), dim3((unsigned)blocks), dim3(256), 0, s, series,   \
-                               qd, ax, in, plans, d_n_in, out_off, out_dist, cap, counters);                                 \
+                               qd, ax, in, plans, d_n_in, out_off, out_dist, cap, counters, list, share_mode, num_cu);        \
         else                                                                                                                 \
             hipLaunchKernelGGL((kvm_dtw_dp_reg_wide_kernel<V, CSTAR, AB, EX>), dim3((unsigned)blocks), dim3(256), 0, s,      \
-                               series, qd, ax, in, plans, d_n_in, out_off, out_dist, cap, counters);                         \
+                               series, qd, ax, in, plans, d_n_in, out_off, out_dist, cap, counters, list, share_mode, num_cu); \
     } while (0)
     const bool exact = ax.cb_exact != nullptr;  // the run on the sequential path's candidates: exact cb[], the reference's comparison
     if (qd.early_abandon) {
@@ -1109,11 +922,12 @@ static hipError_t launch_dp_reg_c(const double *series, const kvm_query_dev &qd,
 template <int V>
 static hipError_t launch_dp_reg(const double *series, const kvm_query_dev &qd, const kvm_dtw_aux &ax, const kvm_cand *in,
                                 const dp_plan *plans, const unsigned long long *d_n_in, int64_t max_in, int32_t *out_off, double *out_dist,
-                                int64_t cap, unsigned long long *counters, int num_cu, hipStream_t s) {
+                                int64_t cap, unsigned long long *counters, int num_cu, const unsigned *list, int share_mode,
+                                hipStream_t s) {
 #define KVM_DP_CASE(C)                                                                                          \
     case C:                                                                                                     \
         if constexpr (C < V)                                                                                    \
-            return launch_dp_reg_c<V, C>(series, qd, ax, in, plans, d_n_in, max_in, out_off, out_dist, cap, counters, num_cu, s); \
+            return launch_dp_reg_c<V, C>(series, qd, ax, in, plans, d_n_in, max_in, out_off, out_dist, cap, counters, num_cu, list, share_mode, s); \
         break;
     switch (qd.rho % V) {
         KVM_DP_CASE(0) KVM_DP_CASE(1) KVM_DP_CASE(2) KVM_DP_CASE(3)
@@ -1125,22 +939,23 @@ static hipError_t launch_dp_reg(const double *series, const kvm_query_dev &qd, c
 
 int64_t kvm_dtw_dp_max_waves(int num_cu) { return (int64_t)num_cu * 4 * 2 * DP_BLOCKS_PER_CU; }  // (the prep kernel's grid)
 
-size_t kvm_dtw_plan_bytes(int64_t n) { return (size_t)n * sizeof(dp_plan); }
+size_t kvm_dtw_plan_bytes(int64_t n) { return (size_t)n * (sizeof(dp_plan) + sizeof(unsigned)); }
 
 // `plan_buf`: kvm_dtw_plan_bytes(max_in) bytes of scratch for the per-candidate plan records (unused when ax.cb_exact is
 // set: the second run on the sequential path's candidates has nothing left to decide in front of the DP)
 hipError_t kvm_launch_dtw_dp(const double *series, int64_t n, const kvm_query_dev &qd, const kvm_dtw_aux &ax, const kvm_cand *in,
                              const unsigned long long *d_n_in, int64_t max_in, void *plan_buf, int32_t *out_off, double *out_dist,
-                             int64_t cap, unsigned long long *counters, int num_cu, int force_lds, hipStream_t s,
+                             int64_t cap, unsigned long long *counters, int num_cu, int dp_form, hipStream_t s,
                              hipEvent_t ev_dp_start) {
     (void)n;
     if (max_in <= 0) return hipSuccess;
     dp_plan *plans = reinterpret_cast<dp_plan *>(plan_buf);
+    unsigned *list = ax.cb_exact ? nullptr : reinterpret_cast<unsigned *>(plans + max_in);
     if (!ax.cb_exact) {
         int64_t pblocks = (int64_t)num_cu * 2 * DP_BLOCKS_PER_CU;  // (as many waves as the patch scratch has slices)
         if (pblocks > (max_in + 3) / 4) pblocks = (max_in + 3) / 4;
         hipLaunchKernelGGL(kvm_dtw_prep_kernel, dim3((unsigned)pblocks), dim3(256), 0, s, series, qd, ax, in, d_n_in, plans,
-                           counters);
+                           list, counters);
         const hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
@@ -1148,13 +963,20 @@ hipError_t kvm_launch_dtw_dp(const double *series, int64_t n, const kvm_query_de
         const hipError_t e = hipEventRecord(ev_dp_start, s);
         if (e != hipSuccess) return e;
     }
+    const bool force_lds = dp_form == 1;
+    // packed register form (kvm_dtw_pair.hip): any V, two candidates per wave for rho <= 255 -- the first sweep.  It takes the
+    // share of the compact list that dp_pack_share gives it; the one-candidate-per-wave kernel below takes the rest.
+    if (dp_form != 1 && dp_form != 2 && !ax.cb_exact && dp_pack_l(qd.rho) > 0 && qd.m >= 2) {
+        const hipError_t e = kvm_launch_dtw_dp_pack(series, qd, ax, in, plans, list, dp_form, max_in, out_off, out_dist, cap, counters, num_cu, s);
+        if (e != hipSuccess) return e;
+    }
     // register form: band of r+1 even-k cells over 64 lanes, V = pow2 cells per lane, V <= 8 (r <= 511)
     const int need = (qd.rho + 1 + 63) / 64;
     if (!force_lds && need <= 8 && qd.m >= 2) {
-        if (need <= 1) return launch_dp_reg<1>(series, qd, ax, in, plans, d_n_in, max_in, out_off, out_dist, cap, counters, num_cu, s);
-        if (need <= 2) return launch_dp_reg<2>(series, qd, ax, in, plans, d_n_in, max_in, out_off, out_dist, cap, counters, num_cu, s);
-        if (need <= 4) return launch_dp_reg<4>(series, qd, ax, in, plans, d_n_in, max_in, out_off, out_dist, cap, counters, num_cu, s);
-        return launch_dp_reg<8>(series, qd, ax, in, plans, d_n_in, max_in, out_off, out_dist, cap, counters, num_cu, s);
+        if (need <= 1) return launch_dp_reg<1>(series, qd, ax, in, plans, d_n_in, max_in, out_off, out_dist, cap, counters, num_cu, list, dp_form, s);
+        if (need <= 2) return launch_dp_reg<2>(series, qd, ax, in, plans, d_n_in, max_in, out_off, out_dist, cap, counters, num_cu, list, dp_form, s);
+        if (need <= 4) return launch_dp_reg<4>(series, qd, ax, in, plans, d_n_in, max_in, out_off, out_dist, cap, counters, num_cu, list, dp_form, s);
+        return launch_dp_reg<8>(series, qd, ax, in, plans, d_n_in, max_in, out_off, out_dist, cap, counters, num_cu, list, dp_form, s);
     }
     // generic form (any r): arrays in LDS when they fit, else in a stream-ordered global scratch
     const size_t need_bytes = dp_lds_doubles(qd.m, qd.rho) * sizeof(double);

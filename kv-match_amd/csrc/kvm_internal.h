@@ -348,11 +348,18 @@ hipError_t kvm_launch_retile_dtw(const double *series, const double2 *prefix, co
                                  int64_t n_tiles, kvm_tile *out_tiles, unsigned long long *counters, hipStream_t s);
 // waves of the DP launch that use a slice of kvm_dtw_aux::patch (the launch never starts more)
 int64_t kvm_dtw_dp_max_waves(int num_cu);
-size_t kvm_dtw_plan_bytes(int64_t n);  // scratch of kvm_launch_dtw_dp: one plan record per candidate
+size_t kvm_dtw_plan_bytes(int64_t n);  // scratch of kvm_launch_dtw_dp: one plan record per candidate + the compact list of
+                                       // the candidates that reach the DP
 hipError_t kvm_launch_dtw_dp(const double *series, int64_t n, const kvm_query_dev &qd, const kvm_dtw_aux &ax, const kvm_cand *in,
                              const unsigned long long *d_n_in, int64_t max_in, void *plan_buf, int32_t *out_off, double *out_dist,
-                             int64_t cap, unsigned long long *counters, int num_cu, int force_lds, hipStream_t s,
+                             int64_t cap, unsigned long long *counters, int num_cu, int dp_form, hipStream_t s,
                              hipEvent_t ev_dp_start = nullptr);  // recorded between the prologue kernel and the DP
+// dp_form = KVM_OPT_DP_KERNEL: 0 auto, 1 generic LDS form, 2 one candidate per wave in registers, 3 packed register form
+// kvm_dtw_pair.hip: the packed register form (two candidates per wave, any V); kvm_dtw_pack_v: its cells per lane, 0 = none
+int kvm_dtw_pack_v(int rho);
+hipError_t kvm_launch_dtw_dp_pack(const double *series, const kvm_query_dev &qd, const kvm_dtw_aux &ax, const kvm_cand *in,
+                                  const void *plans, const unsigned *list, int share_mode, int64_t max_in, int32_t *out_off,
+                                  double *out_dist, int64_t cap, unsigned long long *counters, int num_cu, hipStream_t s);
 
 // counters layout (unsigned long long[KVM_CNT_TOTAL])
 #define KVM_CNT_ANSWERS 0
@@ -373,6 +380,8 @@ hipError_t kvm_launch_dtw_dp(const double *series, int64_t n, const kvm_query_de
 #define KVM_CNT_AMBIG 15              // DTW: candidates handed to the sequential reference-ordered path
 #define KVM_CNT_UCR_TIES 16           // KVM_OPT_UCR_LOOPS, cNSM-ED: windows handed to the executor's literal distance() loop
 #define KVM_CNT_DP_RERUN 17           // DTW: candidates swept a second time with their row minima in full (see dp_reg_sweep)
+#define KVM_CNT_DP_LIST 18            // DTW: candidates the prologue passes on to the DP (entries of the compact list)
+#define KVM_CNT_QUEUE2 19             // DTW: work-queue head of the one-candidate-per-wave DP kernel behind the packed one
 #define KVM_CNT_TOTAL 20
 
 // kvm_index.hip: index build step 1 on the device
