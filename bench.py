@@ -68,6 +68,9 @@ def parse():
                     help="phase-2 passes (queries of the stream) per step; 0 = per-workload default")
     ap.add_argument("--in-flight", type=int, default=5,
                     help="queries in flight per GPU (contexts over one resident series, one host thread each)")
+    ap.add_argument("--python-threads", type=int, default=0,
+                    help="1: drive the in-flight contexts from Python threads (rounds 1-3) instead of the library's native "
+                         "per-context host threads (kvm_run_jobs); the interpreter lock then bounds latency-bound streams")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong", "both"],
                     help="weak: --candidates per GPU; strong: --candidates in total, split over the GPUs; both: weak is the "
                          "headline, the strong run of the same launch is reported in `strong`")
@@ -404,6 +407,16 @@ def main():
             return i, j, ans.offsets, ans.distances
         return job
 
+    job_cache = {}
+
+    def job_desc(i, j):
+        d = job_cache.get((i, j))
+        if d is None:
+            kw = plans[i][3]
+            d = job_cache[(i, j)] = kvmatch.Job(plans[i][0], shards[j % NL], 1, queries[j], a.epsilon, rho=kw.get("rho", 0),
+                                                alpha=kw.get("alpha", 0.0), beta=kw.get("beta", 0.0))
+        return d
+
     def step():
         # the stream cycles through the NQ queries (and, "mixed", through the four variants); query j runs over list j mod NL
         ids = [((step_no[0] + t) % len(plans), (step_no[0] + t) % NQ) for t in range(qps)]
@@ -412,9 +425,15 @@ def main():
             res = sstream.run([dict(valid_positions=shards[j % NL], last_segment=1, query_data=queries[j], epsilon=a.epsilon,
                                     variant=plans[i][0], **plans[i][3]) for i, j in ids])
             last["res"] = [(i, j, o, d) for (i, j), (o, d) in zip(ids, res)][-NQ * len(plans):]
-        else:
+        elif a.python_threads:
             res = qstream.run([host_job(i, j) for i, j in ids])
             last["res"] = res[-NQ * len(plans):]
+        else:
+            # calls as data, the per-context host threads in native code (kvm_run_jobs): every result is complete -- sorted,
+            # in host memory -- when the call returns; the last NQ x #variants are read back here for the parity checks
+            keep = range(max(0, len(ids) - NQ * len(plans)), len(ids))
+            res = qstream.run_jobs([job_desc(i, j) for i, j in ids], collect=keep)
+            last["res"] = [(ids[t][0], ids[t][1], res[t].offsets, res[t].distances) for t in keep]
 
     def set_option(opt, val):
         (sstream if use_dist else qstream).set_option(opt, val)

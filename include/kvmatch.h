@@ -231,7 +231,8 @@ int kvm_verify_cnsm_ed(kvm_ctx *ctx, const double *query, int32_t m, const int32
 /* RSM-DTW.  Replaces K/QueryEngineDtw.java:349-452.  `rho` is the resolved Sakoe-Chiba half-width
  * (see kvm_resolve_rho).  rho >= m, and an interval whose fetched data is no longer than rho points (one that starts beyond
  * offset n - m + 1), are inputs on which the reference ends in ArrayIndexOutOfBoundsException (DtwUtils.lowerUpperLemire
- * stores to u[i - r - 1] with a negative index); these entry points compute the natural extension instead of failing. */
+ * stores to u[i - r - 1] with a negative index): both DTW entry points return KVM_ERR_INDEX_OUT_OF_BOUNDS there, first
+ * offender in the reference's order (KVM_OPT_STRICT_BOUNDS, default on; 0 computes the envelope's natural extension). */
 int kvm_verify_rsm_dtw(kvm_ctx *ctx, const double *query, int32_t m, const int32_t *left, const int32_t *right,
                        int32_t k, int32_t shift, double epsilon, int32_t rho, kvm_result **result);
 
@@ -239,6 +240,30 @@ int kvm_verify_rsm_dtw(kvm_ctx *ctx, const double *query, int32_t m, const int32
 int kvm_verify_cnsm_dtw(kvm_ctx *ctx, const double *query, int32_t m, const int32_t *left, const int32_t *right,
                         int32_t k, int32_t shift, double epsilon, int32_t rho, double alpha, double beta,
                         kvm_result **result);
+
+/* ---- several queries in flight (host layer; replaces nothing in the reference: its engines are single-threaded and not
+ * re-entrant, K/QueryEngine.java:61-68 -- a server runs one engine instance per thread over the same data file) ---------- */
+
+/* One phase-2 call as data: `variant` 0 rsm_ed, 1 cnsm_ed, 2 rsm_dtw, 3 cnsm_dtw; the other fields are the arguments of the
+ * matching kvm_verify_* (rho / alpha / beta ignored where the variant has none).  All pointers are borrowed until
+ * kvm_run_jobs returns. */
+typedef struct kvm_job {
+    int32_t variant, m;
+    const double *query;
+    const int32_t *left, *right;
+    int32_t k, shift;
+    double epsilon;
+    int32_t rho, reserved;
+    double alpha, beta;
+} kvm_job;
+
+/* Runs jobs[0..n_jobs) on the n_ctx contexts (normally one that owns a series and n_ctx - 1 that share it:
+ * kvm_share_series), one host thread per context, every thread taking the next job in order as soon as its context is
+ * free -- exactly what n_ctx threads calling kvm_verify_* in a loop do, without a foreign-language driver between the
+ * calls.  results[i] / status[i] receive job i's kvm_result (caller frees) and status; after a failing job no further
+ * job is started.  Returns KVM_OK or the status of the first (lowest-index) job that failed. */
+int kvm_run_jobs(kvm_ctx *const *ctxs, int32_t n_ctx, const kvm_job *jobs, int64_t n_jobs, kvm_result **results,
+                 int32_t *status);
 
 /* `r <= 1 -> floor(r*m) else floor(r)`  (K/QueryEngineDtw.java:135-140). */
 int32_t kvm_resolve_rho(double r, int32_t m);

@@ -1029,6 +1029,7 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
                                          pl.chunk_lo, pl.chunk_hi, d_run_chunk));
     }
 
+    KVM_TP("  plan launches");
     // correlation-form ED pruner: centred query and its chunk-granular prefix sums
     std::vector<double> qcen, qcpre;
     std::vector<double2> qpref, qpref8, qpref16;
@@ -1180,9 +1181,11 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
             else
                 HIPCHK(ctx, kvm_launch_retile_cnsm(ctx->d_series, ctx->d_prefix, qd, d_tiles, pl.n_tiles, tA, tB,
                                                    counters + KVM_CNT_TILES_A, stream));
+            KVM_TP("  retile launch");
             HIPCHK(ctx, kvm_launch_ed_dot(ctx->d_series, ctx->d_prefix, ctx->n, qd, tA, pl.n_tiles, tB, pl.n_tiles, tB, 0, surv,
                                           pl.windows, counters, ctx->num_cu, counters + KVM_CNT_TILES_A, out.d_off, out.d_dist, out.cap,
                                           stream));
+            KVM_TP("  ed_dot launch");
         } else if (gen) {
             // the series once more, every point minus the first point of its prefix block: the source of the LDS-DMA staging (no
             // register, no VALU between HBM and LDS), 8 B per point; built on first use
@@ -1244,6 +1247,7 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
             }
             HIPCHK(ctx, kvm_launch_upload((char *)ctx->b_query.p + qexact_off, hp + qexact_off, (size_t)m * 12, stream));
         }
+        KVM_TP("  cnsm order + upload");
         const double *q_exact = cnsm ? (const double *)((const char *)ctx->b_query.p + qexact_off) : qd.q;
         const int32_t *d_order =
             cnsm ? (const int32_t *)((const char *)ctx->b_query.p + qexact_off + (size_t)m * 8) : nullptr;
@@ -1265,6 +1269,7 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
         HIPCHK(ctx, kvm_launch_exact_ed(ctx->d_series, qd, q_exact, d_order, surv, counters + KVM_CNT_CANDS1, pl.windows,
                                         rws, out.d_off, out.d_dist, out.cap, counters, ctx->num_cu, stream, ties,
                                         counters + KVM_CNT_UCR_TIES, ties ? pl.windows : 0));
+        KVM_TP("  exact launch");
     } else {
         const int use_lb = (int)ctx->opt_lb_cascade;
         if ((rc = ensure(ctx, ctx->b_cands, (size_t)pl.windows * sizeof(kvm_cand) + 64))) return rc;

@@ -34,12 +34,19 @@ SYMBOLS = [
     "kvm_index_rows_group_offsets", "kvm_index_build", "kvm_index_file_size", "kvm_index_file_bytes", "kvm_index_file_info",
     "kvm_index_file_write", "kvm_index_file_free", "kvm_phase2_time_estimate_ms", "kvm_phase1_should_stop",
     "kvm_verify_rsm_ed", "kvm_verify_cnsm_ed", "kvm_verify_rsm_dtw", "kvm_verify_cnsm_dtw", "kvm_resolve_rho",
-    "kvm_cnsm_dtw_order", "kvm_sort_and_merge_intervals",
+    "kvm_cnsm_dtw_order", "kvm_sort_and_merge_intervals", "kvm_run_jobs",
     "kvm_result_count", "kvm_result_candidates", "kvm_result_elapsed_ms", "kvm_result_offsets",
     "kvm_result_distances", "kvm_result_stat", "kvm_result_free",
     "kvm_set_option", "kvm_get_option", "kvm_last_kernel_ns", "kvm_verify_device", "kvm_pack_answers_device",
     "kvm_gen_series", "kvm_gen_intervals", "kvm_write_series_file",
 ]
+
+
+class KvmJob(C.Structure):
+    """struct kvm_job of include/kvmatch.h: one phase-2 call as data (kvm_run_jobs)."""
+    _fields_ = [("variant", C.c_int32), ("m", C.c_int32), ("query", C.c_void_p), ("left", C.c_void_p), ("right", C.c_void_p),
+                ("k", C.c_int32), ("shift", C.c_int32), ("epsilon", C.c_double), ("rho", C.c_int32), ("reserved", C.c_int32),
+                ("alpha", C.c_double), ("beta", C.c_double)]
 
 
 class KvMatchDeviceError(RuntimeError):
@@ -120,6 +127,7 @@ def load():
         "kvm_resolve_rho": (i32, [f64, i32]),
         "kvm_cnsm_dtw_order": (C.c_int, [vp, i32, vp]),
         "kvm_sort_and_merge_intervals": (i64, [vp, vp, i64, vp, vp]),
+        "kvm_run_jobs": (C.c_int, [C.POINTER(vp), i32, C.POINTER(KvmJob), i64, C.POINTER(vp), C.POINTER(i32)]),
         "kvm_result_count": (i64, [vp]),
         "kvm_result_candidates": (i64, [vp]),
         "kvm_result_elapsed_ms": (f64, [vp]),

@@ -382,10 +382,68 @@ class QueryStream:
             raise err[0]
         return out
 
+    def run_jobs(self, jobs, collect=None):
+        """The same stream with the per-thread loop in native code (kvm_run_jobs): `jobs` are `Job` descriptors -- calls as
+        data -- and every context's host thread is a native one, so the calls are not serialised by this interpreter's lock
+        between them (a Python thread holds it for 40 - 80 us per call: marshalling, result objects).  Returns the Answers in
+        job order; raises what the first failing job's engine would have raised.  `collect`: indices whose results are
+        wanted as Answers objects (default: all); the other results -- complete, sorted, in host memory when the call
+        returns -- are released unread and their slots hold None (a throughput driver checks a sample)."""
+        jobs = list(jobs)
+        n = len(jobs)
+        if n == 0:
+            return []
+        lib = self.ctxs[0]._lib
+        arr = (_lib.KvmJob * n)()
+        for a, j in zip(arr, jobs):
+            a.variant, a.m, a.query, a.left, a.right = j.variant, j.q.size, j.q.ctypes.data, j.left.ctypes.data, j.right.ctypes.data
+            a.k, a.shift, a.epsilon, a.rho, a.alpha, a.beta = j.left.size, j.shift, j.epsilon, j.rho, j.alpha, j.beta
+        hs = (C.c_void_p * len(self.ctxs))(*[c._h for c in self.ctxs])
+        res = (C.c_void_p * n)()
+        st = (C.c_int32 * n)()
+        rc = lib.kvm_run_jobs(hs, len(self.ctxs), arr, n, res, st)
+        if rc:
+            for r in res:
+                if r:
+                    lib.kvm_result_free(r)
+            bad = next((i for i in range(n) if st[i]), None)
+            # (the message lives in the context that ran the job; which one is not recorded: try them all)
+            for c in self.ctxs:
+                msg = lib.kvm_last_error(c._h)
+                if msg:
+                    _lib.check(rc, c._h)
+            raise _lib.KvMatchDeviceError(f"[{rc}] job {bad} failed")
+        if collect is None:
+            return [self.ctxs[0]._collect(C.c_void_p(r)) for r in res]
+        want = set(int(i) % n for i in collect)
+        out = [None] * n
+        for i, r in enumerate(res):
+            if i in want:
+                out[i] = self.ctxs[0]._collect(C.c_void_p(r))
+            else:
+                lib.kvm_result_free(r)
+        return out
+
     def close(self):
         for c in self.ctxs[1:]:
             c.close()
         self.ctxs = self.ctxs[:1]
+
+
+class Job:
+    """One phase-2 call as data, for QueryStream.run_jobs: the arguments of the engine's verify() -- `variant` 0 QueryEngine,
+    1 NormQueryEngine, 2 QueryEngineDtw, 3 NormQueryEngineDtw; rho an int (points) or a float (the REPL's fraction rule)."""
+
+    def __init__(self, variant, valid_positions, last_segment, query_data, epsilon, rho=0, alpha=0.0, beta=0.0):
+        self.variant = int(variant)
+        self.q = np.ascontiguousarray(query_data, dtype=np.float64)
+        if self.q.ndim != 1 or self.q.size > 2**31 - 1:
+            raise _lib.KvMatchIllegalArgument("query_data must be a one-dimensional sequence")
+        self.left, self.right = _as_intervals(valid_positions)
+        self.shift = (int(last_segment) - 1) * WU0
+        self.epsilon = float(epsilon)
+        self.rho = resolve_rho(rho, self.q.size) if self.variant >= 2 else 0
+        self.alpha, self.beta = float(alpha), float(beta)
 
     def __enter__(self):
         return self

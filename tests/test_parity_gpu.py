@@ -1552,3 +1552,38 @@ def test_residue_of_a_spike_in_the_references_running_sums(built):
             for eps in (8.0, 2.0):
                 compare(kvmatch.NormQueryEngineDtw(ctx).verify((Ld, Rd), 1, q, eps, 12, 1e9, 1e9), oracle.cnsm_dtw(s, q, Ld, Rd, 0, eps, 12, 1e9, 1e9),
                         tag=f"spike dtw scale={scale} burst={burst} eps={eps}")
+
+
+def test_run_jobs_is_the_same_stream_in_native_threads(world):
+    """kvm_run_jobs (QueryStream.run_jobs): calls as data, one native host thread per context.  Every job's answers equal
+    the oracle's (and therefore the one-call-at-a-time engines'), in job order, all four variants mixed in one stream;
+    results that are not collected are released; a failing job raises what its engine would have raised."""
+    kvmatch, datagen, series, ctx = world
+    m = 256
+    s, q, L, R = planted(world, m)
+    try:
+        want = [oracle.rsm_ed(s, q, L, R, 0, 6.0), oracle.cnsm_ed(s, q, L, R, 0, 3.0, 1.5, 2.0),
+                oracle.rsm_dtw(s, q, L, R, 0, 6.0, 12), oracle.cnsm_dtw(s, q, L, R, 0, 3.0, 12, 1.5, 2.0)]
+        mk = [lambda: kvmatch.Job(0, (L, R), 1, q, 6.0), lambda: kvmatch.Job(1, (L, R), 1, q, 3.0, alpha=1.5, beta=2.0),
+              lambda: kvmatch.Job(2, (L, R), 1, q, 6.0, rho=12), lambda: kvmatch.Job(3, (L, R), 1, q, 3.0, rho=12, alpha=1.5, beta=2.0)]
+        qs = kvmatch.QueryStream(ctx, in_flight=3)
+        try:
+            jobs = [mk[i % 4]() for i in range(22)]
+            got = qs.run_jobs(jobs)
+            assert len(got) == 22
+            for i, g in enumerate(got):
+                compare(g, want[i % 4], tag=f"job {i}")
+            some = qs.run_jobs(jobs, collect=[3, -1])
+            assert [x is not None for x in some] == [i in (3, 21) for i in range(22)]
+            compare(some[3], want[3], tag="collected 3")
+            compare(some[21], want[21 % 4], tag="collected last")
+            assert qs.run_jobs([]) == []
+            # a list the cNSM engines cannot index (not sorted by left): IllegalArgumentException in Java
+            bad = kvmatch.Job(1, (L[::-1].copy(), R[::-1].copy()), 1, q, 3.0, alpha=1.5, beta=2.0)
+            with pytest.raises(kvmatch.KvMatchIllegalArgument):
+                qs.run_jobs([mk[0](), bad, mk[0]()])
+            compare(qs.run_jobs([mk[0]()])[0], want[0], tag="after a failed stream")
+        finally:
+            qs.close()
+    finally:
+        ctx.load_series(series)
