@@ -71,6 +71,8 @@ def parse():
     ap.add_argument("--python-threads", type=int, default=0,
                     help="1: drive the in-flight contexts from Python threads (rounds 1-3) instead of the library's native "
                          "per-context host threads (kvm_run_jobs); the interpreter lock then bounds latency-bound streams")
+    ap.add_argument("--sub-workloads", type=int, default=1,
+                    help="default workload, N=1: also time cNSM-ED and cNSM-DTW as streams (child runs of this program)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong", "both"],
                     help="weak: --candidates per GPU; strong: --candidates in total, split over the GPUs; both: weak is the "
                          "headline, the strong run of the same launch is reported in `strong`")
@@ -102,7 +104,25 @@ def timed_steps(fn, steps, warmup, world):
     return dt
 
 
-def roofline_block(wl, plans, launches, m):
+def file_sha16(path):
+    import hashlib
+    try:
+        return hashlib.sha256(open(path, "rb").read()).hexdigest()[:16]
+    except OSError:
+        return None
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return None
+
+
+def roofline_block(wl, plans, launches, m, rates=None):
     """Roofline of the workload's dominant kernel.  None of these kernels is HBM-bound (a tile of 64 consecutive candidates
     needs m+63 points, not 64*m: 63 of every 64 algorithmic bytes are served from LDS): the binding roof is the fp64
     vector pipe, so `bound` says so; the HBM view (8*m algorithmic bytes per candidate) is kept as secondary
@@ -122,7 +142,11 @@ def roofline_block(wl, plans, launches, m):
         ach = ops / ks / 1e12 if ks > 0 else 0.0
         return {"bound": "fp64_valu", "achieved": ach, "peak": FP64_VALU_PEAK_TOPS_NOFMA, "unit": "TFLOP/s",
                 "frac": ach / FP64_VALU_PEAK_TOPS_NOFMA, "traffic": None,
-                "kernel": "kvm_dtw_dp_reg_kernel (banded DP, early abandon off: every candidate that reaches it runs all cells)",
+                "kernel": "kvm_dtw_dp_pack_kernel (banded DP, two candidates per wave; lists of <= 3072 DPs: kvm_dtw_dp_reg_kernel) -- "
+                          "early abandon off: every candidate that reaches it runs all cells",
+                **({"fp64_nofma_sustained_tops": rates.get("fp64_cellmix_tops"), "fp64_nofma_sustained_source":
+                    "measured by this run (kvm_measure_device 2: the DP's cell mix sub/mul/min/min/add, register-only, 4 waves per SIMD)"}
+                   if rates else {}),
                 "kernel_ms": ks * 1e3 / max(1, len(ls)), "launches_measured": len(ls),
                 "dp_candidates_per_launch": dps / max(1, len(ls)), "cells_per_candidate": cells,
                 "cells_per_s": dps * cells / ks if ks > 0 else 0.0,
@@ -142,7 +166,12 @@ def roofline_block(wl, plans, launches, m):
     if v == 0 and os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
-            traffic, tsrc = tj.get("hbm_bytes_per_launch"), "profiles/ed_traffic.json: " + tj.get("source", "stored rocprofv3 --pmc pass")
+            # the stored PMC passes belong to ONE build of the pruner: if kvm_ed_dot.hip has changed since, they say nothing
+            now_sha = file_sha16(os.path.join(ROOT, "kv-match_amd", "csrc", "kvm_ed_dot.hip"))
+            if tj.get("kvm_ed_dot_sha16") in (None, now_sha):
+                traffic, tsrc = tj.get("hbm_bytes_per_launch"), "profiles/ed_traffic.json: " + tj.get("source", "stored rocprofv3 --pmc pass")
+            else:
+                tsrc = None
         except Exception:
             traffic = None
     return {"bound": "fp64_valu", "achieved": ach, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -157,11 +186,10 @@ def roofline_block(wl, plans, launches, m):
             "hbm_algorithmic_gbs": algo_bytes / ks / 1e9 if ks > 0 else 0.0,
             "hbm_measured_gbs": (traffic * nl / ks / 1e9) if (traffic and ks > 0) else None,
             "hbm_peak_gbs": HBM_PEAK_GBS,
-            "fp64_fma_sustained_tflops": 56.8,
-            "fp64_fma_sustained_source": "profiles/micro/mfma_f64_rate.hip (profiles/r02_mfma_f64_rate.log): a register-only "
-                                         "v_fma_f64 loop at 4 waves/SIMD sustains 56.8 TFLOP/s on this part (54.5 at the 2 "
-                                         "waves/SIMD this kernel runs at; v_mfma_f64_16x16x4 46.6) -- NOT measured by this run; "
-                                         "`peak` stays the vendor figure",
+            "fp64_fma_sustained_tflops": rates.get("fp64_fma_tflops") if rates else None,
+            "hbm_achievable_gbs": rates.get("hbm_triad_gbs") if rates else None,
+            "fp64_fma_sustained_source": "measured by this run on this box (kvm_measure_device: a register-only v_fma_f64 loop at 4 "
+                                         "waves/SIMD; an HBM stream triad over 3 x 512 MiB); `peak` stays the vendor figure",
             "note": "bound = fp64 vector pipe: 63 of every 64 algorithmic bytes are served from LDS (tile reuse), so the "
                     "algorithmic-byte rate exceeds the HBM peak by construction; hbm_measured_gbs is the real HBM rate"}
 
@@ -339,7 +367,8 @@ def main():
         # import): probe instead of assuming
         java, javac = shutil.which("java"), shutil.which("javac")
         out["cpu_baseline"] = {
-            "value": o_st["windows"] / cpu_s, "unit": "candidates/s", "cores": 1, "kind": "port",
+            "value": o_st["windows"] / cpu_s, "unit": "candidates/s", "cores": 1, "kind": "port", "cpu_model": cpu_model(),
+            "host_cores": os.cpu_count(),
             "jdk_probe": {"java": java, "javac": javac},
             "sample": f"all {o_st['windows']} candidates of query 0 over list 0 of the N=1 workload, early abandon off (same work "
                       f"per query as `value`), single thread; C restatement of K/QueryEngine.java:338-363 "
@@ -531,7 +560,16 @@ def main():
         "early_abandon_same_answers": ab_match,
         "setup_s": setup_s,
     })
-    out["roofline"] = roofline_block(wl, plans, excl_ns, m)
+    # what THIS box sustains (the vendor peaks are quoted): HBM stream triad, fp64 FMA issue, the DP's non-FMA cell mix
+    rates = {}
+    if rank == 0:
+        try:
+            rates = {"hbm_triad_gbs": ctx.measure_device(0), "fp64_fma_tflops": ctx.measure_device(1),
+                     "fp64_cellmix_tops": ctx.measure_device(2)}
+        except Exception as e:  # noqa: BLE001
+            rates = {"error": repr(e)}
+    out["device_rates_measured"] = rates
+    out["roofline"] = roofline_block(wl, plans, excl_ns, m, rates if "error" not in rates else None)
     out["roofline"]["kernel_ms_note"] = ("HIP events on the kernel's own stream (RSM-ED every point: the start / stop stamps of the "
                                          "dispatch itself, hipExtLaunchKernelGGL), measured in this run right after the "
                                          f"timed region with ONE query in flight, averaged over the {NQ} queries and their "
@@ -556,6 +594,28 @@ def main():
                      else oracle.cnsm_ed(series, queries[j], l_, r_, 0, a.epsilon, 2.0, 10.0))
                 ok = ok and same_answers(g_off, g_dist, o[0], o[1])
             parity[wl] = bool(ok and len(head) == NQ)
+        elif wl == "cnsm_dtw":
+            # the oracle's cNSM-DTW on all host cores, one child process per query (whole intervals dealt to the workers)
+            ok, secs = True, 0.0
+            rho_w = int(lib.kvm_resolve_rho(0.05, m))
+            for (i, j), (g_off, g_dist) in head.items():
+                l_, r_ = shards[j % NL]
+                fin, fout = os.path.join(tmpdir, "_bench_dtw_in.npz"), os.path.join(tmpdir, "_bench_dtw_out.npz")
+                np.savez(fin, q=queries[j], left=l_, right=r_, patch_pos=np.array(patch_pos, dtype=np.int64), patch_val=patch_val)
+                try:
+                    subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline.py"), "cnsm_dtw_answers", str(n),
+                                    str(a.epsilon), str(min(os.cpu_count() or 1, 64)), fin, fout, str(rho_w), "2.0", "10.0"],
+                                   capture_output=True, text=True, timeout=600)
+                    z = np.load(fout)
+                    ok = ok and bool(np.array_equal(z["off"], g_off) and np.array_equal(z["dist"], g_dist))
+                    secs += float(z["seconds"])
+                except Exception:  # noqa: BLE001
+                    ok = False
+            parity[wl] = bool(ok and len(head) == NQ)
+            out["cpu_baseline"] = {"value": sum(my_cands_l[j % NL] for j in range(NQ)) / secs if secs > 0 else None, "unit": "candidates/s",
+                                   "cores": min(os.cpu_count() or 1, 64), "kind": "port", "cpu_model": cpu_model(),
+                                   "sample": f"the oracle's cNSM-DTW (reference's early abandoning and LB cascade) on the {NQ} queries of the stream, "
+                                             "whole intervals dealt to one worker per host core"}
 
     # ---- extras (N=1): the other variants on the same staged series ---------------------------------------
     if rank == 0 and world == 1 and a.extras and wl == "rsm_ed":
@@ -616,7 +676,7 @@ def main():
                 ach2 = r_.stats[4] * cells2 * 5.0 / ks2 / 1e12
                 out["roofline_dtw"] = {"bound": "fp64_valu", "achieved": ach2, "peak": FP64_VALU_PEAK_TOPS_NOFMA, "unit": "TFLOP/s",
                                        "frac": ach2 / FP64_VALU_PEAK_TOPS_NOFMA, "traffic": None,
-                                       "kernel": "kvm_dtw_dp_reg_kernel<4,0> (banded DP with the reference's row test)",
+                                       "kernel": "kvm_dtw_dp_pack_kernel<32,7,1> (banded DP with the reference's row test, two candidates per wave)",
                                        "kernel_ms": ks2 * 1e3, "dp_candidates_per_launch": r_.stats[4], "cells_per_candidate": cells2,
                                        "cells_per_s": r_.stats[4] * cells2 / ks2,
                                        "workload": "cNSM-DTW m=4096 rho=204, 1e6 candidates, eps=10 alpha=2 beta=10 (BASELINE configs[3])",
@@ -641,7 +701,8 @@ def main():
             # DP kernel alone: cascade off on a small slice => every filter-passing window runs the full DP
             ctx.set_option(kvmatch.OPT_LB_CASCADE, 0)
             ctx.set_option(kvmatch.OPT_EARLY_ABANDON, 0)
-            l3, r3 = l2[:256], r2[:256]
+            l3, r3 = l2[:1024], r2[:1024]   # (~66 000 DPs: sixteen rounds of the chip's resident waves -- a steady-state rate, not
+                                            #  the rounding of five-and-a-bit rounds to six)
             # (eps so large that no lower bound and no row bound ever reaches eps^2: every candidate sweeps all its cells)
             g3 = lambda: deng.verify((l3, r3), 1, q2, 1e6, 0.05, 1e9, 1e9)  # noqa: E731
             g3()
@@ -697,8 +758,36 @@ def main():
     if parity:
         out["parity_vs_oracle"] = parity
 
-    (sstream if use_dist else qstream).close()
-    ctx.close()
+    # ---- the other BASELINE configs as STREAMS, timed by the same program in the same run (N = 1, default workload): one
+    # child process each (the workload loops of this file at reduced --steps), their lines kept under `configs` and their
+    # values lifted to the top level -- so that the driver's one command times configs[1], [2] and [3]
+    if rank == 0 and world == 1 and a.extras and wl == "rsm_ed" and a.sub_workloads:
+        (sstream if use_dist else qstream).close()
+        ctx.close()
+        ctx = None
+        out["configs"] = {}
+        for w, extra in (("cnsm_ed", []), ("cnsm_dtw", ["--queries", str(min(NQ, 4))])):
+            cmd = [sys.executable, os.path.abspath(__file__), "--workload", w, "--steps", str(max(2, a.steps // 4)), "--warmup", "1",
+                   "--extras", "0", "--cpu-baseline", str(a.cpu_baseline), "--n", str(n), "--candidates", str(a.candidates),
+                   "--in-flight", str(a.in_flight), "--epsilon", repr(a.epsilon), "--sub-workloads", "0"] + extra
+            t1 = time.perf_counter()
+            try:
+                cp = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+                line = json.loads(cp.stdout.strip().splitlines()[-1])
+                keep = {k: line.get(k) for k in ("metric", "value", "unit", "steps", "ms_per_step", "ms_per_query", "value_early_abandon",
+                                                 "early_abandon_same_answers", "config", "roofline", "parity_vs_oracle", "cpu_baseline")}
+                keep["seconds"] = time.perf_counter() - t1
+                out["configs"][w] = keep
+                out["value_" + w] = line.get("value")
+                out["value_" + w + "_early_abandon"] = line.get("value_early_abandon")
+                for k2, v2 in (line.get("parity_vs_oracle") or {}).items():
+                    out.setdefault("parity_vs_oracle", {})[k2 + "_stream"] = v2
+            except Exception as e:  # noqa: BLE001
+                out["configs"][w] = {"error": repr(e)}
+
+    if ctx is not None:
+        (sstream if use_dist else qstream).close()
+        ctx.close()
     if rank == 0:
         print(json.dumps(out))
     if use_dist:

@@ -351,6 +351,12 @@ int64_t kvm_get_option(const kvm_ctx *ctx, int32_t option);
  * kvm_verify_* / kvm_verify_device call on this ctx; 0 unless KVM_OPT_TIMING is set. */
 int64_t kvm_last_kernel_ns(const kvm_ctx *ctx);
 
+/* What the device under this run sustains, for the roofline lines of a benchmark (vendor peaks are quoted, these are
+ * measured): `what` 0 = HBM stream triad over 3 x 512 MiB, GB/s; 1 = fp64 FMA issue rate, register-only, TFLOP/s (FMA = 2);
+ * 2 = fp64 issue rate of the banded DP's cell mix (sub, mul, min, min, add; no FMA), Tops/s.  Allocates and frees its own
+ * 1.5 GiB (what = 0); waits for the context's stream.  Replaces nothing in the reference. */
+int kvm_measure_device(kvm_ctx *ctx, int32_t what, double *value);
+
 /* ---- device-resident variant (multi-GPU host plumbing: no host copies, caller's stream) ----------- */
 
 /* Same computation as kvm_verify_*, but survivors stay in device memory so that the host layer can

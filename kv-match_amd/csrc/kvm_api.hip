@@ -179,7 +179,16 @@ static void finish_timing(kvm_ctx *ctx) {
     if (hipEventSynchronize(ctx->ev1) == hipSuccess && hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) == hipSuccess)
         ctx->last_kernel_ns = (int64_t)((double)ms * 1e6);
 }
-extern "C" int64_t kvm_last_kernel_ns(const kvm_ctx *ctx) {
+extern "C" int kvm_measure_device(kvm_ctx *ctx, int32_t what, double *value) {
+    if (!ctx) return KVM_ERR_INVALID_HANDLE;
+    if (!value || what < 0 || what > 2) return fail(ctx, KVM_ERR_ILLEGAL_ARGUMENT, "kvm_measure_device: what = 0, 1 or 2 and a result pointer");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, kvm_measure_device_rate(what, ctx->num_cu, ctx->stream, ctx->ev0, ctx->ev1, value));
+    return KVM_OK;
+}
+
+int64_t kvm_last_kernel_ns(const kvm_ctx *ctx) {
     if (!ctx) return 0;
     finish_timing(const_cast<kvm_ctx *>(ctx));
     return ctx->last_kernel_ns;

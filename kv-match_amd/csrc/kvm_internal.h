@@ -361,6 +361,9 @@ hipError_t kvm_launch_dtw_dp_pack(const double *series, const kvm_query_dev &qd,
                                   const void *plans, const unsigned *list, int share_mode, int64_t max_in, int32_t *out_off,
                                   double *out_dist, int64_t cap, unsigned long long *counters, int num_cu, hipStream_t s);
 
+// kvm_selftest.hip: what the device under the run sustains (kvm_measure_device)
+hipError_t kvm_measure_device_rate(int what, int num_cu, hipStream_t s, hipEvent_t e0, hipEvent_t e1, double *value);
+
 // counters layout (unsigned long long[KVM_CNT_TOTAL])
 #define KVM_CNT_ANSWERS 0
 #define KVM_CNT_WINDOWS 1

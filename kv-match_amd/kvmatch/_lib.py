@@ -37,7 +37,7 @@ SYMBOLS = [
     "kvm_cnsm_dtw_order", "kvm_sort_and_merge_intervals", "kvm_run_jobs",
     "kvm_result_count", "kvm_result_candidates", "kvm_result_elapsed_ms", "kvm_result_offsets",
     "kvm_result_distances", "kvm_result_stat", "kvm_result_free",
-    "kvm_set_option", "kvm_get_option", "kvm_last_kernel_ns", "kvm_verify_device", "kvm_pack_answers_device",
+    "kvm_set_option", "kvm_get_option", "kvm_last_kernel_ns", "kvm_measure_device", "kvm_verify_device", "kvm_pack_answers_device",
     "kvm_gen_series", "kvm_gen_intervals", "kvm_write_series_file",
 ]
 
@@ -138,6 +138,7 @@ def load():
         "kvm_set_option": (C.c_int, [vp, i32, i64]),
         "kvm_get_option": (i64, [vp, i32]),
         "kvm_last_kernel_ns": (i64, [vp]),
+        "kvm_measure_device": (C.c_int, [vp, i32, C.POINTER(f64)]),
         "kvm_verify_device": (C.c_int, [vp, i32, vp, i32, vp, vp, i32, i32, f64, i32, f64, f64, vp, vp, i64, vp,
                                         C.POINTER(i64), vp]),
         "kvm_pack_answers_device": (C.c_int, [vp, vp, vp, vp, i64, vp, vp]),
