@@ -75,6 +75,9 @@ extern "C" {
 #define KVM_ERR_INDEX_OUT_OF_BOUNDS (-8) /* the reference ends in ArrayIndexOutOfBoundsException on this input
                                             (KVM_OPT_STRICT_BOUNDS; the shim throws the same) */
 
+#define KVM_ERR_NO_MEMORY (-9)     /* host allocation failed inside the library (std::bad_alloc): no C++ exception ever crosses
+                                      this boundary; -> java.lang.OutOfMemoryError in the shim */
+
 typedef struct kvm_ctx kvm_ctx;
 typedef struct kvm_result kvm_result;
 

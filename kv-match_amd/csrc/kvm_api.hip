@@ -2,6 +2,7 @@
 // points and result objects.  Host orchestration only; every distance is computed by the HIP kernels in
 // kvm_ed*.hip / kvm_dtw*.hip.  There is deliberately no CPU fallback: every entry point fails with
 // KVM_ERR_DEVICE when HIP is unusable.
+#include "kvm_guard.h"
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -35,6 +36,12 @@ static int fail(kvm_ctx *ctx, int code, const std::string &msg) {
 }
 
 void kvm_set_error(kvm_ctx *ctx, const std::string &msg) { fail(ctx, 0, msg); }  // for the host-only translation units
+void kvm_set_error_noexcept(kvm_ctx *ctx, const char *msg) noexcept {
+    try {
+        (ctx ? ctx->err : g_open_err).assign(msg);
+    } catch (...) {  // (not even the message fits: the status code has to do)
+    }
+}
 
 #define HIPCHK(ctx, call)                                                                            \
     do {                                                                                             \
@@ -70,6 +77,7 @@ extern "C" const char *kvm_version(void) { return "kvmatch-hip 0.1 (gfx950)"; }
 extern "C" const char *kvm_last_error(const kvm_ctx *ctx) { return ctx ? ctx->err.c_str() : g_open_err.c_str(); }
 
 extern "C" int kvm_open(int device, kvm_ctx **out) {
+    return kvm_guard<int>(nullptr, [&]() -> int {
     if (!out) return fail(nullptr, KVM_ERR_ILLEGAL_ARGUMENT, "kvm_open: null out pointer");
     *out = nullptr;
     int ndev = 0;
@@ -108,6 +116,7 @@ extern "C" int kvm_open(int device, kvm_ctx **out) {
     }
     *out = ctx;
     return KVM_OK;
+    });
 }
 
 static void free_series(kvm_ctx *ctx) {
@@ -180,12 +189,14 @@ static void finish_timing(kvm_ctx *ctx) {
         ctx->last_kernel_ns = (int64_t)((double)ms * 1e6);
 }
 extern "C" int kvm_measure_device(kvm_ctx *ctx, int32_t what, double *value) {
+    return kvm_guard<int>(ctx, [&]() -> int {
     if (!ctx) return KVM_ERR_INVALID_HANDLE;
     if (!value || what < 0 || what > 2) return fail(ctx, KVM_ERR_ILLEGAL_ARGUMENT, "kvm_measure_device: what = 0, 1 or 2 and a result pointer");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     HIPCHK(ctx, kvm_measure_device_rate(what, ctx->num_cu, ctx->stream, ctx->ev0, ctx->ev1, value));
     return KVM_OK;
+    });
 }
 
 int64_t kvm_last_kernel_ns(const kvm_ctx *ctx) {
@@ -253,6 +264,7 @@ static int alloc_series(kvm_ctx *ctx, int64_t n) {
 }
 
 extern "C" int kvm_load_series_f64(kvm_ctx *ctx, const double *host_values, int64_t n) {
+    return kvm_guard<int>(ctx, [&]() -> int {
     if (!ctx) return KVM_ERR_INVALID_HANDLE;
     if (!host_values) return fail(ctx, KVM_ERR_ILLEGAL_ARGUMENT, "null series");
     int rc = alloc_series(ctx, n);
@@ -262,9 +274,11 @@ extern "C" int kvm_load_series_f64(kvm_ctx *ctx, const double *host_values, int6
         return fail(ctx, KVM_ERR_DEVICE, "copying the series to the device failed");
     }
     return finish_load(ctx);
+    });
 }
 
 extern "C" int kvm_load_series_be64(kvm_ctx *ctx, const void *be_bytes, int64_t n) {
+    return kvm_guard<int>(ctx, [&]() -> int {
     if (!ctx) return KVM_ERR_INVALID_HANDLE;
     if (!be_bytes) return fail(ctx, KVM_ERR_ILLEGAL_ARGUMENT, "null series");
     int rc = alloc_series(ctx, n);
@@ -276,9 +290,11 @@ extern "C" int kvm_load_series_be64(kvm_ctx *ctx, const void *be_bytes, int64_t 
         return fail(ctx, KVM_ERR_DEVICE, "staging the big-endian series failed");
     }
     return finish_load(ctx);
+    });
 }
 
 extern "C" int kvm_load_series_file(kvm_ctx *ctx, const char *path, int64_t n) {
+    return kvm_guard<int>(ctx, [&]() -> int {
     if (!ctx) return KVM_ERR_INVALID_HANDLE;
     if (!path) return fail(ctx, KVM_ERR_ILLEGAL_ARGUMENT, "null path");
     if (n < 1 || n > 2147483647LL)  // (before the file is touched: a bad length is the caller's error, not an I/O error)
@@ -296,9 +312,11 @@ extern "C" int kvm_load_series_file(kvm_ctx *ctx, const char *path, int64_t n) {
     int rc = kvm_load_series_be64(ctx, map, n);
     munmap(map, (size_t)n * 8);
     return rc;
+    });
 }
 
 extern "C" int kvm_attach_series_device(kvm_ctx *ctx, const double *device_values, int64_t n) {
+    return kvm_guard<int>(ctx, [&]() -> int {
     if (!ctx) return KVM_ERR_INVALID_HANDLE;
     if (!device_values || n < 1 || n > 2147483647LL) return fail(ctx, KVM_ERR_ILLEGAL_ARGUMENT, "bad device series");
     // device-to-device copy into the ctx's own padded buffer (see alloc_series); the caller's array is not
@@ -310,9 +328,11 @@ extern "C" int kvm_attach_series_device(kvm_ctx *ctx, const double *device_value
         return fail(ctx, KVM_ERR_DEVICE, "copying the device series failed");
     }
     return finish_load(ctx);
+    });
 }
 
 extern "C" int kvm_share_series(kvm_ctx *ctx, const kvm_ctx *owner) {
+    return kvm_guard<int>(ctx, [&]() -> int {
     if (!ctx || !owner) return KVM_ERR_INVALID_HANDLE;
     if (ctx == owner) return fail(ctx, KVM_ERR_ILLEGAL_ARGUMENT, "a context cannot share its own series");
     if (!owner->d_series || !owner->d_prefix) return fail(ctx, KVM_ERR_NO_SERIES, "the owner context has no series loaded");
@@ -327,11 +347,13 @@ extern "C" int kvm_share_series(kvm_ctx *ctx, const kvm_ctx *owner) {
     ctx->own_series = false;
     ctx->n = owner->n;
     return KVM_OK;
+    });
 }
 
 extern "C" int64_t kvm_series_length(const kvm_ctx *ctx) { return ctx ? ctx->n : KVM_ERR_INVALID_HANDLE; }
 
 extern "C" int kvm_read_time_series(kvm_ctx *ctx, int32_t left, int32_t length, double *out) {
+    return kvm_guard<int>(ctx, [&]() -> int {
     if (!ctx) return KVM_ERR_INVALID_HANDLE;
     if (!ctx->d_series) return fail(ctx, KVM_ERR_NO_SERIES, "no series loaded");
     // K/operator/file/TimeSeriesFileOperator.java:55-57
@@ -345,9 +367,11 @@ extern "C" int kvm_read_time_series(kvm_ctx *ctx, int32_t left, int32_t length, 
                                ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return KVM_OK;
+    });
 }
 
 extern "C" int kvm_window_means(kvm_ctx *ctx, int32_t w, int32_t first, int64_t count, double *out) {
+    return kvm_guard<int>(ctx, [&]() -> int {
     if (!ctx) return KVM_ERR_INVALID_HANDLE;
     if (!ctx->d_series) return fail(ctx, KVM_ERR_NO_SERIES, "no series loaded");
     if (w < 1 || first < 1 || count < 0 || !out || (int64_t)first + count - 1 + w - 1 > ctx->n)
@@ -368,6 +392,7 @@ extern "C" int kvm_window_means(kvm_ctx *ctx, int32_t w, int32_t first, int64_t 
         ctx->last_kernel_ns = (int64_t)(ms * 1e6);
     }
     return KVM_OK;
+    });
 }
 
 // ---- index build, step 1 (kvm_index.hip) ----------------------------------------------------------------------
@@ -485,8 +510,8 @@ static int index_rows_build(kvm_ctx *ctx, int32_t w, bool grouped, kvm_index_row
     *out = r;
     return KVM_OK;
 }
-extern "C" int kvm_index_rows_build(kvm_ctx *ctx, int32_t w, kvm_index_rows **out) { return index_rows_build(ctx, w, false, out); }
-extern "C" int kvm_index_rows_build_grouped(kvm_ctx *ctx, int32_t w, kvm_index_rows **out) { return index_rows_build(ctx, w, true, out); }
+extern "C" int kvm_index_rows_build(kvm_ctx *ctx, int32_t w, kvm_index_rows **out) { return kvm_guard<int>(ctx, [&]() -> int { return index_rows_build(ctx, w, false, out); }); }
+extern "C" int kvm_index_rows_build_grouped(kvm_ctx *ctx, int32_t w, kvm_index_rows **out) { return kvm_guard<int>(ctx, [&]() -> int { return index_rows_build(ctx, w, true, out); }); }
 extern "C" int64_t kvm_index_rows_groups(const kvm_index_rows *r) { return r ? r->n_groups : 0; }
 extern "C" const double *kvm_index_rows_group_keys(const kvm_index_rows *r) { return r ? r->group_keys : nullptr; }
 extern "C" const int32_t *kvm_index_rows_group_offsets(const kvm_index_rows *r) { return r ? r->group_off : nullptr; }
@@ -539,6 +564,7 @@ extern "C" int32_t kvm_resolve_rho(double r, int32_t m) {
 }
 
 extern "C" int kvm_cnsm_dtw_order(const double *query, int32_t m, int32_t *order) {
+    return kvm_guard<int>(nullptr, [&]() -> int {
     if (!query || m < 1) return fail(nullptr, KVM_ERR_ILLEGAL_ARGUMENT, "kvm_cnsm_dtw_order: bad arguments");
     // K/NormQueryEngineDtw.java:205-211 (statistics) and :461-464 (z-normalisation)
     double ex = 0, ex2 = 0;
@@ -553,6 +579,7 @@ extern "C" int kvm_cnsm_dtw_order(const double *query, int32_t m, int32_t *order
     const bool ok = kvm_jsort::cnsm_dtw_order(zq.data(), m, ord.data());
     if (order) std::memcpy(order, ord.data(), (size_t)m * sizeof(int32_t));
     return ok ? KVM_OK : fail(nullptr, KVM_ERR_ILLEGAL_ARGUMENT, "Comparison method violates its general contract!");
+    });
 }
 
 static bool kvm_trace_on() {
@@ -848,6 +875,7 @@ static int ensure_envelope(kvm_ctx *ctx, int32_t rho, hipStream_t stream) {
 // DtwUtils.lowerUpperLemire (K/utils/DtwUtils.java:93-134) returns for the whole series fetched as one chunk.  The DTW
 // engines use it for every point that is at least rho away from both ends of its fetched chunk.
 extern "C" int kvm_data_envelope(kvm_ctx *ctx, int32_t rho, int32_t first, int64_t count, double *upper, double *lower) {
+    return kvm_guard<int>(ctx, [&]() -> int {
     if (!ctx) return KVM_ERR_INVALID_HANDLE;
     if (!ctx->d_series) return fail(ctx, KVM_ERR_NO_SERIES, "no series loaded");
     if (rho < 0 || first < 1 || count < 0 || (int64_t)first + count - 1 > ctx->n || !upper || !lower)
@@ -861,6 +889,7 @@ extern "C" int kvm_data_envelope(kvm_ctx *ctx, int32_t rho, int32_t first, int64
     }
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return KVM_OK;
+    });
 }
 
 // Runs the kernels of one variant; survivors land (unsorted) in out.d_off/out.d_dist, counters stay on the
@@ -1544,28 +1573,37 @@ static int verify_host(kvm_ctx *ctx, int variant, const double *query, int32_t m
 extern "C" int kvm_verify_rsm_ed(kvm_ctx *ctx, const double *query, int32_t m, const int32_t *left,
                                  const int32_t *right, int32_t k, int32_t shift, double epsilon,
                                  kvm_result **result) {
+    return kvm_guard<int>(ctx, [&]() -> int {
     return verify_host(ctx, V_RSM_ED, query, m, left, right, k, shift, epsilon, 0, 1.0, 0.0, result);
+    });
 }
 extern "C" int kvm_verify_cnsm_ed(kvm_ctx *ctx, const double *query, int32_t m, const int32_t *left,
                                   const int32_t *right, int32_t k, int32_t shift, double epsilon, double alpha,
                                   double beta, kvm_result **result) {
+    return kvm_guard<int>(ctx, [&]() -> int {
     return verify_host(ctx, V_CNSM_ED, query, m, left, right, k, shift, epsilon, 0, alpha, beta, result);
+    });
 }
 extern "C" int kvm_verify_rsm_dtw(kvm_ctx *ctx, const double *query, int32_t m, const int32_t *left,
                                   const int32_t *right, int32_t k, int32_t shift, double epsilon, int32_t rho,
                                   kvm_result **result) {
+    return kvm_guard<int>(ctx, [&]() -> int {
     return verify_host(ctx, V_RSM_DTW, query, m, left, right, k, shift, epsilon, rho, 1.0, 0.0, result);
+    });
 }
 extern "C" int kvm_verify_cnsm_dtw(kvm_ctx *ctx, const double *query, int32_t m, const int32_t *left,
                                    const int32_t *right, int32_t k, int32_t shift, double epsilon, int32_t rho,
                                    double alpha, double beta, kvm_result **result) {
+    return kvm_guard<int>(ctx, [&]() -> int {
     return verify_host(ctx, V_CNSM_DTW, query, m, left, right, k, shift, epsilon, rho, alpha, beta, result);
+    });
 }
 
 extern "C" int kvm_verify_device(kvm_ctx *ctx, int32_t variant, const double *query, int32_t m, const int32_t *left,
                                  const int32_t *right, int32_t k, int32_t shift, double epsilon, int32_t rho,
                                  double alpha, double beta, int32_t *d_out_off, double *d_out_dist, int64_t cap,
                                  int64_t *d_out_count, int64_t *cnt_candidate, void *stream) {
+    return kvm_guard<int>(ctx, [&]() -> int {
     if (!ctx) return KVM_ERR_INVALID_HANDLE;
     if (variant < 0 || variant > 3 || !d_out_off || !d_out_dist || !d_out_count || cap < 0)
         return fail(ctx, KVM_ERR_ILLEGAL_ARGUMENT, "bad kvm_verify_device arguments");
@@ -1599,10 +1637,12 @@ extern "C" int kvm_verify_device(kvm_ctx *ctx, int32_t variant, const double *qu
     HIPCHK(ctx, hipEventRecord(ctx->ev_staged, s));
     ctx->staged_pending = true;
     return KVM_OK;
+    });
 }
 
 extern "C" int kvm_pack_answers_device(kvm_ctx *ctx, const int32_t *d_off, const double *d_dist, const int64_t *d_count,
                                        int64_t pack_cap, double *d_packed, void *stream) {
+    return kvm_guard<int>(ctx, [&]() -> int {
     if (!ctx) return KVM_ERR_INVALID_HANDLE;
     if (!d_off || !d_dist || !d_count || !d_packed || pack_cap < 0)
         return fail(ctx, KVM_ERR_ILLEGAL_ARGUMENT, "bad kvm_pack_answers_device arguments");
@@ -1610,6 +1650,7 @@ extern "C" int kvm_pack_answers_device(kvm_ctx *ctx, const int32_t *d_off, const
     HIPCHK(ctx, kvm_launch_pack_answers(d_off, d_dist, d_count, pack_cap, (double2 *)d_packed,
                                         stream ? (hipStream_t)stream : ctx->stream));
     return KVM_OK;
+    });
 }
 
 // ---- results ----------------------------------------------------------------------------------------------

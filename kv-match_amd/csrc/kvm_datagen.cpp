@@ -6,6 +6,7 @@
 // run of it is reproducible; here one 64-bit seed fixes the whole series (xoshiro256** streams).
 // kvm_gen_intervals produces phase-1-shaped candidate lists: sorted, disjoint, non-adjacent
 // intervals with geometric lengths.
+#include "kvm_guard.h"
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
@@ -88,6 +89,7 @@ void gen_sine(rng &g, double *out, int64_t len) {  // SineGenerator(2, 10, 2, 10
 }  // namespace
 
 extern "C" int kvm_gen_series(uint64_t seed, int64_t n, double *out) {
+    return kvm_guard<int>(nullptr, [&]() -> int {
     if (n < 1 || !out) return KVM_ERR_ILLEGAL_ARGUMENT;
     rng g(seed);
     int64_t left = n, pos = 0;
@@ -106,11 +108,13 @@ extern "C" int kvm_gen_series(uint64_t seed, int64_t n, double *out) {
         left -= l;
     }
     return KVM_OK;
+    });
 }
 
 extern "C" int64_t kvm_gen_intervals(uint64_t seed, int64_t n, int32_t m, int64_t target_candidates,
                                      double mean_len, const int32_t *must_cover, int32_t n_must, int32_t *left,
                                      int32_t *right, int64_t cap) {
+    return kvm_guard<int64_t>(nullptr, [&]() -> int64_t {
     if (n < m || m < 1 || target_candidates < 0 || mean_len < 1 || !left || !right) return KVM_ERR_ILLEGAL_ARGUMENT;
     rng g(seed ^ 0x6b766d5f69766c73ULL);
     const int64_t last = n - m + 1;  // largest valid window start
@@ -168,9 +172,11 @@ extern "C" int64_t kvm_gen_intervals(uint64_t seed, int64_t n, int32_t m, int64_
         right[i] = (int32_t)merged[i].r;
     }
     return (int64_t)merged.size();
+    });
 }
 
 extern "C" int kvm_write_series_file(const char *path, const double *values, int64_t n) {
+    return kvm_guard<int>(nullptr, [&]() -> int {
     if (!path || !values || n < 0) return KVM_ERR_ILLEGAL_ARGUMENT;
     FILE *f = std::fopen(path, "wb");
     if (!f) return KVM_ERR_IO;
@@ -192,4 +198,5 @@ extern "C" int kvm_write_series_file(const char *path, const double *values, int
     }
     std::fclose(f);
     return KVM_OK;
+    });
 }

@@ -17,6 +17,7 @@
 //            or more is refused.
 // The walk is sequential by nature (each decision depends on the row merged so far): one pass per attempted union, read
 // straight from the grouped step-1 arrays; the lines of the file are encoded by a few host threads.
+#include "kvm_guard.h"
 #include <algorithm>
 #include <cstdint>
 #include <cstdio>
@@ -149,6 +150,7 @@ double now_ms() {
 }  // namespace
 
 extern "C" int kvm_index_build(kvm_ctx *ctx, int32_t w, kvm_index_file **out) {
+    return kvm_guard<int>(ctx, [&]() -> int {
     if (!ctx) return KVM_ERR_INVALID_HANDLE;
     if (!out) {
         kvm_set_error(ctx, "null result pointer");
@@ -317,6 +319,7 @@ extern "C" int kvm_index_build(kvm_ctx *ctx, int32_t w, kvm_index_file **out) {
     f->encode_ms = now_ms() - t2;
     *out = f;
     return KVM_OK;
+    });
 }
 
 extern "C" int64_t kvm_index_file_size(const kvm_index_file *f) { return f ? (int64_t)f->image.size() : 0; }
@@ -335,18 +338,21 @@ extern "C" int64_t kvm_index_file_info(const kvm_index_file *f, int32_t what) {
     return 0;
 }
 extern "C" int kvm_index_file_write(const kvm_index_file *f, const char *path) {
+    return kvm_guard<int>(nullptr, [&]() -> int {
     if (!f || !path) return KVM_ERR_ILLEGAL_ARGUMENT;
     FILE *fp = std::fopen(path, "wb");
     if (!fp) return KVM_ERR_IO;
     const size_t n = f->image.size();
     const bool ok = std::fwrite(f->image.data(), 1, n, fp) == n;
     return (std::fclose(fp) == 0 && ok) ? KVM_OK : KVM_ERR_IO;
+    });
 }
 extern "C" void kvm_index_file_free(kvm_index_file *f) { delete f; }
 
 // ---- sortAndMergeIntervals (K/QueryEngine.java:664-693): the step between phase 1 and phase 2 -------------------------
 extern "C" int64_t kvm_sort_and_merge_intervals(const int32_t *left, const int32_t *right, int64_t k, int32_t *out_left,
                                                 int32_t *out_right) {
+    return kvm_guard<int64_t>(nullptr, [&]() -> int64_t {
     if (k < 0 || (k > 0 && (!left || !right || !out_left || !out_right))) return KVM_ERR_ILLEGAL_ARGUMENT;
     std::vector<ival> v((size_t)k);
     for (int64_t i = 0; i < k; i++) v[(size_t)i] = ival{left[i], right[i]};
@@ -373,4 +379,5 @@ extern "C" int64_t kvm_sort_and_merge_intervals(const int32_t *left, const int32
         out_right[i] = v[(size_t)i].last;
     }
     return k;
+    });
 }

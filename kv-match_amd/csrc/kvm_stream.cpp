@@ -6,6 +6,7 @@
 // (profiles/r04_stream_native_0.log).
 #include <atomic>
 #include <exception>
+#include <new>
 #include <thread>
 #include <vector>
 
@@ -56,7 +57,9 @@ extern "C" int kvm_run_jobs(kvm_ctx *const *ctxs, int32_t n_ctx, const kvm_job *
             if (first == KVM_OK && rcs[(size_t)i] != KVM_OK) first = rcs[(size_t)i];
         }
         return first;
-    } catch (const std::exception &) {  // (bad_alloc, or std::system_error from a thread that could not be started)
+    } catch (const std::bad_alloc &) {
+        return KVM_ERR_NO_MEMORY;
+    } catch (const std::exception &) {  // (std::system_error from a thread that could not be started)
         return KVM_ERR_DEVICE;
     }
 }

@@ -22,10 +22,12 @@ static void throw_for(JNIEnv *env, kvm_ctx *ctx, int rc) {
     const char *msg = kvm_last_error(ctx);
     /* range/parameter errors -> IllegalArgumentException (K/operator/file/TimeSeriesFileOperator.java:55-57); where the
      * reference's DtwUtils.lowerUpperLemire indexes below its arrays (K/utils/DtwUtils.java:81-90; KVM_OPT_STRICT_BOUNDS) ->
-     * ArrayIndexOutOfBoundsException with the index as its message, as JDK 8 words it; everything else -> IOException
-     * (what query() declares, K/QueryEngine.java:155) */
+     * ArrayIndexOutOfBoundsException with the index as its message, as JDK 8 words it; a host allocation that failed inside
+     * the library (KVM_ERR_NO_MEMORY: no C++ exception crosses the C ABI) -> OutOfMemoryError, what the JVM's own `new`
+     * would have thrown; everything else -> IOException (what query() declares, K/QueryEngine.java:155) */
     jclass cls = (*env)->FindClass(env, rc == KVM_ERR_ILLEGAL_ARGUMENT      ? "java/lang/IllegalArgumentException"
                                         : rc == KVM_ERR_INDEX_OUT_OF_BOUNDS ? "java/lang/ArrayIndexOutOfBoundsException"
+                                        : rc == KVM_ERR_NO_MEMORY           ? "java/lang/OutOfMemoryError"
                                                                             : "java/io/IOException");
     (*env)->ThrowNew(env, cls, msg ? msg : "kvmatch error");
 }

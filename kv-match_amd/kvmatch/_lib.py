@@ -18,6 +18,7 @@ KVM_ERR_DEVICE = -5
 KVM_ERR_NO_SERIES = -6
 KVM_ERR_UNSUPPORTED = -7
 KVM_ERR_INDEX_OUT_OF_BOUNDS = -8
+KVM_ERR_NO_MEMORY = -9
 
 STAT_WINDOWS, STAT_PASS_FILTER, STAT_PASS_LB_KIM, STAT_PASS_LB_KEOGH, STAT_PASS_LB_KEOGH2, STAT_KERNEL_NS, \
     STAT_RECHECKED, STAT_DTW_SEQUENTIAL = range(8)
@@ -166,4 +167,6 @@ def check(rc, ctx=None):
         raise KvMatchIOError(msg)
     if rc == KVM_ERR_INDEX_OUT_OF_BOUNDS:
         raise KvMatchIndexOutOfBounds(msg)
+    if rc == KVM_ERR_NO_MEMORY:
+        raise MemoryError(msg)  # -> java.lang.OutOfMemoryError
     raise KvMatchDeviceError(f"[{rc}] {msg}")

@@ -21,6 +21,7 @@ static kvm_index_rows g_rows;
 static std::string g_err;
 
 void kvm_set_error(kvm_ctx *, const std::string &msg) { g_err = msg; }
+void kvm_set_error_noexcept(kvm_ctx *, const char *msg) noexcept { try { g_err = msg; } catch (...) {} }
 
 extern "C" {
 int kvm_index_rows_build_grouped(kvm_ctx *, int32_t, kvm_index_rows **out) {

@@ -279,3 +279,45 @@ def test_interval_argument_forms_cannot_be_misread(built):
         _as_intervals(([1, 10, 30], [5, 20, 40]))
     with pytest.raises(kvmatch.KvMatchIllegalArgument):
         _as_intervals([1, 5, 10, 20])
+
+
+def test_no_cpp_exception_crosses_the_c_abi(built, tmp_path):
+    """The extern "C" entry points run their bodies behind kvm_guard (csrc/kvm_guard.h): a std::bad_alloc inside the library
+    comes back as KVM_ERR_NO_MEMORY (-> MemoryError here, OutOfMemoryError in the JNI shim) instead of unwinding into the
+    caller's frame -- which would end a JVM, and ends a ctypes caller with SIGABRT.  Forced in a child process whose address
+    space is capped just above what it already uses, on a host-only entry point (no GPU): sortAndMergeIntervals of 2e7
+    intervals needs ~0.5 GB of vectors."""
+    import subprocess
+    import sys
+    code = r"""
+import resource, sys
+sys.path.insert(0, %r)
+import numpy as np
+from kvmatch import _lib
+lib = _lib.load()
+k = 20_000_000
+left = np.arange(1, 3 * k, 3, dtype=np.int32)[:k].copy(); right = left + 1
+ol = np.empty_like(left); orr = np.empty_like(right)
+assert lib.kvm_sort_and_merge_intervals(left.ctypes.data, right.ctypes.data, 1000, ol.ctypes.data, orr.ctypes.data) == 1000
+with open("/proc/self/statm") as f: vm = int(f.read().split()[0]) * resource.getpagesize()
+resource.setrlimit(resource.RLIMIT_AS, (vm + (96 << 20), vm + (96 << 20)))
+rc = lib.kvm_sort_and_merge_intervals(left.ctypes.data, right.ctypes.data, k, ol.ctypes.data, orr.ctypes.data)
+print("rc", rc)
+try:
+    _lib.check(int(rc), None)
+except MemoryError as e:
+    print("MemoryError", e)
+""" % os.path.join(ROOT, "kv-match_amd")
+    cp = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert cp.returncode == 0, (cp.returncode, cp.stdout[-500:], cp.stderr[-2000:])
+    assert "rc -9" in cp.stdout and "MemoryError" in cp.stdout, cp.stdout
+
+
+def test_integration_listing_is_the_shipped_adapter():
+    """INTEGRATION.md section 2 shows the Java adapter a maintainer adds: the listing is the shipped source file from its
+    `package` line on, verbatim -- so the document cannot lag the natives the JNI shim implements."""
+    java = open(os.path.join(ROOT, "kv-match_amd", "java", "cn", "edu", "fudan", "dsm", "kvmatch", "gpu", "Phase2Gpu.java")).read()
+    body = java[java.index("package cn.edu"):].rstrip() + "\n"
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    a = doc.index("```java\npackage cn.edu.fudan.dsm.kvmatch.gpu;") + len("```java\n")
+    assert doc[a: doc.index("```\n", a)] == body
