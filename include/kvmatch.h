@@ -29,8 +29,7 @@
  * (ii) a thread_local memo of the ED pruner's launch-shape model.  Nothing else is shared.
  *
  * Environment (read once per process; all optional, none changes an answer):
- *   KVM_ED_KERNEL=1|3|4  default ED pruning kernel where KVM_OPT_ED_KERNEL is 0 (auto)
- *   KVM_ED_GEN=1         the same as KVM_ED_KERNEL=4 (lane-granular tiles staged by LDS-DMA, experimental)
+ *   KVM_ED_KERNEL=1|3    default ED pruning kernel where KVM_OPT_ED_KERNEL is 0 (auto)
  *   KVM_TRACE=1          per-stage host timings of every call on stderr
  *   KVM_DEBUG_SYNC=1     DTW calls wait for the stream after every stage and name it on stderr
  *   KVM_LIB=<path>       (Python binding only) load another build of this library
@@ -317,12 +316,14 @@ void kvm_result_free(kvm_result *r);
 #define KVM_OPT_LB_CASCADE 2     /* 1 (default): LB_Kim / LB_Keogh screens in front of the exact DTW stage; 0: every
                                     filter-passing candidate goes to the exact stage.  Same answers either way. */
 #define KVM_OPT_ED_KERNEL 3      /* ED pruning kernel: 0 auto (default = 3), 1 wave-per-candidate (the cross-check of
-                                    the tests), 3 LDS-tiled correlation form, 4 correlation form on lane-granular
-                                    tiles staged by LDS-DMA (experimental; RSM-ED with every point evaluated, 3
-                                    otherwise).  All return identical answers.  (2 and round 2's 4 were removed in
-                                    round 3 and are refused.) */
+                                    the tests), 3 LDS-tiled correlation form.  Identical answers.  (2 and 4 -- the
+                                    direct LDS-tiled and the lane-granular pruners of rounds 2 - 3 -- were removed and
+                                    are refused.) */
 #define KVM_OPT_TIMING 4         /* 1: record HIP-event kernel times into KVM_STAT_KERNEL_NS */
-#define KVM_OPT_DP_KERNEL 5      /* 0 auto (default: register-resident band when rho <= 511), 1 generic LDS form */
+#define KVM_OPT_DP_KERNEL 5      /* banded-DP form: 0 auto (rho <= 511: band in registers -- two candidates per wave when
+                                    more than 3072 reach the DP and rho = 64 .. 255, any number of cells per lane), 1
+                                    generic LDS form, 2 one candidate per wave, 3 packed form for every list length.
+                                    Identical answers. */
 #define KVM_OPT_SORT_VIOLATION 6 /* cNSM-DTW only.  NormQueryEngineDtw sorts its query with a comparator that breaks
                                     the Comparator contract (K/NormQueryEngineDtw.java:475-478); for some queries
                                     (about half of white-noise ones, a few percent of random walks, no smooth one)

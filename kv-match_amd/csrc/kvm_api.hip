@@ -124,8 +124,6 @@ static void free_series(kvm_ctx *ctx) {
     ctx->d_series = nullptr;
     if (ctx->own_series && ctx->d_prefix) hipFree(ctx->d_prefix);  // (a shared series belongs to its owner context)
     if (ctx->own_series && ctx->d_blockmax) hipFree(ctx->d_blockmax);
-    if (ctx->own_series && ctx->d_series_sh) hipFree(ctx->d_series_sh);
-    ctx->d_series_sh = nullptr;
     ctx->own_series = false;
     ctx->d_prefix = nullptr;
     ctx->d_blockmax = nullptr;
@@ -165,8 +163,8 @@ extern "C" int kvm_set_option(kvm_ctx *ctx, int32_t option, int64_t value) {
         case KVM_OPT_EARLY_ABANDON: ctx->opt_early_abandon = value ? 1 : 0; return KVM_OK;
         case KVM_OPT_LB_CASCADE: ctx->opt_lb_cascade = value ? 1 : 0; return KVM_OK;
         case KVM_OPT_ED_KERNEL:
-            if (value != 0 && value != 1 && value != 3 && value != 4)
-                return fail(ctx, KVM_ERR_ILLEGAL_ARGUMENT, "KVM_OPT_ED_KERNEL in {0,1,3,4}");
+            if (value != 0 && value != 1 && value != 3)
+                return fail(ctx, KVM_ERR_ILLEGAL_ARGUMENT, "KVM_OPT_ED_KERNEL in {0,1,3}");
             ctx->opt_ed_kernel = value;
             return KVM_OK;
         case KVM_OPT_TIMING: ctx->opt_timing = value ? 1 : 0; return KVM_OK;
@@ -229,12 +227,6 @@ static int finish_load_steps(kvm_ctx *ctx) {
     // largest x^2 per prefix block: what the reference's running sums may still carry the residue of (kvm_hist_*)
     HIPCHK(ctx, hipMalloc((void **)&ctx->d_blockmax, (size_t)((ctx->n >> KVM_PS_BLOCK_LOG2) + 1) * sizeof(double)));
     HIPCHK(ctx, kvm_launch_blockmax(ctx->d_series, ctx->n, ctx->d_blockmax, ctx->stream));
-    if (const char *e = getenv("KVM_ED_GEN")) {
-        if (e[0] == '1') {  // (the block-centred copy the lane-granular pruner stages from: with the series, so that sharing contexts see it)
-            HIPCHK(ctx, hipMalloc((void **)&ctx->d_series_sh, (size_t)(ctx->n + KVM_SERIES_PAD) * sizeof(double)));
-            HIPCHK(ctx, kvm_launch_shift_series(ctx->d_series, ctx->n, ctx->d_series_sh, ctx->stream));
-        }
-    }
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return KVM_OK;
 }
@@ -343,7 +335,6 @@ extern "C" int kvm_share_series(kvm_ctx *ctx, const kvm_ctx *owner) {
     ctx->d_series = owner->d_series;  // values and prefix sums are read-only after staging
     ctx->d_prefix = owner->d_prefix;
     ctx->d_blockmax = owner->d_blockmax;
-    ctx->d_series_sh = owner->d_series_sh;
     ctx->own_series = false;
     ctx->n = owner->n;
     return KVM_OK;
@@ -964,17 +955,15 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
         HIPCHK(ctx, hipEventSynchronize(ctx->ev_staged));
         ctx->staged_pending = false;
     }
-    // ED pruning kernel: 1 = wave-per-candidate (the cross-check), 3 = LDS-tiled correlation form, 4 = correlation form on
-    // lane-granular tiles staged by LDS-DMA (RSM-ED with every point evaluated; otherwise 3); 0 = auto (KVM_ED_KERNEL in the
-    // environment overrides auto).  (2, the direct LDS-tiled form, and round 2's 4, lanes along the window, were removed in
-    // round 3: one cross-check pruner is enough.)
+    // ED pruning kernel: 1 = wave-per-candidate (the cross-check), 3 = LDS-tiled correlation form; 0 = auto (KVM_ED_KERNEL in
+    // the environment overrides auto).  (2, the direct LDS-tiled form, and 4, lane-granular tiles staged by LDS-DMA, were
+    // removed in rounds 3 and 4: the latter stayed 2 - 3 % behind the default -- HISTORY.md.)
     static const int env_ed_kernel = [] {
         const char *e = getenv("KVM_ED_KERNEL");
         const int v = e ? atoi(e) : 0;
-        return (v == 1 || v == 3 || v == 4) ? v : 0;
+        return (v == 1 || v == 3) ? v : 0;
     }();
-    const int ed_kernel_opt = ctx->opt_ed_kernel != 0 ? (int)ctx->opt_ed_kernel : (env_ed_kernel ? env_ed_kernel : 3);
-    const int ed_kernel = ed_kernel_opt == 4 ? 3 : ed_kernel_opt;
+    const int ed_kernel = ctx->opt_ed_kernel != 0 ? (int)ctx->opt_ed_kernel : (env_ed_kernel ? env_ed_kernel : 3);
     auto tp_ = std::chrono::steady_clock::now();
     // 32-candidate tiles for the LDS-tiled kernels (ED pruners, fused DTW lower-bound stage), 64 otherwise
     // (DTW cascade: 64-candidate tiles first, trimmed and cut to <= 32 on the device by kvm_retile_dtw_kernel)
@@ -983,26 +972,14 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
     const bool retile_rsm = !cnsm && !dtw && ed_kernel == 3 && ctx->opt_early_abandon;
     const bool retile = (cnsm && !dtw && ed_kernel == 3) || retile_rsm;
     // host-planned list for the correlation-form pruner (RSM-ED, every point evaluated): the class A / B / C tiling
-    // (kvm_ed_dot.hip); KVM_ED_GEN=1 in the environment: lane-granular tiles of 8 candidates staged by LDS-DMA (kvm_ed_g.hip,
-    // round 3: +5-8 % with four queries in flight, 15-20 % SLOWER as a single launch -- its LDS-DMA volume per point is twice the
-    // register staging's and the CU's DMA path, not the FMA pipe, sets its pace: not the default)
-    static const bool env_gen = [] {
-        const char *e = getenv("KVM_ED_GEN");
-        return e && e[0] == '1';
-    }();
-    const bool gen = !dtw && ed_kernel == 3 && !retile && (env_gen || ed_kernel_opt == 4);
-    const int32_t tile_max = gen ? 8 : retile ? KVM_TILE_MAX : (!dtw && ed_kernel == 3) ? KVM_TILE_TILED : KVM_TILE_MAX;
-    const bool hybrid = !dtw && ed_kernel == 3 && !retile && !gen;
+    // (kvm_ed_dot.hip)
+    const int32_t tile_max = retile ? KVM_TILE_MAX : (!dtw && ed_kernel == 3) ? KVM_TILE_TILED : KVM_TILE_MAX;
+    const bool hybrid = !dtw && ed_kernel == 3 && !retile;
     // query block: q | (qu | ql for DTW) | pad || (qc | pad | q_pref | q_pref8 | qT for ED) || (zQ sorted | order: cNSM-ED
     // exact pass); the runs follow it in the pinned staging buffer, where build_plan writes them directly
     const int nchunks4 = (m + ED4_JC - 1) / ED4_JC, nchunks8 = (m + ED8_JC - 1) / ED8_JC;
     const size_t qmain = (size_t)m * 8 * (dtw ? 3 : 1) + KVM_SERIES_PAD * sizeof(double);
-    // (... | qc_pre: m + 1 running sums of qc, padded to a multiple of 16 B | q_pref16: the chunk sums at 16-point granularity)
-    const int n16 = (m + 15) / 16;
-    const size_t qpre_bytes = (((size_t)m + 1) * 8 + 15) / 16 * 16, qp16_bytes = ((size_t)n16 + 2) * 16;
-    const size_t qdot_old = (size_t)m * 8 + KVM_SERIES_PAD * sizeof(double) + ((size_t)2 * nchunks4 + 1 + nchunks8 + 1) * 16;
-    const size_t qdot0 = dtw ? 0 : qdot_old + qpre_bytes + qp16_bytes;
-    const size_t qdot = qdot0;
+    const size_t qdot = dtw ? 0 : (size_t)m * 8 + KVM_SERIES_PAD * sizeof(double) + ((size_t)2 * nchunks4 + 1 + nchunks8 + 1) * 16;
     const size_t qexact_off = qmain + qdot;
     // DTW: the reference's summation order of the LB_Keogh loops and the query / its envelope in that order
     // (uo | lo | qo | order) behind the main block
@@ -1069,8 +1046,8 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
 
     KVM_TP("  plan launches");
     // correlation-form ED pruner: centred query and its chunk-granular prefix sums
-    std::vector<double> qcen, qcpre;
-    std::vector<double2> qpref, qpref8, qpref16;
+    std::vector<double> qcen;
+    std::vector<double2> qpref, qpref8;
     if (!dtw) {
         // (pruner-side quantities, guard-banded: the summation order is free, so four interleaved partial sums keep the
         // adders busy -- the plain sequential loops cost ~20 us of the host's critical path at m = 8192)
@@ -1099,20 +1076,6 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
                 a2[u] += c * c;
             }
         }
-        // lane-granular pruner (kvm_ed_g.hip): running sums of qc per point and its chunk sums per 16 points
-        qcpre.resize((size_t)m + 1);
-        qpref16.resize((size_t)n16 + 2);
-        {
-            double r1 = 0, r2 = 0;
-            for (int j = 0; j < m; j++) {
-                if (j % 16 == 0) qpref16[(size_t)(j / 16)] = make_double2(r1, r2);
-                qcpre[(size_t)j] = r1;
-                r1 += qcen[(size_t)j];
-                r2 += qcen[(size_t)j] * qcen[(size_t)j];
-            }
-            qcpre[(size_t)m] = r1;
-            for (size_t t = (size_t)((m + 15) / 16); t < qpref16.size(); t++) qpref16[t] = make_double2(r1, r2);
-        }
         const double p1 = (a1[0] + a1[1]) + (a1[2] + a1[3]), p2 = (a2[0] + a2[1]) + (a2[2] + a2[3]);
         for (size_t t = (size_t)((m + ED16_JC - 1) / ED16_JC); t <= (size_t)2 * nchunks4; t++) qpref[t] = make_double2(p1, p2);
         qpref8[(size_t)nchunks8] = make_double2(p1, p2);
@@ -1130,8 +1093,6 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
         std::memcpy(hp + qmain + (size_t)m * 8 + KVM_SERIES_PAD * sizeof(double), qpref.data(), qpref.size() * 16);
         std::memcpy(hp + qmain + (size_t)m * 8 + KVM_SERIES_PAD * sizeof(double) + qpref.size() * 16, qpref8.data(),
                     qpref8.size() * 16);
-        std::memcpy(hp + qmain + qdot_old, qcpre.data(), qcpre.size() * 8);
-        std::memcpy(hp + qmain + qdot_old + qpre_bytes, qpref16.data(), qpref16.size() * 16);
     }
     const size_t qfirst = (cnsm && !dtw) ? qexact_off : qbytes;  // the exact-pass block is staged later (see below)
     if (dtw) {
@@ -1190,8 +1151,6 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
                     : (const double2 *)((const char *)ctx->b_query.p + qmain + (size_t)m * 8 +
                                         KVM_SERIES_PAD * sizeof(double));
     qd.q_pref8 = dtw ? nullptr : qd.q_pref + (2 * nchunks4 + 1);
-    qd.qc_pre = dtw ? nullptr : (const double *)((const char *)ctx->b_query.p + qmain + qdot_old);
-    qd.q_pref16 = dtw ? nullptr : (const double2 *)((const char *)ctx->b_query.p + qmain + qdot_old + qpre_bytes);
     qd.qu = dtw ? qd.q + m : nullptr;
     qd.ql = dtw ? qd.q + 2 * (size_t)m : nullptr;
     unsigned long long *counters = (unsigned long long *)ctx->b_counters.p;
@@ -1205,7 +1164,7 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
     if (n_tiles + pl.n_tiles_b + pl.n_tiles_c == 0) return KVM_OK;
 
     // (the default ED pruner on a host-planned list stamps its own begin and end: kvm_launch_ed_dot)
-    const bool self_timed = ctx->opt_timing && !dtw && !retile && !gen && ed_kernel == 3;
+    const bool self_timed = ctx->opt_timing && !dtw && !retile && ed_kernel == 3;
     if (ctx->opt_timing && !self_timed) HIPCHK(ctx, hipEventRecord(ctx->ev0, stream));
     if (!dtw) {
         // pruning pass (fast kernels, guard band) -> survivors -> exact pass in the reference's operation order
@@ -1224,17 +1183,6 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
                                           pl.windows, counters, ctx->num_cu, counters + KVM_CNT_TILES_A, out.d_off, out.d_dist, out.cap,
                                           stream));
             KVM_TP("  ed_dot launch");
-        } else if (gen) {
-            // the series once more, every point minus the first point of its prefix block: the source of the LDS-DMA staging (no
-            // register, no VALU between HBM and LDS), 8 B per point; built on first use
-            if (!ctx->d_series_sh) {
-                if (!ctx->own_series) return fail(ctx, KVM_ERR_UNSUPPORTED, "KVM_ED_GEN=1 on a context that shares another one's series: run one query on the owner first");
-                HIPCHK(ctx, hipMalloc((void **)&ctx->d_series_sh, (size_t)(ctx->n + KVM_SERIES_PAD) * sizeof(double)));
-                HIPCHK(ctx, kvm_launch_shift_series(ctx->d_series, ctx->n, ctx->d_series_sh, stream));
-            }
-            if ((rc = ensure(ctx, ctx->b_aux, kvm_ed_g_scratch_bytes(n_tiles, ctx->num_cu)))) return rc;
-            HIPCHK(ctx, kvm_launch_ed_g(ctx->d_series, ctx->d_series_sh, ctx->d_prefix, qd, d_tiles, n_tiles, surv, pl.windows, counters,
-                                        ctx->num_cu, out.d_off, out.d_dist, out.cap, ctx->b_aux.p, stream));
         }
         else if (ed_kernel == 3)
             HIPCHK(ctx, kvm_launch_ed_dot(ctx->d_series, ctx->d_prefix, ctx->n, qd, d_tiles, pl.n_tiles, d_tiles + pl.n_tiles,

@@ -193,16 +193,6 @@ hipError_t kvm_launch_bswap64(uint64_t *d, int64_t n, hipStream_t s) {
     return hipGetLastError();
 }
 
-// x[i] - x[first point of i's prefix block] for the whole padded series (the pad stays zero): what kvm_ed_g.hip stages by LDS-DMA
-__global__ __launch_bounds__(256) void kvm_shift_series_kernel(const double *__restrict__ x, int64_t n, double *__restrict__ out) {
-    const int64_t total = n + KVM_SERIES_PAD;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
-        out[i] = i < n ? x[i] - x[(i >> KVM_PS_BLOCK_LOG2) << KVM_PS_BLOCK_LOG2] : 0.0;
-}
-hipError_t kvm_launch_shift_series(const double *x, int64_t n, double *out, hipStream_t s) {
-    hipLaunchKernelGGL(kvm_shift_series_kernel, dim3(256 * 16), dim3(256), 0, s, x, n, out);
-    return hipGetLastError();
-}
 
 // Hybrid ED tiling (kvm_ed_dot.hip): per run floor(count/64) full 64-candidate tiles; what is left goes to class A, to
 // class B and / or to class C by kvm_ed_remainder_classes (the class-B tile takes the first <= 32 candidates of the

@@ -84,8 +84,6 @@ struct kvm_ctx {
     bool own_series = false;
     double2 *d_prefix = nullptr;  // n entries {sum x, sum x^2}, block-restarted
     double *d_blockmax = nullptr; // max x^2 of every prefix block (NaN if the block holds one): kvm_run_hist
-    double *d_series_sh = nullptr; // x[i] - x[first point of i's prefix block] (+ KVM_SERIES_PAD): the LDS-DMA staging source of
-                                   // the lane-granular ED pruner (kvm_ed_g.hip): already centred, so no VALU touches it on the way
     // cached data envelope for LB_Keogh2 (per rho)
     double *d_env_u = nullptr, *d_env_l = nullptr;
     int32_t env_rho = -1;
@@ -234,8 +232,6 @@ struct kvm_query_dev {
     const double2 *q_pref;  // q_pref[t] = { sum_{j < t*ED16_JC} (q_j - q_mean), sum_{j < t*ED16_JC} (q_j - q_mean)^2 }, t = 0 .. 2*ceil(m/ED4_JC)
                             // (class C chunks; a class B chunk is two of them; entries past m hold the totals)
     const double2 *q_pref8; // the same at ED8_JC granularity
-    const double *qc_pre;   // [m + 1] qc_pre[k] = sum_{j < k} qc[j] (kvm_ed_g.hip: re-basing a window that crosses a prefix block)
-    const double2 *q_pref16; // as q_pref at 16-point granularity: t = 0 .. ceil(m / 16) (kvm_ed_g.hip: chunk lengths vary per unit)
     const double *run_hist; // cNSM: per run, the largest x^2 among the points the reference's running sums of that run pass
                             // over (to the granularity of the prefix blocks; NaN with a NaN among them) -- see kvm_hist_*
 };
@@ -255,14 +251,6 @@ hipError_t kvm_launch_ed_dot(const double *series, const double2 *prefix, int64_
                              const kvm_tile *tilesC, int64_t nC, kvm_surv *surv,
                              int64_t cap, unsigned long long *counters, int num_cu, const unsigned long long *d_counts,
                              int32_t *out_off, double *out_dist, int64_t out_cap, hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
-// Lane-granular form of the same pruner (kvm_ed_g.hip; RSM, every point evaluated): `tiles8` = the list cut into tiles of 8
-// consecutive candidates (one lane each), 64 of them per wavefront whatever runs they come from; window chunks staged by
-// LDS-DMA from `series_sh` (kvm_ctx::d_series_sh)
-hipError_t kvm_launch_ed_g(const double *series, const double *series_sh, const double2 *prefix, const kvm_query_dev &qd,
-                           const kvm_tile *tiles8, int64_t n_tiles8, kvm_surv *surv, int64_t cap, unsigned long long *counters,
-                           int num_cu, int32_t *out_off, double *out_dist, int64_t out_cap, void *scratch, hipStream_t s);
-size_t kvm_ed_g_scratch_bytes(int64_t n_tiles8, int num_cu);  // `scratch`: partial accumulators + arrival counters
-hipError_t kvm_launch_shift_series(const double *x, int64_t n, double *out, hipStream_t s);
 // cNSM: 64-candidate tiles -> trimmed class-A / class-B tile lists of the candidates passing the guarded (alpha, beta)
 // filter; the list lengths go to d_counts[0..1] (kvm_launch_ed_dot then takes nA, nB as upper bounds; no class C here)
 hipError_t kvm_launch_retile_rsm(const double *series, const kvm_query_dev &qd, const kvm_tile *tiles, int64_t n_tiles,

@@ -60,7 +60,7 @@ for step in range(steps):
             other = kvmatch.Phase2Context(0).share_series(ctx); other.set_option(kvmatch.OPT_SORT_VIOLATION, 1)
         else:
             ctx.set_option(kvmatch.OPT_EARLY_ABANDON, int(rng.integers(0, 2))); ctx.set_option(kvmatch.OPT_LB_CASCADE, int(rng.integers(0, 2)))
-            ctx.set_option(kvmatch.OPT_DP_KERNEL, int(rng.integers(0, 2))); ctx.set_option(kvmatch.OPT_ED_KERNEL, int(rng.choice([0, 0, 1, 3, 4])))
+            ctx.set_option(kvmatch.OPT_DP_KERNEL, int(rng.integers(0, 2))); ctx.set_option(kvmatch.OPT_ED_KERNEL, int(rng.choice([0, 0, 1, 3])))
     except Exception as e:
         bad += 1; print(f"EXCEPTION step {step} op {op}: {type(e).__name__} {str(e)[:120]}", flush=True)
 print("steps", steps, "differences", bad)

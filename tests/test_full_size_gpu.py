@@ -40,7 +40,7 @@ def test_rsm_ed_and_cnsm_ed_config_2_3(big):
     assert int((R.astype(np.int64) - L + 1).sum()) >= 1_000_000
     want = oracle.rsm_ed(series, q, L, R, 0, 10.0)
     eng = kvmatch.QueryEngine(ctx)
-    for kern in (0, 1, 3, 4):             # every pruning kernel, abandon on and off: one answer list
+    for kern in (0, 1, 3):             # every pruning kernel, abandon on and off: one answer list
         ctx.set_option(kvmatch.OPT_ED_KERNEL, kern)
         for ab in (1, 0):
             ctx.set_option(kvmatch.OPT_EARLY_ABANDON, ab)

@@ -340,7 +340,7 @@ def test_shift_clipping_empty_and_errors(world):
 def test_knobs_do_not_change_answers(world):
     kvmatch = world[0]
     ctx = world[3]
-    for removed in (2, 5, -1):   # (2: the direct LDS-tiled pruner, removed in round 3)
+    for removed in (2, 4, 5, -1):   # (2: the direct LDS-tiled pruner, removed in round 3; 4: the lane-granular one, round 4)
         with pytest.raises(kvmatch.KvMatchIllegalArgument):
             ctx.set_option(kvmatch.OPT_ED_KERNEL, removed)
     assert ctx.get_option(kvmatch.OPT_ED_KERNEL) == 0 and ctx.get_option(kvmatch.OPT_STRICT_BOUNDS) == 1 and ctx.get_option(kvmatch.OPT_UCR_LOOPS) == 0
@@ -363,7 +363,7 @@ def test_knobs_do_not_change_answers(world):
     finally:
         ctx.set_option(kvmatch.OPT_DP_KERNEL, 0)
     assert np.array_equal(b2.offsets, base_dtw.offsets) and np.array_equal(b2.distances, base_dtw.distances)
-    for k in (1, 3, 4):
+    for k in (1, 3):
         ctx.set_option(kvmatch.OPT_ED_KERNEL, k)
         try:
             a = kvmatch.QueryEngine(ctx).verify((L, R), 1, q, 5.0)
@@ -741,7 +741,7 @@ def test_query_lengths_all_variants(world, m):
     ctx.load_series(s)
     L, R = datagen.gen_intervals(len(s), m, 3_000, 12.0, must_cover=[qoff, 10_000, 90_000], seed=m)
     eps = 0.5 * np.sqrt(m) + 0.2
-    for k in (1, 3, 4):
+    for k in (1, 3):
         ctx.set_option(kvmatch.OPT_ED_KERNEL, k)
         compare(kvmatch.QueryEngine(ctx).verify((L, R), 1, q, eps), oracle.rsm_ed(s, q, L, R, 0, eps), tag=f"len rsm k{k}")
         if m >= 2:
@@ -775,7 +775,7 @@ def test_interval_shapes(world):
     left += [69_990, len(s) - m - 40]
     right += [70_010, len(s) + 500]          # the last interval runs past n - m + 1 and is clipped
     L, R = np.array(left, dtype=np.int32), np.array(right, dtype=np.int32)
-    for k in (1, 3, 4):
+    for k in (1, 3):
         ctx.set_option(kvmatch.OPT_ED_KERNEL, k)
         compare(kvmatch.QueryEngine(ctx).verify((L, R), 1, q, 3.0), oracle.rsm_ed(s, q, L, R, 0, 3.0), tag=f"shapes k{k}")
         compare(kvmatch.NormQueryEngine(ctx).verify((L, R), 1, q, 3.0, 1.5, 3.0),
