@@ -368,7 +368,10 @@ int kvm_measure_device(kvm_ctx *ctx, int32_t what, double *value);
  * 3 cnsm_dtw.  d_out_off / d_out_dist are device buffers of `cap` entries, d_out_count a device
  * int64.  Unsorted.  `stream` is a hipStream_t (NULL = the ctx stream).  The ED variants return without
  * waiting for the stream; the DTW variants wait for it once (the number of candidates that need the sequential tie
- * path is only known on the device, and that path's scratch is sized on the host). */
+ * path is only known on the device, and that path's scratch is sized on the host).  Ordering: the next call on this
+ * context is ordered behind this one's kernels on the device (stream order, or an event wait when it runs on another
+ * stream); the host only waits until the call's inputs have left the pinned staging buffer, so back-to-back calls overlap
+ * their host work with the previous call's kernels.  The caller must not read d_out_* before `stream` has caught up. */
 int kvm_verify_device(kvm_ctx *ctx, int32_t variant, const double *query, int32_t m, const int32_t *left,
                       const int32_t *right, int32_t k, int32_t shift, double epsilon, int32_t rho, double alpha,
                       double beta, int32_t *d_out_off, double *d_out_dist, int64_t cap, int64_t *d_out_count,

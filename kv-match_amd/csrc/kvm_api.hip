@@ -92,11 +92,13 @@ extern "C" int kvm_open(int device, kvm_ctx **out) {
     ctx->device = device;
     if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreate(&ctx->stream)) != hipSuccess ||
         (e = hipEventCreate(&ctx->ev0)) != hipSuccess || (e = hipEventCreate(&ctx->ev1)) != hipSuccess ||
-        (e = hipEventCreateWithFlags(&ctx->ev_staged, hipEventDisableTiming)) != hipSuccess) {
+        (e = hipEventCreateWithFlags(&ctx->ev_staged, hipEventDisableTiming)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&ctx->ev_done, hipEventDisableTiming)) != hipSuccess) {
         std::string msg = std::string("kvm_open: ") + hipGetErrorString(e);
         if (ctx->ev0) hipEventDestroy(ctx->ev0);
         if (ctx->ev1) hipEventDestroy(ctx->ev1);
         if (ctx->ev_staged) hipEventDestroy(ctx->ev_staged);
+        if (ctx->ev_done) hipEventDestroy(ctx->ev_done);
         if (ctx->stream) hipStreamDestroy(ctx->stream);
         delete ctx;
         return fail(nullptr, KVM_ERR_DEVICE, msg);
@@ -109,6 +111,8 @@ extern "C" int kvm_open(int device, kvm_ctx **out) {
             hipEventDestroy(ctx->ev0);
             hipEventDestroy(ctx->ev1);
             hipEventDestroy(ctx->ev_staged);
+    hipEventDestroy(ctx->ev_done);
+            hipEventDestroy(ctx->ev_done);
             hipStreamDestroy(ctx->stream);
             delete ctx;
             return fail(nullptr, KVM_ERR_DEVICE, msg);
@@ -951,6 +955,12 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
     HIPCHK(ctx, hipSetDevice(ctx->device));
     // Scratch buffers and the pinned staging area are reused by every call: wait until the previous call's device
     // work has drained (kvm_verify_device returns without synchronising the caller's stream).
+    if (ctx->done_pending) {
+        // the previous kvm_verify_device call may still be reading the device scratch on its stream: this call's stream waits
+        // for it on the DEVICE (a call on the same stream is ordered behind it anyway)
+        if (ctx->done_stream != stream) HIPCHK(ctx, hipStreamWaitEvent(stream, ctx->ev_done, 0));
+        ctx->done_pending = false;
+    }
     if (ctx->staged_pending) {
         HIPCHK(ctx, hipEventSynchronize(ctx->ev_staged));
         ctx->staged_pending = false;
@@ -1579,11 +1589,14 @@ extern "C" int kvm_verify_device(kvm_ctx *ctx, int32_t variant, const double *qu
         HIPCHK(ctx, hipMemcpyAsync(d_out_count, (unsigned long long *)ctx->b_counters.p + KVM_CNT_ANSWERS,
                                    sizeof(int64_t), hipMemcpyDeviceToDevice, s));
     }
-    // Everything this call has enqueued behind run_variant's own record -- the sequential tie path's kernels, the copy of the
-    // answer count out of the counters -- still reads the context's scratch: the next call (possibly on another stream) must
-    // wait for all of it before it reuses the buffers.
-    HIPCHK(ctx, hipEventRecord(ctx->ev_staged, s));
-    ctx->staged_pending = true;
+    // Everything this call has enqueued -- the pipeline, the sequential tie path's kernels, the copy of the answer count out
+    // of the counters -- reads the context's device scratch: the next call, possibly on another stream, must be ordered
+    // behind all of it before it reuses the buffers.  That is a device-side wait on ev_done (run_variant); the HOST only
+    // ever waits for ev_staged, recorded behind the last read of the pinned staging buffer, so it can prepare the next
+    // call while this one still runs.
+    HIPCHK(ctx, hipEventRecord(ctx->ev_done, s));
+    ctx->done_stream = s;
+    ctx->done_pending = true;
     return KVM_OK;
     });
 }

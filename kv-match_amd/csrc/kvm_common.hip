@@ -194,6 +194,15 @@ hipError_t kvm_launch_bswap64(uint64_t *d, int64_t n, hipStream_t s) {
 }
 
 
+// Grid of the tile-expansion kernels: one wavefront per run -- but the launch also carries the call's query block over from
+// the pinned staging buffer (grid-stride loop at its head), and a list of a few runs (a selective query, a full scan's single
+// run) must not leave a 200 KB block to one workgroup's ~100 dependent PCIe round trips per thread: at least as many
+// workgroups as the dedicated upload kernel used (one per 2 KB, up to 512).  Workgroups beyond the runs leave after the copy.
+static unsigned kvm_expand_grid(int64_t n_runs, size_t up_bytes) {
+    const int64_t by_runs = (n_runs + 3) / 4, by_bytes = (int64_t)std::min<size_t>((up_bytes / 8 + 255) / 256, 512);
+    return (unsigned)std::max<int64_t>(by_runs, std::max<int64_t>(by_bytes, 1));
+}
+
 // Hybrid ED tiling (kvm_ed_dot.hip): per run floor(count/64) full 64-candidate tiles; what is left goes to class A, to
 // class B and / or to class C by kvm_ed_remainder_classes (the class-B tile takes the first <= 32 candidates of the
 // remainder, the class-C tile the rest).
@@ -251,7 +260,7 @@ hipError_t kvm_launch_expand_tiles_hybrid(const kvm_run *runs, int64_t n_runs, i
                                           kvm_tile *tilesC, unsigned long long *counters, int32_t *run_maxk, hipStream_t s,
                                           void *up_dst, const void *up_src_pinned, size_t up_bytes) {
     if (n_runs <= 0) return up_bytes ? kvm_launch_upload(up_dst, up_src_pinned, up_bytes, s) : hipSuccess;
-    hipLaunchKernelGGL(kvm_expand_tiles_hybrid_kernel, dim3((unsigned)((n_runs + 3) / 4)), dim3(256), 0, s, runs, n_runs,
+    hipLaunchKernelGGL(kvm_expand_tiles_hybrid_kernel, dim3(kvm_expand_grid(n_runs, up_bytes)), dim3(256), 0, s, runs, n_runs,
                        hybrid, tilesA, tilesB, tilesC, counters, run_maxk, (unsigned long long *)up_dst,
                        (const unsigned long long *)up_src_pinned, (int64_t)((up_bytes + 7) / 8));
     return hipGetLastError();
@@ -377,7 +386,7 @@ hipError_t kvm_launch_expand_tiles(const kvm_run *runs, int64_t n_runs, int32_t 
                                    unsigned long long *counters, int32_t *run_maxk, hipStream_t s, const double *blockmax,
                                    double *run_hist, int32_t m, int64_t n, void *up_dst, const void *up_src_pinned, size_t up_bytes) {
     if (n_runs <= 0) return up_bytes ? kvm_launch_upload(up_dst, up_src_pinned, up_bytes, s) : hipSuccess;
-    hipLaunchKernelGGL(kvm_expand_tiles_kernel, dim3((unsigned)((n_runs + 3) / 4)), dim3(256), 0, s, runs, n_runs,
+    hipLaunchKernelGGL(kvm_expand_tiles_kernel, dim3(kvm_expand_grid(n_runs, up_bytes)), dim3(256), 0, s, runs, n_runs,
                        tile_max, tiles, counters, run_maxk, blockmax, run_hist, m, n, (unsigned long long *)up_dst,
                        (const unsigned long long *)up_src_pinned, (int64_t)((up_bytes + 7) / 8));
     return hipGetLastError();

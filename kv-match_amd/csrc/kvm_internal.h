@@ -79,6 +79,9 @@ struct kvm_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t ev_staged = nullptr;  // recorded after the last H2D copy out of h_pinned (guards its reuse)
     bool staged_pending = false;
+    hipEvent_t ev_done = nullptr;    // recorded at the very end of a kvm_verify_device call, behind everything that reads the
+    hipStream_t done_stream = nullptr;  // context's device scratch: a later call on ANOTHER stream makes that stream wait for
+    bool done_pending = false;       // it (hipStreamWaitEvent: a device-side wait, the host goes on preparing the call)
     int64_t n = 0;
     double *d_series = nullptr;
     bool own_series = false;

@@ -1,12 +1,17 @@
 """Multi-GPU host layer: one process per GPU (torch.distributed; backend "nccl" is RCCL on ROCm).
 
-The candidate set shards embarrassingly: the series is replicated on every GPU, the interval list is
-cut into `world` contiguous shards of about equal candidate count (cutting inside an interval where needed), each
-rank verifies its shard, and ONE all-gather moves the surviving (offset, distance) pairs: first the per-rank
-counts (world x int64), then one padded all-gather of a packed [max_count, 2] fp64 buffer (offset stored exactly
-as fp64; int32 fits).  The payload is tiny (16 B per answer), so the collective is latency-bound; xGMI bandwidth
-is irrelevant to it.  Every rank ends with the full answer list, sorted by (distance, offset) exactly as the
-single-GPU path sorts (K/QueryEngine.java:373).
+The candidate set shards embarrassingly: the series is replicated on every GPU and the interval list is
+dealt out to the ranks balanced by candidate count -- WHOLE intervals, interleaved (split_intervals: within every round
+of `world` consecutive intervals the longest goes to the rank that is lightest so far; contiguous slices that cut inside
+an interval only for lists of fewer than 8 intervals per rank).  Neighbouring intervals land on different GPUs (the
+expensive candidates of a DTW query cluster around the matches), and because no interval is cut a sharded cNSM run
+restarts the reference's running sums exactly where the unsharded one does: bit-identical answers.  Each rank verifies
+its shard with the answers left in HBM (kvm_verify_device), and ONE all-gather moves them: a fixed-size block of
+[count | first pack_cap (offset, distance) pairs] per rank as fp64 pairs (an int32 offset is exact in fp64); only if some
+rank holds more than pack_cap answers does a second, exact-size exchange follow (gather_answers).  The payload is tiny
+(16 B per answer), so the collective is latency-bound; xGMI bandwidth is irrelevant to it.  A rank whose shard fails takes
+part with a count of -1, so that nobody is left waiting.  Every rank ends with the full answer list, sorted by
+(distance, offset) exactly as the single-GPU path sorts (K/QueryEngine.java:373).
 """
 import numpy as np
 

@@ -77,6 +77,24 @@ def main():
         with open(os.path.join(out_dir, f"bad_shard_r{rank}.txt"), "w") as f:
             f.write(repr(outcome))
         ss.close()
+        # the same two things TOGETHER in one stream: more answers than the packed block holds (pack_cap = 2: every query
+        # takes the exact-size second exchange) and, further down the same stream, a shard that fails on one rank -- the
+        # queries in front of it come back complete on both ranks, the stream ends at the failing query on both
+        ss2 = D.ShardedStream(ctx, 0, cands + 64, in_flight=2, pack_cap=2)
+        good = [dict(valid_positions=(l, r), last_segment=1, query_data=q, variant=v_, **args[v_]) for v_ in (0, 1, 3)]
+        res = ss2.run(good)
+        for i, (offs, dists) in enumerate(res):
+            np.savez(os.path.join(out_dir, f"small_cap{i}_r{rank}.npz"), offs=offs, dists=dists, variant=good[i]["variant"])
+        outcome2 = []
+        try:
+            ss2.run(good + [dict(valid_positions=(lb, rb), last_segment=1, query_data=q, variant=0, **args[0])] + good[:1])
+            outcome2.append("no error")
+        except Exception as e:  # noqa: BLE001
+            outcome2.append(type(e).__name__)
+        outcome2.append(len(ss2.run(good[:2])))          # usable afterwards
+        with open(os.path.join(out_dir, f"small_cap_bad_shard_r{rank}.txt"), "w") as f:
+            f.write(repr(outcome2))
+        ss2.close()
     dist.barrier()
     dist.destroy_process_group()
 

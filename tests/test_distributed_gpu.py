@@ -59,6 +59,15 @@ def test_sharded_verifier_two_ranks_one_device(built, tmp_path):
     # a shard-dependent error ends the query on EVERY rank (the job above would have hung in the all-gather otherwise)
     assert (tmp_path / "bad_shard_r0.txt").read_text() == repr(["ShardFailed", "ShardFailed", 3])
     assert (tmp_path / "bad_shard_r1.txt").read_text() == repr(["KvMatchIllegalArgument", "KvMatchIllegalArgument", 3])
+    # more answers than the packed block holds (the exact-size second exchange of ShardedStream) -- and a failing shard later
+    # in the same stream
+    for i in range(3):
+        for rank in range(2):
+            z = np.load(tmp_path / f"small_cap{i}_r{rank}.npz")
+            w_off, w_dist, _ = want[int(z["variant"])]
+            assert len(w_off) > 2 and np.array_equal(z["offs"], w_off) and np.array_equal(z["dists"], w_dist), (i, rank)
+    assert (tmp_path / "small_cap_bad_shard_r0.txt").read_text() == repr(["ShardFailed", 2])
+    assert (tmp_path / "small_cap_bad_shard_r1.txt").read_text() == repr(["KvMatchIllegalArgument", 2])
 
 
 def test_bench_launched_path_two_ranks_rehearsal(built):
