@@ -3,6 +3,8 @@ intervals (configs[1..3]).  The oracle (with the reference's early abandoning) i
 against directly; on top of that, size-independent properties: the self match and every planted copy are found, the
 answers do not depend on the pruning kernel, the early-abandon switch or on how the list is sharded, and cntCandidate is
 additive over shards."""
+import os
+
 import numpy as np
 import pytest
 
@@ -155,3 +157,60 @@ def test_phase1_should_stop_is_a_pure_function(big):
         stop, last2 = kvmatch.phase1_should_stop(0, i, 0.02 * (i + 1), 4000 >> min(i, 10), 4_000_000 >> i if i < 6 else 62_500, 8192, last2)
         again.append(stop)
     assert stops == again and stops[-1] and not any(stops[:5])
+
+
+# BETA_BASE of K/experiments/NormQueryDtwSelectivityGenerate.java:38, indexed by log2(m) - 8
+BETA_BASE = (12.663, 19.651, 24.289, 44.974, 56.526)
+
+
+@pytest.mark.parametrize("variant", ["cnsm_ed", "cnsm_dtw"])
+def test_the_references_own_parameter_grid_at_full_size(big, variant):
+    """The grid the reference's experiment driver sweeps (K/experiments/NormQueryDtwSelectivityGenerate.java:38,63-93):
+    alpha in {1.1, 1.5, 2.0} x beta = BETA_BASE[log2(m) - 8] * {0.5, 1, 5, 10} x eps in {1, 10}, ten seeded query offsets per
+    setting -- cNSM-ED and cNSM-DTW at m = 4096 (rho = floor(0.05 m) = 204; the table has five entries, so m = 4096 is its
+    last) over the n = 1e8 series, the reference's early abandoning on.  Every query: answers (offsets, order, every bit of
+    every distance), cntCandidate and the stage counters equal the oracle's.  The oracle runs on the host's cores in
+    parallel (ctypes releases the interpreter lock); the list is 1e5 candidates per query so that 240 oracle runs fit a test."""
+    import concurrent.futures as cf
+    kvmatch, datagen, series, ctx, q8, qoff8, planted = big
+    m, rho = 4096, 204
+    beta_base = BETA_BASE[int(np.log2(m)) - 8]
+    rng = np.random.default_rng(20241004)
+    settings = [(eps, alpha, beta_base * f) for eps in (1.0, 10.0) for alpha in (1.1, 1.5, 2.0) for f in (0.5, 1.0, 5.0, 10.0)]
+    jobs = []
+    for si, (eps, alpha, beta) in enumerate(settings):
+        for t in range(10):
+            qo = int(rng.integers(1, N - m))
+            if variant == "cnsm_dtw":   # (the reference can only run queries its Arrays.sort accepts: conftest.sortable_query)
+                from conftest import sortable_query
+                qo = sortable_query(series, m, qo, step=100_003)   # (hop over whole noise segments, where that sort throws throughout)
+            jobs.append((si, t, qo, eps, alpha, beta))
+    lists = [datagen.gen_intervals(N, m, 100_000, 64.0, must_cover=[j[2] for j in jobs[k::4]], seed=40 + k) for k in range(4)]
+
+    def cpu(job):
+        si, t, qo, eps, alpha, beta = job
+        L, R = lists[(si * 10 + t) % 4]
+        q = series[qo - 1: qo - 1 + m]
+        return (oracle.cnsm_ed(series, q, L, R, 0, eps, alpha, beta) if variant == "cnsm_ed"
+                else oracle.cnsm_dtw(series, q, L, R, 0, eps, rho, alpha, beta))
+
+    with cf.ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as pool:
+        wants = list(pool.map(cpu, jobs))
+    eng = kvmatch.NormQueryEngine(ctx) if variant == "cnsm_ed" else kvmatch.NormQueryEngineDtw(ctx)
+    n_answers = 0
+    for job, want in zip(jobs, wants):
+        si, t, qo, eps, alpha, beta = job
+        L, R = lists[(si * 10 + t) % 4]
+        q = series[qo - 1: qo - 1 + m].copy()
+        got = eng.verify((L, R), 1, q, eps, alpha, beta) if variant == "cnsm_ed" else eng.verify((L, R), 1, q, eps, rho, alpha, beta)
+        st = want[2]
+        assert same(got, want), job
+        assert got.cnt_candidate == st["cnt_candidate"] and got.stats[0] == st["windows"] and got.stats[1] == st["pass_filter"], job
+        if variant == "cnsm_dtw":
+            # the screens in front of the exact stage may keep what the reference drops (never the reverse); the exact stage
+            # decides with the reference's own values, so the DPs it starts are the reference's dtw() calls
+            assert got.stats[2] >= st["pass_kim"] and got.stats[3] >= st["pass_keogh"], (job, got.stats, st)
+            assert got.stats[4] == st["pass_keogh2"], (job, got.stats, st)
+        assert qo in set(want[0].tolist()), job      # the self match (K/experiments/NormQueryTestGroupBySelectivity.java:101-103)
+        n_answers += len(got)
+    assert n_answers >= len(jobs)
