@@ -66,8 +66,8 @@ def parse():
     ap.add_argument("--ed-kernel", type=int, default=0)
     ap.add_argument("--queries-per-step", type=int, default=0,
                     help="phase-2 passes (queries of the stream) per step; 0 = per-workload default")
-    ap.add_argument("--in-flight", type=int, default=5,
-                    help="queries in flight per GPU (contexts over one resident series, one host thread each)")
+    ap.add_argument("--in-flight", type=int, default=8,
+                    help="queries in flight per GPU (contexts over one resident series, one host thread each); 8 since round 4: with native host threads the latency-bound streams keep gaining up to there, the headline is flat from 5 on (profiles/r04_bench_if{5,8}.json)")
     ap.add_argument("--python-threads", type=int, default=0,
                     help="1: drive the in-flight contexts from Python threads (rounds 1-3) instead of the library's native "
                          "per-context host threads (kvm_run_jobs); the interpreter lock then bounds latency-bound streams")
@@ -500,6 +500,42 @@ def main():
             r_ = engines[i].verify(shards[j % NL], 1, queries[j], a.epsilon, *pos_)
             if rep >= 2:
                 excl_ns.append({"plan": i, "ns": int(lib.kvm_last_kernel_ns(h)), "stats": list(r_.stats)})
+    # The LIST's own bound for the RSM-ED pruner: a tile streams its whole window whatever its width, so a
+    # list of short intervals cannot run at the rate of full tiles.  Per tile of c candidates:
+    #     max( 2 m c / R_A ,  8 (m + c - 1) / B )
+    # with R_A = the FMA rate this kernel reaches on the same number of candidates in FULL 64-candidate tiles, isolated
+    # and spread over the series like the list's own intervals (measured here, same clocks), and B = 6.3 TB/s of window
+    # bytes; summed over the tiles the plan cuts the list into (64-candidate tiles + one remainder per interval).
+    list_bound = None
+    if rank == 0 and world == 1 and wl == "rsm_ed":
+        try:
+            l0, r0 = shards[0]
+            lens = (r0.astype(np.int64) - l0 + 1)
+            tiles_c = np.concatenate([np.full(int((lens // 64).sum()), 64, dtype=np.int64), (lens % 64)[(lens % 64) > 0]])
+            n_full = max(1, my_cands // 64)
+            stride = max(64, (n - m - 64) // n_full)   # (spread over the whole series, like the list's own intervals)
+            fl = (1 + np.arange(n_full, dtype=np.int64) * stride).astype(np.int32)
+            fr = (fl + 63).astype(np.int32)
+            ns_a = []
+            for rep in range(6):
+                engines[0].verify((fl, fr), 1, queries[rep % NQ], a.epsilon)
+                if rep >= 2:
+                    ns_a.append(int(lib.kvm_last_kernel_ns(h)))
+            t_a = float(np.mean(ns_a)) * 1e-9
+            rate_a = 2.0 * m * 64 * n_full / t_a
+            bw = 6.3e12
+            per_tile = np.maximum(2.0 * m * tiles_c / rate_a, 8.0 * (m + tiles_c - 1) / bw)
+            list_bound = {"list_bound_ms": float(per_tile.sum()) * 1e3, "full_tiles_kernel_ms": t_a * 1e3,
+                          "full_tiles_tflops": rate_a / 1e12, "full_tiles_frac_of_peak": rate_a / 1e12 / FP64_VALU_PEAK_TFLOPS,
+                          "tiles": int(len(tiles_c)), "tiles_full": int((tiles_c == 64).sum()),
+                          "tiles_33_63": int(((tiles_c > 32) & (tiles_c < 64)).sum()), "tiles_17_32": int(((tiles_c > 16) & (tiles_c <= 32)).sum()),
+                          "tiles_1_16": int((tiles_c <= 16).sum()), "window_bytes": float(8.0 * (m + tiles_c - 1).sum()),
+                          "bandwidth_assumed_gbs": bw / 1e9,
+                          "note": "sum over the list's tiles of max(FMA time at the rate of full isolated tiles measured in this run, "
+                                  "window bytes / 6.3 TB/s): what this kernel's tiling can reach on THIS list; kernel_ms / list_bound_ms "
+                                  "is the part the tile mix (classes B / C, partly filled class-A tiles) costs beyond it"}
+        except Exception as e:  # noqa: BLE001
+            list_bound = {"error": repr(e)}
     ctx.set_option(kvmatch.OPT_TIMING, 0)
 
     # ---- same workload with the reference's early abandoning on (reported, not the headline) -------------
@@ -570,6 +606,10 @@ def main():
             rates = {"error": repr(e)}
     out["device_rates_measured"] = rates
     out["roofline"] = roofline_block(wl, plans, excl_ns, m, rates if "error" not in rates else None)
+    if list_bound:
+        out["roofline"].update(list_bound)
+        if "list_bound_ms" in list_bound and out["roofline"].get("kernel_ms"):
+            out["roofline"]["frac_of_list_bound"] = list_bound["list_bound_ms"] / out["roofline"]["kernel_ms"]
     out["roofline"]["kernel_ms_note"] = ("HIP events on the kernel's own stream (RSM-ED every point: the start / stop stamps of the "
                                          "dispatch itself, hipExtLaunchKernelGGL), measured in this run right after the "
                                          f"timed region with ONE query in flight, averaged over the {NQ} queries and their "

@@ -6,6 +6,8 @@
 #include <vector>
 typedef double d4 __attribute__((ext_vector_type(4)));
 
+// MODE 3 (round 4): do the matrix pipe and the vector pipe add up?  Waves 0 and 2 of every workgroup run
+// the MFMA loop, waves 1 and 3 the v_fma_f64 loop: with 4 workgroup-waves per SIMD every SIMD holds two of each kind.
 template <int MODE>  // 0: MFMA from registers, 1: MFMA with operands from LDS, 2: vector FMA (16 per step, 8 accumulators x2)
 __global__ __launch_bounds__(256) void rate_kernel(double *out, int iters) {
     __shared__ double lds[4096];
@@ -17,8 +19,9 @@ __global__ __launch_bounds__(256) void rate_kernel(double *out, int iters) {
     double v[16];
     for (int k = 0; k < 16; k++) v[k] = k * 1e-3;
     const double *p = lds + (threadIdx.x >> 6) * 1024 + lane;
+    const bool mfma_wave = MODE == 3 && (((threadIdx.x >> 6) & 1) == 0);
     for (int it = 0; it < iters; it++) {
-        if (MODE == 0) {
+        if (MODE == 0 || (MODE == 3 && mfma_wave)) {
             acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(b, a, acc1, 0, 0, 0);
             acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, a, acc2, 0, 0, 0);
@@ -58,9 +61,11 @@ static void run(const char *name, int blocks_per_cu, int num_cu) {
     hipEventSynchronize(e1);
     float ms = 0;
     hipEventElapsedTime(&ms, e0, e1);
-    // per iteration per wave: MODE 0/1: 4 MFMA x 2048 flop; MODE 2: 64 FMA instr x 64 lanes x 2 flop
-    const double flop = (double)blocks * 4 * iters * (MODE == 2 ? 64.0 * 64 * 2 : 4.0 * 2048);
-    printf("%-28s %d waves/SIMD: %8.3f ms  %7.2f TFLOP/s\n", name, blocks_per_cu, ms, flop / ms / 1e9);
+    // per iteration per wave: MODE 0/1: 4 MFMA x 2048 flop; MODE 2: 64 FMA instr x 64 lanes x 2 flop; MODE 3: half the waves each
+    const double flop = (double)blocks * 4 * iters * (MODE == 2 ? 64.0 * 64 * 2 : MODE == 3 ? 0.5 * (64.0 * 64 * 2 + 4.0 * 2048) : 4.0 * 2048);
+    printf("%-28s %d waves/SIMD: %8.3f ms  %7.2f TFLOP/s", name, blocks_per_cu, ms, flop / ms / 1e9);
+    if (MODE == 3) printf("  (vector part %.2f + matrix part %.2f)", (double)blocks * 2 * iters * 64.0 * 64 * 2 / ms / 1e9, (double)blocks * 2 * iters * 4.0 * 2048 / ms / 1e9);
+    printf("\n");
     hipFree(out);
 }
 
@@ -73,6 +78,7 @@ int main() {
         run<0>("mfma_f64 16x16x4 (regs)", w, cu);
         run<1>("mfma_f64 16x16x4 (LDS fed)", w, cu);
         run<2>("v_fma_f64", w, cu);
+        if (w >= 2) run<3>("half mfma_f64 + half v_fma", w, cu);
     }
     return 0;
 }
