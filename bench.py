@@ -142,7 +142,7 @@ def roofline_block(wl, plans, launches, m, rates=None):
         ach = ops / ks / 1e12 if ks > 0 else 0.0
         return {"bound": "fp64_valu", "achieved": ach, "peak": FP64_VALU_PEAK_TOPS_NOFMA, "unit": "TFLOP/s",
                 "frac": ach / FP64_VALU_PEAK_TOPS_NOFMA, "traffic": None,
-                "kernel": "kvm_dtw_dp_pack_kernel (banded DP, two candidates per wave; lists of <= 3072 DPs: kvm_dtw_dp_reg_kernel) -- "
+                "kernel": "kvm_dtw_dp_reg_kernel (banded DP; rho >= 256 and lists of more than 32 768 DPs: kvm_dtw_dp_pack_kernel) -- "
                           "early abandon off: every candidate that reaches it runs all cells",
                 **({"fp64_nofma_sustained_tops": rates.get("fp64_cellmix_tops"), "fp64_nofma_sustained_source":
                     "measured by this run (kvm_measure_device 2: the DP's cell mix sub/mul/min/min/add, register-only, 4 waves per SIMD)"}
@@ -716,7 +716,7 @@ def main():
                 ach2 = r_.stats[4] * cells2 * 5.0 / ks2 / 1e12
                 out["roofline_dtw"] = {"bound": "fp64_valu", "achieved": ach2, "peak": FP64_VALU_PEAK_TOPS_NOFMA, "unit": "TFLOP/s",
                                        "frac": ach2 / FP64_VALU_PEAK_TOPS_NOFMA, "traffic": None,
-                                       "kernel": "kvm_dtw_dp_pack_kernel<32,7,1> (banded DP with the reference's row test, two candidates per wave)",
+                                       "kernel": "kvm_dtw_dp_reg_kernel<4,0> (banded DP with the reference's row test; lists of more than 32 768 DPs: kvm_dtw_dp_pack_kernel<32,7,1>, two candidates per wave)",
                                        "kernel_ms": ks2 * 1e3, "dp_candidates_per_launch": r_.stats[4], "cells_per_candidate": cells2,
                                        "cells_per_s": r_.stats[4] * cells2 / ks2,
                                        "workload": "cNSM-DTW m=4096 rho=204, 1e6 candidates, eps=10 alpha=2 beta=10 (BASELINE configs[3])",
@@ -756,10 +756,21 @@ def main():
             kns = lib.kvm_last_kernel_ns(h)
             ex["dtw_dp_kernel_cells_per_s"] = r_.stats[0] * cells2 / (kns * 1e-9) if kns else None
             if kns:
-                out.setdefault("roofline_dtw", {})["full_dp"] = {
-                    "achieved": r_.stats[0] * cells2 * 5.0 / (kns * 1e-9) / 1e12, "frac": r_.stats[0] * cells2 * 5.0 / (kns * 1e-9) / 1e12 / FP64_VALU_PEAK_TOPS_NOFMA,
-                    "kernel_ms": kns * 1e-6, "dp_candidates_per_launch": r_.stats[0],
-                    "note": "cascade and early abandoning off on a slice of the list: every candidate runs ALL its cells (executed = algorithmic)"}
+                fd = {"achieved": r_.stats[0] * cells2 * 5.0 / (kns * 1e-9) / 1e12, "frac": r_.stats[0] * cells2 * 5.0 / (kns * 1e-9) / 1e12 / FP64_VALU_PEAK_TOPS_NOFMA,
+                      "kernel_ms": kns * 1e-6, "dp_candidates_per_launch": r_.stats[0],
+                      "note": "cascade and early abandoning off on a slice of the list: every candidate runs ALL its cells (executed = algorithmic); "
+                              "KVM_OPT_DP_KERNEL auto; by_form: the same slice through each register form (2 = one candidate per wave, "
+                              "3 = two per wave)"}
+                by_form = {}
+                for form in (2, 3):
+                    ctx.set_option(kvmatch.OPT_DP_KERNEL, form)
+                    g3()
+                    g3()
+                    k2 = lib.kvm_last_kernel_ns(h)
+                    by_form[str(form)] = {"kernel_ms": k2 * 1e-6, "frac": r_.stats[0] * cells2 * 5.0 / (k2 * 1e-9) / 1e12 / FP64_VALU_PEAK_TOPS_NOFMA if k2 else None}
+                ctx.set_option(kvmatch.OPT_DP_KERNEL, 0)
+                fd["by_form"] = by_form
+                out.setdefault("roofline_dtw", {})["full_dp"] = fd
             ctx.set_option(kvmatch.OPT_TIMING, 0)
             ctx.set_option(kvmatch.OPT_LB_CASCADE, 1)
             ctx.set_option(kvmatch.OPT_EARLY_ABANDON, 1)

@@ -270,6 +270,8 @@ __device__ __forceinline__ void dp_pack_sweep(const double *__restrict__ series,
     // pop the work queue (wave-uniform; every entry of the list is a candidate that runs; the bound on `pops` is a guard)
     auto fetch = [&](pw_half &T) -> bool {
         if (drained || pops++ > n_in) { drained = true; return false; }
+        // (a look before the pop, see dp_reg_sweep: a drained queue is not worth an atomic per wave)
+        if (__hip_atomic_load(&counters[KVM_CNT_QUEUE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= n_in) { drained = true; return false; }
         unsigned long long popped = 0;
         if (lane == 0) popped = atomicAdd(&counters[KVM_CNT_QUEUE], 1ULL);
         const unsigned long long pos = kvm_uniform_u64(popped);

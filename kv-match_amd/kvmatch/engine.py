@@ -436,6 +436,13 @@ class QueryStream:
         self.ctxs = self.ctxs[:1]
 
 
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
 class Job:
     """One phase-2 call as data, for QueryStream.run_jobs: the arguments of the engine's verify() -- `variant` 0 QueryEngine,
     1 NormQueryEngine, 2 QueryEngineDtw, 3 NormQueryEngineDtw; rho an int (points) or a float (the REPL's fraction rule)."""
@@ -450,12 +457,6 @@ class Job:
         self.epsilon = float(epsilon)
         self.rho = resolve_rho(rho, self.q.size) if self.variant >= 2 else 0
         self.alpha, self.beta = float(alpha), float(beta)
-
-    def __enter__(self):
-        return self
-
-    def __exit__(self, *exc):
-        self.close()
 
 
 class _EngineBase:

@@ -10,7 +10,7 @@ forms = [int(a) for a in sys.argv[1:]] or [0]
 series = datagen.gen_series(n, seed=0x4B564D31)
 qoff = n // 3 + 17
 q = series[qoff - 1: qoff - 1 + m].copy()
-L, R = datagen.gen_intervals(n, m, 1_000_000, 64.0, must_cover=[qoff], seed=2)
+L, R = datagen.gen_intervals(n, m, int(float(os.environ.get("DP_CANDIDATES", "1e6"))), 64.0, must_cover=[qoff], seed=2)
 ctx = kvmatch.Phase2Context(0); ctx.load_series(series)
 ctx.set_option(kvmatch.OPT_TIMING, 1)
 eng = kvmatch.NormQueryEngineDtw(ctx)
@@ -21,7 +21,7 @@ for ab in (0, 1):
     ctx.set_option(kvmatch.OPT_EARLY_ABANDON, ab)
     for form in forms:
         ctx.set_option(kvmatch.OPT_DP_KERNEL, form)
-        for i in range(4):
+        for i in range(5):
             t = time.perf_counter(); a = eng.verify((L, R), 1, q, 10.0, 0.05, 2.0, 10.0); dt = time.perf_counter() - t
             ns = ctx._lib.kvm_last_kernel_ns(ctx._h)
             key = (a.offsets.tobytes(), a.distances.tobytes())

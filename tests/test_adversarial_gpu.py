@@ -10,10 +10,12 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.strict_sort
-def test_adversarial_inputs_all_variants(built):
+@pytest.mark.parametrize("dp_form", [0, 3])   # 3: every DTW list through the packed register form of the DP
+def test_adversarial_inputs_all_variants(built, dp_form):
     import kvmatch
     from kvmatch import datagen
     ctx = kvmatch.Phase2Context(0)
+    ctx.set_option(kvmatch.OPT_DP_KERNEL, dp_form)
     lines = []
     total, bad, ties = adversarial.run(kvmatch, datagen, oracle, ctx, rounds=1, seed=11, log=lines.append)
     ctx.close()

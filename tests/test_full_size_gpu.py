@@ -82,8 +82,11 @@ def test_dtw_config_4(big):
     q = series[qoff - 1: qoff - 1 + m].copy()
     L, R = datagen.gen_intervals(N, m, 100_000, 64.0, must_cover=[qoff, planted[1]], seed=2)
     want = oracle.cnsm_dtw(series, q, L, R, 0, 3.0, rho, 2.0, 10.0)
-    got = kvmatch.NormQueryEngineDtw(ctx).verify((L, R), 1, q, 3.0, 0.05, 2.0, 10.0)
-    assert same(got, want) and got.cnt_candidate == want[2]["cnt_candidate"]
+    for dp_form in (0, 3, 2):                                              # (3: two candidates per wave, 2: one; 0 picks by list length)
+        ctx.set_option(kvmatch.OPT_DP_KERNEL, dp_form)
+        got = kvmatch.NormQueryEngineDtw(ctx).verify((L, R), 1, q, 3.0, 0.05, 2.0, 10.0)
+        assert same(got, want) and got.cnt_candidate == want[2]["cnt_candidate"], dp_form
+    ctx.set_option(kvmatch.OPT_DP_KERNEL, 0)
     assert qoff in set(want[0].tolist()) and want[1][0] == 0.0
     ctx.set_option(kvmatch.OPT_LB_CASCADE, 0)                              # the cascade is only an optimisation
     got = kvmatch.NormQueryEngineDtw(ctx).verify((L[:200], R[:200]), 1, q, 3.0, 0.05, 2.0, 10.0)

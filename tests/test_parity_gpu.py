@@ -77,11 +77,23 @@ def test_cnsm_ed(world, m, eps, alpha, beta):
     assert planted.qoff in got.offsets.tolist() and len(got) >= 2
 
 
-# rho picks the DP kernel form: register band with V = 1 (rho <= 63), 2, 4, 8 (<= 511) cells per lane, LDS form above
+# rho picks the DP kernel form: one candidate per wave with V = 1 (rho <= 63), 2, 4, 8 (<= 511) cells per lane, LDS form above;
+# packed form (dp_form 3, or auto on long lists): 32 lanes x V = 3 .. 8 for rho = 64 .. 255, 64 lanes x V = 5 .. 7 for 256 .. 447
 @pytest.mark.parametrize("m,eps,rho", [(64, 2.0, 3), (256, 4.0, 0.05), (512, 6.0, 25), (300, 5.0, 0), (129, 3.0, 200),
                                        (257, 4.0, 127), (1000, 8.0, 100), (1031, 8.0, 77), (1500, 10.0, 300),
-                                       (1200, 9.0, 511), (1200, 9.0, 600), (100, 3.0, 63), (100, 3.0, 64)])
-def test_rsm_dtw(world, m, eps, rho):
+                                       (1200, 9.0, 511), (1200, 9.0, 600), (100, 3.0, 63), (100, 3.0, 64),
+                                       (2048, 10.0, 0.05), (2300, 10.0, 255), (2300, 10.0, 256), (2600, 10.0, 447), (2600, 10.0, 448)])
+@pytest.mark.parametrize("dp_form", [0, 3])   # 3: the packed register form for every list length (auto keeps short lists off it)
+def test_rsm_dtw(world, m, eps, rho, dp_form):
+    kvmatch = world[0]
+    world[3].set_option(kvmatch.OPT_DP_KERNEL, dp_form)
+    try:
+        _rsm_dtw(world, m, eps, rho)
+    finally:
+        world[3].set_option(kvmatch.OPT_DP_KERNEL, 0)
+
+
+def _rsm_dtw(world, m, eps, rho):
     kvmatch = world[0]
     s, q, L, R = planted(world, m)
     loose = oracle.resolve_rho(rho, m) >= m
@@ -190,10 +202,15 @@ def test_dtw_engines_die_where_the_reference_does(world):
 
 @pytest.mark.parametrize("m,eps,rho,alpha,beta", [(128, 3.0, 6, 1.5, 2.0), (512, 6.0, 0.05, 1.3, 1.5),
                                                   (1024, 8.0, 51, 2.0, 10.0)])
-def test_cnsm_dtw(world, m, eps, rho, alpha, beta):
+@pytest.mark.parametrize("dp_form", [0, 3])
+def test_cnsm_dtw(world, m, eps, rho, alpha, beta, dp_form):
     kvmatch = world[0]
     s, q, L, R = planted(world, m)
-    got = kvmatch.NormQueryEngineDtw(world[3]).verify((L, R), 1, q, eps, rho, alpha, beta)
+    world[3].set_option(kvmatch.OPT_DP_KERNEL, dp_form)
+    try:
+        got = kvmatch.NormQueryEngineDtw(world[3]).verify((L, R), 1, q, eps, rho, alpha, beta)
+    finally:
+        world[3].set_option(kvmatch.OPT_DP_KERNEL, 0)
     want = oracle.cnsm_dtw(s, q, L, R, 0, eps, oracle.resolve_rho(rho, m), alpha, beta)
     compare(got, want, tag=f"cnsm_dtw m={m}")
     assert got.stats[1] == want[2]["pass_filter"]
