@@ -208,12 +208,18 @@ __device__ __forceinline__ int dp_row_test_hi(bool valid, unsigned hi, double cb
     return (Bf > E + tol) ? 1 : 2;
 }
 
-// The packed register form (kvm_dtw_pair.hip) for band half-width rho: lanes per candidate L (32: two candidates per wave,
-// rho = 64 .. 255; 64: one candidate, rho = 256 .. 447, where an odd V fills the lanes better than dp_reg_sweep's V = 8) and
-// cells per lane V = ceil((rho + 1) / L); L = 0: it has none (rho < 64: two cells per lane amortise the per-lane
-// instructions no better than dp_reg_sweep's one -- m = 1024, rho = 51: 1.69 against 1.64 ms for 32 768 DPs,
-// profiles/r04_dp_bench_m.log; rho >= 448: V = 8 on 64 lanes is dp_reg_sweep's own shape).
-__host__ __device__ static inline int dp_pack_l(int rho) { return rho < 64 ? 0 : (rho <= 255 ? 32 : (rho <= 447 ? 64 : 0)); }
+// The packed register form (kvm_dtw_pair.hip) for band half-width rho: lanes per candidate L and cells per lane
+// V = ceil((rho + 1) / L); L = 0: it has none.
+//   rho = 128 .. 191, 256 .. 447   L = 64 (one candidate per wave): V = 3, 5, 6, 7 fills the lanes better than dp_reg_sweep's
+//                                  next power of two (rho = 150: 151 of 192 slots instead of 151 of 256);
+//   rho = 64 .. 127, 192 .. 255    L = 32 (two candidates per wave, long lists only: dp_pack_share);
+//   rho < 64                       none: two cells per lane amortise the per-lane instructions no better than dp_reg_sweep's
+//                                  one (m = 1024, rho = 51: 1.69 against 1.64 ms for 32 768 DPs, profiles/r04_dp_bench_m.log);
+//   rho >= 448                     none: V = 8 on 64 lanes is dp_reg_sweep's own shape.
+__host__ __device__ static inline int dp_pack_l(int rho) {
+    if (rho < 64 || rho > 447) return 0;
+    return (rho >= 256 || (rho >= 128 && rho <= 191)) ? 64 : 32;
+}
 __host__ __device__ static inline int dp_pack_v(int rho) {
     const int l = dp_pack_l(rho);
     return l ? (rho + l) / l : 0;

@@ -565,7 +565,7 @@ hipError_t kvm_launch_dtw_dp_pack(const double *series, const kvm_query_dev &qd,
 #define KVM_PACK_W(VV) \
     case VV: return launch_pack<64, VV>(series, qd, ax, in, plans, list, share_mode, max_in, out_off, out_dist, cap, counters, num_cu, s);
     if (dp_pack_l(qd.rho) == 64) {
-        switch (dp_pack_v(qd.rho)) { KVM_PACK_W(5) KVM_PACK_W(6) KVM_PACK_W(7) }
+        switch (dp_pack_v(qd.rho)) { KVM_PACK_W(3) KVM_PACK_W(5) KVM_PACK_W(6) KVM_PACK_W(7) }
     }
 #undef KVM_PACK_W
 #endif

@@ -82,7 +82,7 @@ def test_cnsm_ed(world, m, eps, alpha, beta):
 @pytest.mark.parametrize("m,eps,rho", [(64, 2.0, 3), (256, 4.0, 0.05), (512, 6.0, 25), (300, 5.0, 0), (129, 3.0, 200),
                                        (257, 4.0, 127), (1000, 8.0, 100), (1031, 8.0, 77), (1500, 10.0, 300),
                                        (1200, 9.0, 511), (1200, 9.0, 600), (100, 3.0, 63), (100, 3.0, 64),
-                                       (2048, 10.0, 0.05), (2300, 10.0, 255), (2300, 10.0, 256), (2600, 10.0, 447), (2600, 10.0, 448)])
+                                       (2048, 10.0, 0.05), (2300, 10.0, 127), (2300, 10.0, 128), (3000, 12.0, 0.05), (2300, 10.0, 191), (2300, 10.0, 192), (2300, 10.0, 255), (2300, 10.0, 256), (2600, 10.0, 447), (2600, 10.0, 448)])
 @pytest.mark.parametrize("dp_form", [0, 3])   # 3: the packed register form for every list length (auto keeps short lists off it)
 def test_rsm_dtw(world, m, eps, rho, dp_form):
     kvmatch = world[0]
