@@ -200,6 +200,12 @@ void kvm_index_file_free(kvm_index_file *f);
  * larger); tests/test_full_size_gpu.py::test_phase2_time_model_against_measured_calls holds the estimate to measured calls.
  * `variant`: 0 rsm_ed, 1 cnsm_ed, 2 rsm_dtw, 3 cnsm_dtw.  Pure function; < 0 for an unknown variant. */
 double kvm_phase2_time_estimate_ms(int32_t variant, int64_t disjoint_windows, int64_t candidate_offsets, int32_t length);
+/* The same with the number of candidates that reach the banded DP (KVM_STAT_PASS_LB_KEOGH2 of an earlier call on the same
+ * list, or a caller's own bound): the DTW engines' time follows it -- 3 or 700 DPs for the same number of offsets -- and
+ * no a-priori model can know it.  dp_count < 0 or an ED variant: identical to kvm_phase2_time_estimate_ms.  num_cu: compute
+ * units of the device (0 = 256, one MI355X). */
+double kvm_phase2_time_estimate_dp_ms(int32_t variant, int64_t disjoint_windows, int64_t candidate_offsets, int32_t length,
+                                      int64_t dp_count, int32_t num_cu);
 /* The early-termination test itself, deterministic (K/QueryEngine.java:316-327: `if (i >= 5 && totalTimeUsageEstimated >
  * lastTotalTimeUsageEstimated) break; lastTotalTimeUsageEstimated = totalTimeUsageEstimated;`).  The reference adds the
  * WALL-CLOCK time of phase 1 so far to its phase-2 estimate, so `lastSegment` -- and with it the candidate list -- differs

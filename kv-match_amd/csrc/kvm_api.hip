@@ -539,6 +539,25 @@ extern "C" double kvm_phase2_time_estimate_ms(int32_t variant, int64_t disjoint_
            (K[variant][2] * m + K[variant][4]) * ((double)candidate_offsets / 1e5) + K[variant][3] * floor_units;
 }
 
+// The same estimate when the number of candidates that reach the banded DP is known (the library knows it 0.1 ms into a DTW
+// call, behind the screens; KVM_STAT_PASS_LB_KEOGH2 of a finished call): the D term above stands for ONE DP -- the lone wave of
+// a selective query -- and the DPs of a call run in rounds of the resident waves (three per SIMD: 12 per CU), a last round of
+// <= 4 / <= 8 per CU at 0.46 / 0.65 of a full one (kvm_dtw_dp.h).  `dp_count` < 0, or an ED variant: the a-priori form.  With
+// the reference's early abandoning the DPs of a long list end early, so for such lists this is an upper bound.
+extern "C" double kvm_phase2_time_estimate_dp_ms(int32_t variant, int64_t disjoint_windows, int64_t candidate_offsets, int32_t length,
+                                                 int64_t dp_count, int32_t num_cu) {
+    const double base = kvm_phase2_time_estimate_ms(variant, disjoint_windows, candidate_offsets, length);
+    if (base < 0 || variant < 2 || dp_count < 0) return base;
+    static const double K[4][5] = {
+#include "kvm_cost_model.inc"
+    };
+    const double m = (double)length, one_dp = K[variant][3] * m * m / 1e3;
+    const int64_t round = 12LL * (num_cu > 0 ? num_cu : 256), tail = dp_count % round;
+    double units = (double)(dp_count / round) / 0.46;   // full rounds, in units of a lone DP
+    if (tail) units += 3 * tail <= round ? 1.0 : (3 * tail <= 2 * round ? 0.65 / 0.46 : 1.0 / 0.46);
+    return base - one_dp + one_dp * units;   // (no DP at all: the call is its chain and its screens)
+}
+
 // The phase-1 early-termination test of the four engines (K/QueryEngine.java:316-327: `i >= 5 && totalTimeUsageEstimated >
 // lastTotalTimeUsageEstimated`), deterministic: the caller supplies its phase-1 cost so far from a model of its own (index rows
 // scanned x a constant, say) instead of reading the wall clock, the phase-2 term is the estimate above.

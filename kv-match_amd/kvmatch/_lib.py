@@ -33,7 +33,7 @@ SYMBOLS = [
     "kvm_index_rows_build", "kvm_index_rows_count", "kvm_index_rows_keys", "kvm_index_rows_first", "kvm_index_rows_last",
     "kvm_index_rows_free", "kvm_index_rows_build_grouped", "kvm_index_rows_groups", "kvm_index_rows_group_keys",
     "kvm_index_rows_group_offsets", "kvm_index_build", "kvm_index_file_size", "kvm_index_file_bytes", "kvm_index_file_info",
-    "kvm_index_file_write", "kvm_index_file_free", "kvm_phase2_time_estimate_ms", "kvm_phase1_should_stop",
+    "kvm_index_file_write", "kvm_index_file_free", "kvm_phase2_time_estimate_ms", "kvm_phase2_time_estimate_dp_ms", "kvm_phase1_should_stop",
     "kvm_verify_rsm_ed", "kvm_verify_cnsm_ed", "kvm_verify_rsm_dtw", "kvm_verify_cnsm_dtw", "kvm_resolve_rho",
     "kvm_cnsm_dtw_order", "kvm_sort_and_merge_intervals", "kvm_run_jobs",
     "kvm_result_count", "kvm_result_candidates", "kvm_result_elapsed_ms", "kvm_result_offsets",
@@ -120,6 +120,7 @@ def load():
         "kvm_index_file_write": (C.c_int, [vp, C.c_char_p]),
         "kvm_index_file_free": (None, [vp]),
         "kvm_phase2_time_estimate_ms": (f64, [i32, i64, i64, i32]),
+        "kvm_phase2_time_estimate_dp_ms": (f64, [i32, i64, i64, i32, i64, i32]),
         "kvm_phase1_should_stop": (i32, [i32, i32, f64, i64, i64, i32, C.POINTER(f64)]),
         "kvm_verify_rsm_ed": (C.c_int, [vp, vp, i32, vp, vp, i32, i32, f64, C.POINTER(vp)]),
         "kvm_verify_cnsm_ed": (C.c_int, [vp, vp, i32, vp, vp, i32, i32, f64, f64, f64, C.POINTER(vp)]),

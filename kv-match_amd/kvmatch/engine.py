@@ -128,6 +128,13 @@ def phase2_time_estimate_ms(variant, disjoint_windows, candidate_offsets, length
     return float(_lib.load().kvm_phase2_time_estimate_ms(int(variant), int(disjoint_windows), int(candidate_offsets), int(length)))
 
 
+def phase2_time_estimate_dp_ms(variant, disjoint_windows, candidate_offsets, length, dp_count, num_cu=0):
+    """phase2_time_estimate_ms with the number of candidates that reach the banded DP (Answers.stats[STAT_PASS_LB_KEOGH2] of
+    a call on the same list): what the DTW engines' time actually follows."""
+    return float(_lib.load().kvm_phase2_time_estimate_dp_ms(int(variant), int(disjoint_windows), int(candidate_offsets), int(length),
+                                                            int(dp_count), int(num_cu)))
+
+
 def phase1_should_stop(variant, segment_index, phase1_ms_so_far, disjoint_windows, candidate_offsets, length, last_total_ms):
     """The early-termination test of the phase-1 loop (K/QueryEngine.java:316-327) with a caller-supplied, deterministic
     phase-1 cost instead of the reference's wall clock.  Returns ``(stop, last_total_ms)``: carry the second value into the
