@@ -15,7 +15,7 @@
 struct plan_sums {
     long long nr, ta, tb, tc, w;
 };
-static_assert(sizeof(plan_sums) == KVM_PLAN_SUMS_BYTES, "kvm_api.hip sizes the block-total scratch of kvm_launch_plan_runs with it");
+static_assert(sizeof(plan_sums) == KVM_PLAN_SUMS_BYTES, "kvm_verify.hip sizes the block-total scratch of kvm_launch_plan_runs with it");
 __device__ __forceinline__ plan_sums plan_add(plan_sums a, plan_sums b) {
     return plan_sums{a.nr + b.nr, a.ta + b.ta, a.tb + b.tb, a.tc + b.tc, a.w + b.w};
 }

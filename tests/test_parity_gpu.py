@@ -1260,7 +1260,7 @@ def test_ed_pruner_every_window_split_and_awkward_window_lengths(world):
 
 def test_ed_pruner_class_c_on_a_long_list_of_short_runs(built):
     """Class-C tiles (remainders of 1..16 candidates, two per row) are only used when the list needs more than one round of
-    the chip's wave slots (kvm_api.hip: hybrid_mode): 90 000 runs of 1..48 candidates, early abandoning off -> several
+    the chip's wave slots (kvm_verify.hip: hybrid_mode): 90 000 runs of 1..48 candidates, early abandoning off -> several
     thousand units of each class, with planted copies of the query inside tiles of every class; bit for bit against
     the oracle, and the same answers with early abandoning on (device-built lists, classes A and B only)."""
     import kvmatch
