@@ -9,10 +9,12 @@ cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_r04
 rm -rf $OUT; mkdir -p $OUT
 timeout 900 python3 bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
-# (the default command starts child runs for configs[2] and [3]; under the profiler each workload is traced on its own)
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --cpu-baseline 0 --sub-workloads 0 > $OUT/bench_trace.json 2> $OUT/bench_trace.err
-timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_cnsm_ed -- python3 bench.py --workload cnsm_ed --steps 5 --warmup 1 --extras 0 --cpu-baseline 0 > $OUT/bench_trace_cnsm_ed.json 2> $OUT/bench_trace_cnsm_ed.err
-timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_cnsm_dtw -- python3 bench.py --workload cnsm_dtw --steps 5 --warmup 1 --extras 0 --cpu-baseline 0 --queries 4 > $OUT/bench_trace_cnsm_dtw.json 2> $OUT/bench_trace_cnsm_dtw.err
+# (the default command starts child runs for configs[2] and [3]; under the profiler each workload is traced on its own -- and
+# driven by Python threads: with eight NATIVE host threads launching at once rocprofv3's kernel tracing itself segfaults
+# inside hipLaunchKernel now and then (two of three attempts; never without the profiler))
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --cpu-baseline 0 --sub-workloads 0 --python-threads 1 > $OUT/bench_trace.json 2> $OUT/bench_trace.err
+timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_cnsm_ed -- python3 bench.py --workload cnsm_ed --steps 5 --warmup 1 --extras 0 --cpu-baseline 0 --python-threads 1 > $OUT/bench_trace_cnsm_ed.json 2> $OUT/bench_trace_cnsm_ed.err
+timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_cnsm_dtw -- python3 bench.py --workload cnsm_dtw --steps 5 --warmup 1 --extras 0 --cpu-baseline 0 --queries 4 --python-threads 1 > $OUT/bench_trace_cnsm_dtw.json 2> $OUT/bench_trace_cnsm_dtw.err
 timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace1 -- python3 bench.py --cpu-baseline 0 --in-flight 1 --steps 2 --sub-workloads 0 > $OUT/bench_trace1.json 2> $OUT/bench_trace1.err
 for t in trace trace1 trace_cnsm_ed trace_cnsm_dtw; do n=0; for f in $(find $OUT/$t -name "*kernel_stats.csv" | sort); do cp "$f" $OUT/${t}_kernel_stats_$n.csv; n=$((n+1)); done; done
 B="python3 bench.py --steps 2 --warmup 1 --queries-per-step 20 --extras 0 --cpu-baseline 0 --in-flight 1 --sub-workloads 0"
