@@ -201,7 +201,8 @@ def test_dtw_engines_die_where_the_reference_does(world):
 
 
 @pytest.mark.parametrize("m,eps,rho,alpha,beta", [(128, 3.0, 6, 1.5, 2.0), (512, 6.0, 0.05, 1.3, 1.5),
-                                                  (1024, 8.0, 51, 2.0, 10.0)])
+                                                  (1024, 8.0, 51, 2.0, 10.0), (1500, 9.0, 100, 1.5, 5.0),
+                                                  (3000, 12.0, 0.05, 2.0, 10.0), (2600, 11.0, 300, 1.5, 5.0)])
 @pytest.mark.parametrize("dp_form", [0, 3])
 def test_cnsm_dtw(world, m, eps, rho, alpha, beta, dp_form):
     kvmatch = world[0]
