@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One-off stress run (not part of the test suite): random DTW verifications (RSM-DTW and cNSM-DTW, cascade on and off,
-register and LDS forms of the DP) against the oracle, bit for bit.  `stress_dtw.py [cases]`."""
+every form of the DP: KVM_OPT_DP_KERNEL 0 .. 3) against the oracle, bit for bit.  `stress_dtw.py [cases]`."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "kv-match_amd")); sys.path.insert(0, ROOT)
@@ -27,7 +27,7 @@ for c in range(cases):
     if kind == 0: s = base[int(rng.integers(0, 1_500_000)):][:n].copy()
     elif kind == 1: s = np.cumsum(rng.uniform(-1, 1, n)) + rng.uniform(-3000, 3000)
     else: s = 3 * np.sin(np.arange(n) * rng.uniform(0.0005, 0.05)) + rng.normal(0, 0.2, n)
-    m = int(rng.choice([64, 200, 513, 1024, 2000, 3000]))
+    m = int(rng.choice([64, 200, 513, 1024, 2000, 3000, 4096]))
     rho = int(rng.choice([2, 3, max(2, m // 40), max(2, m // 20), max(2, m // 10), max(2, m // 4)]))  # (<= 1 would mean a fraction of m)
     qoff = int(rng.integers(1, n - m + 1))
     planted = [int(p) for p in rng.integers(1, n - m + 1, 3)]
@@ -42,10 +42,11 @@ for c in range(cases):
     tot_answers += len(o1[0]) + len(o2[0])
     for cascade in (1, 0):
         ctx.set_option(kvmatch.OPT_LB_CASCADE, cascade)
-        for dpk in (0, 1):
+        for dpk in (0, 1, 2, 3):   # auto, LDS form, one candidate per wave, packed form
             ctx.set_option(kvmatch.OPT_DP_KERNEL, dpk)
             tag = f"case {c} n={n} m={m} rho={rho} ml={mean_len} eps={eps:.2f} a={alpha} b={beta} cascade={cascade} dp={dpk}"
             same(kvmatch.QueryEngineDtw(ctx).verify((L, R), 1, q, eps, rho), o1, "rsm " + tag)
             same(kvmatch.NormQueryEngineDtw(ctx).verify((L, R), 1, q, eps, rho, alpha, beta), o2, "cnsm " + tag)
+    if c % 10 == 9: print("  ...", c + 1, "cases, mismatches", bad, flush=True)
 print("cases", cases, "mismatches", bad, "oracle answers total", tot_answers)
 sys.exit(1 if bad else 0)
