@@ -321,3 +321,28 @@ def test_integration_listing_is_the_shipped_adapter():
     doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
     a = doc.index("```java\npackage cn.edu.fudan.dsm.kvmatch.gpu;") + len("```java\n")
     assert doc[a: doc.index("```\n", a)] == body
+
+
+def test_run_jobs_rejects_bad_arguments_without_a_gpu(built):
+    """kvm_run_jobs' argument checks run before any GPU call: null context arrays / handles, negative counts, missing result
+    arrays come back as status codes (no device is needed, none is touched); the Python Job marshals what verify() would
+    pass (shift = (lastSegment - 1) * 25, rho resolved like the REPL's prompt)."""
+    import ctypes as C
+    import kvmatch
+    from kvmatch import _lib
+    lib = _lib.load()
+    jobs = (_lib.KvmJob * 1)()
+    res = (C.c_void_p * 1)()
+    st = (C.c_int32 * 1)()
+    null_ctx = (C.c_void_p * 1)(None)
+    assert lib.kvm_run_jobs(None, 1, jobs, 1, res, st) == _lib.KVM_ERR_ILLEGAL_ARGUMENT
+    assert lib.kvm_run_jobs(null_ctx, 0, jobs, 1, res, st) == _lib.KVM_ERR_ILLEGAL_ARGUMENT
+    assert lib.kvm_run_jobs(null_ctx, 1, jobs, -1, res, st) == _lib.KVM_ERR_ILLEGAL_ARGUMENT
+    assert lib.kvm_run_jobs(null_ctx, 1, None, 1, res, st) == _lib.KVM_ERR_ILLEGAL_ARGUMENT
+    assert lib.kvm_run_jobs(null_ctx, 1, jobs, 1, None, st) == _lib.KVM_ERR_ILLEGAL_ARGUMENT
+    assert lib.kvm_run_jobs(null_ctx, 1, jobs, 1, res, st) == _lib.KVM_ERR_INVALID_HANDLE
+    assert C.sizeof(_lib.KvmJob) == 72        # struct kvm_job of include/kvmatch.h (two int32, three pointers, ... on LP64)
+    j = kvmatch.Job(3, (np.array([5, 40], dtype=np.int32), np.array([9, 44], dtype=np.int32)), 3, np.arange(200.0), 2.5, rho=0.05,
+                    alpha=1.5, beta=2.0)
+    assert (j.variant, j.shift, j.rho, j.epsilon, j.alpha, j.beta, j.q.size, j.left.tolist()) == (3, 50, 10, 2.5, 1.5, 2.0, 200, [5, 40])
+    assert kvmatch.Job(0, [(1, 2)], 1, [1.0] * 30, 1.0).rho == 0
