@@ -35,6 +35,16 @@ int main(int argc, char **argv) {
         show("RSM-DTW ", kvmatch::QueryEngineDtw(ctx).verify(iv, 1, q, eps, 0.05));
         show("cNSM-ED ", kvmatch::NormQueryEngine(ctx).verify(iv, 1, q, eps, 1.5, 5.0));
         show("cNSM-DTW", kvmatch::NormQueryEngineDtw(ctx).verify(iv, 1, q, eps, 0.05, 1.5, 5.0));
+        {   // several queries in flight over the one resident series: native host threads (kvm_run_jobs)
+            kvmatch::QueryStream qs(ctx, 3);
+            std::vector<int32_t> l, r;
+            kvmatch::detail::flatten(iv, l, r);
+            std::vector<kvm_job> jobs;
+            for (int i = 0; i < 6; i++) jobs.push_back(kvmatch::QueryStream::job(i % 2, q, l, r, 1, eps, 0, 1.5, 5.0));
+            auto res = qs.run(jobs);
+            show("stream[0] RSM-ED ", res[0]);
+            show("stream[5] cNSM-ED", res[5]);
+        }
         // index-free full scans (experiments/ucr/*), step 1 of the index build, the phase-2 time model
         show("UCR-ED  ", kvmatch::UcrEdQueryExecutor(ctx, n, q, eps, 1.5, 5.0, 50000).run());
         show("UCR-DTW ", kvmatch::UcrDtwQueryExecutor(ctx, n, q, eps, kvm_resolve_rho(0.05, m), 1.5, 5.0).run());

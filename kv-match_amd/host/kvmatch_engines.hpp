@@ -9,6 +9,8 @@
 #include <algorithm>
 #include <string>
 #include <utility>
+#include <memory>
+#include <new>
 #include <vector>
 
 #include "../../include/kvmatch.h"
@@ -95,6 +97,8 @@ public:
         if (rc) throw IOException("cannot write " + path);
         return image;
     }
+    // one more engine over the series `owner` has staged (kvm_share_series): a second query in flight
+    void shareSeries(const Phase2Context &owner) { check(kvm_share_series(ctx_, owner.ctx_), ctx_); }
     void setOption(int32_t option, int64_t value) { check(kvm_set_option(ctx_, option, value), ctx_); }
     int64_t seriesLength() const { return kvm_series_length(ctx_); }
     kvm_ctx *handle() const { return ctx_; }
@@ -104,6 +108,7 @@ public:
         std::string msg = kvm_last_error(ctx);
         if (rc == KVM_ERR_ILLEGAL_ARGUMENT) throw IllegalArgumentException(msg);
         if (rc == KVM_ERR_INDEX_OUT_OF_BOUNDS) throw ArrayIndexOutOfBoundsException(msg);  // (KVM_OPT_STRICT_BOUNDS)
+        if (rc == KVM_ERR_NO_MEMORY) throw std::bad_alloc();                                // (OutOfMemoryError in the JNI shim)
         throw IOException("[" + std::to_string(rc) + "] " + msg);
     }
 
@@ -130,6 +135,47 @@ inline Answers collect(kvm_result *res) {
     return a;
 }
 }  // namespace detail
+
+// Several queries in flight: n contexts over one resident series, one native host thread each (kvm_run_jobs) -- the loop a
+// server runs with one engine instance per thread (the engines are not re-entrant, K/QueryEngine.java:61-68).  Jobs are the
+// arguments of the engines' verify() as data; the answers come back in job order.
+class QueryStream {
+public:
+    QueryStream(Phase2Context &owner, int in_flight) {
+        ctxs_.push_back(owner.handle());
+        for (int i = 1; i < in_flight; i++) {
+            extra_.emplace_back(new Phase2Context(0));
+            extra_.back()->shareSeries(owner);
+            ctxs_.push_back(extra_.back()->handle());
+        }
+    }
+    static kvm_job job(int32_t variant, const std::vector<double> &q, const std::vector<int32_t> &left, const std::vector<int32_t> &right,
+                       int lastSegment, double epsilon, int32_t rho = 0, double alpha = 0, double beta = 0) {
+        kvm_job j{};
+        j.variant = variant; j.m = (int32_t)q.size(); j.query = q.data(); j.left = left.data(); j.right = right.data();
+        j.k = (int32_t)left.size(); j.shift = (lastSegment - 1) * 25; j.epsilon = epsilon; j.rho = rho; j.alpha = alpha; j.beta = beta;
+        return j;
+    }
+    std::vector<Answers> run(const std::vector<kvm_job> &jobs) {
+        std::vector<kvm_result *> res(jobs.size(), nullptr);
+        std::vector<int32_t> st(jobs.size(), 0);
+        const int rc = kvm_run_jobs(ctxs_.data(), (int32_t)ctxs_.size(), jobs.data(), (int64_t)jobs.size(), res.data(), st.data());
+        if (rc != KVM_OK) {
+            for (kvm_result *r : res) kvm_result_free(r);
+            for (kvm_ctx *c : ctxs_)   // (the message lives in the context that ran the failing job)
+                if (kvm_last_error(c)[0]) Phase2Context::check(rc, c);
+            Phase2Context::check(rc, nullptr);
+        }
+        std::vector<Answers> out;
+        out.reserve(res.size());
+        for (kvm_result *r : res) out.push_back(detail::collect(r));
+        return out;
+    }
+
+private:
+    std::vector<kvm_ctx *> ctxs_;
+    std::vector<std::unique_ptr<Phase2Context>> extra_;
+};
 
 // RSM-ED: verify() replaces K/QueryEngine.java:338-363 (+ sort :373)
 class QueryEngine {

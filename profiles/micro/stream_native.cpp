@@ -28,7 +28,7 @@ int main(int argc, char **argv) {
     }
     kvm_ctx *own; if (kvm_open(0, &own)) { fprintf(stderr, "open: %s\n", kvm_last_error(nullptr)); return 1; }
     if (kvm_load_series_f64(own, s.data(), n)) { fprintf(stderr, "load: %s\n", kvm_last_error(own)); return 1; }
-    for (int T : {1, 2, 3, 5, 8}) {
+    for (int T : {1, 2, 3, 5, 8, 12, 16}) {
         std::vector<kvm_ctx *> ctx{own};
         for (int t = 1; t < T; t++) { kvm_ctx *c; kvm_open(0, &c); kvm_share_series(c, own); ctx.push_back(c); }
         for (int rep = 0; rep < 2; rep++) {

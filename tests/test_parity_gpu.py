@@ -1025,6 +1025,11 @@ def test_cpp_host_mirror_cli(world):
         assert mo, line
         assert int(mo.group(1)) == int(a.offsets[0]) and int(mo.group(3)) == len(a), (name, line)
         assert abs(float(mo.group(2)) - a.distances[0]) <= 1e-5 * max(1.0, a.distances[0]), (name, line)
+    # the C++ QueryStream (kvm_run_jobs: three contexts, native host threads): first and last job of a six-job stream
+    for tag, name in (("stream[0]", "RSM-ED"), ("stream[5]", "cNSM-ED")):
+        line = next(l for l in out.stdout.splitlines() if l.startswith(tag))
+        mo = re.search(r"Best: (-?\d+), distance: (\S+) .*#answers: (\d+)", line)
+        assert mo and int(mo.group(1)) == int(want[name].offsets[0]) and int(mo.group(3)) == len(want[name]), line
     keys, first, last, gk, go = c2.index_rows(50, grouped=True)
     idx = next(l for l in out.stdout.splitlines() if l.startswith("index w=50"))
     nums = [int(x) for x in re.findall(r"\d+", idx)]
