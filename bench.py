@@ -142,7 +142,7 @@ def roofline_block(wl, plans, launches, m, rates=None):
         ach = ops / ks / 1e12 if ks > 0 else 0.0
         return {"bound": "fp64_valu", "achieved": ach, "peak": FP64_VALU_PEAK_TOPS_NOFMA, "unit": "TFLOP/s",
                 "frac": ach / FP64_VALU_PEAK_TOPS_NOFMA, "traffic": None,
-                "kernel": "kvm_dtw_dp_reg_kernel (banded DP; rho >= 256 and lists of more than 32 768 DPs: kvm_dtw_dp_pack_kernel) -- "
+                "kernel": "kvm_dtw_dp_reg_kernel (banded DP; rho = 128 .. 191 and 256 .. 447: kvm_dtw_dp_pack_kernel, odd cells per lane) -- "
                           "early abandon off: every candidate that reaches it runs all cells",
                 **({"fp64_nofma_sustained_tops": rates.get("fp64_cellmix_tops"), "fp64_nofma_sustained_source":
                     "measured by this run (kvm_measure_device 2: the DP's cell mix sub/mul/min/min/add, register-only, 4 waves per SIMD)"}
@@ -716,7 +716,7 @@ def main():
                 ach2 = r_.stats[4] * cells2 * 5.0 / ks2 / 1e12
                 out["roofline_dtw"] = {"bound": "fp64_valu", "achieved": ach2, "peak": FP64_VALU_PEAK_TOPS_NOFMA, "unit": "TFLOP/s",
                                        "frac": ach2 / FP64_VALU_PEAK_TOPS_NOFMA, "traffic": None,
-                                       "kernel": "kvm_dtw_dp_reg_kernel<4,0> (banded DP with the reference's row test; lists of more than 32 768 DPs: kvm_dtw_dp_pack_kernel<32,7,1>, two candidates per wave)",
+                                       "kernel": "kvm_dtw_dp_reg_kernel<4,0> (banded DP with the reference's row test)",
                                        "kernel_ms": ks2 * 1e3, "dp_candidates_per_launch": r_.stats[4], "cells_per_candidate": cells2,
                                        "cells_per_s": r_.stats[4] * cells2 / ks2,
                                        "workload": "cNSM-DTW m=4096 rho=204, 1e6 candidates, eps=10 alpha=2 beta=10 (BASELINE configs[3])",

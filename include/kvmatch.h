@@ -327,9 +327,9 @@ void kvm_result_free(kvm_result *r);
                                     are refused.) */
 #define KVM_OPT_TIMING 4         /* 1: record HIP-event kernel times into KVM_STAT_KERNEL_NS */
 #define KVM_OPT_DP_KERNEL 5      /* banded-DP form: 0 auto (rho <= 511: band in registers; the packed form -- any number of
-                                    cells per lane -- for rho = 128 .. 191 and 256 .. 447 and, two candidates per wave, for
-                                    lists of more than 128 DPs per CU at the other rho in 64 .. 255), 1 generic LDS form, 2 one candidate per wave,
-                                    3 packed form wherever it exists.  Identical answers. */
+                                    cells per lane -- for rho = 128 .. 191 and 256 .. 447), 1 generic LDS form, 2 one candidate per
+                                    wave, 3 packed form wherever it exists (also two candidates per wave at the other rho in
+                                    64 .. 255, which the default never picks).  Identical answers. */
 #define KVM_OPT_SORT_VIOLATION 6 /* cNSM-DTW only.  NormQueryEngineDtw sorts its query with a comparator that breaks
                                     the Comparator contract (K/NormQueryEngineDtw.java:475-478); for some queries
                                     (about half of white-noise ones, a few percent of random walks, no smooth one)

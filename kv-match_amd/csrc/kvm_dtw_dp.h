@@ -226,19 +226,20 @@ __host__ __device__ static inline int dp_pack_v(int rho) {
 }
 
 // How the candidates that reach the DP (R of them, in the prologue's compact list) are shared between the packed kernel
-// and the one-candidate-per-wave kernel behind it.  With 64 lanes per candidate (rho >= 256) the packed form is the same
-// shape with better filled lanes: it takes everything (m = 8192, rho = 409: 13.2 -> 10.9 ms for 8 192 full DPs, 1.97 -> 1.86 ms
-// for a query's 477).  With two candidates per wave (rho <= 255) it executes 14 % fewer instructions per cell but runs two
-// waves per SIMD instead of three, a wave's two DPs take 1.4 ms where a lone DP takes 0.6 - 0.9 ms, and a half that has
-// run out of work idles through its partner's instructions: on 24 576 - 49 152 equally long synthetic DPs it is 3 - 9 %
-// ahead (profiles/r04_ab_pack_{7,9}.log), on the bench's cNSM-DTW query -- row tests live, three in four DPs answers,
-// abandoning on -- 15 % behind at 13 508 DPs and level at 50 299 (profiles/r04_dp_real_sizes.log).  So it takes a list only
-// when that is long: more than 128 candidates per CU (eight of its rounds); everything else stays with the kernel whose
-// lone DP is the fastest.  Entries [0, share) are the packed kernel's.  mode = KVM_OPT_DP_KERNEL: 2 nothing packed, 3
-// everything packed.
+// and the one-candidate-per-wave kernel behind it.  With 64 lanes per candidate (rho = 128 .. 191, 256 .. 447) the packed form
+// is the same shape with better filled lanes: it takes everything (m = 8192, rho = 409: 13.2 -> 10.9 ms for 8 192 full DPs,
+// 1.97 -> 1.86 ms for a query's 477; rho = 150: 7.5 -> 6.6 ms for 24 576).  With two candidates per wave (the other rho in
+// 64 .. 255) it executes 14 % fewer instructions per cell but runs two waves per SIMD instead of three, a wave's two DPs take
+// 1.4 ms where a lone DP takes 0.6 - 0.9 ms, and a half that has run out of work idles through its partner's instructions:
+// on 24 576 - 49 152 equally long synthetic DPs it was 3 - 9 % ahead on some boxes (profiles/r04_ab_pack_{7,9}.log) and 4 %
+// behind on another (r04_ab_pack_11.log); on the bench's cNSM-DTW query -- row tests live, three in four DPs answers -- 15 %
+// behind at 13 508 DPs and level at 50 299 (r04_dp_real_sizes.log).  No list length at which it is reliably ahead: the
+// default never picks it; KVM_OPT_DP_KERNEL = 3 does (the GPU suite runs every DTW shape through it).
+// Entries [0, share) are the packed kernel's.  mode = KVM_OPT_DP_KERNEL: 2 nothing packed, 3 everything packed.
 __host__ __device__ static inline unsigned long long dp_pack_share(unsigned long long R, int num_cu, int mode, int rho) {
+    (void)num_cu;
     const int l = dp_pack_l(rho);
     if (!l || mode == 2) return 0;
     if (mode == 3 || l == 64) return R;
-    return R <= 128ULL * (unsigned long long)num_cu ? 0 : R;
+    return 0;
 }
