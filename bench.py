@@ -817,7 +817,7 @@ def main():
         ctx.close()
         ctx = None
         out["configs"] = {}
-        for w, extra in (("cnsm_ed", []), ("cnsm_dtw", ["--queries", str(min(NQ, 4))])):
+        for w, extra in (("cnsm_ed", []), ("cnsm_dtw", [])):
             cmd = [sys.executable, os.path.abspath(__file__), "--workload", w, "--steps", str(max(2, a.steps // 4)), "--warmup", "1",
                    "--extras", "0", "--cpu-baseline", str(a.cpu_baseline), "--n", str(n), "--candidates", str(a.candidates),
                    "--in-flight", str(a.in_flight), "--epsilon", repr(a.epsilon), "--sub-workloads", "0"] + extra
