@@ -273,6 +273,28 @@ typedef struct kvm_job {
 int kvm_run_jobs(kvm_ctx *const *ctxs, int32_t n_ctx, const kvm_job *jobs, int64_t n_jobs, kvm_result **results,
                  int32_t *status);
 
+/* The same loop for the device-resident variant (the multi-GPU host layer: every rank keeps several sharded queries in
+ * flight and ONE thread of the caller issues the collectives in query order).  Slot t = a context with its own stream and
+ * output buffers; job i runs on slot i mod n_slots: kvm_verify_device + kvm_pack_answers_device, enqueued, not waited for.
+ * Hand-shake through two int32 arrays of n_jobs entries owned by the caller: the library sets produced[i] = 1 once job i's
+ * kernels are enqueued on its slot's stream (a job that failed: its status in status[i], and {-1, 0} stored into the slot's
+ * packed block on that stream, so that a collective over the blocks tells every rank) and does not start job i + n_slots
+ * before the caller has set consumed[i] (the slot's buffers are free again); *stop != 0 ends the stream early.  Blocks until
+ * every job is enqueued or the stream is stopped: call it from a thread of its own.  cnt_candidate[i] as kvm_verify_device. */
+typedef struct kvm_device_slot {
+    kvm_ctx *ctx;
+    void *stream;        /* hipStream_t of the slot */
+    int32_t *d_off;      /* device, cap entries */
+    double *d_dist;      /* device, cap entries */
+    int64_t cap;
+    int64_t *d_count;    /* device */
+    double *d_packed;    /* device, 2 * (pack_cap + 1) doubles */
+    int64_t pack_cap;
+} kvm_device_slot;
+int kvm_run_device_jobs(const kvm_device_slot *slots, int32_t n_slots, const kvm_job *jobs, int64_t n_jobs,
+                        volatile int32_t *produced, const volatile int32_t *consumed, const volatile int32_t *stop,
+                        int64_t *cnt_candidate, int32_t *status);
+
 /* `r <= 1 -> floor(r*m) else floor(r)`  (K/QueryEngineDtw.java:135-140). */
 int32_t kvm_resolve_rho(double r, int32_t m);
 

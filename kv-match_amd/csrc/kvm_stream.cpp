@@ -7,6 +7,7 @@
 #include <atomic>
 #include <exception>
 #include <new>
+#include <chrono>
 #include <thread>
 #include <vector>
 
@@ -60,6 +61,58 @@ extern "C" int kvm_run_jobs(kvm_ctx *const *ctxs, int32_t n_ctx, const kvm_job *
     } catch (const std::bad_alloc &) {
         return KVM_ERR_NO_MEMORY;
     } catch (const std::exception &) {  // (std::system_error from a thread that could not be started)
+        return KVM_ERR_DEVICE;
+    }
+}
+
+// ---- the device-resident form: slots enqueue, the caller's own thread runs the collectives (kvmatch.distributed.ShardedStream)
+int kvm_poison_packed_device(kvm_ctx *ctx, double *d_packed, void *stream);  // kvm_verify.hip (internal)
+
+extern "C" int kvm_run_device_jobs(const kvm_device_slot *slots, int32_t n_slots, const kvm_job *jobs, int64_t n_jobs,
+                                   volatile int32_t *produced, const volatile int32_t *consumed, const volatile int32_t *stop,
+                                   int64_t *cnt_candidate, int32_t *status) {
+    if (!slots || n_slots < 1 || n_jobs < 0 || (n_jobs > 0 && (!jobs || !produced || !consumed || !stop || !status)))
+        return KVM_ERR_ILLEGAL_ARGUMENT;
+    for (int32_t t = 0; t < n_slots; t++)
+        if (!slots[t].ctx) return KVM_ERR_INVALID_HANDLE;
+    try {
+        std::atomic<int> first_rc{KVM_OK};
+        auto loop = [&](int32_t t) {
+            const kvm_device_slot &s = slots[t];
+            bool failed = false;  // a slot that has failed keeps taking part with the failure mark (every rank ends the stream there)
+            for (int64_t i = t; i < n_jobs; i += n_slots) {
+                while (i - n_slots >= 0 && !consumed[i - n_slots] && !*stop) std::this_thread::sleep_for(std::chrono::microseconds(5));
+                if (*stop) return;
+                int rc = KVM_OK;
+                if (!failed) {
+                    const kvm_job &j = jobs[i];
+                    int64_t cnt = 0;
+                    rc = kvm_verify_device(s.ctx, j.variant, j.query, j.m, j.left, j.right, j.k, j.shift, j.epsilon, j.rho, j.alpha, j.beta,
+                                           s.d_off, s.d_dist, s.cap, s.d_count, &cnt, s.stream);
+                    if (rc == KVM_OK) rc = kvm_pack_answers_device(s.ctx, s.d_off, s.d_dist, s.d_count, s.pack_cap, s.d_packed, s.stream);
+                    if (cnt_candidate) cnt_candidate[i] = cnt;
+                    if (rc != KVM_OK) failed = true;
+                }
+                if (failed) {
+                    if (rc == KVM_OK) rc = KVM_ERR_DEVICE;   // (a job behind the slot's failure)
+                    (void)kvm_poison_packed_device(s.ctx, s.d_packed, s.stream);
+                    int expected = KVM_OK;
+                    first_rc.compare_exchange_strong(expected, rc);
+                }
+                status[i] = rc;
+                std::atomic_thread_fence(std::memory_order_release);
+                produced[i] = 1;
+            }
+        };
+        std::vector<std::thread> th;
+        th.reserve((size_t)n_slots);
+        for (int32_t t = 1; t < n_slots; t++) th.emplace_back(loop, t);
+        loop(0);
+        for (auto &x : th) x.join();
+        return first_rc.load();
+    } catch (const std::bad_alloc &) {
+        return KVM_ERR_NO_MEMORY;
+    } catch (const std::exception &) {
         return KVM_ERR_DEVICE;
     }
 }

@@ -790,6 +790,17 @@ extern "C" int kvm_pack_answers_device(kvm_ctx *ctx, const int32_t *d_off, const
     });
 }
 
+// the failure mark of the multi-GPU exchange: {-1, 0} in front of a slot's packed block (kvm_run_device_jobs)
+int kvm_poison_packed_device(kvm_ctx *ctx, double *d_packed, void *stream) {
+    return kvm_guard<int>(ctx, [&]() -> int {
+    if (!ctx || !d_packed) return KVM_ERR_INVALID_HANDLE;
+    static const double mark[2] = {-1.0, 0.0};
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipMemcpyAsync(d_packed, mark, sizeof mark, hipMemcpyHostToDevice, stream ? (hipStream_t)stream : ctx->stream));
+    return KVM_OK;
+    });
+}
+
 // ---- results ----------------------------------------------------------------------------------------------
 extern "C" int64_t kvm_result_count(const kvm_result *r) { return r ? (int64_t)r->off.size() : 0; }
 extern "C" int64_t kvm_result_candidates(const kvm_result *r) { return r ? r->candidates : 0; }

@@ -35,7 +35,7 @@ SYMBOLS = [
     "kvm_index_rows_group_offsets", "kvm_index_build", "kvm_index_file_size", "kvm_index_file_bytes", "kvm_index_file_info",
     "kvm_index_file_write", "kvm_index_file_free", "kvm_phase2_time_estimate_ms", "kvm_phase2_time_estimate_dp_ms", "kvm_phase1_should_stop",
     "kvm_verify_rsm_ed", "kvm_verify_cnsm_ed", "kvm_verify_rsm_dtw", "kvm_verify_cnsm_dtw", "kvm_resolve_rho",
-    "kvm_cnsm_dtw_order", "kvm_sort_and_merge_intervals", "kvm_run_jobs",
+    "kvm_cnsm_dtw_order", "kvm_sort_and_merge_intervals", "kvm_run_jobs", "kvm_run_device_jobs",
     "kvm_result_count", "kvm_result_candidates", "kvm_result_elapsed_ms", "kvm_result_offsets",
     "kvm_result_distances", "kvm_result_stat", "kvm_result_free",
     "kvm_set_option", "kvm_get_option", "kvm_last_kernel_ns", "kvm_measure_device", "kvm_verify_device", "kvm_pack_answers_device",
@@ -48,6 +48,12 @@ class KvmJob(C.Structure):
     _fields_ = [("variant", C.c_int32), ("m", C.c_int32), ("query", C.c_void_p), ("left", C.c_void_p), ("right", C.c_void_p),
                 ("k", C.c_int32), ("shift", C.c_int32), ("epsilon", C.c_double), ("rho", C.c_int32), ("reserved", C.c_int32),
                 ("alpha", C.c_double), ("beta", C.c_double)]
+
+
+class KvmDeviceSlot(C.Structure):
+    """struct kvm_device_slot of include/kvmatch.h (kvm_run_device_jobs)."""
+    _fields_ = [("ctx", C.c_void_p), ("stream", C.c_void_p), ("d_off", C.c_void_p), ("d_dist", C.c_void_p), ("cap", C.c_int64),
+                ("d_count", C.c_void_p), ("d_packed", C.c_void_p), ("pack_cap", C.c_int64)]
 
 
 class KvMatchDeviceError(RuntimeError):
@@ -130,6 +136,8 @@ def load():
         "kvm_cnsm_dtw_order": (C.c_int, [vp, i32, vp]),
         "kvm_sort_and_merge_intervals": (i64, [vp, vp, i64, vp, vp]),
         "kvm_run_jobs": (C.c_int, [C.POINTER(vp), i32, C.POINTER(KvmJob), i64, C.POINTER(vp), C.POINTER(i32)]),
+        "kvm_run_device_jobs": (C.c_int, [C.POINTER(KvmDeviceSlot), i32, C.POINTER(KvmJob), i64, C.POINTER(i32), C.POINTER(i32),
+                                          C.POINTER(i32), C.POINTER(i64), C.POINTER(i32)]),
         "kvm_result_count": (i64, [vp]),
         "kvm_result_candidates": (i64, [vp]),
         "kvm_result_elapsed_ms": (f64, [vp]),

@@ -228,7 +228,9 @@ class ShardedStream:
 
     Each slot has its own context (sharing the rank's resident series), its own HIP stream and its own device buffers;
     slot threads run the device-resident verification and the pack kernel (kvm_verify_device, kvm_pack_answers_device) of
-    the queries dealt to them.  The exchange is NOT done by those threads: collectives must be issued in the same order on
+    the queries dealt to them -- native threads inside the library (kvm_run_device_jobs) since round 4: between the calls of a
+    Python slot thread the interpreter lock is held for 40 - 80 us, which bounds a rank's shards once they are shorter than
+    that (strong scaling); `native=False` keeps the Python threads.  The exchange is NOT done by those threads: collectives must be issued in the same order on
     every rank, so the calling thread alone performs the all-gathers, in query order, on its own stream, as each query's
     packed block becomes ready -- the all-gather and the host copy of query i overlap the kernels of query i+1.
 
@@ -237,11 +239,11 @@ class ShardedStream:
         # -> [(offsets, distances), ...] in query order, the merged sorted answer list on every rank
     """
 
-    def __init__(self, ctx, variant, max_candidates, in_flight=2, group=None, pack_cap=4096):
+    def __init__(self, ctx, variant, max_candidates, in_flight=2, group=None, pack_cap=4096, native=True):
         import torch
         import torch.distributed as dist
         from .engine import Phase2Context
-        self.group, self.variant = group, int(variant)
+        self.group, self.variant, self.native = group, int(variant), bool(native)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.dev = torch.device(f"cuda:{ctx.device}")
         self.pack_cap = int(pack_cap)
@@ -269,10 +271,99 @@ class ShardedStream:
         return [int(s["ctx"]._lib.kvm_last_kernel_ns(s["ctx"]._h)) for s in self.slots]
 
     def run(self, queries):
+        queries = list(queries)
+        if self.native and queries:
+            return self._run_native(queries)
+        return self._run_python(queries)
+
+    def _run_native(self, queries):
+        """The slots' loops in native threads (kvm_run_device_jobs, started from one helper thread that sits in the C call with
+        the interpreter lock released); this thread polls `produced`, runs the exchange of each query in order and hands the
+        slot back through `consumed`."""
+        import ctypes as C
+        import threading
+        import time
+        import torch
+        import torch.distributed as dist
+        from . import _lib
+        from .engine import Job, resolve_rho
+        nq, ns = len(queries), len(self.slots)
+        lib = self.slots[0]["ctx"]._lib
+        jobs_py = []
+        for q in queries:   # marshalling errors (a malformed list, a bad rho) are the caller's, on every rank alike: raise at once
+            var = self.variant if q.get("variant") is None else int(q["variant"])
+            rho = resolve_rho(q.get("rho", 0), len(q["query_data"]), q.get("resolved")) if var >= 2 else 0
+            jobs_py.append(Job(var, q["valid_positions"], q["last_segment"], q["query_data"], q["epsilon"], rho=int(rho),
+                               alpha=q.get("alpha", 1.0), beta=q.get("beta", 0.0)))
+        arr = (_lib.KvmJob * nq)()
+        for a, j in zip(arr, jobs_py):
+            a.variant, a.m, a.query, a.left, a.right = j.variant, j.q.size, j.q.ctypes.data, j.left.ctypes.data, j.right.ctypes.data
+            a.k, a.shift, a.epsilon, a.rho, a.alpha, a.beta = j.left.size, j.shift, j.epsilon, j.rho, j.alpha, j.beta
+        slots = (_lib.KvmDeviceSlot * ns)()
+        for t, s in enumerate(self.slots):
+            v = s["v"]
+            slots[t].ctx, slots[t].stream = s["ctx"]._h, C.c_void_p(s["stream"].cuda_stream)
+            slots[t].d_off, slots[t].d_dist, slots[t].cap = v.out_off.data_ptr(), v.out_dist.data_ptr(), v.cap
+            slots[t].d_count, slots[t].d_packed, slots[t].pack_cap = v.count.data_ptr(), v.packed.data_ptr(), v.pack_cap
+        produced, consumed = (C.c_int32 * nq)(), (C.c_int32 * nq)()
+        stop, status, cnts = (C.c_int32 * 1)(), (C.c_int32 * nq)(), (C.c_int64 * nq)()
+        rc_box = []
+        helper = threading.Thread(target=lambda: rc_box.append(lib.kvm_run_device_jobs(slots, ns, arr, nq, produced, consumed, stop, cnts, status)))
+        helper.start()
+        out, err = [], None
+        k = self.pack_cap
+        try:
+            for qi in range(nq):
+                while not produced[qi]:
+                    if not helper.is_alive() and not produced[qi]:
+                        raise _lib.KvMatchDeviceError("the slots' native loop ended before query %d was enqueued" % qi)
+                    time.sleep(1e-5)
+                si = qi % ns
+                s = self.slots[si]
+                if status[qi] and self.world == 1:
+                    _lib.check(int(status[qi]), s["ctx"]._h)
+                with torch.cuda.stream(self.comm_stream):
+                    self.comm_stream.wait_stream(s["stream"])   # (the slot's stream holds this query's kernels and nothing behind them:
+                    if self.world > 1:                          #  its next job waits for `consumed`)
+                        dist.all_gather_into_tensor(self.gathered[si], s["v"].packed, group=self.group)
+                        self.host[si].copy_(self.gathered[si], non_blocking=True)
+                    else:
+                        self.host[si][: k + 1].copy_(s["v"].packed, non_blocking=True)
+                    self.comm_stream.synchronize()
+                    host = self.host[si].numpy().reshape(self.world, k + 1, 2)
+                    counts = host[:, 0, 0].astype(np.int64)
+                    if counts.min() < 0:   # some rank failed on its shard of this query: every rank sees it here and stops
+                        if status[qi]:
+                            try:
+                                _lib.check(int(status[qi]), s["ctx"]._h)
+                            except Exception as e:  # noqa: BLE001
+                                err = e
+                        else:
+                            err = ShardFailed(f"rank(s) {np.nonzero(counts < 0)[0].tolist()} failed on their shard of query {qi}")
+                        break
+                    if counts.max() <= k:
+                        offs = np.concatenate([host[w, 1:1 + counts[w], 0] for w in range(self.world)]).astype(np.int32)
+                        dists = np.concatenate([host[w, 1:1 + counts[w], 1] for w in range(self.world)])
+                        out.append(sort_answers(offs, dists))
+                    else:  # rare: more answers than the packed block holds -> exact-size exchange of the slot's full lists
+                        n_local = int(s["v"].count.item())
+                        vo, vd = s["v"].out_off[:n_local], s["v"].out_dist[:n_local]
+                        out.append(gather_answers(vo, vd, group=self.group) if self.world > 1
+                                   else sort_answers(vo.cpu().numpy(), vd.cpu().numpy()))
+                consumed[qi] = 1
+        finally:
+            stop[0] = 1
+            helper.join()
+            torch.cuda.synchronize(self.dev)   # (slots that ran ahead of an early end: their kernels read the job arrays above)
+        if err is not None:
+            raise err
+        self.cnt_candidate = [int(c) for c in cnts]
+        return out
+
+    def _run_python(self, queries):
         import threading
         import torch
         import torch.distributed as dist
-        queries = list(queries)
         nq, ns = len(queries), len(self.slots)
         produced = [threading.Event() for _ in range(nq)]
         consumed = [threading.Event() for _ in range(nq)]
