@@ -312,45 +312,69 @@ class ShardedStream:
         helper.start()
         out, err = [], None
         k = self.pack_cap
-        try:
-            for qi in range(nq):
-                while not produced[qi]:
-                    if not helper.is_alive() and not produced[qi]:
-                        raise _lib.KvMatchDeviceError("the slots' native loop ended before query %d was enqueued" % qi)
-                    time.sleep(1e-5)
-                si = qi % ns
-                s = self.slots[si]
-                if status[qi] and self.world == 1:
-                    _lib.check(int(status[qi]), s["ctx"]._h)
+        if "issued" not in self.slots[0]:
+            for s in self.slots:
+                s["issued"] = torch.cuda.Event()
+
+        def issue(qi):
+            """query qi's exchange and host copy, enqueued on the exchange stream behind the slot's kernels; nothing waits here"""
+            while not produced[qi]:
+                if not helper.is_alive() and not produced[qi]:
+                    raise _lib.KvMatchDeviceError("the slots' native loop ended before query %d was enqueued" % qi)
+                time.sleep(1e-5)
+            si = qi % ns
+            s = self.slots[si]
+            if status[qi] and self.world == 1:
+                _lib.check(int(status[qi]), s["ctx"]._h)
+            with torch.cuda.stream(self.comm_stream):
+                self.comm_stream.wait_stream(s["stream"])   # (the slot's stream holds this query's kernels and nothing behind them:
+                if self.world > 1:                          #  its next job waits for `consumed`)
+                    dist.all_gather_into_tensor(self.gathered[si], s["v"].packed, group=self.group)
+                    self.host[si].copy_(self.gathered[si], non_blocking=True)
+                else:
+                    self.host[si][: k + 1].copy_(s["v"].packed, non_blocking=True)
+                s["issued"].record(self.comm_stream)
+
+        def finish(qi):
+            """wait for query qi's block, merge it, hand the slot back; returns an error (the stream ends here) or None"""
+            si = qi % ns
+            s = self.slots[si]
+            s["issued"].synchronize()
+            host = self.host[si].numpy().reshape(self.world, k + 1, 2)
+            counts = host[:, 0, 0].astype(np.int64)
+            if counts.min() < 0:   # some rank failed on its shard of this query: every rank sees it here and stops
+                if status[qi]:
+                    try:
+                        _lib.check(int(status[qi]), s["ctx"]._h)
+                    except Exception as e:  # noqa: BLE001
+                        return e
+                return ShardFailed(f"rank(s) {np.nonzero(counts < 0)[0].tolist()} failed on their shard of query {qi}")
+            if counts.max() <= k:
+                offs = np.concatenate([host[w, 1:1 + counts[w], 0] for w in range(self.world)]).astype(np.int32)
+                dists = np.concatenate([host[w, 1:1 + counts[w], 1] for w in range(self.world)])
+                out.append(sort_answers(offs, dists))
+            else:  # rare: more answers than the packed block holds -> exact-size exchange of the slot's full lists
                 with torch.cuda.stream(self.comm_stream):
-                    self.comm_stream.wait_stream(s["stream"])   # (the slot's stream holds this query's kernels and nothing behind them:
-                    if self.world > 1:                          #  its next job waits for `consumed`)
-                        dist.all_gather_into_tensor(self.gathered[si], s["v"].packed, group=self.group)
-                        self.host[si].copy_(self.gathered[si], non_blocking=True)
-                    else:
-                        self.host[si][: k + 1].copy_(s["v"].packed, non_blocking=True)
-                    self.comm_stream.synchronize()
-                    host = self.host[si].numpy().reshape(self.world, k + 1, 2)
-                    counts = host[:, 0, 0].astype(np.int64)
-                    if counts.min() < 0:   # some rank failed on its shard of this query: every rank sees it here and stops
-                        if status[qi]:
-                            try:
-                                _lib.check(int(status[qi]), s["ctx"]._h)
-                            except Exception as e:  # noqa: BLE001
-                                err = e
-                        else:
-                            err = ShardFailed(f"rank(s) {np.nonzero(counts < 0)[0].tolist()} failed on their shard of query {qi}")
+                    n_local = int(s["v"].count.item())
+                    vo, vd = s["v"].out_off[:n_local], s["v"].out_dist[:n_local]
+                    out.append(gather_answers(vo, vd, group=self.group) if self.world > 1
+                               else sort_answers(vo.cpu().numpy(), vd.cpu().numpy()))
+            consumed[qi] = 1
+            return None
+
+        # The exchange of query i + 1 is enqueued BEFORE the block of query i is waited for (one query of lag, when there are at
+        # least two slots): the host's wait, merge and sort of one query overlap the all-gather of the next.  The order of the
+        # collectives -- gather i + 1, then the rare exact-size exchange of query i -- depends on the counts alone, which every
+        # rank sees alike.
+        lag = 1 if ns > 1 else 0
+        try:
+            for qi in range(nq + lag):
+                if qi < nq:
+                    issue(qi)
+                if qi - lag >= 0:
+                    err = finish(qi - lag)
+                    if err is not None:
                         break
-                    if counts.max() <= k:
-                        offs = np.concatenate([host[w, 1:1 + counts[w], 0] for w in range(self.world)]).astype(np.int32)
-                        dists = np.concatenate([host[w, 1:1 + counts[w], 1] for w in range(self.world)])
-                        out.append(sort_answers(offs, dists))
-                    else:  # rare: more answers than the packed block holds -> exact-size exchange of the slot's full lists
-                        n_local = int(s["v"].count.item())
-                        vo, vd = s["v"].out_off[:n_local], s["v"].out_dist[:n_local]
-                        out.append(gather_answers(vo, vd, group=self.group) if self.world > 1
-                                   else sort_answers(vo.cpu().numpy(), vd.cpu().numpy()))
-                consumed[qi] = 1
         finally:
             stop[0] = 1
             helper.join()
