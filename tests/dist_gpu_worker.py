@@ -52,6 +52,11 @@ def main():
         for i, (offs, dists) in enumerate(res):
             np.savez(os.path.join(out_dir, f"stream{i}_r{rank}.npz"), offs=offs, dists=dists, cnt=int(cnts[i].item()),
                      variant=queries[i]["variant"])
+        # (the slots' loops are native threads by default; the Python slot threads of rounds 2-3 stay available: same stream)
+        ssp = D.ShardedStream(ctx, 0, cands, in_flight=2, native=False)
+        for i, (offs, dists) in enumerate(ssp.run(queries)):
+            np.savez(os.path.join(out_dir, f"pystream{i}_r{rank}.npz"), offs=offs, dists=dists, variant=queries[i]["variant"])
+        ssp.close()
         # one bad shard: rank 1's list ends in an interval beyond the series (readTimeSeries' IllegalArgument, for that rank
         # only).  Nobody may be left waiting in the all-gather: the failing rank takes part with a count of -1, rank 1 raises
         # its own error, rank 0 raises ShardFailed -- from ShardedVerifier.verify and, at the same query, from ShardedStream.run.

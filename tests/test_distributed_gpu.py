@@ -54,7 +54,8 @@ def test_sharded_verifier_two_ranks_one_device(built, tmp_path):
             w_off, w_dist, w_st = want[int(z["variant"])]
             assert np.array_equal(z["offs"], w_off) and np.array_equal(z["dists"], w_dist), (i, rank)
             assert int(z["cnt"]) == w_st["cnt_candidate"]
-
+            z = np.load(tmp_path / f"pystream{i}_r{rank}.npz")       # (the same stream through Python slot threads)
+            assert np.array_equal(z["offs"], w_off) and np.array_equal(z["dists"], w_dist), (i, rank)
 
     # a shard-dependent error ends the query on EVERY rank (the job above would have hung in the all-gather otherwise)
     assert (tmp_path / "bad_shard_r0.txt").read_text() == repr(["ShardFailed", "ShardFailed", 3])
