@@ -967,12 +967,10 @@ hipError_t kvm_launch_dtw_dp(const double *series, int64_t n, const kvm_query_de
         if (e != hipSuccess) return e;
     }
     const bool force_lds = dp_form == 1;
-    // packed register form (kvm_dtw_pair.hip): any V, two candidates per wave for rho <= 255 -- the first sweep.  It takes the
-    // share of the compact list that dp_pack_share gives it; the one-candidate-per-wave kernel below takes the rest.
-    if (dp_form != 1 && dp_form != 2 && !ax.cb_exact && dp_pack_l(qd.rho) > 0 && qd.m >= 2) {
-        const hipError_t e = kvm_launch_dtw_dp_pack(series, qd, ax, in, plans, list, dp_form, max_in, out_off, out_dist, cap, counters, num_cu, s);
-        if (e != hipSuccess) return e;
-    }
+    // packed register form (kvm_dtw_pair.hip): any V, two candidates per wave for rho <= 255.  dp_pack_share gives it either the
+    // whole compact list or nothing (a function of rho and the option alone): exactly one of the two register kernels is launched.
+    if (dp_form != 1 && dp_form != 2 && !ax.cb_exact && qd.m >= 2 && dp_pack_share(1ULL, num_cu, dp_form, qd.rho) > 0)
+        return kvm_launch_dtw_dp_pack(series, qd, ax, in, plans, list, dp_form, max_in, out_off, out_dist, cap, counters, num_cu, s);
     // register form: band of r+1 even-k cells over 64 lanes, V = pow2 cells per lane, V <= 8 (r <= 511)
     const int need = (qd.rho + 1 + 63) / 64;
     if (!force_lds && need <= 8 && qd.m >= 2) {
