@@ -13,6 +13,17 @@
 
 #include "../../include/kvmatch.h"
 
+// The helper threads of a call.  Joined on every path out of it: a std::thread that is still joinable when it is destroyed
+// ends the process (std::terminate), and the C ABI must hand back a status instead -- e.g. when the third of eight threads
+// cannot be started (std::system_error) while two are already running.
+struct thread_group {
+    std::vector<std::thread> th;
+    ~thread_group() {
+        for (auto &x : th)
+            if (x.joinable()) x.join();
+    }
+};
+
 static int run_one(kvm_ctx *c, const kvm_job &j, kvm_result **r) {
     switch (j.variant) {
         case 0: return kvm_verify_rsm_ed(c, j.query, j.m, j.left, j.right, j.k, j.shift, j.epsilon, r);
@@ -47,11 +58,17 @@ extern "C" int kvm_run_jobs(kvm_ctx *const *ctxs, int32_t n_ctx, const kvm_job *
             }
         };
         const int32_t nt = (int32_t)(n_jobs < n_ctx ? (n_jobs > 0 ? n_jobs : 1) : n_ctx);
-        std::vector<std::thread> th;
-        th.reserve((size_t)nt);
-        for (int32_t t = 1; t < nt; t++) th.emplace_back(loop, ctxs[t]);
-        loop(ctxs[0]);  // the calling thread drives the first context
-        for (auto &x : th) x.join();
+        {
+            thread_group g;
+            g.th.reserve((size_t)nt);
+            try {
+                for (int32_t t = 1; t < nt; t++) g.th.emplace_back(loop, ctxs[t]);
+            } catch (...) {
+                failed.store(true);  // the threads that did start take no further job; ~thread_group joins them
+                throw;
+            }
+            loop(ctxs[0]);  // the calling thread drives the first context
+        }
         int first = KVM_OK;
         for (int64_t i = 0; i < n_jobs; i++) {
             if (status) status[i] = rcs[(size_t)i];
@@ -77,12 +94,17 @@ extern "C" int kvm_run_device_jobs(const kvm_device_slot *slots, int32_t n_slots
         if (!slots[t].ctx) return KVM_ERR_INVALID_HANDLE;
     try {
         std::atomic<int> first_rc{KVM_OK};
+        std::atomic<bool> abort{false};  // this call's own stop (a helper thread could not be started)
+        // (the flags are shared with a caller written in another language: plain int32 words, read and written here with
+        // acquire / release so that a job's status and enqueued work are visible before its `produced` flag)
+        auto flag = [](const volatile int32_t *p) { return __atomic_load_n(const_cast<const int32_t *>(p), __ATOMIC_ACQUIRE) != 0; };
         auto loop = [&](int32_t t) {
             const kvm_device_slot &s = slots[t];
             bool failed = false;  // a slot that has failed keeps taking part with the failure mark (every rank ends the stream there)
             for (int64_t i = t; i < n_jobs; i += n_slots) {
-                while (i - n_slots >= 0 && !consumed[i - n_slots] && !*stop) std::this_thread::sleep_for(std::chrono::microseconds(5));
-                if (*stop) return;
+                while (i - n_slots >= 0 && !flag(&consumed[i - n_slots]) && !flag(stop) && !abort.load(std::memory_order_relaxed))
+                    std::this_thread::sleep_for(std::chrono::microseconds(5));
+                if (flag(stop) || abort.load(std::memory_order_relaxed)) return;
                 int rc = KVM_OK;
                 if (!failed) {
                     const kvm_job &j = jobs[i];
@@ -100,15 +122,20 @@ extern "C" int kvm_run_device_jobs(const kvm_device_slot *slots, int32_t n_slots
                     first_rc.compare_exchange_strong(expected, rc);
                 }
                 status[i] = rc;
-                std::atomic_thread_fence(std::memory_order_release);
-                produced[i] = 1;
+                __atomic_store_n(const_cast<int32_t *>(&produced[i]), 1, __ATOMIC_RELEASE);
             }
         };
-        std::vector<std::thread> th;
-        th.reserve((size_t)n_slots);
-        for (int32_t t = 1; t < n_slots; t++) th.emplace_back(loop, t);
-        loop(0);
-        for (auto &x : th) x.join();
+        {
+            thread_group g;
+            g.th.reserve((size_t)n_slots);
+            try {
+                for (int32_t t = 1; t < n_slots; t++) g.th.emplace_back(loop, t);
+            } catch (...) {
+                abort.store(true);
+                throw;
+            }
+            loop(0);
+        }
         return first_rc.load();
     } catch (const std::bad_alloc &) {
         return KVM_ERR_NO_MEMORY;
