@@ -174,8 +174,15 @@ def roofline_block(wl, plans, launches, m, rates=None):
                 tsrc = None
         except Exception:
             traffic = None
+    # per launch as well: a stream of queries mixes launches that fill the chip with launches of a few hundred tiles whose
+    # duration is one unit's latency (cNSM-ED: a query whose (alpha, beta) filter passes almost nothing) -- the mean alone hides both
+    per_launch = sorted(({"candidates_evaluated": int(x["stats"][kvmatch.STAT_PASS_FILTER] if v == 1 else x["stats"][kvmatch.STAT_WINDOWS]),
+                          "kernel_ms": x["ns"] * 1e-6} for x in ls), key=lambda d: d["candidates_evaluated"])
+    for d in per_launch:
+        d["frac"] = d["candidates_evaluated"] * m * 2.0 / (d["kernel_ms"] * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS
     return {"bound": "fp64_valu", "achieved": ach, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": ach / FP64_VALU_PEAK_TFLOPS, "traffic": traffic,
+            "frac_largest_launch": per_launch[-1]["frac"] if per_launch else None, "per_launch": per_launch,
             "traffic_source": (tsrc + " -- NOT measured by this run (gpurun refuses --pmc together with tracing)") if tsrc else None,
             "kernel": "kvm_ed_dot_kernel (ED pruning pass incl. the in-place exact evaluation of its survivors" +
                       ("; cNSM: + the (alpha, beta) retile before it)" if v == 1 else ")"),
