@@ -15,3 +15,9 @@ run python -u profiles/stress_dtw.py 60
 SEED=77 run python -u profiles/stress_dtw.py 40
 SEED=1234 run python -u profiles/stress_dtw.py 40
 fi
+if [ $PART = c ]; then   # (the last build of the round: other seeds)
+DP_FORM=0 SEED=9001 run python -u profiles/stress_adversarial.py 3
+DP_FORM=3 SEED=9002 run python -u profiles/stress_adversarial.py 2
+SEED=9003 run python -u profiles/stress_dtw.py 60
+SEED=9004 run python -u profiles/stress_dtw.py 40
+fi
