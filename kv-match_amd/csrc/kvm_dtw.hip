@@ -585,13 +585,6 @@ __device__ __forceinline__ void dp_reg_sweep(const double *__restrict__ series, 
     using BUF = dp_buf<V>;
     constexpr int LIN = BUF::LIN, LIVE = BUF::LIVE, NBLK = 64 / V;
     constexpr int WAVE_LDS = 2 * LIN + 64 * V + 64;  // buffer A, buffer B, result scratch, finished row minima
-    // Which rows' minima are carried.  The reference tests EVERY row (`min_cost + cb[i+r+1] >= bsf`, K/utils/DtwUtils.java:319-325),
-    // but its test is a valid lower bound of the final cell -- a row that fires proves DTW >= eps^2 up to rounding -- so which
-    // rows are looked at changes WHEN a reject is abandoned, never what is decided, as long as a final cell within `tol` of eps^2
-    // goes to the sequential path like every other tie (below).  2: every row (EXACT: the reference's own comparison, in its
-    // order).  1: one row in V, the rows of register slot 0 (abandoning sweeps: one v_min3_u32 per step instead of V, one
-    // hand-over per block instead of V).  0: none (early abandoning off: every cell runs anyway, the final cell decides).
-    constexpr int TRK = EXACT ? 2 : (ABANDON ? 1 : 0);
     __shared__ __attribute__((aligned(16))) double lds_all[4 * WAVE_LDS];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     double *bufA = lds_all + wave * WAVE_LDS, *bufB = bufA + LIN, *scratch = bufB + LIN, *bufR = scratch + 64 * V;
@@ -631,13 +624,13 @@ __device__ __forceinline__ void dp_reg_sweep(const double *__restrict__ series, 
         if (!EXACT) {
             pl = plans[idx];
             if (pl.which < 0) continue;  // dropped by the prologue, or queued for the sequential path
-            if (TRK != 0 && pl.which == 1) dp_build_patch(series, r, pl, cand.start, m, lane, patch);
+            if (pl.which == 1) dp_build_patch(series, r, pl, cand.start, m, lane, patch);
         }
         if (lane == 0) atomicAdd(&counters[KVM_CNT_PASS_KEOGH2], 1ULL);
         const double *__restrict__ cb_src = EXACT ? ax.cb_exact + (size_t)idx * 2 * m + (cand.lim != 0.0 ? m : 0) : nullptr;
         // prefix of the cb terms below the first index the row test needs (cb[I0 + 1]: chunk Ic covers cb[Ic+1 .. Ic+64])
         double pref0 = 0.0;
-        if (!EXACT && TRK != 0) {
+        if (!EXACT) {
             for (int base = 0; base <= I0; base += 64) {
                 const int k = base + lane;
                 pref0 += kvm_wave_sum((k <= I0 && k < m) ? dp_cb_term(x, qd, ax, patch, pl, cand.start, mean, sd, k) : 0.0);
@@ -708,15 +701,8 @@ __device__ __forceinline__ void dp_reg_sweep(const double *__restrict__ series, 
                 const int I = Ib + s;
                 // the row that left this lane's last slot moves on to the next lane; lane 0 starts a new row: it
                 // never receives, so its r_in keeps the INF it was initialised with (no constant to re-materialise)
-                if constexpr (TRK == 2) {
-                    if constexpr (FULLMIN) r_in = dp_from_left(R[(V - s) % V], r_in);
-                    else rh_in = dp_u32_from_left(Rh[(V - s) % V], rh_in);
-                } else if constexpr (TRK == 1) {  // (slot 0 leaves the lane at step 0 of a block)
-                    if (s == 0) {
-                        if constexpr (FULLMIN) r_in = dp_from_left(R[0], r_in);
-                        else rh_in = dp_u32_from_left(Rh[0], rh_in);
-                    }
-                }
+                if constexpr (FULLMIN) r_in = dp_from_left(R[(V - s) % V], r_in);
+                else rh_in = dp_u32_from_left(Rh[(V - s) % V], rh_in);
                 // ---- E-update (diagonal 2I - r) ----
                 halo_l = dp_from_left(O[V - 1], halo_l);
 #pragma unroll
@@ -752,29 +738,17 @@ __device__ __forceinline__ void dp_reg_sweep(const double *__restrict__ series, 
                 // band edge k = 2r+1: O[r] must read as INF (>= 1e20: `edge_pen` is 1e20 in that lane, 0 elsewhere)
                 O[CSTAR] += edge_pen;
                 // ---- row minima (slot 0 takes over the row handed in from the left) ----
-                if constexpr (TRK == 2) {
-                    if constexpr (FULLMIN) {
+                if constexpr (FULLMIN) {
 #pragma unroll
-                        for (int c = 0; c < V; c++)
-                            R[((c - s) % V + V) % V] = dp_min(dp_min(c == 0 ? r_in : R[((c - s) % V + V) % V], E[c]), O[c]);
-                        if (edge_lane) *reinterpret_cast<double *>(lds_raw + pr + 8 * s) = R[((CSTAR - s) % V + V) % V];  // row I - r is complete
-                    } else {
+                    for (int c = 0; c < V; c++)
+                        R[((c - s) % V + V) % V] = dp_min(dp_min(c == 0 ? r_in : R[((c - s) % V + V) % V], E[c]), O[c]);
+                    if (edge_lane) *reinterpret_cast<double *>(lds_raw + pr + 8 * s) = R[((CSTAR - s) % V + V) % V];  // row I - r is complete
+                } else {
 #pragma unroll
-                        for (int c = 0; c < V; c++)
-                            Rh[((c - s) % V + V) % V] = dp_umin3(c == 0 ? rh_in : Rh[((c - s) % V + V) % V],
-                                                                 (unsigned)__double2hiint(E[c]), (unsigned)__double2hiint(O[c]));
-                        if (edge_lane) *reinterpret_cast<unsigned *>(lds_raw + pr + 4 * s) = Rh[((CSTAR - s) % V + V) % V];
-                    }
-                } else if constexpr (TRK == 1) {
-                    // slot 0 alone: at step s its row is in cell s of this lane; the row it holds is complete in the edge lane at
-                    // step CSTAR (strip entry s of the block: lanes t = CSTAR mod V of the row test)
-                    if constexpr (FULLMIN) {
-                        R[0] = dp_min(dp_min(s == 0 ? r_in : R[0], E[s]), O[s]);
-                        if (s == CSTAR && edge_lane) *reinterpret_cast<double *>(lds_raw + pr + 8 * s) = R[0];
-                    } else {
-                        Rh[0] = dp_umin3(s == 0 ? rh_in : Rh[0], (unsigned)__double2hiint(E[s]), (unsigned)__double2hiint(O[s]));
-                        if (s == CSTAR && edge_lane) *reinterpret_cast<unsigned *>(lds_raw + pr + 4 * s) = Rh[0];
-                    }
+                    for (int c = 0; c < V; c++)
+                        Rh[((c - s) % V + V) % V] = dp_umin3(c == 0 ? rh_in : Rh[((c - s) % V + V) % V],
+                                                             (unsigned)__double2hiint(E[c]), (unsigned)__double2hiint(O[c]));
+                    if (edge_lane) *reinterpret_cast<unsigned *>(lds_raw + pr + 4 * s) = Rh[((CSTAR - s) % V + V) % V];
                 }
             }
         };
@@ -823,7 +797,7 @@ __device__ __forceinline__ void dp_reg_sweep(const double *__restrict__ series, 
                 ja += BUF::GROUP; jb += BUF::GROUP;
             }
             // ---- row test of the rows finished in macro-steps Ic .. Ic+63 (lane t: row Ic + t - r) ----
-            if (TRK != 0 && decision == 0) {
+            if (decision == 0) {
                 const int I = Ic + lane, k = I + 1;  // needs cb[I + 1]
                 double cbv, term = 0.0;
                 if (EXACT) {
@@ -834,7 +808,7 @@ __device__ __forceinline__ void dp_reg_sweep(const double *__restrict__ series, 
                     cbv = pl.total - (pref + (inc - term));
                     pref += kvm_readlane_f64(inc, 63);
                 }
-                const bool valid = I >= r && I <= m - 2 && (TRK == 2 || (lane % V) == CSTAR);  // (TRK 1: the rows of slot 0)
+                const bool valid = I >= r && I <= m - 2;
                 const int t = FULLMIN ? dp_row_test(valid, bufR[lane], cbv, eps2, tol, EXACT, value)
                                       : dp_row_test_hi(valid, bufR32[lane], cbv, eps2, tol);
                 if (t) {
@@ -879,11 +853,6 @@ __device__ __forceinline__ void dp_reg_sweep(const double *__restrict__ series, 
                 decision = one(std::true_type{});
             }
         }
-        // Not every row was looked at: a row that was not may have fired in the reference (-> rejected there) with the final cell
-        // at or a rounding below eps^2.  The final cell bounds every row's test from above up to rounding (`tol` covers the m-term
-        // sums on both sides), so only a final cell within tol of eps^2 can hide that: such a candidate is a tie like any other
-        // and takes the sequential path, whose sweep carries every row.  (NaN: not within tol -> not an answer, as before.)
-        if (TRK != 2 && decision == 0 && fabs(result - eps2) <= tol) decision = 2;
         if (decision == 2) {
             dp_emit_ambig(ax, counters, cand, lane);
             if (lane == 0) atomicAdd(&counters[KVM_CNT_PASS_KEOGH2], ~0ULL);  // (counted again when the exact run starts it)

@@ -173,14 +173,9 @@ __device__ __forceinline__ void dp_pack_sweep(const double *__restrict__ series,
         unsigned rh_in;
 #pragma unroll
         for (int s = 0; s < V; s++) {
-            // Row minima: ONE row in V is carried, the rows of register slot 0 (see TRK in dp_reg_sweep, kvm_dtw.hip: the row test is
-            // a valid lower bound of the final cell, so which rows are looked at changes when a reject is abandoned, never what is
-            // decided -- a final cell within tol of eps^2 goes to the sequential path, `after` below).  Slot 0 leaves the lane at
-            // step 0 of a block: the row that left the previous lane moves on to this lane; a candidate's first lane starts a new row
-            if (s == 0) {
-                if constexpr (FULLMIN) r_in = pw_from_left(R[0], guardL);
-                else rh_in = pw_u32_from_left(RH(0), guardL);
-            }
+            // the row that left the previous lane's last slot moves on to this lane; a candidate's first lane starts a new row
+            if constexpr (FULLMIN) r_in = pw_from_left(R[(V - s) % V], guardL);
+            else rh_in = pw_u32_from_left(RH((V - s) % V), guardL);
             // ---- E-update (diagonal 2I - r) ----
             halo_l = pw_from_left(O[V - 1], guardL);
 #pragma unroll
@@ -216,14 +211,17 @@ __device__ __forceinline__ void dp_pack_sweep(const double *__restrict__ series,
             // band edge k = 2r+1: O[r] must read as INF (>= 1e20: `edge_pen` is 1e20 in that lane, 0 elsewhere)
             O[CSTAR] += edge_pen;
             // ---- row minima (slot 0 takes over the row handed in from the left) ----
-            // (at step s slot 0's row is in cell s of this lane; it is complete in the edge lane at step CSTAR: strip entry s of the
-            // block, i.e. lanes u = CSTAR mod V of the row test)
             if constexpr (FULLMIN) {
-                R[0] = dp_min(dp_min(s == 0 ? r_in : R[0], E[s]), O[s]);
-                if (s == CSTAR && edge_lane) *reinterpret_cast<double *>(lds_raw + pr + 8 * s) = R[0];
+#pragma unroll
+                for (int c = 0; c < V; c++)
+                    R[((c - s) % V + V) % V] = dp_min(dp_min(c == 0 ? r_in : R[((c - s) % V + V) % V], E[c]), O[c]);
+                if (edge_lane) *reinterpret_cast<double *>(lds_raw + pr + 8 * s) = R[((CSTAR - s) % V + V) % V];  // row I - r is complete
             } else {
-                setRH(0, dp_umin3(s == 0 ? rh_in : RH(0), (unsigned)__double2hiint(E[s]), (unsigned)__double2hiint(O[s])));
-                if (s == CSTAR && edge_lane) *reinterpret_cast<unsigned *>(lds_raw + pr + 4 * s) = RH(0);
+#pragma unroll
+                for (int c = 0; c < V; c++)
+                    setRH(((c - s) % V + V) % V, dp_umin3(c == 0 ? rh_in : RH(((c - s) % V + V) % V),
+                                                          (unsigned)__double2hiint(E[c]), (unsigned)__double2hiint(O[c])));
+                if (edge_lane) *reinterpret_cast<unsigned *>(lds_raw + pr + 4 * s) = RH(((CSTAR - s) % V + V) % V);
             }
             // ---- the next block's values that can land now ----
             if ((s & 1) == 1) {
@@ -388,7 +386,7 @@ __device__ __forceinline__ void dp_pack_sweep(const double *__restrict__ series,
             const double inc = dp_scan_add(term, lane);
             const double cbv = T.pl.total - (T.pref + (inc - term));
             T.pref += kvm_readlane_f64(inc, 63);
-            const bool valid = lane < CH && I >= r && I <= m - 2 && (lane % V) == CSTAR;  // (the rows of slot 0)
+            const bool valid = lane < CH && I >= r && I <= m - 2;
             const double *stripD = wbase + 2 * H * SIZE + h * 64;
             const unsigned *strip32 = reinterpret_cast<const unsigned *>(stripD);
             double value;
@@ -414,12 +412,7 @@ __device__ __forceinline__ void dp_pack_sweep(const double *__restrict__ series,
         if (Ic + CH > Ilast) {  // the chunk held macro-step Ilast: cell (m-1, m-1) is in the half's scratch (:333-336)
             if (T.decision == 0) {
                 const double v = (wbase + 2 * H * SIZE + H * 64 + h * 8)[kfin % V];
-                if (fabs(v - eps2) <= tol) {
-                    // not every row was looked at: one that was not may have fired in the reference with the final cell at or a
-                    // rounding below eps^2 -- a tie like any other: the sequential path, whose sweep carries every row, decides
-                    dp_emit_ambig(ax, counters, T.cand, lane);
-                    if (lane == 0) atomicAdd(&counters[KVM_CNT_PASS_KEOGH2], ~0ULL);  // (counted again when the exact run starts it)
-                } else if (lane == 0 && v <= eps2) {
+                if (lane == 0 && v <= eps2) {
                     const unsigned long long o = atomicAdd(&counters[KVM_CNT_ANSWERS], 1ULL);
                     if ((int64_t)o < cap) {
                         out_off[o] = T.cand.start;
