@@ -289,14 +289,26 @@ class ShardedStream:
         from .engine import Job, resolve_rho
         nq, ns = len(queries), len(self.slots)
         lib = self.slots[0]["ctx"]._lib
-        jobs_py = []
-        for q in queries:   # marshalling errors (a malformed list, a bad rho) are the caller's, on every rank alike: raise at once
-            var = self.variant if q.get("variant") is None else int(q["variant"])
-            rho = resolve_rho(q.get("rho", 0), len(q["query_data"]), q.get("resolved")) if var >= 2 else 0
-            jobs_py.append(Job(var, q["valid_positions"], q["last_segment"], q["query_data"], q["epsilon"], rho=int(rho),
-                               alpha=q.get("alpha", 1.0), beta=q.get("beta", 0.0)))
+        # A query that cannot even be marshalled on THIS rank (its shard of the list is malformed, say) must not leave the other
+        # ranks waiting in its all-gather: it becomes a job the library refuses (no query), i.e. a failed shard like any other --
+        # the slot takes part with the failure mark and this rank raises its own error when the stream reaches that query.
+        jobs_py, marshal_err = [], {}
+        for qi, q in enumerate(queries):
+            try:
+                var = self.variant if q.get("variant") is None else int(q["variant"])
+                rho = resolve_rho(q.get("rho", 0), len(q["query_data"]), q.get("resolved")) if var >= 2 else 0
+                jobs_py.append(Job(var, q["valid_positions"], q["last_segment"], q["query_data"], q["epsilon"], rho=int(rho),
+                                   alpha=q.get("alpha", 1.0), beta=q.get("beta", 0.0)))
+            except Exception as e:  # noqa: BLE001
+                if self.world == 1:
+                    raise
+                jobs_py.append(None)
+                marshal_err[qi] = e
         arr = (_lib.KvmJob * nq)()
         for a, j in zip(arr, jobs_py):
+            if j is None:
+                a.variant, a.m, a.k = 0, 0, 0       # (query = NULL, m = 0: KVM_ERR_ILLEGAL_ARGUMENT before anything is touched)
+                continue
             a.variant, a.m, a.query, a.left, a.right = j.variant, j.q.size, j.q.ctypes.data, j.left.ctypes.data, j.right.ctypes.data
             a.k, a.shift, a.epsilon, a.rho, a.alpha, a.beta = j.left.size, j.shift, j.epsilon, j.rho, j.alpha, j.beta
         slots = (_lib.KvmDeviceSlot * ns)()
@@ -343,6 +355,8 @@ class ShardedStream:
             host = self.host[si].numpy().reshape(self.world, k + 1, 2)
             counts = host[:, 0, 0].astype(np.int64)
             if counts.min() < 0:   # some rank failed on its shard of this query: every rank sees it here and stops
+                if qi in marshal_err:
+                    return marshal_err[qi]
                 if status[qi]:
                     try:
                         _lib.check(int(status[qi]), s["ctx"]._h)

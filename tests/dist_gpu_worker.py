@@ -79,6 +79,14 @@ def main():
             outcome.append(type(e).__name__)
         res = ss.run(queries[:1] + queries[2:])       # and the stream is usable afterwards
         outcome.append(len(res))
+        # a shard that cannot even be marshalled on one rank (left[] and right[] of different lengths): the same, collectively
+        bad = dict(queries[0], valid_positions=(l, r) if rank == 0 else (l, r[:-1]))
+        try:
+            ss.run([queries[0], bad, queries[2]])
+            outcome.append("no error")
+        except Exception as e:  # noqa: BLE001
+            outcome.append(type(e).__name__)
+        outcome.append(len(ss.run(queries[:1])))
         with open(os.path.join(out_dir, f"bad_shard_r{rank}.txt"), "w") as f:
             f.write(repr(outcome))
         ss.close()
