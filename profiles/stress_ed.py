@@ -38,7 +38,7 @@ for c in range(cases):
     o1 = oracle.rsm_ed(s, q, L, R, 0, eps); o2 = oracle.cnsm_ed(s, q, L, R, 0, eps, alpha, beta)
     for ab in (0, 1):
         ctx.set_option(kvmatch.OPT_EARLY_ABANDON, ab)
-        for k in (3, 4):
+        for k in (3, 1):   # (3 the correlation-form pruner = the default, 1 the wave-per-candidate cross-check)
             ctx.set_option(kvmatch.OPT_ED_KERNEL, k)
             tag = f"case {c} n={n} m={m} ml={mean_len} eps={eps:.2f} a={alpha} b={beta} ab={ab} k={k}"
             same(kvmatch.QueryEngine(ctx).verify((L, R), 1, q, eps), o1, "rsm " + tag)
