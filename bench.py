@@ -81,7 +81,15 @@ def parse():
     ap.add_argument("--workload", default="rsm_ed", choices=["rsm_ed", "cnsm_ed", "cnsm_dtw", "mixed"],
                     help="rsm_ed = BASELINE configs[1] (headline); cnsm_ed = configs[2]; cnsm_dtw = configs[3] "
                          "(m=4096, rho=5%%); mixed = configs[4]-style stream alternating all four variants")
-    return ap.parse_args()
+    a = ap.parse_args()
+    # Under rocprofv3's kernel tracing, eight NATIVE host threads launching at once make the profiler's own library fall over
+    # inside hipLaunchKernel now and then (never without it: profiles/prof_r04.sh).  So that `rocprofv3 ... -- python3 bench.py`
+    # still gives the per-kernel summary of this very command, a profiled run drives its contexts from Python threads (the
+    # line says so in `config.host_threads`; its stream rates are then the interpreter's, its kernel durations are not).
+    a.profiled = any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", "")
+    if a.profiled and not a.python_threads:
+        a.python_threads = 1
+    return a
 
 
 def timed_steps(fn, steps, warmup, world):
@@ -593,7 +601,9 @@ def main():
                                 "cnsm_ed": "cNSM-ED phase 2, alpha=2 beta=10 (BASELINE configs[2])",
                                 "cnsm_dtw": "cNSM-DTW phase 2, rho=5%, alpha=2 beta=10 (BASELINE configs[3])",
                                 "mixed": "mixed ED+DTW query stream (BASELINE configs[4] style)"}[wl], "n": n, "m": m,
-                   "queries_per_step": qps, "queries_in_flight": F, "distinct_queries": NQ, "distinct_interval_lists": NL,
+                   "queries_per_step": qps, "queries_in_flight": F,
+                   "host_threads": ("python (a profiler is attached)" if a.profiled else "python") if a.python_threads else "native (kvm_run_jobs)",
+                   "distinct_queries": NQ, "distinct_interval_lists": NL,
                    "candidates_per_query_per_gpu": my_cands,
                    "candidates_per_gpu": my_cands, "intervals_per_gpu": int(len(shards[0][0])), "epsilon": a.epsilon,
                    "early_abandon": False, "parallelism": f"candidate shards x{world}, series replicated",
