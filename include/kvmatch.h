@@ -195,7 +195,7 @@ void kvm_index_file_free(kvm_index_file *f);
  * terms a GPU call adds: C, its launch chain; D, the one unit of work that holds an answer and walks the whole window
  * (`length` points for the ED engines, one banded DP ~ length^2 for the DTW engines); E, the part of a candidate's cost
  * that does not grow with the query.  Constants fitted on an MI355X by
- * profiles/fit_cost_model.py -> profiles/r03_phase2_cost_model.json and compiled in from kv-match_amd/csrc/kvm_cost_model.inc
+ * profiles/fit_cost_model.py -> profiles/r04_phase2_cost_model.json and compiled in from kv-match_amd/csrc/kvm_cost_model.inc
  * (the Java constants are A = 4.07 / B = 0.27 for RSM-ED and 9.72 / 0.0107 for the others: five to six orders of magnitude
  * larger); tests/test_full_size_gpu.py::test_phase2_time_model_against_measured_calls holds the estimate to measured calls.
  * `variant`: 0 rsm_ed, 1 cnsm_ed, 2 rsm_dtw, 3 cnsm_dtw.  Pure function; < 0 for an unknown variant. */

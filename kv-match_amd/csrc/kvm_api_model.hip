@@ -8,7 +8,7 @@
 // from the series always has its self match) and walks the whole window -- m points for the ED engines, one banded DP of
 // m macro-steps x O(m) cells (rho = 5 percent of m) for the DTW engines -- and E, the part of a candidate's cost that does not
 // grow with m.  The constants are generated: profiles/fit_cost_model.py writes kvm_cost_model.inc next to
-// profiles/r03_phase2_cost_model.json (non-negative least squares on relative residuals, 27-48 (intervals, offsets, m) points
+// profiles/r04_phase2_cost_model.json (non-negative least squares on relative residuals, 27-48 (intervals, offsets, m) points
 // per variant on n = 1e8, early abandon on, selective queries, one MI355X): {C [ms], A [ms per interval], B [ms per 1e5
 // offset-points], D, E [ms per 1e5 offsets]}; tests/test_full_size_gpu.py holds the estimate to measured calls.
 extern "C" double kvm_phase2_time_estimate_ms(int32_t variant, int64_t disjoint_windows, int64_t candidate_offsets, int32_t length) {

@@ -17,7 +17,7 @@ up to 39 %.)
 
 fitted per variant on n = 1e8 with the reference's behaviour (early abandon on), by non-negative least squares on
 RELATIVE residuals (the estimate feeds a ratio test, so a 20 % miss matters equally at 0.2 ms and at 5 ms).
-Output: JSON on stdout (committed as profiles/r03_phase2_cost_model.json) and, with OUT_INC=<path>, the constants as a C
+Output: JSON on stdout (committed as profiles/r04_phase2_cost_model.json) and, with OUT_INC=<path>, the constants as a C
 initialiser (kv-match_amd/csrc/kvm_cost_model.inc, which kvm_phase2_time_estimate_ms includes: one source for the numbers;
 tests/test_full_size_gpu.py::test_phase2_time_model_against_measured_calls holds the estimate to measured calls)."""
 import json, os, sys, time
@@ -78,7 +78,7 @@ for name, r in rows.items():
 print(json.dumps(out, indent=1))
 if os.environ.get("OUT_INC"):
     with open(os.environ["OUT_INC"], "w") as f:
-        f.write("// generated by profiles/fit_cost_model.py (see profiles/r03_phase2_cost_model.json): {C [ms], A [ms per interval],\n"
+        f.write("// generated by profiles/fit_cost_model.py (see profiles/r04_phase2_cost_model.json): {C [ms], A [ms per interval],\n"
                 "// B [ms per 1e5 offset-points], D [ms per point (ED) | per m^2 / 1e3 (DTW)], E [ms per 1e5 offsets]} for rsm_ed, cnsm_ed, rsm_dtw, cnsm_dtw\n")
         for name in ("rsm_ed", "cnsm_ed", "rsm_dtw", "cnsm_dtw"):
             o = out[name]
