@@ -21,3 +21,11 @@ DP_FORM=3 SEED=9002 run python -u profiles/stress_adversarial.py 2
 SEED=9003 run python -u profiles/stress_dtw.py 60
 SEED=9004 run python -u profiles/stress_dtw.py 40
 fi
+if [ $PART = d ]; then   # (more seeds on the last build: the campaign, not the suite, found the row-bound tie)
+DP_FORM=0 SEED=31337 run python -u profiles/stress_adversarial.py 2
+DP_FORM=3 SEED=424242 run python -u profiles/stress_adversarial.py 2
+DP_FORM=2 SEED=777 run python -u profiles/stress_adversarial.py 2
+DP_FORM=0 SEED=5150 run python -u profiles/stress_adversarial.py 2
+SEED=8086 run python -u profiles/stress_dtw.py 60
+SEED=6502 run python -u profiles/stress_dtw.py 60
+fi
