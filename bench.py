@@ -87,7 +87,7 @@ def parse():
     # still gives the per-kernel summary of this very command, a profiled run drives its contexts from Python threads (the
     # line says so in `config.host_threads`; its stream rates are then the interpreter's, its kernel durations are not).
     a.profiled = any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", "")
-    if a.profiled and not a.python_threads:
+    if a.profiled and not a.python_threads and os.environ.get("KVM_BENCH_PROFILED_NATIVE") != "1":
         a.python_threads = 1
     return a
 

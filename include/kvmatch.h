@@ -197,7 +197,8 @@ void kvm_index_file_free(kvm_index_file *f);
  * that does not grow with the query.  Constants fitted on an MI355X by
  * profiles/fit_cost_model.py -> profiles/r04_phase2_cost_model.json and compiled in from kv-match_amd/csrc/kvm_cost_model.inc
  * (the Java constants are A = 4.07 / B = 0.27 for RSM-ED and 9.72 / 0.0107 for the others: five to six orders of magnitude
- * larger); tests/test_full_size_gpu.py::test_phase2_time_model_against_measured_calls holds the estimate to measured calls.
+ * larger); tests/test_zz_perf_gpu.py::test_phase2_time_model_against_measured_calls checks the estimate against
+ * measured calls on held-out shapes (it fails beyond twice the worst residual of the variant's own fit).
  * `variant`: 0 rsm_ed, 1 cnsm_ed, 2 rsm_dtw, 3 cnsm_dtw.  Pure function; < 0 for an unknown variant. */
 double kvm_phase2_time_estimate_ms(int32_t variant, int64_t disjoint_windows, int64_t candidate_offsets, int32_t length);
 /* The same with the number of candidates that reach the banded DP (KVM_STAT_PASS_LB_KEOGH2 of an earlier call on the same
@@ -269,7 +270,8 @@ typedef struct kvm_job {
  * kvm_share_series), one host thread per context, every thread taking the next job in order as soon as its context is
  * free -- exactly what n_ctx threads calling kvm_verify_* in a loop do, without a foreign-language driver between the
  * calls.  results[i] / status[i] receive job i's kvm_result (caller frees) and status; after a failing job no further
- * job is started.  Returns KVM_OK or the status of the first (lowest-index) job that failed. */
+ * job is started.  Returns KVM_OK or the status of the first (lowest-index) job that failed; that job's message is then
+ * what kvm_last_error(ctxs[0]) returns, whichever context ran it. */
 int kvm_run_jobs(kvm_ctx *const *ctxs, int32_t n_ctx, const kvm_job *jobs, int64_t n_jobs, kvm_result **results,
                  int32_t *status);
 

@@ -8,6 +8,16 @@
 
 static thread_local std::string g_open_err;
 
+// Every event / the stream a context owns, destroyed exactly once (kvm_open's failure paths and kvm_close share this list).
+static void destroy_events(kvm_ctx *ctx) {
+    hipEvent_t *evs[] = {&ctx->ev0, &ctx->ev1, &ctx->ev_staged, &ctx->ev_done, &ctx->ev_env};
+    for (hipEvent_t *e : evs) {
+        if (*e) hipEventDestroy(*e);
+        *e = nullptr;
+    }
+    if (ctx->stream) hipStreamDestroy(ctx->stream);
+    ctx->stream = nullptr;
+}
 
 int kvm_fail(kvm_ctx *ctx, int code, const std::string &msg) {
     if (ctx) ctx->err = msg; else g_open_err = msg;
@@ -68,11 +78,7 @@ extern "C" int kvm_open(int device, kvm_ctx **out) {
         (e = hipEventCreateWithFlags(&ctx->ev_staged, hipEventDisableTiming)) != hipSuccess ||
         (e = hipEventCreateWithFlags(&ctx->ev_done, hipEventDisableTiming)) != hipSuccess) {
         std::string msg = std::string("kvm_open: ") + hipGetErrorString(e);
-        if (ctx->ev0) hipEventDestroy(ctx->ev0);
-        if (ctx->ev1) hipEventDestroy(ctx->ev1);
-        if (ctx->ev_staged) hipEventDestroy(ctx->ev_staged);
-        if (ctx->ev_done) hipEventDestroy(ctx->ev_done);
-        if (ctx->stream) hipStreamDestroy(ctx->stream);
+        destroy_events(ctx);
         delete ctx;
         return kvm_fail(nullptr, KVM_ERR_DEVICE, msg);
     }
@@ -81,12 +87,7 @@ extern "C" int kvm_open(int device, kvm_ctx **out) {
         ctx->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         if (std::strstr(prop.gcnArchName, "gfx950") == nullptr) {
             std::string msg = std::string("kvm_open: built for gfx950 only, device is ") + prop.gcnArchName;
-            hipEventDestroy(ctx->ev0);
-            hipEventDestroy(ctx->ev1);
-            hipEventDestroy(ctx->ev_staged);
-    hipEventDestroy(ctx->ev_done);
-            hipEventDestroy(ctx->ev_done);
-            hipStreamDestroy(ctx->stream);
+            destroy_events(ctx);
             delete ctx;
             return kvm_fail(nullptr, KVM_ERR_DEVICE, msg);
         }
@@ -125,11 +126,7 @@ extern "C" int kvm_close(kvm_ctx *ctx) {
     if (ctx->h_readback) hipHostFree(ctx->h_readback);
     if (ctx->h_readback2) hipHostFree(ctx->h_readback2);
     kvm_idx_block_drop();
-    hipEventDestroy(ctx->ev0);
-    hipEventDestroy(ctx->ev1);
-    hipEventDestroy(ctx->ev_staged);
-    if (ctx->ev_env) hipEventDestroy(ctx->ev_env);
-    hipStreamDestroy(ctx->stream);
+    destroy_events(ctx);
     delete ctx;
     return KVM_OK;
 }

@@ -5,23 +5,117 @@
 // threads of kvmatch.QueryStream peak at 80 us per call of an early-abandoning RSM-ED stream, these threads at 54 - 60
 // (profiles/r04_stream_native_0.log).
 #include <atomic>
-#include <exception>
-#include <new>
 #include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <exception>
+#include <functional>
+#include <mutex>
+#include <new>
 #include <thread>
 #include <vector>
 
+#include <pthread.h>
+
+#include <string>
+
 #include "../../include/kvmatch.h"
 
-// The helper threads of a call.  Joined on every path out of it: a std::thread that is still joinable when it is destroyed
-// ends the process (std::terminate), and the C ABI must hand back a status instead -- e.g. when the third of eight threads
-// cannot be started (std::system_error) while two are already running.
-struct thread_group {
-    std::vector<std::thread> th;
-    ~thread_group() {
-        for (auto &x : th)
-            if (x.joinable()) x.join();
+struct kvm_ctx;
+void kvm_set_error_noexcept(kvm_ctx *ctx, const char *msg) noexcept;  // kvm_api.hip
+
+// The helper threads of a call are PERSISTENT (round 5): a process-wide pool of workers that sleep between calls, grown on
+// demand and never shrunk.  Rounds 4's form started n_ctx - 1 fresh std::threads per kvm_run_jobs call and joined them at
+// its end; every such thread initialises its own HIP thread state on its first launch and tears it down when it exits, and
+// a tool that hooks the runtime (rocprofv3's kernel tracing) registers / drops per-thread buffers at the same two points --
+// hundreds of times in a bench run.  With workers that live as long as the process, that happens once per worker.
+// A call hands its loops to the pool and waits for all of them on every path out (thread_group's destructor): the loops
+// reference the call's stack frame.  If a worker cannot be started (std::system_error) the loops already handed over are
+// told to stop by the caller's flag and waited for; the C ABI hands back a status.
+namespace {
+class worker_pool {
+public:
+    struct ticket {   // one per call: how many of its loops are still running
+        std::mutex mu;
+        std::condition_variable cv;
+        int pending = 0;
+    };
+    // runs fn on a pool thread; throws (std::system_error / std::bad_alloc) if no worker can be had
+    void submit(ticket &t, std::function<void()> fn) {
+        std::unique_lock<std::mutex> lk(mu_);
+        // every queued task needs a sleeping worker of its own (a worker that has been notified but has not woken yet still
+        // counts as sleeping, and its task is still queued); busy workers are not counted on
+        if ((int)q_.size() + 1 > waiting_) {
+            std::thread th([this] { work(); });   // may throw: nothing has been queued yet
+            th.detach();                          // (lives until the process ends; it only ever blocks on cv_)
+        }
+        q_.push_back(task{&t, std::move(fn)});    // (may throw: a worker started above just goes to sleep)
+        {
+            std::lock_guard<std::mutex> tl(t.mu);
+            t.pending++;
+        }
+        lk.unlock();
+        cv_.notify_one();
     }
+    static void wait(ticket &t) {
+        std::unique_lock<std::mutex> lk(t.mu);
+        t.cv.wait(lk, [&] { return t.pending == 0; });
+    }
+    static worker_pool &get() {
+        // never destroyed: its threads may outlive static destruction.  A fork()ed child inherits the object but none of
+        // its threads (and possibly a locked mutex): it starts over with an empty pool of its own.
+        static std::once_flag once;
+        std::call_once(once, [] {
+            instance() = new worker_pool();
+            pthread_atfork(nullptr, nullptr, [] { instance() = new worker_pool(); });
+        });
+        return *instance();
+    }
+
+private:
+    static worker_pool *&instance() {
+        static worker_pool *p = nullptr;
+        return p;
+    }
+    struct task {
+        ticket *t;
+        std::function<void()> fn;
+    };
+    void work() {
+        std::unique_lock<std::mutex> lk(mu_);
+        for (;;) {
+            if (q_.empty()) {
+                waiting_++;
+                cv_.wait(lk, [&] { return !q_.empty(); });
+                waiting_--;
+            }
+            task k = std::move(q_.front());
+            q_.pop_front();
+            lk.unlock();
+            try {
+                k.fn();
+            } catch (...) {  // (the loops catch their own; nothing may escape a detached thread)
+            }
+            {
+                std::lock_guard<std::mutex> tl(k.t->mu);
+                k.t->pending--;
+                // notify under the lock: the waiter owns the ticket and may destroy it as soon as it sees pending == 0
+                k.t->cv.notify_all();
+            }
+            lk.lock();
+        }
+    }
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::deque<task> q_;
+    int waiting_ = 0;   // workers asleep in cv_.wait
+};
+}  // namespace
+
+struct thread_group {
+    worker_pool::ticket t;
+    void start(std::function<void()> fn) { worker_pool::get().submit(t, std::move(fn)); }
+    ~thread_group() { worker_pool::wait(t); }
 };
 
 static int run_one(kvm_ctx *c, const kvm_job &j, kvm_result **r) {
@@ -47,37 +141,63 @@ extern "C" int kvm_run_jobs(kvm_ctx *const *ctxs, int32_t n_ctx, const kvm_job *
         std::atomic<int64_t> next{0};
         std::atomic<bool> failed{false};
         std::vector<int> rcs((size_t)n_jobs, KVM_OK);
-        auto loop = [&](kvm_ctx *c) {
+        // A failing job's message lives in the context that ran it (a context's text is not cleared by later successes, and
+        // another context may still carry the text of a failure handled long ago): every thread keeps the message of ITS
+        // lowest-index failure, and the one of the call's first failing job is copied to ctxs[0] below -- that is where
+        // a caller reads kvm_last_error after kvm_run_jobs.
+        std::vector<int64_t> bad_job((size_t)n_ctx, -1);
+        std::vector<std::string> bad_msg((size_t)n_ctx);
+        auto loop = [&](int32_t t) {
+            kvm_ctx *c = ctxs[t];
             for (;;) {
                 if (failed.load(std::memory_order_relaxed)) return;
                 const int64_t i = next.fetch_add(1);
                 if (i >= n_jobs) return;
                 const int rc = run_one(c, jobs[i], &results[i]);
                 rcs[(size_t)i] = rc;
-                if (rc != KVM_OK) failed.store(true);
+                if (rc != KVM_OK) {
+                    failed.store(true);
+                    if (bad_job[(size_t)t] < 0) {
+                        bad_job[(size_t)t] = i;
+                        try {
+                            bad_msg[(size_t)t] = kvm_last_error(c);
+                        } catch (...) {  // (no memory for the text: the status has to do)
+                        }
+                    }
+                }
             }
         };
         const int32_t nt = (int32_t)(n_jobs < n_ctx ? (n_jobs > 0 ? n_jobs : 1) : n_ctx);
         {
             thread_group g;
-            g.th.reserve((size_t)nt);
             try {
-                for (int32_t t = 1; t < nt; t++) g.th.emplace_back(loop, ctxs[t]);
+                for (int32_t t = 1; t < nt; t++) g.start([&loop, t] { loop(t); });
             } catch (...) {
                 failed.store(true);  // the threads that did start take no further job; ~thread_group joins them
                 throw;
             }
-            loop(ctxs[0]);  // the calling thread drives the first context
+            loop(0);  // the calling thread drives the first context
         }
         int first = KVM_OK;
+        int64_t first_job = -1;
         for (int64_t i = 0; i < n_jobs; i++) {
             if (status) status[i] = rcs[(size_t)i];
-            if (first == KVM_OK && rcs[(size_t)i] != KVM_OK) first = rcs[(size_t)i];
+            if (first == KVM_OK && rcs[(size_t)i] != KVM_OK) {
+                first = rcs[(size_t)i];
+                first_job = i;
+            }
         }
+        for (int32_t t = 1; t < n_ctx && first_job >= 0; t++)   // (t = 0: the text is where it belongs already)
+            if (bad_job[(size_t)t] == first_job) kvm_set_error_noexcept(ctxs[0], bad_msg[(size_t)t].c_str());
         return first;
     } catch (const std::bad_alloc &) {
+        kvm_set_error_noexcept(ctxs[0], "kvm_run_jobs: out of host memory (std::bad_alloc)");
         return KVM_ERR_NO_MEMORY;
-    } catch (const std::exception &) {  // (std::system_error from a thread that could not be started)
+    } catch (const std::exception &e) {  // (std::system_error from a thread that could not be started)
+        kvm_set_error_noexcept(ctxs[0], e.what());
+        return KVM_ERR_DEVICE;
+    } catch (...) {  // nothing foreign crosses the C ABI (kvm_guard.h)
+        kvm_set_error_noexcept(ctxs[0], "kvm_run_jobs: unknown C++ exception");
         return KVM_ERR_DEVICE;
     }
 }
@@ -127,9 +247,8 @@ extern "C" int kvm_run_device_jobs(const kvm_device_slot *slots, int32_t n_slots
         };
         {
             thread_group g;
-            g.th.reserve((size_t)n_slots);
             try {
-                for (int32_t t = 1; t < n_slots; t++) g.th.emplace_back(loop, t);
+                for (int32_t t = 1; t < n_slots; t++) g.start([&loop, t] { loop(t); });
             } catch (...) {
                 abort.store(true);
                 throw;
@@ -140,6 +259,8 @@ extern "C" int kvm_run_device_jobs(const kvm_device_slot *slots, int32_t n_slots
     } catch (const std::bad_alloc &) {
         return KVM_ERR_NO_MEMORY;
     } catch (const std::exception &) {
+        return KVM_ERR_DEVICE;
+    } catch (...) {  // nothing foreign crosses the C ABI (kvm_guard.h)
         return KVM_ERR_DEVICE;
     }
 }

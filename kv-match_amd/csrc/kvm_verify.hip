@@ -23,6 +23,10 @@ enum { V_RSM_ED = 0, V_CNSM_ED = 1, V_RSM_DTW = 2, V_CNSM_DTW = 3 };
 // may have been built on ANOTHER stream by an earlier kvm_verify_device call that returned without synchronising: the
 // event recorded behind the build orders this call's stream after it.
 static int ensure_envelope(kvm_ctx *ctx, int32_t rho, hipStream_t stream) {
+    // An earlier kvm_verify_device call may still be running on ANOTHER stream and reading the envelope arrays (run_variant
+    // has made its own stream wait already and cleared the flag; kvm_data_envelope comes here directly): order this stream
+    // behind it on the device before anything below can rebuild them.
+    if (ctx->done_pending && ctx->done_stream != stream) HIPCHK(ctx, hipStreamWaitEvent(stream, ctx->ev_done, 0));
     if (ctx->env_rho == rho && ctx->d_env_u) {
         if (ctx->ev_env && ctx->env_stream != stream) HIPCHK(ctx, hipStreamWaitEvent(stream, ctx->ev_env, 0));
         return KVM_OK;
@@ -32,8 +36,8 @@ static int ensure_envelope(kvm_ctx *ctx, int32_t rho, hipStream_t stream) {
         HIPCHK(ctx, hipMalloc((void **)&ctx->d_env_l, (size_t)ctx->n * 8));
     }
     ctx->env_rho = -1;
-    // (a rebuild for another rho overwrites arrays the previous call's kernels may still be reading on another stream:
-    // run_variant has already waited for that call's ev_staged, which is recorded behind all of them)
+    // (a rebuild for another rho overwrites arrays the previous call's kernels may still be reading on another stream: this
+    // stream has been ordered behind that call's ev_done -- recorded on every exit of kvm_verify_device -- above or in run_variant)
     HIPCHK(ctx, kvm_launch_envelope(ctx->d_series, ctx->n, rho, ctx->d_env_u, ctx->d_env_l, stream));
     if (!ctx->ev_env) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_env, hipEventDisableTiming));
     HIPCHK(ctx, hipEventRecord(ctx->ev_env, stream));
@@ -742,12 +746,33 @@ extern "C" int kvm_verify_device(kvm_ctx *ctx, int32_t variant, const double *qu
     if (variant < 0 || variant > 3 || !d_out_off || !d_out_dist || !d_out_count || cap < 0)
         return kvm_fail(ctx, KVM_ERR_ILLEGAL_ARGUMENT, "bad kvm_verify_device arguments");
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    // Everything this call enqueues -- the pipeline, the sequential tie path's kernels, the copy of the answer count out of
+    // the counters -- reads the context's device scratch: the next call, possibly on another stream, must be ordered behind
+    // all of it before it reuses the buffers.  That is a device-side wait on ev_done (run_variant, ensure_envelope), so the
+    // event is recorded on EVERY way out of this call, a failure half-way down the pipeline included (its kernels are still
+    // running); the HOST only ever waits for ev_staged, recorded behind the last read of the pinned staging buffer, so it
+    // can prepare the next call while this one still runs.
+    struct done_guard {
+        kvm_ctx *c;
+        hipStream_t s;
+        bool armed;
+        ~done_guard() {
+            if (armed && hipSetDevice(c->device) == hipSuccess && hipEventRecord(c->ev_done, s) == hipSuccess) {
+                c->done_stream = s;
+                c->done_pending = true;
+            }
+        }
+    };
     plan pl;
     verify_out out{d_out_off, d_out_dist, cap, false};
     kvm_query_dev dtw_qd;
     kvm_dtw_aux dtw_ax;
+    // (run_variant clears done_pending once this call's stream is ordered behind the previous call, before it enqueues
+    // anything: a failure that leaves the flag set -- an argument error -- has enqueued nothing, and the previous call's
+    // mark must stay in place)
     int rc = run_variant(ctx, variant, query, m, left, right, k, shift, epsilon, rho, alpha, beta, pl, out, s, nullptr, dtw_qd,
                          dtw_ax);
+    done_guard guard{ctx, s, rc == KVM_OK || !ctx->done_pending};
     if (rc) return rc;
     if (cnt_candidate) *cnt_candidate = pl.cnt_candidate;
     if (variant >= V_RSM_DTW && pl.n_tiles + pl.n_tiles_b + pl.n_tiles_c > 0) {
@@ -765,15 +790,7 @@ extern "C" int kvm_verify_device(kvm_ctx *ctx, int32_t variant, const double *qu
         HIPCHK(ctx, hipMemcpyAsync(d_out_count, (unsigned long long *)ctx->b_counters.p + KVM_CNT_ANSWERS,
                                    sizeof(int64_t), hipMemcpyDeviceToDevice, s));
     }
-    // Everything this call has enqueued -- the pipeline, the sequential tie path's kernels, the copy of the answer count out
-    // of the counters -- reads the context's device scratch: the next call, possibly on another stream, must be ordered
-    // behind all of it before it reuses the buffers.  That is a device-side wait on ev_done (run_variant); the HOST only
-    // ever waits for ev_staged, recorded behind the last read of the pinned staging buffer, so it can prepare the next
-    // call while this one still runs.
-    HIPCHK(ctx, hipEventRecord(ctx->ev_done, s));
-    ctx->done_stream = s;
-    ctx->done_pending = true;
-    return KVM_OK;
+    return KVM_OK;   // (~done_guard records ev_done behind everything enqueued above)
     });
 }
 

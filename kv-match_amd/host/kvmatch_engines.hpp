@@ -162,9 +162,7 @@ public:
         const int rc = kvm_run_jobs(ctxs_.data(), (int32_t)ctxs_.size(), jobs.data(), (int64_t)jobs.size(), res.data(), st.data());
         if (rc != KVM_OK) {
             for (kvm_result *r : res) kvm_result_free(r);
-            for (kvm_ctx *c : ctxs_)   // (the message lives in the context that ran the failing job)
-                if (kvm_last_error(c)[0]) Phase2Context::check(rc, c);
-            Phase2Context::check(rc, nullptr);
+            Phase2Context::check(rc, ctxs_[0]);   // (kvm_run_jobs leaves the first failing job's message in the first context)
         }
         std::vector<Answers> out;
         out.reserve(res.size());

@@ -420,11 +420,9 @@ class QueryStream:
                 if r:
                     lib.kvm_result_free(r)
             bad = next((i for i in range(n) if st[i]), None)
-            # (the message lives in the context that ran the job; which one is not recorded: try them all)
-            for c in self.ctxs:
-                msg = lib.kvm_last_error(c._h)
-                if msg:
-                    _lib.check(rc, c._h)
+            # (kvm_run_jobs leaves the first failing job's message in the first context, whichever context ran the job:
+            # a context's own text may be that of a failure handled long ago)
+            _lib.check(rc, self.ctxs[0]._h)
             raise _lib.KvMatchDeviceError(f"[{rc}] job {bad} failed")
         if collect is None:
             return [self.ctxs[0]._collect(C.c_void_p(r)) for r in res]

@@ -240,6 +240,25 @@ def test_ed_launch_model_on_the_cpu(tmp_path):
     assert r.returncode == 0 and "FAIL" not in r.stdout and r.stdout.count("ok  ") >= 13, r.stdout + r.stderr[-2000:]
 
 
+def test_stream_host_layer_under_thread_and_address_sanitizers(tmp_path):
+    """kvm_stream.cpp (kvm_run_jobs, kvm_run_device_jobs, the persistent worker pool) is host-only code that several threads
+    run through at once: compiled as it is -- with stand-ins for the library entry points its loops call
+    (tests/harness/stream_harness.cpp) -- under ThreadSanitizer and under ASan + UBSan.  Checked: a context is never
+    entered twice at once, results and statuses per job, the first failing job's text ends up in the first context,
+    several callers share the pool, the produced / consumed hand-shake of the device-resident form incl. a failing slot, and
+    a fork()ed child gets a pool of its own."""
+    import subprocess
+    src = [os.path.join(ROOT, "tests", "harness", "stream_harness.cpp"), os.path.join(ROOT, "kv-match_amd", "csrc", "kvm_stream.cpp")]
+    for san, arg, checks in (("thread", "tsan", 5), ("address,undefined", "fork", 6)):
+        exe = tmp_path / ("stream_harness_" + arg)
+        r = subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-fsanitize=" + san,
+                            "-fno-sanitize-recover=all", "-pthread", "-o", str(exe)] + src, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        r = subprocess.run([str(exe), arg], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and "FAIL" not in r.stdout and r.stdout.count("ok  ") == checks, r.stdout + r.stderr[-3000:]
+        assert "WARNING: ThreadSanitizer" not in r.stderr and "ERROR: AddressSanitizer" not in r.stderr, r.stderr[-3000:]
+
+
 def test_sort_and_merge_intervals_is_the_reference_step_between_the_phases(built):
     """kvm_sort_and_merge_intervals (host only) == QueryEngine.sortAndMergeIntervals (K/QueryEngine.java:664-693)."""
     import numpy as np

@@ -1606,6 +1606,13 @@ def test_run_jobs_is_the_same_stream_in_native_threads(world):
             with pytest.raises(kvmatch.KvMatchIllegalArgument):
                 qs.run_jobs([mk[0](), bad, mk[0]()])
             compare(qs.run_jobs([mk[0]()])[0], want[0], tag="after a failed stream")
+            # the text raised is the failing job's own, whichever context ran it -- not what the failure above left in one
+            # of the contexts (kvm_run_jobs hands the first failing job's message to the first context)
+            for pos in range(5):
+                stream = [mk[0]() for _ in range(5)]
+                stream[pos] = kvmatch.Job(1, (L, R), 1, q, 3.0, alpha=-1.0, beta=2.0)
+                with pytest.raises(kvmatch.KvMatchIllegalArgument, match="alpha must be > 0"):
+                    qs.run_jobs(stream)
         finally:
             qs.close()
     finally:
