@@ -38,6 +38,9 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <mutex>
+#include <type_traits>
+#include <utility>
 
 typedef double ed4_d2 __attribute__((ext_vector_type(2)));
 
@@ -79,6 +82,49 @@ __device__ __forceinline__ void edd_fmac_bc(double &acc, double q16, double w, i
 #define EDD_RING_D 4                         // blocks a global load is issued ahead of its LDS write
 typedef double ed4_d2u __attribute__((ext_vector_type(2), aligned(8)));
 
+// ---- class A with SIXTEEN candidates per lane (round 5; every-point evaluation only): 16 rows x 4 lanes x 16 candidates ----
+// The same 64-candidate tiles, but half the bytes per FMA come back from the LDS into the VGPRs -- and those returns, not the
+// LDS array, are what takes issue slots from the FMAs (profiles/r03_ed_loop_variants.log; profiles/r05_ed_a16.log: 58.3
+// against 49.8 TFLOP/s for the 8-per-lane loop on one box, the library's full tiles at 47.4).
+//   * lane -> (row, lane in row): lc = lane >> 4, row = (lane & 15) ^ ((lane >> 1) & 8); rows EDD16_ROW_B = 1040 bytes apart.
+//     Every hardware lane group of ds_read_b128 ({0-3,12-15,20-27}, {4-11,16-19,28-31}, ...) then covers 16 distinct 16-byte
+//     slots: slot = row + 8 lc (mod 16) = lane & 15.
+//   * a row of the wave's LDS is a plain circular ring of 128 points = one chunk; no lookahead copy: a lane's read pointer is
+//     a VGPR + an immediate, and each of the four lane classes steps its pointer back by the ring's length at ONE known
+//     sub-step of the revolution (pair k of a revolution sits at 8 (16 lc + 20) + 16 k bytes: lc's pointer passes the end
+//     at k = 54 - 8 lc, i.e. at sub-step 27 - 4 lc).
+//   * stream staging: per 16-point block a lane fetches the 4 points 4 lc .. 4 lc + 3 of its row's block, two blocks ahead of
+//     the LDS write; block b of the next revolution is written at sub-step 4 b (its old content died at sub-step 4 b - 2:
+//     lane class 0's last read of it; lane class 3 reads the new content from sub-step 4 b + 15 on).
+//   * the query values need no LDS at all: one 8-byte global load per lane and block (qc is 64 KB, every wave reads it: L2),
+//     then v_fmac_f64_dpp row_newbcast as in the other classes.
+//   * a window that does not end on a chunk boundary runs its last revolution to the end: qc is followed by KVM_SERIES_PAD
+//     zeros, so the extra terms are x * 0 (a NaN / Inf there makes the sum NaN, which keeps the candidate for the exact pass).
+#define EDD16_ROWS 16
+#define EDD16_ROW_B 1040                     // bytes: 1024 of ring + one 16-byte slot of skew
+#define EDD16_WAVE_B (EDD16_ROWS * EDD16_ROW_B)
+#define EDD16_RINGP 16                       // register ring, pairs: sub-step G holds pairs 2G .. 2G + 9, loads 2G + 10, 2G + 11
+#ifndef EDD16_AHEAD
+#define EDD16_AHEAD 4                        // blocks a global load is issued ahead of its LDS write (1, 2 or 4)
+#endif
+#ifndef EDD_A16
+#define EDD_A16 1                            // 0: class A on 8 lanes x 8 candidates in every mode (rounds 2 - 4)
+#endif
+template <int K>
+__device__ __forceinline__ void edd_fmac_bcK(double &acc, double q16, double w) {
+    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(q16), "v"(w), "n"(K));
+}
+// compile-time loops: every register index and LDS offset of the 16-per-lane loop is a constant EXPRESSION (with 16
+// accumulators, "constant after unrolling" left the register ring in scratch memory: 1.9 TFLOP/s)
+template <int... I, class F>
+__device__ __forceinline__ void edd_static_for_impl(std::integer_sequence<int, I...>, F &&f) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void edd_static_for(F &&f) {
+    edd_static_for_impl(std::make_integer_sequence<int, N>{}, f);
+}
+
 #define EDD_ROWS 8
 #define EDD_ROWLEN 192                       // staged points per row per chunk (both configurations)
 #define EDD_LOADS (EDD_ROWLEN / 64)
@@ -100,14 +146,16 @@ static_assert(EDD_RING_LEN == ED8_JC && EDD_RING_LEN + EDD_RING_AHEAD + 6 <= EDD
 template <int CI, int SUB>
 struct edd_cfg {
     // (class B: 128 like class A when its rows are staged as a stream -- one revolution of the ring --, 160 in the chunked form)
-    static constexpr int JC = CI == 8 ? ED8_JC : (SUB == 2 ? (EDD_RING_C ? ED8_JC : ED16_JC) : (EDD_RING_B ? ED8_JC : ED4_JC));
+    static constexpr int JC = CI >= 8 ? ED8_JC : (SUB == 2 ? (EDD_RING_C ? ED8_JC : ED16_JC) : (EDD_RING_B ? ED8_JC : ED4_JC));
     static constexpr bool PREF8 = JC == ED8_JC;   // chunk prefix sums of the query at ED8_JC granularity
-    static constexpr int TILE = 8 * CI / SUB;            // candidates per tile: 64 / 32 / 16
-    static constexpr int TPU = EDD_ROWS * SUB;           // tiles per unit (= per wavefront)
+    static constexpr int TILE = CI == 16 ? 64 : 8 * CI / SUB;                  // candidates per tile: 64 / 32 / 16
+    static constexpr int TPU = CI == 16 ? EDD16_ROWS : EDD_ROWS * SUB;         // tiles per unit (= per wavefront)
+    static constexpr int WAVE_DOUBLES = CI == 16 ? EDD16_WAVE_B / 8 : EDD_WAVE_LDS;   // a wave's LDS region
     static constexpr int QS = PREF8 ? 1 : JC / ED16_JC;  // stride of a chunk in the q_pref array it reads
     __device__ static constexpr int row_shift(int r) { return CI == 8 ? (r & 3) * 2 : ((r >> 1) & 1) * 2; }  // doubles
 };
 #define EDD_TILES_A (EDD_ROWS)
+#define EDD_TILES_A16 (EDD16_ROWS)
 #define EDD_TILES_B (EDD_ROWS)
 #define EDD_TILES_C (EDD_ROWS * 2)
 
@@ -142,9 +190,11 @@ __device__ __forceinline__ void edd_body(const edd_args &A, const kvm_tile *__re
     using cfg = edd_cfg<CI, SUB>;
     constexpr int JC = cfg::JC;
     const int lane = threadIdx.x & 63;
-    const int row = lane >> 3;
+    constexpr bool RING16 = CI == 16;                   // 16 rows x 4 lanes x 16 candidates (see EDD16_*)
+    static_assert(!RING16 || SUB == 1, "one tile per row");
+    const int row = RING16 ? ((lane & 15) ^ ((lane >> 1) & 8)) : lane >> 3;
     const int sub = SUB == 2 ? ((lane >> 2) & 1) : 0;   // which of the row's tiles this lane works on
-    const int lc = SUB == 2 ? (lane & 3) : (lane & 7);  // lane within the tile
+    const int lc = RING16 ? lane >> 4 : (SUB == 2 ? (lane & 3) : (lane & 7));  // lane within the tile
     const kvm_query_dev &qd = A.qd;
     const int m = qd.m;
     const double eps2 = qd.eps2;
@@ -161,7 +211,9 @@ __device__ __forceinline__ void edd_body(const edd_args &A, const kvm_tile *__re
     // wave-uniform tile descriptors (for staging): in registers, or (class C: 16 of them) in the wave's LDS ...
     int32_t rstart[EDD_ROWS];
     double rshift[EDD_ROWS];
-    if constexpr (SUB == 1) {
+    if constexpr (RING16) {
+        // (stream staging only: every lane stages pieces of its own row)
+    } else if constexpr (SUB == 1) {
 #pragma unroll
         for (int r = 0; r < EDD_ROWS; r++) {
             rstart[r] = (t0 + r < n_tiles) ? tiles[t0 + r].start : 1;  // empty rows stage from the head of the series
@@ -433,8 +485,40 @@ __device__ __forceinline__ void edd_body(const edd_args &A, const kvm_tile *__re
         if (ring) *reinterpret_cast<ed4_d2 *>(wdstC[sb] + pos) = v;
         if (ahead) *reinterpret_cast<ed4_d2 *>(wdstC[sb] + EDD_RINGC_LEN + pos) = v;
     };
+    // ---- stream staging, 16 candidates per lane: lane (row, lc) stages points 4 lc .. 4 lc + 3 of every 16-point block of its row
+    char *const rowp16 = reinterpret_cast<char *>(lds_wave2) + row * EDD16_ROW_B;
+    const double *gsrc16 = series + ((int64_t)mine.start - 1 + 4 * lc);   // + window point of the block
+    char *const wdst16 = rowp16 + 32 * lc;                                  // + 128 x (block of the ring)
+    auto ld16 = [&](int j, ed4_d2 &u, ed4_d2 &v) {   // (unguarded: the series is padded, KVM_SERIES_PAD)
+        const ed4_d2u a = *reinterpret_cast<const ed4_d2u *>(gsrc16 + j), b = *reinterpret_cast<const ed4_d2u *>(gsrc16 + j + 2);
+        u = ed4_d2{a.x, a.y};
+        v = ed4_d2{b.x, b.y};
+    };
+    auto wr16 = [&](int b, ed4_d2 u, ed4_d2 v) {
+        u.x -= c_row; u.y -= c_row; v.x -= c_row; v.y -= c_row;
+        *reinterpret_cast<ed4_d2 *>(wdst16 + 128 * b) = u;
+        *reinterpret_cast<ed4_d2 *>(wdst16 + 128 * b + 16) = v;
+    };
+    ed4_d2 pend16[EDD16_AHEAD][2], R16[EDD16_RINGP];   // blocks fetched and not yet written; the window registers (carried from chunk to chunk)
+    static_assert(EDD16_AHEAD == 1 || EDD16_AHEAD == 2 || EDD16_AHEAD == 4, "8 blocks per revolution: static register indices");
+    double qq16[2];                          // query values of the block in hand and of the next: qc[j + (lane & 15)]
     if (work && ch_lo < ch_hi) {
-        if constexpr (RINGC) {
+        if constexpr (RING16) {
+            const int jb = ch_lo * JC;
+            {
+                ed4_d2 u[8], v[8];
+#pragma unroll
+                for (int b = 0; b < 8; b++) ld16(jb + 16 * b, u[b], v[b]);
+                qq16[0] = qc[jb + (lane & 15)];
+#pragma unroll
+                for (int i = 0; i < EDD16_AHEAD; i++) ld16(jb + 128 + 16 * i, pend16[i][0], pend16[i][1]);
+#pragma unroll
+                for (int b = 0; b < 8; b++) wr16(b, u[b], v[b]);
+            }
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < 10; i++) R16[i] = *reinterpret_cast<const ed4_d2 *>(rowp16 + 128 * lc + 16 * i);
+        } else if constexpr (RINGC) {
             const int jb = ch_lo * JC;
             ed4_d2 p3[2][3];
 #pragma unroll
@@ -475,9 +559,48 @@ __device__ __forceinline__ void edd_body(const edd_args &A, const kvm_tile *__re
     for (int ch = ch_lo; work && ch < ch_hi; ch++) {
         const int j0 = ch * JC;
         const bool more = ch + 1 < ch_hi;
-        if (!RINGED && !RINGC && more) load_chunk(j0 + JC);
+        if (!RINGED && !RINGC && !RING16 && more) load_chunk(j0 + JC);
         const int jlim = min(JC, m - j0);
-        if (RINGC) {
+        if constexpr (RING16) {
+            {
+                // One revolution of the ring = one chunk of 128 points = 32 sub-steps of 4 points, as compile-time loops.  Sub-step
+                // G holds the window pairs 2G .. 2G + 9 of its lane (positions 16 lc + 4G .. + 19) in R16[(2G + i) % 16] and
+                // fetches pairs 2G + 10, 2G + 11 for the next; the last five sub-steps fetch what the next revolution starts with.
+                const char *P = rowp16 + 128 * lc + 160;   // pair k of this revolution: P + 16 k (see EDD16_ROW_B)
+                edd_static_for<32>([&](auto Gc) {
+                    constexpr int G = decltype(Gc)::value;
+                    if constexpr (G % 4 == 0) {
+                        constexpr int b = G / 4;
+                        // (vector-memory loads return in order: the query value is needed one block on, the window points
+                        // EDD16_AHEAD blocks on -- issued behind it, they may stay in flight when the wait for it comes)
+                        qq16[(b + 1) & 1] = qc[j0 + 16 * (b + 1) + (lane & 15)];
+                        wr16(b, pend16[b % EDD16_AHEAD][0], pend16[b % EDD16_AHEAD][1]);
+                        ld16(j0 + 128 + 16 * (b + EDD16_AHEAD), pend16[b % EDD16_AHEAD][0], pend16[b % EDD16_AHEAD][1]);
+                    }
+                    if constexpr (G == 27 || G == 23 || G == 19 || G == 15) {
+                        constexpr int cls = (27 - G) / 4;
+                        P = (lc == cls) ? P - 1024 : P;
+                    }
+                    R16[(2 * G + 10) % EDD16_RINGP] = *reinterpret_cast<const ed4_d2 *>(P + 16 * (2 * G));
+                    R16[(2 * G + 11) % EDD16_RINGP] = *reinterpret_cast<const ed4_d2 *>(P + 16 * (2 * G + 1));
+                    // fence: the reads above stay above it (memory clobber), the FMAs below it (accumulator operands)
+                    asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]),
+                                 "+v"(acc[7]), "+v"(acc[8 % CI]), "+v"(acc[9 % CI]), "+v"(acc[10 % CI]), "+v"(acc[11 % CI]), "+v"(acc[12 % CI]),
+                                 "+v"(acc[13 % CI]), "+v"(acc[14 % CI]), "+v"(acc[15 % CI])::"memory");
+                    const double q16 = qq16[(G / 4) & 1];
+                    edd_static_for<4>([&](auto kc) {
+                        constexpr int k = decltype(kc)::value;
+                        edd_static_for<CI>([&](auto ac) {
+                            constexpr int a = decltype(ac)::value;
+                            constexpr int i = a + k;   // w[i] = X[c0 + 4G + i]
+                            const ed4_d2 &pr = R16[(2 * G + i / 2) % EDD16_RINGP];
+                            edd_fmac_bcK<4 * (G & 3) + k>(acc[a], q16, (i & 1) ? pr.y : pr.x);
+                        });
+                    });
+                });
+                (void)jlim;
+            }
+        } else if (RINGC) {
             if constexpr (RINGC) {
                 // One chunk of 128 points = two revolutions of the half rows' rings = 8 blocks of 16 points; at the start the
                 // half rows hold [j0, j0 + 48).  Block B's turn writes points [j0 + 16 (B + 3), + 16) of both tiles -- fetched four
@@ -772,7 +895,7 @@ __device__ __forceinline__ void edd_body(const edd_args &A, const kvm_tile *__re
                     break;  // split unit: the other parts wait at the barrier below
                 }
             }
-            if (!RINGED && !RINGC) store_chunk();
+            if (!RINGED && !RINGC && !RING16) store_chunk();
         }
     }
     if (f > 1) {
@@ -786,8 +909,8 @@ __device__ __forceinline__ void edd_body(const edd_args &A, const kvm_tile *__re
         if (part > 0 || !work) return;
         for (int p = 1; p < f; p++) {
 #pragma unroll
-            for (int a = 0; a < CI; a++) acc[a] += wlds[p * EDD_WAVE_LDS + a * 64 + lane];
-            if (ABANDON) vm &= reinterpret_cast<const unsigned *>(wlds + p * EDD_WAVE_LDS + CI * 64)[lane];
+            for (int a = 0; a < CI; a++) acc[a] += wlds[p * cfg::WAVE_DOUBLES + a * 64 + lane];
+            if (ABANDON) vm &= reinterpret_cast<const unsigned *>(wlds + p * cfg::WAVE_DOUBLES + CI * 64)[lane];
         }
     } else if (!work) {
         return;
@@ -1045,37 +1168,66 @@ hipError_t kvm_launch_retile_cnsm(const double *series, const double2 *prefix, c
     return hipGetLastError();
 }
 
-// One launch covers the three tile classes.  Workgroups [0, blocksA) run the CI=8 body on `tilesA`, the next blocksC the
-// two-tiles-per-row CI=4 body on `tilesC`, the rest the CI=4 body on `tilesB`; a unit = 8 class-A / 8 class-B / 16 class-C
-// tiles, shared by f consecutive waves of a workgroup when the window is split.
+// Class A on 16 candidates per lane: where every point is evaluated AND the list is long enough.  With the reference's
+// early abandoning a wave's 1024 candidates would have to die together before it could leave (512 with 8 per lane), and
+// those calls are bound by their launch chain, not by the FMA rate.  A 16-tile unit split f ways is as many parts as an
+// 8-tile unit split f / 2 ways: a list so short that the 8-per-lane form wants its four-way split (a few hundred tiles left
+// by a selective filter: the call lasts as long as one part) stays with the 8-per-lane form -- decided per launch (`a16`).
+template <bool ABANDON>
+__host__ __device__ constexpr bool edd_a16() { return EDD_A16 && !ABANDON; }
+template <bool ABANDON>
+constexpr size_t edd_lds_bytes() {
+    return edd_a16<ABANDON>() ? std::max((size_t)4 * EDD16_WAVE_B, (size_t)4 * EDD_WAVE_LDS * 8) : (size_t)4 * EDD_WAVE_LDS * 8;
+}
+
+// One launch covers the three tile classes.  Workgroups [0, blocksA) run the CI=8 (or CI=16) body on `tilesA`, the next
+// blocksC the two-tiles-per-row CI=4 body on `tilesC`, the rest the CI=4 body on `tilesB`; a unit = 8 (16) class-A / 8 class-B /
+// 16 class-C tiles, shared by f consecutive waves of a workgroup when the window is split.
 template <bool NORM, bool ABANDON>
 __global__ __launch_bounds__(256, 2) void kvm_ed_dot_kernel(edd_args A, const kvm_tile *__restrict__ tilesA, int64_t nA,
                                                             const kvm_tile *__restrict__ tilesB, int64_t nB,
                                                             const kvm_tile *__restrict__ tilesC, int64_t nC, int fA, int fB,
                                                             int fC, int64_t blocksA, int64_t blocksC,
                                                             const unsigned long long *__restrict__ d_counts,
-                                                            int64_t split_units) {
+                                                            int64_t split_units, int a16, int64_t a16_min_units) {
+    constexpr bool A16 = edd_a16<ABANDON>();
     if (d_counts) {  // tile lists built on the device (retile kernels): the launch only knows upper bounds
         nA = (int64_t)d_counts[0];
         nB = (int64_t)d_counts[1];
         nC = (int64_t)d_counts[2];
-        // the grid was sized for a 4-way split of the bounds; split only if the real lists are short
-        const int64_t uA = (nA + EDD_TILES_A - 1) / EDD_TILES_A, uB = (nB + EDD_TILES_B - 1) / EDD_TILES_B,
-                      uC = (nC + EDD_TILES_C - 1) / EDD_TILES_C;
-        fA = fB = fC = (uA + uB + uC <= split_units) ? 4 : 1;
-        blocksA = (uA * fA + 3) / 4;
+        // the grid was sized for a 4-way split of the bounds (in 8-tile units); split only if the real lists are short
+        const int64_t uA8 = (nA + EDD_TILES_A - 1) / EDD_TILES_A, uA16 = (nA + EDD_TILES_A16 - 1) / EDD_TILES_A16,
+                      uB = (nB + EDD_TILES_B - 1) / EDD_TILES_B, uC = (nC + EDD_TILES_C - 1) / EDD_TILES_C;
+        const bool small = uA8 + uB + uC <= split_units;
+        fB = fC = small ? 4 : 1;
+        a16 = A16 && a16 && !small && uA16 + uB + uC >= a16_min_units;   // (the host's rule, on the real counts: edd_use_a16)
+        fA = a16 ? (uA16 + uB + uC <= split_units ? 2 : 1) : (small ? 4 : 1);
+        blocksA = ((a16 ? uA16 : uA8) * fA + 3) / 4;
         blocksC = (uC * fC + 3) / 4;
-        (void)uB;
     }
-    // declared as double2 so that the window/query reads are provably 16-B aligned (ds_read_b128)
-    __shared__ __attribute__((aligned(256))) double2 lds_all2[4 * EDD_WAVE_LDS / 2];
+    // (wave-uniform by construction, but after the 64-bit compares above the compiler keeps it in a VGPR, and a scalar select
+    // on it -- `t0 = slot / fA * (a16 ? 16 : 8)` -- was MISCOMPILED in one build of this file: v_cmp into VCC followed by
+    // s_cselect_b32 on a stale SCC, the s_and_b64 vcc, vcc, exec between them gone; units then started every 8 tiles and
+    // covered 16.  So: an SGPR, and no select -- each form computes its own t0 from a constant.)
+    a16 = __builtin_amdgcn_readfirstlane(a16);
+    // declared as double2 so that the window/query reads are provably 16-B aligned (ds_read_b128).  Dynamic: the 16-per-lane
+    // form of class A needs 4 x 16 640 B, 1 KB more than a static array may have (edd_lds_bytes)
+    extern __shared__ __attribute__((aligned(256))) double2 lds_all2[];
     const int wave = threadIdx.x >> 6;
     double2 *lds_wave2 = lds_all2 + wave * (EDD_WAVE_LDS / 2);
     // launch order = longest units first: class A (a unit over the whole window: 0.50 ms at m = 8192), then class C
     // (0.35), then class B (0.26)
     const int64_t blk = (int64_t)blockIdx.x;
     if (blk < blocksA) {
-        const int64_t slot = blk * 4 + wave, t0 = (slot / fA) * EDD_TILES_A;
+        const int64_t slot = blk * 4 + wave;
+        if constexpr (A16) {
+            if (a16) {
+                const int64_t t0 = (slot / fA) * EDD_TILES_A16;
+                edd_body<16, 1, NORM, ABANDON>(A, tilesA, nA, t0, lds_all2 + wave * (EDD16_WAVE_B / 16), (int)(slot % fA), fA, t0 < nA);
+                return;
+            }
+        }
+        const int64_t t0 = (slot / fA) * EDD_TILES_A;
         edd_body<8, 1, NORM, ABANDON>(A, tilesA, nA, t0, lds_wave2, (int)(slot % fA), fA, t0 < nA);
     } else if (blk < blocksA + blocksC) {
         const int64_t slot = (blk - blocksA) * 4 + wave, t0 = (slot / fC) * EDD_TILES_C;
@@ -1088,9 +1240,10 @@ __global__ __launch_bounds__(256, 2) void kvm_ed_dot_kernel(edd_args A, const kv
 }
 
 // The launcher's model of a launch (window splits, tile classes): kvm_ed_launch_model.h (host-only, unit-tested on the CPU).
-static_assert(EDM_TILES_A == EDD_TILES_A && EDM_TILES_B == EDD_TILES_B && EDM_TILES_C == EDD_TILES_C, "model and kernel agree on the unit sizes");
-int kvm_ed_dot_choose_classes(int m, int64_t tilesA, int64_t tilesB, int64_t tilesC, int num_cu) {
-    return edd_choose_classes(m, tilesA, tilesB, tilesC, num_cu);
+static_assert(EDM_TILES_A == EDD_TILES_A && EDM_TILES_A16 == EDD_TILES_A16 && EDM_TILES_B == EDD_TILES_B && EDM_TILES_C == EDD_TILES_C, "model and kernel agree on the unit sizes");
+int kvm_ed_dot_choose_classes(int m, int64_t tilesA, int64_t tilesB, int64_t tilesC, int num_cu, int early_abandon) {
+    (void)early_abandon;   // (the question -- class C or not -- arises only on lists that do not fill the wave slots once, where
+    return edd_choose_classes(m, tilesA, tilesB, tilesC, num_cu);   // class A runs in its 8-per-lane form)
 }
 
 hipError_t kvm_launch_ed_dot(const double *series, const double2 *prefix, int64_t n, const kvm_query_dev &qd,
@@ -1101,8 +1254,22 @@ hipError_t kvm_launch_ed_dot(const double *series, const double2 *prefix, int64_
                              hipEvent_t ev_stop) {
     (void)n;
     if (nA + nB + nC <= 0) return hipSuccess;
-    const int64_t unitsA = (nA + EDD_TILES_A - 1) / EDD_TILES_A, unitsB = (nB + EDD_TILES_B - 1) / EDD_TILES_B,
-                  unitsC = (nC + EDD_TILES_C - 1) / EDD_TILES_C;
+    const bool a16_ok = (qd.early_abandon ? edd_a16<true>() : edd_a16<false>()) && !getenv("KVM_ED_NO_A16");   // (experiments)
+    bool a16 = false;
+    const int64_t unitsA16 = (nA + EDD_TILES_A16 - 1) / EDD_TILES_A16;
+    int64_t unitsA = (nA + EDD_TILES_A - 1) / EDD_TILES_A;
+    const int64_t unitsB = (nB + EDD_TILES_B - 1) / EDD_TILES_B, unitsC = (nC + EDD_TILES_C - 1) / EDD_TILES_C;
+    // (more than 64 KB of LDS per workgroup has to be allowed once per kernel)
+    static std::once_flag lds_once;
+    static hipError_t lds_rc = hipSuccess;
+    std::call_once(lds_once, [] {
+        if (edd_lds_bytes<false>() > 65536) {
+            lds_rc = hipFuncSetAttribute((const void *)kvm_ed_dot_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)edd_lds_bytes<false>());
+            if (lds_rc == hipSuccess)
+                lds_rc = hipFuncSetAttribute((const void *)kvm_ed_dot_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)edd_lds_bytes<false>());
+        }
+    });
+    if (lds_rc != hipSuccess) return lds_rc;
     const int64_t unitsS = unitsB + unitsC;  // the short units: one split factor for both classes
     // Window split (see edd_body): only worth it while the units are few compared with the 8 wave slots per CU, and
     // impossible with early abandon (waves leave early).  Pick the split pair with the smallest modelled makespan.
@@ -1114,6 +1281,7 @@ hipError_t kvm_launch_ed_dot(const double *series, const double2 *prefix, int64_
         // filter leaves a few hundred units for 2048 wave slots): the grid covers a 4-way split of the bounds and the
         // kernel decides from the real counts (early abandon: only when the list cannot fill the chip anyway)
         split_units = -1;  // (bounds too large to size the grid for a split: the kernel then never splits)
+        a16 = a16_ok;      // (the kernel decides from the real counts)
         if ((double)(unitsA + unitsS) < 16.0 * slots) {
             fA = fB = 4;
             // (profiles/ed_norm_split_sweep.py: a four-way split pays up to one unit per wave slot for long windows and up to
@@ -1129,24 +1297,36 @@ hipError_t kvm_launch_ed_dot(const double *series, const double2 *prefix, int64_
     } else if ((double)(unitsA + unitsS) < 16.0 * slots) {
         // (the model costs a few microseconds of the host's critical path: remember the last shape -- a query stream
         // over one index tends to repeat it)
-        struct memo_t { int64_t a, b, c; int cu, m, fa, fb; };
-        static thread_local memo_t memo = {-1, -1, -1, 0, 0, 1, 1};
-        if (memo.a == unitsA && memo.b == unitsB && memo.c == unitsC && memo.cu == num_cu && memo.m == qd.m) {
+        struct memo_t { int64_t a, b, c; int cu, m, fa, fb; bool ok, a16; };
+        static thread_local memo_t memo = {-1, -1, -1, 0, 0, 1, 1, false, false};
+        if (memo.a == unitsA && memo.b == unitsB && memo.c == unitsC && memo.cu == num_cu && memo.m == qd.m && memo.ok == a16_ok) {
             fA = memo.fa;
             fB = memo.fb;
+            a16 = memo.a16;
         } else {
-            (void)edd_best_split(qd.m, (double)unitsA, (double)unitsB, (double)unitsC, slots, fA, fB);
-            memo = {unitsA, unitsB, unitsC, num_cu, qd.m, fA, fB};
+            // the form of class A by the list's size (edd_use_a16), then the split pair of that form by the model
+            a16 = a16_ok && edd_use_a16(qd.m, unitsA16 + unitsB + unitsC, slots);
+            (void)edd_best_split(qd.m, (double)(a16 ? unitsA16 : unitsA), (double)unitsB, (double)unitsC, slots, fA, fB, a16);
+            memo = {unitsA, unitsB, unitsC, num_cu, qd.m, fA, fB, a16_ok, a16};
         }
+    } else {
+        a16 = a16_ok;   // many rounds of the wave slots: throughput alone
     }
+    if (a16 && !d_counts) unitsA = unitsA16;
     if (const char *e = getenv("KVM_ED_SPLIT")) {  // experiments: "fA,fB"
         int a = 0, b = 0;
         if (sscanf(e, "%d,%d", &a, &b) == 2 && (a == 1 || a == 2 || a == 4) && (b == 1 || b == 2 || b == 4))
             fA = a, fB = b;
     }
+    if (const char *e = getenv("KVM_ED_A16")) {   // experiments: force the form of class A on host-planned lists
+        if (!d_counts && a16_ok && (e[0] == '0' || e[0] == '1')) {
+            a16 = e[0] == '1';
+            unitsA = a16 ? unitsA16 : (nA + EDD_TILES_A - 1) / EDD_TILES_A;
+        }
+    }
     if (getenv("KVM_TRACE"))
-        fprintf(stderr, "[kvm] ed_dot m %d unitsA %lld unitsB %lld unitsC %lld split %d,%d\n", (int)qd.m, (long long)unitsA,
-                (long long)unitsB, (long long)unitsC, fA, fB);
+        fprintf(stderr, "[kvm] ed_dot m %d unitsA %lld (%d per lane) unitsB %lld unitsC %lld split %d,%d\n", (int)qd.m, (long long)unitsA,
+                a16 ? 16 : 8, (long long)unitsB, (long long)unitsC, fA, fB);
     const int fC = fB;
     int64_t blocksA = (unitsA * fA + 3) / 4, blocksB = (unitsB * fB + 3) / 4, blocksC = (unitsC * fC + 3) / 4;
     if (d_counts) {
@@ -1154,10 +1334,11 @@ hipError_t kvm_launch_ed_dot(const double *series, const double2 *prefix, int64_
         // tile lands in exactly one class, so the lists together hold at most nA tiles = nA / 8 (+ one partly filled
         // unit per class) units.  The kernel lays the classes out from the real counts; the grid only has to cover that total (workgroups
         // that find nothing return at once, but each of them still has to be given its 63 KB of LDS first).
-        const int64_t units_total = (nA + EDD_TILES_A - 1) / EDD_TILES_A + 3;
+        const int64_t units_total = (nA + EDD_TILES_A - 1) / EDD_TILES_A + 3;   // (8 tiles per unit: a class-B unit's, the smaller)
         blocksA = (units_total * fA + 3) / 4 + 3;
         blocksB = blocksC = 0;
     }
+    const int64_t a16_min = edd_a16_min_units(qd.m, slots);
     dim3 grid((unsigned)(blocksA + blocksB + blocksC)), block(256);
     edd_args A{series, prefix, qd, surv, cap, counters, out_off, out_dist, out_cap};
     // (ev_start / ev_stop: the kernel's own begin and end -- hipExtLaunchKernelGGL stamps the dispatch itself, so the time between
@@ -1165,11 +1346,11 @@ hipError_t kvm_launch_ed_dot(const double *series, const double2 *prefix, int64_
 #define LAUNCH(NORM, AB)                                                                                                          \
     do {                                                                                                                          \
         if (ev_start && ev_stop)                                                                                                  \
-            hipExtLaunchKernelGGL((kvm_ed_dot_kernel<NORM, AB>), grid, block, 0, s, ev_start, ev_stop, 0, A, tilesA, nA, tilesB,  \
-                                  nB, tilesC, nC, fA, fB, fC, blocksA, blocksC, d_counts, split_units);                          \
+            hipExtLaunchKernelGGL((kvm_ed_dot_kernel<NORM, AB>), grid, block, edd_lds_bytes<AB>(), s, ev_start, ev_stop, 0, A, tilesA, nA, tilesB,  \
+                                  nB, tilesC, nC, fA, fB, fC, blocksA, blocksC, d_counts, split_units, (int)a16, a16_min);       \
         else                                                                                                                      \
-            hipLaunchKernelGGL((kvm_ed_dot_kernel<NORM, AB>), grid, block, 0, s, A, tilesA, nA, tilesB, nB, tilesC, nC, fA, fB,   \
-                               fC, blocksA, blocksC, d_counts, split_units);                                                      \
+            hipLaunchKernelGGL((kvm_ed_dot_kernel<NORM, AB>), grid, block, edd_lds_bytes<AB>(), s, A, tilesA, nA, tilesB, nB, tilesC, nC, fA, fB,   \
+                               fC, blocksA, blocksC, d_counts, split_units, (int)a16, a16_min);                                   \
     } while (0)
     if (qd.normalised) {
         if (qd.early_abandon) LAUNCH(true, true); else LAUNCH(true, false);

@@ -11,6 +11,7 @@
 #define ED16_JC 80
 #endif
 #define EDM_TILES_A 8   // tiles per unit (= per wavefront): classes A and B one per row, class C two
+#define EDM_TILES_A16 16  // class A in its 16-candidates-per-lane form (every-point evaluation): 16 rows of 4 lanes
 #define EDM_TILES_B 8
 #define EDM_TILES_C 16
 
@@ -67,22 +68,30 @@ static inline double edd_makespan(const double cnt_in[3], const double w[3], dou
     return t;
 }
 // modelled duration (microseconds, without the launch's constant) of unitsA / unitsB / unitsC units split fA / fB ways
-static inline double edd_model(int m, double unitsA, double unitsB, double unitsC, int fA, int fB, double slots) {
+// Class A in its 16-per-lane form (kvm_ed_dot.hip, EDD16_*): when?  profiles/ed_a16_sweep.py -> profiles/r05_a16_sweep.log, 36
+// list shapes, both forms under their best split pair: the 16-per-lane form is 2 - 6 % ahead wherever the list's units (16-tile
+// class-A units + class-B + class-C units) come to 0.85 of the wave slots or more (worst case there + 2 %), and from 0.4 of
+// the slots on for windows of 4096 points and more; on shorter lists it is up to 17 % behind (half as many, longer parts).
+static inline int64_t edd_a16_min_units(int m, double slots) { return (int64_t)std::ceil((m >= 4096 ? 0.4 : 0.85) * slots); }
+static inline bool edd_use_a16(int m, int64_t units16, double slots) { return units16 >= edd_a16_min_units(m, slots); }
+// (a16: the class-A units are 16-tile units of the 16-per-lane form; a16 / b16 fitted by profiles/fit_ed_a16.py to the same
+// sweep, the rest of the model as it was: rms log error 6 %)
+static inline double edd_model(int m, double unitsA, double unitsB, double unitsC, int fA, int fB, double slots, bool a16 = false) {
     auto chunks = [](int mm, int jc, int f) { return std::ceil(std::ceil((double)mm / jc) / f); };
-    const double w[3] = {5.188 + 4.535 * chunks(m, ED8_JC, fA), 6.360 + 3.899 * chunks(m, ED8_JC, fB),
-                         3.951 + 3.719 * chunks(m, ED8_JC, fB)};                      // launch order: A, C, B
+    const double w[3] = {a16 ? 9.627 + 8.894 * chunks(m, ED8_JC, fA) : 5.188 + 4.535 * chunks(m, ED8_JC, fA),
+                         6.360 + 3.899 * chunks(m, ED8_JC, fB), 3.951 + 3.719 * chunks(m, ED8_JC, fB)};   // launch order: A, C, B
     auto parts = [](double units, int f) { return 4.0 * std::ceil(units * f / 4.0); };  // whole workgroups of 4 waves
     const double cnt[3] = {parts(unitsA, fA), parts(unitsC, fB), parts(unitsB, fB)};
     return edd_makespan(cnt, w, slots);
 }
 
 // smallest modelled duration over the nine split pairs
-static inline double edd_best_split(int m, double unitsA, double unitsB, double unitsC, double slots, int &fA, int &fB) {
+static inline double edd_best_split(int m, double unitsA, double unitsB, double unitsC, double slots, int &fA, int &fB, bool a16 = false) {
     double best = 1e300;
     fA = fB = 1;
     for (int a = 1; a <= 4; a *= 2)
         for (int b = 1; b <= 4; b *= 2) {
-            const double t = edd_model(m, unitsA, unitsB, unitsC, a, b, slots);
+            const double t = edd_model(m, unitsA, unitsB, unitsC, a, b, slots, a16);
             if (t < best * (1.0 - 1e-3)) best = t, fA = a, fB = b;   // (near ties: the coarser split)
         }
     return best;
@@ -92,20 +101,21 @@ static inline double edd_best_split(int m, double unitsA, double unitsB, double 
 // C fills the lanes better (a remainder of <= 16 takes 19 us of a wave at m = 8192 instead of 30) but its units last
 // longer: on a list that does not fill the wave slots once the model decides (profiles/ed_hybrid_sweep.py: with the
 // model's splits class C is 1.0-1.5 x faster on lists of short runs and within +-2 % elsewhere, 4 shapes of 90 lose 5-10 %).
-static inline int edd_choose_classes(int m, int64_t tilesA, int64_t tilesB, int64_t tilesC, int num_cu) {
+static inline int edd_choose_classes(int m, int64_t tilesA, int64_t tilesB, int64_t tilesC, int num_cu, bool a16 = false) {
     const double slots = (double)num_cu * 8;
-    const int64_t uA = (tilesA + EDM_TILES_A - 1) / EDM_TILES_A, uB = (tilesB + EDM_TILES_B - 1) / EDM_TILES_B,
+    const int tpa = a16 ? EDM_TILES_A16 : EDM_TILES_A;
+    const int64_t uA = (tilesA + tpa - 1) / tpa, uB = (tilesB + EDM_TILES_B - 1) / EDM_TILES_B,
                   uC = (tilesC + EDM_TILES_C - 1) / EDM_TILES_C, uBC = (tilesB + tilesC + EDM_TILES_B - 1) / EDM_TILES_B;
     if (tilesC <= 0) return 1;
     if ((double)(uA + uB + uC) > slots) return 2;  // throughput-bound: fewer, fuller tiles
-    struct memo_t { int64_t a, b, c; int cu, m, mode; };
-    static thread_local memo_t memo = {-1, -1, -1, 0, 0, 1};
-    if (memo.a == tilesA && memo.b == tilesB && memo.c == tilesC && memo.cu == num_cu && memo.m == m) return memo.mode;
+    struct memo_t { int64_t a, b, c; int cu, m, mode; bool a16; };
+    static thread_local memo_t memo = {-1, -1, -1, 0, 0, 1, false};
+    if (memo.a == tilesA && memo.b == tilesB && memo.c == tilesC && memo.cu == num_cu && memo.m == m && memo.a16 == a16) return memo.mode;
     int fa, fb;
-    const double t1 = edd_best_split(m, (double)uA, (double)uBC, 0.0, slots, fa, fb);
-    const double t2 = edd_best_split(m, (double)uA, (double)uB, (double)uC, slots, fa, fb);
+    const double t1 = edd_best_split(m, (double)uA, (double)uBC, 0.0, slots, fa, fb, a16);
+    const double t2 = edd_best_split(m, (double)uA, (double)uB, (double)uC, slots, fa, fb, a16);
     const int mode = t2 <= t1 * 1.02 ? 2 : 1;
-    memo = {tilesA, tilesB, tilesC, num_cu, m, mode};
+    memo = {tilesA, tilesB, tilesC, num_cu, m, mode, a16};
     return mode;
 }
 

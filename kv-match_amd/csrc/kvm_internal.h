@@ -248,7 +248,7 @@ hipError_t kvm_launch_ed_wave(const double *series, const double2 *prefix, int64
 #define ED8_JC 128  // q_pref16): class B (4 candidates per lane), class A (8 per lane), class C (4 per lane, two 16-candidate
 #define ED16_JC 80  // tiles per row)
 // host: classes A / B (1) or A / B / C (2) for a host-planned list (the launcher's model of the launch)
-int kvm_ed_dot_choose_classes(int m, int64_t tilesA, int64_t tilesB, int64_t tilesC, int num_cu);
+int kvm_ed_dot_choose_classes(int m, int64_t tilesA, int64_t tilesB, int64_t tilesC, int num_cu, int early_abandon);
 hipError_t kvm_launch_ed_dot(const double *series, const double2 *prefix, int64_t n, const kvm_query_dev &qd,
                              const kvm_tile *tilesA, int64_t nA, const kvm_tile *tilesB, int64_t nB,
                              const kvm_tile *tilesC, int64_t nC, kvm_surv *surv,

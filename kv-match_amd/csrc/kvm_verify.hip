@@ -195,7 +195,7 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
     // here, from the totals; the device-side plan follows the same rule (kvm_plan_tiles: hybrid = 2 with class C, 1 without).
     int hybrid_mode = 0;
     if (hybrid) {
-        hybrid_mode = kvm_ed_dot_choose_classes(m, pl.n_tiles, pl.n_tiles_b, pl.n_tiles_c, ctx->num_cu);
+        hybrid_mode = kvm_ed_dot_choose_classes(m, pl.n_tiles, pl.n_tiles_b, pl.n_tiles_c, ctx->num_cu, (int)ctx->opt_early_abandon);
         if (const char *e = getenv("KVM_ED_HYBRID"))  // experiments: force the tiling (1 = classes A / B, 2 = A / B / C)
             if (e[0] == '1' || e[0] == '2') hybrid_mode = e[0] - '0';
         if (hybrid_mode == 1) {

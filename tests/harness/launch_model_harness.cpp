@@ -41,6 +41,12 @@ int main() {
     CHECK(edd_choose_classes(8192, 14842, 4262, 5522, 256) == 2, "bench list: classes A / B / C");
     CHECK(edd_choose_classes(8192, 1600, 3000, 19000, 256) == 2, "200 000 candidates in runs of ~8: classes A / B / C");
     CHECK(edd_choose_classes(8192, 1600, 3000, 19000, 256) == 2, "(memoised) the same again");
+    // class A on 16 candidates per lane: by the size of the list (profiles/r05_a16_sweep.log)
+    CHECK(edd_use_a16(8192, 931 + 533 + 344, slots), "bench list (0.88 of the wave slots in 16-tile units): 16 per lane");
+    CHECK(!edd_use_a16(8192, 195 + 17 + 9, slots) && !edd_use_a16(2048, 931 + 267 + 170, slots) && edd_use_a16(2048, 1948 + 161 + 82, slots),
+          "short lists stay with 8 per lane; m < 4096 from 0.85 of the slots on");
+    t = edd_best_split(8192, 931, 533, 344, slots, fa, fb, true);
+    CHECK((fa == 2 || fa == 1) && t > 300 && t < 600, "bench list, 16 per lane: split %d,%d modelled %.0f us", fa, fb, t);
     // degenerate inputs end, with finite results
     const double z = edd_model(8192, 0, 0, 0, 4, 4, slots);
     CHECK(z == 0.0, "no units: %.1f", z);

@@ -2,6 +2,7 @@
 no compute entry point is called here."""
 import ctypes
 import os
+import sys
 import re
 
 import numpy as np
@@ -237,7 +238,7 @@ def test_ed_launch_model_on_the_cpu(tmp_path):
                         os.path.join(ROOT, "tests", "harness", "launch_model_harness.cpp")], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     r = subprocess.run([str(exe)], capture_output=True, text=True)
-    assert r.returncode == 0 and "FAIL" not in r.stdout and r.stdout.count("ok  ") >= 13, r.stdout + r.stderr[-2000:]
+    assert r.returncode == 0 and "FAIL" not in r.stdout and r.stdout.count("ok  ") >= 16, r.stdout + r.stderr[-2000:]
 
 
 def test_stream_host_layer_under_thread_and_address_sanitizers(tmp_path):
@@ -257,6 +258,34 @@ def test_stream_host_layer_under_thread_and_address_sanitizers(tmp_path):
         r = subprocess.run([str(exe), arg], capture_output=True, text=True, timeout=300)
         assert r.returncode == 0 and "FAIL" not in r.stdout and r.stdout.count("ok  ") == checks, r.stdout + r.stderr[-3000:]
         assert "WARNING: ThreadSanitizer" not in r.stderr and "ERROR: AddressSanitizer" not in r.stderr, r.stderr[-3000:]
+
+
+def test_no_scalar_select_on_a_stale_scc_in_the_device_code(tmp_path):
+    """A miscompile met in round 5 (hipcc of ROCm 7.2, kvm_ed_dot.hip): a wave-uniform condition kept in a VGPR, `v_cmp`
+    into VCC, then `s_cselect_b32` -- which reads SCC -- with the `s_and_b64 vcc, vcc, exec` between them dropped: the select
+    took the SCC of the exec-mask restore in front of it and the pruner's units started every 8 tiles while covering 16
+    (answers lost and duplicated; caught by the parity suite).  Every HIP source is compiled to gfx950 assembly and
+    scanned for an SCC reader fed by an exec-mask operation (profiles/tools/scc_lint.py)."""
+    import subprocess
+    from concurrent.futures import ThreadPoolExecutor
+    csrc = os.path.join(ROOT, "kv-match_amd", "csrc")
+    srcs = sorted(f for f in os.listdir(csrc) if f.endswith(".hip"))
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-S", "--cuda-device-only"]
+
+    def asm(f):
+        out = str(tmp_path / (f[:-4] + ".s"))
+        r = subprocess.run(["/opt/rocm/bin/hipcc"] + flags + ["-o", out, os.path.join(csrc, f)], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return out
+    with ThreadPoolExecutor(max_workers=6) as ex:
+        outs = list(ex.map(asm, srcs))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "profiles", "tools", "scc_lint.py")] + outs, capture_output=True, text=True)
+    assert r.returncode == 0 and "0 stale-SCC suspects" in r.stdout, r.stdout[-3000:]
+    # the linter does see the pattern
+    bad = tmp_path / "bad.s"
+    bad.write_text("f:\n\ts_or_b64 exec, exec, s[0:1]\n\tv_cmp_eq_u32_e32 vcc, 0, v128\n\ts_cselect_b32 s0, 3, 4\n")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "profiles", "tools", "scc_lint.py"), str(bad)], capture_output=True, text=True)
+    assert r.returncode == 1 and "1 stale-SCC suspects" in r.stdout, r.stdout
 
 
 def test_sort_and_merge_intervals_is_the_reference_step_between_the_phases(built):
