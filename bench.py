@@ -82,12 +82,13 @@ def parse():
                     help="rsm_ed = BASELINE configs[1] (headline); cnsm_ed = configs[2]; cnsm_dtw = configs[3] "
                          "(m=4096, rho=5%%); mixed = configs[4]-style stream alternating all four variants")
     a = ap.parse_args()
-    # Under rocprofv3's kernel tracing, eight NATIVE host threads launching at once make the profiler's own library fall over
-    # inside hipLaunchKernel now and then (never without it: profiles/prof_r04.sh).  So that `rocprofv3 ... -- python3 bench.py`
-    # still gives the per-kernel summary of this very command, a profiled run drives its contexts from Python threads (the
-    # line says so in `config.host_threads`; its stream rates are then the interpreter's, its kernel durations are not).
+    # Under rocprofv3's kernel tracing the library's native host threads used to take the profiler's library down inside
+    # hipLaunchKernel (two attempts of three, seconds into the run: eight threads making their FIRST launch at the same moment,
+    # profiles/r05_prof_native_crash.log), and rounds 3-4 drove a profiled run from Python threads instead.  Since round 5 every
+    # thread's first call runs alone (kvm_stream.cpp) and a profiled run is driven exactly like an unprofiled one
+    # (profiles/prof_r05.sh: the default command, attempts all complete); KVM_BENCH_PROFILED_PYTHON=1 brings the old behaviour back.
     a.profiled = any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", "")
-    if a.profiled and not a.python_threads and os.environ.get("KVM_BENCH_PROFILED_NATIVE") != "1":
+    if a.profiled and not a.python_threads and os.environ.get("KVM_BENCH_PROFILED_PYTHON") == "1":
         a.python_threads = 1
     return a
 

@@ -79,7 +79,9 @@ __device__ __forceinline__ void edd_fmac_bc(double &acc, double q16, double w, i
 }
 #define EDD_RING_LEN 128                     // points of the ring (= ED8_JC: one chunk is one revolution, all addresses static)
 #define EDD_RING_AHEAD 80                    // lookahead region [128, 208): the start of the next revolution (>= 64 + 8 window points)
+#ifndef EDD_RING_D
 #define EDD_RING_D 4                         // blocks a global load is issued ahead of its LDS write
+#endif
 typedef double ed4_d2u __attribute__((ext_vector_type(2), aligned(8)));
 
 // ---- class A with SIXTEEN candidates per lane (round 5; every-point evaluation only): 16 rows x 4 lanes x 16 candidates ----

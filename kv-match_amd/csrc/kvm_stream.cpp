@@ -118,7 +118,7 @@ struct thread_group {
     ~thread_group() { worker_pool::wait(t); }
 };
 
-static int run_one(kvm_ctx *c, const kvm_job &j, kvm_result **r) {
+static int run_one_call(kvm_ctx *c, const kvm_job &j, kvm_result **r) {
     switch (j.variant) {
         case 0: return kvm_verify_rsm_ed(c, j.query, j.m, j.left, j.right, j.k, j.shift, j.epsilon, r);
         case 1: return kvm_verify_cnsm_ed(c, j.query, j.m, j.left, j.right, j.k, j.shift, j.epsilon, j.alpha, j.beta, r);
@@ -126,6 +126,26 @@ static int run_one(kvm_ctx *c, const kvm_job &j, kvm_result **r) {
         case 3: return kvm_verify_cnsm_dtw(c, j.query, j.m, j.left, j.right, j.k, j.shift, j.epsilon, j.rho, j.alpha, j.beta, r);
     }
     return KVM_ERR_ILLEGAL_ARGUMENT;
+}
+// A thread's FIRST call runs alone: it is where the HIP runtime (and a tool that hooks it) sets up its per-thread state, and
+// eight threads doing that at the same moment is what `rocprofv3 --kernel-trace -- python3 bench.py` fell over in (SIGSEGV in a
+// copy inside the tool's launch callback, seconds into the run, two attempts of three with the pool and without:
+// profiles/r05_prof_native_crash.log).  Once per thread of the process; the calls after it run freely.
+struct first_call_alone {
+    std::unique_lock<std::mutex> lk;
+    first_call_alone() {
+        static std::mutex mu;
+        if (!done()) lk = std::unique_lock<std::mutex>(mu);
+    }
+    ~first_call_alone() { done() = true; }
+    static bool &done() {
+        thread_local bool d = false;
+        return d;
+    }
+};
+static int run_one(kvm_ctx *c, const kvm_job &j, kvm_result **r) {
+    first_call_alone guard;
+    return run_one_call(c, j, r);
 }
 
 extern "C" int kvm_run_jobs(kvm_ctx *const *ctxs, int32_t n_ctx, const kvm_job *jobs, int64_t n_jobs, kvm_result **results,
@@ -229,6 +249,7 @@ extern "C" int kvm_run_device_jobs(const kvm_device_slot *slots, int32_t n_slots
                 if (!failed) {
                     const kvm_job &j = jobs[i];
                     int64_t cnt = 0;
+                    first_call_alone guard;
                     rc = kvm_verify_device(s.ctx, j.variant, j.query, j.m, j.left, j.right, j.k, j.shift, j.epsilon, j.rho, j.alpha, j.beta,
                                            s.d_off, s.d_dist, s.cap, s.d_count, &cnt, s.stream);
                     if (rc == KVM_OK) rc = kvm_pack_answers_device(s.ctx, s.d_off, s.d_dist, s.d_count, s.pack_cap, s.d_packed, s.stream);
