@@ -1340,7 +1340,8 @@ hipError_t kvm_launch_ed_dot(const double *series, const double2 *prefix, int64_
         blocksA = (units_total * fA + 3) / 4 + 3;
         blocksB = blocksC = 0;
     }
-    const int64_t a16_min = edd_a16_min_units(qd.m, slots);
+    int64_t a16_min = edd_a16_min_units(qd.m, slots);
+    if (const char *e = getenv("KVM_ED_A16_MIN_UNITS")) a16_min = atoll(e);   // tests: device-built lists of any size through the 16-per-lane form
     dim3 grid((unsigned)(blocksA + blocksB + blocksC)), block(256);
     edd_args A{series, prefix, qd, surv, cap, counters, out_off, out_dist, out_cap};
     // (ev_start / ev_stop: the kernel's own begin and end -- hipExtLaunchKernelGGL stamps the dispatch itself, so the time between

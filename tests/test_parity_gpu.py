@@ -1577,6 +1577,58 @@ def test_residue_of_a_spike_in_the_references_running_sums(built):
                         tag=f"spike dtw scale={scale} burst={burst} eps={eps}")
 
 
+def test_ed_pruner_sixteen_per_lane_form_on_every_list_shape(world, monkeypatch, capfd):
+    """Class A of the ED pruner on 16 candidates per lane (round 5: 16 rows x 4 lanes, ring-staged rows, compile-time loops) is
+    chosen by the launcher for long lists only; here it is FORCED (KVM_ED_A16=1 on host-planned lists; device-built cNSM lists
+    through KVM_ED_A16_MIN_UNITS=0 and KVM_ED_SPLIT_UNITS=0) with early abandoning off, over window lengths that do and do not
+    end on a chunk boundary (25 .. 4097: the last revolution runs on the zeros behind the query), every window split, lists
+    of short, long and single-candidate runs, a shifted list and runs that end on the last window of the series.  Answers,
+    order and every distance equal the oracle's; so does the 8-per-lane form's (KVM_ED_A16=0) on the same calls."""
+    kvmatch, datagen, series, ctx = world
+    monkeypatch.setenv("KVM_ED_A16_MIN_UNITS", "0")
+    monkeypatch.setenv("KVM_ED_SPLIT_UNITS", "0")
+    ctx.set_option(kvmatch.OPT_EARLY_ABANDON, 0)
+    try:
+        n = len(series)
+        for m, eps in ((25, 1.5), (100, 2.5), (128, 3.0), (129, 3.0), (300, 4.0), (1024, 9.0), (4097, 12.0)):
+            s, q, L, R = planted(world, m)
+            lists = [("mean run 48", L, R, 1)]
+            l2, r2 = datagen.gen_intervals(n, m, 60_000, 400.0, must_cover=[planted.qoff, 40_000, 200_000, 250_000], seed=5)
+            lists.append(("mean run 400", l2, r2, 1))
+            l3 = np.unique(np.concatenate([np.arange(1, n - m, 97, dtype=np.int32), np.array([planted.qoff], np.int32)])).astype(np.int32)
+            l3 = l3[np.concatenate(([True], np.diff(l3) > 1))]        # (disjoint, non-adjacent: the form phase 1 hands over)
+            lists.append(("single candidates", l3, l3.copy(), 1))
+            # one run that reaches the last window of the series, and the first
+            lists.append(("ends of the series", np.array([1, 40_000 - 30, n - m + 1 - 200], np.int32), np.array([70, 40_000 + 40, n - m + 1], np.int32), 1))
+            lists.append(("lastSegment 3", (L + 50).astype(np.int32), (R + 50).astype(np.int32), 3))
+            for name, ll, rr, ls in lists:
+                shift = (ls - 1) * 25
+                want_r = oracle.rsm_ed(s, q, ll, rr, shift, eps)
+                want_c = oracle.cnsm_ed(s, q, ll, rr, shift, eps, 1.5, 3.0)
+                for form in ("1", "0"):
+                    monkeypatch.setenv("KVM_ED_A16", form)
+                    for split in (("1,1", "2,2", "4,4") if form == "1" and name != "single candidates" else ("",)):
+                        if split:
+                            monkeypatch.setenv("KVM_ED_SPLIT", split)
+                        else:
+                            monkeypatch.delenv("KVM_ED_SPLIT", raising=False)
+                        compare(kvmatch.QueryEngine(ctx).verify((ll, rr), ls, q, eps), want_r, tag=f"rsm m={m} {name} form={form} split={split}")
+                    monkeypatch.delenv("KVM_ED_SPLIT", raising=False)
+                    compare(kvmatch.NormQueryEngine(ctx).verify((ll, rr), ls, q, eps, 1.5, 3.0), want_c, tag=f"cnsm m={m} {name} form={form}")
+        # (the launcher's trace says which form ran)
+        monkeypatch.setenv("KVM_ED_A16", "1")
+        monkeypatch.setenv("KVM_TRACE", "1")
+        capfd.readouterr()
+        kvmatch.QueryEngine(ctx).verify((L, R), 1, q, eps)
+        assert "(16 per lane)" in capfd.readouterr().err
+        monkeypatch.setenv("KVM_ED_A16", "0")
+        kvmatch.QueryEngine(ctx).verify((L, R), 1, q, eps)
+        assert "(8 per lane)" in capfd.readouterr().err
+    finally:
+        ctx.set_option(kvmatch.OPT_EARLY_ABANDON, 1)
+        ctx.load_series(series)
+
+
 def test_run_jobs_is_the_same_stream_in_native_threads(world):
     """kvm_run_jobs (QueryStream.run_jobs): calls as data, one native host thread per context.  Every job's answers equal
     the oracle's (and therefore the one-call-at-a-time engines'), in job order, all four variants mixed in one stream;
