@@ -13,22 +13,24 @@
 // terms) -- about 1e5 ulps, versus the <= sqrt(m) ulps the accumulations can lose.  Candidates inside the band go to
 // the exact pass like every other survivor.
 //
-// Mapping: one wavefront = 8 rows x 8 lanes; a row is one tile of consecutive candidates staged once per chunk in
-// wave-private LDS (no workgroup barrier anywhere), a lane owns CI adjacent candidates (CI accumulators):
-//   CI = 8 : 64-candidate tiles, chunk 128.  Per 2 points one ds_read_b128 of the window and one broadcast ds_read_b128
-//            of (qc[j], qc[j+1]) feed 16 FMAs: LDS at half the VALU rate -> VALU-bound.  Used for full tiles and for
-//            run remainders of more than 32 candidates.
-//   CI = 4 : class B, 32-candidate tiles, chunk 160.  8 FMAs per 2 reads; per lane-slot as fast as CI = 8 in practice, and
-//            only half the idle lanes on a short remainder.
-//   CI = 4, two tiles per row : class C, 16-candidate tiles, TWO unrelated tiles per row (lanes 0-3 / 4-7, each half of
-//            the row's LDS region staged from its own tile's position), chunk 80 -- the per-chunk work (27 loads, 27 LDS
-//            writes, ring start-up) is amortised over half as many points, so a unit of 16 such tiles takes 1.3 x a
-//            class-B unit of 8 tiles (0.35 against 0.26 ms): worth it for remainders of <= 16 candidates only
-//            (kvm_ed_remainder_classes, profiles/ed_class_cost.py).
+// Mapping: one wavefront = 8 rows x 8 lanes; a row is one tile of consecutive candidates whose window streams through a ring in
+// wave-private LDS (no workgroup barrier in the loop), a lane owns CI adjacent candidates (CI accumulators); every class
+// works in chunks of 128 window points = one revolution of its ring (EDD_RING_*):
+//   CI = 8 : class A, 64-candidate tiles -- full tiles and run remainders of more than 32 candidates.  Since round 5 long
+//            lists whose every point is evaluated run class A on 16 candidates per lane instead (16 rows x 4 lanes, EDD16_*).
+//   CI = 4 : class B, 32-candidate tiles; per lane-slot as fast as CI = 8 in practice, and only half the idle lanes on a
+//            short remainder.
+//   CI = 4, two tiles per row : class C, 16-candidate tiles, TWO unrelated tiles per row (lanes 0-3 / 4-7, each half row a
+//            ring of its own, staged from its own tile's position): a unit of 16 such tiles takes 1.3 x a class-B unit of 8
+//            (0.35 against 0.26 ms): worth it for remainders of <= 16 candidates only (kvm_ed_remainder_classes,
+//            profiles/ed_class_cost.py).
 // Lane stride inside a row is CI*8 B; rows are displaced by 16 B against each other ((r>>1)&1 for CI=4, r&3 for CI=8) so
 // that every 16-lane group of ds_read_b128 -- which mixes lanes of four rows -- covers 16 distinct 16-B slots
-// (conflict-free; SQ_LDS_BANK_CONFLICT ~ 1 % of LDS cycles).  The loads are written with a clang ext_vector type:
-// hipcc scalarises HIP's double2 and re-pairs it as ds_read2_b64, whose 8-B banking rules conflict 4-way here.
+// (conflict-free; SQ_LDS_BANK_CONFLICT ~ 0).  The loads are written with a clang ext_vector type: hipcc scalarises HIP's
+// double2 and re-pairs it as ds_read2_b64, whose 8-B banking rules conflict 4-way here.
+// The variants this file used to carry as compile-time switches -- chunk-wise staging (27 loads + 27 LDS writes per chunk),
+// query values by broadcast LDS reads, a deeper register prefetch -- were measured in rounds 2-3 (HISTORY.md) and removed in
+// round 5; the generated code did not change.
 #include "kvm_internal.h"
 #include "kvm_seqadd.h"
 #include "kvm_ed_launch_model.h"
@@ -44,32 +46,18 @@
 
 typedef double ed4_d2 __attribute__((ext_vector_type(2)));
 
-#ifndef EDD_PD
-#define EDD_PD 1  // sub-steps between an LDS read of the hot loop and its first use (1 or 3)
-#endif
-// Class A (64-candidate tiles) stages its rows as a STREAM (round 3): a row of the wave's LDS is a ring of 128 points with an
+// Classes A and B stage their rows as a STREAM (round 3): a row of the wave's LDS is a ring of 128 points with an
 // 80-point lookahead region behind it; every 16 window points each lane fetches ONE 16-byte piece (two points of its own
 // row, four blocks ahead) and writes it where the ring has just gone dead -- 8 global loads and 13 LDS writes per 128 points
 // instead of 27 + 27 per chunk (a chunk re-staged the 64 points it shares with its neighbour and restarted the register
 // ring).  The arithmetic is unchanged: the same products accumulate in the same order.
-#ifndef EDD_RING
-#define EDD_RING 1
-#endif
-#ifndef EDD_RING_B
-#define EDD_RING_B EDD_RING                  // class B (32-candidate tiles) too
-#endif
-#ifndef EDD_RING_C
-#define EDD_RING_C EDD_RING                  // class C (two 16-candidate tiles per row): two rings of 64 points per row
-#endif
+// Class C (two 16-candidate tiles per row): two rings of 64 points per row.
 #define EDD_RINGC_LEN 64                     // class C: ring of a half row (half a chunk: two revolutions per chunk)
 #define EDD_RINGC_AHEAD 32                   // ... and its lookahead region (>= 16 + 8 window points)
-// Stream-staged classes A and B take their query values from a REGISTER by DPP row broadcast instead of two broadcast LDS reads
+// All classes take their query values from a REGISTER by DPP row broadcast instead of two broadcast LDS reads
 // per sub-step: one ds_read_b64 per lane and 16 points puts q[j + (lane & 15)] into a VGPR pair, and v_fmac_f64_dpp
 // row_newbcast:K (the only DPP form the DP ALU has, gfx90a+) feeds lane K's value of every 16-lane row to the FMA.  Halves the
 // hot loop's LDS reads (class B, 4 candidates per lane, is LDS-bound).  The same operation: acc = fma(w, q, acc).
-#ifndef EDD_QDPP
-#define EDD_QDPP 1
-#endif
 #define EDD_BC_CASE(K) case K: asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:" #K " row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(q16), "v"(w)); break;
 __device__ __forceinline__ void edd_fmac_bc(double &acc, double q16, double w, int k) {  // k: a constant after unrolling
     switch (k) {
@@ -137,23 +125,20 @@ __device__ __forceinline__ void edd_static_for(F &&f) {
 #define EDD_TAB 32                           // class C: per-tile staging table (16 row shifts, 16 starts; padded so that a
                                              // wave's region stays a multiple of 256 B), in doubles
 #define EDD_WAVE_LDS (EDD_ROWS * EDD_RS + EDD_ROWLEN + EDD_TAB)
-static_assert(ED16_JC + 16 <= EDD_SUB_LEN && 2 * EDD_SUB_LEN == EDD_ROWLEN && ED4_JC + 8 * 4 <= EDD_ROWLEN && ED8_JC + 8 * 8 <= EDD_ROWLEN, "chunk + tile must fit the staged (half) row");
+static_assert(2 * EDD_SUB_LEN == EDD_ROWLEN && ED8_JC + 8 * 8 <= EDD_ROWLEN, "chunk + tile must fit the staged (half) row");
 static_assert(EDD_SUB_OFF >= EDD_SUB_LEN && EDD_SUB_OFF + EDD_SUB_LEN + 2 <= EDD_RS && (EDD_SUB_OFF * 8) % 256 == 128, "class-C half rows");
 static_assert(4 * EDD_WAVE_LDS * 8 <= 65536 && EDD_WAVE_LDS % 2 == 0 && EDD_RS % 2 == 0 && (EDD_RS * 8) % 256 == 0, "LDS");
-static_assert(ED4_JC % 16 == 0 && ED8_JC % 16 == 0 && ED16_JC % 16 == 0, "chunks are whole groups of 16 points (4 sub-steps of the register ring)");
+static_assert(ED8_JC % 16 == 0, "chunks are whole groups of 16 points (4 sub-steps of the register ring)");
 static_assert(EDD_RINGC_LEN + EDD_RINGC_AHEAD <= EDD_SUB_LEN && 2 * EDD_RINGC_LEN == ED8_JC && EDD_RINGC_AHEAD >= 24 + 8, "class C: ring + lookahead fit a half row");
 static_assert(EDD_RING_LEN == ED8_JC && EDD_RING_LEN + EDD_RING_AHEAD + 6 <= EDD_RS && EDD_RING_LEN + 16 <= EDD_ROWLEN && EDD_RING_AHEAD >= 72 + 8,
               "ring + lookahead fit a row; the query ring + its lookahead fit the query region");
 
 template <int CI, int SUB>
 struct edd_cfg {
-    // (class B: 128 like class A when its rows are staged as a stream -- one revolution of the ring --, 160 in the chunked form)
-    static constexpr int JC = CI >= 8 ? ED8_JC : (SUB == 2 ? (EDD_RING_C ? ED8_JC : ED16_JC) : (EDD_RING_B ? ED8_JC : ED4_JC));
-    static constexpr bool PREF8 = JC == ED8_JC;   // chunk prefix sums of the query at ED8_JC granularity
+    static constexpr int JC = ED8_JC;                    // every class: one chunk = one revolution of its ring(s)
     static constexpr int TILE = CI == 16 ? 64 : 8 * CI / SUB;                  // candidates per tile: 64 / 32 / 16
     static constexpr int TPU = CI == 16 ? EDD16_ROWS : EDD_ROWS * SUB;         // tiles per unit (= per wavefront)
     static constexpr int WAVE_DOUBLES = CI == 16 ? EDD16_WAVE_B / 8 : EDD_WAVE_LDS;   // a wave's LDS region
-    static constexpr int QS = PREF8 ? 1 : JC / ED16_JC;  // stride of a chunk in the q_pref array it reads
     __device__ static constexpr int row_shift(int r) { return CI == 8 ? (r & 3) * 2 : ((r >> 1) & 1) * 2; }  // doubles
 };
 #define EDD_TILES_A (EDD_ROWS)
@@ -203,25 +188,16 @@ __device__ __forceinline__ void edd_body(const edd_args &A, const kvm_tile *__re
     const double *__restrict__ series = A.series;
     const double2 *__restrict__ prefix = A.prefix;
     const double *__restrict__ qc = qd.qc;
-    const double2 *__restrict__ q_pref = cfg::PREF8 ? qd.q_pref8 : qd.q_pref;  // (else ED16_JC-granular, chunk stride cfg::QS)
+    const double2 *__restrict__ q_pref = qd.q_pref8;   // prefix sums of the centred query at chunk granularity
     double *wlds = reinterpret_cast<double *>(lds_wave2);
     double *qlds = wlds + EDD_ROWS * EDD_RS;
     double *tab_shift = qlds + EDD_ROWLEN;                                  // class C: shift / start of the unit's 16 tiles
     int32_t *tab_start = reinterpret_cast<int32_t *>(tab_shift + 16);
     const int nchunks = (m + JC - 1) / JC;
 
-    // wave-uniform tile descriptors (for staging): in registers, or (class C: 16 of them) in the wave's LDS ...
-    int32_t rstart[EDD_ROWS];
-    double rshift[EDD_ROWS];
-    if constexpr (RING16) {
-        // (stream staging only: every lane stages pieces of its own row)
-    } else if constexpr (SUB == 1) {
-#pragma unroll
-        for (int r = 0; r < EDD_ROWS; r++) {
-            rstart[r] = (t0 + r < n_tiles) ? tiles[t0 + r].start : 1;  // empty rows stage from the head of the series
-            rshift[r] = series[rstart[r] - 1];
-        }
-    } else {
+    // class C: the start / shift of the unit's 16 tiles in the wave's LDS (a lane stages pieces of BOTH tiles of its row); the
+    // other classes need no table: every lane stages pieces of its own row
+    if constexpr (SUB == 2) {
         if (lane < cfg::TPU) {
             const int32_t st = (t0 + lane < n_tiles) ? tiles[t0 + lane].start : 1;
             tab_start[lane] = st;
@@ -236,7 +212,7 @@ __device__ __forceinline__ void edd_body(const edd_args &A, const kvm_tile *__re
     const double hist = NORM ? kvm_run_hist_of(qd, mine.run) : 0.0;  // residue the reference's running sums may carry (kvm_hist_*)
     const int c0 = CI * lc;
     const double qbar = qd.q_mean;
-    const double2 qtot = q_pref[nchunks * cfg::QS];
+    const double2 qtot = q_pref[nchunks];
 
     // Shifted sums of points [jlo, J) of candidate a's window, re-based to the row shift; for cNSM also the window's
     // mean - c_row, sigma and sigma guard (always from the full window).
@@ -370,76 +346,11 @@ __device__ __forceinline__ void edd_body(const edd_args &A, const kvm_tile *__re
         if (cntp == 0) work = false;  // nothing in this wave passed the (alpha, beta) filter
     }
 
-    double stage[EDD_ROWS + 1][EDD_LOADS];
-    // class C: the 192 staged points of a row are two runs of 96, one per tile; load t of a lane falls into tile
-    // 0 (t = 0), tile 1 (t = 2) or, for t = 1, tile 0 for lanes < 32 and tile 1 above.  The series index each of a lane's
-    // 24 loads starts from is fixed for the unit: kept in registers (int32: offsets are Java ints), so that a chunk's
-    // staging costs one 64-bit add per load, as in class A.
-    auto sub_of = [&](int t) -> int { return t == 0 ? 0 : (t == 2 ? 1 : (lane >> 5)); };
-    int32_t sidx[SUB == 2 ? EDD_ROWS : 1][EDD_LOADS];
-    if constexpr (SUB == 2) {
-#pragma unroll
-        for (int r = 0; r < EDD_ROWS; r++) {
-#pragma unroll
-            for (int t = 0; t < EDD_LOADS; t++) {
-                const int sb = sub_of(t);
-                sidx[r][t] = tab_start[r * 2 + sb] - 1 + (t * 64 + lane - sb * EDD_SUB_LEN);
-            }
-        }
-    }
-    auto load_chunk = [&](int j0) {
-#pragma unroll
-        for (int r = 0; r < EDD_ROWS; r++) {
-            if constexpr (SUB == 1) {
-                const double *src = series + ((int64_t)rstart[r] - 1 + j0);  // unguarded: series is padded (KVM_SERIES_PAD)
-#pragma unroll
-                for (int t = 0; t < EDD_LOADS; t++) stage[r][t] = src[t * 64 + lane];  // raw: shifted when stored
-            } else {
-#pragma unroll
-                for (int t = 0; t < EDD_LOADS; t++) {
-                    stage[r][t] = series[(int64_t)sidx[r][t] + j0];
-                }
-            }
-        }
-#pragma unroll
-        for (int t = 0; t < EDD_LOADS; t++) stage[EDD_ROWS][t] = qc[j0 + t * 64 + lane];
-    };
-    auto store_chunk = [&]() {
-        // The subtraction of the row shift is the first use of the prefetched values.  Its operands pass through an
-        // empty asm placed after the chunk's arithmetic, so the compiler cannot hoist the subtractions (and with them
-        // the wait for the loads) above the FMA block that is there to cover the load latency.
-        if constexpr (SUB == 1) {
-            double sh[EDD_ROWS];
-#pragma unroll
-            for (int r = 0; r < EDD_ROWS; r++) sh[r] = rshift[r];
-            asm volatile("" : "+v"(sh[0]), "+v"(sh[1]), "+v"(sh[2]), "+v"(sh[3]), "+v"(sh[4]), "+v"(sh[5]), "+v"(sh[6]), "+v"(sh[7])::"memory");
-#pragma unroll
-            for (int r = 0; r < EDD_ROWS; r++) {
-#pragma unroll
-                for (int t = 0; t < EDD_LOADS; t++) wlds[r * EDD_RS + cfg::row_shift(r) + t * 64 + lane] = stage[r][t] - sh[r];
-            }
-        } else {
-            asm volatile("" ::: "memory");  // (the shifts are read from LDS behind this point: same effect)
-#pragma unroll
-            for (int r = 0; r < EDD_ROWS; r++) {
-#pragma unroll
-                for (int t = 0; t < EDD_LOADS; t++) {
-                    const int sb = sub_of(t);
-                    wlds[r * EDD_RS + cfg::row_shift(r) + sb * EDD_SUB_OFF + (t * 64 + lane - sb * EDD_SUB_LEN)] =
-                        stage[r][t] - tab_shift[r * 2 + sb];
-                }
-            }
-        }
-#pragma unroll
-        for (int t = 0; t < EDD_LOADS; t++) qlds[t * 64 + lane] = stage[EDD_ROWS][t];
-    };
-
     double acc[CI];
 #pragma unroll
     for (int a = 0; a < CI; a++) acc[a] = 0.0;
     const int ch_lo = nchunks * part / f, ch_hi = nchunks * (part + 1) / f;
-    constexpr bool RINGED = SUB == 1 && (CI == 8 ? EDD_RING : EDD_RING_B);
-    // ---- stream staging (class A): lane = 8 row + piece stages points 2 piece, 2 piece + 1 of every 16-point block of its row
+    // ---- stream staging (classes A and B): lane = 8 row + piece stages points 2 piece, 2 piece + 1 of every 16-point block of its row
     const double *gsrc = series + ((int64_t)mine.start - 1 + 2 * lc);               // + point index of the block
     double *wdst = wlds + row * EDD_RS + cfg::row_shift(row) + 2 * lc;               // + position in the row
     ed4_d2 st[EDD_RING_D], qst[2];
@@ -462,8 +373,8 @@ __device__ __forceinline__ void edd_body(const edd_args &A, const kvm_tile *__re
         if (ahead && lane < 8) *reinterpret_cast<ed4_d2 *>(qlds + EDD_RING_LEN + 2 * lane) = v;
     };
     // ---- stream staging, class C: lane = 8 row + piece stages points 2 piece, 2 piece + 1 of every 16-point block of BOTH tiles
-    // of its row (two streams per row, a ring of 64 points + 32 of lookahead each, in the half rows of the chunked form)
-    constexpr bool RINGC = SUB == 2 && EDD_RING_C;
+    // of its row (two streams per row, a ring of 64 points + 32 of lookahead each, in the two halves of the row)
+    constexpr bool RINGC = SUB == 2;
     const double *gsrcC[2] = {series, series};
     double *wdstC[2] = {wlds, wlds};
     double shC[2] = {0.0, 0.0};
@@ -538,7 +449,7 @@ __device__ __forceinline__ void edd_body(const edd_args &A, const kvm_tile *__re
 #pragma unroll
                 for (int b = 0; b < 3; b++) ringc_wr(sb, p3[sb][b], 16 * b, true, false);
             ring_wrq(q0v, 0, false);
-        } else if constexpr (RINGED) {
+        } else {
             const int jb = ch_lo * JC;
             ed4_d2 p6[6];
 #pragma unroll
@@ -550,18 +461,13 @@ __device__ __forceinline__ void edd_body(const edd_args &A, const kvm_tile *__re
 #pragma unroll
             for (int b = 0; b < 6; b++) ring_wr(p6[b], 16 * b, true, false);
             ring_wrq(q0v, 0, false);
-        } else {
-            load_chunk(ch_lo * JC);
-            store_chunk();
         }
     }
     const ed4_d2 *X2 = reinterpret_cast<const ed4_d2 *>(lds_wave2) +
                        (row * (EDD_RS / 2) + cfg::row_shift(row) / 2 + sub * (EDD_SUB_OFF / 2) + (CI / 2) * lc);
-    const ed4_d2 *Q2 = reinterpret_cast<const ed4_d2 *>(lds_wave2) + EDD_ROWS * (EDD_RS / 2);
     for (int ch = ch_lo; work && ch < ch_hi; ch++) {
         const int j0 = ch * JC;
         const bool more = ch + 1 < ch_hi;
-        if (!RINGED && !RINGC && !RING16 && more) load_chunk(j0 + JC);
         const int jlim = min(JC, m - j0);
         if constexpr (RING16) {
             {
@@ -602,26 +508,20 @@ __device__ __forceinline__ void edd_body(const edd_args &A, const kvm_tile *__re
                 });
                 (void)jlim;
             }
-        } else if (RINGC) {
-            if constexpr (RINGC) {
+        } else if constexpr (RINGC) {
+            {
                 // One chunk of 128 points = two revolutions of the half rows' rings = 8 blocks of 16 points; at the start the
                 // half rows hold [j0, j0 + 48).  Block B's turn writes points [j0 + 16 (B + 3), + 16) of both tiles -- fetched four
                 // blocks ago -- where the ring went dead a block ago (the first two blocks of a revolution also behind the ring),
                 // then fetches the blocks four further on.  A block runs only if it lies wholly inside the window (the last
                 // chunk of a window may be partial); what is left of a partial block is added point by point.
-                constexpr int NP = CI / 2 + 2, PD = 1, RING = 8, U = RING / 2, NQ = PD + 1;
-                constexpr int AH = NP + 2 * (PD - 1);
-                ed4_d2 R[RING], Q[NQ][2];
+                constexpr int RING = 8, U = RING / 2, AH = CI / 2 + 2;
+                ed4_d2 R[RING];
 #pragma unroll
                 for (int j = 0; j < AH; j++) R[j] = X2[j];
                 const double *q16p = qlds + (lane & 15);   // (query values by DPP row broadcast, as in classes A and B)
                 double qq[2];
-                if constexpr (EDD_QDPP) {
-                    qq[0] = q16p[0];
-                } else {
-                    Q[0][0] = Q2[0];
-                    Q[0][1] = Q2[1];
-                }
+                qq[0] = q16p[0];
                 int done_blocks = 0;
                 // (GUARDED = the last, partial chunk: a test per block; a full chunk runs its eight blocks as one basic block)
                 auto blocks = [&](auto guarded_tag) {
@@ -646,35 +546,20 @@ __device__ __forceinline__ void edd_body(const edd_args &A, const kvm_tile *__re
                         }
                         // (the 16 query values of the NEXT block; a guarded block's successor may lie past the window: its
                         // values are staged -- the query is padded -- and never used)
-                        if constexpr (EDD_QDPP) qq[(B + 1) & 1] = q16p[16 * (B + 1)];
+                        qq[(B + 1) & 1] = q16p[16 * (B + 1)];
 #pragma unroll
                         for (int g = 0; g < U; g++) {
                             const int G = B * U + g, Gx = G & 15;   // (the window rings go round twice per chunk)
                             R[(2 * g + AH) % RING] = X2[2 * Gx + AH];
                             R[(2 * g + AH + 1) % RING] = X2[2 * Gx + AH + 1];
-                            if constexpr (!EDD_QDPP) {
-                                Q[(g + PD) % NQ][0] = Q2[2 * (G + PD)];
-                                Q[(g + PD) % NQ][1] = Q2[2 * (G + PD) + 1];
-                            }
+                            // fence: the reads above stay above it (memory clobber), the FMAs below it (accumulator operands)
                             asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3])::"memory");
-#define EDD_W(k) (((k) & 1) ? R[(2 * g + (k) / 2) % RING].y : R[(2 * g + (k) / 2) % RING].x)
-                            if constexpr (EDD_QDPP) {
-                                const double qv = qq[B & 1];
+#define EDD_W(k) (((k) & 1) ? R[(2 * g + (k) / 2) % RING].y : R[(2 * g + (k) / 2) % RING].x)   // w[k] = X[c0 + 4G + k]
+                            const double qv = qq[B & 1];
 #pragma unroll
-                                for (int k = 0; k < 4; k++)
+                            for (int k = 0; k < 4; k++)
 #pragma unroll
-                                    for (int a = 0; a < CI; a++) edd_fmac_bc(acc[a], qv, EDD_W(a + k), 4 * g + k);
-                            } else {
-                                const ed4_d2 q0 = Q[g % NQ][0], q1 = Q[g % NQ][1];
-#pragma unroll
-                                for (int a = 0; a < CI; a++) acc[a] = __builtin_fma(EDD_W(a), q0.x, acc[a]);
-#pragma unroll
-                                for (int a = 0; a < CI; a++) acc[a] = __builtin_fma(EDD_W(a + 1), q0.y, acc[a]);
-#pragma unroll
-                                for (int a = 0; a < CI; a++) acc[a] = __builtin_fma(EDD_W(a + 2), q1.x, acc[a]);
-#pragma unroll
-                                for (int a = 0; a < CI; a++) acc[a] = __builtin_fma(EDD_W(a + 3), q1.y, acc[a]);
-                            }
+                                for (int a = 0; a < CI; a++) edd_fmac_bc(acc[a], qv, EDD_W(a + k), 4 * g + k);
 #undef EDD_W
                         }
                     }
@@ -692,26 +577,24 @@ __device__ __forceinline__ void edd_body(const edd_args &A, const kvm_tile *__re
                     }
                 }
             }
-        } else if (RINGED && jlim == JC) {
-            if constexpr (RINGED) {
+        } else if (jlim == JC) {
+            {
+                // Classes A and B.  Window registers: a ring of RING pairs, R[p % RING] = (X[c0 + 2p], X[c0 + 2p + 1]); sub-step G
+                // (4 points) reads pairs 2G .. 2G + CI/2 + 1 and, before its arithmetic, issues the LDS reads of the two window
+                // pairs the next sub-step adds -- into ring slots that died a sub-step earlier.  RING / 2 sub-steps advance the
+                // ring by exactly RING pairs, so every register index is a compile-time constant (no rotation moves).
                 // One revolution of the ring = one chunk of 128 points = 8 blocks of 16 points = 32 sub-steps, all unrolled:
                 // every LDS address and every register index is a compile-time constant.  At the start the rows hold the
                 // points [j0, j0 + 96); block B's turn writes points [j0 + 16 (B + 6), + 16) -- fetched four blocks ago --
                 // where the ring went dead two blocks ago (and, for the blocks that start the next revolution, behind the
                 // ring as well, where this revolution's last sub-steps read them), then fetches the block four further on.
-                constexpr int NP = CI / 2 + 2, PD = 1, RING = 8, U = RING / 2, NQ = PD + 1;
-                constexpr int AH = NP + 2 * (PD - 1);
-                ed4_d2 R[RING], Q[NQ][2];
+                constexpr int RING = 8, U = RING / 2, AH = CI / 2 + 2;
+                ed4_d2 R[RING];
 #pragma unroll
                 for (int j = 0; j < AH; j++) R[j] = X2[j];
                 const double *q16p = qlds + (lane & 15);
                 double qq[2];
-                if constexpr (EDD_QDPP) {
-                    qq[0] = q16p[0];
-                } else {
-                    Q[0][0] = Q2[0];
-                    Q[0][1] = Q2[1];
-                }
+                qq[0] = q16p[0];
 #pragma unroll
                 for (int B = 0; B < 8; B++) {
                     {
@@ -729,46 +612,30 @@ __device__ __forceinline__ void edd_body(const edd_args &A, const kvm_tile *__re
                     }
                     // (the 16 query values of the NEXT block, one per lane of a 16-lane row; the last block's come from the
                     // lookahead behind the query ring, written three blocks ago)
-                    if constexpr (EDD_QDPP) qq[(B + 1) & 1] = q16p[16 * (B + 1)];
+                    qq[(B + 1) & 1] = q16p[16 * (B + 1)];
 #pragma unroll
                     for (int g = 0; g < U; g++) {
                         const int G = B * U + g;
                         R[(2 * g + AH) % RING] = X2[2 * G + AH];
                         R[(2 * g + AH + 1) % RING] = X2[2 * G + AH + 1];
-                        if constexpr (!EDD_QDPP) {
-                            Q[(g + PD) % NQ][0] = Q2[2 * (G + PD)];
-                            Q[(g + PD) % NQ][1] = Q2[2 * (G + PD) + 1];
-                        }
                         if constexpr (CI == 8)
                             asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]),
                                          "+v"(acc[6]), "+v"(acc[7])::"memory");
                         else
                             asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3])::"memory");
 #define EDD_W(k) (((k) & 1) ? R[(2 * g + (k) / 2) % RING].y : R[(2 * g + (k) / 2) % RING].x)
-                        if constexpr (EDD_QDPP) {
-                            const double qv = qq[B & 1];
+                        const double qv = qq[B & 1];
 #pragma unroll
-                            for (int k = 0; k < 4; k++)
+                        for (int k = 0; k < 4; k++)
 #pragma unroll
-                                for (int a = 0; a < CI; a++) edd_fmac_bc(acc[a], qv, EDD_W(a + k), 4 * g + k);
-                        } else {
-                            const ed4_d2 q0 = Q[g % NQ][0], q1 = Q[g % NQ][1];
-#pragma unroll
-                            for (int a = 0; a < CI; a++) acc[a] = __builtin_fma(EDD_W(a), q0.x, acc[a]);
-#pragma unroll
-                            for (int a = 0; a < CI; a++) acc[a] = __builtin_fma(EDD_W(a + 1), q0.y, acc[a]);
-#pragma unroll
-                            for (int a = 0; a < CI; a++) acc[a] = __builtin_fma(EDD_W(a + 2), q1.x, acc[a]);
-#pragma unroll
-                            for (int a = 0; a < CI; a++) acc[a] = __builtin_fma(EDD_W(a + 3), q1.y, acc[a]);
-                        }
+                            for (int a = 0; a < CI; a++) edd_fmac_bc(acc[a], qv, EDD_W(a + k), 4 * g + k);
 #undef EDD_W
                     }
                 }
             }
-        } else if (RINGED) {
-            if constexpr (RINGED) {
-                // the last, partial chunk of the window: the rows hold [j0, j0 + 96); the points up to j0 + jlim + 72 go BEHIND
+        } else {
+            {
+                // classes A and B, the last, partial chunk of the window: the rows hold [j0, j0 + 96); the points up to j0 + jlim + 72 go BEHIND
                 // each other in the lookahead region, so that the row is linear from the ring's start (nothing of this chunk
                 // may be overwritten), and the query values [j0 + 64, j0 + 128) arrive in place
                 const ed4_d2 e10 = ring_ld(j0 + 160), e11 = ring_ld(j0 + 176), e12 = ring_ld(j0 + 192);
@@ -788,60 +655,6 @@ __device__ __forceinline__ void edd_body(const edd_args &A, const kvm_tile *__re
                     for (int a = 0; a < CI; a++) acc[a] = __builtin_fma(X[jj + a], qv, acc[a]);
                 }
             }
-        } else if (jlim == JC) {
-            // Window registers: a ring of RING pairs, R[p % RING] = (X[c0 + 2p], X[c0 + 2p + 1]).  Sub-step G (4 points)
-            // reads pairs 2G .. 2G + CI/2 + 1 and, before its arithmetic, issues the LDS reads of the two window pairs and
-            // the two query pairs that sub-step G + PD will add -- into ring slots that died PD sub-steps earlier.  RING/2
-            // sub-steps advance the ring by exactly RING pairs, so every register index below is a compile-time constant
-            // (no rotation moves), and every LDS read has PD sub-steps of FMAs (32 / 16 each) to land.
-            constexpr int NP = CI / 2 + 2;
-            constexpr int PD = SUB == 2 ? 1 : EDD_PD;   // (class C: 20 sub-steps per chunk, not a multiple of 8)
-            constexpr int RING = PD == 1 ? 8 : 16, U = RING / 2, NQ = PD + 1;
-            static_assert(NP + 2 * PD <= RING && (JC / 4) % U == 0 && U % NQ == 0, "static ring / query-buffer indices");
-            ed4_d2 R[RING], Q[NQ][2];
-#pragma unroll
-            for (int j = 0; j < NP + 2 * (PD - 1); j++) R[j] = X2[j];
-#pragma unroll
-            for (int d = 0; d < PD; d++) {
-                Q[d][0] = Q2[2 * d];
-                Q[d][1] = Q2[2 * d + 1];
-            }
-            for (int body = 0; body < JC / 4 / U; body++) {
-#pragma unroll
-                for (int g = 0; g < U; g++) {
-                    const int G = body * U + g;
-                    constexpr int AH = NP + 2 * (PD - 1);  // first pair sub-step G loads, relative to 2G
-                    R[(2 * g + AH) % RING] = X2[2 * G + AH];  // (the last sub-steps of a chunk read past it: staged, unused)
-                    R[(2 * g + AH + 1) % RING] = X2[2 * G + AH + 1];
-                    Q[(g + PD) % NQ][0] = Q2[2 * (G + PD)];
-                    Q[(g + PD) % NQ][1] = Q2[2 * (G + PD) + 1];
-                    // fence: the reads above stay above it (memory clobber), the FMAs below it (accumulator operands)
-                    if constexpr (CI == 8)
-                        asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]),
-                                     "+v"(acc[6]), "+v"(acc[7])::"memory");
-                    else
-                        asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3])::"memory");
-                    const ed4_d2 q0 = Q[g % NQ][0], q1 = Q[g % NQ][1];
-                    // w[k] = X[c0 + 4G + k], k < CI + 4
-#define EDD_W(k) (((k) & 1) ? R[(2 * g + (k) / 2) % RING].y : R[(2 * g + (k) / 2) % RING].x)
-#pragma unroll
-                    for (int a = 0; a < CI; a++) acc[a] = __builtin_fma(EDD_W(a), q0.x, acc[a]);
-#pragma unroll
-                    for (int a = 0; a < CI; a++) acc[a] = __builtin_fma(EDD_W(a + 1), q0.y, acc[a]);
-#pragma unroll
-                    for (int a = 0; a < CI; a++) acc[a] = __builtin_fma(EDD_W(a + 2), q1.x, acc[a]);
-#pragma unroll
-                    for (int a = 0; a < CI; a++) acc[a] = __builtin_fma(EDD_W(a + 3), q1.y, acc[a]);
-#undef EDD_W
-                }
-            }
-        } else {
-            const double *X = reinterpret_cast<const double *>(X2);
-            for (int jj = 0; jj < jlim; jj++) {
-                const double qv = qlds[jj];
-#pragma unroll
-                for (int a = 0; a < CI; a++) acc[a] = __builtin_fma(X[jj + a], qv, acc[a]);
-            }
         }
         if (more) {
             // early abandon (reference behaviour): the distance is a sum of non-negative terms, so a candidate whose
@@ -853,7 +666,7 @@ __device__ __forceinline__ void edd_body(const edd_args &A, const kvm_tile *__re
             constexpr int EVERY = JC >= ED8_JC ? 7 : 15;   // (chunks between two tests of an unsplit unit: ~1024 points)
             if (ABANDON && (ch == ch_lo || (f == 1 && ((ch - ch_lo) & EVERY) == EVERY))) {
                 const int jlo = ch_lo * JC, J = j0 + JC;
-                const double2 qa = q_pref[(ch + 1) * cfg::QS], qb = q_pref[ch_lo * cfg::QS];
+                const double2 qa = q_pref[ch + 1], qb = q_pref[ch_lo];
                 const double2 qp = make_double2(qa.x - qb.x, qa.y - qb.y);
                 // (a rolled loop: this runs once per 8 chunks, and unrolling its eight prefix-sum evaluations around
                 // the hot loop's live registers made the compiler spill)
@@ -897,7 +710,6 @@ __device__ __forceinline__ void edd_body(const edd_args &A, const kvm_tile *__re
                     break;  // split unit: the other parts wait at the barrier below
                 }
             }
-            if (!RINGED && !RINGC && !RING16) store_chunk();
         }
     }
     if (f > 1) {
