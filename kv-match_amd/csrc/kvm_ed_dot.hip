@@ -95,10 +95,25 @@ typedef double ed4_d2u __attribute__((ext_vector_type(2), aligned(8)));
 #define EDD16_WAVE_B (EDD16_ROWS * EDD16_ROW_B)
 #define EDD16_RINGP 16                       // register ring, pairs: sub-step G holds pairs 2G .. 2G + 9, loads 2G + 10, 2G + 11
 #ifndef EDD16_AHEAD
-#define EDD16_AHEAD 4                        // blocks a global load is issued ahead of its LDS write (1, 2 or 4)
-#endif
+#define EDD16_AHEAD (EDD16_KARATSUBA ? 2 : 4)   // blocks a global load is issued ahead of its LDS write (1, 2 or 4; the
+#endif                                          // Karatsuba form has 25 accumulators and a third register ring to hold)
 #ifndef EDD_A16
 #define EDD_A16 1                            // 0: class A on 8 lanes x 8 candidates in every mode (rounds 2 - 4)
+#endif
+// The 16-per-lane form computes the correlation of a PAIR of candidates (2u, 2u + 1) with three half-length sums instead of
+// four (the two-parallel fast FIR structure, Karatsuba's trick on the even / odd phases of window and query):
+//     acc[2u]   = EE(u) + OO(u)                      EE(u) = sum_t x[2(u + t)]     qc[2t]
+//     acc[2u+1] = SS(u) - OO(u) - EE(u + 1)          OO(u) = sum_t x[2(u + t) + 1] qc[2t + 1]
+//                                                    SS(u) = sum_t (x[2(u + t) + 1] + x[2(u + t) + 2]) (qc[2t] + qc[2t + 1])
+// A lane's 16 candidates are 8 pairs: 9 EE + 8 OO + 8 SS = 25 accumulators, 25 FMAs per TWO window points instead of 32, and
+// one addition per two points for the sums of neighbouring window values -- formed in registers: the LDS holds the plain
+// window as before, a ds_read_b128 returns (x[2n], x[2n + 1]) = entry n of the even and of the odd phase.  The query's
+// phases qc[2t], qc[2t + 1] and their sums come from three host-built arrays (kvm_query_dev::qk).  Algebraically the same
+// sum; its rounding differs from the plain form's by a few ulps of sum |x| |qc| -- five orders of magnitude inside the guard
+// band the pruner keeps around eps^2 (1e-11 of the same magnitudes), and the exact pass decides as before.
+// profiles/r05_ed_a16k.log: the loop alone 68.2 against 57.7 TFLOP/s counted as 16 FMAs per point.
+#ifndef EDD16_KARATSUBA
+#define EDD16_KARATSUBA 1
 #endif
 template <int K>
 __device__ __forceinline__ void edd_fmac_bcK(double &acc, double q16, double w) {
@@ -415,6 +430,17 @@ __device__ __forceinline__ void edd_body(const edd_args &A, const kvm_tile *__re
     ed4_d2 pend16[EDD16_AHEAD][2], R16[EDD16_RINGP];   // blocks fetched and not yet written; the window registers (carried from chunk to chunk)
     static_assert(EDD16_AHEAD == 1 || EDD16_AHEAD == 2 || EDD16_AHEAD == 4, "8 blocks per revolution: static register indices");
     double qq16[2];                          // query values of the block in hand and of the next: qc[j + (lane & 15)]
+    // Karatsuba form: 9 + 8 + 8 accumulators; XS16[n % 16] = R16[n].y + R16[n + 1].x (sum of the neighbouring window points
+    // 2n + 1, 2n + 2 of the lane); the three query phases of the 16 taps (= 32 points) in hand and of the next 16
+    double kE[9], kO[8], kS[8], XS16[16], qe16[2], qo16[2], qs16[2];
+    const int nk = kvm_qk_len(m);
+    const double *__restrict__ qe_g = qd.qk, *__restrict__ qo_g = qd.qk + nk, *__restrict__ qs_g = qd.qk + 2 * (size_t)nk;
+    if constexpr (RING16 && EDD16_KARATSUBA) {
+#pragma unroll
+        for (int u = 0; u < 9; u++) kE[u] = 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; u++) kO[u] = kS[u] = 0.0;
+    }
     if (work && ch_lo < ch_hi) {
         if constexpr (RING16) {
             const int jb = ch_lo * JC;
@@ -422,7 +448,13 @@ __device__ __forceinline__ void edd_body(const edd_args &A, const kvm_tile *__re
                 ed4_d2 u[8], v[8];
 #pragma unroll
                 for (int b = 0; b < 8; b++) ld16(jb + 16 * b, u[b], v[b]);
-                qq16[0] = qc[jb + (lane & 15)];
+                if constexpr (EDD16_KARATSUBA) {
+                    qe16[0] = qe_g[jb / 2 + (lane & 15)];
+                    qo16[0] = qo_g[jb / 2 + (lane & 15)];
+                    qs16[0] = qs_g[jb / 2 + (lane & 15)];
+                } else {
+                    qq16[0] = qc[jb + (lane & 15)];
+                }
 #pragma unroll
                 for (int i = 0; i < EDD16_AHEAD; i++) ld16(jb + 128 + 16 * i, pend16[i][0], pend16[i][1]);
 #pragma unroll
@@ -430,7 +462,11 @@ __device__ __forceinline__ void edd_body(const edd_args &A, const kvm_tile *__re
             }
             asm volatile("" ::: "memory");
 #pragma unroll
-            for (int i = 0; i < 10; i++) R16[i] = *reinterpret_cast<const ed4_d2 *>(rowp16 + 128 * lc + 16 * i);
+            for (int i = 0; i < (EDD16_KARATSUBA ? 12 : 10); i++) R16[i] = *reinterpret_cast<const ed4_d2 *>(rowp16 + 128 * lc + 16 * i);
+            if constexpr (EDD16_KARATSUBA) {
+#pragma unroll
+                for (int i = 0; i < 11; i++) XS16[i] = R16[i].y + R16[i + 1].x;
+            }
         } else if constexpr (RINGC) {
             const int jb = ch_lo * JC;
             ed4_d2 p3[2][3];
@@ -469,8 +505,73 @@ __device__ __forceinline__ void edd_body(const edd_args &A, const kvm_tile *__re
         const int j0 = ch * JC;
         const bool more = ch + 1 < ch_hi;
         const int jlim = min(JC, m - j0);
-        if constexpr (RING16) {
+        if constexpr (RING16 && EDD16_KARATSUBA) {
             {
+                // One revolution of the ring = one chunk of 128 points = 64 taps = 16 sub-steps of 4 taps (8 points), as
+                // compile-time loops.  Pair p of the lane = its window points 16 lc + 2p, + 1 = rowp16 + 128 lc + 16 p; sub-step S
+                // holds pairs 4S .. 4S + 11 in R16[p % 16] (and the sums XS16 of pairs 4S .. 4S + 10) and fetches pairs
+                // 4S + 12 .. 4S + 15 for the next; lane class lc's pointer passes the end of the ring at sub-step 13 - 2 lc.
+                const char *P = rowp16 + 128 * lc + 192;
+                const int t0 = j0 / 2;
+                edd_static_for<16>([&](auto Sc) {
+                    constexpr int S = decltype(Sc)::value;
+                    if constexpr (S % 4 == 0) {   // the query phases of the NEXT 16 taps (issued before this turn's window points)
+                        constexpr int B = S / 4;
+                        qe16[(B + 1) & 1] = qe_g[t0 + 16 * (B + 1) + (lane & 15)];
+                        qo16[(B + 1) & 1] = qo_g[t0 + 16 * (B + 1) + (lane & 15)];
+                        qs16[(B + 1) & 1] = qs_g[t0 + 16 * (B + 1) + (lane & 15)];
+                    }
+#ifndef EDD_DBG_NOSTAGE   // (experiments, profiles/ab_a16k.sh: what the staging alone / the arithmetic alone cost)
+                    if constexpr (S % 2 == 0) {
+                        constexpr int b = S / 2;
+                        wr16(b, pend16[b % EDD16_AHEAD][0], pend16[b % EDD16_AHEAD][1]);
+                        ld16(j0 + 128 + 16 * (b + EDD16_AHEAD), pend16[b % EDD16_AHEAD][0], pend16[b % EDD16_AHEAD][1]);
+                    }
+#endif
+                    if constexpr (S == 13 || S == 11 || S == 9 || S == 7) {
+                        constexpr int cls = (13 - S) / 2;
+                        P = (lc == cls) ? P - 1024 : P;
+                    }
+                    edd_static_for<4>([&](auto ic) {
+                        constexpr int i = decltype(ic)::value;
+                        R16[(4 * S + 12 + i) % 16] = *reinterpret_cast<const ed4_d2 *>(P + 64 * S + 16 * i);
+                    });
+                    // fence: the reads above stay above it (memory clobber), the FMAs below it (accumulator operands)
+                    asm volatile("" : "+v"(kE[0]), "+v"(kE[1]), "+v"(kE[2]), "+v"(kE[3]), "+v"(kE[4]), "+v"(kE[5]), "+v"(kE[6]), "+v"(kE[7]),
+                                 "+v"(kE[8]), "+v"(kO[0]), "+v"(kO[1]), "+v"(kO[2]), "+v"(kO[3]), "+v"(kO[4]), "+v"(kO[5]), "+v"(kO[6]),
+                                 "+v"(kO[7])::"memory");
+                    const double qev = qe16[(S / 4) & 1], qov = qo16[(S / 4) & 1], qsv = qs16[(S / 4) & 1];
+#ifdef EDD_DBG_NOFMA
+                    edd_static_for<1>([&](auto kc) {
+#else
+                    edd_static_for<4>([&](auto kc) {
+#endif
+                        constexpr int k = decltype(kc)::value;
+                        constexpr int K = 4 * (S & 3) + k, T = 4 * S + k;   // the tap's lane in the query registers; the tap itself
+                        edd_static_for<9>([&](auto uc) {
+                            constexpr int u = decltype(uc)::value;
+                            edd_fmac_bcK<K>(kE[u], qev, R16[(T + u) % 16].x);
+                        });
+                        edd_static_for<8>([&](auto uc) {
+                            constexpr int u = decltype(uc)::value;
+                            edd_fmac_bcK<K>(kO[u], qov, R16[(T + u) % 16].y);
+                        });
+                        edd_static_for<8>([&](auto uc) {
+                            constexpr int u = decltype(uc)::value;
+                            edd_fmac_bcK<K>(kS[u], qsv, XS16[(T + u) % 16]);
+                        });
+                    });
+                    // the sums the next sub-step adds (pairs 4S + 11 .. 4S + 15 have landed by now)
+                    edd_static_for<4>([&](auto ic) {
+                        constexpr int i = decltype(ic)::value;
+                        XS16[(4 * S + 11 + i) % 16] = R16[(4 * S + 11 + i) % 16].y + R16[(4 * S + 12 + i) % 16].x;
+                    });
+                });
+                (void)jlim;
+            }
+        } else if constexpr (RING16) {
+            {
+                // (the plain form, EDD16_KARATSUBA = 0)
                 // One revolution of the ring = one chunk of 128 points = 32 sub-steps of 4 points, as compile-time loops.  Sub-step
                 // G holds the window pairs 2G .. 2G + 9 of its lane (positions 16 lc + 4G .. + 19) in R16[(2G + i) % 16] and
                 // fetches pairs 2G + 10, 2G + 11 for the next; the last five sub-steps fetch what the next revolution starts with.
@@ -710,6 +811,14 @@ __device__ __forceinline__ void edd_body(const edd_args &A, const kvm_tile *__re
                     break;  // split unit: the other parts wait at the barrier below
                 }
             }
+        }
+    }
+    if constexpr (RING16 && EDD16_KARATSUBA) {
+        // the pairs' three sums -> the sixteen correlations (linear: a part's share of them adds up like the plain form's)
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            acc[2 * u] = kE[u] + kO[u];
+            acc[2 * u + 1] = kS[u] - kO[u] - kE[u + 1];
         }
     }
     if (f > 1) {
@@ -1060,6 +1169,11 @@ int kvm_ed_dot_choose_classes(int m, int64_t tilesA, int64_t tilesB, int64_t til
     return edd_choose_classes(m, tilesA, tilesB, tilesC, num_cu);   // class A runs in its 8-per-lane form)
 }
 
+static bool env_set(const char *name) {   // (set AND not empty: `VAR= cmd` leaves an empty string in the environment)
+    const char *e = getenv(name);
+    return e && e[0] && e[0] != '0';
+}
+
 hipError_t kvm_launch_ed_dot(const double *series, const double2 *prefix, int64_t n, const kvm_query_dev &qd,
                              const kvm_tile *tilesA, int64_t nA, const kvm_tile *tilesB, int64_t nB,
                              const kvm_tile *tilesC, int64_t nC, kvm_surv *surv,
@@ -1068,7 +1182,7 @@ hipError_t kvm_launch_ed_dot(const double *series, const double2 *prefix, int64_
                              hipEvent_t ev_stop) {
     (void)n;
     if (nA + nB + nC <= 0) return hipSuccess;
-    const bool a16_ok = (qd.early_abandon ? edd_a16<true>() : edd_a16<false>()) && !getenv("KVM_ED_NO_A16");   // (experiments)
+    const bool a16_ok = (qd.early_abandon ? edd_a16<true>() : edd_a16<false>()) && !env_set("KVM_ED_NO_A16");   // (experiments)
     bool a16 = false;
     const int64_t unitsA16 = (nA + EDD_TILES_A16 - 1) / EDD_TILES_A16;
     int64_t unitsA = (nA + EDD_TILES_A - 1) / EDD_TILES_A;

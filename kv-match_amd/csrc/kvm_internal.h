@@ -232,9 +232,10 @@ struct kvm_query_dev {
     // correlation-form pruner (kvm_ed_dot.hip): statistics of the device query q[] (raw for RSM, zQ for cNSM)
     double q_mean;          // mean of q
     const double *qc;       // q - q_mean, device, m entries (+ KVM_SERIES_PAD spare)
-    const double2 *q_pref;  // q_pref[t] = { sum_{j < t*ED16_JC} (q_j - q_mean), sum_{j < t*ED16_JC} (q_j - q_mean)^2 }, t = 0 .. 2*ceil(m/ED4_JC)
-                            // (class C chunks; a class B chunk is two of them; entries past m hold the totals)
-    const double2 *q_pref8; // the same at ED8_JC granularity
+    const double2 *q_pref8; // q_pref8[t] = { sum_{j < t*ED8_JC} (q_j - q_mean), sum_{j < t*ED8_JC} (q_j - q_mean)^2 }, t = 0 .. ceil(m/ED8_JC)
+                            // (entries past m hold the totals)
+    const double *qk;       // the phases of qc for the 16-per-lane class A (kvm_ed_dot.hip, EDD16_KARATSUBA): three arrays of
+                            // kvm_qk_len(m) doubles -- qc[2t] | qc[2t + 1] | qc[2t] + qc[2t + 1] -- zero beyond the query
     const double *run_hist; // cNSM: per run, the largest x^2 among the points the reference's running sums of that run pass
                             // over (to the granularity of the prefix blocks; NaN with a NaN among them) -- see kvm_hist_*
 };
@@ -244,6 +245,10 @@ struct kvm_query_dev {
 hipError_t kvm_launch_ed_wave(const double *series, const double2 *prefix, int64_t n, const kvm_query_dev &qd,
                               const kvm_tile *tiles, int64_t n_tiles, kvm_surv *surv, int64_t cap,
                               unsigned long long *counters, hipStream_t s);
+#ifdef __HIPCC__
+__host__ __device__
+#endif
+static inline int kvm_qk_len(int m) { return (m + 1) / 2 + KVM_SERIES_PAD / 2; }
 #define ED4_JC 160  // chunk lengths of the correlation-form pruner (also the granularity of kvm_query_dev::q_pref / q_pref8 /
 #define ED8_JC 128  // q_pref16): class B (4 candidates per lane), class A (8 per lane), class C (4 per lane, two 16-candidate
 #define ED16_JC 80  // tiles per row)

@@ -165,11 +165,12 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
     // (kvm_ed_dot.hip)
     const int32_t tile_max = retile ? KVM_TILE_MAX : (!dtw && ed_kernel == 3) ? KVM_TILE_TILED : KVM_TILE_MAX;
     const bool hybrid = !dtw && ed_kernel == 3 && !retile;
-    // query block: q | (qu | ql for DTW) | pad || (qc | pad | q_pref | q_pref8 | qT for ED) || (zQ sorted | order: cNSM-ED
-    // exact pass); the runs follow it in the pinned staging buffer, where build_plan writes them directly
-    const int nchunks4 = (m + ED4_JC - 1) / ED4_JC, nchunks8 = (m + ED8_JC - 1) / ED8_JC;
+    // query block: q | (qu | ql for DTW) | pad || (qc | pad | q_pref8 | qk = the three phase arrays of qc, for ED) || (zQ
+    // sorted | order: cNSM-ED exact pass); the runs follow it in the pinned staging buffer, where build_plan writes them directly
+    const int nchunks8 = (m + ED8_JC - 1) / ED8_JC, nk = kvm_qk_len(m);
     const size_t qmain = (size_t)m * 8 * (dtw ? 3 : 1) + KVM_SERIES_PAD * sizeof(double);
-    const size_t qdot = dtw ? 0 : (size_t)m * 8 + KVM_SERIES_PAD * sizeof(double) + ((size_t)2 * nchunks4 + 1 + nchunks8 + 1) * 16;
+    const size_t qpref_off = (size_t)m * 8 + KVM_SERIES_PAD * sizeof(double), qk_off = qpref_off + ((size_t)nchunks8 + 1) * 16;
+    const size_t qdot = dtw ? 0 : qk_off + (size_t)3 * nk * 8;
     const size_t qexact_off = qmain + qdot;
     // DTW: the reference's summation order of the LB_Keogh loops and the query / its envelope in that order
     // (uo | lo | qo | order) behind the main block
@@ -237,7 +238,7 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
     KVM_TP("  plan launches");
     // correlation-form ED pruner: centred query and its chunk-granular prefix sums
     std::vector<double> qcen;
-    std::vector<double2> qpref, qpref8;
+    std::vector<double2> qpref8;
     if (!dtw) {
         // (pruner-side quantities, guard-banded: the summation order is free, so four interleaved partial sums keep the
         // adders busy -- the plain sequential loops cost ~20 us of the host's critical path at m = 8192)
@@ -248,15 +249,12 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
         for (; i4 < m; i4++) s4[0] += q[i4];
         qd.q_mean = ((s4[0] + s4[1]) + (s4[2] + s4[3])) / m;
         qcen.resize(m);
-        qpref.resize((size_t)2 * nchunks4 + 1);  // ED16_JC-granular: class C uses every entry, class B every second one
         qpref8.resize((size_t)nchunks8 + 1);
-        static_assert(ED4_JC % 4 == 0 && ED8_JC % 4 == 0 && ED16_JC % 4 == 0 && ED4_JC == 2 * ED16_JC,
-                      "chunk boundaries fall between groups of four; class B chunks are two class C chunks");
+        static_assert(ED8_JC % 4 == 0, "chunk boundaries fall between groups of four");
         double a1[4] = {0, 0, 0, 0}, a2[4] = {0, 0, 0, 0};
         const double qm = qd.q_mean;
         int i = 0;
         for (; i < m; i += 4) {
-            if (i % ED16_JC == 0) qpref[(size_t)(i / ED16_JC)] = make_double2((a1[0] + a1[1]) + (a1[2] + a1[3]), (a2[0] + a2[1]) + (a2[2] + a2[3]));
             if (i % ED8_JC == 0) qpref8[(size_t)(i / ED8_JC)] = make_double2((a1[0] + a1[1]) + (a1[2] + a1[3]), (a2[0] + a2[1]) + (a2[2] + a2[3]));
             const int lim = std::min(4, m - i);
             for (int u = 0; u < lim; u++) {
@@ -267,7 +265,6 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
             }
         }
         const double p1 = (a1[0] + a1[1]) + (a1[2] + a1[3]), p2 = (a2[0] + a2[1]) + (a2[2] + a2[3]);
-        for (size_t t = (size_t)((m + ED16_JC - 1) / ED16_JC); t <= (size_t)2 * nchunks4; t++) qpref[t] = make_double2(p1, p2);
         qpref8[(size_t)nchunks8] = make_double2(p1, p2);
     }
     const size_t tbytes = (size_t)((retile || dtw) ? 3 * pl.n_tiles : pl.n_tiles + pl.n_tiles_b + pl.n_tiles_c) * sizeof(kvm_tile);
@@ -280,9 +277,16 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
     std::memcpy(hp, q.data(), (size_t)m * 8);
     if (!dtw) {
         std::memcpy(hp + qmain, qcen.data(), (size_t)m * 8);
-        std::memcpy(hp + qmain + (size_t)m * 8 + KVM_SERIES_PAD * sizeof(double), qpref.data(), qpref.size() * 16);
-        std::memcpy(hp + qmain + (size_t)m * 8 + KVM_SERIES_PAD * sizeof(double) + qpref.size() * 16, qpref8.data(),
-                    qpref8.size() * 16);
+        std::memcpy(hp + qmain + qpref_off, qpref8.data(), qpref8.size() * 16);
+        // the phases of the centred query (kvm_ed_dot.hip, EDD16_KARATSUBA): qc[2t] | qc[2t + 1] | their sum, zero beyond m
+        double *qe = (double *)(hp + qmain + qk_off), *qo = qe + nk, *qs = qo + nk;
+        std::memset(qe, 0, (size_t)3 * nk * 8);
+        for (int t = 0; 2 * t < m; t++) {
+            const double e = qcen[(size_t)2 * t], o = 2 * t + 1 < m ? qcen[(size_t)2 * t + 1] : 0.0;
+            qe[t] = e;
+            qo[t] = o;
+            qs[t] = e + o;
+        }
     }
     const size_t qfirst = (cnsm && !dtw) ? qexact_off : qbytes;  // the exact-pass block is staged later (see below)
     if (dtw) {
@@ -337,10 +341,8 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
     }
     qd.q = (const double *)ctx->b_query.p;
     qd.qc = dtw ? nullptr : (const double *)((const char *)ctx->b_query.p + qmain);
-    qd.q_pref = dtw ? nullptr
-                    : (const double2 *)((const char *)ctx->b_query.p + qmain + (size_t)m * 8 +
-                                        KVM_SERIES_PAD * sizeof(double));
-    qd.q_pref8 = dtw ? nullptr : qd.q_pref + (2 * nchunks4 + 1);
+    qd.q_pref8 = dtw ? nullptr : (const double2 *)((const char *)ctx->b_query.p + qmain + qpref_off);
+    qd.qk = dtw ? nullptr : (const double *)((const char *)ctx->b_query.p + qmain + qk_off);
     qd.qu = dtw ? qd.q + m : nullptr;
     qd.ql = dtw ? qd.q + 2 * (size_t)m : nullptr;
     unsigned long long *counters = (unsigned long long *)ctx->b_counters.p;
