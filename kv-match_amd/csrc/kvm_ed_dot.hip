@@ -1091,11 +1091,10 @@ hipError_t kvm_launch_retile_cnsm(const double *series, const double2 *prefix, c
     return hipGetLastError();
 }
 
-// Class A on 16 candidates per lane: where every point is evaluated AND the list is long enough.  With the reference's
-// early abandoning a wave's 1024 candidates would have to die together before it could leave (512 with 8 per lane), and
-// those calls are bound by their launch chain, not by the FMA rate.  A 16-tile unit split f ways is as many parts as an
-// 8-tile unit split f / 2 ways: a list so short that the 8-per-lane form wants its four-way split (a few hundred tiles left
-// by a selective filter: the call lasts as long as one part) stays with the 8-per-lane form -- decided per launch (`a16`).
+// Class A on 16 candidates per lane: where every point is evaluated and the list is not tiny (edd_use_a16: decided per launch,
+// `a16`; device-built lists: inside the kernel, from the real counts).  With the reference's early abandoning a wave's 1024
+// candidates would have to die together before it could leave (512 with 8 per lane), and those calls are bound by their
+// launch chain, not by the FMA rate: never there.
 template <bool ABANDON>
 __host__ __device__ constexpr bool edd_a16() { return EDD_A16 && !ABANDON; }
 template <bool ABANDON>
@@ -1123,8 +1122,11 @@ __global__ __launch_bounds__(256, 2) void kvm_ed_dot_kernel(edd_args A, const kv
                       uB = (nB + EDD_TILES_B - 1) / EDD_TILES_B, uC = (nC + EDD_TILES_C - 1) / EDD_TILES_C;
         const bool small = uA8 + uB + uC <= split_units;
         fB = fC = small ? 4 : 1;
-        a16 = A16 && a16 && !small && uA16 + uB + uC >= a16_min_units;   // (the host's rule, on the real counts: edd_use_a16)
-        fA = a16 ? (uA16 + uB + uC <= split_units ? 2 : 1) : (small ? 4 : 1);
+        // (the host's rule, on the real counts: edd_use_a16 -- and, cNSM: only on lists that fill the wave slots: a part's
+        // prologue there is the (alpha, beta) filter of 16 candidates per lane, and the bench's queries, whose filter leaves
+        // ~ 900 eight-tile units, take 0.173 ms in this form against 0.152 in the other)
+        a16 = A16 && a16 && uA16 + uB + uC >= a16_min_units && !(NORM && small);
+        fA = small ? 4 : ((a16 && uA16 + uB + uC <= split_units) ? 2 : 1);
         blocksA = ((a16 ? uA16 : uA8) * fA + 3) / 4;
         blocksC = (uC * fC + 3) / 4;
     }

@@ -68,17 +68,18 @@ static inline double edd_makespan(const double cnt_in[3], const double w[3], dou
     return t;
 }
 // modelled duration (microseconds, without the launch's constant) of unitsA / unitsB / unitsC units split fA / fB ways
-// Class A in its 16-per-lane form (kvm_ed_dot.hip, EDD16_*): when?  profiles/ed_a16_sweep.py -> profiles/r05_a16_sweep.log, 36
-// list shapes, both forms under their best split pair: the 16-per-lane form is 2 - 6 % ahead wherever the list's units (16-tile
-// class-A units + class-B + class-C units) come to 0.85 of the wave slots or more (worst case there + 2 %), and from 0.4 of
-// the slots on for windows of 4096 points and more; on shorter lists it is up to 17 % behind (half as many, longer parts).
-static inline int64_t edd_a16_min_units(int m, double slots) { return (int64_t)std::ceil((m >= 4096 ? 0.4 : 0.85) * slots); }
+// Class A in its 16-per-lane form (kvm_ed_dot.hip, EDD16_*: 16 rows x 4 lanes, the Karatsuba split of a pair's correlation):
+// when?  profiles/ed_a16_sweep.py -> profiles/r05_a16k_sweep.log, 36 list shapes, both forms under their best split pair: the
+// 16-per-lane form is 5 - 19 % ahead from 0.1 of the wave slots in units (16-tile class-A units + class-B + class-C units) on
+// for windows of 4096 points and more, and 4 - 15 % ahead from 0.25 of the slots on for shorter windows; below that it is 3 - 6 %
+// behind (half as many, longer parts, and a part's prologue fills a 128-point ring per row).
+static inline int64_t edd_a16_min_units(int m, double slots) { return (int64_t)std::ceil((m >= 4096 ? 0.1 : 0.25) * slots); }
 static inline bool edd_use_a16(int m, int64_t units16, double slots) { return units16 >= edd_a16_min_units(m, slots); }
 // (a16: the class-A units are 16-tile units of the 16-per-lane form; a16 / b16 fitted by profiles/fit_ed_a16.py to the same
 // sweep, the rest of the model as it was: rms log error 6 %)
 static inline double edd_model(int m, double unitsA, double unitsB, double unitsC, int fA, int fB, double slots, bool a16 = false) {
     auto chunks = [](int mm, int jc, int f) { return std::ceil(std::ceil((double)mm / jc) / f); };
-    const double w[3] = {a16 ? 9.627 + 8.894 * chunks(m, ED8_JC, fA) : 5.188 + 4.535 * chunks(m, ED8_JC, fA),
+    const double w[3] = {a16 ? 10.693 + 7.331 * chunks(m, ED8_JC, fA) : 5.188 + 4.535 * chunks(m, ED8_JC, fA),
                          6.360 + 3.899 * chunks(m, ED8_JC, fB), 3.951 + 3.719 * chunks(m, ED8_JC, fB)};   // launch order: A, C, B
     auto parts = [](double units, int f) { return 4.0 * std::ceil(units * f / 4.0); };  // whole workgroups of 4 waves
     const double cnt[3] = {parts(unitsA, fA), parts(unitsC, fB), parts(unitsB, fB)};

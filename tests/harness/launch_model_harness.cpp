@@ -43,8 +43,9 @@ int main() {
     CHECK(edd_choose_classes(8192, 1600, 3000, 19000, 256) == 2, "(memoised) the same again");
     // class A on 16 candidates per lane: by the size of the list (profiles/r05_a16_sweep.log)
     CHECK(edd_use_a16(8192, 931 + 533 + 344, slots), "bench list (0.88 of the wave slots in 16-tile units): 16 per lane");
-    CHECK(!edd_use_a16(8192, 195 + 17 + 9, slots) && !edd_use_a16(2048, 931 + 267 + 170, slots) && edd_use_a16(2048, 1948 + 161 + 82, slots),
-          "short lists stay with 8 per lane; m < 4096 from 0.85 of the slots on");
+    CHECK(!edd_use_a16(8192, 150, slots) && edd_use_a16(8192, 195 + 17 + 9, slots) && !edd_use_a16(2048, 195 + 17 + 9, slots) &&
+              edd_use_a16(2048, 466 + 267 + 170, slots),
+          "tiny lists stay with 8 per lane: below 0.1 of the wave slots in units, 0.25 for m < 4096");
     t = edd_best_split(8192, 931, 533, 344, slots, fa, fb, true);
     CHECK((fa == 2 || fa == 1) && t > 300 && t < 600, "bench list, 16 per lane: split %d,%d modelled %.0f us", fa, fb, t);
     // degenerate inputs end, with finite results
