@@ -196,7 +196,12 @@ def roofline_block(wl, plans, launches, m, rates=None):
             "kernel": "kvm_ed_dot_kernel (ED pruning pass incl. the in-place exact evaluation of its survivors" +
                       ("; cNSM: + the (alpha, beta) retile before it)" if v == 1 else ")"),
             "kernel_ms": ks * 1e3 / nl, "launches_measured": len(ls), "candidates_evaluated_per_launch": evaluated / nl,
-            "executed_fma_tflops": ach,
+            # `achieved` counts the ALGORITHMIC work: one multiply-add per (candidate, point), 2 m flop per candidate.  Since round 5
+            # class A of a long list whose every point is evaluated computes a PAIR of candidates from three half-length sums
+            # instead of four (kvm_ed_dot.hip, EDD16_KARATSUBA): 25 FMAs per 32 (candidate, point) pairs there -- the FMAs the
+            # pruner executes are then fewer than the terms it accounts for (the second figure is filled in by the caller
+            # where it knows the list's tiles)
+            "executed_fma_tflops": ach, "executed_fma_note": "as `achieved` unless `executed_fma_share` is present",
             "reference_arithmetic_tflops": evaluated * m * 3.0 / ks / 1e12 if ks > 0 else 0.0,  # sub, mul, add per term
             "algorithmic_bytes_per_launch": algo_bytes / nl,
             "hbm_algorithmic_gbs": algo_bytes / ks / 1e9 if ks > 0 else 0.0,
@@ -545,7 +550,7 @@ def main():
                           "full_tiles_tflops": rate_a / 1e12, "full_tiles_frac_of_peak": rate_a / 1e12 / FP64_VALU_PEAK_TFLOPS,
                           "tiles": int(len(tiles_c)), "tiles_full": int((tiles_c == 64).sum()),
                           "tiles_33_63": int(((tiles_c > 32) & (tiles_c < 64)).sum()), "tiles_17_32": int(((tiles_c > 16) & (tiles_c <= 32)).sum()),
-                          "tiles_1_16": int((tiles_c <= 16).sum()), "window_bytes": float(8.0 * (m + tiles_c - 1).sum()),
+                          "tiles_1_16": int((tiles_c <= 16).sum()), "cands_in_class_a": int(tiles_c[tiles_c > 32].sum()), "window_bytes": float(8.0 * (m + tiles_c - 1).sum()),
                           "bandwidth_assumed_gbs": bw / 1e9,
                           "note": "sum over the list's tiles of max(FMA time at the rate of full isolated tiles measured in this run, "
                                   "window bytes / 6.3 TB/s): what this kernel's tiling can reach on THIS list; kernel_ms / list_bound_ms "
@@ -628,6 +633,13 @@ def main():
         out["roofline"].update(list_bound)
         if "list_bound_ms" in list_bound and out["roofline"].get("kernel_ms"):
             out["roofline"]["frac_of_list_bound"] = list_bound["list_bound_ms"] / out["roofline"]["kernel_ms"]
+        if "cands_in_class_a" in list_bound and not os.environ.get("KVM_ED_NO_A16"):
+            # class A (tiles of more than 32 candidates) runs the Karatsuba form on this list: 25 FMAs per 32 terms
+            share = (list_bound["cands_in_class_a"] * 25.0 / 32.0 + (my_cands - list_bound["cands_in_class_a"])) / max(1, my_cands)
+            out["roofline"]["executed_fma_share"] = share
+            out["roofline"]["executed_fma_tflops"] = out["roofline"]["achieved"] * share
+            out["roofline"]["executed_fma_note"] = ("class A of this list computes pairs of candidates from three half-length sums "
+                                                    "(25 FMAs per 32 terms); `achieved` counts the terms, this the FMAs")
     out["roofline"]["kernel_ms_note"] = ("HIP events on the kernel's own stream (RSM-ED every point: the start / stop stamps of the "
                                          "dispatch itself, hipExtLaunchKernelGGL), measured in this run right after the "
                                          f"timed region with ONE query in flight, averaged over the {NQ} queries and their "
