@@ -337,23 +337,29 @@ __device__ __forceinline__ void edd_body(const edd_args &A, const kvm_tile *__re
     // ---- which of my CI candidates are alive (bit a of `vm`); `fm`: degenerate sigma, survives unconditionally ----
     bool work = active;  // wave-uniform
     unsigned vm = 0, fm = 0;
+    // (a unit split f ways, every point evaluated: only part 0 -- which finishes the candidates -- needs the (alpha, beta)
+    // filter; the other parts accumulate for every candidate of their tiles and hand over.  Each part repeating the filter
+    // of all its lane's candidates was 3 / 4 of that work at f = 4, on lists whose parts are short to begin with.)
+    const bool need_filter = NORM && (ABANDON || part == 0);
 #pragma unroll
     for (int a = 0; a < CI; a++) {
         kvm_raw_sums raw0[4];
         if constexpr (NORM) {
-            if (a % 4 == 0) issue_full(raw0, a);
+            if (need_filter && a % 4 == 0) issue_full(raw0, a);
         }
         if (c0 + a < mine.count) {
             bool ok = true;
             if constexpr (NORM) {
-                const edd_cstat st = stats_from(raw0[a % 4], a, 0, m);
-                ok = kvm_cnsm_filter_guarded(c_row + st.mc, st.sg, qd.meanQ, qd.stdQ, qd.alpha, qd.beta, st.gd);
-                if (ok && (!(st.sg == st.sg) || !(st.sg > 0.0) || kvm_guard_degenerate(st.gd.g))) fm |= 1u << a;  // exact pass decides
+                if (need_filter) {
+                    const edd_cstat st = stats_from(raw0[a % 4], a, 0, m);
+                    ok = kvm_cnsm_filter_guarded(c_row + st.mc, st.sg, qd.meanQ, qd.stdQ, qd.alpha, qd.beta, st.gd);
+                    if (ok && (!(st.sg == st.sg) || !(st.sg > 0.0) || kvm_guard_degenerate(st.gd.g))) fm |= 1u << a;  // exact pass decides
+                }
             }
             if (ok) vm |= 1u << a;
         }
     }
-    if (NORM) {
+    if (NORM && need_filter) {
         unsigned cntp = (unsigned)__popc(vm);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) cntp += __shfl_xor(cntp, o, 64);
@@ -1125,7 +1131,7 @@ __global__ __launch_bounds__(256, 2) void kvm_ed_dot_kernel(edd_args A, const kv
         // (the host's rule, on the real counts: edd_use_a16 -- and, cNSM: only on lists that fill the wave slots: a part's
         // prologue there is the (alpha, beta) filter of 16 candidates per lane, and the bench's queries, whose filter leaves
         // ~ 900 eight-tile units, take 0.173 ms in this form against 0.152 in the other)
-        a16 = A16 && a16 && uA16 + uB + uC >= a16_min_units && !(NORM && small);
+        a16 = A16 && a16 && uA16 + uB + uC >= a16_min_units && !(NORM && small && a16 != 2);   // (a16 == 2: experiments)
         fA = small ? 4 : ((a16 && uA16 + uB + uC <= split_units) ? 2 : 1);
         blocksA = ((a16 ? uA16 : uA8) * fA + 3) / 4;
         blocksC = (uC * fC + 3) / 4;
@@ -1185,7 +1191,7 @@ hipError_t kvm_launch_ed_dot(const double *series, const double2 *prefix, int64_
     (void)n;
     if (nA + nB + nC <= 0) return hipSuccess;
     const bool a16_ok = (qd.early_abandon ? edd_a16<true>() : edd_a16<false>()) && !env_set("KVM_ED_NO_A16");   // (experiments)
-    bool a16 = false;
+    bool a16 = false, norm_small_a16 = false;
     const int64_t unitsA16 = (nA + EDD_TILES_A16 - 1) / EDD_TILES_A16;
     int64_t unitsA = (nA + EDD_TILES_A - 1) / EDD_TILES_A;
     const int64_t unitsB = (nB + EDD_TILES_B - 1) / EDD_TILES_B, unitsC = (nC + EDD_TILES_C - 1) / EDD_TILES_C;
@@ -1212,6 +1218,7 @@ hipError_t kvm_launch_ed_dot(const double *series, const double2 *prefix, int64_
         // kernel decides from the real counts (early abandon: only when the list cannot fill the chip anyway)
         split_units = -1;  // (bounds too large to size the grid for a split: the kernel then never splits)
         a16 = a16_ok;      // (the kernel decides from the real counts)
+        norm_small_a16 = a16_ok && env_set("KVM_ED_NORM_SMALL_A16");
         if ((double)(unitsA + unitsS) < 16.0 * slots) {
             fA = fB = 4;
             // (profiles/ed_norm_split_sweep.py: a four-way split pays up to one unit per wave slot for long windows and up to
@@ -1278,10 +1285,10 @@ hipError_t kvm_launch_ed_dot(const double *series, const double2 *prefix, int64_
     do {                                                                                                                          \
         if (ev_start && ev_stop)                                                                                                  \
             hipExtLaunchKernelGGL((kvm_ed_dot_kernel<NORM, AB>), grid, block, edd_lds_bytes<AB>(), s, ev_start, ev_stop, 0, A, tilesA, nA, tilesB,  \
-                                  nB, tilesC, nC, fA, fB, fC, blocksA, blocksC, d_counts, split_units, (int)a16, a16_min);       \
+                                  nB, tilesC, nC, fA, fB, fC, blocksA, blocksC, d_counts, split_units, norm_small_a16 ? 2 : (int)a16, a16_min); \
         else                                                                                                                      \
             hipLaunchKernelGGL((kvm_ed_dot_kernel<NORM, AB>), grid, block, edd_lds_bytes<AB>(), s, A, tilesA, nA, tilesB, nB, tilesC, nC, fA, fB,   \
-                               fC, blocksA, blocksC, d_counts, split_units, (int)a16, a16_min);                                   \
+                               fC, blocksA, blocksC, d_counts, split_units, norm_small_a16 ? 2 : (int)a16, a16_min);             \
     } while (0)
     if (qd.normalised) {
         if (qd.early_abandon) LAUNCH(true, true); else LAUNCH(true, false);

@@ -167,7 +167,10 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
     const bool hybrid = !dtw && ed_kernel == 3 && !retile;
     // query block: q | (qu | ql for DTW) | pad || (qc | pad | q_pref8 | qk = the three phase arrays of qc, for ED) || (zQ
     // sorted | order: cNSM-ED exact pass); the runs follow it in the pinned staging buffer, where build_plan writes them directly
-    const int nchunks8 = (m + ED8_JC - 1) / ED8_JC, nk = kvm_qk_len(m);
+    // (the phase arrays serve the 16-per-lane class A, which runs only where every point is evaluated: an abandoning call --
+    // bound by its launch chain and by the host's 50 us per call -- neither builds nor uploads their 3 (m / 2 + 1024) doubles)
+    const bool want_qk = !dtw && !ctx->opt_early_abandon;
+    const int nchunks8 = (m + ED8_JC - 1) / ED8_JC, nk = want_qk ? kvm_qk_len(m) : 0;
     const size_t qmain = (size_t)m * 8 * (dtw ? 3 : 1) + KVM_SERIES_PAD * sizeof(double);
     const size_t qpref_off = (size_t)m * 8 + KVM_SERIES_PAD * sizeof(double), qk_off = qpref_off + ((size_t)nchunks8 + 1) * 16;
     const size_t qdot = dtw ? 0 : qk_off + (size_t)3 * nk * 8;
@@ -280,8 +283,8 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
         std::memcpy(hp + qmain + qpref_off, qpref8.data(), qpref8.size() * 16);
         // the phases of the centred query (kvm_ed_dot.hip, EDD16_KARATSUBA): qc[2t] | qc[2t + 1] | their sum, zero beyond m
         double *qe = (double *)(hp + qmain + qk_off), *qo = qe + nk, *qs = qo + nk;
-        std::memset(qe, 0, (size_t)3 * nk * 8);
-        for (int t = 0; 2 * t < m; t++) {
+        if (want_qk) std::memset(qe, 0, (size_t)3 * nk * 8);
+        for (int t = 0; want_qk && 2 * t < m; t++) {
             const double e = qcen[(size_t)2 * t], o = 2 * t + 1 < m ? qcen[(size_t)2 * t + 1] : 0.0;
             qe[t] = e;
             qo[t] = o;
@@ -342,7 +345,7 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
     qd.q = (const double *)ctx->b_query.p;
     qd.qc = dtw ? nullptr : (const double *)((const char *)ctx->b_query.p + qmain);
     qd.q_pref8 = dtw ? nullptr : (const double2 *)((const char *)ctx->b_query.p + qmain + qpref_off);
-    qd.qk = dtw ? nullptr : (const double *)((const char *)ctx->b_query.p + qmain + qk_off);
+    qd.qk = want_qk ? (const double *)((const char *)ctx->b_query.p + qmain + qk_off) : nullptr;
     qd.qu = dtw ? qd.q + m : nullptr;
     qd.ql = dtw ? qd.q + 2 * (size_t)m : nullptr;
     unsigned long long *counters = (unsigned long long *)ctx->b_counters.p;
