@@ -1128,10 +1128,11 @@ __global__ __launch_bounds__(256, 2) void kvm_ed_dot_kernel(edd_args A, const kv
                       uB = (nB + EDD_TILES_B - 1) / EDD_TILES_B, uC = (nC + EDD_TILES_C - 1) / EDD_TILES_C;
         const bool small = uA8 + uB + uC <= split_units;
         fB = fC = small ? 4 : 1;
-        // (the host's rule, on the real counts: edd_use_a16 -- and, cNSM: only on lists that fill the wave slots: a part's
-        // prologue there is the (alpha, beta) filter of 16 candidates per lane, and the bench's queries, whose filter leaves
-        // ~ 900 eight-tile units, take 0.173 ms in this form against 0.152 in the other)
-        a16 = A16 && a16 && uA16 + uB + uC >= a16_min_units && !(NORM && small && a16 != 2);   // (a16 == 2: experiments)
+        // (the host's rule, on the real counts: edd_use_a16.  a16 == 2, experiments (KVM_ED_NORM_SMALL_A16=0): cNSM lists that
+        // do not fill the wave slots stay with 8 per lane -- before only part 0 of a split unit ran the (alpha, beta) filter
+        // that was the faster form for the bench's queries, 0.152 against 0.173 ms; since then the two are level for one
+        // query alone and the stream of eight gains 7 % with 16 per lane: fewer FMAs to share the chip with)
+        a16 = A16 && a16 && uA16 + uB + uC >= a16_min_units && !(NORM && small && a16 == 2);
         fA = small ? 4 : ((a16 && uA16 + uB + uC <= split_units) ? 2 : 1);
         blocksA = ((a16 ? uA16 : uA8) * fA + 3) / 4;
         blocksC = (uC * fC + 3) / 4;
@@ -1218,7 +1219,7 @@ hipError_t kvm_launch_ed_dot(const double *series, const double2 *prefix, int64_
         // kernel decides from the real counts (early abandon: only when the list cannot fill the chip anyway)
         split_units = -1;  // (bounds too large to size the grid for a split: the kernel then never splits)
         a16 = a16_ok;      // (the kernel decides from the real counts)
-        norm_small_a16 = a16_ok && env_set("KVM_ED_NORM_SMALL_A16");
+        { const char *e = getenv("KVM_ED_NORM_SMALL_A16"); norm_small_a16 = a16_ok && e && e[0] == '0'; }
         if ((double)(unitsA + unitsS) < 16.0 * slots) {
             fA = fB = 4;
             // (profiles/ed_norm_split_sweep.py: a four-way split pays up to one unit per wave slot for long windows and up to
