@@ -379,6 +379,12 @@ void kvm_result_free(kvm_result *r);
                                     holds <= rho points (a stub beyond the last window offset) -> KVM_ERR_INDEX_OUT_OF_BOUNDS,
                                     which the JNI shim throws as ArrayIndexOutOfBoundsException.  0: compute the envelope's
                                     natural extension (window clipped at the array's ends) and answer. */
+#define KVM_OPT_IN_FLIGHT 9      /* 1 (default) .. 64: how many contexts the caller keeps busy on this GPU at the same time with
+                                    threads of its own (kvm_run_jobs / kvm_run_device_jobs know theirs and need no option).  A
+                                    hint to the ED pruner's launcher, results are the same: with other launches next to its
+                                    own it plans a list for throughput (no window split beyond its share of the chip, the
+                                    short tiles in their denser form) instead of for the shortest single launch.  Replaces
+                                    nothing in the reference. */
 int kvm_set_option(kvm_ctx *ctx, int32_t option, int64_t value);
 int64_t kvm_get_option(const kvm_ctx *ctx, int32_t option);
 /* Device time (ns, HIP events on the launch stream) of the verification kernels of the most recent

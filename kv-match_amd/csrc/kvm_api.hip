@@ -146,8 +146,14 @@ extern "C" int kvm_set_option(kvm_ctx *ctx, int32_t option, int64_t value) {
         case KVM_OPT_SORT_VIOLATION: ctx->opt_sort_violation = value ? 1 : 0; return KVM_OK;
         case KVM_OPT_UCR_LOOPS: ctx->opt_ucr_loops = value ? 1 : 0; return KVM_OK;
         case KVM_OPT_STRICT_BOUNDS: ctx->opt_strict_bounds = value ? 1 : 0; return KVM_OK;
+        case KVM_OPT_IN_FLIGHT: ctx->opt_in_flight = value < 1 ? 1 : (value > 64 ? 64 : value); return KVM_OK;
     }
     return kvm_fail(ctx, KVM_ERR_ILLEGAL_ARGUMENT, "unknown option");
+}
+
+// kvm_stream.cpp (internal): the contexts of one kvm_run_jobs / kvm_run_device_jobs call, for its duration (0 afterwards)
+void kvm_set_run_in_flight(kvm_ctx *ctx, int n) noexcept {
+    if (ctx) ctx->run_in_flight = n;
 }
 
 // The events around the timed kernel are read only once everything behind them has been enqueued (and, on the host path,
@@ -188,6 +194,7 @@ extern "C" int64_t kvm_get_option(const kvm_ctx *ctx, int32_t option) {
         case KVM_OPT_SORT_VIOLATION: return ctx->opt_sort_violation;
         case KVM_OPT_UCR_LOOPS: return ctx->opt_ucr_loops;
         case KVM_OPT_STRICT_BOUNDS: return ctx->opt_strict_bounds;
+        case KVM_OPT_IN_FLIGHT: return ctx->opt_in_flight;
     }
     return KVM_ERR_ILLEGAL_ARGUMENT;
 }

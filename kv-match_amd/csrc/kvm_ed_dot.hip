@@ -95,8 +95,8 @@ typedef double ed4_d2u __attribute__((ext_vector_type(2), aligned(8)));
 #define EDD16_WAVE_B (EDD16_ROWS * EDD16_ROW_B)
 #define EDD16_RINGP 16                       // register ring, pairs: sub-step G holds pairs 2G .. 2G + 9, loads 2G + 10, 2G + 11
 #ifndef EDD16_AHEAD
-#define EDD16_AHEAD (EDD16_KARATSUBA ? 2 : 4)   // blocks a global load is issued ahead of its LDS write (1, 2 or 4; the
-#endif                                          // Karatsuba form has 25 accumulators and a third register ring to hold)
+#define EDD16_AHEAD 2                        // blocks a global load is issued ahead of its LDS write (1, 2 or 4; four: 0.299 against
+#endif                                       // 0.286 ms on full tiles -- 25 accumulators and three register rings are held already)
 #ifndef EDD_A16
 #define EDD_A16 1                            // 0: class A on 8 lanes x 8 candidates in every mode (rounds 2 - 4)
 #endif
@@ -112,9 +112,9 @@ typedef double ed4_d2u __attribute__((ext_vector_type(2), aligned(8)));
 // sum; its rounding differs from the plain form's by a few ulps of sum |x| |qc| -- five orders of magnitude inside the guard
 // band the pruner keeps around eps^2 (1e-11 of the same magnitudes), and the exact pass decides as before.
 // profiles/r05_ed_a16k.log: the loop alone 68.2 against 57.7 TFLOP/s counted as 16 FMAs per point.
-#ifndef EDD16_KARATSUBA
-#define EDD16_KARATSUBA 1
-#endif
+// (The plain 16-per-lane loop -- 16 accumulators, one FMA per term -- was the step before this one: profiles/r05_a16_*.log.)
+// The same form serves class B on EIGHT candidates per lane (32-candidate tiles on the same 4-lane rows, 16 to a wavefront:
+// 5 + 4 + 4 accumulators, 13 FMAs per two points instead of 16, and half the LDS bytes per term of the 4-per-lane class B).
 template <int K>
 __device__ __forceinline__ void edd_fmac_bcK(double &acc, double q16, double w) {
     asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(q16), "v"(w), "n"(K));
@@ -151,13 +151,15 @@ static_assert(EDD_RING_LEN == ED8_JC && EDD_RING_LEN + EDD_RING_AHEAD + 6 <= EDD
 template <int CI, int SUB>
 struct edd_cfg {
     static constexpr int JC = ED8_JC;                    // every class: one chunk = one revolution of its ring(s)
-    static constexpr int TILE = CI == 16 ? 64 : 8 * CI / SUB;                  // candidates per tile: 64 / 32 / 16
-    static constexpr int TPU = CI == 16 ? EDD16_ROWS : EDD_ROWS * SUB;         // tiles per unit (= per wavefront)
-    static constexpr int WAVE_DOUBLES = CI == 16 ? EDD16_WAVE_B / 8 : EDD_WAVE_LDS;   // a wave's LDS region
+    static constexpr bool ROW4 = CI == 16 || SUB == 4;                         // four-lane rows (EDD16_*)
+    static constexpr int TILE = ROW4 ? 4 * CI : 8 * CI / SUB;                  // candidates per tile: 64 / 32 / 16
+    static constexpr int TPU = ROW4 ? EDD16_ROWS : EDD_ROWS * SUB;             // tiles per unit (= per wavefront)
+    static constexpr int WAVE_DOUBLES = ROW4 ? EDD16_WAVE_B / 8 : EDD_WAVE_LDS;   // a wave's LDS region
     __device__ static constexpr int row_shift(int r) { return CI == 8 ? (r & 3) * 2 : ((r >> 1) & 1) * 2; }  // doubles
 };
 #define EDD_TILES_A (EDD_ROWS)
 #define EDD_TILES_A16 (EDD16_ROWS)
+#define EDD_TILES_B16 (EDD16_ROWS)          // class B on four-lane rows (8 candidates per lane): with the 16-per-lane class A
 #define EDD_TILES_B (EDD_ROWS)
 #define EDD_TILES_C (EDD_ROWS * 2)
 
@@ -192,8 +194,8 @@ __device__ __forceinline__ void edd_body(const edd_args &A, const kvm_tile *__re
     using cfg = edd_cfg<CI, SUB>;
     constexpr int JC = cfg::JC;
     const int lane = threadIdx.x & 63;
-    constexpr bool RING16 = CI == 16;                   // 16 rows x 4 lanes x 16 candidates (see EDD16_*)
-    static_assert(!RING16 || SUB == 1, "one tile per row");
+    constexpr bool RING16 = CI == 16 || SUB == 4;       // 16 rows x 4 lanes x CI candidates, pairs from three sums (see EDD16_*):
+    static_assert(!RING16 || (CI == 16 && SUB == 1) || (CI == 8 && SUB == 4), "<16, 1> = class A, <8, 4> = class B on four-lane rows");
     const int row = RING16 ? ((lane & 15) ^ ((lane >> 1) & 8)) : lane >> 3;
     const int sub = SUB == 2 ? ((lane >> 2) & 1) : 0;   // which of the row's tiles this lane works on
     const int lc = RING16 ? lane >> 4 : (SUB == 2 ? (lane & 3) : (lane & 7));  // lane within the tile
@@ -222,7 +224,7 @@ __device__ __forceinline__ void edd_body(const edd_args &A, const kvm_tile *__re
     // ... and this lane's own tile
     kvm_tile mine;
     mine.start = 1; mine.count = 0; mine.run_start = 1; mine.run = 0;
-    if (t0 + row * SUB + sub < n_tiles) mine = tiles[t0 + row * SUB + sub];
+    if (t0 + (RING16 ? row : row * SUB + sub) < n_tiles) mine = tiles[t0 + (RING16 ? row : row * SUB + sub)];
     const double c_row = series[mine.start - 1];
     const double hist = NORM ? kvm_run_hist_of(qd, mine.run) : 0.0;  // residue the reference's running sums may carry (kvm_hist_*)
     const int c0 = CI * lc;
@@ -435,17 +437,17 @@ __device__ __forceinline__ void edd_body(const edd_args &A, const kvm_tile *__re
     };
     ed4_d2 pend16[EDD16_AHEAD][2], R16[EDD16_RINGP];   // blocks fetched and not yet written; the window registers (carried from chunk to chunk)
     static_assert(EDD16_AHEAD == 1 || EDD16_AHEAD == 2 || EDD16_AHEAD == 4, "8 blocks per revolution: static register indices");
-    double qq16[2];                          // query values of the block in hand and of the next: qc[j + (lane & 15)]
     // Karatsuba form: 9 + 8 + 8 accumulators; XS16[n % 16] = R16[n].y + R16[n + 1].x (sum of the neighbouring window points
     // 2n + 1, 2n + 2 of the lane); the three query phases of the 16 taps (= 32 points) in hand and of the next 16
-    double kE[9], kO[8], kS[8], XS16[16], qe16[2], qo16[2], qs16[2];
+    constexpr int NP = CI / 2;               // pairs of candidates per lane
+    double kE[NP + 1], kO[NP], kS[NP], XS16[16], qe16[2], qo16[2], qs16[2];
     const int nk = kvm_qk_len(m);
     const double *__restrict__ qe_g = qd.qk, *__restrict__ qo_g = qd.qk + nk, *__restrict__ qs_g = qd.qk + 2 * (size_t)nk;
-    if constexpr (RING16 && EDD16_KARATSUBA) {
+    if constexpr (RING16) {
 #pragma unroll
-        for (int u = 0; u < 9; u++) kE[u] = 0.0;
+        for (int u = 0; u < NP + 1; u++) kE[u] = 0.0;
 #pragma unroll
-        for (int u = 0; u < 8; u++) kO[u] = kS[u] = 0.0;
+        for (int u = 0; u < NP; u++) kO[u] = kS[u] = 0.0;
     }
     if (work && ch_lo < ch_hi) {
         if constexpr (RING16) {
@@ -454,13 +456,9 @@ __device__ __forceinline__ void edd_body(const edd_args &A, const kvm_tile *__re
                 ed4_d2 u[8], v[8];
 #pragma unroll
                 for (int b = 0; b < 8; b++) ld16(jb + 16 * b, u[b], v[b]);
-                if constexpr (EDD16_KARATSUBA) {
-                    qe16[0] = qe_g[jb / 2 + (lane & 15)];
-                    qo16[0] = qo_g[jb / 2 + (lane & 15)];
-                    qs16[0] = qs_g[jb / 2 + (lane & 15)];
-                } else {
-                    qq16[0] = qc[jb + (lane & 15)];
-                }
+                qe16[0] = qe_g[jb / 2 + (lane & 15)];
+                qo16[0] = qo_g[jb / 2 + (lane & 15)];
+                qs16[0] = qs_g[jb / 2 + (lane & 15)];
 #pragma unroll
                 for (int i = 0; i < EDD16_AHEAD; i++) ld16(jb + 128 + 16 * i, pend16[i][0], pend16[i][1]);
 #pragma unroll
@@ -468,11 +466,9 @@ __device__ __forceinline__ void edd_body(const edd_args &A, const kvm_tile *__re
             }
             asm volatile("" ::: "memory");
 #pragma unroll
-            for (int i = 0; i < (EDD16_KARATSUBA ? 12 : 10); i++) R16[i] = *reinterpret_cast<const ed4_d2 *>(rowp16 + 128 * lc + 16 * i);
-            if constexpr (EDD16_KARATSUBA) {
+            for (int i = 0; i < NP + 4; i++) R16[i] = *reinterpret_cast<const ed4_d2 *>(rowp16 + 8 * CI * lc + 16 * i);
 #pragma unroll
-                for (int i = 0; i < 11; i++) XS16[i] = R16[i].y + R16[i + 1].x;
-            }
+            for (int i = 0; i < NP + 3; i++) XS16[i] = R16[i].y + R16[i + 1].x;
         } else if constexpr (RINGC) {
             const int jb = ch_lo * JC;
             ed4_d2 p3[2][3];
@@ -511,13 +507,14 @@ __device__ __forceinline__ void edd_body(const edd_args &A, const kvm_tile *__re
         const int j0 = ch * JC;
         const bool more = ch + 1 < ch_hi;
         const int jlim = min(JC, m - j0);
-        if constexpr (RING16 && EDD16_KARATSUBA) {
+        if constexpr (RING16) {
             {
                 // One revolution of the ring = one chunk of 128 points = 64 taps = 16 sub-steps of 4 taps (8 points), as
-                // compile-time loops.  Pair p of the lane = its window points 16 lc + 2p, + 1 = rowp16 + 128 lc + 16 p; sub-step S
-                // holds pairs 4S .. 4S + 11 in R16[p % 16] (and the sums XS16 of pairs 4S .. 4S + 10) and fetches pairs
-                // 4S + 12 .. 4S + 15 for the next; lane class lc's pointer passes the end of the ring at sub-step 13 - 2 lc.
-                const char *P = rowp16 + 128 * lc + 192;
+                // compile-time loops.  Pair p of the lane = its window points CI lc + 2p, + 1 = rowp16 + 8 CI lc + 16 p; sub-step S
+                // holds pairs 4S .. 4S + NP + 3 in R16[p % 16] (and the sums XS16 of pairs 4S .. 4S + NP + 2) and fetches pairs
+                // 4S + NP + 4 .. + 7 for the next; lane class lc's pointer passes the end of the ring at sub-step
+                // (1024 - 8 CI lc - 16 (NP + 4)) / 64 = 13 - 2 lc (16 per lane) / 14 - lc (8 per lane).
+                const char *P = rowp16 + 8 * CI * lc + 16 * (NP + 4);
                 const int t0 = j0 / 2;
                 edd_static_for<16>([&](auto Sc) {
                     constexpr int S = decltype(Sc)::value;
@@ -534,18 +531,24 @@ __device__ __forceinline__ void edd_body(const edd_args &A, const kvm_tile *__re
                         ld16(j0 + 128 + 16 * (b + EDD16_AHEAD), pend16[b % EDD16_AHEAD][0], pend16[b % EDD16_AHEAD][1]);
                     }
 #endif
-                    if constexpr (S == 13 || S == 11 || S == 9 || S == 7) {
-                        constexpr int cls = (13 - S) / 2;
+                    constexpr int W0 = (1024 - 16 * (NP + 4)) / 64, WS = 8 * CI / 64;   // class lc steps back at sub-step W0 - WS lc
+                    static_assert((1024 - 16 * (NP + 4)) % 64 == 0 && (8 * CI) % 64 == 0, "whole sub-steps");
+                    if constexpr (S == W0 || S == W0 - WS || S == W0 - 2 * WS || S == W0 - 3 * WS) {
+                        constexpr int cls = (W0 - S) / WS;
                         P = (lc == cls) ? P - 1024 : P;
                     }
                     edd_static_for<4>([&](auto ic) {
                         constexpr int i = decltype(ic)::value;
-                        R16[(4 * S + 12 + i) % 16] = *reinterpret_cast<const ed4_d2 *>(P + 64 * S + 16 * i);
+                        R16[(4 * S + NP + 4 + i) % 16] = *reinterpret_cast<const ed4_d2 *>(P + 64 * S + 16 * i);
                     });
                     // fence: the reads above stay above it (memory clobber), the FMAs below it (accumulator operands)
-                    asm volatile("" : "+v"(kE[0]), "+v"(kE[1]), "+v"(kE[2]), "+v"(kE[3]), "+v"(kE[4]), "+v"(kE[5]), "+v"(kE[6]), "+v"(kE[7]),
-                                 "+v"(kE[8]), "+v"(kO[0]), "+v"(kO[1]), "+v"(kO[2]), "+v"(kO[3]), "+v"(kO[4]), "+v"(kO[5]), "+v"(kO[6]),
-                                 "+v"(kO[7])::"memory");
+                    if constexpr (NP == 8)
+                        asm volatile("" : "+v"(kE[0]), "+v"(kE[1]), "+v"(kE[2]), "+v"(kE[3]), "+v"(kE[4]), "+v"(kE[5]), "+v"(kE[6]), "+v"(kE[7]),
+                                     "+v"(kE[NP]), "+v"(kO[0]), "+v"(kO[1]), "+v"(kO[2]), "+v"(kO[3]), "+v"(kO[4 % NP]), "+v"(kO[5 % NP]),
+                                     "+v"(kO[6 % NP]), "+v"(kO[7 % NP])::"memory");
+                    else
+                        asm volatile("" : "+v"(kE[0]), "+v"(kE[1]), "+v"(kE[2]), "+v"(kE[3]), "+v"(kE[4]), "+v"(kO[0]), "+v"(kO[1]), "+v"(kO[2]),
+                                     "+v"(kO[3]), "+v"(kS[0]), "+v"(kS[1]), "+v"(kS[2]), "+v"(kS[3])::"memory");
                     const double qev = qe16[(S / 4) & 1], qov = qo16[(S / 4) & 1], qsv = qs16[(S / 4) & 1];
 #ifdef EDD_DBG_NOFMA
                     edd_static_for<1>([&](auto kc) {
@@ -554,63 +557,23 @@ __device__ __forceinline__ void edd_body(const edd_args &A, const kvm_tile *__re
 #endif
                         constexpr int k = decltype(kc)::value;
                         constexpr int K = 4 * (S & 3) + k, T = 4 * S + k;   // the tap's lane in the query registers; the tap itself
-                        edd_static_for<9>([&](auto uc) {
+                        edd_static_for<NP + 1>([&](auto uc) {
                             constexpr int u = decltype(uc)::value;
                             edd_fmac_bcK<K>(kE[u], qev, R16[(T + u) % 16].x);
                         });
-                        edd_static_for<8>([&](auto uc) {
+                        edd_static_for<NP>([&](auto uc) {
                             constexpr int u = decltype(uc)::value;
                             edd_fmac_bcK<K>(kO[u], qov, R16[(T + u) % 16].y);
                         });
-                        edd_static_for<8>([&](auto uc) {
+                        edd_static_for<NP>([&](auto uc) {
                             constexpr int u = decltype(uc)::value;
                             edd_fmac_bcK<K>(kS[u], qsv, XS16[(T + u) % 16]);
                         });
                     });
-                    // the sums the next sub-step adds (pairs 4S + 11 .. 4S + 15 have landed by now)
+                    // the sums the next sub-step adds (the pairs fetched above have landed by now)
                     edd_static_for<4>([&](auto ic) {
                         constexpr int i = decltype(ic)::value;
-                        XS16[(4 * S + 11 + i) % 16] = R16[(4 * S + 11 + i) % 16].y + R16[(4 * S + 12 + i) % 16].x;
-                    });
-                });
-                (void)jlim;
-            }
-        } else if constexpr (RING16) {
-            {
-                // (the plain form, EDD16_KARATSUBA = 0)
-                // One revolution of the ring = one chunk of 128 points = 32 sub-steps of 4 points, as compile-time loops.  Sub-step
-                // G holds the window pairs 2G .. 2G + 9 of its lane (positions 16 lc + 4G .. + 19) in R16[(2G + i) % 16] and
-                // fetches pairs 2G + 10, 2G + 11 for the next; the last five sub-steps fetch what the next revolution starts with.
-                const char *P = rowp16 + 128 * lc + 160;   // pair k of this revolution: P + 16 k (see EDD16_ROW_B)
-                edd_static_for<32>([&](auto Gc) {
-                    constexpr int G = decltype(Gc)::value;
-                    if constexpr (G % 4 == 0) {
-                        constexpr int b = G / 4;
-                        // (vector-memory loads return in order: the query value is needed one block on, the window points
-                        // EDD16_AHEAD blocks on -- issued behind it, they may stay in flight when the wait for it comes)
-                        qq16[(b + 1) & 1] = qc[j0 + 16 * (b + 1) + (lane & 15)];
-                        wr16(b, pend16[b % EDD16_AHEAD][0], pend16[b % EDD16_AHEAD][1]);
-                        ld16(j0 + 128 + 16 * (b + EDD16_AHEAD), pend16[b % EDD16_AHEAD][0], pend16[b % EDD16_AHEAD][1]);
-                    }
-                    if constexpr (G == 27 || G == 23 || G == 19 || G == 15) {
-                        constexpr int cls = (27 - G) / 4;
-                        P = (lc == cls) ? P - 1024 : P;
-                    }
-                    R16[(2 * G + 10) % EDD16_RINGP] = *reinterpret_cast<const ed4_d2 *>(P + 16 * (2 * G));
-                    R16[(2 * G + 11) % EDD16_RINGP] = *reinterpret_cast<const ed4_d2 *>(P + 16 * (2 * G + 1));
-                    // fence: the reads above stay above it (memory clobber), the FMAs below it (accumulator operands)
-                    asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]),
-                                 "+v"(acc[7]), "+v"(acc[8 % CI]), "+v"(acc[9 % CI]), "+v"(acc[10 % CI]), "+v"(acc[11 % CI]), "+v"(acc[12 % CI]),
-                                 "+v"(acc[13 % CI]), "+v"(acc[14 % CI]), "+v"(acc[15 % CI])::"memory");
-                    const double q16 = qq16[(G / 4) & 1];
-                    edd_static_for<4>([&](auto kc) {
-                        constexpr int k = decltype(kc)::value;
-                        edd_static_for<CI>([&](auto ac) {
-                            constexpr int a = decltype(ac)::value;
-                            constexpr int i = a + k;   // w[i] = X[c0 + 4G + i]
-                            const ed4_d2 &pr = R16[(2 * G + i / 2) % EDD16_RINGP];
-                            edd_fmac_bcK<4 * (G & 3) + k>(acc[a], q16, (i & 1) ? pr.y : pr.x);
-                        });
+                        XS16[(4 * S + NP + 3 + i) % 16] = R16[(4 * S + NP + 3 + i) % 16].y + R16[(4 * S + NP + 4 + i) % 16].x;
                     });
                 });
                 (void)jlim;
@@ -819,10 +782,10 @@ __device__ __forceinline__ void edd_body(const edd_args &A, const kvm_tile *__re
             }
         }
     }
-    if constexpr (RING16 && EDD16_KARATSUBA) {
-        // the pairs' three sums -> the sixteen correlations (linear: a part's share of them adds up like the plain form's)
+    if constexpr (RING16) {
+        // the pairs' three sums -> the lane's correlations (linear: a part's share of them adds up like a plain sum's)
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
+        for (int u = 0; u < NP; u++) {
             acc[2 * u] = kE[u] + kO[u];
             acc[2 * u + 1] = kS[u] - kO[u] - kE[u + 1];
         }
@@ -1117,7 +1080,7 @@ __global__ __launch_bounds__(256, 2) void kvm_ed_dot_kernel(edd_args A, const kv
                                                             const kvm_tile *__restrict__ tilesC, int64_t nC, int fA, int fB,
                                                             int fC, int64_t blocksA, int64_t blocksC,
                                                             const unsigned long long *__restrict__ d_counts,
-                                                            int64_t split_units, int a16, int64_t a16_min_units) {
+                                                            int64_t split_units, int a16, int64_t a16_min_units, int b16) {
     constexpr bool A16 = edd_a16<ABANDON>();
     if (d_counts) {  // tile lists built on the device (retile kernels): the launch only knows upper bounds
         nA = (int64_t)d_counts[0];
@@ -1135,13 +1098,17 @@ __global__ __launch_bounds__(256, 2) void kvm_ed_dot_kernel(edd_args A, const kv
         a16 = A16 && a16 && uA16 + uB + uC >= a16_min_units && !(NORM && small && a16 == 2);
         fA = small ? 4 : ((a16 && uA16 + uB + uC <= split_units) ? 2 : 1);
         blocksA = ((a16 ? uA16 : uA8) * fA + 3) / 4;
-        blocksC = (uC * fC + 3) / 4;
+        // (the second region of the grid: class C -- or, with class B on the four-lane rows, class B, whose 16-tile units
+        // are the longer ones)
+        b16 = b16 && a16;
+        blocksC = b16 ? (((nB + EDD_TILES_B16 - 1) / EDD_TILES_B16) * fB + 3) / 4 : (uC * fC + 3) / 4;
     }
     // (wave-uniform by construction, but after the 64-bit compares above the compiler keeps it in a VGPR, and a scalar select
     // on it -- `t0 = slot / fA * (a16 ? 16 : 8)` -- was MISCOMPILED in one build of this file: v_cmp into VCC followed by
     // s_cselect_b32 on a stale SCC, the s_and_b64 vcc, vcc, exec between them gone; units then started every 8 tiles and
     // covered 16.  So: an SGPR, and no select -- each form computes its own t0 from a constant.)
     a16 = __builtin_amdgcn_readfirstlane(a16);
+    b16 = __builtin_amdgcn_readfirstlane(b16);
     // declared as double2 so that the window/query reads are provably 16-B aligned (ds_read_b128).  Dynamic: the 16-per-lane
     // form of class A needs 4 x 16 640 B, 1 KB more than a static array may have (edd_lds_bytes)
     extern __shared__ __attribute__((aligned(256))) double2 lds_all2[];
@@ -1161,18 +1128,32 @@ __global__ __launch_bounds__(256, 2) void kvm_ed_dot_kernel(edd_args A, const kv
         }
         const int64_t t0 = (slot / fA) * EDD_TILES_A;
         edd_body<8, 1, NORM, ABANDON>(A, tilesA, nA, t0, lds_wave2, (int)(slot % fA), fA, t0 < nA);
+    } else if (A16 && b16) {
+        // class B on the four-lane rows as well (`b16`, only with a16: 16 tiles of <= 32 candidates per wavefront, 8 per lane,
+        // pairs from three sums) in the second region, class C behind it -- the longer units first
+        if constexpr (A16) {
+            if (blk < blocksA + blocksC) {
+                const int64_t slot = (blk - blocksA) * 4 + wave, t0 = (slot / fB) * EDD_TILES_B16;
+                edd_body<8, 4, NORM, ABANDON>(A, tilesB, nB, t0, lds_all2 + wave * (EDD16_WAVE_B / 16), (int)(slot % fB), fB, t0 < nB);
+            } else {
+                const int64_t slot = (blk - blocksA - blocksC) * 4 + wave, t0 = (slot / fC) * EDD_TILES_C;
+                if (d_counts && (blk - blocksA - blocksC) * 4 / fC * EDD_TILES_C >= nC) return;  // whole workgroup past the list
+                edd_body<4, 2, NORM, ABANDON>(A, tilesC, nC, t0, lds_wave2, (int)(slot % fC), fC, t0 < nC);
+            }
+        }
     } else if (blk < blocksA + blocksC) {
         const int64_t slot = (blk - blocksA) * 4 + wave, t0 = (slot / fC) * EDD_TILES_C;
         edd_body<4, 2, NORM, ABANDON>(A, tilesC, nC, t0, lds_wave2, (int)(slot % fC), fC, t0 < nC);
     } else {
-        const int64_t slot = (blk - blocksA - blocksC) * 4 + wave, t0 = (slot / fB) * EDD_TILES_B;
+        const int64_t slot = (blk - blocksA - blocksC) * 4 + wave;
+        const int64_t t0 = (slot / fB) * EDD_TILES_B;
         if (d_counts && (blk - blocksA - blocksC) * 4 / fB * EDD_TILES_B >= nB) return;  // whole workgroup past the list
         edd_body<4, 1, NORM, ABANDON>(A, tilesB, nB, t0, lds_wave2, (int)(slot % fB), fB, t0 < nB);
     }
 }
 
 // The launcher's model of a launch (window splits, tile classes): kvm_ed_launch_model.h (host-only, unit-tested on the CPU).
-static_assert(EDM_TILES_A == EDD_TILES_A && EDM_TILES_A16 == EDD_TILES_A16 && EDM_TILES_B == EDD_TILES_B && EDM_TILES_C == EDD_TILES_C, "model and kernel agree on the unit sizes");
+static_assert(EDM_TILES_A == EDD_TILES_A && EDM_TILES_A16 == EDD_TILES_A16 && EDM_TILES_B16 == EDD_TILES_B16 && EDM_TILES_B == EDD_TILES_B && EDM_TILES_C == EDD_TILES_C, "model and kernel agree on the unit sizes");
 int kvm_ed_dot_choose_classes(int m, int64_t tilesA, int64_t tilesB, int64_t tilesC, int num_cu, int early_abandon) {
     (void)early_abandon;   // (the question -- class C or not -- arises only on lists that do not fill the wave slots once, where
     return edd_choose_classes(m, tilesA, tilesB, tilesC, num_cu);   // class A runs in its 8-per-lane form)
@@ -1188,7 +1169,7 @@ hipError_t kvm_launch_ed_dot(const double *series, const double2 *prefix, int64_
                              const kvm_tile *tilesC, int64_t nC, kvm_surv *surv,
                              int64_t cap, unsigned long long *counters, int num_cu, const unsigned long long *d_counts,
                              int32_t *out_off, double *out_dist, int64_t out_cap, hipStream_t s, hipEvent_t ev_start,
-                             hipEvent_t ev_stop) {
+                             hipEvent_t ev_stop, int in_flight) {
     (void)n;
     if (nA + nB + nC <= 0) return hipSuccess;
     const bool a16_ok = (qd.early_abandon ? edd_a16<true>() : edd_a16<false>()) && !env_set("KVM_ED_NO_A16");   // (experiments)
@@ -1211,21 +1192,32 @@ hipError_t kvm_launch_ed_dot(const double *series, const double2 *prefix, int64_
     // Window split (see edd_body): only worth it while the units are few compared with the 8 wave slots per CU, and
     // impossible with early abandon (waves leave early).  Pick the split pair with the smallest modelled makespan.
     int fA = 1, fB = 1;
-    const double slots = (double)num_cu * 8;
+    // Several queries in flight (kvm_run_jobs / kvm_run_device_jobs, or KVM_OPT_IN_FLIGHT of a caller with threads of its own):
+    // the launches of the other contexts fill what this one leaves idle, so a split only has to cover this launch's SHARE of
+    // the wave slots -- a part's prologue is then mostly lost work (the bench's stream of 8: 2.71e9 candidates/s unsplit
+    // against 2.65e9 with the split that is fastest for the same list alone, profiles/r05_b8k_pairs.log)
+    if (const char *e = getenv("KVM_ED_IN_FLIGHT"))   // experiments
+        if (e[0]) in_flight = atoi(e);
+    in_flight = std::max(1, std::min(in_flight, 64));
+    const double slots_all = (double)num_cu * 8, slots = std::max(slots_all / in_flight, 64.0);
+    bool b16 = false;
     int64_t split_units = 0;
     if (d_counts) {
         // device-built lists (cNSM): the real counts are unknown here and usually far below the bounds (a selective
         // filter leaves a few hundred units for 2048 wave slots): the grid covers a 4-way split of the bounds and the
         // kernel decides from the real counts (early abandon: only when the list cannot fill the chip anyway)
         split_units = -1;  // (bounds too large to size the grid for a split: the kernel then never splits)
-        a16 = a16_ok;      // (the kernel decides from the real counts)
+        a16 = b16 = a16_ok;      // (the kernel decides from the real counts)
         { const char *e = getenv("KVM_ED_NORM_SMALL_A16"); norm_small_a16 = a16_ok && e && e[0] == '0'; }
-        if ((double)(unitsA + unitsS) < 16.0 * slots) {
+        if ((double)(unitsA + unitsS) < 16.0 * slots_all) {
             fA = fB = 4;
             // (profiles/ed_norm_split_sweep.py: a four-way split pays up to one unit per wave slot for long windows and up to
             // half of that for short ones, whose parts are mostly prologue; it was 4 x slots until late in round 2, which
             // cost up to 1.57 x at m = 1024)
-            split_units = (qd.early_abandon || qd.m < 4096) ? (int64_t)(slots / 2) : (int64_t)slots;
+            // (NOT of this launch's share with queries in flight: what passes a selective filter is a few hundred units, and
+            // unsplit they last a whole window each -- the bench's cNSM stream loses 15 % with a quarter of the slots here,
+            // profiles/r05_in_flight_ab.log)
+            split_units = (qd.early_abandon || qd.m < 4096) ? (int64_t)(slots_all / 2) : (int64_t)slots_all;
             if (const char *e = getenv("KVM_ED_SPLIT_UNITS")) split_units = atoll(e);  // experiments
         }
     } else if (qd.early_abandon) {
@@ -1235,20 +1227,27 @@ hipError_t kvm_launch_ed_dot(const double *series, const double2 *prefix, int64_
     } else if ((double)(unitsA + unitsS) < 16.0 * slots) {
         // (the model costs a few microseconds of the host's critical path: remember the last shape -- a query stream
         // over one index tends to repeat it)
-        struct memo_t { int64_t a, b, c; int cu, m, fa, fb; bool ok, a16; };
-        static thread_local memo_t memo = {-1, -1, -1, 0, 0, 1, 1, false, false};
-        if (memo.a == unitsA && memo.b == unitsB && memo.c == unitsC && memo.cu == num_cu && memo.m == qd.m && memo.ok == a16_ok) {
+        struct memo_t { int64_t a, b, c; int cu, m, fl, fa, fb; bool ok, a16, b16; };
+        static thread_local memo_t memo = {-1, -1, -1, 0, 0, 0, 1, 1, false, false, false};
+        if (memo.a == unitsA && memo.b == unitsB && memo.c == unitsC && memo.cu == num_cu && memo.m == qd.m && memo.fl == in_flight &&
+            memo.ok == a16_ok) {
             fA = memo.fa;
             fB = memo.fb;
             a16 = memo.a16;
+            b16 = memo.b16;
         } else {
-            // the form of class A by the list's size (edd_use_a16), then the split pair of that form by the model
-            a16 = a16_ok && edd_use_a16(qd.m, unitsA16 + unitsB + unitsC, slots);
-            (void)edd_best_split(qd.m, (double)(a16 ? unitsA16 : unitsA), (double)unitsB, (double)unitsC, slots, fA, fB, a16);
-            memo = {unitsA, unitsB, unitsC, num_cu, qd.m, fA, fB, a16_ok, a16};
+            // the form of class A by the list's size (edd_use_a16), then the split pair of that form by the model.  Class B
+            // moves to the four-lane rows with it where throughput counts (queries in flight): 2.4 % more candidates/s in the
+            // bench's stream at every split pair, but its 16-tile units pack worse into ONE launch's tail -- the same list
+            // alone 0.385 ms at its best pair against 0.372 (profiles/r05_b8k_ab.log, r05_b8k_pairs.log)
+            a16 = a16_ok && edd_use_a16(qd.m, unitsA16 + unitsB + unitsC, slots_all);
+            b16 = a16 && in_flight > 1;
+            (void)edd_best_split(qd.m, (double)(a16 ? unitsA16 : unitsA), (double)(b16 ? (nB + EDD_TILES_B16 - 1) / EDD_TILES_B16 : unitsB),
+                                 (double)unitsC, slots, fA, fB, b16 ? 2 : (a16 ? 1 : 0));
+            memo = {unitsA, unitsB, unitsC, num_cu, qd.m, in_flight, fA, fB, a16_ok, a16, b16};
         }
     } else {
-        a16 = a16_ok;   // many rounds of the wave slots: throughput alone
+        a16 = b16 = a16_ok;   // many rounds of the wave slots: throughput alone
     }
     if (a16 && !d_counts) unitsA = unitsA16;
     if (const char *e = getenv("KVM_ED_SPLIT")) {  // experiments: "fA,fB"
@@ -1259,14 +1258,20 @@ hipError_t kvm_launch_ed_dot(const double *series, const double2 *prefix, int64_
     if (const char *e = getenv("KVM_ED_A16")) {   // experiments: force the form of class A on host-planned lists
         if (!d_counts && a16_ok && (e[0] == '0' || e[0] == '1')) {
             a16 = e[0] == '1';
+            b16 = a16 && in_flight > 1;
             unitsA = a16 ? unitsA16 : (nA + EDD_TILES_A - 1) / EDD_TILES_A;
         }
     }
+    if (const char *e = getenv("KVM_ED_B16"))    // experiments: class B on the four-lane rows (only with 16 per lane in class A)
+        if (e[0] == '0' || e[0] == '1') b16 = a16 && e[0] == '1';
     if (getenv("KVM_TRACE"))
-        fprintf(stderr, "[kvm] ed_dot m %d unitsA %lld (%d per lane) unitsB %lld unitsC %lld split %d,%d\n", (int)qd.m, (long long)unitsA,
-                a16 ? 16 : 8, (long long)unitsB, (long long)unitsC, fA, fB);
+        fprintf(stderr, "[kvm] ed_dot m %d unitsA %lld (%d per lane) unitsB %lld (class B %d per lane) unitsC %lld split %d,%d in flight %d\n", (int)qd.m,
+                (long long)unitsA, a16 ? 16 : 8, (long long)((b16 && !d_counts) ? (nB + EDD_TILES_B16 - 1) / EDD_TILES_B16 : unitsB), b16 ? 8 : 4,
+                (long long)unitsC, fA, fB, in_flight);
     const int fC = fB;
-    int64_t blocksA = (unitsA * fA + 3) / 4, blocksB = (unitsB * fB + 3) / 4, blocksC = (unitsC * fC + 3) / 4;
+    const int64_t unitsB16 = (nB + EDD_TILES_B16 - 1) / EDD_TILES_B16;
+    const int64_t unitsB_launch = (b16 && !d_counts) ? unitsB16 : unitsB;
+    int64_t blocksA = (unitsA * fA + 3) / 4, blocksB = (unitsB_launch * fB + 3) / 4, blocksC = (unitsC * fC + 3) / 4;
     if (d_counts) {
         // device-built lists (classes A and B only): nA = nB = the number of tiles that were trimmed, and every trimmed
         // tile lands in exactly one class, so the lists together hold at most nA tiles = nA / 8 (+ one partly filled
@@ -1276,7 +1281,7 @@ hipError_t kvm_launch_ed_dot(const double *series, const double2 *prefix, int64_
         blocksA = (units_total * fA + 3) / 4 + 3;
         blocksB = blocksC = 0;
     }
-    int64_t a16_min = edd_a16_min_units(qd.m, slots);
+    int64_t a16_min = edd_a16_min_units(qd.m, slots_all);
     if (const char *e = getenv("KVM_ED_A16_MIN_UNITS")) a16_min = atoll(e);   // tests: device-built lists of any size through the 16-per-lane form
     dim3 grid((unsigned)(blocksA + blocksB + blocksC)), block(256);
     edd_args A{series, prefix, qd, surv, cap, counters, out_off, out_dist, out_cap};
@@ -1286,10 +1291,10 @@ hipError_t kvm_launch_ed_dot(const double *series, const double2 *prefix, int64_
     do {                                                                                                                          \
         if (ev_start && ev_stop)                                                                                                  \
             hipExtLaunchKernelGGL((kvm_ed_dot_kernel<NORM, AB>), grid, block, edd_lds_bytes<AB>(), s, ev_start, ev_stop, 0, A, tilesA, nA, tilesB,  \
-                                  nB, tilesC, nC, fA, fB, fC, blocksA, blocksC, d_counts, split_units, norm_small_a16 ? 2 : (int)a16, a16_min); \
+                                  nB, tilesC, nC, fA, fB, fC, blocksA, (b16 && !d_counts) ? blocksB : blocksC, d_counts, split_units, norm_small_a16 ? 2 : (int)a16, a16_min, (int)b16); \
         else                                                                                                                      \
             hipLaunchKernelGGL((kvm_ed_dot_kernel<NORM, AB>), grid, block, edd_lds_bytes<AB>(), s, A, tilesA, nA, tilesB, nB, tilesC, nC, fA, fB,   \
-                               fC, blocksA, blocksC, d_counts, split_units, norm_small_a16 ? 2 : (int)a16, a16_min);             \
+                               fC, blocksA, (b16 && !d_counts) ? blocksB : blocksC, d_counts, split_units, norm_small_a16 ? 2 : (int)a16, a16_min, (int)b16);             \
     } while (0)
     if (qd.normalised) {
         if (qd.early_abandon) LAUNCH(true, true); else LAUNCH(true, false);

@@ -12,6 +12,7 @@
 #endif
 #define EDM_TILES_A 8   // tiles per unit (= per wavefront): classes A and B one per row, class C two
 #define EDM_TILES_A16 16  // class A in its 16-candidates-per-lane form (every-point evaluation): 16 rows of 4 lanes
+#define EDM_TILES_B16 16  // ... and class B with it: 8 candidates per lane on the same four-lane rows
 #define EDM_TILES_B 8
 #define EDM_TILES_C 16
 
@@ -75,24 +76,31 @@ static inline double edd_makespan(const double cnt_in[3], const double w[3], dou
 // behind (half as many, longer parts, and a part's prologue fills a 128-point ring per row).
 static inline int64_t edd_a16_min_units(int m, double slots) { return (int64_t)std::ceil((m >= 4096 ? 0.1 : 0.25) * slots); }
 static inline bool edd_use_a16(int m, int64_t units16, double slots) { return units16 >= edd_a16_min_units(m, slots); }
-// (a16: the class-A units are 16-tile units of the 16-per-lane form; a16 / b16 fitted by profiles/fit_ed_a16.py to the same
-// sweep, the rest of the model as it was: rms log error 6 %)
-static inline double edd_model(int m, double unitsA, double unitsB, double unitsC, int fA, int fB, double slots, bool a16 = false) {
+// (form 0: 8 per lane.  form 1: the class-A units are 16-tile units of the 16-per-lane form; its two constants fitted by
+// profiles/fit_ed_a16.py to the same sweep, the rest of the model as it was: rms log error 6 %.  form 2: class B as well on
+// the four-lane rows, 8 per lane, in 16-tile units, launched before class C (its units are the longer ones); its two
+// constants fitted to profiles/r05_b8k_sweep.log with the others held: rms log error 7 %, the pair picked 2 % behind the best)
+static inline double edd_model(int m, double unitsA, double unitsB, double unitsC, int fA, int fB, double slots, int form = 0) {
     auto chunks = [](int mm, int jc, int f) { return std::ceil(std::ceil((double)mm / jc) / f); };
-    const double w[3] = {a16 ? 10.693 + 7.331 * chunks(m, ED8_JC, fA) : 5.188 + 4.535 * chunks(m, ED8_JC, fA),
-                         6.360 + 3.899 * chunks(m, ED8_JC, fB), 3.951 + 3.719 * chunks(m, ED8_JC, fB)};   // launch order: A, C, B
+    const double wA = form ? 10.693 + 7.331 * chunks(m, ED8_JC, fA) : 5.188 + 4.535 * chunks(m, ED8_JC, fA),
+                 wC = 6.360 + 3.899 * chunks(m, ED8_JC, fB),
+                 wB = form == 2 ? 13.139 + 5.252 * chunks(m, ED8_JC, fB) : 3.951 + 3.719 * chunks(m, ED8_JC, fB);
     auto parts = [](double units, int f) { return 4.0 * std::ceil(units * f / 4.0); };  // whole workgroups of 4 waves
-    const double cnt[3] = {parts(unitsA, fA), parts(unitsC, fB), parts(unitsB, fB)};
+    if (form == 2) {   // launch order with the four-lane forms: A, B, C
+        const double w2[3] = {wA, wB, wC}, cnt2[3] = {parts(unitsA, fA), parts(unitsB, fB), parts(unitsC, fB)};
+        return edd_makespan(cnt2, w2, slots);
+    }
+    const double w[3] = {wA, wC, wB}, cnt[3] = {parts(unitsA, fA), parts(unitsC, fB), parts(unitsB, fB)};   // launch order: A, C, B
     return edd_makespan(cnt, w, slots);
 }
 
 // smallest modelled duration over the nine split pairs
-static inline double edd_best_split(int m, double unitsA, double unitsB, double unitsC, double slots, int &fA, int &fB, bool a16 = false) {
+static inline double edd_best_split(int m, double unitsA, double unitsB, double unitsC, double slots, int &fA, int &fB, int form = 0) {
     double best = 1e300;
     fA = fB = 1;
     for (int a = 1; a <= 4; a *= 2)
         for (int b = 1; b <= 4; b *= 2) {
-            const double t = edd_model(m, unitsA, unitsB, unitsC, a, b, slots, a16);
+            const double t = edd_model(m, unitsA, unitsB, unitsC, a, b, slots, form);
             if (t < best * (1.0 - 1e-3)) best = t, fA = a, fB = b;   // (near ties: the coarser split)
         }
     return best;
@@ -102,7 +110,7 @@ static inline double edd_best_split(int m, double unitsA, double unitsB, double 
 // C fills the lanes better (a remainder of <= 16 takes 19 us of a wave at m = 8192 instead of 30) but its units last
 // longer: on a list that does not fill the wave slots once the model decides (profiles/ed_hybrid_sweep.py: with the
 // model's splits class C is 1.0-1.5 x faster on lists of short runs and within +-2 % elsewhere, 4 shapes of 90 lose 5-10 %).
-static inline int edd_choose_classes(int m, int64_t tilesA, int64_t tilesB, int64_t tilesC, int num_cu, bool a16 = false) {
+static inline int edd_choose_classes(int m, int64_t tilesA, int64_t tilesB, int64_t tilesC, int num_cu, bool a16 = false) {   // (a16: class A in 16-tile units, model form 1)
     const double slots = (double)num_cu * 8;
     const int tpa = a16 ? EDM_TILES_A16 : EDM_TILES_A;
     const int64_t uA = (tilesA + tpa - 1) / tpa, uB = (tilesB + EDM_TILES_B - 1) / EDM_TILES_B,
@@ -113,8 +121,8 @@ static inline int edd_choose_classes(int m, int64_t tilesA, int64_t tilesB, int6
     static thread_local memo_t memo = {-1, -1, -1, 0, 0, 1, false};
     if (memo.a == tilesA && memo.b == tilesB && memo.c == tilesC && memo.cu == num_cu && memo.m == m && memo.a16 == a16) return memo.mode;
     int fa, fb;
-    const double t1 = edd_best_split(m, (double)uA, (double)uBC, 0.0, slots, fa, fb, a16);
-    const double t2 = edd_best_split(m, (double)uA, (double)uB, (double)uC, slots, fa, fb, a16);
+    const double t1 = edd_best_split(m, (double)uA, (double)uBC, 0.0, slots, fa, fb, a16 ? 1 : 0);
+    const double t2 = edd_best_split(m, (double)uA, (double)uB, (double)uC, slots, fa, fb, a16 ? 1 : 0);
     const int mode = t2 <= t1 * 1.02 ? 2 : 1;
     memo = {tilesA, tilesB, tilesC, num_cu, m, mode, a16};
     return mode;

@@ -143,6 +143,20 @@ struct first_call_alone {
         return d;
     }
 };
+// The launcher of the ED pruner plans a list differently when launches of other contexts run next to its own (KVM_OPT_IN_FLIGHT):
+// the contexts of a call here are told for its duration.
+void kvm_set_run_in_flight(kvm_ctx *ctx, int n) noexcept;  // kvm_api.hip (internal)
+template <class Get>
+struct in_flight_mark {
+    Get get;
+    int32_t n;
+    in_flight_mark(Get g, int32_t count, int32_t busy) : get(g), n(count) {
+        for (int32_t t = 0; t < n; t++) kvm_set_run_in_flight(get(t), busy);
+    }
+    ~in_flight_mark() {
+        for (int32_t t = 0; t < n; t++) kvm_set_run_in_flight(get(t), 0);
+    }
+};
 static int run_one(kvm_ctx *c, const kvm_job &j, kvm_result **r) {
     first_call_alone guard;
     return run_one_call(c, j, r);
@@ -189,6 +203,8 @@ extern "C" int kvm_run_jobs(kvm_ctx *const *ctxs, int32_t n_ctx, const kvm_job *
         };
         const int32_t nt = (int32_t)(n_jobs < n_ctx ? (n_jobs > 0 ? n_jobs : 1) : n_ctx);
         {
+            auto get = [&](int32_t t) { return ctxs[t]; };
+            in_flight_mark<decltype(get)> mark(get, n_ctx, nt);
             thread_group g;
             try {
                 for (int32_t t = 1; t < nt; t++) g.start([&loop, t] { loop(t); });
@@ -267,6 +283,8 @@ extern "C" int kvm_run_device_jobs(const kvm_device_slot *slots, int32_t n_slots
             }
         };
         {
+            auto get = [&](int32_t t) { return slots[t].ctx; };
+            in_flight_mark<decltype(get)> mark(get, n_slots, (int32_t)std::min<int64_t>(n_slots, std::max<int64_t>(n_jobs, 1)));
             thread_group g;
             try {
                 for (int32_t t = 1; t < n_slots; t++) g.start([&loop, t] { loop(t); });

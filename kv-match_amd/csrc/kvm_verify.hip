@@ -376,13 +376,13 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
             KVM_TP("  retile launch");
             HIPCHK(ctx, kvm_launch_ed_dot(ctx->d_series, ctx->d_prefix, ctx->n, qd, tA, pl.n_tiles, tB, pl.n_tiles, tB, 0, surv,
                                           pl.windows, counters, ctx->num_cu, counters + KVM_CNT_TILES_A, out.d_off, out.d_dist, out.cap,
-                                          stream));
+                                          stream, nullptr, nullptr, kvm_in_flight(ctx)));
             KVM_TP("  ed_dot launch");
         }
         else if (ed_kernel == 3)
             HIPCHK(ctx, kvm_launch_ed_dot(ctx->d_series, ctx->d_prefix, ctx->n, qd, d_tiles, pl.n_tiles, d_tiles + pl.n_tiles,
                                           pl.n_tiles_b, d_tiles + pl.n_tiles + pl.n_tiles_b, pl.n_tiles_c, surv, pl.windows, counters, ctx->num_cu, nullptr, out.d_off, out.d_dist,
-                                          out.cap, stream, self_timed ? ctx->ev0 : nullptr, self_timed ? ctx->ev1 : nullptr));
+                                          out.cap, stream, self_timed ? ctx->ev0 : nullptr, self_timed ? ctx->ev1 : nullptr, kvm_in_flight(ctx)));
         else
             HIPCHK(ctx, kvm_launch_ed_wave(ctx->d_series, ctx->d_prefix, ctx->n, qd, d_tiles, n_tiles, surv,
                                            pl.windows, counters, stream));

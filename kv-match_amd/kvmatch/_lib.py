@@ -23,7 +23,7 @@ KVM_ERR_NO_MEMORY = -9
 STAT_WINDOWS, STAT_PASS_FILTER, STAT_PASS_LB_KIM, STAT_PASS_LB_KEOGH, STAT_PASS_LB_KEOGH2, STAT_KERNEL_NS, \
     STAT_RECHECKED, STAT_DTW_SEQUENTIAL = range(8)
 OPT_EARLY_ABANDON, OPT_LB_CASCADE, OPT_ED_KERNEL, OPT_TIMING, OPT_DP_KERNEL, OPT_SORT_VIOLATION, OPT_UCR_LOOPS, \
-    OPT_STRICT_BOUNDS = 1, 2, 3, 4, 5, 6, 7, 8
+    OPT_STRICT_BOUNDS, OPT_IN_FLIGHT = 1, 2, 3, 4, 5, 6, 7, 8, 9
 
 # every symbol include/kvmatch.h declares (checked by tests/test_abi.py)
 SYMBOLS = [

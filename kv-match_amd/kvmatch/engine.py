@@ -386,11 +386,20 @@ class QueryStream:
                 except BaseException as e:  # noqa: BLE001 (re-raised in the caller's thread)
                     err.append(e)
 
-        threads = [threading.Thread(target=worker, args=(c,)) for c in self.ctxs]
-        for t in threads:
-            t.start()
-        for t in threads:
-            t.join()
+        # (the threads are this interpreter's: the library is told how many contexts they keep busy -- KVM_OPT_IN_FLIGHT)
+        busy = min(len(self.ctxs), len(jobs))
+        old = [c.get_option(_lib.OPT_IN_FLIGHT) for c in self.ctxs]
+        for c in self.ctxs:
+            c.set_option(_lib.OPT_IN_FLIGHT, busy)
+        try:
+            threads = [threading.Thread(target=worker, args=(c,)) for c in self.ctxs[:busy]]
+            for t in threads:
+                t.start()
+            for t in threads:
+                t.join()
+        finally:
+            for c, o in zip(self.ctxs, old):
+                c.set_option(_lib.OPT_IN_FLIGHT, o)
         if err:
             raise err[0]
         return out

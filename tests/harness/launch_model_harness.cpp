@@ -46,8 +46,14 @@ int main() {
     CHECK(!edd_use_a16(8192, 150, slots) && edd_use_a16(8192, 195 + 17 + 9, slots) && !edd_use_a16(2048, 195 + 17 + 9, slots) &&
               edd_use_a16(2048, 466 + 267 + 170, slots),
           "tiny lists stay with 8 per lane: below 0.1 of the wave slots in units, 0.25 for m < 4096");
-    t = edd_best_split(8192, 931, 533, 344, slots, fa, fb, true);
+    t = edd_best_split(8192, 931, 533, 344, slots, fa, fb, 1);
     CHECK((fa == 2 || fa == 1) && t > 300 && t < 600, "bench list, 16 per lane: split %d,%d modelled %.0f us", fa, fb, t);
+    // ... and class B on the four-lane rows as well (form 2, 16-tile units; measured 0.385 - 0.40 ms alone)
+    t = edd_best_split(8192, 928, 267, 347, slots, fa, fb, 2);
+    CHECK(t > 300 && t < 600, "bench list, four-lane forms: split %d,%d modelled %.0f us", fa, fb, t);
+    // several queries in flight: the launcher hands the model its share of the wave slots; the long units of a list of many rounds are not split
+    (void)edd_best_split(8192, 928, 267, 347, slots / 8, fa, fb, 2);
+    CHECK(fa == 1 && fb <= 2, "bench list on an eighth of the wave slots: split %d,%d", fa, fb);
     // degenerate inputs end, with finite results
     const double z = edd_model(8192, 0, 0, 0, 4, 4, slots);
     CHECK(z == 0.0, "no units: %.1f", z);

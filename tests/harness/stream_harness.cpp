@@ -23,6 +23,7 @@ struct kvm_ctx {
     std::string err;
     std::atomic<int> inside{0};
     std::atomic<int> calls{0};
+    std::atomic<int> in_flight{0}, in_flight_max{0};
 };
 struct kvm_result {
     int64_t job_tag;
@@ -63,6 +64,11 @@ const char *kvm_last_error(const kvm_ctx *c) { return c ? c->err.c_str() : ""; }
 int kvm_poison_packed_device(kvm_ctx *, double *d_packed, void *) {
     if (d_packed) d_packed[0] = -1.0;
     return KVM_OK;
+}
+void kvm_set_run_in_flight(kvm_ctx *c, int n) noexcept {
+    if (!c) return;
+    c->in_flight = n;
+    if (n > c->in_flight_max) c->in_flight_max = n;
 }
 void kvm_set_error_noexcept(kvm_ctx *c, const char *msg) noexcept {
     try {
@@ -163,8 +169,16 @@ int main(int argc, char **argv) {
         for (int n_jobs : {0, 1, 3, 8, 9, 50}) wrong += one_stream(ctxs, n_jobs, -1);
         for (int bad : {0, 1, 7, 8, 30, 49}) wrong += one_stream(ctxs, 50, bad);
         CHECK(wrong == 0 && g_overlap == 0, "one caller, 8 contexts: %d violated expectations, %d overlapping entries", wrong, (int)g_overlap);
+        // (the contexts are told how many of them the call keeps busy -- 8 for >= 8 jobs, 3 for 3 -- and that it is over)
+        int marks = 0;
+        for (auto &c : ctxs) marks += c.in_flight == 0 && c.in_flight_max == 8;
+        CHECK(marks == 8, "the in-flight mark reaches every context and is taken back (%d of 8)", marks);
+        std::vector<kvm_ctx> three(8);
+        wrong = one_stream(three, 3, -1);
+        CHECK(wrong == 0 && three[0].in_flight_max == 3 && three[7].in_flight_max == 3 && three[7].in_flight == 0, "3 jobs on 8 contexts: 3 in flight");
         std::vector<kvm_ctx> one(1);
         CHECK(one_stream(one, 20, -1) == 0 && one_stream(one, 20, 5) == 0, "one context: the calling thread alone");
+        CHECK(one[0].in_flight_max == 1 && one[0].in_flight == 0, "one context: one in flight");
     }
     // 2. several callers at once, each with its own contexts, sharing the pool (what a ShardedStream beside a QueryStream does)
     {
@@ -188,6 +202,7 @@ int main(int argc, char **argv) {
         std::vector<kvm_ctx> ctxs(3);
         int wrong = device_stream(ctxs, 20, -1) + device_stream(ctxs, 20, 7) + device_stream(ctxs, 2, -1);
         CHECK(wrong == 0 && g_overlap == 0, "kvm_run_device_jobs, 3 slots: %d violated expectations", wrong);
+        CHECK(ctxs[0].in_flight == 0 && ctxs[2].in_flight_max == 3, "kvm_run_device_jobs marks its slots' contexts (%d)", (int)ctxs[2].in_flight_max);
     }
     // 4. argument checks touch nothing
     {

@@ -250,7 +250,7 @@ def test_stream_host_layer_under_thread_and_address_sanitizers(tmp_path):
     a fork()ed child gets a pool of its own."""
     import subprocess
     src = [os.path.join(ROOT, "tests", "harness", "stream_harness.cpp"), os.path.join(ROOT, "kv-match_amd", "csrc", "kvm_stream.cpp")]
-    for san, arg, checks in (("thread", "tsan", 5), ("address,undefined", "fork", 6)):
+    for san, arg, checks in (("thread", "tsan", 9), ("address,undefined", "fork", 10)):
         exe = tmp_path / ("stream_harness_" + arg)
         r = subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-fsanitize=" + san,
                             "-fno-sanitize-recover=all", "-pthread", "-o", str(exe)] + src, capture_output=True, text=True)

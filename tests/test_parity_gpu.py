@@ -1605,9 +1605,10 @@ def test_ed_pruner_sixteen_per_lane_form_on_every_list_shape(world, monkeypatch,
                 shift = (ls - 1) * 25
                 want_r = oracle.rsm_ed(s, q, ll, rr, shift, eps)
                 want_c = oracle.cnsm_ed(s, q, ll, rr, shift, eps, 1.5, 3.0)
-                for form in ("1", "0"):
-                    monkeypatch.setenv("KVM_ED_A16", form)
-                    for split in (("1,1", "2,2", "4,4") if form == "1" and name != "single candidates" else ("",)):
+                for form in ("1b", "1", "0"):    # ("1b": class B on the four-lane rows as well, 8 per lane -- KVM_ED_B16)
+                    monkeypatch.setenv("KVM_ED_A16", form[0])
+                    monkeypatch.setenv("KVM_ED_B16", "1" if form == "1b" else "0")
+                    for split in (("1,1", "2,2", "4,4") if form != "0" and name != "single candidates" else ("",)):
                         if split:
                             monkeypatch.setenv("KVM_ED_SPLIT", split)
                         else:
@@ -1617,13 +1618,44 @@ def test_ed_pruner_sixteen_per_lane_form_on_every_list_shape(world, monkeypatch,
                     compare(kvmatch.NormQueryEngine(ctx).verify((ll, rr), ls, q, eps, 1.5, 3.0), want_c, tag=f"cnsm m={m} {name} form={form}")
         # (the launcher's trace says which form ran)
         monkeypatch.setenv("KVM_ED_A16", "1")
+        monkeypatch.setenv("KVM_ED_B16", "1")
         monkeypatch.setenv("KVM_TRACE", "1")
         capfd.readouterr()
         kvmatch.QueryEngine(ctx).verify((L, R), 1, q, eps)
-        assert "(16 per lane)" in capfd.readouterr().err
+        err = capfd.readouterr().err
+        assert "(16 per lane)" in err and "(class B 8 per lane)" in err
         monkeypatch.setenv("KVM_ED_A16", "0")
         kvmatch.QueryEngine(ctx).verify((L, R), 1, q, eps)
-        assert "(8 per lane)" in capfd.readouterr().err
+        err = capfd.readouterr().err
+        assert "(8 per lane)" in err and "(class B 4 per lane)" in err
+        # Left to itself the launcher takes class B to the four-lane rows where other queries run next to this one: told by
+        # the caller (KVM_OPT_IN_FLIGHT) or by kvm_run_jobs for the contexts of its call -- and only for its duration
+        monkeypatch.delenv("KVM_ED_B16")
+        monkeypatch.setenv("KVM_ED_A16", "1")
+        want = oracle.rsm_ed(s, q, L, R, 0, eps)
+        kvmatch.QueryEngine(ctx).verify((L, R), 1, q, eps)
+        err = capfd.readouterr().err
+        assert "(class B 4 per lane)" in err and "in flight 1\n" in err
+        ctx.set_option(kvmatch.OPT_IN_FLIGHT, 8)
+        assert ctx.get_option(kvmatch.OPT_IN_FLIGHT) == 8
+        compare(kvmatch.QueryEngine(ctx).verify((L, R), 1, q, eps), want, tag="KVM_OPT_IN_FLIGHT 8")
+        err = capfd.readouterr().err
+        assert "(class B 8 per lane)" in err and "in flight 8\n" in err
+        ctx.set_option(kvmatch.OPT_IN_FLIGHT, 1)
+        qs = kvmatch.QueryStream(ctx, in_flight=3)
+        try:
+            jobs = [kvmatch.Job(0, (L, R), 1, q, eps) for _ in range(6)]
+            for got in qs.run_jobs(jobs):
+                compare(got, want, tag="run_jobs, 3 in flight")
+            err = capfd.readouterr().err
+            assert err.count("in flight 3\n") == 6 and "in flight 1\n" not in err and err.count("(class B 8 per lane)") == 6
+            for got in qs.run([(lambda c: kvmatch.QueryEngine(c).verify((L, R), 1, q, eps)) for _ in range(2)]):
+                compare(got, want, tag="QueryStream.run, 2 jobs on 3 contexts")
+            assert capfd.readouterr().err.count("in flight 2\n") == 2
+        finally:
+            qs.close()
+        kvmatch.QueryEngine(ctx).verify((L, R), 1, q, eps)
+        assert "in flight 1\n" in capfd.readouterr().err
     finally:
         ctx.set_option(kvmatch.OPT_EARLY_ABANDON, 1)
         ctx.load_series(series)
