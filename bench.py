@@ -199,7 +199,7 @@ def roofline_block(wl, plans, launches, m, rates=None):
             "kernel_ms": ks * 1e3 / nl, "launches_measured": len(ls), "candidates_evaluated_per_launch": evaluated / nl,
             # `achieved` counts the ALGORITHMIC work: one multiply-add per (candidate, point), 2 m flop per candidate.  Since round 5
             # class A of a long list whose every point is evaluated computes a PAIR of candidates from three half-length sums
-            # instead of four (kvm_ed_dot.hip, EDD16_KARATSUBA): 25 FMAs per 32 (candidate, point) pairs there -- the FMAs the
+            # instead of four (kvm_ed_dot.hip, the RING16 form of edd_body): 25 FMAs per 32 (candidate, point) pairs there -- the FMAs the
             # pruner executes are then fewer than the terms it accounts for (the second figure is filled in by the caller
             # where it knows the list's tiles)
             "executed_fma_tflops": ach, "executed_fma_note": "as `achieved` unless `executed_fma_share` is present",

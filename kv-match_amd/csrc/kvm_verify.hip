@@ -281,7 +281,7 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
     if (!dtw) {
         std::memcpy(hp + qmain, qcen.data(), (size_t)m * 8);
         std::memcpy(hp + qmain + qpref_off, qpref8.data(), qpref8.size() * 16);
-        // the phases of the centred query (kvm_ed_dot.hip, EDD16_KARATSUBA): qc[2t] | qc[2t + 1] | their sum, zero beyond m
+        // the phases of the centred query (kvm_ed_dot.hip, the RING16 form of edd_body): qc[2t] | qc[2t + 1] | their sum, zero beyond m
         double *qe = (double *)(hp + qmain + qk_off), *qo = qe + nk, *qs = qo + nk;
         if (want_qk) std::memset(qe, 0, (size_t)3 * nk * 8);
         for (int t = 0; want_qk && 2 * t < m; t++) {
