@@ -41,7 +41,9 @@ public final class Phase2Gpu implements AutoCloseable {
     public static native byte[] indexBuild(long ctx, int w);
     /** kvm_set_option; option 6 (KVM_OPT_SORT_VIOLATION) = 1: answer cNSM-DTW queries on which Arrays.sort throws;
      *  option 7 (KVM_OPT_UCR_LOOPS) = 1 around a full scan: the tie behaviour of Ucr{Ed,Dtw}QueryExecutor instead of the engines';
-     *  option 8 (KVM_OPT_STRICT_BOUNDS, default 1) = 0: answer where DtwUtils.lowerUpperLemire ends in ArrayIndexOutOfBounds. */
+     *  option 8 (KVM_OPT_STRICT_BOUNDS, default 1) = 0: answer where DtwUtils.lowerUpperLemire ends in ArrayIndexOutOfBounds;
+     *  option 9 (KVM_OPT_IN_FLIGHT, default 1) = how many contexts the server's threads keep busy on this GPU at once: a hint to
+     *  the ED kernel's launcher (throughput instead of the shortest single launch), the answers are the same. */
     public static native void setOption(long ctx, int option, long value);
     private static native long open(int device) throws IOException;
     private static native void loadSeriesFile(long ctx, String path, long n) throws IOException;
