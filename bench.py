@@ -66,8 +66,12 @@ def parse():
     ap.add_argument("--ed-kernel", type=int, default=0)
     ap.add_argument("--queries-per-step", type=int, default=0,
                     help="phase-2 passes (queries of the stream) per step; 0 = per-workload default")
-    ap.add_argument("--in-flight", type=int, default=8,
-                    help="queries in flight per GPU (contexts over one resident series, one host thread each); 8 since round 4: with native host threads the latency-bound streams keep gaining up to there, the headline is flat from 5 on (profiles/r04_bench_if{5,8}.json)")
+    ap.add_argument("--in-flight", type=int, default=0,
+                    help="queries in flight per GPU (contexts over one resident series, one host thread each); 0 = 8 through the host "
+                         "API (since round 4: with native host threads the latency-bound streams keep gaining up to there, the headline "
+                         "is flat from 5 on, profiles/r04_bench_if{5,8}.json) and 16 in a launched run (a slot of the sharded stream is "
+                         "held until its query's exchange has been merged: 2.52 / 2.59e9 with 8 / 16 against 2.64e9 through the host API, "
+                         "one RCCL rank, profiles/r05_rccl_world1_depth.log)")
     ap.add_argument("--python-threads", type=int, default=0,
                     help="1: drive the in-flight contexts from Python threads (rounds 1-3) instead of the library's native "
                          "per-context host threads (kvm_run_jobs); the interpreter lock then bounds latency-bound streams")
@@ -296,6 +300,8 @@ def main():
         rccl_ranks = dist.get_world_size()
         if rccl_ranks != a.gpus:
             raise SystemExit(f"--gpus {a.gpus} but the RCCL group has {rccl_ranks} ranks")
+    if a.in_flight <= 0:
+        a.in_flight = 16 if use_dist else 8
     n, m = a.n, a.m
     wl = a.workload
     qps = a.queries_per_step if a.queries_per_step > 0 else {"rsm_ed": 300, "cnsm_ed": 300, "cnsm_dtw": 30, "mixed": 40}[wl]
@@ -609,7 +615,7 @@ def main():
                                 "cnsm_dtw": "cNSM-DTW phase 2, rho=5%, alpha=2 beta=10 (BASELINE configs[3])",
                                 "mixed": "mixed ED+DTW query stream (BASELINE configs[4] style)"}[wl], "n": n, "m": m,
                    "queries_per_step": qps, "queries_in_flight": F,
-                   "host_threads": ("python (a profiler is attached)" if a.profiled else "python") if a.python_threads else "native (kvm_run_jobs)",
+                   "host_threads": ("python (a profiler is attached)" if a.profiled else "python") if a.python_threads else ("native (kvm_run_device_jobs)" if use_dist else "native (kvm_run_jobs)"),
                    "distinct_queries": NQ, "distinct_interval_lists": NL,
                    "candidates_per_query_per_gpu": my_cands,
                    "candidates_per_gpu": my_cands, "intervals_per_gpu": int(len(shards[0][0])), "epsilon": a.epsilon,

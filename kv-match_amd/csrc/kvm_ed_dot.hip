@@ -1091,11 +1091,10 @@ __global__ __launch_bounds__(256, 2) void kvm_ed_dot_kernel(edd_args A, const kv
                       uB = (nB + EDD_TILES_B - 1) / EDD_TILES_B, uC = (nC + EDD_TILES_C - 1) / EDD_TILES_C;
         const bool small = uA8 + uB + uC <= split_units;
         fB = fC = small ? 4 : 1;
-        // (the host's rule, on the real counts: edd_use_a16.  a16 == 2, experiments (KVM_ED_NORM_SMALL_A16=0): cNSM lists that
-        // do not fill the wave slots stay with 8 per lane -- before only part 0 of a split unit ran the (alpha, beta) filter
-        // that was the faster form for the bench's queries, 0.152 against 0.173 ms; since then the two are level for one
-        // query alone and the stream of eight gains 7 % with 16 per lane: fewer FMAs to share the chip with)
-        a16 = A16 && a16 && uA16 + uB + uC >= a16_min_units && !(NORM && small && a16 == 2);
+        // (the host's rule, on the real counts: edd_use_a16.  cNSM lists that do not fill the wave slots ran 8 per lane until
+        // only part 0 of a split unit ran the (alpha, beta) filter: since then the two forms are level for one query alone and
+        // the stream of eight gains 7 % with 16 per lane -- fewer FMAs to share the chip with)
+        a16 = A16 && a16 && uA16 + uB + uC >= a16_min_units;
         fA = small ? 4 : ((a16 && uA16 + uB + uC <= split_units) ? 2 : 1);
         blocksA = ((a16 ? uA16 : uA8) * fA + 3) / 4;
         // (the second region of the grid: class C -- or, with class B on the four-lane rows, class B, whose 16-tile units
@@ -1173,7 +1172,7 @@ hipError_t kvm_launch_ed_dot(const double *series, const double2 *prefix, int64_
     (void)n;
     if (nA + nB + nC <= 0) return hipSuccess;
     const bool a16_ok = (qd.early_abandon ? edd_a16<true>() : edd_a16<false>()) && !env_set("KVM_ED_NO_A16");   // (experiments)
-    bool a16 = false, norm_small_a16 = false;
+    bool a16 = false;
     const int64_t unitsA16 = (nA + EDD_TILES_A16 - 1) / EDD_TILES_A16;
     int64_t unitsA = (nA + EDD_TILES_A - 1) / EDD_TILES_A;
     const int64_t unitsB = (nB + EDD_TILES_B - 1) / EDD_TILES_B, unitsC = (nC + EDD_TILES_C - 1) / EDD_TILES_C;
@@ -1208,7 +1207,6 @@ hipError_t kvm_launch_ed_dot(const double *series, const double2 *prefix, int64_
         // kernel decides from the real counts (early abandon: only when the list cannot fill the chip anyway)
         split_units = -1;  // (bounds too large to size the grid for a split: the kernel then never splits)
         a16 = b16 = a16_ok;      // (the kernel decides from the real counts)
-        { const char *e = getenv("KVM_ED_NORM_SMALL_A16"); norm_small_a16 = a16_ok && e && e[0] == '0'; }
         if ((double)(unitsA + unitsS) < 16.0 * slots_all) {
             fA = fB = 4;
             // (profiles/ed_norm_split_sweep.py: a four-way split pays up to one unit per wave slot for long windows and up to
@@ -1291,10 +1289,10 @@ hipError_t kvm_launch_ed_dot(const double *series, const double2 *prefix, int64_
     do {                                                                                                                          \
         if (ev_start && ev_stop)                                                                                                  \
             hipExtLaunchKernelGGL((kvm_ed_dot_kernel<NORM, AB>), grid, block, edd_lds_bytes<AB>(), s, ev_start, ev_stop, 0, A, tilesA, nA, tilesB,  \
-                                  nB, tilesC, nC, fA, fB, fC, blocksA, (b16 && !d_counts) ? blocksB : blocksC, d_counts, split_units, norm_small_a16 ? 2 : (int)a16, a16_min, (int)b16); \
+                                  nB, tilesC, nC, fA, fB, fC, blocksA, (b16 && !d_counts) ? blocksB : blocksC, d_counts, split_units, (int)a16, a16_min, (int)b16); \
         else                                                                                                                      \
             hipLaunchKernelGGL((kvm_ed_dot_kernel<NORM, AB>), grid, block, edd_lds_bytes<AB>(), s, A, tilesA, nA, tilesB, nB, tilesC, nC, fA, fB,   \
-                               fC, blocksA, (b16 && !d_counts) ? blocksB : blocksC, d_counts, split_units, norm_small_a16 ? 2 : (int)a16, a16_min, (int)b16);             \
+                               fC, blocksA, (b16 && !d_counts) ? blocksB : blocksC, d_counts, split_units, (int)a16, a16_min, (int)b16);             \
     } while (0)
     if (qd.normalised) {
         if (qd.early_abandon) LAUNCH(true, true); else LAUNCH(true, false);

@@ -258,8 +258,11 @@ extern "C" int kvm_run_device_jobs(const kvm_device_slot *slots, int32_t n_slots
             const kvm_device_slot &s = slots[t];
             bool failed = false;  // a slot that has failed keeps taking part with the failure mark (every rank ends the stream there)
             for (int64_t i = t; i < n_jobs; i += n_slots) {
-                while (i - n_slots >= 0 && !flag(&consumed[i - n_slots]) && !flag(stop) && !abort.load(std::memory_order_relaxed))
-                    std::this_thread::sleep_for(std::chrono::microseconds(5));
+                // (a slot waits for the caller's exchange of its previous job: milliseconds in a stream that fills the GPU -- the
+                // poll backs off to 40 us so that sixteen waiting slots per rank do not keep a core busy each)
+                for (int nap = 5; i - n_slots >= 0 && !flag(&consumed[i - n_slots]) && !flag(stop) && !abort.load(std::memory_order_relaxed);
+                     nap = nap < 40 ? nap * 2 : 40)
+                    std::this_thread::sleep_for(std::chrono::microseconds(nap));
                 if (flag(stop) || abort.load(std::memory_order_relaxed)) return;
                 int rc = KVM_OK;
                 if (!failed) {
