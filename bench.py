@@ -479,8 +479,7 @@ def main():
         ids = [((step_no[0] + t) % len(plans), (step_no[0] + t) % NQ) for t in range(qps)]
         step_no[0] += qps
         if use_dist:
-            res = sstream.run([dict(valid_positions=shards[j % NL], last_segment=1, query_data=queries[j], epsilon=a.epsilon,
-                                    variant=plans[i][0], **plans[i][3]) for i, j in ids])
+            res = sstream.run([job_desc(i, j) for i, j in ids])   # (the descriptors are marshalled once, as on the host path)
             last["res"] = [(i, j, o, d) for (i, j), (o, d) in zip(ids, res)][-NQ * len(plans):]
         elif a.python_threads:
             res = qstream.run([host_job(i, j) for i, j in ids])

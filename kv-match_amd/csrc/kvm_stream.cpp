@@ -240,6 +240,7 @@ extern "C" int kvm_run_jobs(kvm_ctx *const *ctxs, int32_t n_ctx, const kvm_job *
 
 // ---- the device-resident form: slots enqueue, the caller's own thread runs the collectives (kvmatch.distributed.ShardedStream)
 int kvm_poison_packed_device(kvm_ctx *ctx, double *d_packed, void *stream);  // kvm_verify.hip (internal)
+int kvm_record_event_device(kvm_ctx *ctx, void *event, void *stream);         // kvm_verify.hip (internal)
 
 extern "C" int kvm_run_device_jobs(const kvm_device_slot *slots, int32_t n_slots, const kvm_job *jobs, int64_t n_jobs,
                                    volatile int32_t *produced, const volatile int32_t *consumed, const volatile int32_t *stop,
@@ -259,9 +260,9 @@ extern "C" int kvm_run_device_jobs(const kvm_device_slot *slots, int32_t n_slots
             bool failed = false;  // a slot that has failed keeps taking part with the failure mark (every rank ends the stream there)
             for (int64_t i = t; i < n_jobs; i += n_slots) {
                 // (a slot waits for the caller's exchange of its previous job: milliseconds in a stream that fills the GPU -- the
-                // poll backs off to 40 us so that sixteen waiting slots per rank do not keep a core busy each)
+                // poll backs off to 20 us so that the waiting slots of a rank do not keep a core busy each)
                 for (int nap = 5; i - n_slots >= 0 && !flag(&consumed[i - n_slots]) && !flag(stop) && !abort.load(std::memory_order_relaxed);
-                     nap = nap < 40 ? nap * 2 : 40)
+                     nap = nap < 20 ? nap * 2 : 20)
                     std::this_thread::sleep_for(std::chrono::microseconds(nap));
                 if (flag(stop) || abort.load(std::memory_order_relaxed)) return;
                 int rc = KVM_OK;
@@ -278,6 +279,12 @@ extern "C" int kvm_run_device_jobs(const kvm_device_slot *slots, int32_t n_slots
                 if (failed) {
                     if (rc == KVM_OK) rc = KVM_ERR_DEVICE;   // (a job behind the slot's failure)
                     (void)kvm_poison_packed_device(s.ctx, s.d_packed, s.stream);
+                    int expected = KVM_OK;
+                    first_rc.compare_exchange_strong(expected, rc);
+                }
+                if (s.ready && kvm_record_event_device(s.ctx, s.ready, s.stream) != KVM_OK && rc == KVM_OK) {
+                    rc = KVM_ERR_DEVICE;   // (the caller would wait for an event that was never recorded: end the stream here)
+                    failed = true;
                     int expected = KVM_OK;
                     first_rc.compare_exchange_strong(expected, rc);
                 }

@@ -823,6 +823,16 @@ int kvm_poison_packed_device(kvm_ctx *ctx, double *d_packed, void *stream) {
     });
 }
 
+// kvm_run_device_jobs: a slot's `ready` event, behind the job's kernels on the slot's stream
+int kvm_record_event_device(kvm_ctx *ctx, void *event, void *stream) {
+    return kvm_guard<int>(ctx, [&]() -> int {
+    if (!ctx || !event) return KVM_ERR_INVALID_HANDLE;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipEventRecord((hipEvent_t)event, stream ? (hipStream_t)stream : ctx->stream));
+    return KVM_OK;
+    });
+}
+
 // ---- results ----------------------------------------------------------------------------------------------
 extern "C" int64_t kvm_result_count(const kvm_result *r) { return r ? (int64_t)r->off.size() : 0; }
 extern "C" int64_t kvm_result_candidates(const kvm_result *r) { return r ? r->candidates : 0; }

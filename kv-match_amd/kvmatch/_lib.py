@@ -53,7 +53,7 @@ class KvmJob(C.Structure):
 class KvmDeviceSlot(C.Structure):
     """struct kvm_device_slot of include/kvmatch.h (kvm_run_device_jobs)."""
     _fields_ = [("ctx", C.c_void_p), ("stream", C.c_void_p), ("d_off", C.c_void_p), ("d_dist", C.c_void_p), ("cap", C.c_int64),
-                ("d_count", C.c_void_p), ("d_packed", C.c_void_p), ("pack_cap", C.c_int64)]
+                ("d_count", C.c_void_p), ("d_packed", C.c_void_p), ("pack_cap", C.c_int64), ("ready", C.c_void_p)]
 
 
 class KvMatchDeviceError(RuntimeError):

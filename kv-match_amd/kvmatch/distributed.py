@@ -235,7 +235,7 @@ class ShardedStream:
     packed block becomes ready -- the all-gather and the host copy of query i overlap the kernels of query i+1.
 
         ss = ShardedStream(ctx, variant, max_candidates, in_flight=2)
-        results = ss.run([dict(valid_positions=(l, r), last_segment=1, query_data=q, epsilon=10.0), ...])
+        results = ss.run([dict(valid_positions=(l, r), last_segment=1, query_data=q, epsilon=10.0), ...])   # or kvmatch.Job objects
         # -> [(offsets, distances), ...] in query order, the merged sorted answer list on every rank
     """
 
@@ -255,8 +255,11 @@ class ShardedStream:
                 for opt in (_lib.OPT_EARLY_ABANDON, _lib.OPT_LB_CASCADE, _lib.OPT_ED_KERNEL, _lib.OPT_TIMING, _lib.OPT_DP_KERNEL,
                             _lib.OPT_SORT_VIOLATION, _lib.OPT_UCR_LOOPS, _lib.OPT_STRICT_BOUNDS):
                     c.set_option(opt, ctx.get_option(opt))
+            stream = torch.cuda.Stream(device=self.dev)
             v = ShardedVerifier(c, variant, max_candidates, group=group, pack_cap=pack_cap)
-            self.slots.append(dict(ctx=c, v=v, stream=torch.cuda.Stream(device=self.dev), ready=torch.cuda.Event()))
+            ready = torch.cuda.Event()
+            ready.record(stream)     # (creates the HIP event: the native loop records it behind each of the slot's jobs)
+            self.slots.append(dict(ctx=c, v=v, stream=stream, ready=ready))
         self.comm_stream = torch.cuda.Stream(device=self.dev)
         k = self.pack_cap + 1
         self.gathered = [torch.empty((self.world * k, 2), dtype=torch.float64, device=self.dev) for _ in self.slots]
@@ -294,6 +297,9 @@ class ShardedStream:
         # the slot takes part with the failure mark and this rank raises its own error when the stream reaches that query.
         jobs_py, marshal_err = [], {}
         for qi, q in enumerate(queries):
+            if isinstance(q, Job):     # (marshalled before: a caller that repeats its queries keeps the descriptors)
+                jobs_py.append(q)
+                continue
             try:
                 var = self.variant if q.get("variant") is None else int(q["variant"])
                 rho = resolve_rho(q.get("rho", 0), len(q["query_data"]), q.get("resolved")) if var >= 2 else 0
@@ -317,6 +323,7 @@ class ShardedStream:
             slots[t].ctx, slots[t].stream = s["ctx"]._h, C.c_void_p(s["stream"].cuda_stream)
             slots[t].d_off, slots[t].d_dist, slots[t].cap = v.out_off.data_ptr(), v.out_dist.data_ptr(), v.cap
             slots[t].d_count, slots[t].d_packed, slots[t].pack_cap = v.count.data_ptr(), v.packed.data_ptr(), v.pack_cap
+            slots[t].ready = s["ready"].cuda_event
         produced, consumed = (C.c_int32 * nq)(), (C.c_int32 * nq)()
         stop, status, cnts = (C.c_int32 * 1)(), (C.c_int32 * nq)(), (C.c_int64 * nq)()
         rc_box = []
@@ -330,7 +337,11 @@ class ShardedStream:
 
         def issue(qi):
             """query qi's exchange and host copy, enqueued on the exchange stream behind the slot's kernels; nothing waits here"""
+            spins = 0
             while not produced[qi]:
+                spins += 1
+                if spins < 400:       # (a few tens of microseconds of polling first: the shortest sleep this interpreter can take
+                    continue          #  is 50 - 60 us, as long as an early-abandoning query's whole chain)
                 if not helper.is_alive() and not produced[qi]:
                     raise _lib.KvMatchDeviceError("the slots' native loop ended before query %d was enqueued" % qi)
                 time.sleep(1e-5)
@@ -339,8 +350,8 @@ class ShardedStream:
             if status[qi] and self.world == 1:
                 _lib.check(int(status[qi]), s["ctx"]._h)
             with torch.cuda.stream(self.comm_stream):
-                self.comm_stream.wait_stream(s["stream"])   # (the slot's stream holds this query's kernels and nothing behind them:
-                if self.world > 1:                          #  its next job waits for `consumed`)
+                self.comm_stream.wait_event(s["ready"])     # (recorded by the native loop behind this query's kernels)
+                if self.world > 1:
                     dist.all_gather_into_tensor(self.gathered[si], s["v"].packed, group=self.group)
                     self.host[si].copy_(self.gathered[si], non_blocking=True)
                 else:

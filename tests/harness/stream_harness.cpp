@@ -61,6 +61,12 @@ int kvm_verify_device(kvm_ctx *c, int32_t, const double *, int32_t m, const int3
 int kvm_pack_answers_device(kvm_ctx *, const int32_t *, const double *, const int64_t *, int64_t, double *, void *) { return KVM_OK; }
 const char *kvm_last_error(const kvm_ctx *c) { return c ? c->err.c_str() : ""; }
 }
+static std::atomic<int64_t> g_ready_records{0};
+int kvm_record_event_device(kvm_ctx *, void *event, void *) {
+    if (event) (*static_cast<std::atomic<int64_t> *>(event))++;
+    g_ready_records++;
+    return KVM_OK;
+}
 int kvm_poison_packed_device(kvm_ctx *, double *d_packed, void *) {
     if (d_packed) d_packed[0] = -1.0;
     return KVM_OK;
@@ -137,6 +143,12 @@ static int device_stream(std::vector<kvm_ctx> &ctxs, int n_jobs, int bad) {
         slots[(size_t)t].ctx = &ctxs[(size_t)t];
         slots[(size_t)t].d_packed = packed[(size_t)t].data();
     }
+    // (a `ready` event per slot: recorded once per job of the slot, before the job is reported produced)
+    std::vector<std::atomic<int64_t>> ready((size_t)n_slots);
+    for (int t = 0; t < n_slots; t++) {
+        ready[(size_t)t] = 0;
+        slots[(size_t)t].ready = &ready[(size_t)t];
+    }
     std::vector<kvm_job> jobs;
     for (int i = 0; i < n_jobs; i++) jobs.push_back(job(500 + i, i == bad ? -1.0 : 1.0));
     std::vector<int32_t> produced((size_t)n_jobs, 0), consumed((size_t)n_jobs, 0), st((size_t)n_jobs, 77);
@@ -152,6 +164,7 @@ static int device_stream(std::vector<kvm_ctx> &ctxs, int n_jobs, int bad) {
         const bool after_bad = bad >= 0 && i >= bad && (i - bad) % n_slots == 0;   // the failing slot keeps failing
         if (after_bad ? st[(size_t)i] == KVM_OK : st[(size_t)i] != KVM_OK) wrong++;
         if (!after_bad && cnt[(size_t)i] != 500 + i) wrong++;
+        if (ready[(size_t)(i % n_slots)] != i / n_slots + 1) wrong++;   // recorded for job i, and not yet for the slot's next
         __atomic_store_n(&consumed[(size_t)i], 1, __ATOMIC_RELEASE);
     }
     producer.join();
