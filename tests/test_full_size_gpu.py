@@ -63,6 +63,20 @@ def test_rsm_ed_and_cnsm_ed_config_2_3(big):
             o.append(a.offsets); d.append(a.distances); c += a.cnt_candidate
         so, sd = distributed.sort_answers(np.concatenate(o), np.concatenate(d))
         assert c == want[2]["cnt_candidate"] and np.array_equal(so, want[0]) and np.array_equal(sd, want[1])
+    # the same list planned for throughput (round 5: queries in flight -> no window split beyond the launch's share of the chip,
+    # class B on the four-lane rows): a stream of 8 through kvm_run_jobs and a single call under KVM_OPT_IN_FLIGHT, every point
+    # evaluated (the forms exist only there) -- one answer list
+    ctx.set_option(kvmatch.OPT_EARLY_ABANDON, 0)
+    qs = kvmatch.QueryStream(ctx, in_flight=8)
+    try:
+        for got in qs.run_jobs([kvmatch.Job(0, (L, R), 1, q, 10.0) for _ in range(16)]):
+            assert same(got, want) and got.cnt_candidate == want[2]["cnt_candidate"]
+    finally:
+        qs.close()
+    ctx.set_option(kvmatch.OPT_IN_FLIGHT, 8)
+    assert same(eng.verify((L, R), 1, q, 10.0), want)
+    ctx.set_option(kvmatch.OPT_IN_FLIGHT, 1)
+    ctx.set_option(kvmatch.OPT_EARLY_ABANDON, 1)
     # cNSM-ED, configs[2]: alpha / beta from SURVEY 8d
     neng = kvmatch.NormQueryEngine(ctx)
     for eps, alpha, beta in ((1.0, 1.1, 44.974 * 0.5), (10.0, 2.0, 10.0)):
