@@ -90,7 +90,7 @@ def parse():
     # hipLaunchKernel (two attempts of three, seconds into the run: eight threads making their FIRST launch at the same moment,
     # profiles/r05_prof_native_crash.log), and rounds 3-4 drove a profiled run from Python threads instead.  Since round 5 every
     # thread's first call runs alone (kvm_stream.cpp) and a profiled run is driven exactly like an unprofiled one
-    # (profiles/prof_r05.sh: three attempts of six of the full default command complete, five of five of a short run; what is
+    # (profiles/prof_r05.sh: five attempts of nine of the full default command complete, five of five of a short run; what is
     # left crashes inside the tool's launch callback as before); KVM_BENCH_PROFILED_PYTHON=1 brings the old behaviour back.
     a.profiled = any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", "")
     if a.profiled and not a.python_threads and os.environ.get("KVM_BENCH_PROFILED_PYTHON") == "1":
