@@ -90,8 +90,9 @@ def parse():
     # hipLaunchKernel (two attempts of three, seconds into the run: eight threads making their FIRST launch at the same moment,
     # profiles/r05_prof_native_crash.log), and rounds 3-4 drove a profiled run from Python threads instead.  Since round 5 every
     # thread's first call runs alone (kvm_stream.cpp) and a profiled run is driven exactly like an unprofiled one
-    # (profiles/prof_r05.sh: five attempts of nine of the full default command complete, five of five of a short run; what is
-    # left crashes inside the tool's launch callback as before); KVM_BENCH_PROFILED_PYTHON=1 brings the old behaviour back.
+    # (five attempts of nine of the full default command completed with that alone; since the library's calls also take turns
+    # ENQUEUEING while such a tool is attached -- kvm_enqueue_lock, kvm_verify.hip -- 14 of 14: profiles/r05_prof_attempts_lock.log);
+    # KVM_BENCH_PROFILED_PYTHON=1 brings the old behaviour back.
     a.profiled = any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", "")
     if a.profiled and not a.python_threads and os.environ.get("KVM_BENCH_PROFILED_PYTHON") == "1":
         a.python_threads = 1
@@ -614,7 +615,7 @@ def main():
                                 "cnsm_dtw": "cNSM-DTW phase 2, rho=5%, alpha=2 beta=10 (BASELINE configs[3])",
                                 "mixed": "mixed ED+DTW query stream (BASELINE configs[4] style)"}[wl], "n": n, "m": m,
                    "queries_per_step": qps, "queries_in_flight": F,
-                   "host_threads": ("python (a profiler is attached)" if a.profiled else "python") if a.python_threads else ("native (kvm_run_device_jobs)" if use_dist else "native (kvm_run_jobs)"),
+                   "host_threads": ("python (a profiler is attached)" if a.profiled else "python") if a.python_threads else (("native (kvm_run_device_jobs)" if use_dist else "native (kvm_run_jobs)") + ("; a profiler is attached: the calls' enqueue phases take turns (kvm_verify.hip, kvm_enqueue_lock)" if a.profiled and os.environ.get("KVM_SERIALIZE_ENQUEUE", "") != "0" else "")),
                    "distinct_queries": NQ, "distinct_interval_lists": NL,
                    "candidates_per_query_per_gpu": my_cands,
                    "candidates_per_gpu": my_cands, "intervals_per_gpu": int(len(shards[0][0])), "epsilon": a.epsilon,

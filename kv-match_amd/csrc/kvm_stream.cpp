@@ -130,7 +130,8 @@ static int run_one_call(kvm_ctx *c, const kvm_job &j, kvm_result **r) {
 // A thread's FIRST call runs alone: it is where the HIP runtime (and a tool that hooks it) sets up its per-thread state, and
 // eight threads doing that at the same moment is what `rocprofv3 --kernel-trace -- python3 bench.py` fell over in (SIGSEGV in a
 // copy inside the tool's launch callback, seconds into the run, two attempts of three with the pool and without; with this
-// one of three: profiles/r05_prof_native_crash.log).  Once per thread of the process; the calls after it run freely.
+// one of three: profiles/r05_prof_native_crash.log; what ended it is kvm_enqueue_lock in kvm_verify.hip).  Once per thread of the
+// process; the calls after it run freely.
 struct first_call_alone {
     std::unique_lock<std::mutex> lk;
     first_call_alone() {

@@ -2,6 +2,40 @@
 // path of the DTW engines, result assembly, and the kvm_verify_* / kvm_verify_device / kvm_result_* entry points
 #include "kvm_api_internal.h"
 #include "kvm_jsort.h"
+#include <mutex>
+extern char **environ;
+
+// Under a tool that hooks the runtime's kernel dispatches (rocprofv3 --kernel-trace) several host threads enqueueing at the same
+// moment take the tool's library down: a SIGSEGV in a copy inside its dispatch callback, on whichever thread is launching
+// (profiles/r05_prof_native_crash.log; never seen without the tool).  While such a tool is attached -- its environment: ROCP* /
+// ROCPROF* variables or a rocprofiler library in LD_PRELOAD -- or with KVM_SERIALIZE_ENQUEUE=1, the ENQUEUE phases of the
+// verification calls (plan, copies, launches: everything but the waits for the stream) hold one process-wide lock: the
+// kernels of different contexts still overlap on the GPU, the host threads take turns issuing them.  KVM_SERIALIZE_ENQUEUE=0
+// switches it off.
+struct kvm_enqueue_lock {
+    std::unique_lock<std::mutex> lk;
+    kvm_enqueue_lock() { again(); }
+    void release() {
+        if (lk.owns_lock()) lk.unlock();
+    }
+    void again() {
+        if (enabled() && !lk.owns_lock()) lk = std::unique_lock<std::mutex>(mu());
+    }
+    static std::mutex &mu() {
+        static std::mutex m;
+        return m;
+    }
+    static bool enabled() {
+        static const bool on = [] {
+            if (const char *e = getenv("KVM_SERIALIZE_ENQUEUE"))
+                if (e[0]) return e[0] != '0';
+            for (char **v = environ; v && *v; v++)
+                if (!strncmp(*v, "ROCP", 4) || (!strncmp(*v, "LD_PRELOAD=", 11) && strstr(*v, "rocprofiler"))) return true;
+            return false;
+        }();
+        return on;
+    }
+};
 
 // ---- the shared verification driver ---------------------------------------------------------------------
 
@@ -586,6 +620,7 @@ static int verify_host(kvm_ctx *ctx, int variant, const double *query, int32_t m
     int64_t kernel_ns = 0;
     kvm_query_dev dtw_qd;
     kvm_dtw_aux dtw_ax;
+    kvm_enqueue_lock enq;   // (only under a tool that hooks the launches: see above)
     rc = run_variant(ctx, variant, query, m, left, right, k, shift, epsilon, rho, alpha, beta, pl, out, ctx->stream,
                      &kernel_ns, dtw_qd, dtw_ax);
     if (rc) return rc;
@@ -603,13 +638,16 @@ static int verify_host(kvm_ctx *ctx, int variant, const double *query, int32_t m
     for (int pass = 0; pass < 2 && pl.n_tiles + pl.n_tiles_b + pl.n_tiles_c > 0; pass++) {
         if (!ctx->h_readback)
             HIPCHK(ctx, hipHostMalloc(&ctx->h_readback, KVM_CNT_TOTAL * 8 + KVM_SPEC_ANSWERS * 12 + 64, hipHostMallocDefault));
+        enq.again();
         HIPCHK(ctx, kvm_launch_readback((const unsigned long long *)ctx->b_counters.p, out.d_off, out.d_dist, spec,
                                         ctx->h_readback, ctx->stream));
+        enq.release();
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         std::memcpy(hc, ctx->h_readback, sizeof hc);
         if (pass == 0 && is_dtw && hc[KVM_CNT_AMBIG] > 0) {
             // candidates within rounding of a tie with eps^2: sequential reference-ordered path, then read back again
             n_sequential = (int64_t)hc[KVM_CNT_AMBIG];
+            enq.again();
             if ((rc = dtw_resolve_ambiguous(ctx, dtw_qd, dtw_ax, n_sequential, out, ctx->stream))) return rc;
             continue;
         }
@@ -644,8 +682,10 @@ static int verify_host(kvm_ctx *ctx, int variant, const double *query, int32_t m
         }
         double *pd = (double *)ctx->h_readback2;
         int32_t *po = (int32_t *)(pd + rest);
+        enq.again();
         HIPCHK(ctx, hipMemcpyAsync(pd, out.d_dist + spec, rest * 8, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipMemcpyAsync(po, out.d_off + spec, rest * 4, hipMemcpyDeviceToHost, ctx->stream));
+        enq.release();
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         std::memcpy(dist.data() + spec, pd, rest * 8);
         std::memcpy(off.data() + spec, po, rest * 4);
@@ -775,6 +815,8 @@ extern "C" int kvm_verify_device(kvm_ctx *ctx, int32_t variant, const double *qu
     // (run_variant clears done_pending once this call's stream is ordered behind the previous call, before it enqueues
     // anything: a failure that leaves the flag set -- an argument error -- has enqueued nothing, and the previous call's
     // mark must stay in place)
+    kvm_enqueue_lock enq;   // (only under a tool that hooks the launches: see the top of this file; declared before the guard
+    // below, so that the guard's event is recorded while the lock is still held)
     int rc = run_variant(ctx, variant, query, m, left, right, k, shift, epsilon, rho, alpha, beta, pl, out, s, nullptr, dtw_qd,
                          dtw_ax);
     done_guard guard{ctx, s, rc == KVM_OK || !ctx->done_pending};
@@ -786,7 +828,9 @@ extern "C" int kvm_verify_device(kvm_ctx *ctx, int32_t variant, const double *qu
         unsigned long long n_ambig = 0;
         HIPCHK(ctx, hipMemcpyAsync(&n_ambig, (unsigned long long *)ctx->b_counters.p + KVM_CNT_AMBIG, sizeof n_ambig,
                                    hipMemcpyDeviceToHost, s));
+        enq.release();
         HIPCHK(ctx, hipStreamSynchronize(s));
+        enq.again();
         if (n_ambig > 0 && (rc = dtw_resolve_ambiguous(ctx, dtw_qd, dtw_ax, (int64_t)n_ambig, out, s))) return rc;
     }
     if (pl.n_tiles + pl.n_tiles_b + pl.n_tiles_c == 0) {
@@ -805,6 +849,7 @@ extern "C" int kvm_pack_answers_device(kvm_ctx *ctx, const int32_t *d_off, const
     if (!ctx) return KVM_ERR_INVALID_HANDLE;
     if (!d_off || !d_dist || !d_count || !d_packed || pack_cap < 0)
         return kvm_fail(ctx, KVM_ERR_ILLEGAL_ARGUMENT, "bad kvm_pack_answers_device arguments");
+    kvm_enqueue_lock enq;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, kvm_launch_pack_answers(d_off, d_dist, d_count, pack_cap, (double2 *)d_packed,
                                         stream ? (hipStream_t)stream : ctx->stream));

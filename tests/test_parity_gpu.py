@@ -1661,6 +1661,20 @@ def test_ed_pruner_sixteen_per_lane_form_on_every_list_shape(world, monkeypatch,
         ctx.load_series(series)
 
 
+def test_streams_with_the_enqueue_lock_forced(built):
+    """Under a tool that hooks the kernel dispatches the library's calls take turns enqueueing (kvm_enqueue_lock, kvm_verify.hip:
+    what lets `rocprofv3 --kernel-trace -- python3 bench.py` complete every time).  The lock is decided once per process, from
+    the environment: a child process runs a mixed stream of all four variants through kvm_run_jobs and through the
+    device-resident slots with KVM_SERIALIZE_ENQUEUE=1 -- every lock / release / re-lock path, the DTW calls' wait in the
+    middle included -- and compares with the oracle."""
+    import subprocess
+    import sys
+    env = dict(os.environ, KVM_SERIALIZE_ENQUEUE="1")
+    cp = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "enqueue_lock_worker.py")], env=env,
+                        capture_output=True, text=True, timeout=600)
+    assert cp.returncode == 0 and "equal the oracle" in cp.stdout, cp.stdout[-2000:] + cp.stderr[-4000:]
+
+
 def test_run_jobs_is_the_same_stream_in_native_threads(world):
     """kvm_run_jobs (QueryStream.run_jobs): calls as data, one native host thread per context.  Every job's answers equal
     the oracle's (and therefore the one-call-at-a-time engines'), in job order, all four variants mixed in one stream;
