@@ -33,10 +33,17 @@
  *   KVM_TRACE=1          per-stage host timings of every call on stderr
  *   KVM_DEBUG_SYNC=1     DTW calls wait for the stream after every stage and name it on stderr
  *   KVM_LIB=<path>       (Python binding only) load another build of this library
+ *   KVM_SERIALIZE_ENQUEUE=0|1  the enqueue phases of the verification calls (plan, copies, launches; not the waits) take
+ *                        turns between host threads.  Default: only while a tool that hooks the kernel dispatches is
+ *                        attached (ROCP* variables / a rocprofiler library in LD_PRELOAD): rocprofv3's kernel tracing
+ *                        falls over when several threads enqueue at the same moment
  * Experiments only (read at every call; they change the pruner's launch shape, never an answer):
  *   KVM_ED_SPLIT=fA,fB   window split of class-A / class-B,C units (1, 2 or 4 each) instead of the launcher's model
  *   KVM_ED_HYBRID=1|2    tile classes A / B (1) or A / B / C (2) for host-planned lists instead of the model's choice
  *   KVM_ED_SPLIT_UNITS=n device-built lists: split every unit four ways when there are at most n of them
+ *   KVM_ED_A16=0|1, KVM_ED_NO_A16=1, KVM_ED_B16=0|1, KVM_ED_A16_MIN_UNITS=n   the forms of classes A / B (16 / 8 candidates
+ *                        per lane on four-lane rows) instead of the launcher's rule; KVM_ED_IN_FLIGHT=n its idea of the
+ *                        queries in flight (KVM_OPT_IN_FLIGHT)
  *
  * DTW answer semantics.  The reference's DTW engines do not report {candidates with banded DTW <= eps^2}:
  * DtwUtils.dtw returns `min_cost + cb[i+r+1]` as soon as that lower bound is >= eps^2 (K/utils/DtwUtils.java:
