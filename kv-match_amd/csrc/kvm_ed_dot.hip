@@ -1222,7 +1222,11 @@ hipError_t kvm_launch_ed_dot(const double *series, const double2 *prefix, int64_
         // unit durations are unpredictable; split only when the list cannot fill the chip anyway (latency-bound)
         if ((double)(unitsA + unitsS) * 4.0 <= slots) fA = fB = 4;
         else if ((double)(unitsA + unitsS) * 2.0 <= slots) fA = fB = 2;
-    } else if ((double)(unitsA + unitsS) < 16.0 * slots) {
+    } else if ((double)(unitsA + unitsS) < (in_flight >= 4 && !env_set("KVM_ED_NO_SHARE_RULE") ? 2.0 : 16.0) * slots) {
+        // (alone, the model decides up to 16 rounds of the wave slots -- a launch's tail is its own.  With four or more queries
+        // in flight the other launches are this one's tail: from two rounds of the launch's SHARE on nothing is split -- in
+        // the bench's stream every split of either class costs candidates/s, 2.71e9 unsplit against 2.68 / 2.69 with one class
+        // split two ways and 2.65 with both four ways, profiles/r05_b8k_pairs.log)
         // (the model costs a few microseconds of the host's critical path: remember the last shape -- a query stream
         // over one index tends to repeat it)
         struct memo_t { int64_t a, b, c; int cu, m, fl, fa, fb; bool ok, a16, b16; };
