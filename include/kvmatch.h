@@ -300,7 +300,8 @@ typedef struct kvm_device_slot {
     double *d_packed;    /* device, 2 * (pack_cap + 1) doubles */
     int64_t pack_cap;
     void *ready;         /* hipEvent_t or NULL: recorded on the slot's stream behind each job's last kernel (or its failure
-                            mark), BEFORE produced[i] is set -- what the caller's exchange stream waits for */
+                            mark), BEFORE produced[i] is set -- what the caller's exchange stream waits for.  (Added in
+                            version 0.5, at the end: a caller built against the shorter struct must be rebuilt) */
 } kvm_device_slot;
 int kvm_run_device_jobs(const kvm_device_slot *slots, int32_t n_slots, const kvm_job *jobs, int64_t n_jobs,
                         volatile int32_t *produced, const volatile int32_t *consumed, const volatile int32_t *stop,
