@@ -23,7 +23,7 @@
  * (the reference engines are not re-entrant either).  A ctx owns one HIP stream on one device, its
  * pinned staging block and its scratch buffers.  Different contexts may be used from different host
  * threads at the same time -- several queries in flight against one resident series: kvm_share_series.
- * Multi-GPU = one process (or at least one ctx) per GPU; see kv-match_amd/kvmatch/distributed.py.
+ * Multi-GPU = a kvm_group (below): one call per query over all the GPUs of a node, in one process or one process per GPU.
  * Process-wide state: (i) one pinned host block that the index-build calls (kvm_index_rows_build*) reuse
  * across calls and contexts, behind a mutex (calls that need it at the same time allocate their own);
  * (ii) a thread_local memo of the ED pruner's launch-shape model.  Nothing else is shared.
@@ -428,6 +428,89 @@ int kvm_verify_device(kvm_ctx *ctx, int32_t variant, const double *query, int32_
  * `stream`; used by the multi-GPU host layer before its single all-gather. */
 int kvm_pack_answers_device(kvm_ctx *ctx, const int32_t *d_off, const double *d_dist, const int64_t *d_count,
                             int64_t pack_cap, double *d_packed, void *stream);
+
+/* ---- one engine over the GPUs of a node: candidate shards, ONE all-gather of the answers --------------- */
+
+/* A reference engine is one object per data file (K/QueryEngine.java:70) making one phase-2 pass per query (:155, the loop
+ * over the intervals :343-363).  A kvm_group is that object over several GPUs: the series replicated on every device, the
+ * interval list of a call dealt out to the devices (kvm_split_intervals), every device verifying its shard with the answers
+ * left in HBM (kvm_verify_device + kvm_pack_answers_device, one native host thread per device and slot), ONE ncclAllGather
+ * (RCCL over xGMI, issued from native code: librccl is opened by the library itself, no Python and no torch on the path) of
+ * a fixed-size block [count | first pack_cap (offset, distance) pairs] per rank, then merge and the (distance, offset) sort
+ * of K/QueryEngine.java:373 on the host -- the same kvm_result a single-GPU call returns, bit for bit.  Only when some
+ * rank holds more than pack_cap answers does a second, exact-size exchange follow.  A shard that fails takes part in the
+ * exchange with a count of -1: every rank learns it there and returns an error for that call; nobody is left waiting.
+ *
+ * Two ways to form a group:
+ *   kvm_open_devices  ONE process drives n_dev GPUs (a JVM with 8 devices): ncclCommInitAll inside the process.
+ *   kvm_open_rank     one process per GPU (the launchers of this repository's bench.py, MPI-style hosts): rank `rank` of
+ *                     `world`; `id` = the KVM_GROUP_ID_BYTES bytes kvm_group_unique_id wrote on ONE rank, carried to the
+ *                     others by the host's own means (a file, a socket, a launcher's store); every rank passes the same
+ *                     interval lists to the same sequence of calls and ends with the full answer list.
+ * `in_flight` (1 .. 64): slots per device = sharded queries kvm_run_sharded_jobs overlaps on every device (each slot is a
+ * context of its own over the device's resident series: kvm_share_series).  `flags`: KVM_GROUP_RCCL_ALWAYS makes a group of
+ * ONE rank exchange through RCCL as well (otherwise it copies its block to the host directly and never opens librccl).
+ * Calls on one group must be serialised by the caller (as on a kvm_ctx). */
+typedef struct kvm_group kvm_group;
+#define KVM_GROUP_ID_BYTES 128
+#define KVM_GROUP_RCCL_ALWAYS 1
+#define KVM_ERR_SHARD_FAILED (-10) /* another rank failed on its shard of the call (its own status is what THAT rank returns);
+                                      -> IOException in the shim */
+int kvm_open_devices(const int32_t *devices, int32_t n_dev, int32_t in_flight, int32_t flags, kvm_group **group);
+int kvm_group_unique_id(void *id, int32_t id_bytes);
+int kvm_open_rank(int32_t device, int32_t rank, int32_t world, const void *id, int32_t id_bytes, int32_t in_flight,
+                  int32_t flags, kvm_group **group);
+int kvm_group_close(kvm_group *group);
+const char *kvm_group_last_error(const kvm_group *group);  /* group may be NULL: the last kvm_open_devices / kvm_open_rank error */
+int32_t kvm_group_world(const kvm_group *group);          /* ranks = shards of a call */
+int32_t kvm_group_local_devices(const kvm_group *group);  /* devices this process drives */
+int32_t kvm_group_rccl_ranks(const kvm_group *group);     /* ranks of the RCCL communicator; 0: none was made */
+/* the context of slot `slot` of local device `local_device` (slot 0 owns the device's series): for kvm_get_option,
+ * kvm_read_time_series, kvm_last_kernel_ns ...; NOT for verification calls while a group call runs */
+kvm_ctx *kvm_group_ctx(kvm_group *group, int32_t local_device, int32_t slot);
+#define KVM_GROUP_PACK_CAP 1    /* answers per rank the one fixed-size exchange carries (default 4096; >= 1) */
+#define KVM_GROUP_SPLIT_MODE 2  /* KVM_SPLIT_* (default KVM_SPLIT_AUTO) */
+int kvm_group_configure(kvm_group *group, int32_t what, int64_t value);
+/* kvm_load_series_* on every local device ("replicates to every device"), then kvm_share_series for the slots */
+int kvm_group_load_series_f64(kvm_group *group, const double *host_values, int64_t n);
+int kvm_group_load_series_be64(kvm_group *group, const void *be_bytes, int64_t n);
+int kvm_group_load_series_file(kvm_group *group, const char *path, int64_t n);
+int kvm_group_set_option(kvm_group *group, int32_t option, int64_t value);  /* kvm_set_option on every context of the group */
+
+/* The phase-2 pass of one query on every GPU of the group.  `variant` 0 rsm_ed, 1 cnsm_ed, 2 rsm_dtw, 3 cnsm_dtw; the
+ * other arguments are those of the matching kvm_verify_* (rho / alpha / beta ignored where the variant has none) and
+ * `left`/`right` is the WHOLE list (every rank of a kvm_open_rank group passes the same one).  Replaces the same blocks
+ * as kvm_verify_* (K/QueryEngine.java:338-363 and its three siblings); the result is the one kvm_verify_* returns for the
+ * unsharded list -- offsets, order, distances, cntCandidate -- with the work counters (kvm_result_stat) left at 0. */
+int kvm_verify_sharded(kvm_group *group, int32_t variant, const double *query, int32_t m, const int32_t *left,
+                       const int32_t *right, int32_t k, int32_t shift, double epsilon, int32_t rho, double alpha,
+                       double beta, kvm_result **result);
+/* A stream of such passes, `in_flight` of them overlapping on every device: the slots' threads enqueue, the calling thread
+ * issues the all-gathers in job order and merges (the all-gather and host copy of job i overlap the kernels of job i+1).
+ * results[i] / status[i] as kvm_run_jobs; after a failing job no further job is started and the call returns its status
+ * (every rank of the group stops at the same job). */
+int kvm_run_sharded_jobs(kvm_group *group, const kvm_job *jobs, int64_t n_jobs, kvm_result **results, int32_t *status);
+
+/* The split rule, host only: shard `part` of `parts` of an interval list, balanced by candidate count; every candidate
+ * offset lands in exactly one shard.
+ *   KVM_SPLIT_INTERLEAVED  whole intervals are dealt out in rounds of `parts` consecutive intervals, the longest of a round to
+ *       the shard that is lightest so far: neighbouring intervals land on different GPUs (the expensive candidates of a DTW
+ *       query cluster around the matches), and because no interval is cut a sharded cNSM run restarts the reference's running
+ *       sums (K/NormQueryEngine.java:487) exactly where the unsharded one does.
+ *   KVM_SPLIT_CONTIGUOUS   contiguous slices of the candidate sequence, cut inside an interval where a boundary falls.
+ *   KVM_SPLIT_AUTO         interleaved when the list holds at least 8 intervals per part, else contiguous.
+ * Empty intervals (right < left) belong to no shard.  out_left / out_right: room for k entries, or both NULL to count only.
+ * Returns the number of intervals of the shard, or KVM_ERR_ILLEGAL_ARGUMENT. */
+#define KVM_SPLIT_AUTO 0
+#define KVM_SPLIT_INTERLEAVED 1
+#define KVM_SPLIT_CONTIGUOUS 2
+int64_t kvm_split_intervals(const int32_t *left, const int32_t *right, int64_t k, int32_t parts, int32_t part, int32_t mode,
+                            int32_t *out_left, int32_t *out_right);
+
+/* Layout version of the structs that cross this boundary (kvm_job, kvm_device_slot): 6 since kvm_device_slot.ready (0.5)
+ * and the group entry points.  A binding asserts it at load time instead of mis-striding an array of slots. */
+#define KVM_ABI_VERSION 6
+int32_t kvm_abi_version(void);
 
 /* ---- synthetic inputs: seeded restatement of K/DataGenerator.java:80-119 ------------------------ */
 

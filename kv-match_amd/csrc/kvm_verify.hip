@@ -606,6 +606,61 @@ static int dtw_resolve_ambiguous(kvm_ctx *ctx, const kvm_query_dev &qd, const kv
     return KVM_OK;
 }
 
+// answers.sort(Comparator.comparing(Pair::getSecond)) -- stable on an offset-ascending list
+// (K/QueryEngine.java:373) == sort by (distance, offset).
+// Packed records; above a few thousand answers a stable LSD radix sort (offset digits first, then the bit pattern
+// of the non-negative distance, 11 bits per pass, passes whose digit is the same for every record skipped) instead
+// of a comparison sort: 0.46 -> ~0.1 ms for 10^4 answers.
+static void sort_answers_into(const int32_t *off, const double *dist, int64_t cnt, kvm_result &r) {
+    struct ans_rec {
+        double d;
+        int32_t o;
+    };
+    std::vector<ans_rec> recs((size_t)cnt);
+    for (int64_t i = 0; i < cnt; i++) recs[(size_t)i] = ans_rec{dist[(size_t)i], off[(size_t)i]};
+    if (cnt < 2048) {
+        std::sort(recs.begin(), recs.end(), [](const ans_rec &a, const ans_rec &b) { return a.d != b.d ? a.d < b.d : a.o < b.o; });
+    } else {
+        std::vector<ans_rec> tmp((size_t)cnt);
+        ans_rec *src = recs.data(), *dst = tmp.data();
+        auto key_of = [](const ans_rec &r, int pass) -> uint32_t {
+            if (pass < 3) return ((uint32_t)r.o >> (11 * pass)) & 2047u;  // offsets are positive int32
+            uint64_t u;
+            std::memcpy(&u, &r.d, 8);  // distances are >= 0 and never NaN: the bit pattern is monotone
+            return (uint32_t)(u >> (11 * (pass - 3))) & 2047u;
+        };
+        for (int pass = 0; pass < 9; pass++) {
+            size_t hist[2049] = {0};
+            for (int64_t i = 0; i < cnt; i++) hist[key_of(src[i], pass) + 1]++;
+            bool uniform = false;
+            for (int b = 1; b <= 2048; b++) uniform |= hist[b] == (size_t)cnt;
+            if (uniform) continue;
+            for (int b = 0; b < 2048; b++) hist[b + 1] += hist[b];
+            for (int64_t i = 0; i < cnt; i++) dst[hist[key_of(src[i], pass)]++] = src[i];
+            std::swap(src, dst);
+        }
+        if (src != recs.data()) std::memcpy(recs.data(), src, (size_t)cnt * sizeof(ans_rec));
+    }
+    r.off.resize((size_t)cnt);
+    r.dist.resize((size_t)cnt);
+    for (int64_t i = 0; i < cnt; i++) {
+        r.off[(size_t)i] = recs[(size_t)i].o;
+        r.dist[(size_t)i] = recs[(size_t)i].d;
+    }
+}
+// The group layer's result (kvm_sharded.cpp): the merged answers of all shards, in the order a single call returns them.
+kvm_result *kvm_result_from_pairs(const int32_t *off, const double *dist, int64_t cnt, int64_t candidates, double elapsed_ms) {
+    try {
+        std::unique_ptr<kvm_result> r(new kvm_result());
+        sort_answers_into(off, dist, cnt, *r);
+        r->candidates = candidates;
+        r->elapsed_ms = elapsed_ms;
+        return r.release();
+    } catch (...) {
+        return nullptr;
+    }
+}
+
 static int verify_host(kvm_ctx *ctx, int variant, const double *query, int32_t m, const int32_t *left,
                        const int32_t *right, int32_t k, int32_t shift, double epsilon, int32_t rho, double alpha,
                        double beta, kvm_result **result) {
@@ -691,46 +746,7 @@ static int verify_host(kvm_ctx *ctx, int variant, const double *query, int32_t m
         std::memcpy(off.data() + spec, po, rest * 4);
     }
     KVM_TP("answers D2H");
-    // answers.sort(Comparator.comparing(Pair::getSecond)) -- stable on an offset-ascending list
-    // (K/QueryEngine.java:373) == sort by (distance, offset).
-    // Packed records; above a few thousand answers a stable LSD radix sort (offset digits first, then the bit pattern
-    // of the non-negative distance, 11 bits per pass, passes whose digit is the same for every record skipped) instead
-    // of a comparison sort: 0.46 -> ~0.1 ms for 10^4 answers.
-    struct ans_rec {
-        double d;
-        int32_t o;
-    };
-    std::vector<ans_rec> recs((size_t)cnt);
-    for (int64_t i = 0; i < cnt; i++) recs[(size_t)i] = ans_rec{dist[(size_t)i], off[(size_t)i]};
-    if (cnt < 2048) {
-        std::sort(recs.begin(), recs.end(), [](const ans_rec &a, const ans_rec &b) { return a.d != b.d ? a.d < b.d : a.o < b.o; });
-    } else {
-        std::vector<ans_rec> tmp((size_t)cnt);
-        ans_rec *src = recs.data(), *dst = tmp.data();
-        auto key_of = [](const ans_rec &r, int pass) -> uint32_t {
-            if (pass < 3) return ((uint32_t)r.o >> (11 * pass)) & 2047u;  // offsets are positive int32
-            uint64_t u;
-            std::memcpy(&u, &r.d, 8);  // distances are >= 0 and never NaN: the bit pattern is monotone
-            return (uint32_t)(u >> (11 * (pass - 3))) & 2047u;
-        };
-        for (int pass = 0; pass < 9; pass++) {
-            size_t hist[2049] = {0};
-            for (int64_t i = 0; i < cnt; i++) hist[key_of(src[i], pass) + 1]++;
-            bool uniform = false;
-            for (int b = 1; b <= 2048; b++) uniform |= hist[b] == (size_t)cnt;
-            if (uniform) continue;
-            for (int b = 0; b < 2048; b++) hist[b + 1] += hist[b];
-            for (int64_t i = 0; i < cnt; i++) dst[hist[key_of(src[i], pass)]++] = src[i];
-            std::swap(src, dst);
-        }
-        if (src != recs.data()) std::memcpy(recs.data(), src, (size_t)cnt * sizeof(ans_rec));
-    }
-    r->off.resize((size_t)cnt);
-    r->dist.resize((size_t)cnt);
-    for (int64_t i = 0; i < cnt; i++) {
-        r->off[(size_t)i] = recs[(size_t)i].o;
-        r->dist[(size_t)i] = recs[(size_t)i].d;
-    }
+    sort_answers_into(off.data(), dist.data(), cnt, *r);
     KVM_TP("sort answers");
     r->candidates = pl.cnt_candidate;
     r->stats[KVM_STAT_WINDOWS] = pl.windows;

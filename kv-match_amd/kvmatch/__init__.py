@@ -6,6 +6,8 @@ from ._lib import (KvMatchDeviceError, KvMatchIllegalArgument, KvMatchIndexOutOf
                    OPT_DP_KERNEL, OPT_ED_KERNEL, OPT_LB_CASCADE, OPT_SORT_VIOLATION, OPT_TIMING, STAT_KERNEL_NS, STAT_PASS_FILTER, STAT_PASS_LB_KEOGH,
                    STAT_DTW_SEQUENTIAL, STAT_PASS_LB_KEOGH2, STAT_PASS_LB_KIM, STAT_RECHECKED, STAT_WINDOWS)
 from .engine import phase2_time_estimate_ms, phase2_time_estimate_dp_ms, phase1_should_stop  # noqa
+from .engine import DeviceGroup, split_intervals  # noqa
+from ._lib import KvMatchShardFailed  # noqa
 from .engine import (Answers, IndexBuilder, Job, NormQueryEngine, NormQueryEngineDtw, Phase2Context, QueryEngine, QueryEngineDtw,  # noqa
                      QueryStream, StatisticInfo, cnsm_dtw_order, resolve_rho, sort_and_merge_intervals)
 from .ucr import UcrDtwQueryExecutor, UcrEdQueryExecutor  # noqa

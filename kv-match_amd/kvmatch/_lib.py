@@ -19,6 +19,12 @@ KVM_ERR_NO_SERIES = -6
 KVM_ERR_UNSUPPORTED = -7
 KVM_ERR_INDEX_OUT_OF_BOUNDS = -8
 KVM_ERR_NO_MEMORY = -9
+KVM_ERR_SHARD_FAILED = -10
+KVM_ABI_VERSION = 6
+GROUP_ID_BYTES = 128
+GROUP_RCCL_ALWAYS = 1
+GROUP_PACK_CAP, GROUP_SPLIT_MODE = 1, 2
+SPLIT_AUTO, SPLIT_INTERLEAVED, SPLIT_CONTIGUOUS = 0, 1, 2
 
 STAT_WINDOWS, STAT_PASS_FILTER, STAT_PASS_LB_KIM, STAT_PASS_LB_KEOGH, STAT_PASS_LB_KEOGH2, STAT_KERNEL_NS, \
     STAT_RECHECKED, STAT_DTW_SEQUENTIAL = range(8)
@@ -40,6 +46,10 @@ SYMBOLS = [
     "kvm_result_distances", "kvm_result_stat", "kvm_result_free",
     "kvm_set_option", "kvm_get_option", "kvm_last_kernel_ns", "kvm_measure_device", "kvm_verify_device", "kvm_pack_answers_device",
     "kvm_gen_series", "kvm_gen_intervals", "kvm_write_series_file",
+    "kvm_open_devices", "kvm_group_unique_id", "kvm_open_rank", "kvm_group_close", "kvm_group_last_error", "kvm_group_world",
+    "kvm_group_local_devices", "kvm_group_rccl_ranks", "kvm_group_ctx", "kvm_group_configure", "kvm_group_load_series_f64",
+    "kvm_group_load_series_be64", "kvm_group_load_series_file", "kvm_group_set_option", "kvm_verify_sharded",
+    "kvm_run_sharded_jobs", "kvm_split_intervals", "kvm_abi_version",
 ]
 
 
@@ -155,21 +165,49 @@ def load():
         "kvm_gen_series": (C.c_int, [C.c_uint64, i64, vp]),
         "kvm_gen_intervals": (i64, [C.c_uint64, i64, i32, i64, f64, vp, i32, vp, vp, i64]),
         "kvm_write_series_file": (C.c_int, [C.c_char_p, vp, i64]),
+        "kvm_open_devices": (C.c_int, [vp, i32, i32, i32, C.POINTER(vp)]),
+        "kvm_group_unique_id": (C.c_int, [vp, i32]),
+        "kvm_open_rank": (C.c_int, [i32, i32, i32, vp, i32, i32, i32, C.POINTER(vp)]),
+        "kvm_group_close": (C.c_int, [vp]),
+        "kvm_group_last_error": (C.c_char_p, [vp]),
+        "kvm_group_world": (i32, [vp]),
+        "kvm_group_local_devices": (i32, [vp]),
+        "kvm_group_rccl_ranks": (i32, [vp]),
+        "kvm_group_ctx": (vp, [vp, i32, i32]),
+        "kvm_group_configure": (C.c_int, [vp, i32, i64]),
+        "kvm_group_load_series_f64": (C.c_int, [vp, vp, i64]),
+        "kvm_group_load_series_be64": (C.c_int, [vp, vp, i64]),
+        "kvm_group_load_series_file": (C.c_int, [vp, C.c_char_p, i64]),
+        "kvm_group_set_option": (C.c_int, [vp, i32, i64]),
+        "kvm_verify_sharded": (C.c_int, [vp, i32, vp, i32, vp, vp, i32, i32, f64, i32, f64, f64, C.POINTER(vp)]),
+        "kvm_run_sharded_jobs": (C.c_int, [vp, C.POINTER(KvmJob), i64, C.POINTER(vp), C.POINTER(i32)]),
+        "kvm_split_intervals": (i64, [vp, vp, i64, i32, i32, i32, vp, vp]),
+        "kvm_abi_version": (i32, []),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
+    # (struct kvm_job / kvm_device_slot are passed as arrays: a build with another layout would be mis-strided silently)
+    if lib.kvm_abi_version() != KVM_ABI_VERSION:
+        raise OSError(f"{LIB_PATH}: ABI version {lib.kvm_abi_version()}, this binding is written for {KVM_ABI_VERSION}")
     _lib = lib
     return lib
 
 
-def check(rc, ctx=None):
-    """Translate a status code into the exception the reference would have thrown."""
+class KvMatchShardFailed(RuntimeError):
+    """Another rank of a device group failed on its shard of the call (KVM_ERR_SHARD_FAILED; -> java.io.IOException)."""
+
+
+def check(rc, ctx=None, group=None):
+    """Translate a status code into the exception the reference would have thrown.  `group`: the status comes from a
+    kvm_group entry point (its text is kvm_group_last_error's)."""
     if rc == KVM_OK:
         return
-    msg = load().kvm_last_error(ctx)
+    msg = load().kvm_group_last_error(None if group is True else group) if group is not None else load().kvm_last_error(ctx)
     msg = msg.decode() if msg else f"status {rc}"
+    if rc == KVM_ERR_SHARD_FAILED:
+        raise KvMatchShardFailed(msg)
     if rc == KVM_ERR_ILLEGAL_ARGUMENT:
         raise KvMatchIllegalArgument(msg)
     if rc == KVM_ERR_IO:

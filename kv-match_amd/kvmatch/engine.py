@@ -457,6 +457,134 @@ class QueryStream:
         self.close()
 
 
+class DeviceGroup:
+    """One engine over several GPUs (kvm_group of include/kvmatch.h): the series replicated on every device, the candidate
+    list of a call dealt out to the devices, ONE RCCL all-gather of the answers issued from native code -- the host-side
+    mirror of `new QueryEngine(n, storageType)` (K/QueryEngine.java:70) for a node of GPUs.
+
+        g = DeviceGroup(devices=[0, 1, ..., 7], in_flight=8)                      # one process, eight GPUs
+        g = DeviceGroup(rank=r, world=8, device=local_rank, unique_id=uid)       # one process per GPU (uid from
+        g.load_series(series)                                                     #   DeviceGroup.unique_id() on one rank)
+        ans = g.verify(0, (left, right), 1, q, 10.0)                              # Answers, as QueryEngine.verify
+        res = g.run_jobs([Job(...), ...])                                         # a stream, `in_flight` queries overlapping
+    """
+
+    def __init__(self, devices=None, in_flight=1, rccl_always=False, rank=None, world=None, device=None, unique_id=None):
+        self._lib = _lib.load()
+        self._g = None
+        h = C.c_void_p()
+        flags = _lib.GROUP_RCCL_ALWAYS if rccl_always else 0
+        if rank is None:
+            devs = np.ascontiguousarray([0] if devices is None else list(devices), dtype=np.int32)
+            rc = self._lib.kvm_open_devices(devs.ctypes.data, devs.size, int(in_flight), flags, C.byref(h))
+        else:
+            uid = bytes(unique_id) if unique_id is not None else None
+            rc = self._lib.kvm_open_rank(int(device if device is not None else 0), int(rank), int(world), uid,
+                                         len(uid) if uid is not None else 0, int(in_flight), flags, C.byref(h))
+        _lib.check(rc, group=True)
+        self._g = h
+        self.in_flight = int(in_flight)
+
+    @staticmethod
+    def unique_id():
+        """The bytes one rank makes and the launcher carries to the others (kvm_group_unique_id)."""
+        buf = C.create_string_buffer(_lib.GROUP_ID_BYTES)
+        _lib.check(_lib.load().kvm_group_unique_id(buf, _lib.GROUP_ID_BYTES), group=True)
+        return buf.raw
+
+    world = property(lambda self: int(self._lib.kvm_group_world(self._g)))
+    local_devices = property(lambda self: int(self._lib.kvm_group_local_devices(self._g)))
+    rccl_ranks = property(lambda self: int(self._lib.kvm_group_rccl_ranks(self._g)))
+
+    def load_series(self, values):
+        v = np.ascontiguousarray(values, dtype=np.float64)
+        _lib.check(self._lib.kvm_group_load_series_f64(self._g, v.ctypes.data, v.size), group=self._g)
+
+    def load_series_file(self, path, n):
+        _lib.check(self._lib.kvm_group_load_series_file(self._g, os.fsencode(path), int(n)), group=self._g)
+
+    def set_option(self, option, value):
+        _lib.check(self._lib.kvm_group_set_option(self._g, int(option), int(value)), group=self._g)
+
+    def configure(self, what, value):
+        _lib.check(self._lib.kvm_group_configure(self._g, int(what), int(value)), group=self._g)
+
+    def last_kernel_ns(self, local_device=0, slot=0):
+        return int(self._lib.kvm_last_kernel_ns(self._lib.kvm_group_ctx(self._g, local_device, slot)))
+
+    def _collect(self, res):
+        return Phase2Context._collect(self, res)
+
+    def verify(self, variant, valid_positions, last_segment, query_data, epsilon, rho=0, alpha=0.0, beta=0.0):
+        j = Job(variant, valid_positions, last_segment, query_data, epsilon, rho=rho, alpha=alpha, beta=beta)
+        res = C.c_void_p()
+        rc = self._lib.kvm_verify_sharded(self._g, j.variant, j.q.ctypes.data, j.q.size, j.left.ctypes.data, j.right.ctypes.data,
+                                          j.left.size, j.shift, j.epsilon, j.rho, j.alpha, j.beta, C.byref(res))
+        _lib.check(rc, group=self._g)
+        return self._collect(res)
+
+    def run_jobs(self, jobs, collect=None):
+        """kvm_run_sharded_jobs: `jobs` are `Job` descriptors over the WHOLE candidate lists; returns the Answers in job
+        order (None where `collect` does not ask for them), raises the first failing job's error."""
+        jobs = list(jobs)
+        n = len(jobs)
+        if n == 0:
+            return []
+        arr = _job_array(jobs)
+        res = (C.c_void_p * n)()
+        st = (C.c_int32 * n)()
+        rc = self._lib.kvm_run_sharded_jobs(self._g, arr, n, res, st)
+        if rc:
+            for r in res:
+                if r:
+                    self._lib.kvm_result_free(r)
+            _lib.check(rc, group=self._g)
+        want = None if collect is None else set(int(i) % n for i in collect)
+        out = [None] * n
+        for i, r in enumerate(res):
+            if want is None or i in want:
+                out[i] = self._collect(C.c_void_p(r))
+            else:
+                self._lib.kvm_result_free(r)
+        return out
+
+    def close(self):
+        if self._g is not None:
+            self._lib.kvm_group_close(self._g)
+            self._g = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def split_intervals(valid_positions, parts, part, mode=0):
+    """kvm_split_intervals: shard `part` of `parts` of the list (mode: _lib.SPLIT_AUTO / SPLIT_INTERLEAVED / SPLIT_CONTIGUOUS)."""
+    left, right = _as_intervals(valid_positions)
+    ol, orr = np.empty(left.size, dtype=np.int32), np.empty(left.size, dtype=np.int32)
+    k = _lib.load().kvm_split_intervals(left.ctypes.data, right.ctypes.data, left.size, int(parts), int(part), int(mode),
+                                        ol.ctypes.data, orr.ctypes.data)
+    if k < 0:
+        raise _lib.KvMatchIllegalArgument("bad kvm_split_intervals arguments")
+    return ol[:k].copy(), orr[:k].copy()
+
+
+def _job_array(jobs):
+    arr = (_lib.KvmJob * len(jobs))()
+    for a, j in zip(arr, jobs):
+        a.variant, a.m, a.query, a.left, a.right = j.variant, j.q.size, j.q.ctypes.data, j.left.ctypes.data, j.right.ctypes.data
+        a.k, a.shift, a.epsilon, a.rho, a.alpha, a.beta = j.left.size, j.shift, j.epsilon, j.rho, j.alpha, j.beta
+    return arr
+
+
 class Job:
     """One phase-2 call as data, for QueryStream.run_jobs: the arguments of the engine's verify() -- `variant` 0 QueryEngine,
     1 NormQueryEngine, 2 QueryEngineDtw, 3 NormQueryEngineDtw; rho an int (points) or a float (the REPL's fraction rule)."""
