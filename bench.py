@@ -113,7 +113,7 @@ def timed_steps(fn, steps, warmup, world):
         dist.barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64)   # (control plane: gloo)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     return dt
@@ -280,27 +280,12 @@ def main():
     torch.cuda.set_device(local_rank)
     use_dist = "RANK" in os.environ and "MASTER_PORT" in os.environ  # launched by torch.distributed.run
     rccl_ranks = 0
-    if use_dist and rehearsal:
+    if use_dist:
+        # CONTROL plane only (the barrier around the timed region, the max over ranks, carrying the communicator id): gloo on
+        # the CPU.  The DATA path -- the one all-gather of answers per query -- is the library's own RCCL communicator
+        # (kvm_open_rank: ncclCommInitRank + ncclAllGather issued from native code), made below once the id has travelled.
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo")
-    elif use_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # RCCL prints a version banner on stdout when its first communicator comes up: keep stdout for the one JSON line
-        sys.stdout.flush()
-        saved_stdout = os.dup(1)
-        os.dup2(2, 1)
-        try:
-            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
-            warm = torch.zeros(1, device=f"cuda:{local_rank}")
-            dist.all_reduce(warm)
-            torch.cuda.synchronize()
-        finally:
-            sys.stdout.flush()
-            os.dup2(saved_stdout, 1)
-            os.close(saved_stdout)
-        rccl_ranks = dist.get_world_size()
-        if rccl_ranks != a.gpus:
-            raise SystemExit(f"--gpus {a.gpus} but the RCCL group has {rccl_ranks} ranks")
     if a.in_flight <= 0:
         a.in_flight = 16 if use_dist else 8
     n, m = a.n, a.m
@@ -348,11 +333,13 @@ def main():
 
     def make_lists(total):
         ls = [datagen.gen_intervals(n, m, total, 64.0, must_cover=must, seed=1 + i) for i in range(NL)]
-        return ls, [distributed.split_intervals(l, r, world, rank) for l, r in ls]
+        # (this rank's shard by the library's own rule, kvm_split_intervals: what the group entry points deal it inside a call)
+        return ls, [kvmatch.split_intervals((l, r), world, rank) for l, r in ls]
 
     scalings = ["weak", "strong"] if a.scaling == "both" else [a.scaling]
     full_lists, shards = make_lists(a.candidates * world if scalings[0] == "weak" else a.candidates)
     my_cands_l = [int((r.astype(np.int64) - l + 1).sum()) for l, r in shards]
+    all_cands_l = [int((r.astype(np.int64) - l + 1).sum()) for l, r in full_lists]   # (the whole job's, known to every rank)
     my_cands = my_cands_l[0]
     ctx = kvmatch.Phase2Context(local_rank)
     ctx.load_series(series)
@@ -451,8 +438,25 @@ def main():
     # the reference's engine instances, is not re-entrant).  world = 1: the host API (kvm_verify_*) through QueryStream;
     # launched ranks: device-resident shard verification (kvm_verify_device) through ShardedStream, whose calling thread
     # alone issues the RCCL all-gathers, in query order.
+    # Three drivers of the same stream: the host API (N = 1: kvm_run_jobs over F contexts), the native group (launched ranks:
+    # kvm_open_rank + kvm_run_sharded_jobs -- every rank hands over the WHOLE lists, the library splits, verifies its shard,
+    # all-gathers and merges), and -- only to rehearse the launch on a box with fewer GPUs than ranks -- the Python host layer
+    # of rounds 2-5 over gloo.
     qstream = None if use_dist else kvmatch.QueryStream(ctx, F)
-    sstream = distributed.ShardedStream(ctx, plans[0][0], max(my_cands_l), in_flight=F) if use_dist else None
+    group = None
+    sstream = None
+    if use_dist and rehearsal:
+        sstream = distributed.ShardedStream(ctx, plans[0][0], max(my_cands_l), in_flight=F)
+    elif use_dist:
+        uid = [kvmatch.DeviceGroup.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)          # (the launcher's own store carries the communicator id)
+        group = kvmatch.DeviceGroup(rank=rank, world=world, device=local_rank, unique_id=uid[0], in_flight=F, rccl_always=True)
+        group.load_series(series)
+        rccl_ranks = group.rccl_ranks
+        if rccl_ranks != a.gpus:
+            raise SystemExit(f"--gpus {a.gpus} but the RCCL communicator has {rccl_ranks} ranks")
+        if wl == "mixed":
+            group.set_option(kvmatch.OPT_SORT_VIOLATION, 1)
     eng_cache = {}
 
     def host_job(i, j):
@@ -475,11 +479,27 @@ def main():
                                                 alpha=kw.get("alpha", 0.0), beta=kw.get("beta", 0.0))
         return d
 
+    full_cache = {}
+
+    def job_desc_full(i, j):
+        d = full_cache.get((i, j))
+        if d is None:
+            kw = plans[i][3]
+            d = full_cache[(i, j)] = kvmatch.Job(plans[i][0], full_lists[j % NL], 1, queries[j], a.epsilon, rho=kw.get("rho", 0),
+                                                 alpha=kw.get("alpha", 0.0), beta=kw.get("beta", 0.0))
+        return d
+
     def step():
         # the stream cycles through the NQ queries (and, "mixed", through the four variants); query j runs over list j mod NL
         ids = [((step_no[0] + t) % len(plans), (step_no[0] + t) % NQ) for t in range(qps)]
         step_no[0] += qps
-        if use_dist:
+        keep = range(max(0, len(ids) - NQ * len(plans)), len(ids))
+        if group is not None:
+            # one call: the library splits every list, enqueues the shards on its slots' threads, issues the all-gathers in job
+            # order from this thread and merges; every result is the whole job's answer list, on every rank
+            res = group.run_jobs([job_desc_full(i, j) for i, j in ids], collect=keep)
+            last["res"] = [(ids[t][0], ids[t][1], res[t].offsets, res[t].distances) for t in keep]
+        elif use_dist:
             res = sstream.run([job_desc(i, j) for i, j in ids])   # (the descriptors are marshalled once, as on the host path)
             last["res"] = [(i, j, o, d) for (i, j), (o, d) in zip(ids, res)][-NQ * len(plans):]
         elif a.python_threads:
@@ -488,22 +508,17 @@ def main():
         else:
             # calls as data, the per-context host threads in native code (kvm_run_jobs): every result is complete -- sorted,
             # in host memory -- when the call returns; the last NQ x #variants are read back here for the parity checks
-            keep = range(max(0, len(ids) - NQ * len(plans)), len(ids))
             res = qstream.run_jobs([job_desc(i, j) for i, j in ids], collect=keep)
             last["res"] = [(ids[t][0], ids[t][1], res[t].offsets, res[t].distances) for t in keep]
 
     def set_option(opt, val):
-        (sstream if use_dist else qstream).set_option(opt, val)
+        (group or sstream or qstream).set_option(opt, val)
 
     def sum_cands(ids_count):
-        """candidates verified by `ids_count` consecutive queries of the stream starting at query 0 (whole job)"""
-        per_q = np.array([my_cands_l[j % NL] for j in range(NQ)], dtype=np.int64)
-        tot = int(per_q.sum()) * (ids_count // NQ) + int(per_q[: ids_count % NQ].sum())
-        if world > 1:
-            t = torch.tensor([tot], dtype=torch.int64, device="cuda")
-            dist.all_reduce(t)
-            tot = int(t.item())
-        return tot
+        """candidates verified by `ids_count` consecutive queries of the stream starting at query 0 (whole job: every rank
+        knows the whole lists)"""
+        per_q = np.array([all_cands_l[j % NL] for j in range(NQ)], dtype=np.int64)
+        return int(per_q.sum()) * (ids_count // NQ) + int(per_q[: ids_count % NQ].sum())
 
     # ---- headline: early abandon off ---------------------------------------------------------------------
     set_option(kvmatch.OPT_EARLY_ABANDON, 0)
@@ -575,19 +590,56 @@ def main():
     ab = {(i, j): (o, d) for i, j, o, d in last["res"]}
     ab_match = bool(all(k in ab and np.array_equal(ab[k][0], head[k][0]) and np.array_equal(ab[k][1], head[k][1]) for k in head))
 
+    # ---- the launched path at world 1 (N = 1, default workload): the SAME stream through the native group -- kvm_open_devices
+    # on this one GPU, the exchange through real RCCL (a communicator of one rank) -- next to the host path's rate above.  What
+    # a rank of an 8-GPU job runs, minus the peers.
+    group_w1 = None
+    if rank == 0 and world == 1 and not use_dist and a.extras and wl == "rsm_ed":
+        try:
+            gF = 16
+            with kvmatch.DeviceGroup(devices=[local_rank], in_flight=gF, rccl_always=True) as g1:
+                g1.load_series(series)
+
+                def gstep(n_q, collect=()):
+                    return g1.run_jobs([job_desc_full(0, t % NQ) for t in range(n_q)], collect=collect)
+                group_w1 = {"rccl_ranks": g1.rccl_ranks, "queries_in_flight": gF, "queries_per_step": qps}
+                for key, ab in (("value", 0), ("value_early_abandon", 1)):
+                    g1.set_option(kvmatch.OPT_EARLY_ABANDON, ab)
+                    gstep(qps)
+                    t1 = time.perf_counter()
+                    reps = max(2, a.steps // 4)
+                    for _ in range(reps):
+                        res = gstep(qps, collect=range(qps - NQ, qps))
+                    group_w1[key] = sum_cands(reps * qps) / (time.perf_counter() - t1)
+                    got = {(qps - NQ + t) % NQ: res[qps - NQ + t] for t in range(NQ)}
+                    group_w1["same_answers" + ("_early_abandon" if ab else "")] = bool(all(
+                        np.array_equal(got[j].offsets, head[(0, j)][0]) and np.array_equal(got[j].distances, head[(0, j)][1])
+                        and got[j].cnt_candidate == all_cands_l[j % NL] for j in range(NQ)))
+                group_w1["vs_host_path"] = group_w1["value"] / value
+                group_w1["vs_host_path_early_abandon"] = group_w1["value_early_abandon"] / value_ab
+                group_w1["note"] = ("kvm_run_sharded_jobs on a group of this one GPU: split, slot threads, pack, ncclAllGather (one rank, "
+                                    "real RCCL), host copy, merge and sort inside the library; compared with kvm_run_jobs above")
+        except Exception as e:  # noqa: BLE001
+            group_w1 = {"error": repr(e)}
+
     # ---- --scaling both: the strong-scaling run of the same launch (the --candidates list split over the ranks) ----------
     strong = None
     if len(scalings) == 2:
         set_option(kvmatch.OPT_EARLY_ABANDON, 0)
-        weak_state = (full_lists, shards, my_cands_l)
+        weak_state = (full_lists, shards, my_cands_l, all_cands_l)
         full_lists, shards = make_lists(a.candidates)
         my_cands_l = [int((r.astype(np.int64) - l + 1).sum()) for l, r in shards]
+        all_cands_l = [int((r.astype(np.int64) - l + 1).sum()) for l, r in full_lists]
+        full_cache.clear()
+        job_cache.clear()
         step_no[0] = 0
         dt_s = timed_steps(step, a.steps, a.warmup, world)
         strong = {"value": sum_cands(a.steps * qps) / dt_s, "ms_per_step": dt_s / a.steps * 1e3,
                   "ms_per_query": dt_s / (a.steps * qps) * 1e3, "candidates_per_query_per_gpu": my_cands_l[0],
                   "note": "the same launch, --candidates in total split over the ranks (early abandon off)"}
-        full_lists, shards, my_cands_l = weak_state
+        full_lists, shards, my_cands_l, all_cands_l = weak_state
+        full_cache.clear()
+        job_cache.clear()
         set_option(kvmatch.OPT_EARLY_ABANDON, 1)
 
     out.update({
@@ -615,7 +667,7 @@ def main():
                                 "cnsm_dtw": "cNSM-DTW phase 2, rho=5%, alpha=2 beta=10 (BASELINE configs[3])",
                                 "mixed": "mixed ED+DTW query stream (BASELINE configs[4] style)"}[wl], "n": n, "m": m,
                    "queries_per_step": qps, "queries_in_flight": F,
-                   "host_threads": ("python (a profiler is attached)" if a.profiled else "python") if a.python_threads else (("native (kvm_run_device_jobs)" if use_dist else "native (kvm_run_jobs)") + ("; a profiler is attached: the calls' enqueue phases take turns (kvm_verify.hip, kvm_enqueue_lock)" if a.profiled and os.environ.get("KVM_SERIALIZE_ENQUEUE", "") != "0" else "")),
+                   "host_threads": ("python (a profiler is attached)" if a.profiled else "python") if a.python_threads else (("native (kvm_run_sharded_jobs: split, slot threads, ncclAllGather and merge inside the library)" if group is not None else "native (kvm_run_device_jobs) under a Python exchange thread" if use_dist else "native (kvm_run_jobs)") + ("; a profiler is attached: the calls' enqueue phases take turns (kvm_verify.hip, kvm_enqueue_lock)" if a.profiled and os.environ.get("KVM_SERIALIZE_ENQUEUE", "") != "0" else "")),
                    "distinct_queries": NQ, "distinct_interval_lists": NL,
                    "candidates_per_query_per_gpu": my_cands,
                    "candidates_per_gpu": my_cands, "intervals_per_gpu": int(len(shards[0][0])), "epsilon": a.epsilon,
@@ -624,6 +676,7 @@ def main():
                    "answers_per_query": [int(len(head[k][0])) for k in sorted(head)][:NQ], "ed_kernel": a.ed_kernel},
         "value_early_abandon": value_ab,
         "early_abandon_same_answers": ab_match,
+        **({"group_world1": group_w1} if group_w1 else {}),
         "setup_s": setup_s,
     })
     # what THIS box sustains (the vendor peaks are quoted): HBM stream triad, fp64 FMA issue, the DP's non-FMA cell mix
@@ -850,7 +903,7 @@ def main():
     # child process each (the workload loops of this file at reduced --steps), their lines kept under `configs` and their
     # values lifted to the top level -- so that the driver's one command times configs[1], [2] and [3]
     if rank == 0 and world == 1 and a.extras and wl == "rsm_ed" and a.sub_workloads:
-        (sstream if use_dist else qstream).close()
+        (group or sstream or qstream).close()
         ctx.close()
         ctx = None
         out["configs"] = {}
@@ -874,7 +927,7 @@ def main():
                 out["configs"][w] = {"error": repr(e)}
 
     if ctx is not None:
-        (sstream if use_dist else qstream).close()
+        (group or sstream or qstream).close()
         ctx.close()
     if rank == 0:
         print(json.dumps(out))

@@ -468,6 +468,25 @@ int32_t kvm_group_rccl_ranks(const kvm_group *group);     /* ranks of the RCCL c
 /* the context of slot `slot` of local device `local_device` (slot 0 owns the device's series): for kvm_get_option,
  * kvm_read_time_series, kvm_last_kernel_ns ...; NOT for verification calls while a group call runs */
 kvm_ctx *kvm_group_ctx(kvm_group *group, int32_t local_device, int32_t slot);
+/* Where the threads of the most recent kvm_run_sharded_jobs / kvm_verify_sharded spent their time, nanoseconds summed over
+ * the jobs (measurement only).  The calling thread: waiting for a job's exchange to be issued, waiting for its block to
+ * arrive, merge + sort.  The slot threads, summed over them: waiting for their slot to be handed back, splitting the list (or
+ * waiting for the thread that does), inside kvm_verify_device + kvm_pack_answers_device, waiting for the turn to issue the
+ * job's exchange, and the exchange itself -- preparing it, the all-gather (host time inside RCCL), the readback launch + event.
+ * KVM_GROUP_STAT_JOBS: jobs of that call. */
+#define KVM_GROUP_STAT_JOBS 0
+#define KVM_GROUP_STAT_WAIT_ISSUED_NS 1
+#define KVM_GROUP_STAT_PREPARE_NS 2
+#define KVM_GROUP_STAT_ALL_GATHER_NS 3
+#define KVM_GROUP_STAT_COPY_NS 4
+#define KVM_GROUP_STAT_WAIT_BLOCK_NS 5
+#define KVM_GROUP_STAT_MERGE_NS 6
+#define KVM_GROUP_STAT_SLOT_WAIT_NS 7
+#define KVM_GROUP_STAT_SLOT_SPLIT_NS 8
+#define KVM_GROUP_STAT_SLOT_ENQUEUE_NS 9
+#define KVM_GROUP_STAT_SLOT_TURN_NS 10
+#define KVM_GROUP_STAT_COUNT 11
+int64_t kvm_group_stat(const kvm_group *group, int32_t which);
 #define KVM_GROUP_PACK_CAP 1    /* answers per rank the one fixed-size exchange carries (default 4096; >= 1) */
 #define KVM_GROUP_SPLIT_MODE 2  /* KVM_SPLIT_* (default KVM_SPLIT_AUTO) */
 int kvm_group_configure(kvm_group *group, int32_t what, int64_t value);

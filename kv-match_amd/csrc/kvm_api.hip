@@ -113,6 +113,9 @@ static void free_series(kvm_ctx *ctx) {
     ctx->n = 0;
 }
 
+// the group layer runs a slot on its context's own stream (kvm_sharded.cpp)
+void *kvm_ctx_stream_handle(kvm_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
 extern "C" int kvm_close(kvm_ctx *ctx) {
     if (!ctx) return KVM_ERR_INVALID_HANDLE;
     hipSetDevice(ctx->device);

@@ -1176,17 +1176,31 @@ hipError_t kvm_launch_ed_dot(const double *series, const double2 *prefix, int64_
     const int64_t unitsA16 = (nA + EDD_TILES_A16 - 1) / EDD_TILES_A16;
     int64_t unitsA = (nA + EDD_TILES_A - 1) / EDD_TILES_A;
     const int64_t unitsB = (nB + EDD_TILES_B - 1) / EDD_TILES_B, unitsC = (nC + EDD_TILES_C - 1) / EDD_TILES_C;
-    // (more than 64 KB of LDS per workgroup has to be allowed once per kernel)
-    static std::once_flag lds_once;
-    static hipError_t lds_rc = hipSuccess;
-    std::call_once(lds_once, [] {
-        if (edd_lds_bytes<false>() > 65536) {
-            lds_rc = hipFuncSetAttribute((const void *)kvm_ed_dot_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)edd_lds_bytes<false>());
-            if (lds_rc == hipSuccess)
-                lds_rc = hipFuncSetAttribute((const void *)kvm_ed_dot_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)edd_lds_bytes<false>());
+    // (more than 64 KB of LDS per workgroup has to be allowed once per kernel AND PER DEVICE: the attribute belongs to the
+    // function as loaded on the device that is current, and a process may hold contexts on several GPUs -- kvm_open_devices)
+    {
+        constexpr int MAX_DEV = 64;
+        static std::once_flag lds_once[MAX_DEV];
+        static hipError_t lds_rc[MAX_DEV];
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return e;
+        auto allow = [] {
+            hipError_t rc = hipSuccess;
+            if (edd_lds_bytes<false>() > 65536) {
+                rc = hipFuncSetAttribute((const void *)kvm_ed_dot_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)edd_lds_bytes<false>());
+                if (rc == hipSuccess)
+                    rc = hipFuncSetAttribute((const void *)kvm_ed_dot_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)edd_lds_bytes<false>());
+            }
+            return rc;
+        };
+        if (dev < 0 || dev >= MAX_DEV) {   // (no such box; still correct: set it at every launch)
+            if ((e = allow()) != hipSuccess) return e;
+        } else {
+            std::call_once(lds_once[dev], [&] { lds_rc[dev] = allow(); });
+            if (lds_rc[dev] != hipSuccess) return lds_rc[dev];
         }
-    });
-    if (lds_rc != hipSuccess) return lds_rc;
+    }
     const int64_t unitsS = unitsB + unitsC;  // the short units: one split factor for both classes
     // Window split (see edd_body): only worth it while the units are few compared with the 8 wave slots per CU, and
     // impossible with early abandon (waves leave early).  Pick the split pair with the smallest modelled makespan.

@@ -213,6 +213,7 @@ hipError_t kvm_launch_blockmax(const double *x, int64_t n, double *blockmax, hip
 #define KVM_SPEC_ANSWERS 4096
 hipError_t kvm_launch_readback(const unsigned long long *counters, const int32_t *off, const double *dist, int64_t spec,
                                void *host, hipStream_t s);
+hipError_t kvm_launch_copy_u64(unsigned long long *dst, const unsigned long long *src, hipStream_t s);  // *dst = src ? *src : 0
 hipError_t kvm_launch_pack_answers(const int32_t *off, const double *dist, const int64_t *count, int64_t pack_cap,
                                    double2 *packed, hipStream_t s);
 hipError_t kvm_launch_window_means(const double *x, const double2 *prefix, int32_t w, int64_t first0, int64_t count,

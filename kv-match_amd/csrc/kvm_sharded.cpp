@@ -25,7 +25,7 @@
 
 // internal entry points of the library (kvm_verify.hip)
 int kvm_poison_packed_device(kvm_ctx *ctx, double *d_packed, void *stream);
-int kvm_record_event_device(kvm_ctx *ctx, void *event, void *stream);
+void *kvm_ctx_stream_handle(kvm_ctx *ctx);  // kvm_api.hip: the context's own stream
 // answers.sort(Comparator.comparing(Pair::getSecond)) on an offset-ascending list (K/QueryEngine.java:373) == (distance, offset)
 kvm_result *kvm_result_from_pairs(const int32_t *off, const double *dist, int64_t cnt, int64_t candidates, double elapsed_ms);
 
@@ -159,7 +159,7 @@ extern "C" int32_t kvm_abi_version(void) { return KVM_ABI_VERSION; }
 namespace {
 struct gslot_t {
     kvm_ctx *ctx = nullptr;
-    void *stream = nullptr, *ready = nullptr;
+    void *stream = nullptr;  // the context's own (not owned here): the slot's kernels AND its job's exchange run on it
     int32_t *d_off = nullptr;
     double *d_dist = nullptr;
     int64_t cap = 0;
@@ -169,7 +169,6 @@ struct gslot_t {
 };
 struct gdev_t {
     int device = -1;
-    void *xstream = nullptr;  // the exchange stream of this device: waits for a slot's `ready`, carries the all-gather
     void *comm = nullptr;
     std::vector<gslot_t> slots;
 };
@@ -184,8 +183,9 @@ struct kvm_group {
     bool loaded = false;
     std::vector<gdev_t> devs;
     std::vector<double *> h_block;  // per slot index: pinned, world blocks (what the exchange of that slot's job lands in)
-    std::vector<void *> issued;     // per slot index: event on devs[0].xstream behind that copy
+    std::vector<void *> issued;     // per slot index: event on that slot's stream of devs[0], behind the readback
     std::string err;
+    std::atomic<int64_t> stat[KVM_GROUP_STAT_COUNT] = {};  // where the threads of the last stream spent their time (kvm_group_stat)
 };
 
 namespace {
@@ -224,13 +224,14 @@ int alloc_exchange(kvm_group *g) {
             GCHK(g, kvm_sd_malloc(d.device, (void **)&s.d_packed, bd * 8));
             if (g->use_rccl) GCHK(g, kvm_sd_malloc(d.device, (void **)&s.d_gathered, bd * 8 * (size_t)g->world));
         }
-    for (double *&p : g->h_block) GCHK(g, kvm_sd_host_alloc((void **)&p, bd * 8 * (size_t)g->world));
+    for (double *&p : g->h_block) GCHK(g, kvm_sd_host_alloc(g->devs[0].device, (void **)&p, bd * 8 * (size_t)g->world));
     return KVM_OK;
 }
 void destroy_group(kvm_group *g) {
     if (!g) return;
     for (gdev_t &d : g->devs)  // nothing of a finished call is still running (every call drains its streams), but a failed one may be
-        if (d.xstream) (void)kvm_sd_stream_synchronize(d.device, d.xstream);
+        for (gslot_t &s : d.slots)
+            if (s.stream) (void)kvm_sd_stream_synchronize(d.device, s.stream);
     free_exchange(g);
     for (size_t t = 0; t < g->issued.size(); t++)
         if (!g->devs.empty()) kvm_sd_event_destroy(g->devs[0].device, g->issued[t]);
@@ -238,15 +239,11 @@ void destroy_group(kvm_group *g) {
         if (d.comm) kvm_sd_comm_destroy(d.device, d.comm);
         for (size_t t = d.slots.size(); t-- > 0;) {  // (slot 0 owns the series the others share: closed last)
             gslot_t &s = d.slots[t];
-            if (s.stream) (void)kvm_sd_stream_synchronize(d.device, s.stream);
             kvm_sd_free(d.device, s.d_off);
             kvm_sd_free(d.device, s.d_dist);
             kvm_sd_free(d.device, s.d_count);
-            kvm_sd_event_destroy(d.device, s.ready);
-            kvm_sd_stream_destroy(d.device, s.stream);
-            if (s.ctx) kvm_close(s.ctx);
+            if (s.ctx) kvm_close(s.ctx);   // (with its stream)
         }
-        kvm_sd_stream_destroy(d.device, d.xstream);
     }
     delete g;
 }
@@ -280,11 +277,15 @@ int open_common(const int32_t *devices, int32_t n_dev, int32_t rank0, int32_t wo
         for (gslot_t &s : dv.slots) {
             int rc = kvm_open(dv.device, &s.ctx);
             if (rc) return bail(rc, kvm_last_error(nullptr));
-            if ((rc = kvm_sd_stream_create(dv.device, &s.stream)) || (rc = kvm_sd_event_create(dv.device, &s.ready)) ||
-                (rc = kvm_sd_malloc(dv.device, (void **)&s.d_count, 8)))
-                return bail(rc, kvm_sd_last_error());
+            // A slot runs on its context's OWN stream, and so does its job's exchange.  The runtime deals streams out to its few
+            // hardware queues (four) in the order they are created, and the streams of one queue run one behind the other: a
+            // second stream per slot, created right behind the context's, put every slot stream on the same two queues (an
+            // early-abandoning stream ran at 72 us per query instead of 51), and a separate exchange stream queues a query's
+            // two tiny operations behind whatever 80-us pruner launch is at the head of its queue (36 us per query; at the
+            // highest priority it is worse, not better).  profiles/r06_group_stream_probe.log
+            s.stream = kvm_ctx_stream_handle(s.ctx);
+            if ((rc = kvm_sd_malloc(dv.device, (void **)&s.d_count, 8))) return bail(rc, kvm_sd_last_error());
         }
-        if (int rc = kvm_sd_stream_create(dv.device, &dv.xstream)) return bail(rc, kvm_sd_last_error());
     }
     for (void *&e : g->issued)
         if (int rc = kvm_sd_event_create(g->devs[0].device, &e)) return bail(rc, kvm_sd_last_error());
@@ -359,6 +360,9 @@ extern "C" const char *kvm_group_last_error(const kvm_group *g) { return g ? g->
 extern "C" int32_t kvm_group_world(const kvm_group *g) { return g ? g->world : KVM_ERR_INVALID_HANDLE; }
 extern "C" int32_t kvm_group_local_devices(const kvm_group *g) { return g ? (int32_t)g->devs.size() : KVM_ERR_INVALID_HANDLE; }
 extern "C" int32_t kvm_group_rccl_ranks(const kvm_group *g) { return g ? (g->use_rccl ? g->world : 0) : KVM_ERR_INVALID_HANDLE; }
+extern "C" int64_t kvm_group_stat(const kvm_group *g, int32_t which) {
+    return (g && which >= 0 && which < KVM_GROUP_STAT_COUNT) ? g->stat[which].load() : 0;
+}
 extern "C" kvm_ctx *kvm_group_ctx(kvm_group *g, int32_t local_device, int32_t slot) {
     if (!g || local_device < 0 || local_device >= (int32_t)g->devs.size() || slot < 0 || slot >= g->in_flight) return nullptr;
     return g->devs[(size_t)local_device].slots[(size_t)slot].ctx;
@@ -373,8 +377,7 @@ extern "C" int kvm_group_configure(kvm_group *g, int32_t what, int64_t value) {
         if (what == KVM_GROUP_PACK_CAP) {
             if (value < 1 || value > (1 << 24)) return gfail(g, KVM_ERR_ILLEGAL_ARGUMENT, "pack_cap must be 1 .. 2^24");
             if (value == g->pack_cap) return KVM_OK;
-            for (gdev_t &d : g->devs) GCHK(g, kvm_sd_stream_synchronize(d.device, d.xstream));
-            free_exchange(g);
+            free_exchange(g);   // (no call is running: every call drains what it enqueued)
             g->pack_cap = value;
             return alloc_exchange(g);
         }
@@ -417,6 +420,23 @@ extern "C" int kvm_group_set_option(kvm_group *g, int32_t option, int64_t value)
 }
 
 // ---- a stream of sharded queries ----------------------------------------------------------------------------------
+//
+// Protocol of one kvm_run_sharded_jobs call.  Job i runs on slot i mod F of every local device.
+//   slot thread (d, t), for i = t, t + F, ...:  wait until job i - F has been handed back; split the list (the first thread to
+//       reach the job does it for all local devices); enqueue kvm_verify_device + kvm_pack_answers_device on the slot's stream.
+//       The thread that completes the job's LAST local part is the job's issuer: it waits for its turn -- the exchanges are
+//       issued in job order, on every rank, whichever thread issues them -- and puts the job's exchange onto the slots' own
+//       streams right behind their kernels: the all-gather (one RCCL group over the local devices), on local device 0 the
+//       readback kernel into pinned host memory and the `issued` event.
+//   calling thread, for i = 0, 1, ...:  wait until job i's exchange is issued, wait for its event, merge the blocks of all
+//       ranks, sort, hand the slots back.
+// What must be the same on every rank is the ORDER of collectives on the communicator.  The turnstile gives gather(0),
+// gather(1), ...; two things interleave with it and are pinned to a position every rank computes alike:
+//   * the exact-size second exchange of a job i whose block overflowed: issued by the calling thread once gather(H - 1) has been
+//     issued, H = min(i + F, n_jobs) -- the jobs below H need no slot of job i or later, so their gathers are issued without
+//     anybody's help, and gather(i + F) cannot be issued before job i is handed back;
+//   * the end of a stream at a failing job i (every rank sees the failure mark in the gathered blocks): every rank still issues
+//     the gathers below the same H, then stops -- none is left with a collective its peers never join.
 namespace {
 struct job_state {
     std::mutex split_mu;   // the first slot thread to reach the job splits its list for every local device
@@ -429,15 +449,29 @@ struct job_state {
     // guarded by run_state::mu
     std::vector<int> rc;           // per local device
     std::vector<std::string> msg;
-    int produced = 0;              // local devices whose part of the job is enqueued (ready event recorded)
+    int produced = 0;              // local devices whose part of the job is enqueued
+    bool issued = false;           // the job's exchange is on the streams (or could not be put there: issue_rc)
+    int issue_rc = KVM_OK;
+    std::string issue_msg;
     bool consumed = false;         // merged: the slots of the job are free again
 };
 struct run_state {
     std::mutex mu;
-    std::condition_variable cv_produced, cv_consumed;
-    bool stop = false;
+    std::condition_variable cv_issued;                 // the calling thread waits here (a job issued, the turnstile moved)
+    std::condition_variable cv_turn;                   // issuers wait here for their turn
+    std::vector<std::condition_variable> cv_consumed;  // the threads of slot index t wait on [t]: a job handed back wakes only
+    bool stop = false;                                 // its own slots' threads, not all in_flight x devices of them
+    int64_t next_issue = 0;                            // the turnstile: the job whose exchange is issued next
     std::vector<job_state> js;
-    explicit run_state(size_t n) : js(n) {}
+    run_state(size_t n, size_t slots) : cv_consumed(slots), js(n) {}
+    void end() {   // every loop leaves at its next wait
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            stop = true;
+        }
+        for (auto &cv : cv_consumed) cv.notify_all();
+        cv_turn.notify_all();
+    }
 };
 
 int reserve_slot(const gdev_t &d, gslot_t &s, int64_t cap) {
@@ -481,22 +515,69 @@ void split_job(const kvm_group *g, const kvm_job &j, job_state &J) {
     J.split_done = true;
 }
 
+int64_t lap_ns(std::chrono::steady_clock::time_point &t0) {
+    const auto now = std::chrono::steady_clock::now();
+    const int64_t ns = std::chrono::duration_cast<std::chrono::nanoseconds>(now - t0).count();
+    t0 = now;
+    return ns;
+}
+
+// Job i's exchange onto its slots' OWN streams, behind the kernels the slot threads enqueued there (no thread touches these
+// streams again before the job is handed back): stream order is the only dependency.  Called in job order (the turnstile).
+int issue_exchange(kvm_group *g, job_state &J, int64_t i, std::string &msg) {
+    const int nl = (int)g->devs.size();
+    const size_t t = (size_t)(i % g->in_flight), bd = 2 * ((size_t)g->pack_cap + 1);
+    auto tp = std::chrono::steady_clock::now();
+    std::vector<int> devices((size_t)nl);
+    std::vector<void *> comms((size_t)nl), recv((size_t)nl), streams((size_t)nl);
+    std::vector<const void *> send((size_t)nl);
+    for (int d = 0; d < nl; d++) {
+        gdev_t &dv = g->devs[(size_t)d];
+        gslot_t &s = dv.slots[t];
+        // (a part that failed has marked its block; once more here, in case THAT is what failed)
+        if (J.rc[(size_t)d]) (void)kvm_poison_packed_device(s.ctx, s.d_packed, s.stream);
+        devices[(size_t)d] = dv.device;
+        comms[(size_t)d] = dv.comm;
+        send[(size_t)d] = s.d_packed;
+        recv[(size_t)d] = s.d_gathered;
+        streams[(size_t)d] = s.stream;
+    }
+    gdev_t &d0 = g->devs[0];
+    void *s0 = d0.slots[t].stream;
+    g->stat[KVM_GROUP_STAT_PREPARE_NS] += lap_ns(tp);
+    int rc = KVM_OK;
+    if (g->use_rccl) {
+        rc = kvm_sd_all_gather(nl, devices.data(), comms.data(), send.data(), recv.data(), bd, streams.data());
+        g->stat[KVM_GROUP_STAT_ALL_GATHER_NS] += lap_ns(tp);
+        if (!rc) rc = kvm_sd_readback_blocks(d0.device, g->h_block[t], d0.slots[t].d_gathered, g->world, bd, s0);
+    } else {
+        rc = kvm_sd_readback_blocks(d0.device, g->h_block[t], d0.slots[t].d_packed, 1, bd, s0);
+    }
+    if (!rc) rc = kvm_sd_event_record(d0.device, g->issued[t], s0);
+    g->stat[KVM_GROUP_STAT_COPY_NS] += lap_ns(tp);
+    if (rc) msg = kvm_sd_last_error();
+    return rc;
+}
+
 // The loop of slot t of local device d: jobs t, t + F, t + 2F ...
 void slot_loop(kvm_group *g, run_state &rs, const kvm_job *jobs, int64_t n_jobs, int d, int t) {
     gdev_t &dv = g->devs[(size_t)d];
     gslot_t &s = dv.slots[(size_t)t];
-    const int F = g->in_flight;
+    const int F = g->in_flight, nl = (int)g->devs.size();
     for (int64_t i = t; i < n_jobs; i += F) {
+        auto tp = std::chrono::steady_clock::now();
         {
             std::unique_lock<std::mutex> lk(rs.mu);
-            rs.cv_consumed.wait(lk, [&] { return rs.stop || i - F < 0 || rs.js[(size_t)(i - F)].consumed; });
+            rs.cv_consumed[(size_t)t].wait(lk, [&] { return rs.stop || i - F < 0 || rs.js[(size_t)(i - F)].consumed; });
             if (rs.stop) return;
         }
+        g->stat[KVM_GROUP_STAT_SLOT_WAIT_NS] += lap_ns(tp);
         job_state &J = rs.js[(size_t)i];
         {
             std::lock_guard<std::mutex> sl(J.split_mu);
             if (!J.split_done) split_job(g, jobs[i], J);
         }
+        g->stat[KVM_GROUP_STAT_SLOT_SPLIT_NS] += lap_ns(tp);
         int rc = J.split_rc;
         std::string msg;
         try {
@@ -524,68 +605,57 @@ void slot_loop(kvm_group *g, run_state &rs, const kvm_job *jobs, int64_t n_jobs,
             rc = KVM_ERR_NO_MEMORY;
         }
         if (rc) (void)kvm_poison_packed_device(s.ctx, s.d_packed, s.stream);  // the failure mark every rank will see
-        if (kvm_record_event_device(s.ctx, s.ready, s.stream) != KVM_OK && rc == KVM_OK) {
-            rc = KVM_ERR_DEVICE;
-            try {
-                msg = kvm_last_error(s.ctx);
-            } catch (...) {
+        g->stat[KVM_GROUP_STAT_SLOT_ENQUEUE_NS] += lap_ns(tp);
+        bool issuer;
+        {
+            std::unique_lock<std::mutex> lk(rs.mu);
+            J.rc[(size_t)d] = rc;
+            J.msg[(size_t)d].swap(msg);
+            issuer = ++J.produced == nl;
+            if (issuer) {
+                rs.cv_turn.wait(lk, [&] { return rs.stop || rs.next_issue == i; });
+                if (rs.stop) return;
             }
+        }
+        if (!issuer) continue;
+        g->stat[KVM_GROUP_STAT_SLOT_TURN_NS] += lap_ns(tp);
+        std::string imsg;
+        int irc;
+        try {
+            irc = issue_exchange(g, J, i, imsg);
+        } catch (...) {
+            irc = KVM_ERR_NO_MEMORY;
         }
         {
             std::lock_guard<std::mutex> lk(rs.mu);
-            J.rc[(size_t)d] = rc;
-            J.msg[(size_t)d].swap(msg);
-            J.produced++;
+            J.issue_rc = irc;
+            J.issue_msg.swap(imsg);
+            J.issued = true;
+            rs.next_issue = i + 1;
         }
-        rs.cv_produced.notify_all();
+        rs.cv_turn.notify_all();
+        rs.cv_issued.notify_all();
     }
 }
 
 struct exchange {
     kvm_group *g;
     run_state &rs;
-    const kvm_job *jobs;
+    int64_t n_jobs;
     kvm_result **results;
-    int32_t *status;
     int nl;
     size_t bd;  // doubles per rank block
 
-    // query i's all-gather and host copy, enqueued on the exchange streams behind the slots' kernels; nothing waits here
-    int issue(int64_t i) {
-        job_state &J = rs.js[(size_t)i];
-        {
-            std::unique_lock<std::mutex> lk(rs.mu);
-            rs.cv_produced.wait(lk, [&] { return J.produced == nl; });
-        }
-        const size_t t = (size_t)(i % g->in_flight);
-        std::vector<int> devices((size_t)nl);
-        std::vector<void *> comms((size_t)nl), recv((size_t)nl), streams((size_t)nl);
-        std::vector<const void *> send((size_t)nl);
-        for (int d = 0; d < nl; d++) {
-            gdev_t &dv = g->devs[(size_t)d];
-            gslot_t &s = dv.slots[t];
-            GCHK(g, kvm_sd_stream_wait_event(dv.device, dv.xstream, s.ready));
-            // (a part that failed has marked its block on its own stream; once more here, in case THAT is what failed)
-            if (J.rc[(size_t)d]) (void)kvm_poison_packed_device(s.ctx, s.d_packed, dv.xstream);
-            devices[(size_t)d] = dv.device;
-            comms[(size_t)d] = dv.comm;
-            send[(size_t)d] = s.d_packed;
-            recv[(size_t)d] = s.d_gathered;
-            streams[(size_t)d] = dv.xstream;
-        }
-        gdev_t &d0 = g->devs[0];
-        if (g->use_rccl) {
-            GCHK(g, kvm_sd_all_gather(nl, devices.data(), comms.data(), send.data(), recv.data(), bd, streams.data()));
-            GCHK(g, kvm_sd_copy_d2h_async(d0.device, g->h_block[t], d0.slots[t].d_gathered, bd * 8 * (size_t)g->world, d0.xstream));
-        } else {
-            GCHK(g, kvm_sd_copy_d2h_async(d0.device, g->h_block[t], d0.slots[t].d_packed, bd * 8, d0.xstream));
-        }
-        GCHK(g, kvm_sd_event_record(d0.device, g->issued[t], d0.xstream));
-        return KVM_OK;
+    // every gather below H = min(i + F, n_jobs) is on the streams (see the protocol note above); false: the stream was stopped
+    void wait_horizon(int64_t i) {
+        const int64_t H = std::min<int64_t>(i + g->in_flight, n_jobs);
+        std::unique_lock<std::mutex> lk(rs.mu);
+        rs.cv_issued.wait(lk, [&] { return rs.next_issue >= H; });
     }
 
     // more answers on some rank than the fixed-size block holds (rare): a second, exact-size exchange of the slots' full lists
     int exchange_exact(int64_t i, int64_t mx, std::vector<double> &host) {
+        wait_horizon(i);
         const size_t t = (size_t)(i % g->in_flight);
         const size_t big = 2 * ((size_t)mx + 1);
         std::vector<void *> d_big((size_t)nl, nullptr), d_all((size_t)nl, nullptr);
@@ -603,22 +673,24 @@ struct exchange {
                 (void)gfail_sd(g, rc);
                 break;
             }
-            // (on the exchange stream: ordered behind the slot's kernels by the `ready` wait issue() enqueued there)
-            rc = kvm_pack_answers_device(s.ctx, s.d_off, s.d_dist, s.d_count, mx, (double *)d_big[(size_t)d], dv.xstream);
+            // (on the slot's stream, behind its kernels and the first exchange)
+            rc = kvm_pack_answers_device(s.ctx, s.d_off, s.d_dist, s.d_count, mx, (double *)d_big[(size_t)d], s.stream);
             if (rc) (void)gfail(g, rc, kvm_last_error(s.ctx));
             devices[(size_t)d] = dv.device;
             comms[(size_t)d] = dv.comm;
             send[(size_t)d] = d_big[(size_t)d];
-            streams[(size_t)d] = dv.xstream;
+            streams[(size_t)d] = s.stream;
         }
         gdev_t &d0 = g->devs[0];
         const size_t total = big * (size_t)g->world;
-        if (!rc && (rc = kvm_sd_host_alloc((void **)&h, total * 8))) (void)gfail_sd(g, rc);
-        if (!rc && g->use_rccl && (rc = kvm_sd_all_gather(nl, devices.data(), comms.data(), send.data(), d_all.data(), big, streams.data())))
-            (void)gfail_sd(g, rc);
-        if (!rc && (rc = kvm_sd_copy_d2h_async(d0.device, h, g->use_rccl ? d_all[0] : d_big[0], total * 8, d0.xstream))) (void)gfail_sd(g, rc);
+        if (!rc && (rc = kvm_sd_host_alloc(d0.device, (void **)&h, total * 8))) (void)gfail_sd(g, rc);
+        if (!rc && g->use_rccl) {
+            // (the turnstile is at H and stays there until this job is handed back: no gather is issued beside this collective)
+            if ((rc = kvm_sd_all_gather(nl, devices.data(), comms.data(), send.data(), d_all.data(), big, streams.data()))) (void)gfail_sd(g, rc);
+        }
+        if (!rc && (rc = kvm_sd_copy_d2h_async(d0.device, h, g->use_rccl ? d_all[0] : d_big[0], total * 8, d0.slots[t].stream))) (void)gfail_sd(g, rc);
         for (int d = 0; d < nl; d++) {  // (also on a failure: the buffers below are freed next)
-            const int rs_ = kvm_sd_stream_synchronize(g->devs[(size_t)d].device, g->devs[(size_t)d].xstream);
+            const int rs_ = kvm_sd_stream_synchronize(g->devs[(size_t)d].device, g->devs[(size_t)d].slots[t].stream);
             if (rs_ && !rc) rc = gfail_sd(g, rs_);
         }
         if (!rc) {
@@ -636,11 +708,26 @@ struct exchange {
         return rc;
     }
 
-    // wait for query i's block, merge it into results[i], hand the slots back.  Returns the job's status.
-    int finish(int64_t i) {
+    // wait for job i's exchange and its block, merge it into results[i].  Returns the job's status; *exchange_broken: the
+    // exchange itself failed on this rank (nothing sensible is left to do), as opposed to a shard that failed somewhere.
+    int finish(int64_t i, bool *exchange_broken) {
         job_state &J = rs.js[(size_t)i];
         const size_t t = (size_t)(i % g->in_flight);
-        GCHK(g, kvm_sd_event_synchronize(g->issued[t]));
+        auto tp = std::chrono::steady_clock::now();
+        {
+            std::unique_lock<std::mutex> lk(rs.mu);
+            rs.cv_issued.wait(lk, [&] { return J.issued; });
+        }
+        g->stat[KVM_GROUP_STAT_WAIT_ISSUED_NS] += lap_ns(tp);
+        if (J.issue_rc) {
+            *exchange_broken = true;
+            return gfail(g, J.issue_rc, J.issue_msg);
+        }
+        if (int rc = kvm_sd_event_synchronize(g->issued[t])) {
+            *exchange_broken = true;
+            return gfail_sd(g, rc);
+        }
+        g->stat[KVM_GROUP_STAT_WAIT_BLOCK_NS] += lap_ns(tp);
         const double *h = g->h_block[t];
         const int world = g->world;
         int64_t mx = 0, total = 0;
@@ -661,7 +748,10 @@ struct exchange {
         std::vector<double> exact;
         size_t stride = bd;
         if (mx > g->pack_cap) {
-            if (int rc = exchange_exact(i, mx, exact)) return rc;
+            if (int rc = exchange_exact(i, mx, exact)) {
+                *exchange_broken = true;
+                return rc;
+            }
             h = exact.data();
             stride = 2 * ((size_t)mx + 1);
         }
@@ -677,6 +767,7 @@ struct exchange {
         kvm_result *r = kvm_result_from_pairs(off.data(), dist.data(), (int64_t)off.size(), J.cnt_candidate, ms);
         if (!r) return gfail(g, KVM_ERR_NO_MEMORY, "out of host memory (result)");
         results[i] = r;
+        g->stat[KVM_GROUP_STAT_MERGE_NS] += lap_ns(tp);
         return KVM_OK;
     }
 };
@@ -691,70 +782,52 @@ int run_sharded(kvm_group *g, const kvm_job *jobs, int64_t n_jobs, kvm_result **
     if (!g->loaded) return gfail(g, KVM_ERR_NO_SERIES, "no series loaded (kvm_group_load_series_*)");
     const int nl = (int)g->devs.size(), F = g->in_flight;
     const int used = (int)std::min<int64_t>(F, n_jobs);
-    run_state rs((size_t)n_jobs);
+    for (auto &c : g->stat) c = 0;
+    g->stat[KVM_GROUP_STAT_JOBS] = n_jobs;
+    run_state rs((size_t)n_jobs, (size_t)F);
     for (job_state &J : rs.js) {
         J.rc.assign((size_t)nl, KVM_OK);
         J.msg.resize((size_t)nl);
     }
-    exchange ex{g, rs, jobs, results, status, nl, block_doubles(g)};
+    exchange ex{g, rs, n_jobs, results, nl, block_doubles(g)};
     int first_rc = KVM_OK;
     {
         auto get = [&](int32_t q) { return g->devs[(size_t)(q / F)].slots[(size_t)(q % F)].ctx; };
         kvm_host::in_flight_mark<decltype(get)> mark(get, nl * F, used);
         kvm_host::thread_group tg;  // (waits for every loop on every way out, before rs and the job arrays go away)
         // On EVERY way out of this block -- the stream's end, a failing job, an exception (a worker that could not be started,
-        // std::bad_alloc in the exchange) -- the loops are told to stop before ~thread_group waits for them: a loop leaves at its
-        // next wait; a job it is in the middle of is simply never exchanged.
+        // std::bad_alloc in the merge) -- the loops are told to stop before ~thread_group waits for them.
         struct stopper {
             run_state &rs;
-            ~stopper() {
-                {
-                    std::lock_guard<std::mutex> lk(rs.mu);
-                    rs.stop = true;
-                }
-                rs.cv_consumed.notify_all();
-            }
+            ~stopper() { rs.end(); }
         } stop_on_exit{rs};
         for (int d = 0; d < nl; d++)
             for (int t = 0; t < used; t++) tg.start([g, &rs, jobs, n_jobs, d, t] { slot_loop(g, rs, jobs, n_jobs, d, t); });
-        // The exchange of job i + 1 is enqueued BEFORE the block of job i is waited for (one job of lag, when there are at
-        // least two slots): the host's wait, merge and sort of one query overlap the all-gather of the next.  The order of
-        // the collectives -- gather i + 1, then the rare exact-size exchange of job i -- depends on the counts alone, which
-        // every rank sees alike.
-        const int64_t lag = used > 1 ? 1 : 0;
-        for (int64_t q = 0; q < n_jobs + lag && first_rc == KVM_OK; q++) {
-            if (q < n_jobs) {
-                if (int rc = ex.issue(q)) {   // the exchange itself failed on this rank: nothing sensible is left to do
-                    first_rc = rc;
-                    if (status) status[q] = rc;
-                    break;
-                }
+        for (int64_t i = 0; i < n_jobs; i++) {
+            bool broken = false;
+            const int rc = ex.finish(i, &broken);
+            if (status) status[i] = rc;
+            if (rc) {
+                first_rc = rc;
+                // a shard failed (here or on another rank): every rank sees it at this job; each still issues the gathers its
+                // peers are going to issue (see the protocol note), then the stream ends
+                if (!broken) ex.wait_horizon(i);
+                break;
             }
-            if (q - lag >= 0) {
-                const int64_t i = q - lag;
-                const int rc = ex.finish(i);
-                if (status) status[i] = rc;
-                if (rc) {
-                    first_rc = rc;
-                    break;
-                }
-                {
-                    std::lock_guard<std::mutex> lk(rs.mu);
-                    rs.js[(size_t)i].consumed = true;
-                    rs.js[(size_t)i].L.clear();
-                    rs.js[(size_t)i].R.clear();
-                }
-                rs.cv_consumed.notify_all();
+            {
+                std::lock_guard<std::mutex> lk(rs.mu);
+                rs.js[(size_t)i].consumed = true;
+                rs.js[(size_t)i].L.clear();
+                rs.js[(size_t)i].R.clear();
             }
+            rs.cv_consumed[(size_t)(i % F)].notify_all();
         }
     }
-    // slots that ran ahead of an early end: their kernels still read the caller's job arrays, and an all-gather already
-    // issued for the job behind a failing one must have completed before the buffers are reused
+    // an early end: the kernels of the jobs that ran ahead still read the contexts' scratch, and the gathers already issued
+    // (every rank issued the same ones) must have completed before the buffers are used again
     if (first_rc != KVM_OK)
-        for (gdev_t &d : g->devs) {
+        for (gdev_t &d : g->devs)
             for (int t = 0; t < used; t++) (void)kvm_sd_stream_synchronize(d.device, d.slots[(size_t)t].stream);
-            (void)kvm_sd_stream_synchronize(d.device, d.xstream);
-        }
     return first_rc;
 }
 }  // namespace

@@ -13,6 +13,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <thread>
 
 #include "../../include/kvmatch.h"
 #include "kvm_sharded_dev.h"
@@ -33,24 +34,9 @@ static int fail_hip(const char *what, hipError_t e) {
         if (e_ != hipSuccess) return fail_hip(#call, e_); \
     } while (0)
 
-int kvm_sd_stream_create(int device, void **stream) {
-    SDCHK(hipSetDevice(device));
-    hipStream_t s = nullptr;
-    SDCHK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
-    *stream = s;
-    return KVM_OK;
-}
-void kvm_sd_stream_destroy(int device, void *stream) {
-    if (stream && hipSetDevice(device) == hipSuccess) (void)hipStreamDestroy((hipStream_t)stream);
-}
 int kvm_sd_stream_synchronize(int device, void *stream) {
     SDCHK(hipSetDevice(device));
     SDCHK(hipStreamSynchronize((hipStream_t)stream));
-    return KVM_OK;
-}
-int kvm_sd_stream_wait_event(int device, void *stream, void *event) {
-    SDCHK(hipSetDevice(device));
-    SDCHK(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)event, 0));
     return KVM_OK;
 }
 int kvm_sd_event_create(int device, void **event) {
@@ -69,6 +55,15 @@ int kvm_sd_event_record(int device, void *event, void *stream) {
     return KVM_OK;
 }
 int kvm_sd_event_synchronize(void *event) {
+    // Poll first: hipEventSynchronize parks the thread on the event's signal, and being woken costs 50 - 60 us -- more than a
+    // whole early-abandoning query (profiles/r06_group_stream_probe.log: 72 us per query with the blocking wait alone).  In a
+    // stream that keeps the GPU busy the event has usually completed before anyone asks.
+    for (int spin = 0; spin < 4000; spin++) {
+        const hipError_t e = hipEventQuery((hipEvent_t)event);
+        if (e == hipSuccess) return KVM_OK;
+        if (e != hipErrorNotReady) return fail_hip("hipEventQuery", e);
+        if (spin >= 64) std::this_thread::yield();
+    }
     SDCHK(hipEventSynchronize((hipEvent_t)event));
     return KVM_OK;
 }
@@ -80,7 +75,8 @@ int kvm_sd_malloc(int device, void **p, size_t bytes) {
 void kvm_sd_free(int device, void *p) {
     if (p && hipSetDevice(device) == hipSuccess) (void)hipFree(p);
 }
-int kvm_sd_host_alloc(void **p, size_t bytes) {
+int kvm_sd_host_alloc(int device, void **p, size_t bytes) {
+    SDCHK(hipSetDevice(device));
     SDCHK(hipHostMalloc(p, bytes ? bytes : 8, hipHostMallocDefault));
     return KVM_OK;
 }
@@ -90,6 +86,20 @@ void kvm_sd_host_free(void *p) {
 int kvm_sd_copy_d2h_async(int device, void *dst_host, const void *src_device, size_t bytes, void *stream) {
     SDCHK(hipSetDevice(device));
     SDCHK(hipMemcpyAsync(dst_host, src_device, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    return KVM_OK;
+}
+
+__global__ void __launch_bounds__(256) kvm_sd_readback_kernel(double *__restrict__ dst, const double *__restrict__ src, size_t block_doubles) {
+    const size_t base = (size_t)blockIdx.x * block_doubles;
+    const double c = src[base];
+    const size_t cap = block_doubles / 2 - 1;
+    const size_t n = c > 0 ? (c < (double)cap ? (size_t)c : cap) : 0;
+    for (size_t i = threadIdx.x; i < 2 * (n + 1); i += blockDim.x) dst[base + i] = src[base + i];
+}
+int kvm_sd_readback_blocks(int device, double *dst_host, const double *src_device, int blocks, size_t block_doubles, void *stream) {
+    SDCHK(hipSetDevice(device));
+    hipLaunchKernelGGL(kvm_sd_readback_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dst_host, src_device, block_doubles);
+    SDCHK(hipGetLastError());
     return KVM_OK;
 }
 

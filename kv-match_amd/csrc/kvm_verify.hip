@@ -849,12 +849,10 @@ extern "C" int kvm_verify_device(kvm_ctx *ctx, int32_t variant, const double *qu
         enq.again();
         if (n_ambig > 0 && (rc = dtw_resolve_ambiguous(ctx, dtw_qd, dtw_ax, (int64_t)n_ambig, out, s))) return rc;
     }
-    if (pl.n_tiles + pl.n_tiles_b + pl.n_tiles_c == 0) {
-        HIPCHK(ctx, hipMemsetAsync(d_out_count, 0, sizeof(int64_t), s));
-    } else {
-        HIPCHK(ctx, hipMemcpyAsync(d_out_count, (unsigned long long *)ctx->b_counters.p + KVM_CNT_ANSWERS,
-                                   sizeof(int64_t), hipMemcpyDeviceToDevice, s));
-    }
+    // (the answer count, by a one-thread kernel: a copy command costs the enqueueing thread ~10 us under a lock all streams share)
+    HIPCHK(ctx, kvm_launch_copy_u64((unsigned long long *)d_out_count,
+                                    pl.n_tiles + pl.n_tiles_b + pl.n_tiles_c == 0 ? nullptr
+                                                                                  : (unsigned long long *)ctx->b_counters.p + KVM_CNT_ANSWERS, s));
     return KVM_OK;   // (~done_guard records ev_done behind everything enqueued above)
     });
 }

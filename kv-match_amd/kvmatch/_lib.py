@@ -49,7 +49,7 @@ SYMBOLS = [
     "kvm_open_devices", "kvm_group_unique_id", "kvm_open_rank", "kvm_group_close", "kvm_group_last_error", "kvm_group_world",
     "kvm_group_local_devices", "kvm_group_rccl_ranks", "kvm_group_ctx", "kvm_group_configure", "kvm_group_load_series_f64",
     "kvm_group_load_series_be64", "kvm_group_load_series_file", "kvm_group_set_option", "kvm_verify_sharded",
-    "kvm_run_sharded_jobs", "kvm_split_intervals", "kvm_abi_version",
+    "kvm_run_sharded_jobs", "kvm_split_intervals", "kvm_abi_version", "kvm_group_stat",
 ]
 
 
@@ -183,6 +183,7 @@ def load():
         "kvm_run_sharded_jobs": (C.c_int, [vp, C.POINTER(KvmJob), i64, C.POINTER(vp), C.POINTER(i32)]),
         "kvm_split_intervals": (i64, [vp, vp, i64, i32, i32, i32, vp, vp]),
         "kvm_abi_version": (i32, []),
+        "kvm_group_stat": (i64, [vp, i32]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)

@@ -509,6 +509,13 @@ class DeviceGroup:
     def configure(self, what, value):
         _lib.check(self._lib.kvm_group_configure(self._g, int(what), int(value)), group=self._g)
 
+    def stats(self):
+        """kvm_group_stat of the last stream: where its threads spent their time (microseconds per job)."""
+        names = ("jobs", "wait_issued", "prepare", "all_gather", "copy", "wait_block", "merge", "slots_wait", "slots_split", "slots_enqueue", "slots_turn")
+        v = [int(self._lib.kvm_group_stat(self._g, i)) for i in range(len(names))]
+        jobs = max(1, v[0])
+        return {"jobs": v[0], **{nm + "_us_per_job": x / jobs / 1e3 for nm, x in zip(names[1:], v[1:])}}
+
     def last_kernel_ns(self, local_device=0, slot=0):
         return int(self._lib.kvm_last_kernel_ns(self._lib.kvm_group_ctx(self._g, local_device, slot)))
 

@@ -7,6 +7,7 @@
 //   * the verification path (kvm_verify_device, kvm_pack_answers_device, ...) as a rule that makes a candidate offset an
 //     answer from its value alone, so that the merged result of any sharding can be compared with the unsharded list.
 // Prints one line per check; exit code = failed checks.
+#include <algorithm>
 #include <atomic>
 #include <condition_variable>
 #include <cstdio>
@@ -77,22 +78,11 @@ struct fevent {
     std::condition_variable cv;
     uint64_t issued = 0, completed = 0;
 };
-std::atomic<int64_t> g_live_allocs{0}, g_live_streams{0}, g_live_events{0}, g_live_comms{0};
+std::atomic<int64_t> g_live_allocs{0}, g_live_events{0}, g_live_comms{0};
 thread_local std::string t_sd_err;
 }  // namespace
 
 const char *kvm_sd_last_error() { return t_sd_err.c_str(); }
-int kvm_sd_stream_create(int, void **s) {
-    *s = new fstream();
-    g_live_streams++;
-    return KVM_OK;
-}
-void kvm_sd_stream_destroy(int, void *s) {
-    if (s) {
-        delete (fstream *)s;
-        g_live_streams--;
-    }
-}
 int kvm_sd_stream_synchronize(int, void *s) {
     ((fstream *)s)->sync();
     return KVM_OK;
@@ -124,19 +114,6 @@ int kvm_sd_event_record(int, void *ev, void *s) {
     });
     return KVM_OK;
 }
-int kvm_sd_stream_wait_event(int, void *s, void *ev) {
-    fevent *e = (fevent *)ev;
-    uint64_t gen;
-    {
-        std::lock_guard<std::mutex> lk(e->mu);
-        gen = e->issued;
-    }
-    ((fstream *)s)->push([e, gen] {
-        std::unique_lock<std::mutex> lk(e->mu);
-        e->cv.wait(lk, [&] { return e->completed >= gen; });
-    });
-    return KVM_OK;
-}
 int kvm_sd_event_synchronize(void *ev) {
     fevent *e = (fevent *)ev;
     std::unique_lock<std::mutex> lk(e->mu);
@@ -161,10 +138,22 @@ void kvm_sd_free(int, void *p) {
         g_live_allocs--;
     }
 }
-int kvm_sd_host_alloc(void **p, size_t bytes) { return kvm_sd_malloc(0, p, bytes); }
+int kvm_sd_host_alloc(int, void **p, size_t bytes) { return kvm_sd_malloc(0, p, bytes); }
 void kvm_sd_host_free(void *p) { kvm_sd_free(0, p); }
 int kvm_sd_copy_d2h_async(int, void *dst, const void *src, size_t bytes, void *s) {
     ((fstream *)s)->push([dst, src, bytes] { std::memcpy(dst, src, bytes); });
+    return KVM_OK;
+}
+int kvm_sd_readback_blocks(int, double *dst, const double *src, int blocks, size_t bd, void *s) {
+    ((fstream *)s)->push([=] {
+        for (int b = 0; b < blocks; b++) {
+            const double c = src[(size_t)b * bd];
+            const size_t cap = bd / 2 - 1, n = c > 0 ? std::min((size_t)c, cap) : 0;
+            std::memcpy(dst + (size_t)b * bd, src + (size_t)b * bd, 2 * (n + 1) * sizeof(double));
+            // (what lies behind the pairs present is NOT copied: the merge must not read it)
+            for (size_t i = 2 * (n + 1); i < bd; i++) dst[(size_t)b * bd + i] = -12345.0;
+        }
+    });
     return KVM_OK;
 }
 
@@ -260,6 +249,7 @@ int kvm_sd_all_gather(int n, const int *, void *const *comms, const void *const 
 
 // ---- the verification path -------------------------------------------------------------------------------------------
 struct kvm_ctx {
+    fstream stream;   // the context's own stream: what the group layer runs the slot on
     int device = 0;
     std::string err;
     std::atomic<int> inside{0};
@@ -381,7 +371,7 @@ int kvm_poison_packed_device(kvm_ctx *, double *d_packed, void *stream) {
     });
     return KVM_OK;
 }
-int kvm_record_event_device(kvm_ctx *, void *event, void *stream) { return kvm_sd_event_record(0, event, stream); }
+void *kvm_ctx_stream_handle(kvm_ctx *c) { return c ? &c->stream : nullptr; }
 void kvm_set_run_in_flight(kvm_ctx *c, int n) noexcept {
     if (c && n > c->in_flight_max) c->in_flight_max = n;
 }
@@ -773,8 +763,8 @@ int main() {
         kvm_group_close(g);
         CHECK(wrong == 0, "failing device allocations at open and in a stream: a status, nothing leaked, the group stays usable (%d)", wrong);
     }
-    CHECK(g_live_allocs == 0 && g_live_streams == 0 && g_live_events == 0 && g_live_comms == 0 && g_live_ctx == 0 && g_overlap == 0,
-          "everything given back: %lld allocations, %lld streams, %lld events, %lld communicators, %lld contexts; %d overlapping entries",
-          (long long)g_live_allocs, (long long)g_live_streams, (long long)g_live_events, (long long)g_live_comms, (long long)g_live_ctx, (int)g_overlap);
+    CHECK(g_live_allocs == 0 && g_live_events == 0 && g_live_comms == 0 && g_live_ctx == 0 && g_overlap == 0,
+          "everything given back: %lld allocations, %lld events, %lld communicators, %lld contexts; %d overlapping entries",
+          (long long)g_live_allocs, (long long)g_live_events, (long long)g_live_comms, (long long)g_live_ctx, (int)g_overlap);
     return failed;
 }
