@@ -45,6 +45,28 @@ public final class Phase2Gpu implements AutoCloseable {
      *  option 9 (KVM_OPT_IN_FLIGHT, default 1) = how many contexts the server's threads keep busy on this GPU at once: a hint to
      *  the ED kernel's launcher (throughput instead of the shortest single launch), the answers are the same. */
     public static native void setOption(long ctx, int option, long value);
+    // ---- one engine over ALL the GPUs of a node (kvm_group, include/kvmatch.h): the series on every device, the candidate list
+    // of a call dealt out to them, ONE RCCL all-gather of the answers issued by the library -- one call per query, the result
+    // the single-GPU call returns.  `devices`: HIP ordinals of this process; inFlight: queries a server's threads keep going.
+    public static native long groupOpen(int[] devices, int inFlight) throws IOException;
+    /** One JVM per GPU instead: rank `rank` of `world`; `id` = groupUniqueId() of ONE rank, carried to the others by the host. */
+    public static native long groupOpenRank(int device, int rank, int world, byte[] id, int inFlight) throws IOException;
+    public static native byte[] groupUniqueId() throws IOException;
+    public static native void groupLoadSeriesFile(long group, String path, long n) throws IOException;
+    /** variant 0 rsmEd, 1 cnsmEd, 2 rsmDtw, 3 cnsmDtw; rho / alpha / beta ignored where the variant has none. */
+    public static native Result groupVerify(long group, int variant, double[] q, int[] left, int[] right, int shift, double eps, int rho, double alpha, double beta);
+    public static native void groupSetOption(long group, int option, long value);
+    public static native void groupClose(long group);
+    /** The engine-side handle: `new Phase2Gpu.Group(new int[] {0,1,2,3,4,5,6,7}, dataFile, n)` where an engine holds a Phase2Gpu. */
+    public static final class Group implements AutoCloseable {
+        private long g;
+        public Group(int[] devices, String dataFile, int n) throws IOException { g = groupOpen(devices, 1); groupLoadSeriesFile(g, dataFile, n); }
+        public Result rsmEd  (double[] q, int[] left, int[] right, int shift, double eps) { return groupVerify(g, 0, q, left, right, shift, eps, 0, 0, 0); }
+        public Result cnsmEd (double[] q, int[] left, int[] right, int shift, double eps, double alpha, double beta) { return groupVerify(g, 1, q, left, right, shift, eps, 0, alpha, beta); }
+        public Result rsmDtw (double[] q, int[] left, int[] right, int shift, double eps, int rho) { return groupVerify(g, 2, q, left, right, shift, eps, rho, 0, 0); }
+        public Result cnsmDtw(double[] q, int[] left, int[] right, int shift, double eps, int rho, double alpha, double beta) { return groupVerify(g, 3, q, left, right, shift, eps, rho, alpha, beta); }
+        @Override public void close() { if (g != 0) { groupClose(g); g = 0; } }
+    }
     private static native long open(int device) throws IOException;
     private static native void loadSeriesFile(long ctx, String path, long n) throws IOException;
     private static native void close(long ctx);

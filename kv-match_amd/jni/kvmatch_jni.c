@@ -288,6 +288,81 @@ JNIEXPORT void JNICALL Java_cn_edu_fudan_dsm_kvmatch_gpu_Phase2Gpu_setOption(JNI
     int rc = kvm_set_option(ctx, option, value);
     if (rc) throw_for(env, ctx, rc);
 }
+
+/* ---- one engine over the GPUs of a node (kvm_group): one call per query ---------------------------------------------- */
+static void throw_for_group(JNIEnv *env, kvm_group *g, int rc) {
+    const char *msg = kvm_group_last_error(g);
+    /* as throw_for; KVM_ERR_SHARD_FAILED (another rank failed on its shard) is an IOException like every device failure */
+    jclass cls = (*env)->FindClass(env, rc == KVM_ERR_ILLEGAL_ARGUMENT      ? "java/lang/IllegalArgumentException"
+                                        : rc == KVM_ERR_INDEX_OUT_OF_BOUNDS ? "java/lang/ArrayIndexOutOfBoundsException"
+                                        : rc == KVM_ERR_NO_MEMORY           ? "java/lang/OutOfMemoryError"
+                                                                            : "java/io/IOException");
+    (*env)->ThrowNew(env, cls, msg ? msg : "kvmatch group error");
+}
+JNIEXPORT jlong JNICALL Java_cn_edu_fudan_dsm_kvmatch_gpu_Phase2Gpu_groupOpen(JNIEnv *env, jclass c, jintArray devices, jint inFlight) {
+    (void)c;
+    if (!devices) { throw_new(env, "java/lang/IllegalArgumentException", "groupOpen: null device list"); return 0; }
+    const jsize n = (*env)->GetArrayLength(env, devices);
+    jint devs[64];
+    if (n < 1 || n > 64) { throw_new(env, "java/lang/IllegalArgumentException", "groupOpen: 1 .. 64 devices"); return 0; }
+    (*env)->GetIntArrayRegion(env, devices, 0, n, devs);
+    kvm_group *g = 0;
+    int rc = kvm_open_devices((const int32_t *)devs, n, inFlight, 0, &g);
+    if (rc) { throw_for_group(env, 0, rc); return 0; }
+    return (jlong)(intptr_t)g;
+}
+JNIEXPORT jbyteArray JNICALL Java_cn_edu_fudan_dsm_kvmatch_gpu_Phase2Gpu_groupUniqueId(JNIEnv *env, jclass c) {
+    (void)c;
+    jbyte id[KVM_GROUP_ID_BYTES];
+    int rc = kvm_group_unique_id(id, KVM_GROUP_ID_BYTES);
+    if (rc) { throw_for_group(env, 0, rc); return 0; }
+    jbyteArray out = (*env)->NewByteArray(env, KVM_GROUP_ID_BYTES);
+    if (out) (*env)->SetByteArrayRegion(env, out, 0, KVM_GROUP_ID_BYTES, id);
+    return out;
+}
+JNIEXPORT jlong JNICALL Java_cn_edu_fudan_dsm_kvmatch_gpu_Phase2Gpu_groupOpenRank(JNIEnv *env, jclass c, jint device, jint rank, jint world,
+        jbyteArray id, jint inFlight) {
+    (void)c;
+    jbyte buf[KVM_GROUP_ID_BYTES];
+    const jsize n = id ? (*env)->GetArrayLength(env, id) : 0;
+    if (n == KVM_GROUP_ID_BYTES) (*env)->GetByteArrayRegion(env, id, 0, n, buf);
+    kvm_group *g = 0;
+    int rc = kvm_open_rank(device, rank, world, n == KVM_GROUP_ID_BYTES ? buf : 0, n, inFlight, 0, &g);
+    if (rc) { throw_for_group(env, 0, rc); return 0; }
+    return (jlong)(intptr_t)g;
+}
+JNIEXPORT void JNICALL Java_cn_edu_fudan_dsm_kvmatch_gpu_Phase2Gpu_groupLoadSeriesFile(JNIEnv *env, jclass c, jlong h, jstring path, jlong n) {
+    (void)c;
+    kvm_group *g = (kvm_group *)(intptr_t)h;
+    const char *p = (*env)->GetStringUTFChars(env, path, 0);
+    int rc = kvm_group_load_series_file(g, p, n);
+    (*env)->ReleaseStringUTFChars(env, path, p);
+    if (rc) throw_for_group(env, g, rc);
+}
+/* the phase-2 pass of one query on every GPU of the group: ONE call from the engine (K/QueryEngine.java:338-363 and siblings) */
+JNIEXPORT jobject JNICALL Java_cn_edu_fudan_dsm_kvmatch_gpu_Phase2Gpu_groupVerify(JNIEnv *env, jclass c, jlong h, jint variant,
+        jdoubleArray q, jintArray left, jintArray right, jint shift, jdouble eps, jint rho, jdouble alpha, jdouble beta) {
+    (void)c;
+    kvm_group *g = (kvm_group *)(intptr_t)h;
+    kvm_jni_in in;
+    if (!in_copy(env, q, left, right, &in)) return 0;
+    kvm_result *res = 0;
+    int rc = kvm_verify_sharded(g, variant, in.q, in.m, (const int32_t *)in.left, (const int32_t *)in.right, in.k, shift, eps, rho, alpha,
+                                beta, &res);
+    in_free(&in);
+    if (rc) { throw_for_group(env, g, rc); return 0; }
+    return make_result(env, 0, KVM_OK, res);
+}
+JNIEXPORT void JNICALL Java_cn_edu_fudan_dsm_kvmatch_gpu_Phase2Gpu_groupSetOption(JNIEnv *env, jclass c, jlong h, jint option, jlong value) {
+    (void)c;
+    kvm_group *g = (kvm_group *)(intptr_t)h;
+    int rc = kvm_group_set_option(g, option, value);
+    if (rc) throw_for_group(env, g, rc);
+}
+JNIEXPORT void JNICALL Java_cn_edu_fudan_dsm_kvmatch_gpu_Phase2Gpu_groupClose(JNIEnv *env, jclass c, jlong h) {
+    (void)env; (void)c;
+    kvm_group_close((kvm_group *)(intptr_t)h);
+}
 #else
 /* no <jni.h> in this toolchain: nothing to build */
 typedef int kvm_jni_not_built;

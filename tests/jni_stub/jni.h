@@ -48,6 +48,7 @@ struct JNINativeInterface_ {
     jbyteArray (JNICALL *NewByteArray)(JNIEnv *env, jsize len);
     void (JNICALL *GetIntArrayRegion)(JNIEnv *env, jintArray array, jsize start, jsize l, jint *buf);
     void (JNICALL *GetDoubleArrayRegion)(JNIEnv *env, jdoubleArray array, jsize start, jsize l, jdouble *buf);
+    void (JNICALL *GetByteArrayRegion)(JNIEnv *env, jbyteArray array, jsize start, jsize l, jbyte *buf);
     void (JNICALL *SetIntArrayRegion)(JNIEnv *env, jintArray array, jsize start, jsize l, const jint *buf);
     void (JNICALL *SetDoubleArrayRegion)(JNIEnv *env, jdoubleArray array, jsize start, jsize l, const jdouble *buf);
     void (JNICALL *SetByteArrayRegion)(JNIEnv *env, jbyteArray array, jsize start, jsize l, const jbyte *buf);
