@@ -513,6 +513,8 @@ def main():
 
     def set_option(opt, val):
         (group or sstream or qstream).set_option(opt, val)
+        if group is not None:
+            ctx.set_option(opt, val)   # (the context of the exclusive kernel-timing pass below is not one of the group's)
 
     def sum_cands(ids_count):
         """candidates verified by `ids_count` consecutive queries of the stream starting at query 0 (whole job: every rank
