@@ -178,15 +178,15 @@ def roofline_block(wl, plans, launches, m, rates=None):
     algo_bytes = evaluated * 8.0 * m  # 8*m algorithmic bytes per candidate
     traffic, tsrc = None, None
     tpath = os.path.join(ROOT, "profiles", "ed_traffic.json")
-    if v == 0 and os.path.exists(tpath):
+    if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
+            if v == 1:
+                tj = tj.get("cnsm_ed") or {}
             # the stored PMC passes belong to ONE build of the pruner: if kvm_ed_dot.hip has changed since, they say nothing
             now_sha = file_sha16(os.path.join(ROOT, "kv-match_amd", "csrc", "kvm_ed_dot.hip"))
-            if tj.get("kvm_ed_dot_sha16") in (None, now_sha):
+            if tj.get("hbm_bytes_per_launch") and tj.get("kvm_ed_dot_sha16") in (None, now_sha):
                 traffic, tsrc = tj.get("hbm_bytes_per_launch"), "profiles/ed_traffic.json: " + tj.get("source", "stored rocprofv3 --pmc pass")
-            else:
-                tsrc = None
         except Exception:
             traffic = None
     # per launch as well: a stream of queries mixes launches that fill the chip with launches of a few hundred tiles whose
@@ -214,9 +214,9 @@ def roofline_block(wl, plans, launches, m, rates=None):
             "hbm_measured_gbs": (traffic * nl / ks / 1e9) if (traffic and ks > 0) else None,
             "hbm_peak_gbs": HBM_PEAK_GBS,
             "fp64_fma_sustained_tflops": rates.get("fp64_fma_tflops") if rates else None,
-            "hbm_achievable_gbs": rates.get("hbm_triad_gbs") if rates else None,
+            "hbm_achievable_gbs": rates.get("hbm_read_stream_gbs") if rates else None,
             "fp64_fma_sustained_source": "measured by this run on this box (kvm_measure_device: a register-only v_fma_f64 loop at 4 "
-                                         "waves/SIMD; an HBM stream triad over 3 x 512 MiB); `peak` stays the vendor figure",
+                                         "waves/SIMD; an HBM read stream, 16 B per lane over 1 GiB); `peak` stays the vendor figure",
             "note": "bound = fp64 vector pipe: 63 of every 64 algorithmic bytes are served from LDS (tile reuse), so the "
                     "algorithmic-byte rate exceeds the HBM peak by construction; hbm_measured_gbs is the real HBM rate"}
 
@@ -429,6 +429,33 @@ def main():
                                                 "note": "same port, interval shards over forked worker processes"}
         except Exception as e:
             out["cpu_baseline"]["all_cores"] = {"error": repr(e)}
+
+    if rank == 0 and world == 1 and a.cpu_baseline and wl == "cnsm_ed":
+        # configs[2]: the oracle's cNSM-ED loop (K/NormQueryEngine.java:432-528) over the queries of the stream, in a child
+        # process: one core on a bounded sample (the first three queries), then every query on all host cores
+        try:
+            ncores = min(os.cpu_count() or 1, 64)
+            fin = os.path.join(tmpdir, "_bench_cpu_cnsm_in.npz")
+            np.savez(fin, qs=np.stack(queries), left=np.concatenate([l for l, r in shards]), right=np.concatenate([r for l, r in shards]),
+                     list_off=np.cumsum([0] + [len(l) for l, r in shards]).astype(np.int64),
+                     q_list=np.array([j % NL for j in range(NQ)], dtype=np.int64), one_core_queries=np.int64(min(3, NQ)),
+                     patch_pos=np.array(patch_pos, dtype=np.int64), patch_val=patch_val)
+            cp = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline.py"), "cnsm_ed_stream", str(n), str(a.epsilon),
+                                 str(ncores), fin, "2.0", "10.0"], capture_output=True, text=True, timeout=600)
+            c = json.loads(cp.stdout.strip().splitlines()[-1])
+            out["cpu_baseline"] = {
+                "value": c["one_core_no_abandon"]["candidates_per_s"], "unit": "candidates/s", "cores": 1, "kind": "port",
+                "cpu_model": cpu_model(), "host_cores": os.cpu_count(), "seconds": c["one_core_no_abandon"]["seconds"],
+                "value_early_abandon": c["one_core_early_abandon"]["candidates_per_s"],
+                "sample": f"the first {c['one_core_queries']} of the stream's {NQ} queries over their lists ({c['one_core_no_abandon']['pass_filter']} of "
+                          f"their candidates pass the (alpha, beta) filter and are evaluated over all m points: early abandon off, the same "
+                          f"work per query as `value`), single thread; C restatement of K/NormQueryEngine.java:432-528 (no JDK on this "
+                          f"box; the port avoids Java boxing, so it flatters the CPU side)",
+                "all_cores": {"cores": c["cores"], "value": c["no_abandon"]["candidates_per_s"],
+                              "value_early_abandon": c["early_abandon"]["candidates_per_s"], "seconds": c["no_abandon"]["seconds"],
+                              "note": f"same port, all {NQ} queries of the stream, whole intervals dealt to forked worker processes"}}
+        except Exception as e:  # noqa: BLE001
+            out["cpu_baseline"] = {"error": repr(e)}
 
     step_no = [0]
     last = {}
@@ -681,11 +708,11 @@ def main():
         **({"group_world1": group_w1} if group_w1 else {}),
         "setup_s": setup_s,
     })
-    # what THIS box sustains (the vendor peaks are quoted): HBM stream triad, fp64 FMA issue, the DP's non-FMA cell mix
+    # what THIS box sustains (the vendor peaks are quoted): HBM read stream, fp64 FMA issue, the DP's non-FMA cell mix
     rates = {}
     if rank == 0:
         try:
-            rates = {"hbm_triad_gbs": ctx.measure_device(0), "fp64_fma_tflops": ctx.measure_device(1),
+            rates = {"hbm_read_stream_gbs": ctx.measure_device(0), "fp64_fma_tflops": ctx.measure_device(1),
                      "fp64_cellmix_tops": ctx.measure_device(2)}
         except Exception as e:  # noqa: BLE001
             rates = {"error": repr(e)}

@@ -402,9 +402,9 @@ int64_t kvm_get_option(const kvm_ctx *ctx, int32_t option);
 int64_t kvm_last_kernel_ns(const kvm_ctx *ctx);
 
 /* What the device under this run sustains, for the roofline lines of a benchmark (vendor peaks are quoted, these are
- * measured): `what` 0 = HBM stream triad over 3 x 512 MiB, GB/s; 1 = fp64 FMA issue rate, register-only, TFLOP/s (FMA = 2);
- * 2 = fp64 issue rate of the banded DP's cell mix (sub, mul, min, min, add; no FMA), Tops/s.  Allocates and frees its own
- * 1.5 GiB (what = 0); waits for the context's stream.  Replaces nothing in the reference. */
+ * measured): `what` 0 = HBM read stream, 16 B per lane over 1 GiB, GB/s (what the ED pruner does to HBM is read windows); 1 = fp64
+ * FMA issue rate, register-only, TFLOP/s (FMA = 2); 2 = fp64 issue rate of the banded DP's cell mix (sub, mul, min, min, add; no
+ * FMA), Tops/s.  Allocates and frees its own 1 GiB (what = 0); waits for the context's stream.  Replaces nothing in the reference. */
 int kvm_measure_device(kvm_ctx *ctx, int32_t what, double *value);
 
 /* ---- device-resident variant (multi-GPU host plumbing: no host copies, caller's stream) ----------- */

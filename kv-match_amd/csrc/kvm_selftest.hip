@@ -1,20 +1,22 @@
 // kvm_selftest.hip -- what THIS device sustains, measured by the caller's own run (kvm_measure_device): the roofline lines
 // of bench.py quote vendor peaks; these three numbers say what the box under the run delivers.
-//   0  HBM stream triad   a[i] = b[i] + s * c[i] over 3 x 512 MiB (beyond the 256 MB Infinity Cache): GB/s, 24 B per element
+//   0  HBM read stream    16 B per lane, 1 GiB swept in order (beyond the 256 MB Infinity Cache): GB/s.  What the ED pruner does
+//                         to HBM is READ windows; a triad (two reads, one write: rounds 4-5) reads 4.6 - 5.4 TB/s on the box
+//                         where this reads 6.4 - 6.5 and the guide's float4 copy 6.3 (profiles/micro/hbm_stream.hip,
+//                         profiles/r06_hbm_stream.log)
 //   1  fp64 FMA issue     register-only v_fma_f64, 8 independent chains per lane, 4 waves per SIMD: TFLOP/s (FMA = 2)
 //   2  fp64 non-FMA issue the banded DP's cell mix (sub, mul, min, min, add), register-only: Tops/s
 #include "kvm_internal.h"
 
-__global__ __launch_bounds__(256) void kvm_triad_kernel(double *__restrict__ a, const double *__restrict__ b,
-                                                        const double *__restrict__ c, double s, int64_t n) {
+__global__ __launch_bounds__(256) void kvm_read_stream_kernel(double *__restrict__ out, const double *__restrict__ b, int64_t n) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x * 2;
+    double2 acc = make_double2(0.0, 0.0);
     for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 2; i + 1 < n; i += stride) {
-        const double2 x = *reinterpret_cast<const double2 *>(b + i), y = *reinterpret_cast<const double2 *>(c + i);
-        double2 r;
-        r.x = __builtin_fma(s, y.x, x.x);
-        r.y = __builtin_fma(s, y.y, x.y);
-        *reinterpret_cast<double2 *>(a + i) = r;
+        const double2 x = *reinterpret_cast<const double2 *>(b + i);
+        acc.x += x.x;
+        acc.y += x.y;
     }
+    if (acc.x + acc.y == 12345.678) out[0] = acc.x;  // (never true: keeps the loads alive)
 }
 
 __global__ __launch_bounds__(256) void kvm_fma_rate_kernel(double *out, double x, double y, int iters) {
@@ -66,17 +68,17 @@ hipError_t kvm_measure_device_rate(int what, int num_cu, hipStream_t s, hipEvent
     double *a = nullptr;
     float ms = 0;
     if (what == 0) {
-        const int64_t n = (int64_t)64 << 20;  // 64 Mi doubles = 512 MiB per array
-        ST_CHK(hipMalloc((void **)&a, (size_t)3 * n * sizeof(double)));
-        ST_CHK(hipMemsetAsync(a, 0, (size_t)3 * n * sizeof(double), s));
+        const int64_t n = (int64_t)128 << 20;  // 128 Mi doubles = 1 GiB
+        ST_CHK(hipMalloc((void **)&a, (size_t)n * sizeof(double) + 64));
+        ST_CHK(hipMemsetAsync(a, 0, (size_t)n * sizeof(double) + 64, s));
         const int reps = 8;
-        hipLaunchKernelGGL(kvm_triad_kernel, dim3(num_cu * 16), dim3(256), 0, s, a, a + n, a + 2 * n, 1.5, n);
+        hipLaunchKernelGGL(kvm_read_stream_kernel, dim3(num_cu * 8), dim3(256), 0, s, a + n, a, n);
         ST_CHK(hipEventRecord(e0, s));
-        for (int r = 0; r < reps; r++) hipLaunchKernelGGL(kvm_triad_kernel, dim3(num_cu * 16), dim3(256), 0, s, a, a + n, a + 2 * n, 1.5, n);
+        for (int r = 0; r < reps; r++) hipLaunchKernelGGL(kvm_read_stream_kernel, dim3(num_cu * 8), dim3(256), 0, s, a + n, a, n);
         ST_CHK(hipEventRecord(e1, s));
         ST_CHK(hipEventSynchronize(e1));
         ST_CHK(hipEventElapsedTime(&ms, e0, e1));
-        *value = (double)reps * 24.0 * (double)n / (ms * 1e-3) / 1e9;
+        *value = (double)reps * 8.0 * (double)n / (ms * 1e-3) / 1e9;
         (void)hipFree(a);
         return hipGetLastError();
     }

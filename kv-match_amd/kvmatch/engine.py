@@ -263,7 +263,7 @@ class Phase2Context:
         return data, info
 
     def measure_device(self, what):
-        """What the device sustains (kvm_measure_device): 0 HBM triad GB/s, 1 fp64 FMA TFLOP/s, 2 fp64 non-FMA cell-mix Tops/s."""
+        """What the device sustains (kvm_measure_device): 0 HBM read stream GB/s, 1 fp64 FMA TFLOP/s, 2 fp64 non-FMA cell-mix Tops/s."""
         v = C.c_double()
         _lib.check(self._lib.kvm_measure_device(self._h, int(what), C.byref(v)), self._h)
         return v.value

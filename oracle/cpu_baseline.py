@@ -5,6 +5,11 @@ forked worker processes.  TEST / MEASUREMENT INFRASTRUCTURE ONLY -- lives under 
 
   cpu_baseline.py rsm_ed <n> <eps> <workers> <in.npz>
       times K/QueryEngine.java:338-363 (early abandon off, then on) over `left` / `right` of in.npz; prints one JSON line
+  cpu_baseline.py cnsm_ed_stream <n> <eps> <workers> <in.npz> <alpha> <beta>
+      times K/NormQueryEngine.java:432-528 over the queries of a stream: in.npz holds qs (NQ x m), the NL interval lists
+      concatenated (left / right / list_off) and q_list (the list of each query); one core over the first `one_core_queries`
+      of them, then all of them on `workers` cores (whole intervals dealt to the workers: the running sums restart per
+      interval), early abandon off and on; prints one JSON line
   cpu_baseline.py cnsm_dtw_answers <n> <eps> <workers> <in.npz> <out.npz> <rho> <alpha> <beta>
       the answers of K/NormQueryEngineDtw.java:457-603 for the checker (`parity_vs_oracle` of the cNSM-DTW workload): whole
       intervals dealt round-robin to the workers (running sums restart per interval, so no value depends on the deal; the
@@ -32,6 +37,17 @@ def _work_ed(args):
     return st["windows"], len(off)
 
 
+def _work_cnsm_ed(args):
+    import oracle
+    j, lo, hi, no_abandon = args
+    a, b = _G["list_off"][_G["q_list"][j]], _G["list_off"][_G["q_list"][j] + 1]
+    L, R = _G["L"][a:b][lo:hi], _G["R"][a:b][lo:hi]
+    if len(L) == 0:
+        return 0, 0, 0
+    off, dist, st = oracle.cnsm_ed(_G["series"], _G["qs"][j], L, R, 0, _G["eps"], _G["alpha"], _G["beta"], no_abandon=no_abandon)
+    return int((R.astype(np.int64) - L + 1).sum()), len(off), st["pass_filter"]
+
+
 def _work_dtw(w):
     import oracle
     L, R = _G["L"][w::_G["workers"]], _G["R"][w::_G["workers"]]
@@ -46,7 +62,8 @@ def main():
     from kvmatch import datagen  # host-side generators only (no HIP call is made in this process)
     z = np.load(fin)
     series = datagen.gen_series(n)
-    q, L, R = z["q"], z["left"], z["right"]
+    q = z["q"] if "q" in z else z["qs"][0]
+    L, R = z["left"], z["right"]
     m = len(q)
     # bench.py plants copies of its queries into the series it stages; the slices this leg reads must be the staged ones:
     # the planted windows are handed over with the inputs
@@ -65,6 +82,30 @@ def main():
                 res = pool.map(_work_ed, [(lo, hi, flag) for lo, hi in bounds])
                 dt = time.perf_counter() - t
                 out[name] = {"candidates_per_s": sum(r[0] for r in res) / dt, "seconds": dt, "answers": sum(r[1] for r in res)}
+        print(json.dumps(out))
+    elif mode == "cnsm_ed_stream":
+        alpha, beta = float(sys.argv[6]), float(sys.argv[7])
+        qs, list_off, q_list = z["qs"], z["list_off"], z["q_list"]
+        _G.update(qs=qs, list_off=list_off, q_list=q_list, alpha=alpha, beta=beta)
+        nq = len(qs)
+        n_one = int(z["one_core_queries"]) if "one_core_queries" in z else nq
+        klen = [int(list_off[q_list[j] + 1] - list_off[q_list[j]]) for j in range(nq)]
+        out = {"cores": workers, "queries": nq, "one_core_queries": n_one}
+        for name, flag in (("no_abandon", 1), ("early_abandon", 0)):   # one core, in this process
+            t = time.perf_counter()
+            res = [_work_cnsm_ed((j, 0, klen[j], flag)) for j in range(n_one)]
+            dt = time.perf_counter() - t
+            out["one_core_" + name] = {"candidates_per_s": sum(r[0] for r in res) / dt, "seconds": dt, "answers": sum(r[1] for r in res),
+                                       "pass_filter": sum(r[2] for r in res)}
+        tasks = lambda flag: [(j, klen[j] * i // workers, klen[j] * (i + 1) // workers, flag) for j in range(nq) for i in range(workers)]  # noqa: E731
+        with mp.get_context("fork").Pool(workers) as pool:
+            pool.map(_work_cnsm_ed, [(0, 0, 1, 0)] * workers)  # warm the workers (library load)
+            for name, flag in (("no_abandon", 1), ("early_abandon", 0)):
+                t = time.perf_counter()
+                res = pool.map(_work_cnsm_ed, tasks(flag), chunksize=1)
+                dt = time.perf_counter() - t
+                out[name] = {"candidates_per_s": sum(r[0] for r in res) / dt, "seconds": dt, "answers": sum(r[1] for r in res),
+                             "pass_filter": sum(r[2] for r in res)}
         print(json.dumps(out))
     elif mode == "cnsm_dtw_answers":
         fout, rho, alpha, beta = sys.argv[6], int(sys.argv[7]), float(sys.argv[8]), float(sys.argv[9])
