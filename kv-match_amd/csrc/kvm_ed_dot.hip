@@ -9,9 +9,9 @@
 //       acc = sum x'_j qc_j  (the only O(m) work: one FMA per term),
 //       S1' = sum x', S2' = sum x'^2 (O(1) from the shifted block prefix sums), T1 = sum qc, T2 = sum qc^2, d = mean(q) - c.
 // Everything is formed around local levels, so the terms are O(m var) and the cancellation the naive dot-product
-// identity suffers from is bounded by the explicit guard band 1e-11 * (sum of the magnitudes of the
-// terms) -- about 1e5 ulps, versus the <= sqrt(m) ulps the accumulations can lose.  Candidates inside the band go to
-// the exact pass like every other survivor.
+// identity suffers from is bounded by an explicit guard band that is a FUNCTION OF THE NUMBER OF TERMS
+// (edd_dot_slack below: the worst-case rounding of the accumulation, derived there -- no constant that happens to hold up to
+// some m).  Candidates inside the band go to the exact pass like every other survivor.
 //
 // Mapping: one wavefront = 8 rows x 8 lanes; a row is one tile of consecutive candidates whose window streams through a ring in
 // wave-private LDS (no workgroup barrier in the loop), a lane owns CI adjacent candidates (CI accumulators); every class
@@ -110,7 +110,8 @@ typedef double ed4_d2u __attribute__((ext_vector_type(2), aligned(8)));
 // window as before, a ds_read_b128 returns (x[2n], x[2n + 1]) = entry n of the even and of the odd phase.  The query's
 // phases qc[2t], qc[2t + 1] and their sums come from three host-built arrays (kvm_query_dev::qk).  Algebraically the same
 // sum; its rounding differs from the plain form's by a few ulps of sum |x| |qc| -- five orders of magnitude inside the guard
-// band the pruner keeps around eps^2 (1e-11 of the same magnitudes), and the exact pass decides as before.
+// band the pruner keeps around eps^2 (edd_dot_slack covers this form: its constant is derived for it), and the exact pass
+// decides as before.
 // profiles/r05_ed_a16k.log: the loop alone 68.2 against 57.7 TFLOP/s counted as 16 FMAs per point.
 // (The plain 16-per-lane loop -- 16 accumulators, one FMA per term -- was the step before this one: profiles/r05_a16_*.log.)
 // The same form serves class B on EIGHT candidates per lane (32-candidate tiles on the same 4-lane rows, 16 to a wavefront:
@@ -314,13 +315,38 @@ __device__ __forceinline__ void edd_body(const edd_args &A, const kvm_tile *__re
     static_assert(CI % 4 == 0, "candidates per lane come in fours");
     // correlation-form distance over a range of J points (st, acc and the query sums qp all taken over that range) and
     // its guard band
+    //
+    // THE GUARD BAND.  u = 2^-53.  Everything in the two forms below is O(1) operations on a handful of sums, except
+    //     acc = sum_{j < J} x'_j qc_j,          x' = x - c_row,  qc = q - mean(q),
+    // which the hot loop accumulates with one rounding per FMA.  A chain of L FMAs is off by at most L u sum |x'_j qc_j| (to
+    // first order in u; Higham, Accuracy and Stability, (3.3)), and sum |x' qc| <= (s sum x'^2 + sum qc^2 / s) / 2 for any scale
+    // s > 0 (AM-GM) = (S2' + T2) / 2 with s = 1 (RSM) and (S2' / sg^2 + T2) sg / 2 with s = 1 / sg (cNSM, where acc enters
+    // as 2 acc / sg).  What accumulates acc:
+    //   * the plain loops (classes A, B, C on 8 / 4 candidates per lane): one chain of J FMAs            -> J u (S2' + T2) / 2
+    //   * the pair form (16 / 8 candidates per lane): acc[2u] = EE + OO, acc[2u+1] = SS - OO - EE', each a chain of J / 2
+    //     FMAs over products whose magnitudes sum to at most (S2' + T2) / 2 for EE + OO together and, the inputs of SS being
+    //     sums of two neighbours ((a + b)^2 <= 2 a^2 + 2 b^2), at most (S2' + T2) for SS, plus 2 u relative for the two
+    //     roundings of each SS input and three final additions                                              -> <= 0.8 J u (S2' + T2)
+    //   * a window split f ways adds f - 1 additions of partial sums (each u of the running magnitude), and x' = x - c_row is
+    //     itself rounded once (u |x'|): both below 4 u (S2' + T2) / 2 in all.
+    // acc enters the distance as -2 acc, so the distance inherits at most 1.6 J u (S2' + T2) + 4 u (S2' + T2); the query's own
+    // sums T1, T2 (host, recursive summation over the same J terms) add J u T2 and 2 |d| J u sum |qc| <= J u (T2 + J d^2).
+    // edd_dot_slack = 4 (J + 4) u (S2' + T2): 2.5 x the first-order worst case (the factor also pays for the terms of second
+    // order in J u, below 1e-5 of the first up to J = 2^31 / 64).  The O(1) operations that form the distance from the sums are
+    // below 32 u of the magnitudes they combine (EDD_OPS_U).  At m = 8192 the band is 3.6e-12 (S2' + T2): a third of the
+    // constant 1e-11 rounds 2 - 5 kept, which was inside the worst case only up to m ~ 2e4 -- and twenty times it at
+    // m = 262 144 (tests/test_parity_gpu.py::test_ed_guard_band_scales_with_the_query_length places eps^2 on both sides of
+    // candidates there).  The rounding actually met on data is ~sqrt(J) u: the band costs no pruning power that matters.
+    constexpr double EDD_U = 1.1102230246251565e-16;   // 2^-53
+    constexpr double EDD_OPS_U = 32.0 * EDD_U;
+    auto edd_dot_slack = [&](int J, double s2_scaled, double t2) -> double { return (4.0 * EDD_U) * (double)(J + 4) * (fabs(s2_scaled) + fabs(t2)); };
     auto dist_form = [&](const edd_cstat &st, double acc, int J, const double2 qp, double &slack) -> double {
         if (!NORM) {
             const double d = qbar - c_row;
             const double cross = acc + d * st.s1J;
             const double qq = qp.y + (2.0 * d) * qp.x + J * (d * d);
-            slack = eps2 * 1e-9 + 1e-11 * (fabs(st.s2J) + 2.0 * fabs(acc) + 2.0 * fabs(d * st.s1J) + fabs(qq)) +
-                    st.e2J + 2.0 * fabs(d) * st.e1J;
+            slack = eps2 * 1e-9 + edd_dot_slack(J, st.s2J, qp.y + J * (d * d)) +
+                    EDD_OPS_U * (fabs(st.s2J) + 2.0 * fabs(acc) + 2.0 * fabs(d * st.s1J) + fabs(qq)) + st.e2J + 2.0 * fabs(d) * st.e1J;
             return st.s2J - 2.0 * cross + qq;
         } else {
             const double mc = st.mc, inv = 1.0 / st.sg;
@@ -329,7 +355,8 @@ __device__ __forceinline__ void edd_body(const edd_args &A, const kvm_tile *__re
             const double zz = qp.y + (2.0 * qbar) * qp.x + J * (qbar * qbar);         // sum zq^2
             // (over a partial range the distance depends on the mean to first order: sum_J z_x - sum_J zq is not zero)
             slack = eps2 * 1e-9 + kvm_eps2_slack(eps2, m, st.gd.g, 4.0) +
-                    1e-11 * (fabs(xx) * inv * inv + 2.0 * (fabs(acc) + fabs(qbar * st.s1J) + fabs(mc * qp.x)) * inv + fabs(zz)) +
+                    edd_dot_slack(J, st.s2J * inv * inv, qp.y + J * (qbar * qbar)) +
+                    EDD_OPS_U * (fabs(xx) * inv * inv + 2.0 * (fabs(acc) + fabs(qbar * st.s1J) + fabs(mc * qp.x)) * inv + fabs(zz)) +
                     (st.e2J + 2.0 * fabs(mc) * st.e1J) * inv * inv + 2.0 * inv * fabs(qbar) * st.e1J +
                     2.0 * inv * (fabs(st.s1J - J * mc) * inv + fabs(qp.x + J * qbar)) * st.gd.mean_err;
             return xx * inv * inv - 2.0 * xz * inv + zz;

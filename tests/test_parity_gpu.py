@@ -777,6 +777,76 @@ def test_query_lengths_all_variants(world, m):
                     oracle.cnsm_dtw(s, q, L, R, 0, eps, rho, 2.0, 5.0), tag="len cnsm_dtw")
 
 
+@pytest.mark.parametrize("m", [65_536, 262_144])
+def test_ed_guard_band_scales_with_the_query_length(built, m):
+    """The ED pruner's guard band is a function of the number of terms it accumulates (kvm_ed_dot.hip, edd_dot_slack), not a
+    constant that holds up to some m: queries of 2^16 and 2^18 points -- four and sixteen prefix-sum blocks, a level of 1e3 under
+    the data so that the correlation form cancels -- with eps placed ON candidates' distances, one ulp and 1e-15 .. 1e-11
+    relatively to either side (profiles/fuzz_knife.py's method): the pruner must hand every such candidate to the exact pass,
+    whose decision is the reference's.  RSM-ED and cNSM-ED, early abandoning on and off (host-planned tile classes and window
+    splits), the cross-check kernel once."""
+    import kvmatch
+    from kvmatch import datagen
+    n = 5 * m + 20_000
+    s = datagen.gen_series(n, seed=m) + 1000.0
+    qoff = n // 3
+    planted = [7, n - m - 40]
+    q = datagen.plant_copies(s, qoff, m, planted, [1.0, 1.0], [0.004, -0.006], 0.002, seed=m + 1)
+    rng = np.random.default_rng(m)
+    centres = sorted([qoff] + planted + rng.integers(1, n - m, 5).tolist())
+    L = np.array([max(1, c - 20) for c in centres], dtype=np.int32)
+    R = np.array([min(n - m + 1, c + 25) for c in centres], dtype=np.int32)
+
+    def around(x):
+        out = [x, float(np.nextafter(x, 0.0)), float(np.nextafter(x, np.inf))]
+        return out + [x * (1.0 + o) for o in (1e-15, -1e-15, 1e-13, -1e-13, 1e-11, -1e-11)]
+
+    with kvmatch.Phase2Context(0) as ctx:
+        ctx.load_series(s)
+        cases = (("rsm_ed", lambda e: kvmatch.QueryEngine(ctx).verify((L, R), 1, q, e), lambda e: oracle.rsm_ed(s, q, L, R, 0, e), 1e30),
+                 ("cnsm_ed", lambda e: kvmatch.NormQueryEngine(ctx).verify((L, R), 1, q, e, 2.0, 1e9),
+                  lambda e: oracle.cnsm_ed(s, q, L, R, 0, e, 2.0, 1e9), 1e150))
+        for name, lib, orc, wide in cases:
+            o_off, o_dist, _ = orc(wide)
+            assert len(o_dist) >= 100
+            order = np.argsort(o_dist)
+            picks = [order[1], order[2], order[len(order) // 50], order[len(order) // 8], order[len(order) // 2], order[-1]]
+            for ab in (1, 0):
+                ctx.set_option(kvmatch.OPT_EARLY_ABANDON, ab)
+                for i in picks:
+                    for eps in around(float(o_dist[i])):
+                        compare(lib(eps), orc(eps), tag=f"{name} m={m} abandon={ab} eps at candidate {int(o_off[i])}")
+            ctx.set_option(kvmatch.OPT_EARLY_ABANDON, 1)
+            ctx.set_option(kvmatch.OPT_ED_KERNEL, 1)
+            compare(lib(float(o_dist[picks[2]])), orc(float(o_dist[picks[2]])), tag=f"{name} m={m} wave kernel")
+            ctx.set_option(kvmatch.OPT_ED_KERNEL, 0)
+
+
+@pytest.mark.parametrize("k", [5, 40])
+def test_ed_guard_band_holds_against_coherent_rounding(built, k):
+    """The worst case a length-m rounding bound has to cover, built on purpose: a self-match (true distance 0) whose window is
+    0, 1, v, v, v, ... -- the pruner's dot product adds the same tiny product v (v - mean q) to an accumulator of ~1 four
+    million times, and every one of those additions rounds the same way by the same fraction of an ulp.  With the constant
+    1e-11 that rounds 2 - 5 kept around eps^2 the pruner drops this answer at m = 2^22 for these v (profiles/
+    r06_guard_band_coherent_m4M.log: 22 of 60 scanned values lost; with no band at all, 25 of 60 already at m = 2^20); the band
+    derived from the number of terms (kvm_ed_dot.hip, edd_dot_slack) keeps it, and the exact pass returns the reference's 0.0."""
+    import kvmatch
+    m = 1 << 22
+    v = 1e-8 * (1.0 + k * 1.37e-3)
+    s = np.full(m + 4096, v)
+    qoff = 1001
+    s[qoff - 1], s[qoff] = 0.0, 1.0
+    q = s[qoff - 1: qoff - 1 + m].copy()
+    L, R = np.array([qoff], dtype=np.int32), np.array([qoff + 2], dtype=np.int32)
+    want = oracle.rsm_ed(s, q, L, R, 0, 1.4e-6)
+    assert want[0].tolist() == [qoff] and want[1][0] == 0.0
+    with kvmatch.Phase2Context(0) as ctx:
+        ctx.load_series(s)
+        for ab in (1, 0):
+            ctx.set_option(kvmatch.OPT_EARLY_ABANDON, ab)
+            compare(kvmatch.QueryEngine(ctx).verify((L, R), 1, q, 1.4e-6), want, tag=f"coherent rounding k={k} abandon={ab}")
+
+
 def test_interval_shapes(world):
     """isolated candidates, interval lengths around the 32 / 64 tile sizes, one very long interval, the last window."""
     kvmatch, datagen, series, ctx = world
