@@ -333,10 +333,12 @@ __device__ __forceinline__ void edd_body(const edd_args &A, const kvm_tile *__re
     // sums T1, T2 (host, recursive summation over the same J terms) add J u T2 and 2 |d| J u sum |qc| <= J u (T2 + J d^2).
     // edd_dot_slack = 4 (J + 4) u (S2' + T2): 2.5 x the first-order worst case (the factor also pays for the terms of second
     // order in J u, below 1e-5 of the first up to J = 2^31 / 64).  The O(1) operations that form the distance from the sums are
-    // below 32 u of the magnitudes they combine (EDD_OPS_U).  At m = 8192 the band is 3.6e-12 (S2' + T2): a third of the
-    // constant 1e-11 rounds 2 - 5 kept, which was inside the worst case only up to m ~ 2e4 -- and twenty times it at
-    // m = 262 144 (tests/test_parity_gpu.py::test_ed_guard_band_scales_with_the_query_length places eps^2 on both sides of
-    // candidates there).  The rounding actually met on data is ~sqrt(J) u: the band costs no pruning power that matters.
+    // below 32 u of the magnitudes they combine (EDD_OPS_U).  At m = 8192 the band is 3.6e-12 (S2' + T2), a third of what the
+    // constant 1e-11 of rounds 2 - 5 gave; that constant covers the worst case only up to m of a few 1e4, and a window built for
+    // coherent rounding (0, 1, v, v, v ...: every addition of the chain rounds the same way) loses its self-match with it at
+    // m = 2^22 -- tests/test_parity_gpu.py::test_ed_guard_band_holds_against_coherent_rounding, profiles/r06_guard_band_coherent_*.log;
+    // ::test_ed_guard_band_scales_with_the_query_length places eps^2 on both sides of candidates at m = 2^16 and 2^18.  The
+    // rounding met on ordinary data is ~sqrt(J) u: the band costs no pruning power that matters.
     constexpr double EDD_U = 1.1102230246251565e-16;   // 2^-53
     constexpr double EDD_OPS_U = 32.0 * EDD_U;
     auto edd_dot_slack = [&](int J, double s2_scaled, double t2) -> double { return (4.0 * EDD_U) * (double)(J + 4) * (fabs(s2_scaled) + fabs(t2)); };
