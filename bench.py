@@ -342,6 +342,12 @@ def main():
     all_cands_l = [int((r.astype(np.int64) - l + 1).sum()) for l, r in full_lists]   # (the whole job's, known to every rank)
     my_cands = my_cands_l[0]
     ctx = kvmatch.Phase2Context(local_rank)
+    # rocprofv3's kernel tracing falls over when several host threads enqueue at the same moment: a run under it asks the library
+    # to let its calls take turns enqueueing (KVM_OPT_SERIALIZE_ENQUEUE; the library itself does not look for a profiler).
+    # KVM_SERIALIZE_ENQUEUE=0 in the environment of a profiled run leaves it off.
+    serialize = bool(a.profiled and os.environ.get("KVM_SERIALIZE_ENQUEUE", "") != "0")
+    if serialize:
+        ctx.set_option(kvmatch.OPT_SERIALIZE_ENQUEUE, 1)
     ctx.load_series(series)
     ctx.set_option(kvmatch.OPT_ED_KERNEL, a.ed_kernel)  # (HIP-event timing of the kernels: only in the exclusive pass below --
     #                                                       the event records cost ~0.1 ms of stream time per query)
@@ -479,6 +485,8 @@ def main():
         dist.broadcast_object_list(uid, src=0)          # (the launcher's own store carries the communicator id)
         group = kvmatch.DeviceGroup(rank=rank, world=world, device=local_rank, unique_id=uid[0], in_flight=F, rccl_always=True)
         group.load_series(series)
+        if serialize:
+            group.set_option(kvmatch.OPT_SERIALIZE_ENQUEUE, 1)
         rccl_ranks = group.rccl_ranks
         if rccl_ranks != a.gpus:
             raise SystemExit(f"--gpus {a.gpus} but the RCCL communicator has {rccl_ranks} ranks")
@@ -572,6 +580,7 @@ def main():
             r_ = engines[i].verify(shards[j % NL], 1, queries[j], a.epsilon, *pos_)
             if rep >= 2:
                 excl_ns.append({"plan": i, "ns": int(lib.kvm_last_kernel_ns(h)), "stats": list(r_.stats)})
+    excl_shape = kvmatch.ed_shape(ctx.get_option(kvmatch.OPT_ED_LAST_SHAPE))   # (the form the pruner ran the bench's own list in)
     # The LIST's own bound for the RSM-ED pruner: a tile streams its whole window whatever its width, so a
     # list of short intervals cannot run at the rate of full tiles.  Per tile of c candidates:
     #     max( 2 m c / R_A ,  8 (m + c - 1) / B )
@@ -628,6 +637,8 @@ def main():
             gF = 16
             with kvmatch.DeviceGroup(devices=[local_rank], in_flight=gF, rccl_always=True) as g1:
                 g1.load_series(series)
+                if serialize:
+                    g1.set_option(kvmatch.OPT_SERIALIZE_ENQUEUE, 1)
 
                 def gstep(n_q, collect=()):
                     return g1.run_jobs([job_desc_full(0, t % NQ) for t in range(n_q)], collect=collect)
@@ -696,7 +707,7 @@ def main():
                                 "cnsm_dtw": "cNSM-DTW phase 2, rho=5%, alpha=2 beta=10 (BASELINE configs[3])",
                                 "mixed": "mixed ED+DTW query stream (BASELINE configs[4] style)"}[wl], "n": n, "m": m,
                    "queries_per_step": qps, "queries_in_flight": F,
-                   "host_threads": ("python (a profiler is attached)" if a.profiled else "python") if a.python_threads else (("native (kvm_run_sharded_jobs: split, slot threads, ncclAllGather and merge inside the library)" if group is not None else "native (kvm_run_device_jobs) under a Python exchange thread" if use_dist else "native (kvm_run_jobs)") + ("; a profiler is attached: the calls' enqueue phases take turns (kvm_verify.hip, kvm_enqueue_lock)" if a.profiled and os.environ.get("KVM_SERIALIZE_ENQUEUE", "") != "0" else "")),
+                   "host_threads": ("python (a profiler is attached)" if a.profiled else "python") if a.python_threads else (("native (kvm_run_sharded_jobs: split, slot threads, ncclAllGather and merge inside the library)" if group is not None else "native (kvm_run_device_jobs) under a Python exchange thread" if use_dist else "native (kvm_run_jobs)") + ("; a profiler is attached: this run set KVM_OPT_SERIALIZE_ENQUEUE on its contexts (their enqueue phases take turns)" if serialize else "")),
                    "distinct_queries": NQ, "distinct_interval_lists": NL,
                    "candidates_per_query_per_gpu": my_cands,
                    "candidates_per_gpu": my_cands, "intervals_per_gpu": int(len(shards[0][0])), "epsilon": a.epsilon,
@@ -722,7 +733,7 @@ def main():
         out["roofline"].update(list_bound)
         if "list_bound_ms" in list_bound and out["roofline"].get("kernel_ms"):
             out["roofline"]["frac_of_list_bound"] = list_bound["list_bound_ms"] / out["roofline"]["kernel_ms"]
-        if "cands_in_class_a" in list_bound and not os.environ.get("KVM_ED_NO_A16"):
+        if "cands_in_class_a" in list_bound and excl_shape["per_lane_a"] == 16:
             # class A (tiles of more than 32 candidates) runs the Karatsuba form on this list: 25 FMAs per 32 terms
             share = (list_bound["cands_in_class_a"] * 25.0 / 32.0 + (my_cands - list_bound["cands_in_class_a"])) / max(1, my_cands)
             out["roofline"]["executed_fma_share"] = share

@@ -28,22 +28,14 @@
  * across calls and contexts, behind a mutex (calls that need it at the same time allocate their own);
  * (ii) a thread_local memo of the ED pruner's launch-shape model.  Nothing else is shared.
  *
- * Environment (read once per process; all optional, none changes an answer):
- *   KVM_ED_KERNEL=1|3    default ED pruning kernel where KVM_OPT_ED_KERNEL is 0 (auto)
+ * Environment (read ONCE per process, at the first call that asks; all optional, none changes an answer):
  *   KVM_TRACE=1          per-stage host timings of every call on stderr
  *   KVM_DEBUG_SYNC=1     DTW calls wait for the stream after every stage and name it on stderr
+ *   KVM_SERIALIZE_ENQUEUE=1  the default of KVM_OPT_SERIALIZE_ENQUEUE for contexts opened by this process
  *   KVM_LIB=<path>       (Python binding only) load another build of this library
- *   KVM_SERIALIZE_ENQUEUE=0|1  the enqueue phases of the verification calls (plan, copies, launches; not the waits) take
- *                        turns between host threads.  Default: only while a tool that hooks the kernel dispatches is
- *                        attached (ROCP* variables / a rocprofiler library in LD_PRELOAD): rocprofv3's kernel tracing
- *                        falls over when several threads enqueue at the same moment
- * Experiments only (read at every call; they change the pruner's launch shape, never an answer):
- *   KVM_ED_SPLIT=fA,fB   window split of class-A / class-B,C units (1, 2 or 4 each) instead of the launcher's model
- *   KVM_ED_HYBRID=1|2    tile classes A / B (1) or A / B / C (2) for host-planned lists instead of the model's choice
- *   KVM_ED_SPLIT_UNITS=n device-built lists: split every unit four ways when there are at most n of them
- *   KVM_ED_A16=0|1, KVM_ED_NO_A16=1, KVM_ED_B16=0|1, KVM_ED_A16_MIN_UNITS=n   the forms of classes A / B (16 / 8 candidates
- *                        per lane on four-lane rows) instead of the launcher's rule; KVM_ED_IN_FLIGHT=n its idea of the
- *                        queries in flight (KVM_OPT_IN_FLIGHT)
+ * Nothing else is read from the environment: the launch-shape experiments of rounds 2 - 5 are KVM_OPT_ED_FORCE (a per-context
+ * option the tests use to drive every form of the pruner), and the library does not look for a profiler -- a host that runs
+ * under one sets KVM_OPT_SERIALIZE_ENQUEUE itself (bench.py does, and says so in its line).
  *
  * DTW answer semantics.  The reference's DTW engines do not report {candidates with banded DTW <= eps^2}:
  * DtwUtils.dtw returns `min_cost + cb[i+r+1]` as soon as that lower bound is >= eps^2 (K/utils/DtwUtils.java:
@@ -395,6 +387,30 @@ void kvm_result_free(kvm_result *r);
                                     own it plans a list for throughput (no window split beyond its share of the chip, the
                                     short tiles in their denser form) instead of for the shortest single launch.  Replaces
                                     nothing in the reference. */
+#define KVM_OPT_ED_FORCE 10      /* 0 (default): the ED pruner's launcher chooses its launch shape (tile classes, candidates per
+                                    lane, window split) from its model.  Otherwise a bit field that FORCES parts of the shape --
+                                    for the tests, which drive every form over the same inputs, and for measurements; the
+                                    answers are the same: bits 0-3 window split of class-A units (1, 2 or 4; 0 = model),
+                                    bits 4-7 of class-B / C units, bits 8-9 class A on 16 candidates per lane (1 = never,
+                                    2 = wherever the form exists), bits 10-11 class B on the four-lane rows (1 never, 2 with
+                                    16 per lane in class A), bits 12-13 tile classes of host-planned lists (1 = A / B, 2 = A /
+                                    B / C), bit 14 device-built (cNSM) lists of any size through the 16-per-lane form, bit 15
+                                    device-built lists never split. */
+#define KVM_ED_FORCE(split_a, split_b, a16, b16, classes, dev_a16_any, dev_no_split) \
+    ((int64_t)(split_a) | ((int64_t)(split_b) << 4) | ((int64_t)(a16) << 8) | ((int64_t)(b16) << 10) | ((int64_t)(classes) << 12) | \
+     ((int64_t)(dev_a16_any) << 14) | ((int64_t)(dev_no_split) << 15))
+#define KVM_OPT_ED_LAST_SHAPE 12  /* read only (kvm_get_option): the launch shape of this context's most recent LDS-tiled ED pruner
+                                    launch, in the layout of KVM_OPT_ED_FORCE -- bits 0-3 / 4-7 the window splits, bits 8-9 class A on
+                                    8 (1) or 16 (2) candidates per lane, bits 10-11 class B on 4 (1) or 8 (2) -- plus bits 16-23 the
+                                    queries in flight the launcher planned for.  0: no such launch yet. */
+#define KVM_OPT_SERIALIZE_ENQUEUE 11 /* 0 (default, or KVM_SERIALIZE_ENQUEUE=1 in the environment when the context is opened): host
+                                    threads enqueue freely.  1: the ENQUEUE phases of this context's verification calls (plan,
+                                    copies, launches; not the waits) hold one process-wide lock -- the kernels of different
+                                    contexts still overlap on the GPU, the host threads take turns issuing them.  For hosts that
+                                    run under a tool that hooks kernel dispatches: rocprofv3's kernel tracing falls over when
+                                    several threads enqueue at the same moment (profiles/r05_prof_native_crash.log).  Costs
+                                    nothing where every point is evaluated and a third of an early-abandoning stream's rate
+                                    (39 -> 59 us per query, profiles/r06_enqueue_lock_cost.log), so it is not the default. */
 int kvm_set_option(kvm_ctx *ctx, int32_t option, int64_t value);
 int64_t kvm_get_option(const kvm_ctx *ctx, int32_t option);
 /* Device time (ns, HIP events on the launch stream) of the verification kernels of the most recent

@@ -74,6 +74,11 @@ extern "C" int kvm_open(int device, kvm_ctx **out) {
         return kvm_fail(nullptr, KVM_ERR_ILLEGAL_ARGUMENT, "kvm_open: device ordinal out of range");
     kvm_ctx *ctx = new kvm_ctx();
     ctx->device = device;
+    static const bool serialize_default = [] {   // (read once per process)
+        const char *e = getenv("KVM_SERIALIZE_ENQUEUE");
+        return e && e[0] && e[0] != '0';
+    }();
+    ctx->opt_serialize_enqueue = serialize_default ? 1 : 0;
     if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreate(&ctx->stream)) != hipSuccess ||
         (e = hipEventCreate(&ctx->ev0)) != hipSuccess || (e = hipEventCreate(&ctx->ev1)) != hipSuccess ||
         (e = hipEventCreateWithFlags(&ctx->ev_staged, hipEventDisableTiming)) != hipSuccess ||
@@ -151,6 +156,15 @@ extern "C" int kvm_set_option(kvm_ctx *ctx, int32_t option, int64_t value) {
         case KVM_OPT_UCR_LOOPS: ctx->opt_ucr_loops = value ? 1 : 0; return KVM_OK;
         case KVM_OPT_STRICT_BOUNDS: ctx->opt_strict_bounds = value ? 1 : 0; return KVM_OK;
         case KVM_OPT_IN_FLIGHT: ctx->opt_in_flight = value < 1 ? 1 : (value > 64 ? 64 : value); return KVM_OK;
+        case KVM_OPT_ED_FORCE: {
+            const auto split_ok = [](int64_t f) { return f == 0 || f == 1 || f == 2 || f == 4; };
+            if (value < 0 || value >= (1 << 16) || !split_ok(value & 15) || !split_ok((value >> 4) & 15) || ((value >> 8) & 3) == 3 ||
+                ((value >> 10) & 3) == 3 || ((value >> 12) & 3) == 3)
+                return kvm_fail(ctx, KVM_ERR_ILLEGAL_ARGUMENT, "KVM_OPT_ED_FORCE: see KVM_ED_FORCE in kvmatch.h");
+            ctx->opt_ed_force = value;
+            return KVM_OK;
+        }
+        case KVM_OPT_SERIALIZE_ENQUEUE: ctx->opt_serialize_enqueue = value ? 1 : 0; return KVM_OK;
     }
     return kvm_fail(ctx, KVM_ERR_ILLEGAL_ARGUMENT, "unknown option");
 }
@@ -199,6 +213,9 @@ extern "C" int64_t kvm_get_option(const kvm_ctx *ctx, int32_t option) {
         case KVM_OPT_UCR_LOOPS: return ctx->opt_ucr_loops;
         case KVM_OPT_STRICT_BOUNDS: return ctx->opt_strict_bounds;
         case KVM_OPT_IN_FLIGHT: return ctx->opt_in_flight;
+        case KVM_OPT_ED_FORCE: return ctx->opt_ed_force;
+        case KVM_OPT_SERIALIZE_ENQUEUE: return ctx->opt_serialize_enqueue;
+        case KVM_OPT_ED_LAST_SHAPE: return ctx->last_ed_shape;
     }
     return KVM_ERR_ILLEGAL_ARGUMENT;
 }

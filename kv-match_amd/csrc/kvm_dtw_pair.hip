@@ -36,14 +36,9 @@
 #include "kvm_dtw_dp.h"
 #include <type_traits>
 
-// (both measured on 49 152 full DPs, profiles/r04_ab_pack_9.log: within run-to-run noise of each other; the defaults are
-// the forms with the fewest live registers)
-#ifndef KVM_PW_STATE_SGPR
-#define KVM_PW_STATE_SGPR 0   // 1: keep a half's candidate / plan records in scalar registers instead of re-reading them
-#endif
-#ifndef KVM_PW_PREFETCH
-#define KVM_PW_PREFETCH 0     // 1: issue a chunk's global loads before its blocks instead of after them
-#endif
+// (a half's candidate / plan records are re-read per chunk rather than kept in scalar registers, and a chunk's global loads are
+// issued after its blocks: the alternatives measured within run-to-run noise on 49 152 full DPs, profiles/r04_ab_pack_9.log, and
+// were removed in round 6 -- these are the forms with the fewest live registers)
 #ifndef KVM_DP_PACK_WG_PER_CU
 #define KVM_DP_PACK_WG_PER_CU 2   // resident workgroups per CU = waves per SIMD
 #endif
@@ -103,9 +98,7 @@ struct pw_half {
     int mode;       // PW_FIRST / PW_FULL
     int decision;   // 0 none yet, 1 reject (ABANDON off: the sweep goes on to the end regardless)
     int Ic;         // first macro-step of the next chunk
-#if !KVM_PW_STATE_SGPR
     unsigned idx;
-#endif
     kvm_cand cand;  // (kept in scalar registers: what the compiler cannot hold it parks in VGPR lanes, one instruction
     dp_plan pl;     //  per access -- a re-read from memory is a latency the wave's only partner on its SIMD cannot hide)
     double pref;    // sum of the cb terms below the next chunk's first
@@ -277,25 +270,15 @@ __device__ __forceinline__ void dp_pack_sweep(const double *__restrict__ series,
         const unsigned long long pos = kvm_uniform_u64(popped);
         if (pos >= n_in) { drained = true; return false; }
         const unsigned idx = list[pos];
-#if KVM_PW_STATE_SGPR
-        T.cand = in[idx];
-        T.pl = plans[idx];
-#else
         T.idx = idx;
-#endif
         if (lane == 0) atomicAdd(&counters[KVM_CNT_PASS_KEOGH2], 1ULL);
         return true;
     };
 
     // (re)start the sweep of T's candidate in half h: windows of the first chunk, registers of the half's lanes
     auto start = [&](pw_half &T, const int h, const int mode_req) {
-#if KVM_PW_STATE_SGPR
-        const kvm_cand cand = T.cand;
-        const dp_plan pl = T.pl;
-#else
         const kvm_cand cand = in[T.idx];
         const dp_plan pl = plans[T.idx];
-#endif
         const double *__restrict__ x = series + (cand.start - 1);
         const double mean = cand.mean, sd = cand.std;
         double *__restrict__ patch = ax.patch + ((size_t)(blockIdx.x * 4 + wave) * H + h) * 8 * (size_t)r;
@@ -341,11 +324,7 @@ __device__ __forceinline__ void dp_pack_sweep(const double *__restrict__ series,
 
     // before a chunk: issue the global loads the half needs after it (nothing here waits for them)
     auto pre = [&](const pw_half &T0, const int h, pw_pre &P) {
-#if KVM_PW_STATE_SGPR
-        const pw_half &T = T0;
-#else
         pw_half T = T0; T.cand = in[T0.idx]; T.pl = plans[T0.idx];
-#endif
         const double *__restrict__ x = series + (T.cand.start - 1);
         const double *__restrict__ patch = ax.patch + ((size_t)(blockIdx.x * 4 + wave) * H + h) * 8 * (size_t)r;
         const int k = min(T.Ic + lane + 1, m - 1);   // row test of lane u: needs cb term Ic + u + 1 (clamped: unused beyond m - 1)
@@ -364,16 +343,10 @@ __device__ __forceinline__ void dp_pack_sweep(const double *__restrict__ series,
 
     // after a chunk: row test of the rows it finished, then the end of the candidate or the next chunk's windows
     auto after = [&](pw_half &T, const int h, const bool chunk_full, const pw_pre &P0) {  // chunk_full: the chunk ran in PW_FULL
-#if !KVM_PW_STATE_SGPR
         T.cand = in[T.idx]; T.pl = plans[T.idx];
-#endif
-#if KVM_PW_PREFETCH
-        const pw_pre &P = P0;
-#else
         pw_pre P = P0;
         pre(T, h, P);
         P.xa = (series + (T.cand.start - 1))[min(max(T.Ic + CH + lane, 0), m - 1)];
-#endif
         const double mean = T.cand.mean, sd = T.cand.std;
         const int Ic = T.Ic;
         int t = 0;
@@ -468,9 +441,6 @@ __device__ __forceinline__ void dp_pack_sweep(const double *__restrict__ series,
 #pragma unroll
         for (int h = 0; h < H; h++) {
             P[h].r0 = P[h].r1 = P[h].r2 = P[h].xa = P[h].bq = 0.0;
-#if KVM_PW_PREFETCH
-            if (S[h].active) pre(S[h], h, P[h]);
-#endif
         }
         using M0 = std::integral_constant<int, PW_FIRST>;
         using M1 = std::integral_constant<int, PW_FULL>;
@@ -533,12 +503,8 @@ static hipError_t launch_pack(const double *series, const kvm_query_dev &qd, con
             return launch_pack_c<L, V, C>(series, qd, ax, in, plans, list, share_mode, max_in, out_off, out_dist, cap, counters, num_cu, s); \
         break;
     switch (qd.rho % V) {
-#ifdef KVM_PACK_DEV   // (development builds: rho = 204 only)
-        KVM_PACK_CASE(1)
-#else
         KVM_PACK_CASE(0) KVM_PACK_CASE(1) KVM_PACK_CASE(2) KVM_PACK_CASE(3)
         KVM_PACK_CASE(4) KVM_PACK_CASE(5) KVM_PACK_CASE(6) KVM_PACK_CASE(7)
-#endif
     }
 #undef KVM_PACK_CASE
     return hipErrorInvalidValue;
@@ -554,21 +520,15 @@ hipError_t kvm_launch_dtw_dp_pack(const double *series, const kvm_query_dev &qd,
     case VV: return launch_pack<32, VV>(series, qd, ax, in, plans, list, share_mode, max_in, out_off, out_dist, cap, counters, num_cu, s);
     if (dp_pack_l(qd.rho) == 32) {
         switch (dp_pack_v(qd.rho)) {
-#ifdef KVM_PACK_DEV
-            KVM_PACK_V(7)
-#else
             KVM_PACK_V(3) KVM_PACK_V(4) KVM_PACK_V(5) KVM_PACK_V(6) KVM_PACK_V(7) KVM_PACK_V(8)
-#endif
         }
     }
-#ifndef KVM_PACK_DEV
 #define KVM_PACK_W(VV) \
     case VV: return launch_pack<64, VV>(series, qd, ax, in, plans, list, share_mode, max_in, out_off, out_dist, cap, counters, num_cu, s);
     if (dp_pack_l(qd.rho) == 64) {
         switch (dp_pack_v(qd.rho)) { KVM_PACK_W(3) KVM_PACK_W(5) KVM_PACK_W(6) KVM_PACK_W(7) }
     }
 #undef KVM_PACK_W
-#endif
 #undef KVM_PACK_V
     return hipErrorInvalidValue;
 }

@@ -35,6 +35,7 @@
 #include "kvm_seqadd.h"
 #include "kvm_ed_launch_model.h"
 #include <hip/hip_ext.h>
+bool kvm_trace_on();   // kvm_plan.hip: KVM_TRACE=1, read once
 
 #include <algorithm>
 #include <cmath>
@@ -553,13 +554,11 @@ __device__ __forceinline__ void edd_body(const edd_args &A, const kvm_tile *__re
                         qo16[(B + 1) & 1] = qo_g[t0 + 16 * (B + 1) + (lane & 15)];
                         qs16[(B + 1) & 1] = qs_g[t0 + 16 * (B + 1) + (lane & 15)];
                     }
-#ifndef EDD_DBG_NOSTAGE   // (experiments, profiles/ab_a16k.sh: what the staging alone / the arithmetic alone cost)
                     if constexpr (S % 2 == 0) {
                         constexpr int b = S / 2;
                         wr16(b, pend16[b % EDD16_AHEAD][0], pend16[b % EDD16_AHEAD][1]);
                         ld16(j0 + 128 + 16 * (b + EDD16_AHEAD), pend16[b % EDD16_AHEAD][0], pend16[b % EDD16_AHEAD][1]);
                     }
-#endif
                     constexpr int W0 = (1024 - 16 * (NP + 4)) / 64, WS = 8 * CI / 64;   // class lc steps back at sub-step W0 - WS lc
                     static_assert((1024 - 16 * (NP + 4)) % 64 == 0 && (8 * CI) % 64 == 0, "whole sub-steps");
                     if constexpr (S == W0 || S == W0 - WS || S == W0 - 2 * WS || S == W0 - 3 * WS) {
@@ -579,11 +578,7 @@ __device__ __forceinline__ void edd_body(const edd_args &A, const kvm_tile *__re
                         asm volatile("" : "+v"(kE[0]), "+v"(kE[1]), "+v"(kE[2]), "+v"(kE[3]), "+v"(kE[4]), "+v"(kO[0]), "+v"(kO[1]), "+v"(kO[2]),
                                      "+v"(kO[3]), "+v"(kS[0]), "+v"(kS[1]), "+v"(kS[2]), "+v"(kS[3])::"memory");
                     const double qev = qe16[(S / 4) & 1], qov = qo16[(S / 4) & 1], qsv = qs16[(S / 4) & 1];
-#ifdef EDD_DBG_NOFMA
-                    edd_static_for<1>([&](auto kc) {
-#else
                     edd_static_for<4>([&](auto kc) {
-#endif
                         constexpr int k = decltype(kc)::value;
                         constexpr int K = 4 * (S & 3) + k, T = 4 * S + k;   // the tap's lane in the query registers; the tap itself
                         edd_static_for<NP + 1>([&](auto uc) {
@@ -1187,20 +1182,21 @@ int kvm_ed_dot_choose_classes(int m, int64_t tilesA, int64_t tilesB, int64_t til
     return edd_choose_classes(m, tilesA, tilesB, tilesC, num_cu);   // class A runs in its 8-per-lane form)
 }
 
-static bool env_set(const char *name) {   // (set AND not empty: `VAR= cmd` leaves an empty string in the environment)
-    const char *e = getenv(name);
-    return e && e[0] && e[0] != '0';
-}
-
 hipError_t kvm_launch_ed_dot(const double *series, const double2 *prefix, int64_t n, const kvm_query_dev &qd,
                              const kvm_tile *tilesA, int64_t nA, const kvm_tile *tilesB, int64_t nB,
                              const kvm_tile *tilesC, int64_t nC, kvm_surv *surv,
                              int64_t cap, unsigned long long *counters, int num_cu, const unsigned long long *d_counts,
                              int32_t *out_off, double *out_dist, int64_t out_cap, hipStream_t s, hipEvent_t ev_start,
-                             hipEvent_t ev_stop, int in_flight) {
+                             hipEvent_t ev_stop, int in_flight, int64_t force, int64_t *shape) {
+    // `force` = KVM_OPT_ED_FORCE (kvmatch.h): parts of the launch shape imposed by the caller -- the tests drive every form of
+    // the kernel over the same inputs with it; 0 = everything by the model below
+    const int force_fa = (int)(force & 15), force_fb = (int)((force >> 4) & 15), force_a16 = (int)((force >> 8) & 3),
+              force_b16 = (int)((force >> 10) & 3);
+    const bool force_dev_a16_any = (force >> 14) & 1, force_dev_no_split = (force >> 15) & 1;
     (void)n;
     if (nA + nB + nC <= 0) return hipSuccess;
-    const bool a16_ok = (qd.early_abandon ? edd_a16<true>() : edd_a16<false>()) && !env_set("KVM_ED_NO_A16");   // (experiments)
+    // (the 16-per-lane forms read the query's phase arrays qd.qk: a query block built without them runs 8 per lane)
+    const bool a16_ok = (qd.early_abandon ? edd_a16<true>() : edd_a16<false>()) && force_a16 != 1 && qd.qk != nullptr;
     bool a16 = false;
     const int64_t unitsA16 = (nA + EDD_TILES_A16 - 1) / EDD_TILES_A16;
     int64_t unitsA = (nA + EDD_TILES_A - 1) / EDD_TILES_A;
@@ -1238,8 +1234,6 @@ hipError_t kvm_launch_ed_dot(const double *series, const double2 *prefix, int64_
     // the launches of the other contexts fill what this one leaves idle, so a split only has to cover this launch's SHARE of
     // the wave slots -- a part's prologue is then mostly lost work (the bench's stream of 8: 2.71e9 candidates/s unsplit
     // against 2.65e9 with the split that is fastest for the same list alone, profiles/r05_b8k_pairs.log)
-    if (const char *e = getenv("KVM_ED_IN_FLIGHT"))   // experiments
-        if (e[0]) in_flight = atoi(e);
     in_flight = std::max(1, std::min(in_flight, 64));
     const double slots_all = (double)num_cu * 8, slots = std::max(slots_all / in_flight, 64.0);
     bool b16 = false;
@@ -1259,13 +1253,13 @@ hipError_t kvm_launch_ed_dot(const double *series, const double2 *prefix, int64_
             // unsplit they last a whole window each -- the bench's cNSM stream loses 15 % with a quarter of the slots here,
             // profiles/r05_in_flight_ab.log)
             split_units = (qd.early_abandon || qd.m < 4096) ? (int64_t)(slots_all / 2) : (int64_t)slots_all;
-            if (const char *e = getenv("KVM_ED_SPLIT_UNITS")) split_units = atoll(e);  // experiments
+            if (force_dev_no_split) split_units = 0;
         }
     } else if (qd.early_abandon) {
         // unit durations are unpredictable; split only when the list cannot fill the chip anyway (latency-bound)
         if ((double)(unitsA + unitsS) * 4.0 <= slots) fA = fB = 4;
         else if ((double)(unitsA + unitsS) * 2.0 <= slots) fA = fB = 2;
-    } else if ((double)(unitsA + unitsS) < (in_flight >= 4 && !env_set("KVM_ED_NO_SHARE_RULE") ? 2.0 : 16.0) * slots) {
+    } else if ((double)(unitsA + unitsS) < (in_flight >= 4 ? 2.0 : 16.0) * slots) {
         // (alone, the model decides up to 16 rounds of the wave slots -- a launch's tail is its own.  With four or more queries
         // in flight the other launches are this one's tail: from two rounds of the launch's SHARE on nothing is split -- in
         // the bench's stream every split of either class costs candidates/s, 2.71e9 unsplit against 2.68 / 2.69 with one class
@@ -1295,21 +1289,17 @@ hipError_t kvm_launch_ed_dot(const double *series, const double2 *prefix, int64_
         a16 = b16 = a16_ok;   // many rounds of the wave slots: throughput alone
     }
     if (a16 && !d_counts) unitsA = unitsA16;
-    if (const char *e = getenv("KVM_ED_SPLIT")) {  // experiments: "fA,fB"
-        int a = 0, b = 0;
-        if (sscanf(e, "%d,%d", &a, &b) == 2 && (a == 1 || a == 2 || a == 4) && (b == 1 || b == 2 || b == 4))
-            fA = a, fB = b;
+    if (force_fa) fA = force_fa;
+    if (force_fb) fB = force_fb;
+    if (force_a16 && !d_counts && a16_ok) {   // the form of class A on host-planned lists
+        a16 = force_a16 == 2;
+        b16 = a16 && in_flight > 1;
+        unitsA = a16 ? unitsA16 : (nA + EDD_TILES_A - 1) / EDD_TILES_A;
     }
-    if (const char *e = getenv("KVM_ED_A16")) {   // experiments: force the form of class A on host-planned lists
-        if (!d_counts && a16_ok && (e[0] == '0' || e[0] == '1')) {
-            a16 = e[0] == '1';
-            b16 = a16 && in_flight > 1;
-            unitsA = a16 ? unitsA16 : (nA + EDD_TILES_A - 1) / EDD_TILES_A;
-        }
-    }
-    if (const char *e = getenv("KVM_ED_B16"))    // experiments: class B on the four-lane rows (only with 16 per lane in class A)
-        if (e[0] == '0' || e[0] == '1') b16 = a16 && e[0] == '1';
-    if (getenv("KVM_TRACE"))
+    if (force_b16) b16 = a16 && force_b16 == 2;   // class B on the four-lane rows (only with 16 per lane in class A)
+    if (shape)   // (device-built lists: the kernel picks the forms from the real counts; what is reported is what it may use)
+        *shape = (int64_t)fA | ((int64_t)fB << 4) | ((int64_t)(a16 ? 2 : 1) << 8) | ((int64_t)(b16 ? 2 : 1) << 10) | ((int64_t)in_flight << 16);
+    if (kvm_trace_on())
         fprintf(stderr, "[kvm] ed_dot m %d unitsA %lld (%d per lane) unitsB %lld (class B %d per lane) unitsC %lld split %d,%d in flight %d\n", (int)qd.m,
                 (long long)unitsA, a16 ? 16 : 8, (long long)((b16 && !d_counts) ? (nB + EDD_TILES_B16 - 1) / EDD_TILES_B16 : unitsB), b16 ? 8 : 4,
                 (long long)unitsC, fA, fB, in_flight);
@@ -1327,7 +1317,7 @@ hipError_t kvm_launch_ed_dot(const double *series, const double2 *prefix, int64_
         blocksB = blocksC = 0;
     }
     int64_t a16_min = edd_a16_min_units(qd.m, slots_all);
-    if (const char *e = getenv("KVM_ED_A16_MIN_UNITS")) a16_min = atoll(e);   // tests: device-built lists of any size through the 16-per-lane form
+    if (force_dev_a16_any) a16_min = 0;   // device-built lists of any size through the 16-per-lane form
     dim3 grid((unsigned)(blocksA + blocksB + blocksC)), block(256);
     edd_args A{series, prefix, qd, surv, cap, counters, out_off, out_dist, out_cap};
     // (ev_start / ev_stop: the kernel's own begin and end -- hipExtLaunchKernelGGL stamps the dispatch itself, so the time between

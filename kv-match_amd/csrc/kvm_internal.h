@@ -100,7 +100,8 @@ struct kvm_ctx {
     void *h_readback = nullptr;  // pinned, device-mapped: the readback kernel stores counters + first answers here
     size_t h_pinned_cap = 0;
     int64_t opt_early_abandon = 1, opt_lb_cascade = 1, opt_ed_kernel = 0, opt_timing = 0, opt_dp_kernel = 0,
-            opt_sort_violation = 0, opt_ucr_loops = 0, opt_strict_bounds = 1, opt_in_flight = 1;
+            opt_sort_violation = 0, opt_ucr_loops = 0, opt_strict_bounds = 1, opt_in_flight = 1, opt_ed_force = 0,
+            opt_serialize_enqueue = 0, last_ed_shape = 0;
     int run_in_flight = 0;   // contexts of the kvm_run_jobs / kvm_run_device_jobs call this one is part of right now (kvm_set_run_in_flight)
     int num_cu = 256;
     int64_t last_kernel_ns = 0;
@@ -261,7 +262,8 @@ hipError_t kvm_launch_ed_dot(const double *series, const double2 *prefix, int64_
                              const kvm_tile *tilesC, int64_t nC, kvm_surv *surv,
                              int64_t cap, unsigned long long *counters, int num_cu, const unsigned long long *d_counts,
                              int32_t *out_off, double *out_dist, int64_t out_cap, hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr,
-                             int in_flight = 1);   // in_flight: launches of other contexts expected next to this one (kvm_in_flight)
+                             int in_flight = 1, int64_t force = 0, int64_t *shape = nullptr);   // in_flight: launches of other contexts
+                                                       // expected next to this one (kvm_in_flight); force: KVM_OPT_ED_FORCE; shape: KVM_OPT_ED_LAST_SHAPE
 static inline int kvm_in_flight(const kvm_ctx *ctx) { return (int)std::max<int64_t>(std::max<int64_t>(ctx->opt_in_flight, ctx->run_in_flight), 1); }
 // cNSM: 64-candidate tiles -> trimmed class-A / class-B tile lists of the candidates passing the guarded (alpha, beta)
 // filter; the list lengths go to d_counts[0..1] (kvm_launch_ed_dot then takes nA, nB as upper bounds; no class C here)

@@ -3,37 +3,27 @@
 #include "kvm_api_internal.h"
 #include "kvm_jsort.h"
 #include <mutex>
-extern char **environ;
 
-// Under a tool that hooks the runtime's kernel dispatches (rocprofv3 --kernel-trace) several host threads enqueueing at the same
-// moment take the tool's library down: a SIGSEGV in a copy inside its dispatch callback, on whichever thread is launching
-// (profiles/r05_prof_native_crash.log; never seen without the tool).  While such a tool is attached -- its environment: ROCP* /
-// ROCPROF* variables or a rocprofiler library in LD_PRELOAD -- or with KVM_SERIALIZE_ENQUEUE=1, the ENQUEUE phases of the
-// verification calls (plan, copies, launches: everything but the waits for the stream) hold one process-wide lock: the
-// kernels of different contexts still overlap on the GPU, the host threads take turns issuing them.  KVM_SERIALIZE_ENQUEUE=0
-// switches it off.
+// KVM_OPT_SERIALIZE_ENQUEUE: the ENQUEUE phases of a context's verification calls (plan, copies, launches: everything but the
+// waits for the stream) hold one process-wide lock: the kernels of different contexts still overlap on the GPU, the host
+// threads take turns issuing them.  For hosts that run under a tool that hooks the runtime's kernel dispatches (rocprofv3
+// --kernel-trace): several host threads enqueueing at the same moment take that tool's library down -- a SIGSEGV in a copy
+// inside its dispatch callback, on whichever thread is launching (profiles/r05_prof_native_crash.log; never seen without the
+// tool).  The library does not look for such a tool: the host says so (bench.py sets the option on its contexts when it finds
+// the profiler's environment, and reports it), or KVM_SERIALIZE_ENQUEUE=1 makes it the default of the contexts a process opens.
 struct kvm_enqueue_lock {
     std::unique_lock<std::mutex> lk;
-    kvm_enqueue_lock() { again(); }
+    const bool on;
+    explicit kvm_enqueue_lock(const kvm_ctx *ctx) : on(ctx && ctx->opt_serialize_enqueue) { again(); }
     void release() {
         if (lk.owns_lock()) lk.unlock();
     }
     void again() {
-        if (enabled() && !lk.owns_lock()) lk = std::unique_lock<std::mutex>(mu());
+        if (on && !lk.owns_lock()) lk = std::unique_lock<std::mutex>(mu());
     }
     static std::mutex &mu() {
         static std::mutex m;
         return m;
-    }
-    static bool enabled() {
-        static const bool on = [] {
-            if (const char *e = getenv("KVM_SERIALIZE_ENQUEUE"))
-                if (e[0]) return e[0] != '0';
-            for (char **v = environ; v && *v; v++)
-                if (!strncmp(*v, "ROCP", 4) || (!strncmp(*v, "LD_PRELOAD=", 11) && strstr(*v, "rocprofiler"))) return true;
-            return false;
-        }();
-        return on;
     }
 };
 
@@ -179,15 +169,10 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
         HIPCHK(ctx, hipEventSynchronize(ctx->ev_staged));
         ctx->staged_pending = false;
     }
-    // ED pruning kernel: 1 = wave-per-candidate (the cross-check), 3 = LDS-tiled correlation form; 0 = auto (KVM_ED_KERNEL in
-    // the environment overrides auto).  (2, the direct LDS-tiled form, and 4, lane-granular tiles staged by LDS-DMA, were
-    // removed in rounds 3 and 4: the latter stayed 2 - 3 % behind the default -- HISTORY.md.)
-    static const int env_ed_kernel = [] {
-        const char *e = getenv("KVM_ED_KERNEL");
-        const int v = e ? atoi(e) : 0;
-        return (v == 1 || v == 3) ? v : 0;
-    }();
-    const int ed_kernel = ctx->opt_ed_kernel != 0 ? (int)ctx->opt_ed_kernel : (env_ed_kernel ? env_ed_kernel : 3);
+    // ED pruning kernel: 1 = wave-per-candidate (the cross-check), 3 = LDS-tiled correlation form; 0 = auto = 3.  (2, the direct
+    // LDS-tiled form, and 4, lane-granular tiles staged by LDS-DMA, were removed in rounds 3 and 4: the latter stayed 2 - 3 %
+    // behind the default -- HISTORY.md.)
+    const int ed_kernel = ctx->opt_ed_kernel != 0 ? (int)ctx->opt_ed_kernel : 3;
     auto tp_ = std::chrono::steady_clock::now();
     // 32-candidate tiles for the LDS-tiled kernels (ED pruners, fused DTW lower-bound stage), 64 otherwise
     // (DTW cascade: 64-candidate tiles first, trimmed and cut to <= 32 on the device by kvm_retile_dtw_kernel)
@@ -234,8 +219,7 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
     int hybrid_mode = 0;
     if (hybrid) {
         hybrid_mode = kvm_ed_dot_choose_classes(m, pl.n_tiles, pl.n_tiles_b, pl.n_tiles_c, ctx->num_cu, (int)ctx->opt_early_abandon);
-        if (const char *e = getenv("KVM_ED_HYBRID"))  // experiments: force the tiling (1 = classes A / B, 2 = A / B / C)
-            if (e[0] == '1' || e[0] == '2') hybrid_mode = e[0] - '0';
+        if (const int forced = (int)((ctx->opt_ed_force >> 12) & 3); forced == 1 || forced == 2) hybrid_mode = forced;   // KVM_OPT_ED_FORCE
         if (hybrid_mode == 1) {
             pl.n_tiles_b += pl.n_tiles_c;
             pl.n_tiles_c = 0;
@@ -410,13 +394,13 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
             KVM_TP("  retile launch");
             HIPCHK(ctx, kvm_launch_ed_dot(ctx->d_series, ctx->d_prefix, ctx->n, qd, tA, pl.n_tiles, tB, pl.n_tiles, tB, 0, surv,
                                           pl.windows, counters, ctx->num_cu, counters + KVM_CNT_TILES_A, out.d_off, out.d_dist, out.cap,
-                                          stream, nullptr, nullptr, kvm_in_flight(ctx)));
+                                          stream, nullptr, nullptr, kvm_in_flight(ctx), ctx->opt_ed_force, &ctx->last_ed_shape));
             KVM_TP("  ed_dot launch");
         }
         else if (ed_kernel == 3)
             HIPCHK(ctx, kvm_launch_ed_dot(ctx->d_series, ctx->d_prefix, ctx->n, qd, d_tiles, pl.n_tiles, d_tiles + pl.n_tiles,
                                           pl.n_tiles_b, d_tiles + pl.n_tiles + pl.n_tiles_b, pl.n_tiles_c, surv, pl.windows, counters, ctx->num_cu, nullptr, out.d_off, out.d_dist,
-                                          out.cap, stream, self_timed ? ctx->ev0 : nullptr, self_timed ? ctx->ev1 : nullptr, kvm_in_flight(ctx)));
+                                          out.cap, stream, self_timed ? ctx->ev0 : nullptr, self_timed ? ctx->ev1 : nullptr, kvm_in_flight(ctx), ctx->opt_ed_force, &ctx->last_ed_shape));
         else
             HIPCHK(ctx, kvm_launch_ed_wave(ctx->d_series, ctx->d_prefix, ctx->n, qd, d_tiles, n_tiles, surv,
                                            pl.windows, counters, stream));
@@ -675,7 +659,7 @@ static int verify_host(kvm_ctx *ctx, int variant, const double *query, int32_t m
     int64_t kernel_ns = 0;
     kvm_query_dev dtw_qd;
     kvm_dtw_aux dtw_ax;
-    kvm_enqueue_lock enq;   // (only under a tool that hooks the launches: see above)
+    kvm_enqueue_lock enq(ctx);   // (KVM_OPT_SERIALIZE_ENQUEUE)
     rc = run_variant(ctx, variant, query, m, left, right, k, shift, epsilon, rho, alpha, beta, pl, out, ctx->stream,
                      &kernel_ns, dtw_qd, dtw_ax);
     if (rc) return rc;
@@ -831,7 +815,7 @@ extern "C" int kvm_verify_device(kvm_ctx *ctx, int32_t variant, const double *qu
     // (run_variant clears done_pending once this call's stream is ordered behind the previous call, before it enqueues
     // anything: a failure that leaves the flag set -- an argument error -- has enqueued nothing, and the previous call's
     // mark must stay in place)
-    kvm_enqueue_lock enq;   // (only under a tool that hooks the launches: see the top of this file; declared before the guard
+    kvm_enqueue_lock enq(ctx);   // (KVM_OPT_SERIALIZE_ENQUEUE: see the top of this file; declared before the guard
     // below, so that the guard's event is recorded while the lock is still held)
     int rc = run_variant(ctx, variant, query, m, left, right, k, shift, epsilon, rho, alpha, beta, pl, out, s, nullptr, dtw_qd,
                          dtw_ax);
@@ -863,7 +847,7 @@ extern "C" int kvm_pack_answers_device(kvm_ctx *ctx, const int32_t *d_off, const
     if (!ctx) return KVM_ERR_INVALID_HANDLE;
     if (!d_off || !d_dist || !d_count || !d_packed || pack_cap < 0)
         return kvm_fail(ctx, KVM_ERR_ILLEGAL_ARGUMENT, "bad kvm_pack_answers_device arguments");
-    kvm_enqueue_lock enq;
+    kvm_enqueue_lock enq(ctx);
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, kvm_launch_pack_answers(d_off, d_dist, d_count, pack_cap, (double2 *)d_packed,
                                         stream ? (hipStream_t)stream : ctx->stream));

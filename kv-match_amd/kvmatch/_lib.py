@@ -30,6 +30,18 @@ STAT_WINDOWS, STAT_PASS_FILTER, STAT_PASS_LB_KIM, STAT_PASS_LB_KEOGH, STAT_PASS_
     STAT_RECHECKED, STAT_DTW_SEQUENTIAL = range(8)
 OPT_EARLY_ABANDON, OPT_LB_CASCADE, OPT_ED_KERNEL, OPT_TIMING, OPT_DP_KERNEL, OPT_SORT_VIOLATION, OPT_UCR_LOOPS, \
     OPT_STRICT_BOUNDS, OPT_IN_FLIGHT = 1, 2, 3, 4, 5, 6, 7, 8, 9
+OPT_ED_FORCE, OPT_SERIALIZE_ENQUEUE, OPT_ED_LAST_SHAPE = 10, 11, 12
+
+
+def ed_force(split_a=0, split_b=0, a16=0, b16=0, classes=0, dev_a16_any=0, dev_no_split=0):
+    """KVM_ED_FORCE of include/kvmatch.h: the value of OPT_ED_FORCE (0 = the launcher's model decides that part)."""
+    return split_a | (split_b << 4) | (a16 << 8) | (b16 << 10) | (classes << 12) | (dev_a16_any << 14) | (dev_no_split << 15)
+
+
+def ed_shape(value):
+    """OPT_ED_LAST_SHAPE decoded: window splits, candidates per lane of classes A / B, queries in flight planned for."""
+    return {"split_a": value & 15, "split_b": (value >> 4) & 15, "per_lane_a": {1: 8, 2: 16}.get((value >> 8) & 3),
+            "per_lane_b": {1: 4, 2: 8}.get((value >> 10) & 3), "in_flight": (value >> 16) & 255}
 
 # every symbol include/kvmatch.h declares (checked by tests/test_abi.py)
 SYMBOLS = [

@@ -253,7 +253,7 @@ class ShardedStream:
             if i:
                 from . import _lib
                 for opt in (_lib.OPT_EARLY_ABANDON, _lib.OPT_LB_CASCADE, _lib.OPT_ED_KERNEL, _lib.OPT_TIMING, _lib.OPT_DP_KERNEL,
-                            _lib.OPT_SORT_VIOLATION, _lib.OPT_UCR_LOOPS, _lib.OPT_STRICT_BOUNDS):
+                            _lib.OPT_SORT_VIOLATION, _lib.OPT_UCR_LOOPS, _lib.OPT_STRICT_BOUNDS, _lib.OPT_ED_FORCE, _lib.OPT_SERIALIZE_ENQUEUE):
                     c.set_option(opt, ctx.get_option(opt))
             stream = torch.cuda.Stream(device=self.dev)
             v = ShardedVerifier(c, variant, max_candidates, group=group, pack_cap=pack_cap)

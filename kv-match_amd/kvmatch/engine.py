@@ -355,7 +355,7 @@ class QueryStream:
         self.ctxs = [ctx] + [Phase2Context(ctx.device).share_series(ctx) for _ in range(max(1, int(in_flight)) - 1)]
         for c in self.ctxs[1:]:
             for opt in (_lib.OPT_EARLY_ABANDON, _lib.OPT_LB_CASCADE, _lib.OPT_ED_KERNEL, _lib.OPT_TIMING, _lib.OPT_DP_KERNEL,
-                        _lib.OPT_SORT_VIOLATION, _lib.OPT_UCR_LOOPS, _lib.OPT_STRICT_BOUNDS):
+                        _lib.OPT_SORT_VIOLATION, _lib.OPT_UCR_LOOPS, _lib.OPT_STRICT_BOUNDS, _lib.OPT_ED_FORCE, _lib.OPT_SERIALIZE_ENQUEUE):
                 c.set_option(opt, ctx.get_option(opt))
 
     def set_option(self, option, value):

@@ -30,6 +30,7 @@ def main():
     want = [oracle.rsm_ed(s, q, L, R, 0, 6.0), oracle.cnsm_ed(s, q, L, R, 0, 3.0, 1.5, 2.0),
             oracle.rsm_dtw(s, q, L, R, 0, 6.0, rho), oracle.cnsm_dtw(s, q, L, R, 0, 3.0, rho, 1.5, 2.0)]
     ctx = kvmatch.Phase2Context(0)
+    assert ctx.get_option(kvmatch.OPT_SERIALIZE_ENQUEUE) == 1     # (the default of a process started with the variable set)
     ctx.load_series(s)
     ctx.set_option(kvmatch.OPT_EARLY_ABANDON, 0)
     jobs = [kvmatch.Job(0, (L, R), 1, q, 6.0), kvmatch.Job(1, (L, R), 1, q, 3.0, alpha=1.5, beta=2.0),

@@ -1301,7 +1301,7 @@ def test_ed_pruner_tile_classes_every_remainder_length(world):
 
 def test_ed_pruner_every_window_split_and_awkward_window_lengths(world):
     """The launcher shares a unit between 1, 2 or 4 waves (each takes a range of 128-point chunks, part 0 finishes the
-    candidates): every split pair forced through KVM_ED_SPLIT, window lengths that leave 1..127 points for the last chunk, fewer
+    candidates): every split pair forced through KVM_OPT_ED_FORCE, window lengths that leave 1..127 points for the last chunk, fewer
     chunks than parts (m = 200 split four ways: two parts have no chunk), runs of all three tile classes with a planted copy
     each; RSM-ED with every point evaluated (the device-built lists of cNSM-ED and of early abandoning split by themselves),
     bit for bit against the oracle."""
@@ -1325,11 +1325,14 @@ def test_ed_pruner_every_window_split_and_awkward_window_lengths(world):
             ctx.load_series(s)
             want = oracle.rsm_ed(s, q, L, R, 0, 2.0)
             assert len(want[0]) >= len(lengths)
-            for sp in ("1,1", "1,2", "1,4", "2,1", "2,2", "2,4", "4,1", "4,2", "4,4"):
-                os.environ["KVM_ED_SPLIT"] = sp
-                compare(kvmatch.QueryEngine(ctx).verify((L, R), 1, q, 2.0), want, tag=f"split {sp} m={m}")
+            for fa in (1, 2, 4):
+                for fb in (1, 2, 4):
+                    ctx.set_option(kvmatch.OPT_ED_FORCE, kvmatch.ed_force(split_a=fa, split_b=fb))
+                    compare(kvmatch.QueryEngine(ctx).verify((L, R), 1, q, 2.0), want, tag=f"split {fa},{fb} m={m}")
+                    sh = kvmatch.ed_shape(ctx.get_option(kvmatch.OPT_ED_LAST_SHAPE))
+                    assert (sh["split_a"], sh["split_b"]) == (fa, fb)
     finally:
-        os.environ.pop("KVM_ED_SPLIT", None)
+        ctx.set_option(kvmatch.OPT_ED_FORCE, 0)
         ctx.set_option(kvmatch.OPT_EARLY_ABANDON, 1)
         ctx.load_series(series)
 
@@ -1647,16 +1650,17 @@ def test_residue_of_a_spike_in_the_references_running_sums(built):
                         tag=f"spike dtw scale={scale} burst={burst} eps={eps}")
 
 
-def test_ed_pruner_sixteen_per_lane_form_on_every_list_shape(world, monkeypatch, capfd):
+def test_ed_pruner_sixteen_per_lane_form_on_every_list_shape(world):
     """Class A of the ED pruner on 16 candidates per lane (round 5: 16 rows x 4 lanes, ring-staged rows, compile-time loops) is
-    chosen by the launcher for long lists only; here it is FORCED (KVM_ED_A16=1 on host-planned lists; device-built cNSM lists
-    through KVM_ED_A16_MIN_UNITS=0 and KVM_ED_SPLIT_UNITS=0) with early abandoning off, over window lengths that do and do not
-    end on a chunk boundary (25 .. 4097: the last revolution runs on the zeros behind the query), every window split, lists
+    chosen by the launcher for long lists only; here it is FORCED (KVM_OPT_ED_FORCE: the form of class A on host-planned lists;
+    device-built cNSM lists of any size through it, never split) with early abandoning off, over window lengths that do and do
+    not end on a chunk boundary (25 .. 4097: the last revolution runs on the zeros behind the query), every window split, lists
     of short, long and single-candidate runs, a shifted list and runs that end on the last window of the series.  Answers,
-    order and every distance equal the oracle's; so does the 8-per-lane form's (KVM_ED_A16=0) on the same calls."""
+    order and every distance equal the oracle's; so does the 8-per-lane form's on the same calls.  What ran is read back
+    (KVM_OPT_ED_LAST_SHAPE)."""
     kvmatch, datagen, series, ctx = world
-    monkeypatch.setenv("KVM_ED_A16_MIN_UNITS", "0")
-    monkeypatch.setenv("KVM_ED_SPLIT_UNITS", "0")
+    F = kvmatch.ed_force
+    shape = lambda c=None: kvmatch.ed_shape((c or ctx).get_option(kvmatch.OPT_ED_LAST_SHAPE))  # noqa: E731
     ctx.set_option(kvmatch.OPT_EARLY_ABANDON, 0)
     try:
         n = len(series)
@@ -1675,66 +1679,55 @@ def test_ed_pruner_sixteen_per_lane_form_on_every_list_shape(world, monkeypatch,
                 shift = (ls - 1) * 25
                 want_r = oracle.rsm_ed(s, q, ll, rr, shift, eps)
                 want_c = oracle.cnsm_ed(s, q, ll, rr, shift, eps, 1.5, 3.0)
-                for form in ("1b", "1", "0"):    # ("1b": class B on the four-lane rows as well, 8 per lane -- KVM_ED_B16)
-                    monkeypatch.setenv("KVM_ED_A16", form[0])
-                    monkeypatch.setenv("KVM_ED_B16", "1" if form == "1b" else "0")
-                    for split in (("1,1", "2,2", "4,4") if form != "0" and name != "single candidates" else ("",)):
-                        if split:
-                            monkeypatch.setenv("KVM_ED_SPLIT", split)
-                        else:
-                            monkeypatch.delenv("KVM_ED_SPLIT", raising=False)
+                # ("16+8": class B on the four-lane rows as well, 8 candidates per lane)
+                for form, a16, b16 in (("16+8", 2, 2), ("16", 2, 1), ("8", 1, 1)):
+                    for split in ((1, 2, 4) if form != "8" and name != "single candidates" else (0,)):
+                        ctx.set_option(kvmatch.OPT_ED_FORCE, F(split_a=split, split_b=split, a16=a16, b16=b16, dev_a16_any=1, dev_no_split=1))
                         compare(kvmatch.QueryEngine(ctx).verify((ll, rr), ls, q, eps), want_r, tag=f"rsm m={m} {name} form={form} split={split}")
-                    monkeypatch.delenv("KVM_ED_SPLIT", raising=False)
+                    ctx.set_option(kvmatch.OPT_ED_FORCE, F(a16=a16, b16=b16, dev_a16_any=1, dev_no_split=1))
                     compare(kvmatch.NormQueryEngine(ctx).verify((ll, rr), ls, q, eps, 1.5, 3.0), want_c, tag=f"cnsm m={m} {name} form={form}")
-        # (the launcher's trace says which form ran)
-        monkeypatch.setenv("KVM_ED_A16", "1")
-        monkeypatch.setenv("KVM_ED_B16", "1")
-        monkeypatch.setenv("KVM_TRACE", "1")
-        capfd.readouterr()
+        # which form ran
+        ctx.set_option(kvmatch.OPT_ED_FORCE, F(a16=2, b16=2))
         kvmatch.QueryEngine(ctx).verify((L, R), 1, q, eps)
-        err = capfd.readouterr().err
-        assert "(16 per lane)" in err and "(class B 8 per lane)" in err
-        monkeypatch.setenv("KVM_ED_A16", "0")
+        assert (shape()["per_lane_a"], shape()["per_lane_b"]) == (16, 8)
+        ctx.set_option(kvmatch.OPT_ED_FORCE, F(a16=1))
         kvmatch.QueryEngine(ctx).verify((L, R), 1, q, eps)
-        err = capfd.readouterr().err
-        assert "(8 per lane)" in err and "(class B 4 per lane)" in err
+        assert (shape()["per_lane_a"], shape()["per_lane_b"]) == (8, 4)
         # Left to itself the launcher takes class B to the four-lane rows where other queries run next to this one: told by
         # the caller (KVM_OPT_IN_FLIGHT) or by kvm_run_jobs for the contexts of its call -- and only for its duration
-        monkeypatch.delenv("KVM_ED_B16")
-        monkeypatch.setenv("KVM_ED_A16", "1")
+        ctx.set_option(kvmatch.OPT_ED_FORCE, F(a16=2))
         want = oracle.rsm_ed(s, q, L, R, 0, eps)
         kvmatch.QueryEngine(ctx).verify((L, R), 1, q, eps)
-        err = capfd.readouterr().err
-        assert "(class B 4 per lane)" in err and "in flight 1\n" in err
+        assert shape()["per_lane_b"] == 4 and shape()["in_flight"] == 1
         ctx.set_option(kvmatch.OPT_IN_FLIGHT, 8)
         assert ctx.get_option(kvmatch.OPT_IN_FLIGHT) == 8
         compare(kvmatch.QueryEngine(ctx).verify((L, R), 1, q, eps), want, tag="KVM_OPT_IN_FLIGHT 8")
-        err = capfd.readouterr().err
-        assert "(class B 8 per lane)" in err and "in flight 8\n" in err
+        assert shape()["per_lane_b"] == 8 and shape()["in_flight"] == 8
         ctx.set_option(kvmatch.OPT_IN_FLIGHT, 1)
         qs = kvmatch.QueryStream(ctx, in_flight=3)
         try:
             jobs = [kvmatch.Job(0, (L, R), 1, q, eps) for _ in range(6)]
             for got in qs.run_jobs(jobs):
                 compare(got, want, tag="run_jobs, 3 in flight")
-            err = capfd.readouterr().err
-            assert err.count("in flight 3\n") == 6 and "in flight 1\n" not in err and err.count("(class B 8 per lane)") == 6
+            for c in qs.ctxs:     # (the contexts of the call were told for its duration: every launch planned for 3 in flight)
+                assert shape(c)["in_flight"] == 3 and shape(c)["per_lane_b"] == 8
             for got in qs.run([(lambda c: kvmatch.QueryEngine(c).verify((L, R), 1, q, eps)) for _ in range(2)]):
                 compare(got, want, tag="QueryStream.run, 2 jobs on 3 contexts")
-            assert capfd.readouterr().err.count("in flight 2\n") == 2
+            assert sum(shape(c)["in_flight"] == 2 for c in qs.ctxs) == 2
         finally:
             qs.close()
         kvmatch.QueryEngine(ctx).verify((L, R), 1, q, eps)
-        assert "in flight 1\n" in capfd.readouterr().err
+        assert shape()["in_flight"] == 1
     finally:
+        ctx.set_option(kvmatch.OPT_ED_FORCE, 0)
         ctx.set_option(kvmatch.OPT_EARLY_ABANDON, 1)
         ctx.load_series(series)
 
 
 def test_streams_with_the_enqueue_lock_forced(built):
-    """Under a tool that hooks the kernel dispatches the library's calls take turns enqueueing (kvm_enqueue_lock, kvm_verify.hip:
-    what lets `rocprofv3 --kernel-trace -- python3 bench.py` complete every time).  The lock is decided once per process, from
-    the environment: a child process runs a mixed stream of all four variants through kvm_run_jobs and through the
+    """KVM_OPT_SERIALIZE_ENQUEUE: the calls of a host that runs under a tool hooking the kernel dispatches take turns enqueueing
+    (kvm_enqueue_lock, kvm_verify.hip: what lets `rocprofv3 --kernel-trace -- python3 bench.py` complete every time).  Its
+    default comes from the environment once per process: a child process runs a mixed stream of all four variants through kvm_run_jobs and through the
     device-resident slots with KVM_SERIALIZE_ENQUEUE=1 -- every lock / release / re-lock path, the DTW calls' wait in the
     middle included -- and compares with the oracle."""
     import subprocess
