@@ -800,9 +800,12 @@ extern "C" int kvm_verify_device(kvm_ctx *ctx, int32_t variant, const double *qu
     struct done_guard {
         kvm_ctx *c;
         hipStream_t s;
-        bool armed;
         ~done_guard() {
-            if (armed && hipSetDevice(c->device) == hipSuccess && hipEventRecord(c->ev_done, s) == hipSuccess) {
+            // (armed by what run_variant left behind: it clears done_pending once this call's stream is ordered behind the previous
+            // call, before it enqueues anything -- so a cleared flag means "this call may have enqueued", whether it then
+            // returned, failed half-way or threw; a flag still set means an argument error that enqueued nothing, and the
+            // previous call's mark stays in place)
+            if (!c->done_pending && hipSetDevice(c->device) == hipSuccess && hipEventRecord(c->ev_done, s) == hipSuccess) {
                 c->done_stream = s;
                 c->done_pending = true;
             }
@@ -812,14 +815,11 @@ extern "C" int kvm_verify_device(kvm_ctx *ctx, int32_t variant, const double *qu
     verify_out out{d_out_off, d_out_dist, cap, false};
     kvm_query_dev dtw_qd;
     kvm_dtw_aux dtw_ax;
-    // (run_variant clears done_pending once this call's stream is ordered behind the previous call, before it enqueues
-    // anything: a failure that leaves the flag set -- an argument error -- has enqueued nothing, and the previous call's
-    // mark must stay in place)
     kvm_enqueue_lock enq(ctx);   // (KVM_OPT_SERIALIZE_ENQUEUE: see the top of this file; declared before the guard
     // below, so that the guard's event is recorded while the lock is still held)
+    done_guard guard{ctx, s};    // (before run_variant: an exception out of it -- std::bad_alloc -- leaves through the guard too)
     int rc = run_variant(ctx, variant, query, m, left, right, k, shift, epsilon, rho, alpha, beta, pl, out, s, nullptr, dtw_qd,
                          dtw_ax);
-    done_guard guard{ctx, s, rc == KVM_OK || !ctx->done_pending};
     if (rc) return rc;
     if (cnt_candidate) *cnt_candidate = pl.cnt_candidate;
     if (variant >= V_RSM_DTW && pl.n_tiles + pl.n_tiles_b + pl.n_tiles_c > 0) {

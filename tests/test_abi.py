@@ -270,7 +270,11 @@ def test_no_scalar_select_on_a_stale_scc_in_the_device_code(tmp_path):
     from concurrent.futures import ThreadPoolExecutor
     csrc = os.path.join(ROOT, "kv-match_amd", "csrc")
     srcs = sorted(f for f in os.listdir(csrc) if f.endswith(".hip"))
-    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-S", "--cuda-device-only"]
+    # (the flags of the shipped build, from its Makefile -- not a hand-kept copy that can drift from it)
+    mk = subprocess.run(["make", "-pn", "-C", csrc, "libkvmatch_hip.so"], capture_output=True, text=True).stdout
+    hipflags = next(l.split("=", 1)[1].split() for l in mk.splitlines() if l.startswith("HIPFLAGS :="))   # (printed expanded)
+    flags = [f for f in hipflags if not f.startswith("-W")] + ["-S", "--cuda-device-only"]
+    assert "--offload-arch=gfx950" in flags and "-ffp-contract=off" in flags and "-O3" in flags, flags
 
     def asm(f):
         out = str(tmp_path / (f[:-4] + ".s"))
