@@ -10,8 +10,9 @@
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_r06
-rm -rf $OUT; mkdir -p $OUT
 STEP=${1:-all}
+if [ $STEP = all ]; then rm -rf $OUT; fi
+mkdir -p $OUT
 if [ $STEP = all ] || [ $STEP = bench ]; then
 timeout -k 10 1000 python3 bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; echo "default rc $?"
 fi

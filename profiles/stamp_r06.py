@@ -67,8 +67,9 @@ if d:
     d["derived"] = {
         "lds_bank_conflict_share_of_idx_active": lds.get("SQ_LDS_BANK_CONFLICT", 0) / max(1.0, lds.get("SQ_LDS_IDX_ACTIVE", 0)),
         "valu_insts_per_dp": sq.get("SQ_INSTS_VALU", 0) / 66762.0 if sq.get("SQ_INSTS_VALU") else None,
-        "mean_waves_per_simd_while_busy": (sq.get("SQ_WAVE_CYCLES", 0) / max(1.0, sq.get("SQ_BUSY_CYCLES", 0))) if sq else None,
-        "valu_issue_share_of_wave_cycles": sq.get("SQ_ACTIVE_INST_VALU", 0) / max(1.0, sq.get("SQ_WAVE_CYCLES", 0)) if sq else None}
+        "waves_per_simd": sq.get("SQ_WAVES", 0) / 1024.0 if sq else None,   # (persistent waves: each pops DPs from the list until it is drained)
+        "valu_active_share_of_wave_cycles": sq.get("SQ_ACTIVE_INST_VALU", 0) / max(1.0, sq.get("SQ_WAVE_CYCLES", 0)) if sq else None,
+        "wait_inst_any_share_of_wave_cycles": sq.get("SQ_WAIT_INST_ANY", 0) / max(1.0, sq.get("SQ_WAVE_CYCLES", 0)) if sq else None}
     d["kvm_dtw_sha16"] = sha("kvm_dtw.hip")
     d["kvm_dtw_dp_h_sha16"] = sha("kvm_dtw_dp.h")
     d["workload"] = "profiles/dp_slice.py: cNSM-DTW m = 4096, rho = 204, the 66 762 candidates of bench.py's roofline_dtw.full_dp slice, cascade and abandoning off"
