@@ -15,13 +15,18 @@
 //            #intervals, running #offsets} (ByteUtils.listTripleToByteArray); the table of line offsets, whose last entry
 //            is its own position (IndexFileOperator.writeAll / readOffsetInfo).  Offsets are Java ints: an image of 2 GiB
 //            or more is refused.
-// The walk is sequential by nature (each decision depends on the row merged so far): one pass per attempted union, read
-// straight from the grouped step-1 arrays; the lines of the file are encoded by a few host threads.
+// The walk is sequential (each decision depends on the row merged so far) except at the rows the rule never merges, where it
+// starts afresh: the row sequence is cut there and walked by several host threads (see kvm_index_build); one pass per attempted
+// union, read straight from the grouped step-1 arrays; the lines of the file are encoded by the same number of host threads.
 #include "kvm_guard.h"
 #include <algorithm>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <deque>
+#include <memory>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -31,7 +36,8 @@
 void kvm_set_error(kvm_ctx *ctx, const std::string &msg);  // kvm_api.hip
 
 struct kvm_index_file {
-    std::vector<uint8_t> image;
+    std::unique_ptr<uint8_t[]> image;   // (not a vector: its threads first-touch their own parts; nothing zero-fills 100 MB)
+    size_t image_size = 0;
     int64_t rows_before = 0, rows_after = 0, intervals_before = 0, intervals_after = 0;
     double step1_ms = 0, step2_ms = 0, encode_ms = 0;
 };
@@ -58,9 +64,31 @@ struct vec_view {
     ival at(int64_t i) const { return p[i]; }
 };
 
-// IndexNodeUtils.mergeIndexNode; Emit(first, last) receives every interval handed to addInterval
-template <class N1, class N2, class Emit>
-inline void merge_walk(const N1 &n1, const N2 &n2, Emit emit) {
+// IndexNodeUtils.mergeIndexNode; Emit(first, last) receives every interval handed to addInterval.
+// Bulk(view, i, j) receives a RUN of intervals [i, j) of one list that the walk would hand over one by one unchanged -- every one
+// of them ends more than one position before the interval the other list is holding (`l.last + 1 < other.first`: emitted as it
+// is, the held interval untouched).  The run's end is found by galloping (1, 2, 4 ... then bisection): where a short row is
+// merged into a long union -- the chains of sparse rows at both ends of the key range, the sequential part of step 2 -- most of
+// the long list goes through in runs, copied instead of compared one by one.  Same intervals, same order.
+template <class N>
+inline int64_t run_end(const N &n, int64_t i, int64_t size, int32_t other_first) {
+    // the first index >= i whose interval does NOT end more than one position before other_first (ends are ascending)
+    int64_t step = 1, lo = i, hi = i + 1;
+    while (hi < size && (int64_t)n.at(hi).last + 1 < other_first) {
+        lo = hi;
+        step *= 2;
+        hi = std::min(size, hi + step);
+    }
+    // n[lo] qualifies; n[hi] does not (or hi == size)
+    while (lo + 1 < hi) {
+        const int64_t mid = lo + (hi - lo) / 2;
+        if ((int64_t)n.at(mid).last + 1 < other_first) lo = mid;
+        else hi = mid;
+    }
+    return hi;
+}
+template <class N1, class N2, class Emit, class Bulk1, class Bulk2>
+inline void merge_walk(const N1 &n1, const N2 &n2, Emit emit, Bulk1 bulk1, Bulk2 bulk2) {
     const int64_t s1 = n1.size(), s2 = n2.size();
     int64_t i1 = 0, i2 = 0;
     bool h1 = false, h2 = false;
@@ -72,10 +100,21 @@ inline void merge_walk(const N1 &n1, const N2 &n2, Emit emit) {
             emit(l1.first, l1.last);
             i1++;
             h1 = false;
+            // (the intervals behind it are fresh ones of list 1: a run of them that also ends before l2 goes over as it is)
+            if (i1 + 1 < s1 && (int64_t)n1.at(i1 + 1).last + 1 < l2.first) {
+                const int64_t j = run_end(n1, i1, s1, l2.first);
+                bulk1(n1, i1, j);
+                i1 = j;
+            }
         } else if (l2.last + 1 < l1.first) {
             emit(l2.first, l2.last);
             i2++;
             h2 = false;
+            if (i2 + 1 < s2 && (int64_t)n2.at(i2 + 1).last + 1 < l1.first) {
+                const int64_t j = run_end(n2, i2, s2, l1.first);
+                bulk2(n2, i2, j);
+                i2 = j;
+            }
         } else if (l1.last < l2.last) {
             if (l1.first < l2.first) l2.first = l1.first;
             i1++;
@@ -108,37 +147,40 @@ inline void put_be_double(uint8_t *p, double v) {
     for (int b = 0; b < 8; b++) p[b] = (uint8_t)(u >> (56 - 8 * b));
 }
 
-// IndexNode.toBytesCompact; appends to `out`
-void encode_compact(const ival *pos, int64_t size, std::vector<uint8_t> &out) {
-    const size_t base = out.size();
-    out.resize(base + (size_t)size * 8);
-    uint8_t *result = out.data() + base;
+// IndexNode.toBytesCompact into `result` (nullptr: only the length): groups of up to 255 intervals as
+// {left:int32 BE}{count-1}{right-left}{gap}{right-left}..., every small number biased by -128.  Returns the length.
+template <bool WRITE>
+int64_t encode_compact(const ival *pos, int64_t size, uint8_t *result) {
     int64_t index = 0, length = 0;
     int count = 0;
     bool packing = false;
     while (index < size) {
         if (!packing) {
-            put_be32(result + length, pos[index].first);
+            if (WRITE) put_be32(result + length, pos[index].first);
             length += 4 + 1;
-            result[length++] = (uint8_t)(pos[index].last - pos[index].first - 128);
+            if (WRITE) result[length] = (uint8_t)(pos[index].last - pos[index].first - 128);
+            length++;
             packing = true;
             count = 1;
         } else {
             const int32_t gap = pos[index].first - pos[index - 1].last;
             if (gap < MAXIMUM_DIFF && (count - 1) / 2 + 2 < MAXIMUM_DIFF) {
-                result[length++] = (uint8_t)(gap - 128);
-                result[length++] = (uint8_t)(pos[index].last - pos[index].first - 128);
+                if (WRITE) {
+                    result[length] = (uint8_t)(gap - 128);
+                    result[length + 1] = (uint8_t)(pos[index].last - pos[index].first - 128);
+                }
+                length += 2;
                 count += 2;
             } else {
-                result[length - count - 1] = (uint8_t)((count - 1) / 2 - 128);
+                if (WRITE) result[length - count - 1] = (uint8_t)((count - 1) / 2 - 128);
                 packing = false;
                 continue;
             }
         }
         index++;
     }
-    if (packing) result[length - count - 1] = (uint8_t)((count - 1) / 2 - 128);
-    out.resize(base + (size_t)length);
+    if (packing && WRITE) result[length - count - 1] = (uint8_t)((count - 1) / 2 - 128);
+    return length;
 }
 
 double now_ms() {
@@ -179,32 +221,70 @@ extern "C" int kvm_index_build(kvm_ctx *ctx, int32_t w, kvm_index_file **out) {
     // ---- step 2.  Group g is rawStatisticInfo.get(g) (descending key); its size is goff[g+1] - goff[g].
     // StatisticInfo.getAverage: the double sum of the sizes (exact: integers far below 2^53) over their number.
     const double average = (double)cnt / (double)G;
-    std::vector<ival> stored;                 // intervals of the finished rows, in the order they are finished
-    std::vector<int64_t> stored_off{0};       // row r = stored[stored_off[r], stored_off[r+1])
-    std::vector<double> stored_key;
-    stored.reserve((size_t)cnt);
-    // `last` is either row g_last as step 1 left it (a view into the grouped arrays) or the union built so far (`acc`)
-    std::vector<ival> acc, merged;
-    bool last_is_raw = true;
-    int64_t g_last = 0;
-    auto raw = [&](int64_t g) { return raw_view{rf + goff[g], rl + goff[g], (int64_t)goff[g + 1] - goff[g]}; };
-    auto store = [&](double key) {
-        if (last_is_raw) {
-            const raw_view v = raw(g_last);
-            for (int64_t i = 0; i < v.n; i++) stored.push_back(v.at(i));
-        } else {
-            stored.insert(stored.end(), acc.begin(), acc.end());
-        }
-        stored_off.push_back((int64_t)stored.size());
-        stored_key.push_back(key);
+    // The walk is sequential: whether row i is merged depends on the row built so far.  But it FORGETS: whenever row i is not
+    // merged, the row built so far is finished and the walk goes on from row i alone -- its state then is a function of i.  So the
+    // row sequence is cut into ranges of equal interval count and every range is walked by a host thread that ASSUMES such a
+    // fresh start at its first row; two walks that start afresh at the same row are the same walk from there on.  Afterwards the
+    // ranges are stitched in order: the true walk (thread 0's; later the walk carried over a boundary) continues into the next
+    // range until it starts afresh at a row where that range's own walk did too -- a few rows, fresh starts come every four rows
+    // on average -- and from that row on the range's finished rows are the true ones.  Same rows, same order as one thread's
+    // walk (rounds 4 - 5: 138 ms at n = 1e8, Wu = 50; the sparse rows at both ends of the key range are one unbroken chain of
+    // small rows each, so cutting only at rows the rule can never merge left two threads with twice the work of the others).
+    // Finished rows never hold more intervals than the rows they were made of (a union is kept only if it is shorter than
+    // 0.8 x its parts), so a range's thread writes its finished rows into ONE buffer of `cnt` intervals from the position of its
+    // first row on; what the stitching finishes goes into small side buffers.
+    // (the buffer is kept between calls -- a process builds the five indexes of a series one after the other, and giving
+    // 400 MB back to the system and faulting them in again cost 50 ms per call; a call that finds it taken allocates its own)
+    struct kept_buffer {
+        std::mutex mu;
+        std::unique_ptr<ival[]> p;
+        size_t cap = 0;
     };
-    for (int64_t i = 1; i < G; i++) {
+    static kept_buffer *kept = new kept_buffer();   // (never destroyed: a call may be running at exit)
+    std::unique_lock<std::mutex> kept_lock(kept->mu, std::try_to_lock);
+    std::unique_ptr<ival[]> own;
+    ival *stored;
+    if (kept_lock.owns_lock()) {
+        if (kept->cap < (size_t)cnt + 1) {
+            kept->p.reset();
+            kept->p.reset(new ival[(size_t)cnt + 1]);
+            kept->cap = (size_t)cnt + 1;
+        }
+        stored = kept->p.get();
+    } else {
+        own.reset(new ival[(size_t)cnt + 1]);
+        stored = own.get();
+    }
+    struct row_t {
+        const ival *p;       // the finished row's intervals
+        int64_t n;
+        double key;
+        int64_t first_row;   // the row of step 1 the walk started this row at
+    };
+    struct chain {           // the walk's state: the row being built
+        std::vector<ival> acc, merged;
+        bool last_is_raw = true;   // it is still row g_last as step 1 left it (a view into the grouped arrays), not a union (`acc`)
+        int64_t g_last = 0, first_row = 0;
+    };
+    auto raw = [&](int64_t g) { return raw_view{rf + goff[g], rl + goff[g], (int64_t)goff[g + 1] - goff[g]}; };
+    auto chain_size = [&](const chain &c) { return c.last_is_raw ? raw(c.g_last).n : (int64_t)c.acc.size(); };
+    auto chain_copy = [&](const chain &c, ival *dst) {
+        if (c.last_is_raw) {
+            const raw_view v = raw(c.g_last);
+            for (int64_t i = 0; i < v.n; i++) dst[i] = v.at(i);
+        } else {
+            std::memcpy(dst, c.acc.data(), c.acc.size() * sizeof(ival));
+        }
+    };
+    // row i meets the chain: merged into it -- or the chain's row is finished (finish(key)) and row i starts the next
+    auto step = [&](chain &c, int64_t i, auto &&finish) {
         const raw_view cur = raw(i);
         bool is_merged = false;
         if ((double)cur.n < average * 1.2) {
             // the union, built in one pass (IndexNodeUtils.addInterval cuts every piece to <= 256 positions) and kept
             // only if it is short enough
-            const int64_t last_n = last_is_raw ? raw(g_last).n : (int64_t)acc.size();
+            const int64_t last_n = chain_size(c);
+            std::vector<ival> &merged = c.merged;
             merged.clear();
             auto emit = [&](int32_t a, int32_t b) {
                 while (b - a >= MAXIMUM_DIFF) {
@@ -213,117 +293,203 @@ extern "C" int kvm_index_build(kvm_ctx *ctx, int32_t w, kvm_index_file **out) {
                 }
                 merged.push_back(ival{a, b});
             };
-            if (last_is_raw) merge_walk(raw(g_last), cur, emit);
-            else merge_walk(vec_view{acc.data(), (int64_t)acc.size()}, cur, emit);
+            // (a run of untouched intervals: those of a union are cut already, those of a step-1 row span at most 255
+            // positions -- addInterval would hand each of them on as it is)
+            auto bulk_raw = [&](const raw_view &v, int64_t i0, int64_t j) {
+                for (int64_t t = i0; t < j; t++) merged.push_back(v.at(t));
+            };
+            auto bulk_vec = [&](const vec_view &v, int64_t i0, int64_t j) { merged.insert(merged.end(), v.p + i0, v.p + j); };
+            if (c.last_is_raw) merge_walk(raw(c.g_last), cur, emit, bulk_raw, bulk_raw);
+            else merge_walk(vec_view{c.acc.data(), (int64_t)c.acc.size()}, cur, emit, bulk_vec, bulk_raw);
             if ((double)merged.size() < (double)(last_n + cur.n) * 0.8) {
-                acc.swap(merged);
-                last_is_raw = false;
+                c.acc.swap(merged);
+                c.last_is_raw = false;
                 is_merged = true;
             }
         }
         if (!is_merged) {
-            store(gkey[i - 1]);
-            last_is_raw = true;
-            g_last = i;
+            finish(gkey[i - 1]);
+            c.last_is_raw = true;
+            c.g_last = c.first_row = i;
+        }
+        return !is_merged;   // the walk started afresh at row i
+    };
+    struct walked {
+        int64_t b0 = 0, b1 = 0;    // rows [b0, b1)
+        std::vector<row_t> rows;   // finished, in order
+        chain pending;             // the row being built when the range ended
+    };
+    const int nw = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)std::max(1u, std::thread::hardware_concurrency()), 16, G / 64 + 1}));
+    std::vector<walked> parts(1);
+    for (int t = 1; t < nw; t++) {
+        // ranges of about equal interval count, cut where the true walk certainly starts afresh: at the first row behind the
+        // share point that is never merged (a row of at least 1.2 x the average); the stitching then joins at once.  The sparse
+        // rows at both ends of the key range form chains without such a row, in which two walks started at different rows take
+        // thousands of rows to meet (measured: 2 932 and 1 824 rows at n = 1e8, Wu = 25): a cut inside them buys nothing -- the
+        // true walk redoes the range -- so those chains stay whole, and they are what bounds this step (86 of its 93 ms there).
+        int64_t c = (int64_t)(std::lower_bound(goff, goff + G, (int32_t)(cnt * t / nw)) - goff);
+        while (c < G && !((double)((int64_t)goff[c + 1] - goff[c]) >= average * 1.2)) c++;
+        if (c > parts.back().b0 && c < G) {
+            parts.back().b1 = c;
+            parts.emplace_back();
+            parts.back().b0 = c;
         }
     }
-    store(gkey[G - 1]);
+    parts.back().b1 = G;
+    {
+        auto run = [&](size_t t) {
+            walked &o = parts[t];
+            const double w0 = now_ms();
+            chain &c = o.pending;
+            c.g_last = c.first_row = o.b0;
+            ival *at = stored + goff[o.b0];
+            for (int64_t i = o.b0 + 1; i < o.b1; i++)
+                step(c, i, [&](double key) {
+                    const int64_t nn = chain_size(c);
+                    chain_copy(c, at);
+                    o.rows.push_back(row_t{at, nn, key, c.first_row});
+                    at += nn;
+                });
+            if (getenv("KVM_TRACE"))
+                fprintf(stderr, "[kvm] index walk thread %d rows %lld..%lld intervals %lld: %.1f ms\n", (int)t, (long long)o.b0, (long long)o.b1,
+                        (long long)(goff[o.b1] - goff[o.b0]), now_ms() - w0);
+        };
+        std::vector<std::thread> th;
+        for (size_t t = 1; t < parts.size(); t++) th.emplace_back(run, t);
+        run(0);
+        for (auto &x : th) x.join();
+    }
+    // ---- stitching (one thread; a few rows per boundary)
+    std::vector<row_t> rows_done;
+    std::deque<std::vector<ival>> side;   // rows finished while carrying the true walk over a boundary (stable addresses)
+    chain *truth = &parts[0].pending;      // the true walk's state at the end of the ranges stitched so far
+    rows_done = parts[0].rows;
+    auto finish_side = [&](chain &c, double key) {
+        side.emplace_back((size_t)chain_size(c));
+        chain_copy(c, side.back().data());
+        rows_done.push_back(row_t{side.back().data(), (int64_t)side.back().size(), key, c.first_row});
+    };
+    for (size_t t = 1; t < parts.size(); t++) {
+        walked &o = parts[t];
+        bool joined = false;
+        const double s0 = now_ms();
+        int64_t i_join = o.b1;
+        for (int64_t i = o.b0; i < o.b1 && !joined; i++) {
+            i_join = i;
+            const bool fresh = step(*truth, i, [&](double key) { finish_side(*truth, key); });
+            if (!fresh) continue;
+            // the true walk starts afresh at row i: did this range's own walk as well?  (its finished rows are ordered by first_row)
+            auto it = std::lower_bound(o.rows.begin(), o.rows.end(), i, [](const row_t &r, int64_t v) { return r.first_row < v; });
+            if (it != o.rows.end() && it->first_row == i) {
+                rows_done.insert(rows_done.end(), it, o.rows.end());
+                truth = &o.pending;
+                joined = true;
+            } else if (o.pending.first_row == i) {
+                truth = &o.pending;
+                joined = true;
+            }
+        }
+        // (not joined: the true walk crossed the whole range without a common fresh start -- it simply goes on into the next)
+        if (getenv("KVM_TRACE"))
+            fprintf(stderr, "[kvm] index stitch into range %d (rows %lld..%lld, %zu finished rows): %s after %lld rows, %.1f ms\n", (int)t, (long long)o.b0,
+                    (long long)o.b1, o.rows.size(), joined ? "joined" : "NOT joined", (long long)(i_join - o.b0 + 1), now_ms() - s0);
+    }
+    finish_side(*truth, gkey[G - 1]);   // the end of the walk: the row being built is finished under the last key
     kvm_index_rows_free(rows);
-    const int64_t R = (int64_t)stored_key.size();
+    const int64_t R = (int64_t)rows_done.size();
+    int64_t total_iv = 0;
+    for (const row_t &r : rows_done) total_iv += r.n;
     f->rows_after = R;
-    f->intervals_after = (int64_t)stored.size();
+    f->intervals_after = total_iv;
     const double t2 = now_ms();
     f->step2_ms = t2 - t1;
 
-    // ---- the file image: TreeMap order = ascending key = the finished rows backwards.  The lines are independent of
-    // each other: encoded by a few host threads into per-thread buffers (contiguous ranges of lines), then laid end to end.
-    std::vector<uint8_t> &img = f->image;
-    std::vector<int32_t> offsets;
-    offsets.reserve((size_t)R + 2);
-    bool too_long = false;
+    // ---- the file image: TreeMap order = ascending key = the finished rows backwards: line k is finished row R - 1 - k.  The
+    // lines are independent of each other.  Two passes by the same host threads over contiguous ranges of lines balanced by
+    // intervals: the length of every line (the encoder without its stores), then -- the image allocated once, at its final
+    // size, every offset known -- the lines encoded in place.
+    const int nt = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)std::thread::hardware_concurrency(), 16, R / 64 + 1}));
+    std::vector<int64_t> cut((size_t)nt + 1, R);
+    cut[0] = 0;
     {
-        const int nt = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)std::thread::hardware_concurrency(), 8, R / 64 + 1}));
-        std::vector<std::vector<uint8_t>> part((size_t)nt);
-        std::vector<std::vector<int64_t>> line_len((size_t)nt);
-        // balance by intervals: line k (ascending key) is stored row R-1-k
-        std::vector<int64_t> cut((size_t)nt + 1, R);
-        cut[0] = 0;
-        {
-            const int64_t total = (int64_t)stored.size();
-            int64_t seen = 0;
-            int t = 1;
-            for (int64_t k = 0; k < R && t < nt; k++) {
-                seen += stored_off[(size_t)(R - 1 - k) + 1] - stored_off[(size_t)(R - 1 - k)];
-                if (seen >= total * t / nt) cut[(size_t)t++] = k + 1;
-            }
+        int64_t seen = 0;
+        int t = 1;
+        for (int64_t k = 0; k < R && t < nt; k++) {
+            seen += rows_done[(size_t)(R - 1 - k)].n;
+            if (seen >= total_iv * t / nt) cut[(size_t)t++] = k + 1;
         }
-        auto work = [&](int t) {
-            std::vector<uint8_t> &out = part[(size_t)t];
-            for (int64_t k = cut[(size_t)t]; k < cut[(size_t)t + 1]; k++) {
-                const int64_t r = R - 1 - k;
-                const size_t at = out.size();
-                out.resize(at + 8);
-                put_be_double(out.data() + at, stored_key[(size_t)r]);
-                encode_compact(stored.data() + stored_off[(size_t)r], stored_off[(size_t)r + 1] - stored_off[(size_t)r], out);
-                line_len[(size_t)t].push_back((int64_t)(out.size() - at));
-            }
-        };
+    }
+    auto on_threads = [&](auto &&work) {
         std::vector<std::thread> th;
         for (int t = 1; t < nt; t++) th.emplace_back(work, t);
         work(0);
         for (auto &x : th) x.join();
-        size_t total_bytes = 0;
-        for (auto &v : part) total_bytes += v.size();
-        if (total_bytes > 0x7fffffffULL) too_long = true;
-        if (!too_long) {
-            img.reserve(total_bytes + (size_t)R * 20 + 64);
-            for (int t = 0; t < nt; t++) {
-                size_t at = img.size();
-                for (int64_t len : line_len[(size_t)t]) {
-                    offsets.push_back((int32_t)at);
-                    at += (size_t)len;
-                }
-                img.insert(img.end(), part[(size_t)t].begin(), part[(size_t)t].end());
-            }
-        }
-    }
-    auto mark = [&]() {
-        if (img.size() > 0x7fffffffULL) too_long = true;
-        offsets.push_back((int32_t)img.size());
     };
-    mark();
-    uint32_t cum_iv = 0, cum_off = 0;  // Java int sums (wrap like them)
-    for (int64_t r = R - 1; r >= 0 && !too_long; r--) {
-        uint32_t nofs = 0;
-        for (int64_t t = stored_off[(size_t)r]; t < stored_off[(size_t)r + 1]; t++)
-            nofs += (uint32_t)(stored[(size_t)t].last - stored[(size_t)t].first + 1);
-        cum_iv += (uint32_t)(stored_off[(size_t)r + 1] - stored_off[(size_t)r]);
-        cum_off += nofs;
-        const size_t at = img.size();
-        img.resize(at + 16);
-        put_be_double(img.data() + at, stored_key[(size_t)r]);
-        put_be32(img.data() + at + 8, (int32_t)cum_iv);
-        put_be32(img.data() + at + 12, (int32_t)cum_off);
-    }
-    mark();
-    if (too_long || img.size() + offsets.size() * 4 > 0x7fffffffULL) {
+    std::vector<int64_t> line_len((size_t)R);
+    on_threads([&](int t) {
+        for (int64_t k = cut[(size_t)t]; k < cut[(size_t)t + 1]; k++) {
+            const row_t &r = rows_done[(size_t)(R - 1 - k)];
+            line_len[(size_t)k] = 8 + encode_compact<false>(r.p, r.n, nullptr);
+        }
+    });
+    std::vector<int64_t> line_at((size_t)R + 1, 0);
+    for (int64_t k = 0; k < R; k++) line_at[(size_t)k + 1] = line_at[(size_t)k] + line_len[(size_t)k];
+    const int64_t lines_bytes = line_at[(size_t)R];
+    const int64_t image_bytes = lines_bytes + 16 * R + 4 * (R + 2);   // lines, statistic triples, the offset table (R lines + 2 marks)
+    if (image_bytes > 0x7fffffffLL) {
         delete f;
         kvm_set_error(ctx, "kvm_index_build: the index file would reach 2 GiB (its offsets are Java ints)");
         return KVM_ERR_UNSUPPORTED;
     }
+    f->image.reset(new uint8_t[(size_t)image_bytes]);
+    f->image_size = (size_t)image_bytes;
+    uint8_t *img = f->image.get();
+    on_threads([&](int t) {
+        for (int64_t k = cut[(size_t)t]; k < cut[(size_t)t + 1]; k++) {
+            const row_t &r = rows_done[(size_t)(R - 1 - k)];
+            uint8_t *dst = img + line_at[(size_t)k];
+            put_be_double(dst, r.key);
+            (void)encode_compact<true>(r.p, r.n, dst + 8);
+        }
+    });
+    // the statistic triples {key, running #intervals, running #offsets} in line order (Java int sums: they wrap like them);
+    // the per-row offset counts by the threads, the running sums here
+    std::vector<uint32_t> row_ofs((size_t)R);
+    on_threads([&](int t) {
+        for (int64_t k = cut[(size_t)t]; k < cut[(size_t)t + 1]; k++) {
+            const row_t &r = rows_done[(size_t)(R - 1 - k)];
+            uint32_t nofs = 0;
+            const ival *p = r.p;
+            for (int64_t q = 0; q < r.n; q++) nofs += (uint32_t)(p[q].last - p[q].first + 1);
+            row_ofs[(size_t)k] = nofs;
+        }
+    });
+    uint32_t cum_iv = 0, cum_off = 0;
+    for (int64_t k = 0; k < R; k++) {
+        const row_t &r = rows_done[(size_t)(R - 1 - k)];
+        cum_iv += (uint32_t)r.n;
+        cum_off += row_ofs[(size_t)k];
+        uint8_t *at = img + lines_bytes + 16 * k;
+        put_be_double(at, r.key);
+        put_be32(at + 8, (int32_t)cum_iv);
+        put_be32(at + 12, (int32_t)cum_off);
+    }
+    // the table of line offsets; its last two entries: where the statistic triples begin, and its own position
     {
-        const size_t at = img.size();
-        img.resize(at + offsets.size() * 4);
-        for (size_t t = 0; t < offsets.size(); t++) put_be32(img.data() + at + t * 4, offsets[t]);
+        uint8_t *tab = img + lines_bytes + 16 * R;
+        for (int64_t k = 0; k < R; k++) put_be32(tab + 4 * k, (int32_t)line_at[(size_t)k]);
+        put_be32(tab + 4 * R, (int32_t)lines_bytes);
+        put_be32(tab + 4 * (R + 1), (int32_t)(lines_bytes + 16 * R));
     }
     f->encode_ms = now_ms() - t2;
+    if (getenv("KVM_TRACE")) fprintf(stderr, "[kvm] index build: step1 %.1f step2 %.1f encode %.1f, buffers freed after %.1f ms of the call\n", f->step1_ms, f->step2_ms, f->encode_ms, now_ms() - t0);
     *out = f;
     return KVM_OK;
     });
 }
 
-extern "C" int64_t kvm_index_file_size(const kvm_index_file *f) { return f ? (int64_t)f->image.size() : 0; }
-extern "C" const uint8_t *kvm_index_file_bytes(const kvm_index_file *f) { return f ? f->image.data() : nullptr; }
+extern "C" int64_t kvm_index_file_size(const kvm_index_file *f) { return f ? (int64_t)f->image_size : 0; }
+extern "C" const uint8_t *kvm_index_file_bytes(const kvm_index_file *f) { return f ? f->image.get() : nullptr; }
 extern "C" int64_t kvm_index_file_info(const kvm_index_file *f, int32_t what) {
     if (!f) return 0;
     switch (what) {
@@ -342,8 +508,8 @@ extern "C" int kvm_index_file_write(const kvm_index_file *f, const char *path) {
     if (!f || !path) return KVM_ERR_ILLEGAL_ARGUMENT;
     FILE *fp = std::fopen(path, "wb");
     if (!fp) return KVM_ERR_IO;
-    const size_t n = f->image.size();
-    const bool ok = std::fwrite(f->image.data(), 1, n, fp) == n;
+    const size_t n = f->image_size;
+    const bool ok = std::fwrite(f->image.get(), 1, n, fp) == n;
     return (std::fclose(fp) == 0 && ok) ? KVM_OK : KVM_ERR_IO;
     });
 }

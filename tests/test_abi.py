@@ -188,8 +188,8 @@ def test_index_file_host_code_on_cpu_under_sanitizers(built, tmp_path):
                         "-fno-sanitize-recover=all", "-pthread", "-o", str(exe)] + src, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     rng = np.random.default_rng(17)
-    for trial in range(10):
-        n = int(rng.integers(300, 40_000)) if trial < 8 else 260_000
+    for trial in range(26):     # (the large ones: the row sequence is cut into up to 16 ranges walked by threads and stitched)
+        n = int(rng.integers(300, 40_000)) if trial < 8 else (260_000 if trial < 10 else int(rng.integers(60_000, 400_000)))
         w = int(rng.choice([25, 50, 100, 200, 400]))
         s = _index_series(rng, trial % 5, n)
         keys, first, last, gk, go = oracle.index_rows_grouped(s, w)
