@@ -25,25 +25,40 @@ def big(built):
     ctx.close()
 
 
-def _fit_limits():
-    """variant -> 2 x max_rel_err_of_prediction of the newest profiles/rNN_phase2_cost_model.json (the fit that wrote
-    csrc/kvm_cost_model.inc)."""
+def _fit_files():
     import glob
     import json
     import os
-    files = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "..", "profiles", "r[0-9][0-9]_phase2_cost_model.json")))
+    prof = os.path.join(os.path.dirname(__file__), "..", "profiles")
+    files = sorted(glob.glob(os.path.join(prof, "r[0-9][0-9]_phase2_cost_model.json")))
     assert files, "profiles/rNN_phase2_cost_model.json (written by profiles/fit_cost_model.py) is missing"
     fit = json.load(open(files[-1]))
-    return {v: 2.0 * float(fit[k]["max_rel_err_of_prediction"]) for v, k in enumerate(("rsm_ed", "cnsm_ed", "rsm_dtw", "cnsm_dtw"))}
+    held = files[-1].replace("_cost_model.json", "_held_out.json")
+    return fit, (json.load(open(held)) if os.path.exists(held) else None), held
+
+
+BOX_SPREAD = 0.08   # the boxes of the pool differ by about this much on the same call
+
+
+def _fit_limits(fit, held):
+    """variant -> 1.3 x the model's worst residual -- over the points of its own fit AND over the held-out shapes below as measured
+    when the constants were written (profiles/rNN_phase2_held_out.json) -- plus the spread between boxes."""
+    lim = {}
+    for v, k in enumerate(("rsm_ed", "cnsm_ed", "rsm_dtw", "cnsm_dtw")):
+        worst = float(fit[k]["max_rel_err_of_prediction"])
+        for h in (held or {}).get("shapes", []):
+            if h["variant"] == v:
+                worst = max(worst, abs(h["estimate_ms"] - h["measured_ms"]) / h["measured_ms"])
+        lim[v] = 1.3 * worst + BOX_SPREAD
+    return lim
 
 
 def test_phase2_time_model_against_measured_calls(big):
     """kvm_phase2_time_estimate_ms (constants compiled in from csrc/kvm_cost_model.inc, written by profiles/fit_cost_model.py)
     against calls measured here, on shapes of the regime the fit covers (n = 1e8, selective queries, early abandon on) but
     NOT its grid points: other interval seeds, other run lengths, m = 3072 between its lengths.  The fit's own residuals are
-    <= 19 % for the ED engines and <= 42 % for the DTW engines (profiles/r04_phase2_cost_model.json: refitted at the end of
-    round 4 -- the screens in front of the DP had got faster since round 3's fit and the RSM-DTW shape below sat at 60 % of a 70 % limit).  The table is printed;
-    the test fails beyond twice those.  The DTW engines' time depends on how many candidates reach the DP -- 3 or 700 for the same
+    <= 35 % for the ED engines and <= 42 % for the DTW engines (profiles/r06_phase2_cost_model.json: refitted in round 6).  The
+    table is printed; what fails the run is at its end.  The DTW engines' time depends on how many candidates reach the DP -- 3 or 700 for the same
     number of offsets, decided by the data under the intervals, which no a-priori model knows (this test's shape of 8e5
     offsets at m = 4096 takes 0.96 ms where the grid's 1e6 offsets took 1.2 - 2.5 ms; the model says 1.24).  A change of
     the launch chain or of a kernel that moves calls by more than that fails here, so the constants cannot silently rot."""
@@ -76,14 +91,30 @@ def test_phase2_time_model_against_measured_calls(big):
     print("\nphase-2 time model against measured calls (relative error, variant, m, offsets, mean run, measured ms, estimate ms, answers):")
     for w in sorted(worst, reverse=True):
         print("   %.3f  v%d m=%d offsets=%d run=%.0f  %.3f ms vs %.3f ms  (%d answers)" % w)
-    # the table above is the result; the run only FAILS beyond twice the worst residual of the variant's own fit, read from the
-    # file the compiled-in constants were written with (r04: rsm_ed 19 %, cnsm_ed 17 %, rsm_dtw 21 %, cnsm_dtw 42 % -> limits
-    # 38 / 33 / 43 / 85 %) -- the boxes of the pool differ by 8 % and the DP count is the data's
-    limits = _fit_limits()
-    print("limits (2 x the fit's worst residual per variant):", {k: round(v, 3) for k, v in limits.items()})
+    # Two guards.  (1) The model: the run fails beyond 1.3 x the model's worst residual (its own fit and these shapes as measured
+    # when the constants were written) + the spread between boxes -- r06: 54 / 30 / 51 / 62 %.  The DTW engines' time follows the
+    # number of DPs the data decides, so their a-priori limit stays wide; the form that is GIVEN the DP count is held to 45 %.
+    # (2) The calls themselves: every shape against its time in profiles/rNN_phase2_held_out.json, measured when the constants
+    # were written -- more than 1.3 x (+ the box spread) slower fails, whatever the model says: a regression of the launch chain or
+    # of a kernel cannot hide behind the model's tolerance (rounds 4 - 5: twice the worst residual, which let a 1.8 x slower DTW
+    # call pass).  KVM_WRITE_HELD_OUT=1 rewrites the file from this run (after a refit).
+    import json
+    import os
+    fit, held, held_path = _fit_files()
+    if os.environ.get("KVM_WRITE_HELD_OUT") == "1":
+        held = {"shapes": [{"variant": w[1], "m": w[2], "offsets": w[3], "mean_run": w[4], "measured_ms": w[5], "estimate_ms": w[6]} for w in worst],
+                "note": "tests/test_zz_perf_gpu.py::test_phase2_time_model_against_measured_calls with KVM_WRITE_HELD_OUT=1"}
+        json.dump(held, open(held_path, "w"), indent=1)
+    limits = _fit_limits(fit, held)
+    print("limits (1.3 x the model's worst residual + box spread, per variant):", {k: round(v, 3) for k, v in limits.items()})
     bad = [w for w in worst if w[0] > limits[w[1]]]
     assert not bad, (bad, worst)
     print("the DTW engines with the DP count as an argument (relative error, variant, m, offsets, DPs, measured ms, estimate ms):")
     for w in sorted(with_dp, reverse=True):
         print("   %.3f  v%d m=%d offsets=%d dp=%d  %.3f ms vs %.3f ms" % w)
-    assert not [w for w in with_dp if w[0] > 0.70], with_dp   # (held to 35 %: fails beyond twice that)
+    assert not [w for w in with_dp if w[0] > 0.45], with_dp
+    assert held is not None, "profiles/rNN_phase2_held_out.json is missing (run once with KVM_WRITE_HELD_OUT=1 after a refit)"
+    ref = {(h["variant"], h["m"], h["offsets"]): h["measured_ms"] for h in held["shapes"]}
+    slow = [(w[5] / ref[(w[1], w[2], w[3])], w) for w in worst if w[5] > (1.3 + BOX_SPREAD) * ref[(w[1], w[2], w[3])]]
+    print("measured / recorded time per shape:", sorted(round(w[5] / ref[(w[1], w[2], w[3])], 3) for w in worst))
+    assert not slow, slow
