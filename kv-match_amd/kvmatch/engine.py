@@ -158,6 +158,13 @@ class Phase2Context:
         self._h = h
         self.device = device
         self._keep = None
+        # (this BINDING's own switches, for the parity campaigns of profiles/stress_r06.sh, which run unmodified fuzz scripts with
+        # every form of the ED pruner forced: KVM_PY_ED_FORCE=<KVM_OPT_ED_FORCE value>, KVM_PY_IN_FLIGHT=<n>.  The library reads
+        # neither)
+        if os.environ.get("KVM_PY_ED_FORCE"):
+            self.set_option(_lib.OPT_ED_FORCE, int(os.environ["KVM_PY_ED_FORCE"], 0))
+        if os.environ.get("KVM_PY_IN_FLIGHT"):
+            self.set_option(_lib.OPT_IN_FLIGHT, int(os.environ["KVM_PY_IN_FLIGHT"]))
 
     # -- TimeSeriesOperator side ---------------------------------------------------------------------
     def load_series(self, values):
