@@ -55,8 +55,8 @@ int kvm_ensure_pinned(kvm_ctx *ctx, size_t bytes) {
     return KVM_OK;
 }
 
-// (0.5: round 5 -- struct kvm_device_slot gained `ready`, KVM_OPT_IN_FLIGHT)
-extern "C" const char *kvm_version(void) { return "kvmatch-hip 0.5 (gfx950)"; }
+// (0.6: round 6 -- the group entry points, KVM_OPT_ED_FORCE / _ED_LAST_SHAPE / _SERIALIZE_ENQUEUE, kvm_abi_version() == 6)
+extern "C" const char *kvm_version(void) { return "kvmatch-hip 0.6 (gfx950)"; }
 
 extern "C" const char *kvm_last_error(const kvm_ctx *ctx) { return ctx ? ctx->err.c_str() : g_open_err.c_str(); }
 
