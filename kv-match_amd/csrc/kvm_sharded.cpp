@@ -170,6 +170,7 @@ struct gslot_t {
 struct gdev_t {
     int device = -1;
     void *comm = nullptr;
+    void *gathered = nullptr;   // event behind this device's most recent all-gather (the next one, on another stream, waits for it)
     std::vector<gslot_t> slots;
 };
 }  // namespace
@@ -237,6 +238,7 @@ void destroy_group(kvm_group *g) {
         if (!g->devs.empty()) kvm_sd_event_destroy(g->devs[0].device, g->issued[t]);
     for (gdev_t &d : g->devs) {
         if (d.comm) kvm_sd_comm_destroy(d.device, d.comm);
+        kvm_sd_event_destroy(d.device, d.gathered);
         for (size_t t = d.slots.size(); t-- > 0;) {  // (slot 0 owns the series the others share: closed last)
             gslot_t &s = d.slots[t];
             kvm_sd_free(d.device, s.d_off);
@@ -289,6 +291,8 @@ int open_common(const int32_t *devices, int32_t n_dev, int32_t rank0, int32_t wo
     }
     for (void *&e : g->issued)
         if (int rc = kvm_sd_event_create(g->devs[0].device, &e)) return bail(rc, kvm_sd_last_error());
+    for (gdev_t &dv : g->devs)
+        if (int rc = kvm_sd_event_create(dv.device, &dv.gathered)) return bail(rc, kvm_sd_last_error());
     if (int rc = alloc_exchange(g)) return bail(rc, g->err);
     if (g->use_rccl) {
         int rc;
@@ -547,7 +551,15 @@ int issue_exchange(kvm_group *g, job_state &J, int64_t i, std::string &msg) {
     g->stat[KVM_GROUP_STAT_PREPARE_NS] += lap_ns(tp);
     int rc = KVM_OK;
     if (g->use_rccl) {
-        rc = kvm_sd_all_gather(nl, devices.data(), comms.data(), send.data(), recv.data(), bd, streams.data());
+        // Consecutive jobs run on different streams, and so do their all-gathers.  With peers, two collectives of one
+        // communicator must not be in flight at once (they share its channels): each device's gather is ordered behind its
+        // previous one by an event -- whatever the collective library does about streams on its own.  (At world 1 there is
+        // nobody to be out of step with, and the wait would only put barrier packets into the slots' hardware queues.)
+        if (g->world > 1 && i > 0)
+            for (int d = 0; d < nl && !rc; d++) rc = kvm_sd_stream_wait_event(g->devs[(size_t)d].device, streams[(size_t)d], g->devs[(size_t)d].gathered);
+        if (!rc) rc = kvm_sd_all_gather(nl, devices.data(), comms.data(), send.data(), recv.data(), bd, streams.data());
+        if (g->world > 1)
+            for (int d = 0; d < nl && !rc; d++) rc = kvm_sd_event_record(g->devs[(size_t)d].device, g->devs[(size_t)d].gathered, streams[(size_t)d]);
         g->stat[KVM_GROUP_STAT_ALL_GATHER_NS] += lap_ns(tp);
         if (!rc) rc = kvm_sd_readback_blocks(d0.device, g->h_block[t], d0.slots[t].d_gathered, g->world, bd, s0);
     } else {
@@ -686,7 +698,12 @@ struct exchange {
         if (!rc && (rc = kvm_sd_host_alloc(d0.device, (void **)&h, total * 8))) (void)gfail_sd(g, rc);
         if (!rc && g->use_rccl) {
             // (the turnstile is at H and stays there until this job is handed back: no gather is issued beside this collective)
-            if ((rc = kvm_sd_all_gather(nl, devices.data(), comms.data(), send.data(), d_all.data(), big, streams.data()))) (void)gfail_sd(g, rc);
+            // (ordered behind the last gather like every gather behind its predecessor; the streams are drained below, so the next
+            // gather needs no event of this one)
+            if (g->world > 1)
+                for (int d = 0; d < nl && !rc; d++)
+                    if ((rc = kvm_sd_stream_wait_event(g->devs[(size_t)d].device, streams[(size_t)d], g->devs[(size_t)d].gathered))) (void)gfail_sd(g, rc);
+            if (!rc && (rc = kvm_sd_all_gather(nl, devices.data(), comms.data(), send.data(), d_all.data(), big, streams.data()))) (void)gfail_sd(g, rc);
         }
         if (!rc && (rc = kvm_sd_copy_d2h_async(d0.device, h, g->use_rccl ? d_all[0] : d_big[0], total * 8, d0.slots[t].stream))) (void)gfail_sd(g, rc);
         for (int d = 0; d < nl; d++) {  // (also on a failure: the buffers below are freed next)

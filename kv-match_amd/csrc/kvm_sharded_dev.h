@@ -8,6 +8,7 @@
 #include <stdint.h>
 
 int kvm_sd_stream_synchronize(int device, void *stream);
+int kvm_sd_stream_wait_event(int device, void *stream, void *event);   // device-side: the stream goes on once the event has completed
 int kvm_sd_event_create(int device, void **event);
 void kvm_sd_event_destroy(int device, void *event);
 int kvm_sd_event_record(int device, void *event, void *stream);

@@ -39,6 +39,11 @@ int kvm_sd_stream_synchronize(int device, void *stream) {
     SDCHK(hipStreamSynchronize((hipStream_t)stream));
     return KVM_OK;
 }
+int kvm_sd_stream_wait_event(int device, void *stream, void *event) {
+    SDCHK(hipSetDevice(device));
+    SDCHK(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)event, 0));
+    return KVM_OK;
+}
 int kvm_sd_event_create(int device, void **event) {
     SDCHK(hipSetDevice(device));
     hipEvent_t e = nullptr;

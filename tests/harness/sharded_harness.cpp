@@ -114,6 +114,19 @@ int kvm_sd_event_record(int, void *ev, void *s) {
     });
     return KVM_OK;
 }
+int kvm_sd_stream_wait_event(int, void *s, void *ev) {
+    fevent *e = (fevent *)ev;
+    uint64_t gen;
+    {
+        std::lock_guard<std::mutex> lk(e->mu);
+        gen = e->issued;
+    }
+    ((fstream *)s)->push([e, gen] {
+        std::unique_lock<std::mutex> lk(e->mu);
+        e->cv.wait(lk, [&] { return e->completed >= gen; });
+    });
+    return KVM_OK;
+}
 int kvm_sd_event_synchronize(void *ev) {
     fevent *e = (fevent *)ev;
     std::unique_lock<std::mutex> lk(e->mu);
