@@ -32,6 +32,7 @@ for forced in 0 1 2 3; do
   run python -u profiles/exotic_params.py
   run python -u profiles/fuzz_spikes.py 100 63
   run python -u profiles/fuzz_knife.py 40 67 12
+  run python -u profiles/fuzz_head.py 30 $((70 + forced))
 done
 unset KVM_PY_ED_FORCE KVM_PY_IN_FLIGHT
 fi

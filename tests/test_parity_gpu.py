@@ -658,6 +658,50 @@ def test_knife_edge_rsm_ed_epsilon(world):
         assert a.distances[a.offsets.tolist().index(target)] == np.sqrt(d2)
 
 
+def test_rsm_ed_abandoning_pruner_sees_the_head_of_the_window_only(world):
+    """Early abandoning, m >= 2 * KVM_ED_ABANDON_HEAD (1024): the tiled pruner is given the first 1024 points of the query and
+    the exact pass the rest (kvm_verify.hip, retile branch).  A periodic series whose every window agrees with the query over
+    that head -- so nothing dies where the pruner looks and EVERY candidate reaches the exact pass -- with the differences behind
+    it: some windows die late, some end exactly at epsilon (in and out), some are answers."""
+    kvmatch, datagen, series, ctx = world
+    rng = np.random.default_rng(41)
+    m, period = 2304, 256
+    n = 120_000
+    base = rng.standard_normal(period)
+    s = np.tile(base, n // period + 1)[:n].copy()
+    qoff = 10 * period + 1
+    q = s[qoff - 1: qoff - 1 + m].copy()
+    L = np.arange(1, n - m, period, dtype=np.int64)[:400]      # every candidate start in phase with the query's
+    R = L + 63                                                    # (and 63 starts out of phase behind each)
+    for i, o in enumerate(L.tolist()):                            # spoil the tails: by nothing, a little, or a lot
+        kind = i % 4
+        if kind == 1:
+            s[o - 1 + 1500] += 0.75
+        elif kind == 2:
+            s[o - 1 + 2303] += 3.0
+        elif kind == 3:
+            s[o - 1 + 1024] += 40.0
+    # (the spoiled points of one candidate sit inside its neighbours' windows too: whatever that makes, the oracle sees the same)
+    q = s[qoff - 1: qoff - 1 + m].copy()
+    ctx.load_series(s)
+    for eps in (0.5, 0.76, 3.5, 50.0):
+        for ea in (1, 0):
+            ctx.set_option(kvmatch.OPT_EARLY_ABANDON, ea)
+            got = kvmatch.QueryEngine(ctx).verify((L, R), 1, q, eps)
+            compare(got, oracle.rsm_ed(s, q, L, R, 0, eps), tag=f"head eps {eps} abandon {ea}")
+    ctx.set_option(kvmatch.OPT_EARLY_ABANDON, 1)
+    target = int(L[5])
+    w = s[target - 1: target - 1 + m]
+    d2 = _seq_sum((w - q) * (w - q))
+    if d2 > 0:
+        eps_in, eps_out = _eps_for_d2(d2)
+        a = kvmatch.QueryEngine(ctx).verify((L, R), 1, q, eps_in)
+        b = kvmatch.QueryEngine(ctx).verify((L, R), 1, q, eps_out)
+        compare(a, oracle.rsm_ed(s, q, L, R, 0, eps_in), tag="head knife in")
+        compare(b, oracle.rsm_ed(s, q, L, R, 0, eps_out), tag="head knife out")
+        assert target in a.offsets.tolist() and target not in b.offsets.tolist()
+
+
 def _ref_running_stats(s, run_start, start, m):
     """mean/std of the window `start` as the reference's running sums give them when the interval begins at
     `run_start` (K/NormQueryEngine.java:487-509,523-524), replayed in Python."""
