@@ -368,6 +368,7 @@ __device__ __forceinline__ void edd_body(const edd_args &A, const kvm_tile *__re
 
     // ---- which of my CI candidates are alive (bit a of `vm`); `fm`: degenerate sigma, survives unconditionally ----
     bool work = active;  // wave-uniform
+    bool handoff = false;  // wave-uniform: stopped early with <= EDD_INLINE_MAX live candidates (ABANDON only; see HAND-OVER)
     unsigned vm = 0, fm = 0;
     // (a unit split f ways, every point evaluated: only part 0 -- which finishes the candidates -- needs the (alpha, beta)
     // filter; the other parts accumulate for every candidate of their tiles and hand over.  Each part repeating the filter
@@ -803,6 +804,21 @@ __device__ __forceinline__ void edd_body(const edd_args &A, const kvm_tile *__re
                     if (f == 1) return;
                     break;  // split unit: the other parts wait at the barrier below
                 }
+                // HAND-OVER: a wave that is left with a handful of live candidates stops walking and gives them to the exact
+                // evaluation as they are.  Going on costs the wave's 512 slots for those few: the unit that holds an answer
+                // walked its whole share of the window on a lone wave (up to 64 of a call's 125 us at m = 8192) only to
+                // confirm what the exact evaluation has to establish anyway.  Live candidates by the dozen stay in the tiled
+                // form, so what this can add to the exact pass is bounded: EDD_INLINE_MAX per unit and part.
+                // (Tried instead: the pruner on the first 1024 points only, everything alive there to the exact pass --
+                // as fast on the bench's queries, but a window whose head matches hands over ALL its neighbours: 8 335
+                // instead of 1 099 survivors and 0.55 instead of 0.41 ms on a cNSM query from a smooth stretch.)
+                int alive = __popc(vm);
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) alive += __shfl_xor(alive, o, 64);
+                if (alive <= EDD_INLINE_MAX) {
+                    handoff = true;
+                    break;
+                }
             }
         }
     }
@@ -819,31 +835,41 @@ __device__ __forceinline__ void edd_body(const edd_args &A, const kvm_tile *__re
         if (part > 0 && work) {
 #pragma unroll
             for (int a = 0; a < CI; a++) wlds[a * 64 + lane] = acc[a];
-            if (ABANDON) reinterpret_cast<unsigned *>(wlds + CI * 64)[lane] = vm;  // candidates this part has seen die
+            if (ABANDON) {
+                reinterpret_cast<unsigned *>(wlds + CI * 64)[lane] = vm;  // candidates this part has seen die
+                reinterpret_cast<unsigned *>(wlds + CI * 64)[64 + lane] = handoff ? 1u : 0u;   // ... and whether its sums are whole
+            }
         }
         __syncthreads();
         if (part > 0 || !work) return;
         for (int p = 1; p < f; p++) {
 #pragma unroll
             for (int a = 0; a < CI; a++) acc[a] += wlds[p * cfg::WAVE_DOUBLES + a * 64 + lane];
-            if (ABANDON) vm &= reinterpret_cast<const unsigned *>(wlds + p * cfg::WAVE_DOUBLES + CI * 64)[lane];
+            if (ABANDON) {
+                vm &= reinterpret_cast<const unsigned *>(wlds + p * cfg::WAVE_DOUBLES + CI * 64)[lane];
+                handoff = handoff || reinterpret_cast<const unsigned *>(wlds + p * cfg::WAVE_DOUBLES + CI * 64)[64 + lane] != 0u;
+            }
         }
     } else if (!work) {
         return;
     }
     unsigned keepm = 0;
     kvm_raw_sums rawf[4];
+    if (ABANDON && handoff) {
+        keepm = vm;   // (some part stopped early: there is no whole-window sum to test -- whatever is alive goes on)
+    } else {
 #pragma unroll
-    for (int a = 0; a < CI; a++) {
-        if (a % 4 == 0) issue_full(rawf, a);
-        if ((vm >> a) & 1u) {
-            bool keep = (fm >> a) & 1u;
-            if (!keep) {
-                double slack;
-                const edd_cstat st = stats_from(rawf[a % 4], a, 0, m);
-                keep = !(dist_form(st, acc[a], m, qtot, slack) > eps2 + slack);  // (NaN: a poisoned prefix block -> keep)
+        for (int a = 0; a < CI; a++) {
+            if (a % 4 == 0) issue_full(rawf, a);
+            if ((vm >> a) & 1u) {
+                bool keep = (fm >> a) & 1u;
+                if (!keep) {
+                    double slack;
+                    const edd_cstat st = stats_from(rawf[a % 4], a, 0, m);
+                    keep = !(dist_form(st, acc[a], m, qtot, slack) > eps2 + slack);  // (NaN: a poisoned prefix block -> keep)
+                }
+                if (keep) keepm |= 1u << a;
             }
-            if (keep) keepm |= 1u << a;
         }
     }
     if (!NORM && A.out_off) {
@@ -873,6 +899,9 @@ __device__ __forceinline__ void edd_body(const edd_args &A, const kvm_tile *__re
                         wlds[i * 64 + lane] = (xv - qv) * (xv - qv);               // K/QueryEngine.java:357
                     }
                     if (lane == 0) dist = ex_seq_add(wlds, cnt, dist);              // :357, strictly in order
+                    // (the reference's own early abandoning, K/QueryEngine.java:356, at this loop's granularity: the terms
+                    // are >= 0, so a sum beyond eps^2 stays there; NaN compares false and runs to the end, like there)
+                    if (ABANDON && __shfl((int)(dist > eps2), 0, 64)) break;
                 }
                 if (lane == 0) {
                     atomicAdd(&A.counters[KVM_CNT_RECHECKED], 1ULL);

@@ -252,7 +252,6 @@ hipError_t kvm_launch_ed_wave(const double *series, const double2 *prefix, int64
 __host__ __device__
 #endif
 static inline int kvm_qk_len(int m) { return (m + 1) / 2 + KVM_SERIES_PAD / 2; }
-#define KVM_ED_ABANDON_HEAD 1024   // RSM-ED with early abandoning: window points the pruner looks at (a multiple of its 128-point chunks)
 #define ED4_JC 160  // chunk lengths of the correlation-form pruner (also the granularity of kvm_query_dev::q_pref / q_pref8 /
 #define ED8_JC 128  // q_pref16): class B (4 candidates per lane), class A (8 per lane), class C (4 per lane, two 16-candidate
 #define ED16_JC 80  // tiles per row)

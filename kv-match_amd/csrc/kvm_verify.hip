@@ -392,22 +392,8 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
                 HIPCHK(ctx, kvm_launch_retile_cnsm(ctx->d_series, ctx->d_prefix, qd, d_tiles, pl.n_tiles, tA, tB,
                                                    counters + KVM_CNT_TILES_A, stream));
             KVM_TP("  retile launch");
-            // RSM-ED with early abandoning, long windows: the pruner looks at the HEAD of the window only (KVM_ED_ABANDON_HEAD
-            // points: to it the query simply is that short -- the partial sums of (x - q)^2 only grow, so what is dead there is
-            // dead) and hands what is still alive to the exact pass, which abandons like the reference does.  A launch of this
-            // pruner lasts as long as the one unit that holds an answer, and that unit walked the whole window with 8 candidates
-            // per lane on a lone wave (45 of the launch's 80 us at m = 8192) before the 35-us sequential evaluation the answer
-            // needs anyway; the candidates that pass a 128-point head check by the ten thousand are dead a few hundred points on.
-            kvm_query_dev qd_pr = qd;
-            int32_t *pr_off = out.d_off;
-            double *pr_dist = out.d_dist;
-            if (retile_rsm && m >= 2 * KVM_ED_ABANDON_HEAD) {
-                qd_pr.m = KVM_ED_ABANDON_HEAD;
-                pr_off = nullptr;     // (no evaluation in place by the pruner's waves: they do not know the whole query)
-                pr_dist = nullptr;
-            }
-            HIPCHK(ctx, kvm_launch_ed_dot(ctx->d_series, ctx->d_prefix, ctx->n, qd_pr, tA, pl.n_tiles, tB, pl.n_tiles, tB, 0, surv,
-                                          pl.windows, counters, ctx->num_cu, counters + KVM_CNT_TILES_A, pr_off, pr_dist, out.cap,
+            HIPCHK(ctx, kvm_launch_ed_dot(ctx->d_series, ctx->d_prefix, ctx->n, qd, tA, pl.n_tiles, tB, pl.n_tiles, tB, 0, surv,
+                                          pl.windows, counters, ctx->num_cu, counters + KVM_CNT_TILES_A, out.d_off, out.d_dist, out.cap,
                                           stream, nullptr, nullptr, kvm_in_flight(ctx), ctx->opt_ed_force, &ctx->last_ed_shape));
             KVM_TP("  ed_dot launch");
         }

@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
-"""RSM-ED with early abandoning on windows long enough that the tiled pruner is given the HEAD of the query only
-(m >= 2 * KVM_ED_ABANDON_HEAD = 2048; kvm_verify.hip): random and hostile series, lists of phase-1 shape and single offsets,
-epsilon ON candidates' distances (taken from the oracle's wide-open list) and one ulp to either side, plus thresholds below
-which everything dies in the head and above which nothing does.  Library vs oracle.  `fuzz_head.py [cases] [seed]`."""
+"""RSM-ED with early abandoning on long windows (m >= 2048), where what the pruner's early tests leave alive decides who
+evaluates it (the HAND-OVER rule of kvm_ed_dot.hip: a wave left with a handful of live candidates gives them to the exact
+evaluation): random and hostile series, lists of phase-1 shape and single offsets, epsilon ON candidates' distances (taken
+from the oracle's wide-open list) and one ulp to either side, plus thresholds below which everything dies at once and
+above which nothing does.  Library vs oracle.  `fuzz_head.py [cases] [seed]`."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "kv-match_amd")); sys.path.insert(0, os.path.join(ROOT, "oracle"))

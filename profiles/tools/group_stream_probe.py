@@ -21,6 +21,7 @@ ap.add_argument("--queries", type=int, default=600)
 ap.add_argument("--only", default="")
 ap.add_argument("--depths", default="8,16")
 ap.add_argument("--abandon", default="0,1")
+ap.add_argument("--variant", default="rsm_ed", choices=["rsm_ed", "cnsm_ed"], help="cnsm_ed: alpha = 2, beta = 10 (BASELINE configs[2])")
 a = ap.parse_args()
 n, nq, m = a.n, a.queries, 8192
 depths = [int(x) for x in a.depths.split(",")]
@@ -30,7 +31,10 @@ qo = [n // 7 + 1, n // 3 + 5, n // 2 + 11]
 queries = [series[o - 1:o - 1 + m].copy() for o in qo]
 lists = [datagen.gen_intervals(n, m, 1_000_000, 64.0, must_cover=qo, seed=1 + i) for i in range(4)]
 cands = [int((r.astype(np.int64) - l + 1).sum()) for l, r in lists]
-jobs = [kvmatch.Job(0, lists[t % 4], 1, queries[t % 3], 10.0) for t in range(nq)]
+if a.variant == "cnsm_ed":
+    jobs = [kvmatch.Job(1, lists[t % 4], 1, queries[t % 3], 10.0, alpha=2.0, beta=10.0) for t in range(nq)]
+else:
+    jobs = [kvmatch.Job(0, lists[t % 4], 1, queries[t % 3], 10.0) for t in range(nq)]
 total = sum(cands[t % 4] for t in range(nq))
 if a.only in ("", "host"):
     with kvmatch.Phase2Context(0) as ctx:

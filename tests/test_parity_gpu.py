@@ -658,11 +658,11 @@ def test_knife_edge_rsm_ed_epsilon(world):
         assert a.distances[a.offsets.tolist().index(target)] == np.sqrt(d2)
 
 
-def test_rsm_ed_abandoning_pruner_sees_the_head_of_the_window_only(world):
-    """Early abandoning, m >= 2 * KVM_ED_ABANDON_HEAD (1024): the tiled pruner is given the first 1024 points of the query and
-    the exact pass the rest (kvm_verify.hip, retile branch).  A periodic series whose every window agrees with the query over
-    that head -- so nothing dies where the pruner looks and EVERY candidate reaches the exact pass -- with the differences behind
-    it: some windows die late, some end exactly at epsilon (in and out), some are answers."""
+def test_rsm_ed_abandoning_windows_that_agree_with_the_query_over_their_head(world):
+    """Early abandoning on a periodic series whose every in-phase window agrees with the query over its first 1024 points, with
+    the differences behind them: nothing dies where the head checks look (kvm_retile_rsm_kernel, the pruner's first chunk),
+    waves are left with few or many live candidates (the pruner's HAND-OVER rule, kvm_ed_dot.hip, on both sides of its
+    threshold), some windows die late, some end exactly at epsilon (in and out), some are answers."""
     kvmatch, datagen, series, ctx = world
     rng = np.random.default_rng(41)
     m, period = 2304, 256
