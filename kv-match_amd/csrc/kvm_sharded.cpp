@@ -6,9 +6,10 @@
 //
 // The reference's phase 2 walks the interval list once per query (K/QueryEngine.java:343-363 and the same loop in the other
 // three engines); candidates are independent given the series and the query, so the list shards freely.  Threads
-// of a call: one per (local device, slot) taken from the persistent pool of kvm_host_threads.h -- they split, enqueue and
-// never wait for a kernel (except the one read a DTW call makes) -- and the CALLING thread, which alone issues the collectives,
-// in job order on every rank, waits for each query's block and merges it.
+// of a call: one per (local device, slot) taken from the persistent pool of kvm_host_threads.h -- they split, enqueue, never
+// wait for a kernel (except the one read a DTW call makes), and whichever of them completes a job's last local part issues
+// that job's collective, in job order on every rank (a turnstile) -- and the CALLING thread, which waits for each query's
+// block and merges it (protocol: above run_state, below).
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -555,7 +556,9 @@ int issue_exchange(kvm_group *g, job_state &J, int64_t i, std::string &msg) {
         // communicator must not be in flight at once (they share its channels): each device's gather is ordered behind its
         // previous one by an event -- whatever the collective library does about streams on its own.  (At world 1 there is
         // nobody to be out of step with, and the wait would only put barrier packets into the slots' hardware queues.)
-        if (g->world > 1 && i > 0)
+        // (also a call's first job: on a local device other than 0 the last gather of the previous call may still be finishing --
+        // calls wait for device 0's readbacks; an event that was never recorded counts as complete)
+        if (g->world > 1)
             for (int d = 0; d < nl && !rc; d++) rc = kvm_sd_stream_wait_event(g->devs[(size_t)d].device, streams[(size_t)d], g->devs[(size_t)d].gathered);
         if (!rc) rc = kvm_sd_all_gather(nl, devices.data(), comms.data(), send.data(), recv.data(), bd, streams.data());
         if (g->world > 1)

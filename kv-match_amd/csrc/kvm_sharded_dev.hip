@@ -1,9 +1,9 @@
 // kvm_sharded_dev.hip -- the device layer of the group entry points (kvm_sharded_dev.h) on HIP and RCCL.
 // RCCL is NOT a link dependency of the library: librccl.so.1 (573 MB of kernels the runtime registers at load) is opened the
-// first time a group needs a communicator, so that a single-GPU host never pays for it.  The name asked for is the ROCm
-// install's own soname, found through this library's RUNPATH; in a process that has also imported torch (whose bundled
-// copy is named librccl.so, no soname, and private to torch's extension) this is still ROCm's copy, bound to the one HIP runtime
-// of the process (libamdhip64.so.7, whichever copy was loaded first) like this library itself.
+// first time a group needs a communicator, so that a single-GPU host never pays for it.  The name asked for is the soname:
+// found through this library's RUNPATH in ROCm's install -- or, in a process that has already loaded a copy under that
+// soname (torch ships one as torch/lib/librccl.so, soname librccl.so.1), that copy: one RCCL per process, bound like this
+// library itself to the one HIP runtime of the process (libamdhip64.so.7, whichever copy was loaded first).
 #include <dlfcn.h>
 #include <unistd.h>
 #include <hip/hip_runtime.h>
