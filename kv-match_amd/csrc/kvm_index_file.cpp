@@ -16,10 +16,13 @@
 //            is its own position (IndexFileOperator.writeAll / readOffsetInfo).  Offsets are Java ints: an image of 2 GiB
 //            or more is refused.
 // The walk is sequential (each decision depends on the row merged so far) except at the rows the rule never merges, where it
-// starts afresh: the row sequence is cut there and walked by several host threads (see kvm_index_build); one pass per attempted
-// union, read straight from the grouped step-1 arrays; the lines of the file are encoded by the same number of host threads.
+// starts afresh: the row sequence is cut there and walked by several host threads (see kvm_index_build); inside the long
+// chains of sparse rows at both ends of the key range two threads work as a pipeline -- the next row's union is merged while
+// this row's is still being written (pipe_rec); one pass per attempted union, read straight from the grouped step-1 arrays; the
+// lines of the file are encoded by the same number of host threads.
 #include "kvm_guard.h"
 #include <algorithm>
+#include <atomic>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -137,6 +140,128 @@ inline void merge_walk(const N1 &n1, const N2 &n2, Emit emit, Bulk1 bulk1, Bulk2
     }
 }
 
+// ---- step 2 as a PIPELINE (the chains of sparse rows at both ends of the key range) ------------------------------------------
+// There the walk is one long dependency: row i is merged into the union of the rows before it, 190 times in a row, each union
+// ~4 500 intervals, and whether it is kept is known only at its end -- 22 of step 2's 37 million interval-steps sit in one
+// range no cut can divide (kvm_index_build).  But a union is produced front to back and consumed front to back: the task of row
+// i + 1 can merge into the union of row i WHILE that is being written, a few hundred intervals behind it, on the guess that
+// the union will be kept (it is, 17 times of 18).  A team of D threads takes the rows of a range in turn (row i: thread
+// i mod D); behind every row stands a record: the union's intervals published so far, and -- once the row's task has decided
+// -- whether the walk goes on from that union or afresh from the row itself.  A task whose input turns out to be something
+// else (the predecessor started again, or did not keep its union) starts again.  Same merges, same decisions, same order of
+// finished rows as one thread's walk: the finishing of rows is handed from task to task with the decisions.
+struct alignas(128) pipe_rec {   // (a record to itself on its cache lines: its neighbours are written by other threads)
+    std::atomic<uint64_t> prog{0};   // (attempt << 40) | intervals of `buf` published by that attempt of the row's task
+    std::atomic<int> decided{0};     // 0 not yet | 1 the walk goes on from the union in buf[0, n) | 2 from the row itself (n = its size)
+    int64_t n = 0;
+    int64_t first_row = 0;           // the first row of the chain the walk is in behind this row
+    std::atomic<uint64_t> *buf = nullptr;   // packed intervals (relaxed atomics: a reader may look at an attempt being overwritten;
+};                                          // it finds out at its next look at `prog` and throws away what it made of them)
+constexpr uint64_t PIPE_N_MASK = (1ULL << 40) - 1;
+inline uint64_t pipe_pack(ival v) { return (uint64_t)(uint32_t)v.first | ((uint64_t)(uint32_t)v.last << 32); }
+inline ival pipe_unpack(uint64_t u) { return ival{(int32_t)(uint32_t)u, (int32_t)(uint32_t)(u >> 32)}; }
+inline void pipe_relax(int &spins) {
+    if (++spins > 256) std::this_thread::yield();
+}
+constexpr int64_t PIPE_BATCH = 256;   // intervals between two publications: the reader streams whole batches (a reader at the writer's
+                                      // heels pulls every cache line across the chip one miss at a time)
+struct pipe_sink {   // the output of a task's attempt: addInterval's cut, progress published every PIPE_BATCH intervals
+    pipe_rec *r;
+    int64_t cap, o = 0;
+    uint64_t attempt;
+    bool put(int64_t a, int64_t b) {
+        while (b - a >= MAXIMUM_DIFF) {
+            if (o >= cap) return false;
+            r->buf[o++].store(pipe_pack(ival{(int32_t)a, (int32_t)(a + MAXIMUM_DIFF - 1)}), std::memory_order_relaxed);
+            a += MAXIMUM_DIFF;
+        }
+        if (o >= cap) return false;
+        r->buf[o++].store(pipe_pack(ival{(int32_t)a, (int32_t)b}), std::memory_order_relaxed);
+        if ((o & (PIPE_BATCH - 1)) == 0) r->prog.store((attempt << 40) | (uint64_t)o, std::memory_order_release);
+        return true;
+    }
+};
+struct pipe_src_stream {   // the predecessor's union, as far as it has been published
+    const pipe_rec *r;
+    uint64_t attempt;
+    int64_t seen = 0;
+    // 1: v = interval i; 0: the union is complete and has no interval i; -1: this is not (any more) what the walk goes on from
+    int get(int64_t i, ival &v) {
+        int spins = 0;
+        while (i >= seen) {
+            const int d = r->decided.load(std::memory_order_acquire);
+            const uint64_t p = r->prog.load(std::memory_order_acquire);
+            if ((p >> 40) != attempt || d == 2) return -1;
+            seen = (int64_t)(p & PIPE_N_MASK);
+            if (i < seen) break;
+            if (d == 1) return 0;   // (decided before the last look at prog: `seen` is the union's final size)
+            pipe_relax(spins);
+        }
+        v = pipe_unpack(r->buf[i].load(std::memory_order_relaxed));
+        return 1;
+    }
+};
+struct pipe_src_raw {
+    raw_view v;
+    int get(int64_t i, ival &out) const {
+        if (i >= v.n) return 0;
+        out = v.at(i);
+        return 1;
+    }
+};
+// IndexNodeUtils.mergeIndexNode once more (merge_walk above, without the runs): list 1 from a source that may still be growing.
+// 0: done; -1: the source is not what it seemed (start again); -2: the sink is full (a guess gone far wrong: wait, start again)
+template <class Src>
+inline int merge_from(Src &src, const raw_view &n2, pipe_sink &out) {
+    const int64_t s2 = n2.n;
+    int64_t i1 = 0, i2 = 0;
+    bool h1 = false, h2 = false;
+    ival l1{0, 0}, l2{0, 0};
+    for (;;) {
+        if (!h1) {
+            const int g = src.get(i1, l1);
+            if (g < 0) return -1;
+            if (g == 0) break;
+            h1 = true;
+        }
+        if (i2 >= s2) break;
+        if (!h2) { l2 = n2.at(i2); h2 = true; }
+        if ((int64_t)l1.last + 1 < (int64_t)l2.first) {
+            if (!out.put(l1.first, l1.last)) return -2;
+            i1++;
+            h1 = false;
+        } else if ((int64_t)l2.last + 1 < (int64_t)l1.first) {
+            if (!out.put(l2.first, l2.last)) return -2;
+            i2++;
+            h2 = false;
+        } else if (l1.last < l2.last) {
+            if (l1.first < l2.first) l2.first = l1.first;
+            i1++;
+            h1 = false;
+        } else {
+            if (l2.first < l1.first) l1.first = l2.first;
+            i2++;
+            h2 = false;
+        }
+    }
+    for (;;) {
+        if (!h1) {
+            const int g = src.get(i1, l1);
+            if (g < 0) return -1;
+            if (g == 0) break;
+        }
+        if (!out.put(l1.first, l1.last)) return -2;
+        h1 = false;
+        i1++;
+    }
+    for (; i2 < s2; i2++) {
+        if (!h2) l2 = n2.at(i2);
+        if (!out.put(l2.first, l2.last)) return -2;
+        h2 = false;
+    }
+    return 0;
+}
+
 inline void put_be32(uint8_t *p, int32_t v) {
     const uint32_t u = (uint32_t)v;
     p[0] = (uint8_t)(u >> 24); p[1] = (uint8_t)(u >> 16); p[2] = (uint8_t)(u >> 8); p[3] = (uint8_t)u;
@@ -183,6 +308,11 @@ int64_t encode_compact(const ival *pos, int64_t size, uint8_t *result) {
     return length;
 }
 
+// which ranges get a team: many rows, and rows long enough that a task's merge outweighs its hand-shakes (at n = 1e8 the sparse
+// ends at Wu = 25 and 50 qualify; at Wu >= 100 their rows hold ~ 200 intervals and one thread is as fast).  The CPU harness
+// lowers them (kvm_index_file_test_thresholds) so that lists of a few 10^5 points go through the pipeline under the sanitizers.
+std::atomic<int64_t> g_team_min_rows{4096}, g_team_min_row_size{250};
+
 double now_ms() {
     timespec ts;
     clock_gettime(CLOCK_MONOTONIC, &ts);
@@ -190,6 +320,11 @@ double now_ms() {
 }
 
 }  // namespace
+
+void kvm_index_file_test_thresholds(int64_t rows, int64_t row_size) {   // (C++ linkage: not part of the ABI; tests/harness only)
+    g_team_min_rows.store(rows);
+    g_team_min_row_size.store(row_size);
+}
 
 extern "C" int kvm_index_build(kvm_ctx *ctx, int32_t w, kvm_index_file **out) {
     return kvm_guard<int>(ctx, [&]() -> int {
@@ -319,14 +454,18 @@ extern "C" int kvm_index_build(kvm_ctx *ctx, int32_t w, kvm_index_file **out) {
         std::vector<row_t> rows;   // finished, in order
         chain pending;             // the row being built when the range ended
     };
-    const int nw = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)std::max(1u, std::thread::hardware_concurrency()), 16, G / 64 + 1}));
+    // (threads: at most 16 -- the ranges' own, less what the two teams of the sparse ends add, see run_team below)
+    const int hc = (int)std::max(1u, std::thread::hardware_concurrency());
+    const int team = hc >= 4 ? 2 : 1;   // (measured at n = 1e8 on 64 cores: 2 threads 1.4 x, 4 threads 1.5 x, 6 threads 1.4 x one thread's rate)
+    const int nw = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)hc, 16 - 2 * (team - 1), G / 64 + 1}));
     std::vector<walked> parts(1);
     for (int t = 1; t < nw; t++) {
         // ranges of about equal interval count, cut where the true walk certainly starts afresh: at the first row behind the
         // share point that is never merged (a row of at least 1.2 x the average); the stitching then joins at once.  The sparse
         // rows at both ends of the key range form chains without such a row, in which two walks started at different rows take
         // thousands of rows to meet (measured: 2 932 and 1 824 rows at n = 1e8, Wu = 25): a cut inside them buys nothing -- the
-        // true walk redoes the range -- so those chains stay whole, and they are what bounds this step (86 of its 93 ms there).
+        // true walk redoes the range -- so those chains stay whole (86 of this step's 93 ms were there; they are walked as a
+        // pipeline now: run_team).
         int64_t c = (int64_t)(std::lower_bound(goff, goff + G, (int32_t)(cnt * t / nw)) - goff);
         while (c < G && !((double)((int64_t)goff[c + 1] - goff[c]) >= average * 1.2)) c++;
         if (c > parts.back().b0 && c < G) {
@@ -336,6 +475,133 @@ extern "C" int kvm_index_build(kvm_ctx *ctx, int32_t w, kvm_index_file **out) {
         }
     }
     parts.back().b1 = G;
+    // Ranges of many rows (the sparse ends of the key range: a third of the rows, a tenth of the intervals, nine tenths of the
+    // work) are walked by a team of threads as a pipeline (pipe_rec above); the others by one thread each.
+    const int64_t TEAM_MIN_ROWS = g_team_min_rows.load(), TEAM_MIN_ROW_SIZE = g_team_min_row_size.load();
+    std::atomic<int> pipe_error{0};
+    auto run_team = [&](size_t t, int D) {
+        walked &o = parts[t];
+        const double w0 = now_ms();
+        const int64_t b0 = o.b0, b1 = o.b1, nr = b1 - b0;
+        const int NB = D + 1;   // buffers: row i writes buffer i mod NB, read by row i + 1 alone -- whose thread takes row i + NB next
+        int64_t maxrow = 0;
+        for (int64_t i = b0; i < b1; i++) maxrow = std::max<int64_t>(maxrow, (int64_t)goff[i + 1] - goff[i]);
+        // a union the walk keeps holds fewer than max(largest row, 4.8 x average) intervals (it is kept only below 0.8 x (union
+        // before + row), row < 1.2 x average); a union made on a wrong guess, up to D guesses deep, that + D + 1 rows
+        const int64_t cap = std::max<int64_t>(maxrow, (int64_t)(average * 4.8) + 1) + (int64_t)(average * 1.2 + 1) * (D + 2) + 64;
+        std::unique_ptr<std::atomic<uint64_t>[]> slab(new std::atomic<uint64_t>[(size_t)(cap * NB)]);
+        std::unique_ptr<pipe_rec[]> rec(new pipe_rec[(size_t)nr]);
+        for (int64_t q = 0; q < nr; q++) rec[(size_t)q].buf = slab.get() + ((b0 + q) % NB) * cap;
+        ival *at = stored + goff[b0];   // (handed from task to task with the decisions, like o.rows)
+        // the walk's row behind row i - 1 is finished under row i - 1's key
+        auto finish_behind = [&](int64_t i) {
+            const pipe_rec &pr = rec[(size_t)(i - 1 - b0)];
+            const int64_t nn = pr.n;
+            if (pr.decided.load(std::memory_order_relaxed) == 2) {
+                const raw_view v = raw(i - 1);
+                for (int64_t q = 0; q < nn; q++) at[q] = v.at(q);
+            } else {
+                for (int64_t q = 0; q < nn; q++) at[q] = pipe_unpack(pr.buf[q].load(std::memory_order_relaxed));
+            }
+            o.rows.push_back(row_t{at, nn, gkey[i - 1], pr.first_row});
+            at += nn;
+        };
+        auto wait_decided = [&](const pipe_rec &pr) {
+            int spins = 0;
+            while (pr.decided.load(std::memory_order_acquire) == 0) {
+                if (pipe_error.load(std::memory_order_relaxed)) return false;
+                pipe_relax(spins);
+            }
+            return true;
+        };
+        rec[0].n = (int64_t)goff[b0 + 1] - goff[b0];
+        rec[0].first_row = b0;
+        rec[0].decided.store(2, std::memory_order_release);
+        auto member = [&](int d) {
+            try {
+                for (int64_t i = b0 + 1 + d; i < b1; i += D) {
+                    pipe_rec &me = rec[(size_t)(i - b0)];
+                    const pipe_rec &pr = rec[(size_t)(i - 1 - b0)];
+                    const raw_view cur = raw(i);
+                    bool kept = false;
+                    int64_t mn = 0;
+                    if ((double)cur.n < average * 1.2) {
+                        uint64_t attempt = 0;
+                        bool guess = true;   // merge into the predecessor's union while it is still being made
+                        for (;;) {
+                            if (pipe_error.load(std::memory_order_relaxed)) return;
+                            if (!guess && !wait_decided(pr)) return;
+                            attempt++;
+                            me.prog.store(attempt << 40, std::memory_order_release);   // (whoever reads my union starts again)
+                            pipe_sink out{&me, cap, 0, attempt};
+                            int rc;
+                            if (pr.decided.load(std::memory_order_acquire) == 2) {
+                                pipe_src_raw src{raw(i - 1)};
+                                rc = merge_from(src, cur, out);
+                            } else {
+                                pipe_src_stream src{&pr, pr.prog.load(std::memory_order_acquire) >> 40};
+                                rc = merge_from(src, cur, out);
+                            }
+                            if (rc == 0) {
+                                mn = out.o;
+                                me.prog.store((attempt << 40) | (uint64_t)mn, std::memory_order_release);
+                                break;
+                            }
+                            if (rc == -2) {
+                                if (!guess) {   // (cannot happen: see `cap`)
+                                    pipe_error.store(1);
+                                    return;
+                                }
+                                guess = false;
+                            }
+                        }
+                        if (!wait_decided(pr)) return;   // (it is: the source came to its end)
+                        kept = (double)mn < (double)(pr.n + cur.n) * 0.8;
+                    } else if (!wait_decided(pr)) {
+                        return;
+                    }
+                    if (kept) {
+                        me.n = mn;
+                        me.first_row = pr.first_row;
+                        me.decided.store(1, std::memory_order_release);
+                    } else {
+                        finish_behind(i);
+                        me.n = cur.n;
+                        me.first_row = i;
+                        me.decided.store(2, std::memory_order_release);
+                    }
+                }
+            } catch (...) {
+                pipe_error.store(2);
+            }
+        };
+        {
+            std::vector<std::thread> th;
+            try {
+                for (int d = 1; d < D; d++) th.emplace_back(member, d);
+            } catch (...) {
+                pipe_error.store(2);
+            }
+            member(0);
+            for (auto &x : th) x.join();
+        }
+        if (pipe_error.load()) return;
+        // the walk's state at the end of the range
+        const pipe_rec &lr = rec[(size_t)(nr - 1)];
+        chain &c = o.pending;
+        c.first_row = lr.first_row;
+        if (lr.decided.load() == 2) {
+            c.last_is_raw = true;
+            c.g_last = b1 - 1;
+        } else {
+            c.last_is_raw = false;
+            c.acc.resize((size_t)lr.n);
+            for (int64_t q = 0; q < lr.n; q++) c.acc[(size_t)q] = pipe_unpack(lr.buf[q].load(std::memory_order_relaxed));
+        }
+        if (getenv("KVM_TRACE"))
+            fprintf(stderr, "[kvm] index walk range %d rows %lld..%lld intervals %lld: %.1f ms (a team of %d)\n", (int)t, (long long)b0, (long long)b1,
+                    (long long)(goff[b1] - goff[b0]), now_ms() - w0, D);
+    };
     {
         auto run = [&](size_t t) {
             walked &o = parts[t];
@@ -354,10 +620,25 @@ extern "C" int kvm_index_build(kvm_ctx *ctx, int32_t w, kvm_index_file **out) {
                 fprintf(stderr, "[kvm] index walk thread %d rows %lld..%lld intervals %lld: %.1f ms\n", (int)t, (long long)o.b0, (long long)o.b1,
                         (long long)(goff[o.b1] - goff[o.b0]), now_ms() - w0);
         };
+        auto walk = [&](size_t t) {
+            try {   // (a worker thread: nothing may leave it)
+                const int64_t nrows = parts[t].b1 - parts[t].b0, nint = (int64_t)goff[parts[t].b1] - goff[parts[t].b0];
+                if (team > 1 && nrows >= TEAM_MIN_ROWS && nint >= TEAM_MIN_ROW_SIZE * nrows) run_team(t, team);
+                else run(t);
+            } catch (...) {
+                pipe_error.store(2);
+            }
+        };
         std::vector<std::thread> th;
-        for (size_t t = 1; t < parts.size(); t++) th.emplace_back(run, t);
-        run(0);
+        for (size_t t = 1; t < parts.size(); t++) th.emplace_back(walk, t);
+        walk(0);
         for (auto &x : th) x.join();
+    }
+    if (pipe_error.load()) {
+        kvm_index_rows_free(rows);
+        delete f;
+        kvm_set_error(ctx, "kvm_index_build: step 2 failed (out of memory, or an internal error of the pipelined walk)");
+        return pipe_error.load() == 2 ? KVM_ERR_NO_MEMORY : KVM_ERR_DEVICE;
     }
     // ---- stitching (one thread; a few rows per boundary)
     std::vector<row_t> rows_done;

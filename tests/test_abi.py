@@ -187,6 +187,10 @@ def test_index_file_host_code_on_cpu_under_sanitizers(built, tmp_path):
     r = subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-Wall", "-Werror", "-fsanitize=address,undefined",
                         "-fno-sanitize-recover=all", "-pthread", "-o", str(exe)] + src, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+    exe_tsan = tmp_path / "index_file_harness_tsan"
+    r = subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-Wall", "-Werror", "-fsanitize=thread", "-pthread", "-o", str(exe_tsan)] + src,
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
     rng = np.random.default_rng(17)
     for trial in range(26):     # (the large ones: the row sequence is cut into up to 16 ranges walked by threads and stitched)
         n = int(rng.integers(300, 40_000)) if trial < 8 else (260_000 if trial < 10 else int(rng.integers(60_000, 400_000)))
@@ -199,12 +203,18 @@ def test_index_file_host_code_on_cpu_under_sanitizers(built, tmp_path):
             for arr, dt in ((keys, np.float64), (first, np.int32), (last, np.int32), (gk, np.float64), (go, np.int32)):
                 f.write(np.ascontiguousarray(arr, dtype=dt).tobytes())
         out = tmp_path / "image.out"
-        r = subprocess.run([str(exe), str(rows), str(out)], capture_output=True, text=True,
-                           env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1"))
-        assert r.returncode == 0, (trial, r.stderr[-2000:])
         want, info = oracle.index_file(s, w)
-        assert out.read_bytes() == want, (trial, n, w)
-        assert [int(x) for x in r.stdout.split()] == info
+        # as the library runs it, and with the thresholds of the pipelined walk (kvm_index_file.cpp, run_team: two threads, the
+        # second merging into the union the first is still writing) lowered so that these small lists go through it -- under
+        # ASan / UBSan, and every fourth trial under ThreadSanitizer as well
+        runs = [(exe, []), (exe, ["8", "1"])] + ([(exe_tsan, ["8", "1"])] if trial % 4 == 1 else [])
+        for binary, extra in runs:
+            out.unlink(missing_ok=True)
+            r = subprocess.run([str(binary), str(rows), str(out)] + extra, capture_output=True, text=True,
+                               env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1", TSAN_OPTIONS="halt_on_error=1"))
+            assert r.returncode == 0, (trial, extra, r.stderr[-2000:])
+            assert out.read_bytes() == want, (trial, n, w, extra)
+            assert [int(x) for x in r.stdout.split()] == info
     # no rows at all -> the IllegalArgument path (the Java code dies on rawStatisticInfo.get(0))
     with open(rows, "wb") as f:
         f.write(np.array([0, 0], dtype=np.int64).tobytes() + np.zeros(1, dtype=np.int32).tobytes())
