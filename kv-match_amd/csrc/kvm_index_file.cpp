@@ -395,6 +395,14 @@ extern "C" int kvm_index_build(kvm_ctx *ctx, int32_t w, kvm_index_file **out) {
         int64_t n;
         double key;
         int64_t first_row;   // the row of step 1 the walk started this row at
+        int64_t line_len = -1;   // bytes of the row's line in the file and the offsets it covers, where the range's own thread had
+        uint32_t offsets = 0;    // the time to work them out (below); -1: left to the encoding passes
+    };
+    auto row_line_facts = [](row_t &r) {
+        r.line_len = 8 + encode_compact<false>(r.p, r.n, nullptr);
+        uint32_t nofs = 0;   // (a Java int sum: wraps like it)
+        for (int64_t q = 0; q < r.n; q++) nofs += (uint32_t)(r.p[q].last - r.p[q].first + 1);
+        r.offsets = nofs;
     };
     struct chain {           // the walk's state: the row being built
         std::vector<ival> acc, merged;
@@ -616,9 +624,13 @@ extern "C" int kvm_index_build(kvm_ctx *ctx, int32_t w, kvm_index_file **out) {
                     o.rows.push_back(row_t{at, nn, key, c.first_row});
                     at += nn;
                 });
+            const double w1 = now_ms();
+            // (the ranges between the sparse ends are walked in a few milliseconds; the teams at the ends take ten times as long:
+            // this thread measures its own rows' lines meanwhile -- two of the three encoding passes over nine tenths of the intervals)
+            for (row_t &r : o.rows) row_line_facts(r);
             if (getenv("KVM_TRACE"))
-                fprintf(stderr, "[kvm] index walk thread %d rows %lld..%lld intervals %lld: %.1f ms\n", (int)t, (long long)o.b0, (long long)o.b1,
-                        (long long)(goff[o.b1] - goff[o.b0]), now_ms() - w0);
+                fprintf(stderr, "[kvm] index walk thread %d rows %lld..%lld intervals %lld: %.1f ms + %.1f ms measuring its lines\n", (int)t, (long long)o.b0,
+                        (long long)o.b1, (long long)(goff[o.b1] - goff[o.b0]), w1 - w0, now_ms() - w1);
         };
         auto walk = [&](size_t t) {
             try {   // (a worker thread: nothing may leave it)
@@ -709,8 +721,9 @@ extern "C" int kvm_index_build(kvm_ctx *ctx, int32_t w, kvm_index_file **out) {
     std::vector<int64_t> line_len((size_t)R);
     on_threads([&](int t) {
         for (int64_t k = cut[(size_t)t]; k < cut[(size_t)t + 1]; k++) {
-            const row_t &r = rows_done[(size_t)(R - 1 - k)];
-            line_len[(size_t)k] = 8 + encode_compact<false>(r.p, r.n, nullptr);
+            row_t &r = rows_done[(size_t)(R - 1 - k)];
+            if (r.line_len < 0) row_line_facts(r);
+            line_len[(size_t)k] = r.line_len;
         }
     });
     std::vector<int64_t> line_at((size_t)R + 1, 0);
@@ -734,22 +747,12 @@ extern "C" int kvm_index_build(kvm_ctx *ctx, int32_t w, kvm_index_file **out) {
         }
     });
     // the statistic triples {key, running #intervals, running #offsets} in line order (Java int sums: they wrap like them);
-    // the per-row offset counts by the threads, the running sums here
-    std::vector<uint32_t> row_ofs((size_t)R);
-    on_threads([&](int t) {
-        for (int64_t k = cut[(size_t)t]; k < cut[(size_t)t + 1]; k++) {
-            const row_t &r = rows_done[(size_t)(R - 1 - k)];
-            uint32_t nofs = 0;
-            const ival *p = r.p;
-            for (int64_t q = 0; q < r.n; q++) nofs += (uint32_t)(p[q].last - p[q].first + 1);
-            row_ofs[(size_t)k] = nofs;
-        }
-    });
+    // the per-row offset counts were taken with the line lengths, the running sums here
     uint32_t cum_iv = 0, cum_off = 0;
     for (int64_t k = 0; k < R; k++) {
         const row_t &r = rows_done[(size_t)(R - 1 - k)];
         cum_iv += (uint32_t)r.n;
-        cum_off += row_ofs[(size_t)k];
+        cum_off += r.offsets;
         uint8_t *at = img + lines_bytes + 16 * k;
         put_be_double(at, r.key);
         put_be32(at + 8, (int32_t)cum_iv);
