@@ -58,7 +58,7 @@ void kvm_idx_block_drop() {
     if (p) hipHostFree(p);
 }
 
-static int index_rows_build(kvm_ctx *ctx, int32_t w, bool grouped, kvm_index_rows **out) {
+static int index_rows_build(kvm_ctx *ctx, int32_t w, bool grouped, kvm_index_rows **out, bool with_keys = true) {
     if (!ctx) return KVM_ERR_INVALID_HANDLE;
     if (!out) return kvm_fail(ctx, KVM_ERR_ILLEGAL_ARGUMENT, "null result pointer");
     *out = nullptr;
@@ -88,7 +88,8 @@ static int index_rows_build(kvm_ctx *ctx, int32_t w, bool grouped, kvm_index_row
     }
     char *base = (char *)r->block;
     char *gbase = base + keys_bytes + 2 * fl_bytes;
-    const bool ok = hipMemcpyAsync(base, dev.keys, total * 8, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
+    // (the per-interval keys are half of the bytes; the file builder reads the group keys only and leaves them on the device)
+    const bool ok = (!with_keys || hipMemcpyAsync(base, dev.keys, total * 8, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess) &&
                     hipMemcpyAsync(base + keys_bytes, dev.first, total * 4, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
                     hipMemcpyAsync(base + keys_bytes + fl_bytes, dev.last, total * 4, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
                     (ng == 0 || (hipMemcpyAsync(gbase, dev.group_keys, ng * 8, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
@@ -105,7 +106,7 @@ static int index_rows_build(kvm_ctx *ctx, int32_t w, bool grouped, kvm_index_row
         if (hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) == hipSuccess) ctx->last_kernel_ns = (int64_t)(ms * 1e6);
     }
     r->count = (int64_t)total;
-    r->keys = (const double *)base;
+    r->keys = with_keys ? (const double *)base : nullptr;
     r->first = (const int32_t *)(base + keys_bytes);
     r->last = (const int32_t *)(base + keys_bytes + fl_bytes);
     if (ng) {
@@ -118,6 +119,8 @@ static int index_rows_build(kvm_ctx *ctx, int32_t w, bool grouped, kvm_index_row
 }
 extern "C" int kvm_index_rows_build(kvm_ctx *ctx, int32_t w, kvm_index_rows **out) { return kvm_guard<int>(ctx, [&]() -> int { return index_rows_build(ctx, w, false, out); }); }
 extern "C" int kvm_index_rows_build_grouped(kvm_ctx *ctx, int32_t w, kvm_index_rows **out) { return kvm_guard<int>(ctx, [&]() -> int { return index_rows_build(ctx, w, true, out); }); }
+// kvm_index_build's own call (kvm_index_file.cpp; C++ linkage, not part of the ABI): grouped rows without the per-interval keys
+int kvm_index_rows_build_for_file(kvm_ctx *ctx, int32_t w, kvm_index_rows **out) { return kvm_guard<int>(ctx, [&]() -> int { return index_rows_build(ctx, w, true, out, false); }); }
 extern "C" int64_t kvm_index_rows_groups(const kvm_index_rows *r) { return r ? r->n_groups : 0; }
 extern "C" const double *kvm_index_rows_group_keys(const kvm_index_rows *r) { return r ? r->group_keys : nullptr; }
 extern "C" const int32_t *kvm_index_rows_group_offsets(const kvm_index_rows *r) { return r ? r->group_off : nullptr; }

@@ -37,6 +37,7 @@
 #include "../../include/kvmatch.h"
 
 void kvm_set_error(kvm_ctx *ctx, const std::string &msg);  // kvm_api.hip
+int kvm_index_rows_build_for_file(kvm_ctx *ctx, int32_t w, kvm_index_rows **out);  // kvm_api_index.hip: grouped rows, group keys only
 
 struct kvm_index_file {
     std::unique_ptr<uint8_t[]> image;   // (not a vector: its threads first-touch their own parts; nothing zero-fills 100 MB)
@@ -336,7 +337,7 @@ extern "C" int kvm_index_build(kvm_ctx *ctx, int32_t w, kvm_index_file **out) {
     *out = nullptr;
     const double t0 = now_ms();
     kvm_index_rows *rows = nullptr;
-    int rc = kvm_index_rows_build_grouped(ctx, w, &rows);
+    int rc = kvm_index_rows_build_for_file(ctx, w, &rows);
     if (rc) return rc;
     const int64_t G = kvm_index_rows_groups(rows), cnt = kvm_index_rows_count(rows);
     if (G < 1) {  // (the Java code runs into rawStatisticInfo.get(0) on an empty list, K/IndexBuilder.java:321)

@@ -23,11 +23,11 @@ static std::string g_err;
 void kvm_set_error(kvm_ctx *, const std::string &msg) { g_err = msg; }
 void kvm_set_error_noexcept(kvm_ctx *, const char *msg) noexcept { try { g_err = msg; } catch (...) {} }
 
-extern "C" {
-int kvm_index_rows_build_grouped(kvm_ctx *, int32_t, kvm_index_rows **out) {
+int kvm_index_rows_build_for_file(kvm_ctx *, int32_t, kvm_index_rows **out) {   // (the library's internal step-1 call)
     *out = &g_rows;
     return KVM_OK;
 }
+extern "C" {
 int64_t kvm_index_rows_groups(const kvm_index_rows *r) { return (int64_t)r->gkeys.size(); }
 int64_t kvm_index_rows_count(const kvm_index_rows *r) { return (int64_t)r->keys.size(); }
 const double *kvm_index_rows_group_keys(const kvm_index_rows *r) { return r->gkeys.data(); }
