@@ -39,9 +39,47 @@
 void kvm_set_error(kvm_ctx *ctx, const std::string &msg);  // kvm_api.hip
 int kvm_index_rows_build_for_file(kvm_ctx *ctx, int32_t w, kvm_index_rows **out);  // kvm_api_index.hip: grouped rows, group keys only
 
+// The image of a file that has been freed is kept for the next build (one buffer, the largest seen): a process builds the five
+// indexes of a series one after the other, and 100 MB of fresh pages cost the encoder's threads ~10 ms of faults per call.
+namespace {
+struct image_pool_t {
+    std::mutex mu;
+    std::unique_ptr<uint8_t[]> p;
+    size_t cap = 0;
+};
+image_pool_t *image_pool() {
+    static image_pool_t *pool = new image_pool_t();   // (never destroyed: a file may be freed at exit)
+    return pool;
+}
+}  // namespace
 struct kvm_index_file {
     std::unique_ptr<uint8_t[]> image;   // (not a vector: its threads first-touch their own parts; nothing zero-fills 100 MB)
-    size_t image_size = 0;
+    size_t image_size = 0, image_cap = 0;
+    void take_image(size_t bytes) {
+        image_pool_t *pool = image_pool();
+        {
+            std::lock_guard<std::mutex> lk(pool->mu);
+            if (pool->cap >= bytes) {
+                image = std::move(pool->p);
+                image_cap = pool->cap;
+                pool->cap = 0;
+            }
+        }
+        if (!image) {
+            image.reset(new uint8_t[bytes]);
+            image_cap = bytes;
+        }
+        image_size = bytes;
+    }
+    ~kvm_index_file() {
+        if (!image) return;
+        image_pool_t *pool = image_pool();
+        std::lock_guard<std::mutex> lk(pool->mu);
+        if (image_cap > pool->cap) {
+            pool->p = std::move(image);
+            pool->cap = image_cap;
+        }
+    }
     int64_t rows_before = 0, rows_after = 0, intervals_before = 0, intervals_after = 0;
     double step1_ms = 0, step2_ms = 0, encode_ms = 0;
 };
@@ -736,8 +774,7 @@ extern "C" int kvm_index_build(kvm_ctx *ctx, int32_t w, kvm_index_file **out) {
         kvm_set_error(ctx, "kvm_index_build: the index file would reach 2 GiB (its offsets are Java ints)");
         return KVM_ERR_UNSUPPORTED;
     }
-    f->image.reset(new uint8_t[(size_t)image_bytes]);
-    f->image_size = (size_t)image_bytes;
+    f->take_image((size_t)image_bytes);
     uint8_t *img = f->image.get();
     on_threads([&](int t) {
         for (int64_t k = cut[(size_t)t]; k < cut[(size_t)t + 1]; k++) {
