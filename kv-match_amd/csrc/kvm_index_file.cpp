@@ -436,6 +436,7 @@ extern "C" int kvm_index_build(kvm_ctx *ctx, int32_t w, kvm_index_file **out) {
         int64_t first_row;   // the row of step 1 the walk started this row at
         int64_t line_len = -1;   // bytes of the row's line in the file and the offsets it covers, where the range's own thread had
         uint32_t offsets = 0;    // the time to work them out (below); -1: left to the encoding passes
+        const uint8_t *line = nullptr;   // ... and the line itself, encoded ahead into the range's side buffer
     };
     auto row_line_facts = [](row_t &r) {
         r.line_len = 8 + encode_compact<false>(r.p, r.n, nullptr);
@@ -499,6 +500,7 @@ extern "C" int kvm_index_build(kvm_ctx *ctx, int32_t w, kvm_index_file **out) {
     struct walked {
         int64_t b0 = 0, b1 = 0;    // rows [b0, b1)
         std::vector<row_t> rows;   // finished, in order
+        std::unique_ptr<uint8_t[]> lines;   // their lines, encoded while the end ranges were still being walked
         chain pending;             // the row being built when the range ended
     };
     // (threads: at most 16 -- the ranges' own, less what the two teams of the sparse ends add, see run_team below)
@@ -665,10 +667,24 @@ extern "C" int kvm_index_build(kvm_ctx *ctx, int32_t w, kvm_index_file **out) {
                 });
             const double w1 = now_ms();
             // (the ranges between the sparse ends are walked in a few milliseconds; the teams at the ends take ten times as long:
-            // this thread measures its own rows' lines meanwhile -- two of the three encoding passes over nine tenths of the intervals)
-            for (row_t &r : o.rows) row_line_facts(r);
+            // this thread measures its own rows' lines meanwhile -- nine tenths of the intervals)
+            int64_t bytes = 0;
+            for (row_t &r : o.rows) {
+                row_line_facts(r);
+                bytes += r.line_len;
+            }
+            // ... and encodes them: where a line goes in the file depends on the lines of the lowest keys -- the far end's, finished
+            // last -- so into a buffer of its own; the final pass then copies (a tenth of what encoding costs)
+            o.lines.reset(new uint8_t[(size_t)bytes + 1]);
+            uint8_t *dst = o.lines.get();
+            for (row_t &r : o.rows) {
+                put_be_double(dst, r.key);
+                (void)encode_compact<true>(r.p, r.n, dst + 8);
+                r.line = dst;
+                dst += r.line_len;
+            }
             if (getenv("KVM_TRACE"))
-                fprintf(stderr, "[kvm] index walk thread %d rows %lld..%lld intervals %lld: %.1f ms + %.1f ms measuring its lines\n", (int)t, (long long)o.b0,
+                fprintf(stderr, "[kvm] index walk thread %d rows %lld..%lld intervals %lld: %.1f ms + %.1f ms encoding its lines\n", (int)t, (long long)o.b0,
                         (long long)o.b1, (long long)(goff[o.b1] - goff[o.b0]), w1 - w0, now_ms() - w1);
         };
         auto walk = [&](size_t t) {
@@ -744,11 +760,15 @@ extern "C" int kvm_index_build(kvm_ctx *ctx, int32_t w, kvm_index_file **out) {
     std::vector<int64_t> cut((size_t)nt + 1, R);
     cut[0] = 0;
     {
-        int64_t seen = 0;
+        // (by the work that is left: a line encoded ahead is a copy -- a sixteenth of an interval's cost per interval, say; the
+        // lines of the end ranges, measured and encoded here, are what the threads have to share)
+        auto cost = [](const row_t &r) { return r.line ? r.n / 16 + 1 : r.n + 1; };
+        int64_t total_cost = 0, seen = 0;
+        for (const row_t &r : rows_done) total_cost += cost(r);
         int t = 1;
         for (int64_t k = 0; k < R && t < nt; k++) {
-            seen += rows_done[(size_t)(R - 1 - k)].n;
-            if (seen >= total_iv * t / nt) cut[(size_t)t++] = k + 1;
+            seen += cost(rows_done[(size_t)(R - 1 - k)]);
+            if (seen >= total_cost * t / nt) cut[(size_t)t++] = k + 1;
         }
     }
     auto on_threads = [&](auto &&work) {
@@ -780,6 +800,10 @@ extern "C" int kvm_index_build(kvm_ctx *ctx, int32_t w, kvm_index_file **out) {
         for (int64_t k = cut[(size_t)t]; k < cut[(size_t)t + 1]; k++) {
             const row_t &r = rows_done[(size_t)(R - 1 - k)];
             uint8_t *dst = img + line_at[(size_t)k];
+            if (r.line) {
+                std::memcpy(dst, r.line, (size_t)r.line_len);
+                continue;
+            }
             put_be_double(dst, r.key);
             (void)encode_compact<true>(r.p, r.n, dst + 8);
         }
