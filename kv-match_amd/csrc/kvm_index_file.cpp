@@ -21,6 +21,9 @@
 // this row's is still being written (pipe_rec); one pass per attempted union, read straight from the grouped step-1 arrays; the
 // lines of the file are encoded by the same number of host threads.
 #include "kvm_guard.h"
+#include <pthread.h>
+#include <sched.h>
+
 #include <algorithm>
 #include <atomic>
 #include <cstdint>
@@ -348,9 +351,48 @@ int64_t encode_compact(const ival *pos, int64_t size, uint8_t *result) {
 }
 
 // which ranges get a team: many rows, and rows long enough that a task's merge outweighs its hand-shakes (at n = 1e8 the sparse
-// ends at Wu = 25 and 50 qualify; at Wu >= 100 their rows hold ~ 200 intervals and one thread is as fast).  The CPU harness
-// lowers them (kvm_index_file_test_thresholds) so that lists of a few 10^5 points go through the pipeline under the sanitizers.
-std::atomic<int64_t> g_team_min_rows{4096}, g_team_min_row_size{250};
+// ends qualify at every window length of the reference's index set: 120 intervals per row at Wu = 400, 320 at Wu = 25).  The CPU
+// harness lowers them (kvm_index_file_test_thresholds) so that lists of a few 10^5 points go through the pipeline under the
+// sanitizers.
+std::atomic<int64_t> g_team_min_rows{4096}, g_team_min_row_size{100}, g_team_size{0};   // (team size 0: by the number of CPUs)
+
+// The CPUs that share a last-level cache with the one this thread runs on (/sys/devices/system/cpu/cpuN/cache/index3/
+// shared_cpu_list, e.g. "8-15,136-143"), within what the thread may use: the two threads of a team hand every union from one to
+// the other, and on a chip of many cache domains that costs three times as much across two of them.  false: unknown -- no pinning.
+bool cache_mates(cpu_set_t *out) {
+    const int cpu = sched_getcpu();
+    if (cpu < 0) return false;
+    char path[128];
+    snprintf(path, sizeof path, "/sys/devices/system/cpu/cpu%d/cache/index3/shared_cpu_list", cpu);
+    FILE *fp = fopen(path, "r");
+    if (!fp) return false;
+    char buf[512];
+    const bool got = fgets(buf, sizeof buf, fp) != nullptr;
+    fclose(fp);
+    if (!got) return false;
+    cpu_set_t allowed;
+    if (pthread_getaffinity_np(pthread_self(), sizeof allowed, &allowed) != 0) return false;
+    CPU_ZERO(out);
+    int n = 0;
+    for (const char *q = buf; *q;) {
+        char *end = nullptr;
+        const long a = strtol(q, &end, 10);
+        if (end == q) break;
+        long b = a;
+        q = end;
+        if (*q == '-') {
+            b = strtol(q + 1, &end, 10);
+            q = end;
+        }
+        for (long c = a; c <= b && c < CPU_SETSIZE; c++)
+            if (c >= 0 && CPU_ISSET((int)c, &allowed)) {
+                CPU_SET((int)c, out);
+                n++;
+            }
+        while (*q == ',' || *q == ' ' || *q == '\n') q++;
+    }
+    return n >= 2;
+}
 
 double now_ms() {
     timespec ts;
@@ -360,9 +402,10 @@ double now_ms() {
 
 }  // namespace
 
-void kvm_index_file_test_thresholds(int64_t rows, int64_t row_size) {   // (C++ linkage: not part of the ABI; tests/harness only)
+void kvm_index_file_test_thresholds(int64_t rows, int64_t row_size, int64_t team_size) {   // (C++ linkage: not part of the ABI; tests/harness only)
     g_team_min_rows.store(rows);
     g_team_min_row_size.store(row_size);
+    g_team_size.store(team_size);
 }
 
 extern "C" int kvm_index_build(kvm_ctx *ctx, int32_t w, kvm_index_file **out) {
@@ -505,7 +548,10 @@ extern "C" int kvm_index_build(kvm_ctx *ctx, int32_t w, kvm_index_file **out) {
     };
     // (threads: at most 16 -- the ranges' own, less what the two teams of the sparse ends add, see run_team below)
     const int hc = (int)std::max(1u, std::thread::hardware_concurrency());
-    const int team = hc >= 4 ? 2 : 1;   // (measured at n = 1e8 on 64 cores: 2 threads 1.4 x, 4 threads 1.5 x, 6 threads 1.4 x one thread's rate)
+    // (measured at n = 1e8 on 64 cores in 8 cache domains, Wu = 25, step 2: one thread per end range 99 ms; teams wherever the
+    // scheduler put them: 2 threads 71 ms, 4 threads 65 ms; on CPUs that share a cache (cache_mates): 2 threads 54 ms, 3 threads
+    // 45 ms, 4 threads 40 ms)
+    const int team = g_team_size.load() > 0 ? (int)std::min<int64_t>(g_team_size.load(), 8) : (hc >= 16 ? 4 : (hc >= 4 ? 2 : 1));
     const int nw = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)hc, 16 - 2 * (team - 1), G / 64 + 1}));
     std::vector<walked> parts(1);
     for (int t = 1; t < nw; t++) {
@@ -625,6 +671,11 @@ extern "C" int kvm_index_build(kvm_ctx *ctx, int32_t w, kvm_index_file **out) {
             }
         };
         {
+            // the team on CPUs that share a cache (threads inherit the mask of the thread that starts them); this thread's own
+            // mask -- it may be the caller's -- is put back afterwards
+            cpu_set_t mine, mates;
+            const bool pinned = pthread_getaffinity_np(pthread_self(), sizeof mine, &mine) == 0 && cache_mates(&mates) &&
+                                pthread_setaffinity_np(pthread_self(), sizeof mates, &mates) == 0;
             std::vector<std::thread> th;
             try {
                 for (int d = 1; d < D; d++) th.emplace_back(member, d);
@@ -633,6 +684,7 @@ extern "C" int kvm_index_build(kvm_ctx *ctx, int32_t w, kvm_index_file **out) {
             }
             member(0);
             for (auto &x : th) x.join();
+            if (pinned) (void)pthread_setaffinity_np(pthread_self(), sizeof mine, &mine);
         }
         if (pipe_error.load()) return;
         // the walk's state at the end of the range

@@ -2,7 +2,7 @@
 // and the file layout run here WITHOUT a GPU, under AddressSanitizer / UBSan.  The GPU part -- step 1,
 // kvm_index_rows_build_grouped -- is replaced by rows read from a file the test wrote (the oracle's step-1 rows, grouped);
 // the image kvm_index_build produces from them goes to the output file and the test compares it with the oracle's.
-//   usage: index_file_harness <rows.bin> <image.out> [team_min_rows team_min_row_size]
+//   usage: index_file_harness <rows.bin> <image.out> [team_min_rows team_min_row_size team_size]
 //   rows.bin: int64 count, int64 groups, double keys[count], int32 first[count], int32 last[count],
 //             double group_keys[groups], int32 group_offsets[groups + 1]
 #include <cstdint>
@@ -44,11 +44,11 @@ static bool rd(FILE *f, std::vector<T> &v, size_t n) {
     return n == 0 || fread(v.data(), sizeof(T), n, f) == n;
 }
 
-void kvm_index_file_test_thresholds(int64_t rows, int64_t row_size);   // kvm_index_file.cpp: which ranges of rows a team of threads walks
+void kvm_index_file_test_thresholds(int64_t rows, int64_t row_size, int64_t team_size);   // kvm_index_file.cpp: which ranges of rows a team of threads walks, and of how many
 
 int main(int argc, char **argv) {
-    if (argc != 3 && argc != 5) return 2;
-    if (argc == 5) kvm_index_file_test_thresholds(atoll(argv[3]), atoll(argv[4]));   // (small lists through the pipelined walk as well)
+    if (argc != 3 && argc != 6) return 2;
+    if (argc == 6) kvm_index_file_test_thresholds(atoll(argv[3]), atoll(argv[4]), atoll(argv[5]));   // (small lists through the pipelined walk as well)
     FILE *f = fopen(argv[1], "rb");
     if (!f) return 2;
     int64_t cnt = 0, groups = 0;

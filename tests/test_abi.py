@@ -204,10 +204,10 @@ def test_index_file_host_code_on_cpu_under_sanitizers(built, tmp_path):
                 f.write(np.ascontiguousarray(arr, dtype=dt).tobytes())
         out = tmp_path / "image.out"
         want, info = oracle.index_file(s, w)
-        # as the library runs it, and with the thresholds of the pipelined walk (kvm_index_file.cpp, run_team: two threads, the
-        # second merging into the union the first is still writing) lowered so that these small lists go through it -- under
+        # as the library runs it, and with the thresholds of the pipelined walk (kvm_index_file.cpp, run_team: two or four threads, each
+        # merging into the union its predecessor is still writing) lowered so that these small lists go through it -- under
         # ASan / UBSan, and every fourth trial under ThreadSanitizer as well
-        runs = [(exe, []), (exe, ["8", "1"])] + ([(exe_tsan, ["8", "1"])] if trial % 4 == 1 else [])
+        runs = [(exe, []), (exe, ["8", "1", "2"]), (exe, ["8", "1", "4"])] + ([(exe_tsan, ["8", "1", "2" if trial % 8 == 1 else "4"])] if trial % 4 == 1 else [])
         for binary, extra in runs:
             out.unlink(missing_ok=True)
             r = subprocess.run([str(binary), str(rows), str(out)] + extra, capture_output=True, text=True,
