@@ -170,7 +170,12 @@ const int32_t *kvm_index_rows_group_offsets(const kvm_index_rows *r);
  * builder writes for the same series.  KVM_ERR_ILLEGAL_ARGUMENT when the series holds no window of length w,
  * KVM_ERR_UNSUPPORTED when the file would reach 2 GiB (its offsets are Java ints).  The image is owned by the library
  * until kvm_index_file_free; kvm_index_file_write stores it at `path` (the reference's name is
- * "files/index-" + N + "-" + Wu). */
+ * "files/index-" + N + "-" + Wu).
+ * Host side of a call: up to 16 threads of the library's own for its duration (the sparse rows at both ends of the key
+ * range by teams of four working as a pipeline, placed on CPUs that share a last-level cache -- the calling thread's CPU
+ * mask is changed for the time it works in such a team and put back before the call returns); between calls the process
+ * keeps three buffers for the next build (pinned staging of step 1's rows, 8 B per interval; the finished rows, 8 B per
+ * interval; the image of the last freed file): ~ 1 GB at n = 1e8, Wu = 25. */
 typedef struct kvm_index_file kvm_index_file;
 int kvm_index_build(kvm_ctx *ctx, int32_t w, kvm_index_file **out);
 int64_t kvm_index_file_size(const kvm_index_file *f);
