@@ -128,7 +128,7 @@ extern "C" int kvm_close(kvm_ctx *ctx) {
     free_series(ctx);
     kvm_dev_buf *bufs[] = {&ctx->b_query, &ctx->b_tiles, &ctx->b_out_off, &ctx->b_out_dist, &ctx->b_counters,
                            &ctx->b_cands, &ctx->b_cands2, &ctx->b_aux,   &ctx->b_aux2,    &ctx->b_scratch, &ctx->b_plans,
-                           &ctx->b_ucr};
+                           &ctx->b_ucr,   &ctx->b_edx};
     for (kvm_dev_buf *b : bufs)
         if (b->p) hipFree(b->p);
     if (ctx->h_pinned) hipHostFree(ctx->h_pinned);

@@ -175,7 +175,17 @@ struct edd_args {
     int32_t *out_off;   // answer buffers (RSM: a wave that ends with a few survivors evaluates them exactly itself)
     double *out_dist;
     int64_t out_cap;
+    double *xpart;      // device-built lists of a handful of units: the partial sums of a unit's workgroups (EDD_X_*, see edd_body)
+    unsigned *xcnt;     // ... and how many of them have arrived, per unit (zero between launches)
 };
+// A unit of a TINY device-built list (what a selective predicate leaves: a dozen units for 2048 wave slots) is shared by
+// EDD_X_WG workgroups of four waves -- 16 parts, four chunks each at m = 8192 -- instead of one: such a launch lasts as long as
+// one part (a lone wave issues an fp64 instruction per ~8 cycles: 64 us for a quarter window), and the waves are there for the
+// taking.  The workgroups of a unit hand their sums over through global memory; the one that arrives last finishes the unit.
+#define EDD_X_WG 4
+#define EDD_X_UNITS 128                                  // at most this many units in the list (x 16 parts = one wave per slot)
+#define EDD_X_SLOT (8 * 64 + 64)                         // doubles per workgroup and unit: CI <= 8 sums per lane, the lanes' masks, the flag
+#define EDD_X_BYTES ((size_t)EDD_X_UNITS * EDD_X_WG * EDD_X_SLOT * 8 + (size_t)EDD_X_UNITS * 4)
 #define EDD_INLINE_MAX 4  // survivors per wave-unit that are evaluated in place (more: handed to kvm_exact_ed_kernel)
 
 struct edd_cstat {
@@ -190,9 +200,11 @@ struct edd_cstat {
 // accumulators to part 0 through LDS behind one workgroup barrier, and part 0 finishes the candidates.  A unit is then
 // 1/f as long, which is what lets a few thousand units drain evenly from 2048 wave slots (see the launcher).
 // Every wave of a splitting workgroup reaches the barrier exactly once, whether or not it has work (`active`).
-template <int CI, int SUB, bool NORM, bool ABANDON>
+template <int CI, int SUB, bool NORM, bool ABANDON, bool CROSS = false>
 __device__ __forceinline__ void edd_body(const edd_args &A, const kvm_tile *__restrict__ tiles, int64_t n_tiles, int64_t t0,
-                                         double2 *lds_wave2, const int part, const int f, const bool active) {
+                                         double2 *lds_wave2, const int part, const int f, const bool active,
+                                         const int xp = 0, const int64_t xunit = 0) {   // (CROSS: EDD_X_WG workgroups share the unit: this is number xp; the unit's index)
+    constexpr int xw = CROSS ? EDD_X_WG : 1;
     using cfg = edd_cfg<CI, SUB>;
     constexpr int JC = cfg::JC;
     const int lane = threadIdx.x & 63;
@@ -396,14 +408,14 @@ __device__ __forceinline__ void edd_body(const edd_args &A, const kvm_tile *__re
         unsigned cntp = (unsigned)__popc(vm);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) cntp += __shfl_xor(cntp, o, 64);
-        if (lane == 0 && cntp && part == 0) atomicAdd(&A.counters[KVM_CNT_PASS_FILTER], (unsigned long long)cntp);
+        if (lane == 0 && cntp && part == 0 && xp == 0) atomicAdd(&A.counters[KVM_CNT_PASS_FILTER], (unsigned long long)cntp);
         if (cntp == 0) work = false;  // nothing in this wave passed the (alpha, beta) filter
     }
 
     double acc[CI];
 #pragma unroll
     for (int a = 0; a < CI; a++) acc[a] = 0.0;
-    const int ch_lo = nchunks * part / f, ch_hi = nchunks * (part + 1) / f;
+    const int ch_lo = nchunks * (xp * f + part) / (f * xw), ch_hi = nchunks * (xp * f + part + 1) / (f * xw);
     // ---- stream staging (classes A and B): lane = 8 row + piece stages points 2 piece, 2 piece + 1 of every 16-point block of its row
     const double *gsrc = series + ((int64_t)mine.start - 1 + 2 * lc);               // + point index of the block
     double *wdst = wlds + row * EDD_RS + cfg::row_shift(row) + 2 * lc;               // + position in the row
@@ -853,6 +865,30 @@ __device__ __forceinline__ void edd_body(const edd_args &A, const kvm_tile *__re
     } else if (!work) {
         return;
     }
+    if constexpr (CROSS) {
+        // the unit's workgroups -> the one that arrives last (this wave is part 0 of its workgroup and holds that workgroup's sums).
+        // Every workgroup of the unit gets here or none does: `work` is decided by the unit's tiles alone.
+        double *mine_x = A.xpart + ((size_t)xunit * EDD_X_WG + xp) * EDD_X_SLOT;
+#pragma unroll
+        for (int a = 0; a < CI; a++) mine_x[a * 64 + lane] = acc[a];
+        reinterpret_cast<unsigned *>(mine_x + 8 * 64)[lane] = vm;
+        reinterpret_cast<unsigned *>(mine_x + 8 * 64)[64 + lane] = handoff ? 1u : 0u;
+        __threadfence();
+        unsigned arrived = 0;
+        if (lane == 0) arrived = atomicAdd(&A.xcnt[xunit], 1u);
+        arrived = (unsigned)__builtin_amdgcn_readfirstlane((int)arrived);
+        if (arrived != (unsigned)(xw - 1)) return;
+        __threadfence();
+        if (lane == 0) A.xcnt[xunit] = 0u;   // (for the next launch)
+        for (int w = 0; w < xw; w++) {
+            if (w == xp) continue;
+            const double *px = A.xpart + ((size_t)xunit * EDD_X_WG + w) * EDD_X_SLOT;
+#pragma unroll
+            for (int a = 0; a < CI; a++) acc[a] += __builtin_nontemporal_load(px + a * 64 + lane);
+            vm &= __builtin_nontemporal_load(reinterpret_cast<const unsigned *>(px + 8 * 64) + lane);
+            handoff = handoff || __builtin_nontemporal_load(reinterpret_cast<const unsigned *>(px + 8 * 64) + 64 + lane) != 0u;
+        }
+    }
     unsigned keepm = 0;
     kvm_raw_sums rawf[4];
     if (ABANDON && handoff) {
@@ -1133,8 +1169,10 @@ __global__ __launch_bounds__(256, 2) void kvm_ed_dot_kernel(edd_args A, const kv
                                                             const kvm_tile *__restrict__ tilesC, int64_t nC, int fA, int fB,
                                                             int fC, int64_t blocksA, int64_t blocksC,
                                                             const unsigned long long *__restrict__ d_counts,
-                                                            int64_t split_units, int a16, int64_t a16_min_units, int b16) {
+                                                            int64_t split_units, int a16, int64_t a16_min_units, int b16,
+                                                            int64_t cross_units) {
     constexpr bool A16 = edd_a16<ABANDON>();
+    int xw = 1;   // workgroups per unit (EDD_X_WG for a tiny device-built list)
     if (d_counts) {  // tile lists built on the device (retile kernels): the launch only knows upper bounds
         nA = (int64_t)d_counts[0];
         nB = (int64_t)d_counts[1];
@@ -1154,7 +1192,17 @@ __global__ __launch_bounds__(256, 2) void kvm_ed_dot_kernel(edd_args A, const kv
         // are the longer ones)
         b16 = b16 && a16;
         blocksC = b16 ? (((nB + EDD_TILES_B16 - 1) / EDD_TILES_B16) * fB + 3) / 4 : (uC * fC + 3) / 4;
+        // a handful of units (8 tiles each, classes A and B on 8 / 4 per lane): EDD_X_WG workgroups to a unit (see EDD_X_*)
+        // (cNSM only.  RSM-ED's device-built lists are what a 128-point head check leaves with early abandoning on: their parts
+        // end at the first test or hand over, and sixteen of them cost a unit 8 us more than four -- 111 / 83 / 65 against
+        // 104 / 99 / 56 us on three queries; the cNSM pruner of a selective query: 107 -> 74 us, every point 96 -> 64)
+        if (NORM && small && !a16 && uC == 0 && uA8 + uB <= cross_units && (uA8 + uB) * EDD_X_WG <= (int64_t)gridDim.x) {
+            xw = EDD_X_WG;
+            blocksA = uA8 * EDD_X_WG;
+            blocksC = 0;
+        }
     }
+    xw = __builtin_amdgcn_readfirstlane(xw);
     // (wave-uniform by construction, but after the 64-bit compares above the compiler keeps it in a VGPR, and a scalar select
     // on it -- `t0 = slot / fA * (a16 ? 16 : 8)` -- was MISCOMPILED in one build of this file: v_cmp into VCC followed by
     // s_cselect_b32 on a stale SCC, the s_and_b64 vcc, vcc, exec between them gone; units then started every 8 tiles and
@@ -1169,6 +1217,16 @@ __global__ __launch_bounds__(256, 2) void kvm_ed_dot_kernel(edd_args A, const kv
     // launch order = longest units first: class A (a unit over the whole window: 0.50 ms at m = 8192), then class C
     // (0.35), then class B (0.26)
     const int64_t blk = (int64_t)blockIdx.x;
+    if (xw > 1) {   // (fA = fB = 4: a workgroup's four waves are the four parts of its share of the unit)
+        const int64_t uA8 = (nA + EDD_TILES_A - 1) / EDD_TILES_A, uB = (nB + EDD_TILES_B - 1) / EDD_TILES_B;
+        const int64_t unit = blk / xw;
+        const int xp = (int)(blk % xw);
+        if constexpr (NORM) {
+            if (unit < uA8) edd_body<8, 1, NORM, ABANDON, true>(A, tilesA, nA, unit * EDD_TILES_A, lds_wave2, wave, 4, true, xp, unit);
+            else if (unit < uA8 + uB) edd_body<4, 1, NORM, ABANDON, true>(A, tilesB, nB, (unit - uA8) * EDD_TILES_B, lds_wave2, wave, 4, true, xp, unit);
+        }
+        return;
+    }
     if (blk < blocksA) {
         const int64_t slot = blk * 4 + wave;
         if constexpr (A16) {
@@ -1206,6 +1264,8 @@ __global__ __launch_bounds__(256, 2) void kvm_ed_dot_kernel(edd_args A, const kv
 
 // The launcher's model of a launch (window splits, tile classes): kvm_ed_launch_model.h (host-only, unit-tested on the CPU).
 static_assert(EDM_TILES_A == EDD_TILES_A && EDM_TILES_A16 == EDD_TILES_A16 && EDM_TILES_B16 == EDD_TILES_B16 && EDM_TILES_B == EDD_TILES_B && EDM_TILES_C == EDD_TILES_C, "model and kernel agree on the unit sizes");
+size_t kvm_ed_dot_x_bytes() { return EDD_X_BYTES; }
+size_t kvm_ed_dot_x_counters_at() { return (size_t)EDD_X_UNITS * EDD_X_WG * EDD_X_SLOT * 8; }
 int kvm_ed_dot_choose_classes(int m, int64_t tilesA, int64_t tilesB, int64_t tilesC, int num_cu, int early_abandon) {
     (void)early_abandon;   // (the question -- class C or not -- arises only on lists that do not fill the wave slots once, where
     return edd_choose_classes(m, tilesA, tilesB, tilesC, num_cu);   // class A runs in its 8-per-lane form)
@@ -1216,7 +1276,7 @@ hipError_t kvm_launch_ed_dot(const double *series, const double2 *prefix, int64_
                              const kvm_tile *tilesC, int64_t nC, kvm_surv *surv,
                              int64_t cap, unsigned long long *counters, int num_cu, const unsigned long long *d_counts,
                              int32_t *out_off, double *out_dist, int64_t out_cap, hipStream_t s, hipEvent_t ev_start,
-                             hipEvent_t ev_stop, int in_flight, int64_t force, int64_t *shape) {
+                             hipEvent_t ev_stop, int in_flight, int64_t force, int64_t *shape, double *xpart, unsigned *xcnt) {
     // `force` = KVM_OPT_ED_FORCE (kvmatch.h): parts of the launch shape imposed by the caller -- the tests drive every form of
     // the kernel over the same inputs with it; 0 = everything by the model below
     const int force_fa = (int)(force & 15), force_fb = (int)((force >> 4) & 15), force_a16 = (int)((force >> 8) & 3),
@@ -1266,7 +1326,7 @@ hipError_t kvm_launch_ed_dot(const double *series, const double2 *prefix, int64_
     in_flight = std::max(1, std::min(in_flight, 64));
     const double slots_all = (double)num_cu * 8, slots = std::max(slots_all / in_flight, 64.0);
     bool b16 = false;
-    int64_t split_units = 0;
+    int64_t split_units = 0, cross_units = 0;
     if (d_counts) {
         // device-built lists (cNSM): the real counts are unknown here and usually far below the bounds (a selective
         // filter leaves a few hundred units for 2048 wave slots): the grid covers a 4-way split of the bounds and the
@@ -1344,21 +1404,28 @@ hipError_t kvm_launch_ed_dot(const double *series, const double2 *prefix, int64_
         const int64_t units_total = (nA + EDD_TILES_A - 1) / EDD_TILES_A + 3;   // (8 tiles per unit: a class-B unit's, the smaller)
         blocksA = (units_total * fA + 3) / 4 + 3;
         blocksB = blocksC = 0;
+        // (a tiny list's units take EDD_X_WG workgroups each: the grid covers that for as many units as the bounds allow.  Not with
+        // four or more queries in flight: the other launches fill the chip, and sixteen prologues per unit instead of four are then
+        // work taken from them -- the cNSM stream of eight 9.0 - 9.2e9 against 9.3 - 9.4e9 candidates/s)
+        if (xpart && xcnt && split_units > 0 && in_flight < 4) {
+            cross_units = EDD_X_UNITS;
+            blocksA = std::max<int64_t>(blocksA, std::min<int64_t>(units_total, EDD_X_UNITS) * EDD_X_WG);
+        }
     }
     int64_t a16_min = edd_a16_min_units(qd.m, slots_all);
     if (force_dev_a16_any) a16_min = 0;   // device-built lists of any size through the 16-per-lane form
     dim3 grid((unsigned)(blocksA + blocksB + blocksC)), block(256);
-    edd_args A{series, prefix, qd, surv, cap, counters, out_off, out_dist, out_cap};
+    edd_args A{series, prefix, qd, surv, cap, counters, out_off, out_dist, out_cap, xpart, xcnt};
     // (ev_start / ev_stop: the kernel's own begin and end -- hipExtLaunchKernelGGL stamps the dispatch itself, so the time between
     // them holds neither the launch's dispatch latency nor a host that enqueues later than the GPU gets there)
 #define LAUNCH(NORM, AB)                                                                                                          \
     do {                                                                                                                          \
         if (ev_start && ev_stop)                                                                                                  \
             hipExtLaunchKernelGGL((kvm_ed_dot_kernel<NORM, AB>), grid, block, edd_lds_bytes<AB>(), s, ev_start, ev_stop, 0, A, tilesA, nA, tilesB,  \
-                                  nB, tilesC, nC, fA, fB, fC, blocksA, (b16 && !d_counts) ? blocksB : blocksC, d_counts, split_units, (int)a16, a16_min, (int)b16); \
+                                  nB, tilesC, nC, fA, fB, fC, blocksA, (b16 && !d_counts) ? blocksB : blocksC, d_counts, split_units, (int)a16, a16_min, (int)b16, cross_units); \
         else                                                                                                                      \
             hipLaunchKernelGGL((kvm_ed_dot_kernel<NORM, AB>), grid, block, edd_lds_bytes<AB>(), s, A, tilesA, nA, tilesB, nB, tilesC, nC, fA, fB,   \
-                               fC, blocksA, (b16 && !d_counts) ? blocksB : blocksC, d_counts, split_units, (int)a16, a16_min, (int)b16);             \
+                               fC, blocksA, (b16 && !d_counts) ? blocksB : blocksC, d_counts, split_units, (int)a16, a16_min, (int)b16, cross_units); \
     } while (0)
     if (qd.normalised) {
         if (qd.early_abandon) LAUNCH(true, true); else LAUNCH(true, false);

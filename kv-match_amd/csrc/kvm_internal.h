@@ -93,7 +93,7 @@ struct kvm_ctx {
     hipEvent_t ev_env = nullptr;     // recorded behind the envelope build
     hipStream_t env_stream = nullptr;  // the stream it was built on
     // grow-only scratch
-    kvm_dev_buf b_query, b_tiles, b_out_off, b_out_dist, b_counters, b_cands, b_cands2, b_aux, b_aux2, b_scratch, b_plans, b_ucr;
+    kvm_dev_buf b_query, b_tiles, b_out_off, b_out_dist, b_counters, b_cands, b_cands2, b_aux, b_aux2, b_scratch, b_plans, b_ucr, b_edx;
     void *h_pinned = nullptr;
     void *h_readback2 = nullptr;  // pinned: answers beyond the first KVM_SPEC_ANSWERS (grow-only)
     size_t h_readback2_cap = 0;
@@ -257,12 +257,15 @@ static inline int kvm_qk_len(int m) { return (m + 1) / 2 + KVM_SERIES_PAD / 2; }
 #define ED16_JC 80  // tiles per row)
 // host: classes A / B (1) or A / B / C (2) for a host-planned list (the launcher's model of the launch)
 int kvm_ed_dot_choose_classes(int m, int64_t tilesA, int64_t tilesB, int64_t tilesC, int num_cu, int early_abandon);
+size_t kvm_ed_dot_x_bytes();          // the pruner's cross-workgroup scratch: sums first, then its arrival counters (kvm_ed_dot_x_counters_at)
+size_t kvm_ed_dot_x_counters_at();
 hipError_t kvm_launch_ed_dot(const double *series, const double2 *prefix, int64_t n, const kvm_query_dev &qd,
                              const kvm_tile *tilesA, int64_t nA, const kvm_tile *tilesB, int64_t nB,
                              const kvm_tile *tilesC, int64_t nC, kvm_surv *surv,
                              int64_t cap, unsigned long long *counters, int num_cu, const unsigned long long *d_counts,
                              int32_t *out_off, double *out_dist, int64_t out_cap, hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr,
-                             int in_flight = 1, int64_t force = 0, int64_t *shape = nullptr);   // in_flight: launches of other contexts
+                             int in_flight = 1, int64_t force = 0, int64_t *shape = nullptr,    // in_flight: launches of other contexts
+                             double *xpart = nullptr, unsigned *xcnt = nullptr);   // scratch of kvm_ed_dot_x_bytes() bytes (xcnt zero): tiny device-built lists
                                                        // expected next to this one (kvm_in_flight); force: KVM_OPT_ED_FORCE; shape: KVM_OPT_ED_LAST_SHAPE
 static inline int kvm_in_flight(const kvm_ctx *ctx) { return (int)std::max<int64_t>(std::max<int64_t>(ctx->opt_in_flight, ctx->run_in_flight), 1); }
 // cNSM: 64-candidate tiles -> trimmed class-A / class-B tile lists of the candidates passing the guarded (alpha, beta)

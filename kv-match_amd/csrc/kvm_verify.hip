@@ -392,9 +392,15 @@ static int run_variant(kvm_ctx *ctx, int variant, const double *query, int32_t m
                 HIPCHK(ctx, kvm_launch_retile_cnsm(ctx->d_series, ctx->d_prefix, qd, d_tiles, pl.n_tiles, tA, tB,
                                                    counters + KVM_CNT_TILES_A, stream));
             KVM_TP("  retile launch");
+            // (scratch of the pruner's cross-workgroup hand-over on tiny lists: allocated once, its arrival counters zero between launches)
+            if (!ctx->b_edx.p) {
+                if ((rc = kvm_ensure(ctx, ctx->b_edx, kvm_ed_dot_x_bytes()))) return rc;
+                HIPCHK(ctx, hipMemsetAsync((char *)ctx->b_edx.p + kvm_ed_dot_x_counters_at(), 0, kvm_ed_dot_x_bytes() - kvm_ed_dot_x_counters_at(), stream));
+            }
             HIPCHK(ctx, kvm_launch_ed_dot(ctx->d_series, ctx->d_prefix, ctx->n, qd, tA, pl.n_tiles, tB, pl.n_tiles, tB, 0, surv,
                                           pl.windows, counters, ctx->num_cu, counters + KVM_CNT_TILES_A, out.d_off, out.d_dist, out.cap,
-                                          stream, nullptr, nullptr, kvm_in_flight(ctx), ctx->opt_ed_force, &ctx->last_ed_shape));
+                                          stream, nullptr, nullptr, kvm_in_flight(ctx), ctx->opt_ed_force, &ctx->last_ed_shape,
+                                          (double *)ctx->b_edx.p, (unsigned *)((char *)ctx->b_edx.p + kvm_ed_dot_x_counters_at())));
             KVM_TP("  ed_dot launch");
         }
         else if (ed_kernel == 3)
